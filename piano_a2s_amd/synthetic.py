@@ -1,0 +1,67 @@
+"""Seeded synthetic clips in the reference's batch contract (host side).
+
+The reference trains on rendered corpora that are not redistributable; benchmarks and parity tests
+use random "scores" of the same tensor contract instead.  One batch is the 9-tuple the
+reference's datasets yield (datasets/syn.py:88-121, datasets/asap.py:296-366):
+
+  spectrogram (B,1,T,F) f32 in [0,1] | time_sig (B,bars) i64 | key (B,bars) i64 |
+  upper (B,bars,U) i64 | upper_len (B,bars) i64 | lower (B,bars,L) i64 | lower_len (B,bars) i64 |
+  names [B] | versions (B,) i64
+
+Token rows follow ``pad_single_measure`` (datasets/syn.py:67-74): ``len`` note tokens, then <eos>
+if the row is not full, then <pad>.
+"""
+import numpy as np
+import torch
+
+from .spec import EOS, PAD, SOS, VOCAB_SIZE
+
+_NOTE_IDS = np.array([i for i in range(VOCAB_SIZE) if i not in (SOS, EOS, PAD)], dtype=np.int64)
+
+
+def pad_measure(tokens, max_length):
+    """Token list -> (max_length,) row: tokens | <eos> | <pad>...  (truncates to max_length)."""
+    row = np.full((max_length,), PAD, dtype=np.int64)
+    tokens = np.asarray(tokens, dtype=np.int64)[:max_length]
+    row[:len(tokens)] = tokens
+    if len(tokens) < max_length:
+        row[len(tokens)] = EOS
+    return row
+
+
+def make_batch(batch, cfg, seed, frames=1201, upper_range=(20, 120), lower_range=(10, 80),
+               full_tail=0.01, device="cpu"):
+    """Deterministic batch.  Lengths ~ U{range}; with probability ``full_tail`` per (clip, bar, staff)
+    the row is full-length with no <eos> (exercises the max-steps cap)."""
+    rng = np.random.default_rng(seed)
+    bars = cfg["max_bars"]
+    U, L = cfg["max_length"]
+    spec = rng.random((batch, 1, frames, cfg["freq_bins"]), dtype=np.float32)
+    ts = np.empty((batch, bars), dtype=np.int64)
+    key = np.empty((batch, bars), dtype=np.int64)
+    for b in range(batch):
+        ts[b] = rng.integers(0, cfg["num_time_sig"])
+        key[b] = rng.integers(0, cfg["num_keys"])
+        for k in range(1, bars):                      # constant within the clip w.p. 0.9
+            if rng.random() > 0.9:
+                ts[b, k:] = rng.integers(0, cfg["num_time_sig"])
+            if rng.random() > 0.9:
+                key[b, k:] = rng.integers(0, cfg["num_keys"])
+
+    def staff(maxlen, lo, hi):
+        rows = np.empty((batch, bars, maxlen), dtype=np.int64)
+        lens = np.empty((batch, bars), dtype=np.int64)
+        for b in range(batch):
+            for k in range(bars):
+                n = maxlen if rng.random() < full_tail else int(rng.integers(min(lo, maxlen), min(hi, maxlen) + 1))
+                toks = _NOTE_IDS[rng.integers(0, len(_NOTE_IDS), size=n)]
+                rows[b, k] = pad_measure(toks, maxlen)
+                lens[b, k] = min(n, maxlen)
+        return rows, lens
+
+    up, up_len = staff(U, *upper_range)
+    lo, lo_len = staff(L, *lower_range)
+    t = lambda a: torch.from_numpy(a).to(device)
+    names = [f"syn{seed}_{b}~synthetic" for b in range(batch)]
+    return (t(spec), t(ts), t(key), t(up), t(up_len), t(lo), t(lo_len), names,
+            torch.zeros(batch, dtype=torch.long))

@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+Imports /root/reference/models.py read-only (``music21`` is stubbed: humdrum.py imports it at module
+top but the model only needs the pure-Python LabelsMultiple), drives it on CPU with this repo's
+procedural weights (piano_a2s_amd.spec.procedural_state) and synthetic batches
+(piano_a2s_amd.synthetic.make_batch), and stores inputs' checksums + the reference's outputs.
+Nothing of the reference's text is stored: fixtures are numbers.
+
+Usage:  python tests/golden/make_golden.py [g1] [g2] [tok] [step]
+The fixtures are committed; this script documents how they were made and can regenerate them.
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+from piano_a2s_amd import spec, synthetic  # noqa: E402
+
+SMALL = dict(freq_bins=24, conv_feature_size=32, hidden_size=32, max_length=(12, 8))
+SMALL_BATCH = dict(frames=41, upper_range=(3, 10), lower_range=(2, 7), full_tail=0.1)
+
+
+def load_reference():
+    sys.modules.setdefault("music21", types.ModuleType("music21"))
+    if "/root/reference" not in sys.path:
+        sys.path.insert(1, "/root/reference")
+    saved = sys.modules.pop("data_processing", None), sys.modules.pop("data_processing.humdrum", None)
+    # make sure the REFERENCE's data_processing package is the one models.py sees
+    sys.path.remove(REPO)
+    try:
+        import models as ref_models
+        from data_processing.humdrum import LabelsMultiple as RefLabels
+    finally:
+        sys.path.insert(0, REPO)
+    for k in [k for k in sys.modules if k == "data_processing" or k.startswith("data_processing.")]:
+        del sys.modules[k]
+    return ref_models, RefLabels
+
+
+def digest(tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def no_dropout():
+    """Neutralise dropout in THIS process only: models.py calls F.dropout(...)."""
+    import torch.nn.functional as F
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+
+
+def ref_losses(outs, batch):
+    ts_o, key_o, up_o, lo_o = outs
+    _, ts_t, key_t, up_t, _, lo_t, _, _, _ = batch
+    nll, nll_pad = torch.nn.NLLLoss(), torch.nn.NLLLoss(ignore_index=147)
+    # reference pretrain.py:72-88
+    time_loss = nll(ts_o.permute(0, 2, 1), ts_t)
+    key_loss = nll(key_o.permute(0, 2, 1), key_t)
+    up = nll_pad(up_o.view(up_o.shape[0] * up_o.shape[1], -1, up_o.shape[3]).permute(0, 2, 1),
+                 up_t.view(up_t.shape[0] * up_t.shape[1], -1))
+    lo = nll_pad(lo_o.view(lo_o.shape[0] * lo_o.shape[1], -1, lo_o.shape[3]).permute(0, 2, 1),
+                 lo_t.view(lo_t.shape[0] * lo_t.shape[1], -1))
+    return time_loss + key_loss + up + lo, time_loss, key_loss, up, lo
+
+
+def gt_of(batch):
+    return [batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]]
+
+
+def make_g1(ref_models):
+    cfg = spec.default_cfg(**SMALL)
+    out = {}
+    meta = {"cfg": {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, "cases": {}}
+    batch = synthetic.make_batch(3, cfg, 5, **SMALL_BATCH)
+    meta["batch_seed"] = 5
+    meta["batch_sha256"] = digest([batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]])
+
+    def model_for(seed, eb):
+        st = spec.procedural_state(cfg, seed, eos_bias=eb, lively=True)
+        m = ref_models.ScoreTranscription(**SMALL)
+        m.load_state_dict(st)
+        return m, st
+
+    # --- greedy, eval mode (two weight sets with mid-way early breaks and repeated EOS)
+    for seed, eb in ((11, 3.0), (18, 3.0)):
+        m, st = model_for(seed, eb)
+        m.eval()
+        with torch.no_grad():
+            outs = m(spectrogram=batch[0], inference=True, ground_truth=None, teacher_forcing_ratio=0., device="cpu")
+        name = f"greedy_s{seed}"
+        for n, o in zip(("ts", "key", "up", "lo"), outs):
+            out[f"{name}.{n}"] = o.numpy()
+        meta["cases"][name] = {"weights_seed": seed, "eos_bias": eb, "state_sha256": digest(st.values())}
+
+    # --- eval mode, teacher forced with ground truth (running-stat BN, tf=1)
+    m, st = model_for(11, 3.0)
+    m.eval()
+    with torch.no_grad():
+        outs = m(spectrogram=batch[0], inference=False, ground_truth=gt_of(batch), teacher_forcing_ratio=1.0, device="cpu")
+    for n, o in zip(("ts", "key", "up", "lo"), outs):
+        out[f"eval_tf1.{n}"] = o.numpy()
+    meta["cases"]["eval_tf1"] = {"weights_seed": 11, "eos_bias": 3.0}
+
+    # --- train mode (batch-stat BN), dropout neutralised, tf = 1: outputs, losses, all grads, BN buffers
+    no_dropout()
+    for name, tf, rseed in (("train_tf1", 1.0, None), ("train_tf05", 0.5, 7)):
+        m, st = model_for(11, 3.0)
+        m.train()
+        if rseed is not None:
+            random.seed(rseed)
+        state0 = random.getstate()
+        outs = m(spectrogram=batch[0], inference=False, ground_truth=gt_of(batch), teacher_forcing_ratio=tf, device="cpu")
+        # count python-random draws the forward consumed (a-12): replay from state0 until states match
+        state1 = random.getstate()
+        random.setstate(state0)
+        draws = 0
+        while random.getstate() != state1 and draws < 100000:
+            random.random()
+            draws += 1
+        losses = ref_losses(outs, batch)
+        losses[0].backward()
+        for n, o in zip(("ts", "key", "up", "lo"), outs):
+            out[f"{name}.{n}"] = o.detach().numpy()
+        out[f"{name}.losses"] = np.array([float(l) for l in losses], dtype=np.float64)
+        sd = m.state_dict()
+        for k, p in m.named_parameters():
+            if name == "train_tf1":
+                out[f"{name}.grad.{k}"] = p.grad.numpy().copy()
+            else:
+                out[f"{name}.gradnorm.{k}"] = np.array(float(p.grad.double().norm()))
+        for k in sd:
+            if spec.is_buffer(k):
+                out[f"{name}.buf.{k}"] = sd[k].numpy().copy()
+        meta["cases"][name] = {"weights_seed": 11, "eos_bias": 3.0, "tf": tf, "random_seed": rseed, "draws": draws}
+
+        if name == "train_tf1":
+            # --- one clip + Adadelta step with the very torch objects the reference recipe instantiates
+            params = [p for p in m.parameters()]
+            total = torch.nn.utils.clip_grad_norm_(params, 5.0)
+            opt = torch.optim.Adadelta(params, lr=1.0, rho=0.95, eps=1e-8)
+            opt.step()
+            out["step.total_norm"] = np.array(float(total))
+            for k, p in m.named_parameters():
+                out[f"step.param.{k}"] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g1_small.npz"), **out)
+    with open(os.path.join(HERE, "g1_small.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("g1 written:", len(out), "arrays")
+
+
+FULL_BATCH = dict(frames=1201, upper_range=(6, 24), lower_range=(4, 16), full_tail=0.0)
+
+
+def make_g2(ref_models, seed=2024, eb=None):
+    """Full-size model (16.36 M parameters), procedural weights, B=2."""
+    cfg = spec.default_cfg()
+    eb = 3.0 if eb is None else eb
+    st = spec.procedural_state(cfg, seed, eos_bias=eb, lively=True)
+    batch = synthetic.make_batch(2, cfg, 77, **FULL_BATCH)
+    out, meta = {}, {"weights_seed": seed, "eos_bias": eb, "batch_seed": 77, "batch_kwargs": {k: list(v) if isinstance(v, tuple) else v for k, v in FULL_BATCH.items()},
+                     "state_sha256": digest(st.values()),
+                     "batch_sha256": digest([batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]])}
+    m = ref_models.ScoreTranscription()
+    m.load_state_dict(st)
+    m.eval()
+    with torch.no_grad():
+        ts, key, up, lo = m(spectrogram=batch[0], inference=True, ground_truth=None, teacher_forcing_ratio=0., device="cpu")
+    out["greedy.ts"], out["greedy.key"] = ts.numpy(), key.numpy()
+    out["greedy.up_ids"] = up.argmax(-1).numpy().astype(np.int16)
+    out["greedy.lo_ids"] = lo.argmax(-1).numpy().astype(np.int16)
+    out["greedy.up_rows"] = (up.abs().sum(-1) > 0).sum(-1).numpy().astype(np.int16)   # executed steps per (b,bar)
+    out["greedy.lo_rows"] = (lo.abs().sum(-1) > 0).sum(-1).numpy().astype(np.int16)
+    g = np.random.default_rng(0)
+    idx = g.integers(0, up.numel(), size=2000)
+    out["greedy.up_sample_idx"], out["greedy.up_sample"] = idx, up.flatten()[idx].numpy()
+    idx = g.integers(0, lo.numel(), size=2000)
+    out["greedy.lo_sample_idx"], out["greedy.lo_sample"] = idx, lo.flatten()[idx].numpy()
+    # top-2 margin of every decoded row: how far the argmax is from flipping
+    top2 = up.topk(2, dim=-1).values
+    out["greedy.up_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    top2 = lo.topk(2, dim=-1).values
+    out["greedy.lo_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    print("g2 greedy rows", out["greedy.up_rows"].tolist(), out["greedy.lo_rows"].tolist())
+
+    no_dropout()
+    m.train()
+    outs = m(spectrogram=batch[0], inference=False, ground_truth=gt_of(batch), teacher_forcing_ratio=1.0, device="cpu")
+    losses = ref_losses(outs, batch)
+    losses[0].backward()
+    out["train_tf1.losses"] = np.array([float(l) for l in losses], dtype=np.float64)
+    out["train_tf1.ts"], out["train_tf1.key"] = outs[0].detach().numpy(), outs[1].detach().numpy()
+    idx = g.integers(0, outs[2].numel(), size=2000)
+    out["train_tf1.up_sample_idx"], out["train_tf1.up_sample"] = idx, outs[2].detach().flatten()[idx].numpy()
+    names = []
+    norms = []
+    for k, p in m.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        flat = p.grad.flatten()
+        sidx = g.integers(0, flat.numel(), size=min(64, flat.numel()))
+        out[f"train_tf1.gsample_idx.{k}"] = sidx
+        out[f"train_tf1.gsample.{k}"] = flat[sidx].numpy()
+    out["train_tf1.gradnorms"] = np.array(norms)
+    meta["grad_names"] = names
+    sd = m.state_dict()
+    for k in sd:
+        if spec.is_buffer(k):
+            out[f"train_tf1.buf.{k}"] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "g2_full.npz"), **out)
+    with open(os.path.join(HERE, "g2_full.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("g2 written")
+
+
+def make_tok(RefLabels):
+    lab = RefLabels(extended=True)
+    cases = ["4c", "4c\t8e 8g\n4r", "[2.CC#_ 4ee-;]\t.\n16ffff", "8.r\t4c 4e 4g", "16.BBB#]\t[8cccc-",
+             "2r\t.\n.\t4GG# 4d-\n=\t=", "128CCC\t176BBB-_ 112ee#;", "4c 4e 4g\t4C 4E 4G\n.\t8r\n*\t*"]
+    kats = []
+    for s in cases:
+        try:
+            ids = lab.encode(s)
+            kats.append({"text": s, "ids": ids, "decoded": lab.decode(ids)})
+        except Exception as e:  # noqa: BLE001
+            kats.append({"text": s, "raises": type(e).__name__})
+    for s in ["4h", "4c  4e", ""]:
+        try:
+            lab.encode(s)
+            kats.append({"text": s, "ids": lab.encode(s)})
+        except Exception as e:  # noqa: BLE001
+            kats.append({"text": s, "raises": type(e).__name__})
+    data = {"labels_extended": lab.labels, "n_base": len(RefLabels(extended=False).labels), "kats": kats}
+    with open(os.path.join(HERE, "tokenizer_kat.json"), "w") as f:
+        json.dump(data, f, indent=1)
+    print("tokenizer KATs written:", len(kats))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["tok", "g1", "g2"]
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref_models, RefLabels = load_reference()
+    if "tok" in what:
+        make_tok(RefLabels)
+    if "g1" in what:
+        make_g1(ref_models)
+    if "g2" in what:
+        make_g2(ref_models)
