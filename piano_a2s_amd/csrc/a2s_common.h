@@ -1,0 +1,92 @@
+// Shared definitions for the gfx950 kernels of the piano-a2s hot path (C-ABI library liba2s_hip.so).
+// Everything here is device/host plumbing; the public surface is include/a2s.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define A2S_OK 0
+#define A2S_ERR_ARG (-1)
+#define A2S_ERR_HIP (-2)
+#define A2S_ERR_WORKSPACE (-3)
+
+// one message slot per host thread (one host thread per process/GPU under torchrun)
+extern thread_local char a2s_err_msg[512];
+
+#define A2S_FAIL(code, ...)                                   \
+    do {                                                      \
+        snprintf(a2s_err_msg, sizeof(a2s_err_msg), __VA_ARGS__); \
+        return (code);                                        \
+    } while (0)
+
+#define A2S_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) A2S_FAIL(A2S_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// Launch check: never synchronises; reports the launch-time error only.
+#define A2S_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int a2s_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+#define A2S_WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// tanh / sigmoid through the hardware exp2 + rcp (abs error ~1e-7: far inside the 1e-4 parity budget).
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); clamp keeps exp finite, tanh(+-15) == +-1 in fp32
+    x = fminf(fmaxf(x, -15.f), 15.f);
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f * __frcp_rn(e + 1.f);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    x = fminf(fmaxf(x, -30.f), 30.f);
+    return __frcp_rn(1.f + __expf(-x));
+}
+#endif

@@ -1,0 +1,251 @@
+// fp32 GEMM on the CDNA4 matrix cores: v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate -- bit-for-bit an
+// fmaf chain, so results stay inside the 1e-4 parity budget against the reference's fp32 CPU path).
+//
+//   C[m,n] = act( alpha * sum_k A(m,k) * B(k,n) + beta * C[m,n] + bias[n] )
+//   A(m,k) = A[m*sAm + k*sAk],  B(k,n) = B[k*sBk + n*sBn]   (any strides; 16-byte vector loads when the
+//   unit-stride dimension allows it), optional batch dimension, optional deterministic split-K.
+//
+// Used for every dense contraction of the hot path: Linear 19200->256 (a-2), GRU input
+// projections (a-3), attention key projection (a-7), per-step decoder GEMMs (a-9), heads (a-10) and all
+// their dgrad / wgrad forms (which are the same contraction with other strides).
+//
+// Structure: 256 threads = 4 waves; block tile BM x BN x 32; register-prefetched global->LDS staging
+// (global loads for tile t+1 are in flight while tile t is multiplied); LDS images padded so the
+// fragment reads (lane = (m&15, k>>... ) one dword each) are at most 2-way conflicted.
+#include "a2s_common.h"
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long sAm, sAk, sBk, sBn, ldc;
+    float alpha, beta;
+    int act;                // 0 none, 1 relu, 2 tanh
+    int batch; long bsA, bsB, bsC;
+    int splitk; int kchunk; // kchunk: K range per split (multiple of 32)
+    float* partial;         // [batch*splitk][M][N] when splitk > 1
+    int vecA, vecB;         // 16-byte loads allowed along the operand's unit-stride dimension
+};
+
+#define GEMM_BK 32
+
+template <int ROWS, bool KC> struct LdsTile {
+    // KC  : image [ROWS][BK+4]   (k contiguous, rows 16-byte aligned -> ds_write_b128)
+    // !KC : image [BK][ROWS+16]  (m contiguous)
+    static constexpr int STRIDE = KC ? (GEMM_BK + 4) : (ROWS + 16);
+    static constexpr int SIZE = KC ? ROWS * STRIDE : GEMM_BK * STRIDE;
+    __device__ static __forceinline__ int at(int r, int k) { return KC ? r * STRIDE + k : k * STRIDE + r; }
+};
+
+// One operand tile: ROWS (m or n) x 32 (k).  elem(r,k) = P[r*sR + k*sK].
+template <int ROWS, bool KC, int NLD>
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, long sR, long sK, int r0, int k0,
+                                          int rmax, int kmax, bool vec, f32x4 (&reg)[NLD]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int slot = tid + i * 256;
+        int r, k;
+        if (KC) { r = slot >> 3; k = (slot & 7) * 4; }                 // 8 float4 per row of 32 k
+        else    { constexpr int PER = ROWS / 4; k = slot / PER; r = (slot % PER) * 4; }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const bool in_tile = KC ? (r < ROWS) : (k < GEMM_BK);
+        if (in_tile) {
+            const int gr = r0 + r, gk = k0 + k;
+            if (KC) {
+                if (gr < rmax) {
+                    const float* p = P + (long)gr * sR + (long)gk * sK;
+                    if (vec && gk + 3 < kmax) v = *reinterpret_cast<const f32x4*>(p);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gk + j < kmax) v[j] = p[(long)j * sK];
+                    }
+                }
+            } else {
+                if (gk < kmax) {
+                    const float* p = P + (long)gr * sR + (long)gk * sK;
+                    if (vec && gr + 3 < rmax) v = *reinterpret_cast<const f32x4*>(p);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gr + j < rmax) v[j] = p[(long)j * sR];
+                    }
+                }
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+template <int ROWS, bool KC, int NLD>
+__device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 (&reg)[NLD]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int slot = tid + i * 256;
+        int r, k;
+        if (KC) { r = slot >> 3; k = (slot & 7) * 4; }
+        else    { constexpr int PER = ROWS / 4; k = slot / PER; r = (slot % PER) * 4; }
+        const bool in_tile = KC ? (r < ROWS) : (k < GEMM_BK);
+        if (in_tile) *reinterpret_cast<f32x4*>(lds + LdsTile<ROWS, KC>::at(r, k)) = reg[i];
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
+    constexpr int NLA = (BM * 8 + 255) / 256, NLB = (BN * 8 + 255) / 256;
+    using LA = LdsTile<BM, A_KC>;
+    using LB = LdsTile<BN, B_KC>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (LA::SIZE + LB::SIZE)];
+
+    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
+    const float* A = g.A + (long)zb * g.bsA;
+    const float* B = g.B + (long)zb * g.bsB;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = zs * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave / WN) * (TM * 16), wn = (wave % WN) * (TN * 16);
+    const int lr = lane & 15, lk = lane >> 4;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[NLA], rb[NLB];
+    const int ntiles = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    if (ntiles > 0) {
+        tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, g.vecA, ra);
+        tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, g.vecB, rb);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        float* la = lds + (t & 1) * (LA::SIZE + LB::SIZE);
+        float* lb = la + LA::SIZE;
+        tile_store<BM, A_KC, NLA>(la, ra);
+        tile_store<BN, B_KC, NLB>(lb, rb);
+        __syncthreads();
+        if (t + 1 < ntiles) {   // prefetch next tile while this one is multiplied
+            const int k0 = kbeg + (t + 1) * GEMM_BK;
+            tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra);
+            tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = la[LA::at(wm + i * 16 + lr, ks * 4 + lk)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = lb[LB::at(wn + j * 16 + lr, ks * 4 + lk)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        // the other LDS buffer is written next iteration; its readers finished before the barrier above
+    }
+
+    // epilogue: lane holds rows (lane>>4)*4 + r, column lane&15 of every 16x16 tile
+    const bool partial = g.splitk > 1;
+    float* C = partial ? g.partial + (long)blockIdx.z * g.M * g.N : g.C + (long)zb * g.bsC;
+    const long ldc = partial ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + j * 16 + lr;
+            if (n >= g.N) continue;
+            const float bv = (!partial && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + lk * 4 + r;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r];
+                if (!partial) {
+                    v = g.alpha * v + bv;
+                    if (g.beta != 0.f) v += g.beta * C[(long)m * ldc + n];
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = fast_tanh(v);
+                }
+                C[(long)m * ldc + n] = v;
+            }
+        }
+}
+
+// Fixed-order reduction of the split-K partial slabs (deterministic), with the epilogue applied once.
+__global__ void gemm_splitk_reduce(GemmArgs g) {
+    const long mn = (long)g.M * g.N;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int zb = blockIdx.y;
+    if (idx >= mn) return;
+    const float* p = g.partial + (long)zb * g.splitk * mn + idx;
+    float s = 0.f;
+    for (int i = 0; i < g.splitk; ++i) s += p[(long)i * mn];
+    const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+    float* c = g.C + (long)zb * g.bsC + (long)m * g.ldc + n;
+    float v = g.alpha * s + (g.bias ? g.bias[n] : 0.f);
+    if (g.beta != 0.f) v += g.beta * *c;
+    if (g.act == 1) v = fmaxf(v, 0.f);
+    else if (g.act == 2) v = fast_tanh(v);
+    *c = v;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
+    dim3 grid(a2s_cdiv(g.N, BN), a2s_cdiv(g.M, BM), g.batch * g.splitk);
+    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, g);
+}
+
+size_t a2s_gemm_workspace_bytes_impl(int M, int N, int batch, int splitk) {
+    return splitk > 1 ? (size_t)batch * splitk * M * N * sizeof(float) : 0;
+}
+
+// Heuristic split count for contractions with a tiny output and a huge K (wgrad forms).
+int a2s_gemm_pick_splitk(int M, int N, int K, int batch) {
+    const long tiles = (long)a2s_cdiv(M, 64) * a2s_cdiv(N, 64) * batch;
+    if (tiles >= 256 || K < 4096) return 1;
+    long s = 512 / tiles;
+    const long maxs = K / 512;
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+
+int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
+                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes) {
+    if (M <= 0 || N <= 0 || batch <= 0) return A2S_OK;
+    A2S_REQUIRE(K >= 0 && A && B && C, "gemm: null operand or negative K");
+    A2S_REQUIRE(splitk >= 1, "gemm: splitk must be >= 1");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.act = act;
+    g.batch = batch; g.bsA = bsA; g.bsB = bsB; g.bsC = bsC;
+    g.splitk = splitk; g.partial = ws;
+    g.kchunk = a2s_cdiv(a2s_cdiv(K, splitk), GEMM_BK) * GEMM_BK;
+    if (g.kchunk == 0) g.kchunk = GEMM_BK;
+    if (splitk > 1)
+        A2S_REQUIRE(ws && ws_bytes >= a2s_gemm_workspace_bytes_impl(M, N, batch, splitk), "gemm: split-K workspace too small");
+    // operand orientation: which dimension is unit-stride decides the staging path
+    const bool akc = (sAk == 1) || (sAm != 1);     // generic strides go through the (scalar) k-major path
+    const bool bkc = (sBk == 1) || (sBn != 1);
+    auto aligned = [](const void* p, long s0, long s1) { return ((uintptr_t)p % 16 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0); };
+    g.vecA = (akc ? (sAk == 1 && aligned(A, sAm, bsA)) : (sAm == 1 && aligned(A, sAk, bsA))) ? 1 : 0;
+    g.vecB = (bkc ? (sBk == 1 && aligned(B, sBn, bsB)) : (sBn == 1 && aligned(B, sBk, bsB))) ? 1 : 0;
+
+    if (M <= 16) launch_cfg<16, 64, 1, 4>(g, akc, bkc, st);
+    else if (M <= 32) launch_cfg<32, 64, 2, 2>(g, akc, bkc, st);
+    else if ((long)a2s_cdiv(M, 128) * a2s_cdiv(N, 128) * batch * splitk >= 192) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);
+    else launch_cfg<64, 64, 2, 2>(g, akc, bkc, st);
+    A2S_CHECK_LAUNCH("gemm_f32_kernel");
+    if (splitk > 1) {
+        dim3 grid(a2s_cdiv((long)M * N, 256), batch);
+        hipLaunchKernelGGL(gemm_splitk_reduce, grid, dim3(256), 0, st, g);
+        A2S_CHECK_LAUNCH("gemm_splitk_reduce");
+    }
+    return A2S_OK;
+}

@@ -73,8 +73,13 @@ def is_buffer(name):
     return name.endswith(("running_mean", "running_var", "num_batches_tracked"))
 
 
+# Gain presets for procedural_state(lively=...).  True / "matrix": whole-matrix gains, tuned on the reduced
+# model of fixture G1.  "token": strengthens the fed-back-token path instead (note-decoder embeddings), which
+# is what keeps greedy decoding of the FULL-width model from collapsing onto one symbol (fixture G2).
 _LIVELY_GAINS = (("_decoder.out.weight", 6.0), ("decoder.gru.weight_ih", 3.0), ("_decoder.gru.weight_hh", 2.0),
                  ("attn.v.weight", 4.0), ("attn.attn.weight", 4.0), ("encoder.gru.weight", 2.0))
+_TOKEN_GAINS = (("_decoder.out.weight", 3.0), ("_decoder.embedding.weight", 16.0),
+                ("attn.v.weight", 2.0), ("attn.attn.weight", 2.0))
 
 
 def procedural_state(cfg, seed, eos_bias=0.0, lively=False):
@@ -84,8 +89,8 @@ def procedural_state(cfg, seed, eos_bias=0.0, lively=False):
     ~ U(+-0.1), embeddings ~ U(+-1), BN gamma ~ U(0.5,1.5), beta ~ U(+-0.2), running mean ~ U(+-0.1),
     running var ~ U(0.5,1.5).  ``eos_bias`` is added to the <eos> logit bias of both note decoders so
     greedy decoding terminates at data-dependent steps (exercises the early-break bookkeeping).
-    ``lively`` scales the decoder/attention/encoder-GRU matrices (gains in _LIVELY_GAINS) so that the decoded
-    tokens depend visibly on the audio and on the fed-back tokens instead of collapsing to one symbol.
+    ``lively`` (True/"matrix" or "token") applies one of the gain presets above so that the decoded tokens
+    depend visibly on the audio and on the fed-back tokens instead of collapsing to one symbol.
     """
     rng = np.random.default_rng(seed)
     out = OrderedDict()
@@ -109,7 +114,7 @@ def procedural_state(cfg, seed, eos_bias=0.0, lively=False):
             fan_in = int(np.prod(shape[1:]))
             v = u * np.sqrt(3.0 / fan_in)
         if lively:
-            for key, gain in _LIVELY_GAINS:
+            for key, gain in (_TOKEN_GAINS if lively == "token" else _LIVELY_GAINS):
                 if key in name:
                     v = v * gain
         t = torch.from_numpy(v.astype(np.float32)).reshape(shape)

@@ -29,14 +29,37 @@ def pad_measure(tokens, max_length):
     return row
 
 
+def _ridge_spectrogram(rng, frames, bins):
+    """VQT-like picture in [0,1]: low noise floor + a few sustained partials (note events with harmonics)."""
+    s = 0.15 * rng.random((frames, bins), dtype=np.float32)
+    for _ in range(int(rng.integers(6, 14))):
+        f0 = int(rng.integers(0, max(1, bins - 1)))
+        t0 = int(rng.integers(0, frames))
+        t1 = min(frames, t0 + int(rng.integers(max(2, frames // 40), max(3, frames // 3))))
+        amp = 0.5 + 0.5 * float(rng.random())
+        decay = np.exp(-np.arange(t1 - t0, dtype=np.float32) / max(1.0, 0.5 * (t1 - t0)))
+        for h, w in ((0, 1.0), (bins // 8, 0.6), (bins // 5, 0.4)):      # fundamental + two upper partials
+            f = f0 + h
+            if f < bins:
+                s[t0:t1, f] = np.maximum(s[t0:t1, f], amp * w * decay)
+                if f + 1 < bins:
+                    s[t0:t1, f + 1] = np.maximum(s[t0:t1, f + 1], 0.5 * amp * w * decay)
+    return np.clip(s, 0.0, 1.0)
+
+
 def make_batch(batch, cfg, seed, frames=1201, upper_range=(20, 120), lower_range=(10, 80),
-               full_tail=0.01, device="cpu"):
+               full_tail=0.01, device="cpu", spectrogram="uniform"):
     """Deterministic batch.  Lengths ~ U{range}; with probability ``full_tail`` per (clip, bar, staff)
-    the row is full-length with no <eos> (exercises the max-steps cap)."""
+    the row is full-length with no <eos> (exercises the max-steps cap).  ``spectrogram``: "uniform"
+    (U[0,1) noise) or "ridges" (clip-specific sustained partials on a noise floor, so that
+    different clips encode differently -- used by parity fixtures to catch batch-indexing errors)."""
     rng = np.random.default_rng(seed)
     bars = cfg["max_bars"]
     U, L = cfg["max_length"]
-    spec = rng.random((batch, 1, frames, cfg["freq_bins"]), dtype=np.float32)
+    if spectrogram == "ridges":
+        spec = np.stack([_ridge_spectrogram(rng, frames, cfg["freq_bins"]) for _ in range(batch)])[:, None]
+    else:
+        spec = rng.random((batch, 1, frames, cfg["freq_bins"]), dtype=np.float32)
     ts = np.empty((batch, bars), dtype=np.int64)
     key = np.empty((batch, bars), dtype=np.int64)
     for b in range(batch):

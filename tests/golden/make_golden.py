@@ -160,19 +160,26 @@ def make_g1(ref_models):
     print("g1 written:", len(out), "arrays")
 
 
-FULL_BATCH = dict(frames=1201, upper_range=(6, 24), lower_range=(4, 16), full_tail=0.0)
+FULL_BATCH = dict(frames=1201, upper_range=(6, 24), lower_range=(4, 16), full_tail=0.0, spectrogram="ridges")
 
 
-def make_g2(ref_models, seed=2024, eb=None):
-    """Full-size model (16.36 M parameters), procedural weights, B=2."""
+def make_g2(ref_models, seed=2032, eb=None):
+    """Full-size model (16.36 M parameters, hparams/pretrain.yaml dims), procedural weights, B=2.
+
+    (seed, eos_bias) were chosen by scanning a handful of seeds for a decode that (i) breaks early at
+    data-dependent steps in some bars and runs to the 398/189 caps in others, (ii) differs between the two
+    clips, and (iii) keeps every argmax decision at least 1e-3 away from a tie -- three orders of magnitude
+    above fp32 re-association noise -- so that demanding bit-exact token ids from an implementation that
+    sums in a different order is a fair test.  The margins are stored in the fixture and the parity test
+    asserts that precondition instead of assuming it."""
     cfg = spec.default_cfg()
-    eb = 3.0 if eb is None else eb
-    st = spec.procedural_state(cfg, seed, eos_bias=eb, lively=True)
+    eb = 2.5 if eb is None else eb
+    st = spec.procedural_state(cfg, seed, eos_bias=eb, lively="token")
     batch = synthetic.make_batch(2, cfg, 77, **FULL_BATCH)
     out, meta = {}, {"weights_seed": seed, "eos_bias": eb, "batch_seed": 77, "batch_kwargs": {k: list(v) if isinstance(v, tuple) else v for k, v in FULL_BATCH.items()},
                      "state_sha256": digest(st.values()),
                      "batch_sha256": digest([batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]])}
-    m = ref_models.ScoreTranscription()
+    m = ref_models.ScoreTranscription(**cfg)      # NB the class defaults (437,129) differ from the yaml's (398,189)
     m.load_state_dict(st)
     m.eval()
     with torch.no_grad():
@@ -192,6 +199,14 @@ def make_g2(ref_models, seed=2024, eb=None):
     out["greedy.up_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
     top2 = lo.topk(2, dim=-1).values
     out["greedy.lo_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    for nm, x in (("ts", ts), ("key", key)):
+        top2 = x.topk(2, dim=-1).values
+        out[f"greedy.{nm}_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    decoded_up, decoded_lo = up.abs().sum(-1) > 0, lo.abs().sum(-1) > 0
+    meta["min_margin"] = {"up": float(torch.from_numpy(out["greedy.up_margin"])[decoded_up].min()),
+                          "lo": float(torch.from_numpy(out["greedy.lo_margin"])[decoded_lo].min()),
+                          "ts": float(out["greedy.ts_margin"].min()), "key": float(out["greedy.key_margin"].min())}
+    meta["lively"] = "token"
     print("g2 greedy rows", out["greedy.up_rows"].tolist(), out["greedy.lo_rows"].tolist())
 
     no_dropout()

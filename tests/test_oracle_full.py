@@ -1,0 +1,95 @@
+"""Oracle vs the reference at FULL model size (hparams/pretrain.yaml dims, 16.36 M parameters).
+
+Fixture tests/golden/g2_full.npz was produced by the reference (tests/golden/make_golden.py).  Weights and
+inputs are regenerated from seeds (spec.procedural_state / synthetic.make_batch); their sha256 is checked so
+a drift in the generators cannot silently change the case.
+
+Exact token-id agreement is only a fair demand when no argmax decision is a near-tie: the fixture records the
+top-2 margin of every decision and this file asserts the precondition (>= 1e-3) before relying on it.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref, recipe_ref
+from piano_a2s_amd import spec, synthetic
+
+MARGIN_FLOOR = 1e-3
+
+
+def _digest(tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def g2(golden_dir):
+    data = np.load(os.path.join(golden_dir, "g2_full.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g2_full.json")))
+    cfg = spec.default_cfg()
+    st = spec.procedural_state(cfg, meta["weights_seed"], eos_bias=meta["eos_bias"], lively=meta["lively"])
+    kw = dict(meta["batch_kwargs"])
+    kw["upper_range"], kw["lower_range"] = tuple(kw["upper_range"]), tuple(kw["lower_range"])
+    batch = synthetic.make_batch(2, cfg, meta["batch_seed"], **kw)
+    assert _digest(st.values()) == meta["state_sha256"], "procedural weights drifted from the fixture's"
+    assert _digest(batch[:7]) == meta["batch_sha256"], "synthetic batch drifted from the fixture's"
+    return data, meta, cfg, st, batch
+
+
+def test_fixture_margin_precondition(g2):
+    _, meta, *_ = g2
+    for k, v in meta["min_margin"].items():
+        assert v >= MARGIN_FLOOR, f"fixture has a near-tie in '{k}' ({v:.2e}); exact-id parity would not be a fair claim"
+
+
+def test_full_greedy_ids_exact(g2):
+    data, meta, cfg, st, batch = g2
+    P, B = spec.split_state(st)
+    with torch.no_grad():
+        ts, key, up, lo = model_ref.forward(P, B, cfg, batch[0], inference=True, training=False)
+    up_ids, lo_ids = up.argmax(-1).numpy(), lo.argmax(-1).numpy()
+    assert np.array_equal(up_ids, data["greedy.up_ids"]), "upper-staff token ids"
+    assert np.array_equal(lo_ids, data["greedy.lo_ids"]), "lower-staff token ids"
+    assert np.array_equal((up.abs().sum(-1) > 0).sum(-1).numpy(), data["greedy.up_rows"]), "executed upper steps"
+    assert np.array_equal((lo.abs().sum(-1) > 0).sum(-1).numpy(), data["greedy.lo_rows"]), "executed lower steps"
+    assert np.abs(ts.numpy() - data["greedy.ts"]).max() <= 1e-4
+    assert np.abs(key.numpy() - data["greedy.key"]).max() <= 1e-4
+    for nm, t in (("up", up), ("lo", lo)):
+        got = t.flatten()[torch.from_numpy(data[f"greedy.{nm}_sample_idx"])].numpy()
+        ref = data[f"greedy.{nm}_sample"]
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), f"{nm} sampled log-probs"
+
+
+def test_full_train_loss_and_grad_norms(g2):
+    data, meta, cfg, st, batch = g2
+    P, B = spec.split_state(st)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    B = {k: v.clone() for k, v in B.items()}
+    gt = [batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]]
+    outs = model_ref.forward(P, B, cfg, batch[0], inference=False, ground_truth=gt, teacher_forcing_ratio=1.0,
+                             training=True, dropout=False)
+    losses = recipe_ref.objectives(outs, (batch[1], batch[2], batch[3], batch[5]))
+    ref = data["train_tf1.losses"]
+    for i, l in enumerate(losses):
+        assert abs(float(l.detach()) - ref[i]) <= 1e-4 * abs(ref[i]), f"loss term {i}: {float(l.detach())} vs {ref[i]}"
+    losses[0].backward()
+    norms = data["train_tf1.gradnorms"]
+    for name, rn in zip(meta["grad_names"], norms):
+        gn = float(P[name].grad.double().norm())
+        assert abs(gn - rn) <= 2e-4 * rn + 1e-8, f"grad norm {name}: {gn} vs {rn}"
+        idx = torch.from_numpy(data[f"train_tf1.gsample_idx.{name}"])
+        got = P[name].grad.flatten()[idx].numpy()
+        rs = data[f"train_tf1.gsample.{name}"]
+        # Per-element tolerance 1e-3 of the tensor's largest sampled |grad|.  Measured oracle-vs-reference:
+        # losses <= 1.7e-7 rel, every grad norm <= 6.7e-5 rel, worst element 4.5e-4 (ConvStack BN/conv, the
+        # deepest tensors: the gradient crosses ~2900 decoder steps, 4x1201 GRU steps and batch-stat BN over
+        # 1.15 M positions, and the two sides only differ in fp32 summation grouping: nn.GRU vs explicit cells).
+        assert np.abs(got - rs).max() <= 1e-3 * max(np.abs(rs).max(), rn / np.sqrt(P[name].numel())) + 1e-9, f"grad samples {name}"
+    for k, b in B.items():
+        assert np.abs(b.numpy() - data[f"train_tf1.buf.{k}"]).max() <= 1e-5 * max(1.0, np.abs(data[f"train_tf1.buf.{k}"]).max())
