@@ -1,0 +1,107 @@
+/* a2s.h -- C ABI of liba2s_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the data-parallel training
+ * hot path of piano-a2s (models.ScoreTranscription forward/backward, loss, clip + Adadelta).
+ *
+ * The reference has no native layer: every operation below replaces a torch.nn call made by
+ * /root/reference/models.py (cited per function) that would otherwise run through ATen -> cuDNN/cuBLAS.
+ * The boundary a maintainer binds is this file; INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every tensor is a plain device pointer to fp32 unless stated (ids: int64 `long long` or int32);
+ *     the library BORROWS pointers for the duration of the call and owns no memory;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); calls only
+ *     enqueue work -- they never allocate and never synchronise, with ONE documented exception:
+ *     a2s_note_decoder_fwd in greedy mode polls a device counter every `poll` steps;
+ *   - return value 0 = ok, negative = error (A2S_ERR_*), message via a2s_last_error(); never throws;
+ *   - scratch memory is caller-allocated; *_workspace_bytes() say how much;
+ *   - one host thread per process / GPU (torchrun model); ordering is by stream.
+ */
+#ifndef A2S_H
+#define A2S_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A2S_OK 0
+#define A2S_ERR_ARG (-1)
+#define A2S_ERR_HIP (-2)
+#define A2S_ERR_WORKSPACE (-3)
+
+const char* a2s_last_error(void);
+int a2s_version(void);
+
+/* ---- dense contraction: every nn.Linear / GRU projection of models.py (:68,:123-132,:359,:444-445,:504) and
+ * their backward forms.  C[m,n] = act(alpha * sum_k A(m,k) B(k,n) + beta*C + bias[n]);
+ * A(m,k)=A[m*sAm+k*sAk], B(k,n)=B[k*sBk+n*sBn]; act 0 none / 1 relu / 2 tanh; split-K is deterministic. */
+int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+                 const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
+                 int batch, long bsA, long bsB, long bsC, int splitk, float* workspace, size_t workspace_bytes);
+size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk);
+int a2s_gemm_pick_splitk(int M, int N, int K, int batch);
+
+/* ---- ConvStack (models.py:475-502,:523-534).  Activations are (B, T, C, F); see csrc/a2s_conv.hip.
+ * conv3x3: y = conv(relu(x*in_scale+in_shift)) (scale/shift NULL: plain x), zero padding 1, no bias;
+ * stat_partial [blocks][Cout][2] receives per-block sum / sum-of-squares of y (NULL to skip);
+ * flip=1 runs the data-gradient form with w read as w'[ci][co][2-dt][2-df]. */
+int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
+                float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip);
+int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin);
+/* BatchNorm2d/1d statistics -> affine (models.py:499-505): reduces the partials in fixed order (double),
+ * updates running stats (momentum, unbiased var) and num_batches_tracked when training, emits mean/invstd
+ * (for backward) and scale/shift with y = x*scale+shift.  training=0: uses the running statistics. */
+int a2s_bn_finalize(void* stream, const float* partial, int nblocks, int C, double count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* mean, float* invstd, float* scale, float* shift, float eps, float momentum, int training);
+int a2s_bn_relu_apply(void* stream, const float* x, float* y, const float* scale, const float* shift, long n, int C, int F);
+int a2s_col_stats(void* stream, const float* x, float* partial, long rows, int C, int rows_per_block);
+int a2s_bn1d_relu_dropout(void* stream, const float* x, float* y, const float* scale, const float* shift,
+                          const uint8_t* keep_mask, float inv_keep, long n, int C);
+
+/* ---- GRU (nn.GRU, gate packing [r;z;n]; models.py:63-67,:107-111,:117-120,:353-356) */
+int a2s_gru_gates_fwd(void* stream, const float* gi, long ldgi, const float* gh, long ldgh, const float* hprev, long ldhp,
+                      float* hout, long ldho, float* hout2, long ldho2, float* save, int R, int H);
+/* one direction of one encoder layer over T steps, h0 = 0 (Encoder.forward, models.py:77) */
+int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh,
+                    const float* b_hh, float* out, long out_bstride, long out_tstride, float* hbuf, float* gh,
+                    float* save, float* hn, int B, int T, int H, int reverse);
+
+/* ---- additive attention step (AttentionLayer.forward models.py:452-461 + bmm :242,:394), keys hoisted:
+ * score_t = v . tanh(K[b,t,:] + q[b,:]); a = softmax_t; ctx = sum_t a_t enc[b,t,:]. */
+int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v,
+                      float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
+                      const int* n_done, int n_rows_total);
+
+int a2s_log_softmax_rows(void* stream, const float* x, long ldx, float* y, long ldy, int* argmax_out, int R, int V);
+int a2s_embed_rows(void* stream, const float* table, const long long* ids64, const int* ids32, long id_stride,
+                   int const_id, float* out, long ldo, int col0, int R, int E, const uint8_t* keep_mask, float inv_keep);
+
+/* ---- one (bar, staff) note decode: NoteDecoder.decode_notes, models.py:366-420 */
+typedef struct a2s_note_dec_args {
+    const float* attn_w; const float* attn_b; const float* attn_v;
+    const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
+    const float* out_w; const float* out_b; const float* emb;
+    const float* keys; const float* enc;
+    float* h; float* x; float* q; float* gates; float* attw; float* o;
+    float* gh; float* gi; float* logits;
+    float* probs; long probs_bstride;
+    const long long* gt; long gt_bstride;
+    const uint8_t* tf_flags;          /* HOST array, one flag per step */
+    const uint8_t* drop; float inv_keep;
+    int* argmax_out; long am_bstride;
+    int* eos_seen; long long* lengths; int* n_done;
+    int* steps_exec;                  /* device counter: +1 per step that actually decoded (greedy early break) */
+    int R, T, H, E, V, steps, poll, eos_id;
+} a2s_note_dec_args;
+int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done);
+
+/* ---- packed staff-embedding bi-GRU final states (get_staff_token_from_{gt,probs}, models.py:164-189).
+ * gru_w: 8 device pointers {w_ih,w_hh,b_ih,b_hh} forward then reverse. */
+int a2s_staff_emb_fwd(void* stream, const float* note_emb, const float* const* gru_w, const long long* ids64,
+                      const int* ids32, long id_bstride, const long long* lengths, long len_stride, float* out,
+                      long ldo, int col0, float* hsave, int R, int maxlen, int E, int S);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+// extern "C" surface of liba2s_hip.so (declared in include/a2s.h): thin, exception-free trampolines onto the
+// *_impl launchers of a2s_gemm.hip / a2s_conv.hip / a2s_seq.hip.
+#include "a2s_common.h"
+#include "../../include/a2s.h"
+
+thread_local char a2s_err_msg[512] = {0};
+
+// ---- launchers implemented in the kernel translation units
+int a2s_gemm_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long,
+                  const float*, int, int, long, long, long, int, float*, size_t);
+size_t a2s_gemm_workspace_bytes_impl(int, int, int, int);
+int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int);
+int a2s_conv3x3_stat_blocks_impl(int, int, int, int);
+int a2s_bn_finalize_impl(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*,
+                         float*, float*, float*, float*, float, float, int);
+int a2s_bn_relu_apply_impl(hipStream_t, const float*, float*, const float*, const float*, long, int, int);
+int a2s_col_stats_impl(hipStream_t, const float*, float*, long, int, int);
+int a2s_bn1d_relu_dropout_impl(hipStream_t, const float*, float*, const float*, const float*, const uint8_t*, float, long, int);
+int a2s_gru_gates_fwd_impl(hipStream_t, const float*, long, const float*, long, const float*, long, float*, long, float*, long, float*, int, int);
+int a2s_gru_seq_fwd_impl(hipStream_t, const float*, long, long, const float*, const float*, float*, long, long, float*, float*,
+                         float*, float*, int, int, int, int);
+int a2s_attn_step_fwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, float*, long, float*, long,
+                           float*, int, int, int, const int*, int);
+int a2s_log_softmax_rows_impl(hipStream_t, const float*, long, float*, long, int*, int, int);
+int a2s_embed_rows_impl(hipStream_t, const float*, const long long*, const int*, long, int, float*, long, int, int, int, const uint8_t*, float);
+int a2s_staff_emb_fwd_impl(hipStream_t, const float*, const float* const*, const long long*, const int*, long, const long long*, long,
+                           float*, long, int, float*, int, int, int, int);
+int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch);
+int a2s_note_decoder_fwd_impl(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
+
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+const char* a2s_last_error(void) { return a2s_err_msg; }
+int a2s_version(void) { return 1; }
+
+int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk, const float* B, long sBk,
+                 long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,
+                 int splitk, float* workspace, size_t workspace_bytes) {
+    return a2s_gemm_impl(ST, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk,
+                         workspace, workspace_bytes);
+}
+size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk) { return a2s_gemm_workspace_bytes_impl(M, N, batch, splitk); }
+int a2s_gemm_pick_splitk(int M, int N, int K, int batch) { return a2s_gemm_pick_splitk_impl(M, N, K, batch); }
+
+int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
+                float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip) {
+    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip);
+}
+int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin) { return a2s_conv3x3_stat_blocks_impl(B, T, F, Cin); }
+int a2s_bn_finalize(void* stream, const float* partial, int nblocks, int C, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd, float* scale,
+                    float* shift, float eps, float momentum, int training) {
+    return a2s_bn_finalize_impl(ST, partial, nblocks, C, count, gamma, beta, running_mean, running_var, nbt, mean, invstd, scale,
+                                shift, eps, momentum, training);
+}
+int a2s_bn_relu_apply(void* stream, const float* x, float* y, const float* scale, const float* shift, long n, int C, int F) {
+    return a2s_bn_relu_apply_impl(ST, x, y, scale, shift, n, C, F);
+}
+int a2s_col_stats(void* stream, const float* x, float* partial, long rows, int C, int rows_per_block) {
+    return a2s_col_stats_impl(ST, x, partial, rows, C, rows_per_block);
+}
+int a2s_bn1d_relu_dropout(void* stream, const float* x, float* y, const float* scale, const float* shift, const uint8_t* keep_mask,
+                          float inv_keep, long n, int C) {
+    return a2s_bn1d_relu_dropout_impl(ST, x, y, scale, shift, keep_mask, inv_keep, n, C);
+}
+int a2s_gru_gates_fwd(void* stream, const float* gi, long ldgi, const float* gh, long ldgh, const float* hprev, long ldhp,
+                      float* hout, long ldho, float* hout2, long ldho2, float* save, int R, int H) {
+    return a2s_gru_gates_fwd_impl(ST, gi, ldgi, gh, ldgh, hprev, ldhp, hout, ldho, hout2, ldho2, save, R, H);
+}
+int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh, const float* b_hh,
+                    float* out, long out_bstride, long out_tstride, float* hbuf, float* gh, float* save, float* hn, int B, int T,
+                    int H, int reverse) {
+    return a2s_gru_seq_fwd_impl(ST, gi_all, gi_bstride, gi_tstride, w_hh, b_hh, out, out_bstride, out_tstride, hbuf, gh, save, hn,
+                                B, T, H, reverse);
+}
+int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, float* ctx,
+                      long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H, const int* n_done, int n_rows_total) {
+    return a2s_attn_step_fwd_impl(ST, keys, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, B, T, H, n_done, n_rows_total);
+}
+int a2s_log_softmax_rows(void* stream, const float* x, long ldx, float* y, long ldy, int* argmax_out, int R, int V) {
+    return a2s_log_softmax_rows_impl(ST, x, ldx, y, ldy, argmax_out, R, V);
+}
+int a2s_embed_rows(void* stream, const float* table, const long long* ids64, const int* ids32, long id_stride, int const_id,
+                   float* out, long ldo, int col0, int R, int E, const uint8_t* keep_mask, float inv_keep) {
+    return a2s_embed_rows_impl(ST, table, ids64, ids32, id_stride, const_id, out, ldo, col0, R, E, keep_mask, inv_keep);
+}
+int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done) {
+    if (!args) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "note_decoder_fwd: null args"); return A2S_ERR_ARG; }
+    return a2s_note_decoder_fwd_impl(ST, *args, steps_done);
+}
+int a2s_staff_emb_fwd(void* stream, const float* note_emb, const float* const* gru_w, const long long* ids64, const int* ids32,
+                      long id_bstride, const long long* lengths, long len_stride, float* out, long ldo, int col0, float* hsave,
+                      int R, int maxlen, int E, int S) {
+    if (!gru_w) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "staff_emb_fwd: null weight table"); return A2S_ERR_ARG; }
+    return a2s_staff_emb_fwd_impl(ST, note_emb, gru_w, ids64, ids32, id_bstride, lengths, len_stride, out, ldo, col0, hsave, R,
+                                  maxlen, E, S);
+}
+
+}  // extern "C"

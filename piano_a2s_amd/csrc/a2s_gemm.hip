@@ -205,7 +205,7 @@ size_t a2s_gemm_workspace_bytes_impl(int M, int N, int batch, int splitk) {
 }
 
 // Heuristic split count for contractions with a tiny output and a huge K (wgrad forms).
-int a2s_gemm_pick_splitk(int M, int N, int K, int batch) {
+int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
     const long tiles = (long)a2s_cdiv(M, 64) * a2s_cdiv(N, 64) * batch;
     if (tiles >= 256 || K < 4096) return 1;
     long s = 512 / tiles;

@@ -1,0 +1,382 @@
+// Sequential part of the hot path, forward: GRU cells, additive attention, note-decoder step epilogue,
+// packed staff-embedding bi-GRU, and the C++ step loops that drive them (so no Python runs per step).
+// Reference: Encoder.forward models.py:75-82 (a-3), AttentionLayer models.py:452-461 (a-7), context bmm
+// :242,:394 (a-8), NoteDecoder.decode_notes :366-420 (a-9), get_staff_token_* :164-189 (a-11).
+//
+// Attention is restructured algebraically but not numerically re-ordered beyond fp32 round-off:
+//   energy = tanh(W [h ; enc_t] + b) = tanh(W_h h + b  +  W_e enc_t) = tanh(q + K_t)
+// K = enc W_e^T is step-invariant and computed once per layer by the GEMM; per step only
+// q (a skinny GEMM), the score/softmax and the context remain -- one pass over K and one over enc.
+#include "a2s_common.h"
+#include "../../include/a2s.h"
+
+int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
+                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes);
+
+// ------------------------------------------------------------------------------------------- GRU cell
+// PyTorch packing [r; z; n].  gi = W_ih x + b_ih, gh = W_hh h + b_hh (both (R, 3H), row strides given).
+// h' = (1-z)*n + z*h ;  optional `live` mask (packed-sequence semantics): dead rows keep h.
+// When `save` != null stores r, z, n, gh_n per row ((R, 4H)) for the backward pass.
+__global__ void gru_gates_fwd(const float* __restrict__ gi, long ldgi, const float* __restrict__ gh, long ldgh,
+                              const float* __restrict__ hprev, long ldhp, float* __restrict__ hout, long ldho,
+                              float* __restrict__ hout2, long ldho2, float* __restrict__ save, int R, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)R * H) return;
+    const int r_ = (int)(idx / H), j = (int)(idx % H);
+    const float* a = gi + (long)r_ * ldgi;
+    const float* b = gh + (long)r_ * ldgh;
+    const float rg = fast_sigmoid(a[j] + b[j]);
+    const float zg = fast_sigmoid(a[H + j] + b[H + j]);
+    const float ghn = b[2 * H + j];
+    const float ng = fast_tanh(a[2 * H + j] + rg * ghn);
+    const float hp = hprev[(long)r_ * ldhp + j];
+    const float hn = (1.f - zg) * ng + zg * hp;
+    hout[(long)r_ * ldho + j] = hn;
+    if (hout2) hout2[(long)r_ * ldho2 + j] = hn;
+    if (save) {
+        float* s = save + (long)r_ * 4 * H;
+        s[j] = rg; s[H + j] = zg; s[2 * H + j] = ng; s[3 * H + j] = ghn;
+    }
+}
+
+int a2s_gru_gates_fwd_impl(hipStream_t st, const float* gi, long ldgi, const float* gh, long ldgh, const float* hprev,
+                           long ldhp, float* hout, long ldho, float* hout2, long ldho2, float* save, int R, int H) {
+    hipLaunchKernelGGL(gru_gates_fwd, dim3(a2s_cdiv((long)R * H, 256)), dim3(256), 0, st, gi, ldgi, gh, ldgh, hprev, ldhp,
+                       hout, ldho, hout2, ldho2, save, R, H);
+    A2S_CHECK_LAUNCH("gru_gates_fwd");
+    return A2S_OK;
+}
+
+// One direction of one encoder GRU layer over all T steps (h0 = 0).
+//   gi_all : (B, T, 3H) = x W_ih^T + b_ih for this direction (row stride ld_gi between time steps of a clip)
+//   out    : (B, T, ldo) -- h_t is written at column offset `col0` (fwd dir 0, reverse dir H)
+//   hbuf   : (2, B, H) ping-pong state, gh: (B, 3H) scratch, save: (T, B, 4H) or null
+//   hn     : (B, H) final state
+int a2s_gru_seq_fwd_impl(hipStream_t st, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh,
+                         const float* b_hh, float* out, long out_bstride, long out_tstride, float* hbuf, float* gh,
+                         float* save, float* hn, int B, int T, int H, int reverse) {
+    A2S_REQUIRE(gi_all && w_hh && b_hh && out && hbuf && gh && hn, "gru_seq_fwd: null tensor");
+    hipError_t e = hipMemsetAsync(hbuf, 0, sizeof(float) * B * H, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gru_seq_fwd memset: %s", hipGetErrorString(e));
+    for (int s = 0; s < T; ++s) {
+        const int t = reverse ? T - 1 - s : s;
+        const float* hp = hbuf + (long)(s & 1) * B * H;
+        float* hq = (s == T - 1) ? hn : hbuf + (long)((s + 1) & 1) * B * H;
+        // gh = h W_hh^T + b_hh   (M=B, N=3H, K=H; W_hh is (3H, H): B(k,n) = W[n*H + k])
+        int rc = a2s_gemm_impl(st, B, 3 * H, H, 1.f, hp, H, 1, w_hh, 1, H, 0.f, gh, 3 * H, b_hh, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        rc = a2s_gru_gates_fwd_impl(st, gi_all + (long)t * gi_tstride, gi_bstride, gh, 3 * H, hp, H, hq, H,
+                                    out + (long)t * out_tstride, out_bstride, save ? save + (long)t * B * 4 * H : nullptr, B, H);
+        if (rc) return rc;
+    }
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- attention
+// One workgroup per row (clip).  Pass 1 streams K (T x H): score_t = v . tanh(K_t + q); softmax over T in LDS;
+// pass 2 streams enc (T x 2H): ctx = sum_t a_t enc_t.  Every byte of K and enc is read exactly once.
+template <int H>
+__global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                     const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                     float* __restrict__ ctx, long ldctx, float* __restrict__ ctx2, long ldctx2,
+                                                     float* __restrict__ attw, int T, const int* __restrict__ n_done, int n_rows_total) {
+    if (n_done && *n_done >= n_rows_total) return;      // greedy decode: every clip already emitted <eos>
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // T scores + 16 reduction slots
+    float* sc = sm;
+    float* red = sm + ((T + 3) & ~3);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Kb = Kmat + (long)b * T * H;
+    const float* Eb = enc + (long)b * T * 2 * H;
+    constexpr int PER = (H + 63) / 64;                   // elements of a K row per lane
+    float qv[PER], vv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int j = lane + i * 64;
+        qv[i] = j < H ? q[(long)b * ldq + j] : 0.f;
+        vv[i] = j < H ? v[j] : 0.f;
+    }
+    for (int t = wave; t < T; t += 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int j = lane + i * 64;
+            if (j < H) s = fmaf(vv[i], fast_tanh(Kb[(long)t * H + j] + qv[i]), s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) sc[t] = s;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int t = tid; t < T; t += 256) m = fmaxf(m, sc[t]);
+    m = block_max(m, red);
+    float l = 0.f;
+    for (int t = tid; t < T; t += 256) { const float p = __expf(sc[t] - m); sc[t] = p; l += p; }
+    l = block_sum(l, red);
+    const float inv = 1.f / l;
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+        const float w = sc[t] * inv;
+        sc[t] = w;
+        if (attw) attw[(long)b * T + t] = w;
+    }
+    __syncthreads();
+    for (int d = tid; d < 2 * H; d += 256) {
+        float acc = 0.f;
+        int t = 0;
+        for (; t + 4 <= T; t += 4) {
+            const float e0 = Eb[(long)(t + 0) * 2 * H + d], e1 = Eb[(long)(t + 1) * 2 * H + d];
+            const float e2 = Eb[(long)(t + 2) * 2 * H + d], e3 = Eb[(long)(t + 3) * 2 * H + d];
+            acc = fmaf(sc[t], e0, acc); acc = fmaf(sc[t + 1], e1, acc);
+            acc = fmaf(sc[t + 2], e2, acc); acc = fmaf(sc[t + 3], e3, acc);
+        }
+        for (; t < T; ++t) acc = fmaf(sc[t], Eb[(long)t * 2 * H + d], acc);
+        ctx[(long)b * ldctx + d] = acc;
+        if (ctx2) ctx2[(long)b * ldctx2 + d] = acc;
+    }
+}
+
+int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                           float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
+                           const int* n_done, int n_rows_total) {
+    const size_t shm = (((T + 3) & ~3) + 16) * sizeof(float);
+    if (H == 256) hipLaunchKernelGGL(attn_step_fwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
+    else if (H == 32) hipLaunchKernelGGL(attn_step_fwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
+    else A2S_FAIL(A2S_ERR_ARG, "attn_step_fwd: hidden_size must be 256 or 32 (got %d)", H);
+    A2S_CHECK_LAUNCH("attn_step_fwd");
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- step epilogue
+// One wave per row: log_softmax over V logits -> probs[b, t, :]; argmax (lowest index on ties, as torch);
+// next input token = gt[b,t] when teacher-forced else the argmax; its embedding (optionally dropped out)
+// goes to the first E columns of the next step's GRU input row; EOS bookkeeping of reference
+// models.py:411-419: every hit overwrites lengths[b] = t+1; n_done counts rows that have hit at least once.
+struct StepFinArgs {
+    const float* logits; long ldl;        // (R, V)
+    float* probs; long probs_bstride;     // row b, step t at probs + b*probs_bstride + t*V
+    const long long* gt; long gt_bstride; // ground-truth ids (row b at gt + b*gt_bstride), null in inference
+    const float* emb;                     // (V, E) embedding table
+    float* xnext; long ldx;               // next GRU input rows; token embedding -> columns [0, E)
+    const uint8_t* drop; float inv_keep;  // (R, E) keep mask for the NEXT token or null
+    int* argmax_out; long am_bstride;     // ids[b*am_bstride + t] (int32) or null
+    int* eos_seen; long long* lengths; int* n_done; int* steps_exec;
+    int R, V, E, t, teacher_force, eos_id;
+};
+
+__global__ __launch_bounds__(256) void note_step_finalize(StepFinArgs a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.R) return;
+    if (*a.n_done >= a.R && a.gt == nullptr) return;
+    const float* lg = a.logits + (long)row * a.ldl;
+    float m = -INFINITY; int mi = 0x7fffffff;
+    for (int j = lane; j < a.V; j += 64) { const float x = lg[j]; if (x > m) { m = x; mi = j; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    float s = 0.f;
+    for (int j = lane; j < a.V; j += 64) s += expf(lg[j] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    float* pr = a.probs + (long)row * a.probs_bstride + (long)a.t * a.V;
+    for (int j = lane; j < a.V; j += 64) pr[j] = lg[j] - lse;
+    const long long g = a.gt ? a.gt[(long)row * a.gt_bstride + a.t] : -1;
+    const int next_id = (a.gt && a.teacher_force) ? (int)g : mi;
+    for (int j = lane; j < a.E; j += 64) {
+        float e = a.emb[(long)next_id * a.E + j];
+        if (a.drop) e = a.drop[(long)row * a.E + j] ? e * a.inv_keep : 0.f;
+        a.xnext[(long)row * a.ldx + j] = e;
+    }
+    if (lane == 0) {
+        if (row == 0 && a.steps_exec) *a.steps_exec = a.t + 1;      // steps run in order on one stream
+        if (a.argmax_out) a.argmax_out[(long)row * a.am_bstride + a.t] = mi;
+        const bool hit = a.gt ? (g == a.eos_id) : (mi == a.eos_id);
+        if (hit) {
+            if (!a.eos_seen[row]) { a.eos_seen[row] = 1; atomicAdd(a.n_done, 1); }
+            a.lengths[row] = a.t + 1;
+        }
+    }
+}
+
+int a2s_note_step_finalize_impl(hipStream_t st, const StepFinArgs& a) {
+    hipLaunchKernelGGL(note_step_finalize, dim3(a2s_cdiv(a.R, 4)), dim3(256), 0, st, a);
+    A2S_CHECK_LAUNCH("note_step_finalize");
+    return A2S_OK;
+}
+
+// Row-wise log_softmax (+ argmax) for the time-signature / key heads: (R, V) -> (R, V) with row stride.
+__global__ __launch_bounds__(256) void log_softmax_rows(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
+                                                        int* __restrict__ argmax_out, int R, int V) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* lg = x + (long)row * ldx;
+    float m = -INFINITY; int mi = 0x7fffffff;
+    for (int j = lane; j < V; j += 64) { const float v = lg[j]; if (v > m) { m = v; mi = j; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    float s = 0.f;
+    for (int j = lane; j < V; j += 64) s += expf(lg[j] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    for (int j = lane; j < V; j += 64) y[(long)row * ldy + j] = lg[j] - lse;
+    if (argmax_out && lane == 0) argmax_out[row] = mi;
+}
+
+int a2s_log_softmax_rows_impl(hipStream_t st, const float* x, long ldx, float* y, long ldy, int* argmax_out, int R, int V) {
+    hipLaunchKernelGGL(log_softmax_rows, dim3(a2s_cdiv(R, 4)), dim3(256), 0, st, x, ldx, y, ldy, argmax_out, R, V);
+    A2S_CHECK_LAUNCH("log_softmax_rows");
+    return A2S_OK;
+}
+
+// out[r, col0 + j] = table[ids[r]][j] (optionally dropped out) -- embedding rows into a wider row buffer.
+__global__ void embed_rows(const float* __restrict__ table, const long long* __restrict__ ids64, const int* __restrict__ ids32,
+                           long id_stride, int const_id, float* __restrict__ out, long ldo, int col0, int R, int E,
+                           const uint8_t* __restrict__ drop, float inv_keep) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)R * E) return;
+    const int r = (int)(idx / E), j = (int)(idx % E);
+    const long id = ids64 ? ids64[(long)r * id_stride] : (ids32 ? ids32[(long)r * id_stride] : const_id);
+    float e = table[id * E + j];
+    if (drop) e = drop[idx] ? e * inv_keep : 0.f;
+    out[(long)r * ldo + col0 + j] = e;
+}
+
+int a2s_embed_rows_impl(hipStream_t st, const float* table, const long long* ids64, const int* ids32, long id_stride,
+                        int const_id, float* out, long ldo, int col0, int R, int E, const uint8_t* drop, float inv_keep) {
+    hipLaunchKernelGGL(embed_rows, dim3(a2s_cdiv((long)R * E, 256)), dim3(256), 0, st, table, ids64, ids32, id_stride, const_id,
+                       out, ldo, col0, R, E, drop, inv_keep);
+    A2S_CHECK_LAUNCH("embed_rows");
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- note decoder loop
+// reference NoteDecoder.decode_notes (models.py:366-420) for one (bar, staff): `steps` iterations of
+//   [q | gh] GEMMs -> attention -> gi GEMM -> GRU gates -> out GEMM -> step epilogue.
+// Training: `steps` and the per-step teacher-forcing flags come from the host plan (they are functions of the
+// ground truth and of Python's random stream only).  Greedy: steps = max_steps; every kernel of a step is a
+// no-op once n_done == R, and the host polls n_done every `poll` steps to stop launching.
+typedef a2s_note_dec_args NoteDecArgs;   // one definition only: the public C struct (include/a2s.h)
+
+int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_done) {
+    const int H2 = 2 * a.H, ldx = a.E + H2;
+    int s = 0;
+    for (; s < a.steps; ++s) {
+        const float* hp = a.h + (long)s * a.R * H2;
+        float* hq = a.h + (long)(s + 1) * a.R * H2;
+        float* xs = a.x + (long)s * a.R * ldx;
+        float* qs = a.q + (long)s * a.R * a.H;
+        float* os = a.o + (long)s * a.R * 2 * H2;
+        int rc;
+        // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
+        rc = a2s_gemm_impl(st, a.R, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        // gh = h W_hh^T + b_hh
+        rc = a2s_gemm_impl(st, a.R, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        // attention -> ctx into x[s][:, E:] and o[s][:, 2H:]
+        rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
+                                    a.attw ? a.attw + (long)s * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R);
+        if (rc) return rc;
+        // gi = x W_ih^T + b_ih
+        rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        // h' -> h[s+1] and o[s][:, :2H]
+        rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
+                                    a.gates ? a.gates + (long)s * a.R * 4 * H2 : nullptr, a.R, H2);
+        if (rc) return rc;
+        // logits = o W_out^T + b_out
+        rc = a2s_gemm_impl(st, a.R, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        StepFinArgs f;
+        f.logits = a.logits; f.ldl = a.V; f.probs = a.probs; f.probs_bstride = a.probs_bstride;
+        f.gt = a.gt; f.gt_bstride = a.gt_bstride; f.emb = a.emb;
+        f.xnext = a.x + (long)(s + 1) * a.R * ldx; f.ldx = ldx;
+        f.drop = a.drop ? a.drop + (long)(s + 1) * a.R * a.E : nullptr; f.inv_keep = a.inv_keep;
+        f.argmax_out = a.argmax_out; f.am_bstride = a.am_bstride;
+        f.eos_seen = a.eos_seen; f.lengths = a.lengths; f.n_done = a.n_done; f.steps_exec = a.steps_exec;
+        f.R = a.R; f.V = a.V; f.E = a.E; f.t = s; f.teacher_force = a.tf_flags ? a.tf_flags[s] : 0; f.eos_id = a.eos_id;
+        rc = a2s_note_step_finalize_impl(st, f);
+        if (rc) return rc;
+        if (!a.gt && a.poll > 0 && ((s + 1) % a.poll == 0) && s + 1 < a.steps) {
+            int done = 0;   // greedy only: one small D2H + sync per `poll` steps
+            hipError_t e = hipMemcpyAsync(&done, a.n_done, sizeof(int), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder poll: %s", hipGetErrorString(e));
+            if (done >= a.R) { ++s; break; }
+        }
+    }
+    if (steps_done) *steps_done = s;
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- staff embedding
+// reference get_staff_token_* (models.py:164-189): packed bi-GRU (E -> S) final states.  One workgroup per
+// (row, direction); the 3S x (E+S) weights live in LDS and the whole (<= 398 step) recurrence runs in-kernel.
+// ids come as int32 (argmax buffer) or int64 (ground truth).  Saves per-step h for the backward pass.
+__global__ __launch_bounds__(128) void staff_emb_fwd(const float* __restrict__ note_emb, const float* __restrict__ w_ih_f,
+                                                     const float* __restrict__ w_hh_f, const float* __restrict__ b_ih_f,
+                                                     const float* __restrict__ b_hh_f, const float* __restrict__ w_ih_r,
+                                                     const float* __restrict__ w_hh_r, const float* __restrict__ b_ih_r,
+                                                     const float* __restrict__ b_hh_r, const long long* __restrict__ ids64,
+                                                     const int* __restrict__ ids32, long id_bstride,
+                                                     const long long* __restrict__ lengths, long len_stride,
+                                                     float* __restrict__ out, long ldo, int col0, float* __restrict__ hsave,
+                                                     int maxlen, int E, int S) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const float* w_ih = dir ? w_ih_r : w_ih_f; const float* w_hh = dir ? w_hh_r : w_hh_f;
+    const float* b_ih = dir ? b_ih_r : b_ih_f; const float* b_hh = dir ? b_hh_r : b_hh_f;
+    float* Wi = sm;                       // (3S, E)
+    float* Wh = Wi + 3 * S * E;           // (3S, S)
+    float* bi = Wh + 3 * S * S;           // 3S
+    float* bh = bi + 3 * S;               // 3S
+    float* h = bh + 3 * S;                // S
+    float* xe = h + S;                    // E
+    float* g = xe + E;                    // 6S : gi | gh
+    for (int i = tid; i < 3 * S * E; i += blockDim.x) Wi[i] = w_ih[i];
+    for (int i = tid; i < 3 * S * S; i += blockDim.x) Wh[i] = w_hh[i];
+    for (int i = tid; i < 3 * S; i += blockDim.x) { bi[i] = b_ih[i]; bh[i] = b_hh[i]; }
+    for (int i = tid; i < S; i += blockDim.x) h[i] = 0.f;
+    int len = (int)lengths[(long)b * len_stride];
+    len = max(0, min(len, maxlen));
+    __syncthreads();
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? len - 1 - s : s;
+        const long id = ids64 ? ids64[(long)b * id_bstride + t] : ids32[(long)b * id_bstride + t];
+        for (int i = tid; i < E; i += blockDim.x) xe[i] = note_emb[id * E + i];
+        __syncthreads();
+        for (int r = tid; r < 6 * S; r += blockDim.x) {
+            float acc;
+            if (r < 3 * S) { acc = bi[r]; for (int k = 0; k < E; ++k) acc = fmaf(Wi[r * E + k], xe[k], acc); }
+            else { const int rr = r - 3 * S; acc = bh[rr]; for (int k = 0; k < S; ++k) acc = fmaf(Wh[rr * S + k], h[k], acc); }
+            g[r] = acc;
+        }
+        __syncthreads();
+        if (tid < S) {
+            const float rg = fast_sigmoid(g[tid] + g[3 * S + tid]);
+            const float zg = fast_sigmoid(g[S + tid] + g[4 * S + tid]);
+            const float ng = fast_tanh(g[2 * S + tid] + rg * g[5 * S + tid]);
+            const float hn = (1.f - zg) * ng + zg * h[tid];
+            h[tid] = hn;
+            if (hsave) hsave[(((long)b * 2 + dir) * maxlen + s) * S + tid] = hn;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < S; i += blockDim.x) out[(long)b * ldo + col0 + dir * S + i] = h[i];
+}
+
+int a2s_staff_emb_fwd_impl(hipStream_t st, const float* note_emb, const float* const* w /* 8 GRU tensors f then r */,
+                           const long long* ids64, const int* ids32, long id_bstride, const long long* lengths,
+                           long len_stride, float* out, long ldo, int col0, float* hsave, int R, int maxlen, int E, int S) {
+    A2S_REQUIRE((ids64 != nullptr) != (ids32 != nullptr), "staff_emb_fwd: exactly one of ids64/ids32");
+    const size_t shm = sizeof(float) * (3 * S * E + 3 * S * S + 6 * S + S + E + 6 * S);
+    hipLaunchKernelGGL(staff_emb_fwd, dim3(R, 2), dim3(128), shm, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
+                       ids64, ids32, id_bstride, lengths, len_stride, out, ldo, col0, hsave, maxlen, E, S);
+    A2S_CHECK_LAUNCH("staff_emb_fwd");
+    return A2S_OK;
+}

@@ -1,0 +1,327 @@
+"""Host-side orchestration of the transcription forward pass on liba2s_hip.so (device work = HIP kernels only).
+
+Mirrors ``ScoreTranscription.forward`` of the reference (models.py:26-51) -> ConvStack (:523-543) -> Encoder
+(:75-82) -> HierarchicalDecoder.decode_bars (:191-316).  PyTorch is used for device memory and the stream;
+every arithmetic operation is a call into the C ABI (piano_a2s_amd.hip).  Control flow that the reference
+evaluates on the host per step (teacher-forcing coin flips, EOS bookkeeping, early break) is resolved ONCE
+per forward into a plan when ground truth is given, and on the device (with sparse polling) in greedy mode.
+"""
+import ctypes as C
+import random as _py_random
+
+import torch
+
+from . import hip
+from .spec import EOS, SOS, VOCAB_SIZE
+
+
+def plan_note_steps(gt_rows, max_steps):
+    """Host replay of the reference's loop bookkeeping for one (bar, staff) with ground truth
+    (models.py:388-419): returns (steps executed, lengths per row).
+
+    The loop breaks at the first t where every row has shown <eos> in gt[:, :t]; lengths[b] is overwritten by
+    every <eos> seen at t < steps (so it ends as the LAST such position + 1), default max_steps.
+    """
+    B = gt_rows.shape[0]
+    is_eos = gt_rows == EOS                                      # (B, max_steps) CPU bool
+    first = torch.where(is_eos.any(1), is_eos.float().argmax(1), torch.full((B,), max_steps))
+    steps = int(first.max()) + 1 if bool((first < max_steps).all()) else max_steps
+    steps = min(steps, max_steps)
+    lengths = torch.full((B,), max_steps, dtype=torch.long)
+    for b in range(B):
+        hits = is_eos[b, :steps].nonzero()
+        if hits.numel():
+            lengths[b] = int(hits[-1]) + 1
+    return steps, lengths
+
+
+class Engine:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.poll = 16            # greedy decode: host looks at the device-side done counter every `poll` steps
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _empty(*shape, dev, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=dev)
+
+    def _bn(self, S, name, partial, nblocks, C_, count, training):
+        dev = S[name + ".weight"].device
+        mean, invstd, scale, shift = (self._empty(C_, dev=dev) for _ in range(4))
+        L = hip.lib()
+        hip.check(L.a2s_bn_finalize(hip.stream(), hip._p(partial), nblocks, C_, C.c_double(count), hip._p(S[name + ".weight"]),
+                                    hip._p(S[name + ".bias"]), hip._p(S[name + ".running_mean"]), hip._p(S[name + ".running_var"]),
+                                    hip._p(S[name + ".num_batches_tracked"]), hip._p(mean), hip._p(invstd), hip._p(scale),
+                                    hip._p(shift), hip.f32(1e-5), hip.f32(0.1), 1 if training else 0), "a2s_bn_finalize")
+        return mean, invstd, scale, shift
+
+    # ------------------------------------------------------------------ ConvStack
+    def convstack(self, S, spec_in, training, drop_mask=None):
+        L = hip.lib()
+        B, _, T, F = spec_in.shape
+        dev = spec_in.device
+        x = spec_in.contiguous()
+        chans = [(1, 20), (20, 20), (20, 40), (40, 40)]
+        scale = shift = None
+        saved = {"x0": x, "y": [], "bn": []}
+        for i, (ci, co) in enumerate(chans, start=1):
+            y = self._empty(B, T, co, F, dev=dev)
+            nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
+            partial = self._empty(nblk, co, 2, dev=dev) if training else None
+            hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(y), hip._p(scale),
+                                    hip._p(shift), hip._p(partial), B, T, F, ci, co, 0), "a2s_conv3x3")
+            mean, invstd, scale, shift = self._bn(S, f"convstack.bn{i}", partial, nblk, co, float(B) * T * F, training)
+            saved["y"].append(y)
+            saved["bn"].append((mean, invstd, scale, shift))
+            x = y
+        a4 = self._empty(B * T, 40 * F, dev=dev)
+        hip.check(L.a2s_bn_relu_apply(hip.stream(), hip._p(x), hip._p(a4), hip._p(scale), hip._p(shift), C.c_long(a4.numel()), 40, F),
+                  "a2s_bn_relu_apply")
+        Cf = self.cfg["conv_feature_size"]
+        z = hip.linear(a4, S["convstack.out.weight"])
+        rows = B * T
+        rpb = 64
+        nblk = (rows + rpb - 1) // rpb
+        partial = None
+        if training:
+            partial = self._empty(nblk, Cf, 2, dev=dev)
+            hip.check(L.a2s_col_stats(hip.stream(), hip._p(z), hip._p(partial), C.c_long(rows), Cf, rpb), "a2s_col_stats")
+        mean, invstd, scale, shift = self._bn(S, "convstack.out_bn", partial, nblk, Cf, float(rows), training)
+        out = self._empty(rows, Cf, dev=dev)
+        hip.check(L.a2s_bn1d_relu_dropout(hip.stream(), hip._p(z), hip._p(out), hip._p(scale), hip._p(shift), hip._p(drop_mask),
+                                          hip.f32(1.0 / 0.8), C.c_long(out.numel()), Cf), "a2s_bn1d_relu_dropout")
+        saved.update(a4=a4, z=z, out_bn=(mean, invstd, scale, shift), drop=drop_mask)
+        return out.view(B, T, Cf), saved
+
+    # ------------------------------------------------------------------ Encoder
+    def encoder(self, S, x, training):
+        L = hip.lib()
+        B, T, _ = x.shape
+        H = self.cfg["hidden_size"]
+        dev = x.device
+        saved = {"layers": []}
+        inp = x.reshape(B * T, -1)
+        finals = []
+        for layer in (0, 1):
+            out = self._empty(B, T, 2 * H, dev=dev)
+            lsave = {"in": inp, "dirs": []}
+            for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
+                gi = hip.linear(inp, S[f"encoder.gru.weight_ih_{sfx}"], S[f"encoder.gru.bias_ih_{sfx}"])      # (B*T, 3H)
+                hbuf = self._empty(2, B, H, dev=dev)
+                gh = self._empty(B, 3 * H, dev=dev)
+                hn = self._empty(B, H, dev=dev)
+                gates = self._empty(T, B, 4 * H, dev=dev) if training else None
+                hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H),
+                                            hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(S[f"encoder.gru.bias_hh_{sfx}"]),
+                                            C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
+                                            hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d), "a2s_gru_seq_fwd")
+                finals.append(hn)
+                lsave["dirs"].append({"gi": gi, "gates": gates, "hn": hn})
+            lsave["out"] = out
+            saved["layers"].append(lsave)
+            inp = out.view(B * T, 2 * H)
+        # bridge: hidden = [tanh(fc([hf0;hr0])) | tanh(fc([hf1;hr1]))]   (models.py:78-81); fc applied as two
+        # half-width contractions so the concatenation never materialises
+        W, bias = S["encoder.fc.weight"], S["encoder.fc.bias"]
+        hidden = self._empty(B, 2 * H, dev=dev)
+        for l in (0, 1):
+            hf, hr = finals[2 * l], finals[2 * l + 1]
+            hip.gemm(hf, H, 1, W, 1, 2 * H, hidden, 2 * H, B, H, H, bias=bias, c_off=l * H)
+            hip.gemm(hr, H, 1, W, 1, 2 * H, hidden, 2 * H, B, H, H, beta=1.0, act=2, b_off=H, c_off=l * H)
+        saved["finals"] = finals
+        saved["hidden"] = hidden
+        return saved["layers"][1]["out"], hidden, saved
+
+    # ------------------------------------------------------------------ decoder pieces
+    def _keys(self, S, prefix, enc2d, H):
+        """K = enc W_e^T with W_e = attn.weight[:, 2H:]  (step-invariant half of the attention Linear)."""
+        W = S[prefix + ".attn.weight"]
+        K = self._empty(enc2d.shape[0], H, dev=enc2d.device)
+        hip.gemm(enc2d, 2 * H, 1, W, 1, 4 * H, K, H, enc2d.shape[0], H, 2 * H, b_off=2 * H)
+        return K
+
+    def _staff_token(self, S, ids, lengths, len_stride, out, col0, maxlen, id_bstride, ids_are_i64):
+        L = hip.lib()
+        names = [f"decoder.staff_emb.{w}_{sfx}" for sfx in ("l0", "l0_reverse") for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        arr = (C.c_void_p * 8)(*[S[n].data_ptr() for n in names])
+        R = out.shape[0]
+        E, Sz = self.cfg["note_emb_size"], self.cfg["staff_emb_size"]
+        hip.check(L.a2s_staff_emb_fwd(hip.stream(), hip._p(S["decoder.note_emb.weight"]), arr,
+                                      hip._p(ids) if ids_are_i64 else C.c_void_p(0), C.c_void_p(0) if ids_are_i64 else hip._p(ids),
+                                      C.c_long(id_bstride), hip._p(lengths), C.c_long(len_stride), hip._p(out), C.c_long(out.stride(0)),
+                                      col0, C.c_void_p(0), R, maxlen, E, Sz), "a2s_staff_emb_fwd")
+
+    def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T):
+        """One NoteDecoder.decode_notes call.  probs_bar: view (B, max_steps, V) of the output tensor (strided)."""
+        L = hip.lib()
+        H, E, V = self.cfg["hidden_size"], self.cfg["note_emb_size"], VOCAB_SIZE
+        H2, ldx = 2 * H, E + 2 * H
+        dev = enc.device
+        n = steps
+        h = self._empty(n + 1, B, H2, dev=dev)
+        h[0].copy_(h0)
+        x = self._empty(n + 1, B, ldx, dev=dev)
+        q = self._empty(n, B, H, dev=dev)
+        o = self._empty(n, B, 2 * H2, dev=dev)
+        gates = self._empty(n, B, 4 * H2, dev=dev) if training else None
+        attw = self._empty(n, B, T, dev=dev) if training else None
+        gh, gi = self._empty(B, 3 * H2, dev=dev), self._empty(B, 3 * H2, dev=dev)
+        logits = self._empty(B, V, dev=dev)
+        ids = torch.zeros((B, max_steps), dtype=torch.int32, device=dev)
+        eos_seen = torch.zeros(B, dtype=torch.int32, device=dev)
+        lengths = torch.full((B,), max_steps, dtype=torch.long, device=dev)
+        n_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        steps_exec = torch.zeros(1, dtype=torch.int32, device=dev)
+        drop = None
+        if training and drop_p > 0:
+            drop = (torch.rand((n + 1, B, E), device=dev) >= drop_p).to(torch.uint8)
+        # SOS token embedding -> x[0][:, :E]
+        hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S[prefix + ".embedding.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0), SOS,
+                                   hip._p(x), C.c_long(ldx), 0, B, E, hip._p(drop), hip.f32(1.0 / (1.0 - drop_p) if drop is not None else 1.0)),
+                  "a2s_embed_rows")
+        flags = (C.c_uint8 * max(n, 1))(*([int(f) for f in tf_flags] if tf_flags is not None else [0] * n))
+        a = hip.NoteDecArgs()
+        for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_b", S[prefix + ".attn.attn.bias"]),
+                        ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),
+                        ("w_hh", S[prefix + ".gru.weight_hh_l0"]), ("b_ih", S[prefix + ".gru.bias_ih_l0"]),
+                        ("b_hh", S[prefix + ".gru.bias_hh_l0"]), ("out_w", S[prefix + ".out.weight"]), ("out_b", S[prefix + ".out.bias"]),
+                        ("emb", S[prefix + ".embedding.weight"]), ("keys", keys), ("enc", enc), ("h", h), ("x", x), ("q", q),
+                        ("gates", gates), ("attw", attw), ("o", o), ("gh", gh), ("gi", gi), ("logits", logits),
+                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop)):
+            setattr(a, name, t.data_ptr() if t is not None else None)
+        a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
+        if gt_bar is not None:
+            a.gt, a.gt_bstride = gt_bar.data_ptr(), gt_bar.stride(0)
+        else:
+            a.gt, a.gt_bstride = None, 0
+        a.tf_flags = C.cast(flags, C.c_void_p).value
+        a.inv_keep = 1.0 / (1.0 - drop_p) if drop is not None else 1.0
+        a.am_bstride = max_steps
+        a.R, a.T, a.H, a.E, a.V, a.steps, a.poll, a.eos_id = B, T, H, E, V, n, (self.poll if gt_bar is None else 0), EOS
+        done = C.c_int(0)
+        hip.check(L.a2s_note_decoder_fwd(hip.stream(), C.byref(a), C.byref(done)), "a2s_note_decoder_fwd")
+        # steps the reference would have executed: known from the plan with ground truth; read back from the device
+        # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
+        executed = n if gt_bar is not None else int(steps_exec.item())
+        saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags))
+        return ids, lengths, saved
+
+    # ------------------------------------------------------------------ full forward
+    def forward(self, S, spectrogram, inference=True, ground_truth=None, teacher_forcing_ratio=0.0, training=False,
+                rng=_py_random, dropout=True):
+        """S: dict name -> device tensor (parameters and BN buffers, reference state_dict names)."""
+        if inference:
+            assert teacher_forcing_ratio == 0 and ground_truth is None     # models.py:202-204
+        if not spectrogram.is_cuda:
+            raise hip.A2SError("Engine.forward needs device tensors: the transcription hot path has no CPU implementation")
+        L = hip.lib()
+        cfg = self.cfg
+        H, E, Sz = cfg["hidden_size"], cfg["note_emb_size"], cfg["staff_emb_size"]
+        te, ke, bars = cfg["time_sig_emb_size"], cfg["key_emb_size"], cfg["max_bars"]
+        U, Lo = cfg["max_length"]
+        V = VOCAB_SIZE
+        B, _, T, F = spectrogram.shape
+        dev = spectrogram.device
+        drop_on = training and dropout
+
+        mask = (torch.rand((B * T, cfg["conv_feature_size"]), device=dev) >= 0.2).to(torch.uint8) if drop_on else None
+        conv_out, conv_saved = self.convstack(S, spectrogram, training, mask)
+        enc, hidden, enc_saved = self.encoder(S, conv_out, training)
+        enc2d = enc.view(B * T, 2 * H)
+        keys = {p: self._keys(S, p + ".attn", enc2d, H) for p in ("decoder", "decoder.upper_decoder", "decoder.lower_decoder")}
+
+        gt_cpu = None
+        if ground_truth is not None:
+            ts_gt, key_gt, up_gt, up_len_gt, lo_gt, lo_len_gt = [g.contiguous() for g in ground_truth]
+            gt_cpu = (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())      # ONE host sync per forward
+
+        ts_out = torch.zeros((B, bars, cfg["num_time_sig"]), device=dev)
+        key_out = torch.zeros((B, bars, cfg["num_keys"]), device=dev)
+        up_out = torch.zeros((B, bars, U, V), device=dev)
+        lo_out = torch.zeros((B, bars, Lo, V), device=dev)
+
+        tokw = 4 * Sz + te + ke
+        token = self._empty(B, tokw, dev=dev)
+        sos_ids = torch.tensor([[SOS, EOS]], dtype=torch.long, device=dev).repeat(B, 1)
+        two = torch.full((B,), 2, dtype=torch.long, device=dev)
+        self._staff_token(S, sos_ids, two, 1, token, 0, 2, 2, True)
+        token[:, 2 * Sz:4 * Sz].copy_(token[:, :2 * Sz])
+        hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S["decoder.time_sig_emb.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0),
+                                   cfg["num_time_sig"], hip._p(token), C.c_long(tokw), 4 * Sz, B, te, C.c_void_p(0), hip.f32(1.0)), "embed ts")
+        hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S["decoder.key_emb.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0),
+                                   cfg["num_keys"], hip._p(token), C.c_long(tokw), 4 * Sz + te, B, ke, C.c_void_p(0), hip.f32(1.0)), "embed key")
+
+        ldxb = tokw + 2 * H
+        bar_saved = []
+        for bar in range(bars):
+            xbar = self._empty(B, ldxb, dev=dev)
+            headin = self._empty(B, 4 * H, dev=dev)
+            if drop_on:
+                keep = (torch.rand((B, tokw), device=dev) >= 0.1).to(token.dtype)
+                xbar[:, :tokw].copy_(token * keep / 0.9)
+            else:
+                keep = None
+                xbar[:, :tokw].copy_(token)
+            # bar-level attention + GRU step (models.py:241-247)
+            qb = self._empty(B, H, dev=dev)
+            Wa = S["decoder.attn.attn.weight"]
+            hip.gemm(hidden, 2 * H, 1, Wa, 1, 4 * H, qb, H, B, H, 2 * H, bias=S["decoder.attn.attn.bias"])
+            attw = self._empty(B, T, dev=dev) if training else None
+            hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys["decoder"]), hip._p(enc), hip._p(qb), C.c_long(H),
+                                          hip._p(S["decoder.attn.v.weight"]), C.c_void_p(xbar.data_ptr() + 4 * tokw), C.c_long(ldxb),
+                                          C.c_void_p(headin.data_ptr() + 4 * 2 * H), C.c_long(4 * H), hip._p(attw), B, T, H,
+                                          C.c_void_p(0), 0), "a2s_attn_step_fwd")
+            gi = hip.linear(xbar, S["decoder.gru.weight_ih_l0"], S["decoder.gru.bias_ih_l0"])
+            gh = hip.linear(hidden, S["decoder.gru.weight_hh_l0"], S["decoder.gru.bias_hh_l0"])
+            hnew = self._empty(B, 2 * H, dev=dev)
+            gates = self._empty(B, 8 * H, dev=dev) if training else None
+            hip.check(L.a2s_gru_gates_fwd(hip.stream(), hip._p(gi), C.c_long(6 * H), hip._p(gh), C.c_long(6 * H), hip._p(hidden),
+                                          C.c_long(2 * H), hip._p(hnew), C.c_long(2 * H), hip._p(headin), C.c_long(4 * H),
+                                          hip._p(gates), B, 2 * H), "a2s_gru_gates_fwd")
+            # note decoders (models.py:261-275)
+            staff = {}
+            for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out, 0), ("lo", "decoder.lower_decoder", Lo, lo_out, 1)):
+                if gt_cpu is not None:
+                    steps, plan_len = plan_note_steps(gt_cpu[gi_idx][:, bar, :], maxs)
+                    flags = [rng.random() < teacher_forcing_ratio for _ in range(steps)]      # one draw per executed step
+                    gt_bar = (up_gt if gi_idx == 0 else lo_gt)[:, bar, :]
+                else:
+                    steps, plan_len, flags, gt_bar = maxs, None, None, None
+                ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
+                                                      training, 0.1 if drop_on else 0.0, B, T)
+                if gt_cpu is None:
+                    for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference
+                        rng.random()
+                staff[name] = (ids, lengths, sv)
+            # heads (models.py:281-286)
+            heads = {}
+            for hname, out_t, nc in (("time_sig_out", ts_out, cfg["num_time_sig"]), ("key_out", key_out, cfg["num_keys"])):
+                t1 = hip.linear(headin, S[f"decoder.{hname}.0.weight"], S[f"decoder.{hname}.0.bias"], act=1)
+                t2 = hip.linear(t1, S[f"decoder.{hname}.2.weight"], S[f"decoder.{hname}.2.bias"], act=1)
+                lg = hip.linear(t2, S[f"decoder.{hname}.4.weight"], S[f"decoder.{hname}.4.bias"])
+                am = torch.empty(B, dtype=torch.int32, device=dev)
+                hip.check(L.a2s_log_softmax_rows(hip.stream(), hip._p(lg), C.c_long(nc), C.c_void_p(out_t.data_ptr() + 4 * bar * nc),
+                                                 C.c_long(bars * nc), hip._p(am), B, nc), "a2s_log_softmax_rows")
+                heads[hname] = (t1, t2, lg, am)
+            # next bar token (models.py:289-311): one draw per bar, after both staves
+            teacher_force = rng.random() < teacher_forcing_ratio
+            token = self._empty(B, tokw, dev=dev)
+            if teacher_force and not inference:
+                if int(gt_cpu[2][:, bar].min()) <= 0 or int(gt_cpu[3][:, bar].min()) <= 0:
+                    raise RuntimeError("Length of all samples has to be greater than 0")     # pack_padded_sequence
+                self._staff_token(S, up_gt[:, bar], up_len_gt[:, bar], bars, token, 0, U, bars * U, True)
+                self._staff_token(S, lo_gt[:, bar], lo_len_gt[:, bar], bars, token, 2 * Sz, Lo, bars * Lo, True)
+                ts_ids, key_ids, i64, stride = ts_gt[:, bar], key_gt[:, bar], True, bars
+            else:
+                self._staff_token(S, staff["up"][0], staff["up"][1], 1, token, 0, U, U, False)
+                self._staff_token(S, staff["lo"][0], staff["lo"][1], 1, token, 2 * Sz, Lo, Lo, False)
+                ts_ids, key_ids, i64, stride = heads["time_sig_out"][3], heads["key_out"][3], False, 1
+            for table, ids_, col, width in ((S["decoder.time_sig_emb.weight"], ts_ids, 4 * Sz, te), (S["decoder.key_emb.weight"], key_ids, 4 * Sz + te, ke)):
+                hip.check(L.a2s_embed_rows(hip.stream(), hip._p(table), hip._p(ids_) if i64 else C.c_void_p(0),
+                                           C.c_void_p(0) if i64 else hip._p(ids_), C.c_long(stride), 0, hip._p(token), C.c_long(tokw), col, B,
+                                           width, C.c_void_p(0), hip.f32(1.0)), "embed next token")
+            bar_saved.append(dict(xbar=xbar, headin=headin, qb=qb, attw=attw, gates=gates, hprev=hidden, hnew=hnew, staff=staff,
+                                  heads=heads, keep=keep, teacher_force=teacher_force))
+            hidden = hnew
+        self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, enc_out=enc)
+        return ts_out, key_out, up_out, lo_out

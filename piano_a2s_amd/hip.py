@@ -1,0 +1,92 @@
+"""ctypes binding of liba2s_hip.so (include/a2s.h).  There is NO fallback: if the library is missing or a
+call fails, this raises -- the product path never silently runs anything else."""
+import ctypes as C
+import os
+
+import torch
+
+from .build import LIB
+
+_lib = None
+
+
+class A2SError(RuntimeError):
+    pass
+
+
+class NoteDecArgs(C.Structure):
+    """Mirror of `a2s_note_dec_args` (include/a2s.h) -- same members, same order."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "attn_w", "attn_b", "attn_v", "w_ih", "w_hh", "b_ih", "b_hh", "out_w", "out_b", "emb", "keys", "enc",
+        "h", "x", "q", "gates", "attw", "o", "gh", "gi", "logits")] + [
+        ("probs", C.c_void_p), ("probs_bstride", C.c_long),
+        ("gt", C.c_void_p), ("gt_bstride", C.c_long),
+        ("tf_flags", C.c_void_p),
+        ("drop", C.c_void_p), ("inv_keep", C.c_float),
+        ("argmax_out", C.c_void_p), ("am_bstride", C.c_long),
+        ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p),
+        ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
+        ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise A2SError(f"HIP extension not built: {LIB} is missing (run `python __graft_entry__.py build`). "
+                           "There is no CPU fallback for the transcription hot path.")
+        _lib = C.CDLL(LIB)
+        _lib.a2s_last_error.restype = C.c_char_p
+        _lib.a2s_gemm_workspace_bytes.restype = C.c_size_t
+    return _lib
+
+
+def _p(t):
+    """device pointer of a tensor (None -> NULL); tensors must be CUDA(HIP) and of the dtype the C side expects."""
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    if not t.is_cuda:
+        raise A2SError("liba2s_hip operates on device memory only: got a CPU tensor (no CPU fallback exists)")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise A2SError(f"{what} failed ({rc}): {lib().a2s_last_error().decode()}")
+
+
+def f32(x):
+    return C.c_float(float(x))
+
+
+def gemm(A, sAm, sAk, B, sBk, sBn, Cout, ldc, M, N, K, alpha=1.0, beta=0.0, bias=None, act=0,
+         batch=1, bsA=0, bsB=0, bsC=0, splitk=1, a_off=0, b_off=0, c_off=0):
+    """C[m,n] = act(alpha*sum_k A(m,k)B(k,n) + beta*C + bias[n]); *_off are element offsets into the tensors."""
+    L = lib()
+    ws, ws_bytes = None, 0
+    if splitk > 1:
+        ws_bytes = L.a2s_gemm_workspace_bytes(M, N, batch, splitk)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=Cout.device)
+    pa = C.c_void_p(A.data_ptr() + 4 * a_off)
+    pb = C.c_void_p(B.data_ptr() + 4 * b_off)
+    pc = C.c_void_p(Cout.data_ptr() + 4 * c_off)
+    check(L.a2s_gemm_f32(stream(), M, N, K, f32(alpha), pa, C.c_long(sAm), C.c_long(sAk), pb, C.c_long(sBk), C.c_long(sBn),
+                         f32(beta), pc, C.c_long(ldc), _p(bias), act, batch, C.c_long(bsA), C.c_long(bsB), C.c_long(bsC),
+                         splitk, _p(ws), C.c_size_t(ws_bytes)), "a2s_gemm_f32")
+
+
+def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0):
+    """y = act(x @ weight.T + bias) for row-major contiguous x (M,K) and weight (N,K)."""
+    M, K = x2d.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    gemm(x2d, x2d.stride(0), x2d.stride(1), weight, weight.stride(1), weight.stride(0), out, out.stride(0), M, N, K,
+         bias=bias, act=act, beta=beta)
+    return out

@@ -1,0 +1,242 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point of liba2s_hip.so against the same operation in
+plain fp32 PyTorch on the CPU (oracle primitives where they exist).  Tolerances are fp32 round-off scaled by
+the reduction length; each is stated at the assertion."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _report(name, err):
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/op_errors.txt", "a") as f:
+        f.write(f"{name}: {err:.3e}\n")
+
+
+@pytest.mark.parametrize("M,N,K", [(7, 173, 1024), (64, 1536, 528), (300, 256, 960), (1201 * 2, 256, 19200 // 8),
+                                   (16, 768, 256), (33, 97, 653), (129, 130, 31)])
+def test_gemm_nt(dev, M, N, K):
+    from piano_a2s_amd import hip
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    ref = A @ W.t() + b
+    out = hip.linear(A.to(dev), W.to(dev), b.to(dev))
+    torch.cuda.synchronize()
+    err = _rel(out, ref)
+    _report(f"gemm_nt {M}x{N}x{K}", err)
+    assert err < 2e-6 * max(1.0, K ** 0.5 / 8), err        # fp32 accumulation of K products
+
+
+def test_gemm_strided_forms(dev):
+    """The transposed / sub-matrix / accumulate / activation / split-K forms the model uses."""
+    from piano_a2s_amd import hip
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 96, 80, 4100
+    A = torch.randn(K, M, generator=g)          # A(m,k) = A[k, m]   (m contiguous: wgrad form)
+    Bm = torch.randn(K, N, generator=g)         # B(k,n) = B[k, n]
+    ref = A.t() @ Bm
+    out = torch.zeros(M, N, device=dev)
+    sk = 8
+    hip.gemm(A.to(dev), 1, M, Bm.to(dev), N, 1, out, N, M, N, K, splitk=sk)
+    torch.cuda.synchronize()
+    err = _rel(out, ref)
+    _report("gemm_tn_splitk", err)
+    assert err < 2e-5, err
+    # sub-matrix of the weight (attention W_h half), beta accumulate + tanh
+    H = 32
+    W = torch.randn(H, 4 * H, generator=g)
+    x1, x2 = torch.randn(5, 2 * H, generator=g), torch.randn(5, 2 * H, generator=g)
+    ref = torch.tanh(x1 @ W[:, :2 * H].t() + x2 @ W[:, 2 * H:].t())
+    out = torch.empty(5, H, device=dev)
+    Wd = W.to(dev)
+    hip.gemm(x1.to(dev), 2 * H, 1, Wd, 1, 4 * H, out, H, 5, H, 2 * H)
+    hip.gemm(x2.to(dev), 2 * H, 1, Wd, 1, 4 * H, out, H, 5, H, 2 * H, beta=1.0, act=2, b_off=2 * H)
+    torch.cuda.synchronize()
+    err = _rel(out, ref)
+    _report("gemm_submatrix_beta_tanh", err)
+    assert err < 5e-6, err
+
+
+@pytest.mark.parametrize("Cin,Cout", [(1, 20), (20, 20), (20, 40), (40, 40)])
+@pytest.mark.parametrize("B,T,F", [(2, 9, 24), (1, 41, 480)])
+def test_conv3x3_with_input_affine_and_stats(dev, Cin, Cout, B, T, F):
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(Cin * 100 + Cout + T)
+    x = torch.randn(B, T, Cin, F, generator=g)                      # (B,T,C,F) layout
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    scale = torch.rand(Cin, generator=g) + 0.5
+    shift = torch.randn(Cin, generator=g) * 0.3
+    use_affine = Cin != 1
+    xin = x.permute(0, 2, 1, 3)                                      # NCHW for the torch reference
+    if use_affine:
+        xin = torch.relu(xin * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = torch.nn.functional.conv2d(xin, w, padding=1).permute(0, 2, 1, 3).contiguous()
+    y = torch.empty(B, T, Cout, F, device=dev)
+    nblk = L.a2s_conv3x3_stat_blocks(B, T, F, Cin)
+    part = torch.zeros(nblk, Cout, 2, device=dev)
+    hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x.to(dev)), hip._p(w.to(dev)), hip._p(y),
+                            hip._p(scale.to(dev)) if use_affine else C.c_void_p(0),
+                            hip._p(shift.to(dev)) if use_affine else C.c_void_p(0), hip._p(part), B, T, F, Cin, Cout, 0), "conv")
+    torch.cuda.synchronize()
+    err = _rel(y, ref)
+    _report(f"conv3x3 {Cin}->{Cout} B{B} T{T} F{F}", err)
+    assert err < 5e-6, err                                           # K <= 360 products
+    sums = part.cpu().double().sum(0)
+    ref_s = ref.double().sum(dim=(0, 1, 3))
+    ref_s2 = (ref.double() ** 2).sum(dim=(0, 1, 3))
+    assert float((sums[:, 0] - ref_s).abs().max()) < 1e-3 * float(ref_s.abs().max().clamp_min(1.0))
+    assert float((sums[:, 1] - ref_s2).abs().max()) < 1e-4 * float(ref_s2.abs().max())
+
+
+def test_conv3x3_flip_is_data_gradient(dev):
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(5)
+    B, T, F, Cin, Cout = 2, 7, 24, 20, 40
+    x = torch.randn(B, Cin, T, F, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+    dy = torch.randn(B, Cout, T, F, generator=g)
+    torch.nn.functional.conv2d(x, w, padding=1).backward(dy)
+    ref = x.grad.permute(0, 2, 1, 3).contiguous()                    # (B,T,Cin,F)
+    dyl = dy.permute(0, 2, 1, 3).contiguous().to(dev)                # (B,T,Cout,F)
+    dx = torch.empty(B, T, Cin, F, device=dev)
+    hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dyl), hip._p(w.to(dev)), hip._p(dx), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0),
+                            B, T, F, Cout, Cin, 1), "conv flip")
+    torch.cuda.synchronize()
+    err = _rel(dx, ref)
+    _report("conv3x3 dgrad(flip)", err)
+    assert err < 5e-6, err
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_finalize_matches_oracle_batch_norm(dev, training):
+    from oracle import model_ref
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(9)
+    Cc, n = 20, 4000
+    x = torch.randn(n, Cc, generator=g) * 2 + 3                      # non-zero mean: exercises the E[x^2]-m^2 form
+    P = {"bn.weight": torch.rand(Cc, generator=g) + 0.5, "bn.bias": torch.randn(Cc, generator=g)}
+    Bf = {"bn.running_mean": torch.randn(Cc, generator=g), "bn.running_var": torch.rand(Cc, generator=g) + 0.5,
+          "bn.num_batches_tracked": torch.tensor(3)}
+    Bd = {k: v.clone().to(dev) for k, v in Bf.items()}
+    ref = model_ref.batch_norm(x, P, Bf, "bn", training, channel_dim=1)
+    rpb = 64
+    nblk = (n + rpb - 1) // rpb
+    part = torch.zeros(nblk, Cc, 2, device=dev)
+    xd = x.to(dev)
+    hip.check(L.a2s_col_stats(hip.stream(), hip._p(xd), hip._p(part), C.c_long(n), Cc, rpb), "col_stats")
+    mean, invstd, scale, shift = (torch.empty(Cc, device=dev) for _ in range(4))
+    hip.check(L.a2s_bn_finalize(hip.stream(), hip._p(part), nblk, Cc, C.c_double(n), hip._p(P["bn.weight"].to(dev)),
+                                hip._p(P["bn.bias"].to(dev)), hip._p(Bd["bn.running_mean"]), hip._p(Bd["bn.running_var"]),
+                                hip._p(Bd["bn.num_batches_tracked"]), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift),
+                                hip.f32(1e-5), hip.f32(0.1), int(training)), "bn_finalize")
+    torch.cuda.synchronize()
+    y = xd * scale + shift
+    err = _rel(y, ref)
+    _report(f"bn training={training}", err)
+    assert err < 5e-6, err
+    for k in Bf:
+        assert _rel(Bd[k].float(), Bf[k].float()) < 1e-5, k
+
+
+@pytest.mark.parametrize("H,T,B", [(32, 41, 3), (256, 1201, 2)])
+def test_attention_step(dev, H, T, B):
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(H + T)
+    enc = torch.randn(B, T, 2 * H, generator=g)
+    W = torch.randn(H, 4 * H, generator=g) * (3.0 / (4 * H)) ** 0.5 * 4
+    bias = torch.randn(H, generator=g) * 0.1
+    v = torch.randn(1, H, generator=g) * (3.0 / H) ** 0.5 * 4
+    hid = torch.randn(1, B, 2 * H, generator=g)
+    from oracle import model_ref
+    P = {"a.attn.weight": W, "a.attn.bias": bias, "a.v.weight": v}
+    a_ref = model_ref.attention(hid, enc, P, "a")
+    ctx_ref = torch.bmm(a_ref.unsqueeze(1), enc).squeeze(1)
+    encd, Wd = enc.to(dev), W.to(dev)
+    keys = torch.empty(B * T, H, device=dev)
+    hip.gemm(encd, 2 * H, 1, Wd, 1, 4 * H, keys, H, B * T, H, 2 * H, b_off=2 * H)
+    q = torch.empty(B, H, device=dev)
+    hip.gemm(hid[0].to(dev), 2 * H, 1, Wd, 1, 4 * H, q, H, B, H, 2 * H, bias=bias.to(dev))
+    ctx = torch.empty(B, 2 * H, device=dev)
+    attw = torch.empty(B, T, device=dev)
+    hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys), hip._p(encd), hip._p(q), C.c_long(H), hip._p(v.to(dev)), hip._p(ctx),
+                                  C.c_long(2 * H), C.c_void_p(0), C.c_long(0), hip._p(attw), B, T, H, C.c_void_p(0), 0), "attn")
+    torch.cuda.synchronize()
+    e1, e2 = _rel(attw, a_ref), _rel(ctx, ctx_ref)
+    _report(f"attention H{H} T{T} weights", e1)
+    _report(f"attention H{H} T{T} context", e2)
+    assert e1 < 2e-5 and e2 < 2e-5, (e1, e2)
+
+
+def test_gru_sequence_both_directions(dev):
+    from oracle import model_ref
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(17)
+    B, T, I, H = 3, 23, 32, 32
+    x = torch.randn(B, T, I, generator=g)
+    P = {}
+    for sfx in ("l0", "l0_reverse"):
+        P[f"g.weight_ih_{sfx}"] = torch.randn(3 * H, I, generator=g) * 0.3
+        P[f"g.weight_hh_{sfx}"] = torch.randn(3 * H, H, generator=g) * 0.3
+        P[f"g.bias_ih_{sfx}"] = torch.randn(3 * H, generator=g) * 0.1
+        P[f"g.bias_hh_{sfx}"] = torch.randn(3 * H, generator=g) * 0.1
+    of, hf = model_ref.gru_direction(x, P, "g", "l0")
+    orr, hr = model_ref.gru_direction(x, P, "g", "l0_reverse", reverse=True)
+    out = torch.empty(B, T, 2 * H, device=dev)
+    xd = x.to(dev).reshape(B * T, I)
+    hns = []
+    for d, sfx in enumerate(("l0", "l0_reverse")):
+        gi = hip.linear(xd, P[f"g.weight_ih_{sfx}"].to(dev), P[f"g.bias_ih_{sfx}"].to(dev))
+        hbuf, gh, hn = torch.empty(2, B, H, device=dev), torch.empty(B, 3 * H, device=dev), torch.empty(B, H, device=dev)
+        hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H), hip._p(P[f"g.weight_hh_{sfx}"].to(dev)),
+                                    hip._p(P[f"g.bias_hh_{sfx}"].to(dev)), C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H),
+                                    C.c_long(2 * H), hip._p(hbuf), hip._p(gh), C.c_void_p(0), hip._p(hn), B, T, H, d), "gru_seq")
+        hns.append(hn)
+    torch.cuda.synchronize()
+    e = max(_rel(out[..., :H], of), _rel(out[..., H:], orr), _rel(hns[0], hf), _rel(hns[1], hr))
+    _report("gru_seq bidir", e)
+    assert e < 1e-5, e
+
+
+def test_staff_embedding_ragged_lengths(dev):
+    from oracle import model_ref
+    from piano_a2s_amd import engine, spec
+    cfg = spec.default_cfg(freq_bins=24, conv_feature_size=32, hidden_size=32, max_length=(12, 8))
+    st = spec.procedural_state(cfg, 11)
+    P, _ = spec.split_state(st)
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 173, (4, 12), generator=g)
+    lengths = torch.tensor([1, 12, 5, 7])
+    ref = model_ref._staff_token(ids, lengths, P).squeeze(1)
+    eng = engine.Engine(cfg)
+    S = {k: v.to(dev) for k, v in st.items()}
+    out = torch.zeros(4, 64, device=dev)
+    eng._staff_token(S, ids.to(dev), lengths.to(dev), 1, out, 0, 12, 12, True)
+    out32 = torch.zeros(4, 64, device=dev)
+    eng._staff_token(S, ids.to(torch.int32).to(dev), lengths.to(dev), 1, out32, 0, 12, 12, False)
+    torch.cuda.synchronize()
+    e = max(_rel(out, ref), _rel(out32, ref))
+    _report("staff_emb ragged", e)
+    assert e < 1e-5, e
