@@ -38,7 +38,8 @@ def test_gemm_nt(dev, M, N, K):
     W = torch.randn(N, K, generator=g)
     b = torch.randn(N, generator=g)
     ref = A @ W.t() + b
-    out = hip.linear(A.to(dev), W.to(dev), b.to(dev))
+    Ad, Wd, bd = A.to(dev), W.to(dev), b.to(dev)
+    out = hip.linear(Ad, Wd, bd)
     torch.cuda.synchronize()
     err = _rel(out, ref)
     _report(f"gemm_nt {M}x{N}x{K}", err)
@@ -55,7 +56,8 @@ def test_gemm_strided_forms(dev):
     ref = A.t() @ Bm
     out = torch.zeros(M, N, device=dev)
     sk = 8
-    hip.gemm(A.to(dev), 1, M, Bm.to(dev), N, 1, out, N, M, N, K, splitk=sk)
+    Ad, Bd = A.to(dev), Bm.to(dev)
+    hip.gemm(Ad, 1, M, Bd, N, 1, out, N, M, N, K, splitk=sk)
     torch.cuda.synchronize()
     err = _rel(out, ref)
     _report("gemm_tn_splitk", err)
@@ -67,8 +69,9 @@ def test_gemm_strided_forms(dev):
     ref = torch.tanh(x1 @ W[:, :2 * H].t() + x2 @ W[:, 2 * H:].t())
     out = torch.empty(5, H, device=dev)
     Wd = W.to(dev)
-    hip.gemm(x1.to(dev), 2 * H, 1, Wd, 1, 4 * H, out, H, 5, H, 2 * H)
-    hip.gemm(x2.to(dev), 2 * H, 1, Wd, 1, 4 * H, out, H, 5, H, 2 * H, beta=1.0, act=2, b_off=2 * H)
+    x1d, x2d = x1.to(dev), x2.to(dev)
+    hip.gemm(x1d, 2 * H, 1, Wd, 1, 4 * H, out, H, 5, H, 2 * H)
+    hip.gemm(x2d, 2 * H, 1, Wd, 1, 4 * H, out, H, 5, H, 2 * H, beta=1.0, act=2, b_off=2 * H)
     torch.cuda.synchronize()
     err = _rel(out, ref)
     _report("gemm_submatrix_beta_tanh", err)
@@ -93,9 +96,11 @@ def test_conv3x3_with_input_affine_and_stats(dev, Cin, Cout, B, T, F):
     y = torch.empty(B, T, Cout, F, device=dev)
     nblk = L.a2s_conv3x3_stat_blocks(B, T, F, Cin)
     part = torch.zeros(nblk, Cout, 2, device=dev)
-    hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x.to(dev)), hip._p(w.to(dev)), hip._p(y),
-                            hip._p(scale.to(dev)) if use_affine else C.c_void_p(0),
-                            hip._p(shift.to(dev)) if use_affine else C.c_void_p(0), hip._p(part), B, T, F, Cin, Cout, 0), "conv")
+    # NB: raw pointers do not keep tensors alive -- every device operand is bound to a name for the whole call
+    xd, wd, scd, shd = x.to(dev), w.to(dev), scale.to(dev), shift.to(dev)
+    hip.check(L.a2s_conv3x3(hip.stream(), hip._p(xd), hip._p(wd), hip._p(y),
+                            hip._p(scd) if use_affine else C.c_void_p(0),
+                            hip._p(shd) if use_affine else C.c_void_p(0), hip._p(part), B, T, F, Cin, Cout, 0), "conv")
     torch.cuda.synchronize()
     err = _rel(y, ref)
     _report(f"conv3x3 {Cin}->{Cout} B{B} T{T} F{F}", err)
@@ -119,7 +124,8 @@ def test_conv3x3_flip_is_data_gradient(dev):
     ref = x.grad.permute(0, 2, 1, 3).contiguous()                    # (B,T,Cin,F)
     dyl = dy.permute(0, 2, 1, 3).contiguous().to(dev)                # (B,T,Cout,F)
     dx = torch.empty(B, T, Cin, F, device=dev)
-    hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dyl), hip._p(w.to(dev)), hip._p(dx), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0),
+    wd = w.to(dev)
+    hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dyl), hip._p(wd), hip._p(dx), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0),
                             B, T, F, Cout, Cin, 1), "conv flip")
     torch.cuda.synchronize()
     err = _rel(dx, ref)
@@ -146,8 +152,9 @@ def test_bn_finalize_matches_oracle_batch_norm(dev, training):
     xd = x.to(dev)
     hip.check(L.a2s_col_stats(hip.stream(), hip._p(xd), hip._p(part), C.c_long(n), Cc, rpb), "col_stats")
     mean, invstd, scale, shift = (torch.empty(Cc, device=dev) for _ in range(4))
-    hip.check(L.a2s_bn_finalize(hip.stream(), hip._p(part), nblk, Cc, C.c_double(n), hip._p(P["bn.weight"].to(dev)),
-                                hip._p(P["bn.bias"].to(dev)), hip._p(Bd["bn.running_mean"]), hip._p(Bd["bn.running_var"]),
+    gd, bd = P["bn.weight"].to(dev), P["bn.bias"].to(dev)
+    hip.check(L.a2s_bn_finalize(hip.stream(), hip._p(part), nblk, Cc, C.c_double(n), hip._p(gd),
+                                hip._p(bd), hip._p(Bd["bn.running_mean"]), hip._p(Bd["bn.running_var"]),
                                 hip._p(Bd["bn.num_batches_tracked"]), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift),
                                 hip.f32(1e-5), hip.f32(0.1), int(training)), "bn_finalize")
     torch.cuda.synchronize()
@@ -177,10 +184,11 @@ def test_attention_step(dev, H, T, B):
     keys = torch.empty(B * T, H, device=dev)
     hip.gemm(encd, 2 * H, 1, Wd, 1, 4 * H, keys, H, B * T, H, 2 * H, b_off=2 * H)
     q = torch.empty(B, H, device=dev)
-    hip.gemm(hid[0].to(dev), 2 * H, 1, Wd, 1, 4 * H, q, H, B, H, 2 * H, bias=bias.to(dev))
+    hd, biasd, vd = hid[0].to(dev), bias.to(dev), v.to(dev)
+    hip.gemm(hd, 2 * H, 1, Wd, 1, 4 * H, q, H, B, H, 2 * H, bias=biasd)
     ctx = torch.empty(B, 2 * H, device=dev)
     attw = torch.empty(B, T, device=dev)
-    hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys), hip._p(encd), hip._p(q), C.c_long(H), hip._p(v.to(dev)), hip._p(ctx),
+    hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys), hip._p(encd), hip._p(q), C.c_long(H), hip._p(vd), hip._p(ctx),
                                   C.c_long(2 * H), C.c_void_p(0), C.c_long(0), hip._p(attw), B, T, H, C.c_void_p(0), 0), "attn")
     torch.cuda.synchronize()
     e1, e2 = _rel(attw, a_ref), _rel(ctx, ctx_ref)
@@ -207,11 +215,12 @@ def test_gru_sequence_both_directions(dev):
     out = torch.empty(B, T, 2 * H, device=dev)
     xd = x.to(dev).reshape(B * T, I)
     hns = []
+    Pd = {k: v.to(dev) for k, v in P.items()}
     for d, sfx in enumerate(("l0", "l0_reverse")):
-        gi = hip.linear(xd, P[f"g.weight_ih_{sfx}"].to(dev), P[f"g.bias_ih_{sfx}"].to(dev))
+        gi = hip.linear(xd, Pd[f"g.weight_ih_{sfx}"], Pd[f"g.bias_ih_{sfx}"])
         hbuf, gh, hn = torch.empty(2, B, H, device=dev), torch.empty(B, 3 * H, device=dev), torch.empty(B, H, device=dev)
-        hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H), hip._p(P[f"g.weight_hh_{sfx}"].to(dev)),
-                                    hip._p(P[f"g.bias_hh_{sfx}"].to(dev)), C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H),
+        hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H), hip._p(Pd[f"g.weight_hh_{sfx}"]),
+                                    hip._p(Pd[f"g.bias_hh_{sfx}"]), C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H),
                                     C.c_long(2 * H), hip._p(hbuf), hip._p(gh), C.c_void_p(0), hip._p(hn), B, T, H, d), "gru_seq")
         hns.append(hn)
     torch.cuda.synchronize()
