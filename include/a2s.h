@@ -101,6 +101,62 @@ int a2s_staff_emb_fwd(void* stream, const float* note_emb, const float* const* g
                       const int* ids32, long id_bstride, const long long* lengths, long len_stride, float* out,
                       long ldo, int col0, float* hsave, int R, int maxlen, int E, int S);
 
+/* ======================================================================================= backward
+ * Gradients follow torch.autograd on the reference graph.  All "+=" outputs accumulate (beta = 1 semantics). */
+
+/* dx = g - exp(y) * rowsum(g) for y = log_softmax(x).  Row r of g/y at base + (r/inner)*outer_stride + (r%inner)*V;
+ * time_major=1 writes dx row (r%inner)*n_outer + r/inner (step-major, to line up with the saved step buffers). */
+int a2s_log_softmax_bwd_rows(void* stream, const float* g, const float* y, long outer_stride, int inner, float* dx,
+                             int R, int V, int n_outer, int time_major);
+/* GRU cell backward from the saved [r|z|n|gh_n]; dh = dh_a + dh_b (dh_b may be NULL); hprev NULL = zeros. */
+int a2s_gru_gates_bwd(void* stream, const float* dh_a, long lda, const float* dh_b, long ldb, const float* save,
+                      const float* hprev, long ldhp, float* dgi, long ldgi, float* dgh, long ldgh, float* dgh2, long ldgh2,
+                      float* dhprev, long lddp, int R, int H);
+/* one attention step backward: dq, ds (T per row) and the summed dctx (see csrc/a2s_bwd.hip) */
+int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v,
+                      const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
+                      long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H);
+/* deferred key gradient of S steps: dK += ..., dv partials [B*ceil(T/16)][H] (reduce with a2s_col_sum) */
+int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
+                      float* dv_partial, int B, int T, int S, int H);
+int a2s_attn_dk_blocks(int B, int T);
+int a2s_col_sum(void* stream, const float* x, long ld, float* out, long rows, int C, float alpha, float beta);
+int a2s_embed_scatter_add(void* stream, float* table_grad, const long long* ids64, const int* ids32, long id_stride,
+                          int const_id, const float* g, long ldg, int col0, int R, int E, const uint8_t* keep_mask, float inv_keep);
+int a2s_ew_act_bwd(void* stream, const float* g, const float* y, float* dx, long n, int act);
+
+typedef struct a2s_note_dec_bwd_args {
+    const float* attn_w; const float* attn_v; const float* w_ih; const float* w_hh;
+    const float* keys; const float* enc;
+    const float* h; const float* x; const float* q; const float* gates; const float* attw;   /* saved by the forward */
+    const float* do_all;                 /* (steps, R, 4H): dlogits_all W_out = [dh | dctx] of the output projection */
+    float* dgi_all; float* dgh_all; float* dq_all; float* ds_all; float* dctx_all; float* dx;
+    float* dh;                           /* (2, R, 2H) carry; dh[0] = gradient wrt the initial hidden on return */
+    int R, T, H, E, steps;
+} a2s_note_dec_bwd_args;
+int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);
+
+/* BPTT of one encoder GRU direction (reverse of a2s_gru_seq_fwd) */
+int a2s_gru_seq_bwd(void* stream, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride,
+                    long out_tstride, const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift,
+                    float* dgh_first, float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse);
+/* BPTT of the packed staff-embedding bi-GRU; grads: DEVICE array of 8 pointers (same order as gru_w) */
+int a2s_staff_emb_bwd(void* stream, const float* note_emb, const float* const* gru_w, float* const* grads, float* note_emb_grad,
+                      const long long* ids64, const int* ids32, long id_bstride, const long long* lengths, long len_stride,
+                      const float* dout, long lddo, int col0, const float* hsave, int R, int maxlen, int E, int S);
+
+/* BatchNorm(+ReLU, + optional dropout on the (rows,C) layout) backward, training statistics (models.py:525-541):
+ * dgamma/dbeta +=, dx written (may alias g).  rows x C x F elements, channel of element i = (i/F)%C.
+ * partial: a2s_bn_bwd_partial_floats() floats of scratch; c12: 2*C floats of scratch. */
+int a2s_bn_bwd(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+               const float* shift, const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx,
+               float* partial, float* c12, long rows, int C, int F);
+size_t a2s_bn_bwd_partial_floats(long rows, int C, int F);
+/* conv weight gradient dW += dy (*) relu(x*in_scale+in_shift)  (deterministic two-stage reduction) */
+int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
+                      float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);
+size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
+
 #ifdef __cplusplus
 }
 #endif

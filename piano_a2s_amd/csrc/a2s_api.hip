@@ -28,6 +28,27 @@ int a2s_staff_emb_fwd_impl(hipStream_t, const float*, const float* const*, const
 int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch);
 int a2s_note_decoder_fwd_impl(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
 
+int a2s_log_softmax_bwd_rows_impl(hipStream_t, const float*, const float*, long, int, float*, int, int, int, int);
+int a2s_gru_gates_bwd_impl(hipStream_t, const float*, long, const float*, long, const float*, const float*, long, float*, long, float*, long,
+                           float*, long, float*, long, int, int);
+int a2s_attn_step_bwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, const float*, const float*, long,
+                           const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int);
+int a2s_attn_dk_accum_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int);
+int a2s_col_sum_impl(hipStream_t, const float*, long, float*, long, int, float, float);
+int a2s_embed_scatter_add_impl(hipStream_t, float*, const long long*, const int*, long, int, const float*, long, int, int, int, const uint8_t*, float);
+int a2s_ew_act_bwd_impl(hipStream_t, const float*, const float*, float*, long, int);
+int a2s_note_decoder_bwd_impl(hipStream_t, const a2s_note_dec_bwd_args&);
+int a2s_gru_seq_bwd_impl(hipStream_t, const float*, long, long, const float*, long, long, const float*, const float*, const float*, float*,
+                         float*, float*, float*, float*, int, int, int, int);
+int a2s_staff_emb_bwd_impl(hipStream_t, const float*, const float* const*, float* const*, float*, const long long*, const int*, long,
+                           const long long*, long, const float*, long, int, const float*, int, int, int, int);
+
+int a2s_bn_bwd_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
+                    float*, float*, float*, float*, float*, long, int, int);
+size_t a2s_bn_bwd_partial_floats_impl(long, int, int);
+int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int);
+size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int, int);
+
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -97,5 +118,60 @@ int a2s_staff_emb_fwd(void* stream, const float* note_emb, const float* const* g
     return a2s_staff_emb_fwd_impl(ST, note_emb, gru_w, ids64, ids32, id_bstride, lengths, len_stride, out, ldo, col0, hsave, R,
                                   maxlen, E, S);
 }
+
+int a2s_log_softmax_bwd_rows(void* stream, const float* g, const float* y, long outer_stride, int inner, float* dx, int R, int V,
+                             int n_outer, int time_major) {
+    return a2s_log_softmax_bwd_rows_impl(ST, g, y, outer_stride, inner, dx, R, V, n_outer, time_major);
+}
+int a2s_gru_gates_bwd(void* stream, const float* dh_a, long lda, const float* dh_b, long ldb, const float* save, const float* hprev,
+                      long ldhp, float* dgi, long ldgi, float* dgh, long ldgh, float* dgh2, long ldgh2, float* dhprev, long lddp, int R, int H) {
+    return a2s_gru_gates_bwd_impl(ST, dh_a, lda, dh_b, ldb, save, hprev, ldhp, dgi, ldgi, dgh, ldgh, dgh2, ldgh2, dhprev, lddp, R, H);
+}
+int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, const float* attw,
+                      const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb, float* dctx_out,
+                      long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H) {
+    return a2s_attn_step_bwd_impl(ST, keys, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, B, T, H);
+}
+int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
+                      float* dv_partial, int B, int T, int S, int H) {
+    return a2s_attn_dk_accum_impl(ST, keys, q_all, ds_all, v, dK, dv_partial, B, T, S, H);
+}
+int a2s_attn_dk_blocks(int B, int T) { return B * ((T + 15) / 16); }
+int a2s_col_sum(void* stream, const float* x, long ld, float* out, long rows, int C, float alpha, float beta) {
+    return a2s_col_sum_impl(ST, x, ld, out, rows, C, alpha, beta);
+}
+int a2s_embed_scatter_add(void* stream, float* table_grad, const long long* ids64, const int* ids32, long id_stride, int const_id,
+                          const float* g, long ldg, int col0, int R, int E, const uint8_t* keep_mask, float inv_keep) {
+    return a2s_embed_scatter_add_impl(ST, table_grad, ids64, ids32, id_stride, const_id, g, ldg, col0, R, E, keep_mask, inv_keep);
+}
+int a2s_ew_act_bwd(void* stream, const float* g, const float* y, float* dx, long n, int act) { return a2s_ew_act_bwd_impl(ST, g, y, dx, n, act); }
+int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args) {
+    if (!args) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "note_decoder_bwd: null args"); return A2S_ERR_ARG; }
+    return a2s_note_decoder_bwd_impl(ST, *args);
+}
+int a2s_gru_seq_bwd(void* stream, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride, long out_tstride,
+                    const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift, float* dgh_first,
+                    float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse) {
+    return a2s_gru_seq_bwd_impl(ST, dout, do_bstride, do_tstride, out, out_bstride, out_tstride, gates, w_hh, dhn, dgi_all, dgh_shift,
+                                dgh_first, dhbuf, dgh_tmp, B, T, H, reverse);
+}
+int a2s_staff_emb_bwd(void* stream, const float* note_emb, const float* const* gru_w, float* const* grads, float* note_emb_grad,
+                      const long long* ids64, const int* ids32, long id_bstride, const long long* lengths, long len_stride,
+                      const float* dout, long lddo, int col0, const float* hsave, int R, int maxlen, int E, int S) {
+    if (!gru_w) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "staff_emb_bwd: null weight table"); return A2S_ERR_ARG; }
+    return a2s_staff_emb_bwd_impl(ST, note_emb, gru_w, grads, note_emb_grad, ids64, ids32, id_bstride, lengths, len_stride, dout, lddo,
+                                  col0, hsave, R, maxlen, E, S);
+}
+
+int a2s_bn_bwd(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+               const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx, float* partial, float* c12, long rows, int C, int F) {
+    return a2s_bn_bwd_impl(ST, g, x, mean, invstd, scale, shift, keep_mask, inv_keep, dgamma, dbeta, dx, partial, c12, rows, C, F);
+}
+size_t a2s_bn_bwd_partial_floats(long rows, int C, int F) { return a2s_bn_bwd_partial_floats_impl(rows, C, F); }
+int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
+                      size_t workspace_bytes, int B, int T, int F, int Cin, int Cout) {
+    return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout);
+}
+size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) { return a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout); }
 
 }  // extern "C"

@@ -1,0 +1,424 @@
+// Backward kernels of the sequential part of the hot path + the reverse step loops (no Python per step).
+// Gradient flow follows what torch.autograd does for the reference graph (models.py:191-420): argmax-selected
+// tokens are constants (only their embedding rows receive gradient), log_softmax rows that were never decoded
+// receive nothing, attention keys are hoisted so dK/dEnc contributions of all steps are accumulated once per
+// (bar, staff) instead of once per step.
+#include "a2s_common.h"
+#include "../../include/a2s.h"
+
+int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
+                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes);
+
+// ------------------------------------------------------------------------------------------- log_softmax bwd
+// y = log_softmax(x) row-wise; given g = dL/dy and y: dx = g - exp(y) * sum_j g_j.
+// Row r of g / y lives at base + (r / inner) * outer_stride + (r % inner) * V  (covers (B,5,U,V)[:,bar,:steps]
+// with r = b*steps + s as well as plain matrices); dx is written TIME-MAJOR: row (s*B + b) when time_major.
+__global__ __launch_bounds__(256) void log_softmax_bwd_rows(const float* __restrict__ g, const float* __restrict__ y,
+                                                            long outer_stride, int inner, float* __restrict__ dx,
+                                                            int R, int V, int n_outer, int time_major) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const int ob = row / inner, in = row % inner;
+    const float* gr = g + (long)ob * outer_stride + (long)in * V;
+    const float* yr = y + (long)ob * outer_stride + (long)in * V;
+    float s = 0.f;
+    for (int j = lane; j < V; j += 64) s += gr[j];
+    s = wave_sum(s);
+    const long orow = time_major ? ((long)in * n_outer + ob) : row;
+    for (int j = lane; j < V; j += 64) dx[orow * V + j] = gr[j] - expf(yr[j]) * s;
+}
+
+int a2s_log_softmax_bwd_rows_impl(hipStream_t st, const float* g, const float* y, long outer_stride, int inner, float* dx,
+                                  int R, int V, int n_outer, int time_major) {
+    hipLaunchKernelGGL(log_softmax_bwd_rows, dim3(a2s_cdiv(R, 4)), dim3(256), 0, st, g, y, outer_stride, inner, dx, R, V, n_outer, time_major);
+    A2S_CHECK_LAUNCH("log_softmax_bwd_rows");
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- GRU cell bwd
+// saved = [r | z | n | gh_n] per row (4H).  dh: grad wrt the cell output (dh = dh_a + dh_b, dh_b optional).
+//   dn = dh (1-z)(1-n^2) ; dz = dh (hprev - n) z(1-z) ; dr = dn gh_n r(1-r)
+//   dgi = [dr, dz, dn] ; dgh = [dr, dz, dn*r] ; dh_prev_direct = dh*z
+__global__ void gru_gates_bwd(const float* __restrict__ dh_a, long lda, const float* __restrict__ dh_b, long ldb,
+                              const float* __restrict__ save, const float* __restrict__ hprev, long ldhp,
+                              float* __restrict__ dgi, long ldgi, float* __restrict__ dgh, long ldgh,
+                              float* __restrict__ dgh2, long ldgh2, float* __restrict__ dhprev, long lddp, int R, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)R * H) return;
+    const int r_ = (int)(idx / H), j = (int)(idx % H);
+    const float* s = save + (long)r_ * 4 * H;
+    const float rg = s[j], zg = s[H + j], ng = s[2 * H + j], ghn = s[3 * H + j];
+    float dh = dh_a[(long)r_ * lda + j];
+    if (dh_b) dh += dh_b[(long)r_ * ldb + j];
+    const float hp = hprev ? hprev[(long)r_ * ldhp + j] : 0.f;
+    const float dn = dh * (1.f - zg) * (1.f - ng * ng);
+    const float dz = dh * (hp - ng) * zg * (1.f - zg);
+    const float dr = dn * ghn * rg * (1.f - rg);
+    float* a = dgi + (long)r_ * ldgi;
+    a[j] = dr; a[H + j] = dz; a[2 * H + j] = dn;
+    float* b = dgh + (long)r_ * ldgh;
+    b[j] = dr; b[H + j] = dz; b[2 * H + j] = dn * rg;
+    if (dgh2) { float* c = dgh2 + (long)r_ * ldgh2; c[j] = dr; c[H + j] = dz; c[2 * H + j] = dn * rg; }
+    dhprev[(long)r_ * lddp + j] = dh * zg;
+}
+
+int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const float* dh_b, long ldb, const float* save,
+                           const float* hprev, long ldhp, float* dgi, long ldgi, float* dgh, long ldgh, float* dgh2, long ldgh2,
+                           float* dhprev, long lddp, int R, int H) {
+    hipLaunchKernelGGL(gru_gates_bwd, dim3(a2s_cdiv((long)R * H, 256)), dim3(256), 0, st, dh_a, lda, dh_b, ldb, save, hprev, ldhp,
+                       dgi, ldgi, dgh, ldgh, dgh2, ldgh2, dhprev, lddp, R, H);
+    A2S_CHECK_LAUNCH("gru_gates_bwd");
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- attention bwd (per step)
+// Given dctx (= dctx_a + dctx_b) for one step:  da_t = dctx . enc_t ; ds_t = a_t (da_t - dctx . ctx)   [softmax bwd,
+// sum_t a_t da_t = dctx . ctx];  dq_j = sum_t ds_t v_j (1 - e_tj^2), e = tanh(K_tj + q_j).
+// Writes dq (for the W_h / hidden gradient), ds (T per row, for the deferred dK / dv) and the summed dctx.
+template <int H>
+__global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                     const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                     const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
+                                                     const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
+                                                     float* __restrict__ dctx_out, long lddo, float* __restrict__ dq, long lddq,
+                                                     float* __restrict__ ds_out, int T) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dsv = sm;                               // T
+    float* dc = sm + ((T + 3) & ~3);               // 2H
+    float* red = dc + 2 * H;                       // 16
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Kb = Kmat + (long)b * T * H;
+    const float* Eb = enc + (long)b * T * 2 * H;
+    float part = 0.f;
+    for (int d = tid; d < 2 * H; d += 256) {
+        float g = dctx_a[(long)b * ldda + d];
+        if (dctx_b) g += dctx_b[(long)b * lddb + d];
+        dc[d] = g;
+        if (dctx_out) dctx_out[(long)b * lddo + d] = g;
+        part += g * ctx[(long)b * ldctx + d];
+    }
+    const float dot_ctx = block_sum(part, red);    // also orders the dc[] writes before the reads below
+    // pass over enc: one wave per frame, 2H/64 elements per lane
+    for (int t = wave; t < T; t += 4) {
+        float s = 0.f;
+        for (int d = lane; d < 2 * H; d += 64) s = fmaf(dc[d], Eb[(long)t * 2 * H + d], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float d_s = attw[(long)b * T + t] * (s - dot_ctx);
+            dsv[t] = d_s;
+            if (ds_out) ds_out[(long)b * T + t] = d_s;
+        }
+    }
+    __syncthreads();
+    // pass over K: thread j accumulates dq_j over all frames (H <= 256 threads active)
+    if (tid < H) {
+        const float qj = q[(long)b * ldq + tid], vj = v[tid];
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float e = fast_tanh(Kb[(long)t * H + tid] + qj);
+            acc = fmaf(dsv[t], 1.f - e * e, acc);
+        }
+        dq[(long)b * lddq + tid] = acc * vj;
+    }
+}
+
+int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                           const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
+                           long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H) {
+    const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
+    if (H == 256) hipLaunchKernelGGL(attn_step_bwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
+    else if (H == 32) hipLaunchKernelGGL(attn_step_bwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
+    else A2S_FAIL(A2S_ERR_ARG, "attn_step_bwd: hidden_size must be 256 or 32 (got %d)", H);
+    A2S_CHECK_LAUNCH("attn_step_bwd");
+    return A2S_OK;
+}
+
+// Deferred key / v gradients of one (bar, staff): for every (b, t, j)
+//   dK[b,t,j] += v_j * sum_s ds[s,b,t] (1 - e^2),  dv_j += sum_{s,b,t} ds[s,b,t] e,   e = tanh(K[b,t,j] + q[s,b,j]).
+// One workgroup per (b, tile of 16 frames); thread j keeps K[t,j] for its 16 frames in registers and streams the
+// S queries -- K is read once, traffic is S*(H + 16) floats per workgroup.  dv partials: [nblocks][H].
+template <int H>
+__global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ Kmat, const float* __restrict__ q_all,
+                                                     const float* __restrict__ ds_all, const float* __restrict__ v,
+                                                     float* __restrict__ dK, float* __restrict__ dv_partial, int B, int T, int S) {
+    constexpr int TT = 16;
+    const int tiles = (T + TT - 1) / TT;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * TT;
+    const int j = threadIdx.x;
+    __shared__ float dss[TT];
+    float kreg[TT], acc[TT];
+    float dvj = 0.f;
+    if (j < H) {
+#pragma unroll
+        for (int i = 0; i < TT; ++i) { kreg[i] = (t0 + i < T) ? Kmat[((long)b * T + t0 + i) * H + j] : 0.f; acc[i] = 0.f; }
+    }
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();
+        if (threadIdx.x < TT) dss[threadIdx.x] = (t0 + threadIdx.x < T) ? ds_all[((long)s * B + b) * T + t0 + threadIdx.x] : 0.f;
+        __syncthreads();
+        if (j < H) {
+            const float qj = q_all[((long)s * B + b) * H + j];
+#pragma unroll
+            for (int i = 0; i < TT; ++i) {
+                const float e = fast_tanh(kreg[i] + qj);
+                acc[i] = fmaf(dss[i], 1.f - e * e, acc[i]);
+                dvj = fmaf(dss[i], e, dvj);
+            }
+        }
+    }
+    if (j < H) {
+        const float vj = v[j];
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+            if (t0 + i < T) dK[((long)b * T + t0 + i) * H + j] += vj * acc[i];
+        dv_partial[(long)blockIdx.x * H + j] = dvj;
+    }
+}
+
+int a2s_attn_dk_accum_impl(hipStream_t st, const float* Kmat, const float* q_all, const float* ds_all, const float* v,
+                           float* dK, float* dv_partial, int B, int T, int S, int H) {
+    const int nblk = B * a2s_cdiv(T, 16);
+    if (H == 256) hipLaunchKernelGGL(attn_dk_accum<256>, dim3(nblk), dim3(256), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S);
+    else if (H == 32) hipLaunchKernelGGL(attn_dk_accum<32>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S);
+    else A2S_FAIL(A2S_ERR_ARG, "attn_dk_accum: hidden_size must be 256 or 32 (got %d)", H);
+    A2S_CHECK_LAUNCH("attn_dk_accum");
+    return A2S_OK;
+}
+
+// out[c] (+)= alpha * sum_r x[r*ld + c]   -- bias gradients / reduction of partial slabs, fixed order per column.
+__global__ __launch_bounds__(256) void col_sum(const float* __restrict__ x, long ld, float* __restrict__ out, long rows, int C,
+                                               float alpha, float beta) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;          // 4 row-partitions per column block
+    __shared__ float red[4][64];
+    float s = 0.f;
+    if (c < C) for (long r = part; r < rows; r += 4) s += x[r * ld + c];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[c] = alpha * t + (beta != 0.f ? beta * out[c] : 0.f);
+    }
+}
+
+int a2s_col_sum_impl(hipStream_t st, const float* x, long ld, float* out, long rows, int C, float alpha, float beta) {
+    hipLaunchKernelGGL(col_sum, dim3(a2s_cdiv(C, 64)), dim3(256), 0, st, x, ld, out, rows, C, alpha, beta);
+    A2S_CHECK_LAUNCH("col_sum");
+    return A2S_OK;
+}
+
+// table_grad[id[r]][j] += g[r*ldg + col0 + j] * (keep mask) -- embedding gradient (atomic: duplicate ids collide).
+__global__ void embed_scatter_add(float* __restrict__ table_grad, const long long* __restrict__ ids64, const int* __restrict__ ids32,
+                                  long id_stride, int const_id, const float* __restrict__ g, long ldg, int col0, int R, int E,
+                                  const uint8_t* __restrict__ drop, float inv_keep) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)R * E) return;
+    const int r = (int)(idx / E), j = (int)(idx % E);
+    const long id = ids64 ? ids64[(long)r * id_stride] : (ids32 ? ids32[(long)r * id_stride] : const_id);
+    float v = g[(long)r * ldg + col0 + j];
+    if (drop) v = drop[idx] ? v * inv_keep : 0.f;
+    atomicAdd(table_grad + id * E + j, v);
+}
+
+int a2s_embed_scatter_add_impl(hipStream_t st, float* table_grad, const long long* ids64, const int* ids32, long id_stride,
+                               int const_id, const float* g, long ldg, int col0, int R, int E, const uint8_t* drop, float inv_keep) {
+    hipLaunchKernelGGL(embed_scatter_add, dim3(a2s_cdiv((long)R * E, 256)), dim3(256), 0, st, table_grad, ids64, ids32, id_stride,
+                       const_id, g, ldg, col0, R, E, drop, inv_keep);
+    A2S_CHECK_LAUNCH("embed_scatter_add");
+    return A2S_OK;
+}
+
+// elementwise helpers: dx = g * (1 - y^2) (tanh) / dx = g * [y > 0] (relu); optional in-place (dx == g)
+__global__ void ew_act_bwd(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ dx, long n, int act) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float yy = y[i];
+        dx[i] = act == 2 ? g[i] * (1.f - yy * yy) : (yy > 0.f ? g[i] : 0.f);
+    }
+}
+int a2s_ew_act_bwd_impl(hipStream_t st, const float* g, const float* y, float* dx, long n, int act) {
+    hipLaunchKernelGGL(ew_act_bwd, dim3(min((long)2048, (n + 255) / 256)), dim3(256), 0, st, g, y, dx, n, act);
+    A2S_CHECK_LAUNCH("ew_act_bwd");
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- note decoder reverse loop
+// Reverse of a2s_note_decoder_fwd for one (bar, staff); `steps` = steps the forward executed.
+// argument block: a2s_note_dec_bwd_args (single definition in include/a2s.h)
+
+int a2s_attn_step_bwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, const float*, const float*, long,
+                           const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int);
+
+int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    hipError_t e = hipMemsetAsync(a.dh, 0, sizeof(float) * 2 * R * H2, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd memset: %s", hipGetErrorString(e));
+    int cur = 0;
+    for (int s = a.steps - 1; s >= 0; --s) {
+        float* dh_in = a.dh + (long)cur * R * H2;
+        float* dh_out = a.dh + (long)(cur ^ 1) * R * H2;
+        const float* dos = a.do_all + (long)s * R * 2 * H2;
+        float* dgi = a.dgi_all + (long)s * R * 3 * H2;
+        float* dgh = a.dgh_all + (long)s * R * 3 * H2;
+        float* dxs = a.dx + (long)s * R * ldx;
+        int rc;
+        // GRU cell: dh = carry + dh_from_out;  hprev = h[s]
+        rc = a2s_gru_gates_bwd_impl(st, dh_in, H2, dos, 2 * H2, a.gates + (long)s * R * 4 * H2, a.h + (long)s * R * H2, H2,
+                                    dgi, 3 * H2, dgh, 3 * H2, nullptr, 0, dh_out, H2, R, H2);
+        if (rc) return rc;
+        // dx = dgi W_ih   (R x ldx): [dtok | dctx_from_gru]
+        rc = a2s_gemm_impl(st, R, ldx, 3 * H2, 1.f, dgi, 3 * H2, 1, a.w_ih, ldx, 1, 0.f, dxs, ldx, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        // attention: dctx = dx[:, E:] + do[:, 2H:]
+        rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
+                                    a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
+                                    a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
+                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H);
+        if (rc) return rc;
+        // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
+        rc = a2s_gemm_impl(st, R, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        rc = a2s_gemm_impl(st, R, H2, a.H, 1.f, a.dq_all + (long)s * R * a.H, a.H, 1, a.attn_w, 2 * H2, 1, 1.f, dh_out, H2, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    if (cur != 0) {   // leave the final carry in dh[0]
+        e = hipMemcpyAsync(a.dh, a.dh + (long)R * H2, sizeof(float) * R * H2, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd copy: %s", hipGetErrorString(e));
+    }
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- encoder GRU BPTT
+// Reverse of a2s_gru_seq_fwd for one direction.  dout: (B,T,*) gradient wrt this direction's outputs (column
+// offset already applied); out: the forward outputs (hprev source); dhn: gradient wrt the final state.
+//   dgi_all (B,T,3H) <- per-step input-projection gradients (caller: dW_ih, db_ih, dX via GEMMs)
+//   dgh_shift (B,T,3H) <- dgh of the step whose h_prev is out[:,t]  (row (b,t) pairs with out[b,t]: dW_hh = dgh_shift^T out)
+//   dgh_first (B,3H)   <- dgh of the first processed step (h_prev = 0): only contributes to db_hh
+int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride,
+                         long out_tstride, const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift,
+                         float* dgh_first, float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse) {
+    A2S_REQUIRE(dout && out && gates && w_hh && dgi_all && dgh_shift && dgh_first && dhbuf && dgh_tmp, "gru_seq_bwd: null tensor");
+    hipError_t e;
+    if (dhn) e = hipMemcpyAsync(dhbuf, dhn, sizeof(float) * B * H, hipMemcpyDeviceToDevice, st);
+    else e = hipMemsetAsync(dhbuf, 0, sizeof(float) * B * H, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gru_seq_bwd init: %s", hipGetErrorString(e));
+    e = hipMemsetAsync(dgh_shift, 0, sizeof(float) * (size_t)B * T * 3 * H, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gru_seq_bwd memset: %s", hipGetErrorString(e));
+    int cur = 0;
+    for (int s = T - 1; s >= 0; --s) {                 // s = processing index of the forward pass
+        const int t = reverse ? T - 1 - s : s;          // time index of this step
+        const int tp = reverse ? t + 1 : t - 1;         // time index whose output was h_prev (invalid when s == 0)
+        float* dh_in = dhbuf + (long)cur * B * H;
+        float* dh_out = dhbuf + (long)(cur ^ 1) * B * H;
+        float* dgh = (s == 0) ? dgh_first : dgh_tmp;
+        int rc = a2s_gru_gates_bwd_impl(st, dh_in, H, dout + (long)t * do_tstride, do_bstride, gates + (long)t * B * 4 * H,
+                                        s == 0 ? nullptr : out + (long)tp * out_tstride, out_bstride,
+                                        dgi_all + (long)t * 3 * H, (long)T * 3 * H, dgh, 3 * H,
+                                        s == 0 ? nullptr : dgh_shift + (long)tp * 3 * H, (long)T * 3 * H, dh_out, H, B, H);
+        if (rc) return rc;
+        if (s > 0) {   // dh_prev += dgh W_hh
+            rc = a2s_gemm_impl(st, B, H, 3 * H, 1.f, dgh, 3 * H, 1, w_hh, H, 1, 1.f, dh_out, H, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0);
+            if (rc) return rc;
+        }
+        cur ^= 1;
+    }
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- staff embedding bwd
+// BPTT of staff_emb_fwd for one (row, direction) per workgroup; hsave[(b*2+dir)*maxlen + s] = h after processing
+// step s.  Weight gradients are accumulated per workgroup in LDS and added atomically once at the end; the
+// embedding-table gradient is added atomically per step (duplicate ids).
+__global__ __launch_bounds__(128) void staff_emb_bwd(const float* __restrict__ note_emb, const float* __restrict__ w_ih_f,
+                                                     const float* __restrict__ w_hh_f, const float* __restrict__ b_ih_f,
+                                                     const float* __restrict__ b_hh_f, const float* __restrict__ w_ih_r,
+                                                     const float* __restrict__ w_hh_r, const float* __restrict__ b_ih_r,
+                                                     const float* __restrict__ b_hh_r, float* const* __restrict__ grads /* 8 */,
+                                                     float* __restrict__ note_emb_grad, const long long* __restrict__ ids64,
+                                                     const int* __restrict__ ids32, long id_bstride, const long long* __restrict__ lengths,
+                                                     long len_stride, const float* __restrict__ dout, long lddo, int col0,
+                                                     const float* __restrict__ hsave, int maxlen, int E, int S) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const float* w_ih = dir ? w_ih_r : w_ih_f; const float* w_hh = dir ? w_hh_r : w_hh_f;
+    const float* b_ih = dir ? b_ih_r : b_ih_f; const float* b_hh = dir ? b_hh_r : b_hh_f;
+    float* Wi = sm;                         // 3S*E
+    float* Wh = Wi + 3 * S * E;             // 3S*S
+    float* gWi = Wh + 3 * S * S;            // 3S*E
+    float* gWh = gWi + 3 * S * E;           // 3S*S
+    float* gbi = gWh + 3 * S * S;           // 3S
+    float* gbh = gbi + 3 * S;               // 3S
+    float* bi = gbh + 3 * S; float* bh = bi + 3 * S;
+    float* xe = bh + 3 * S;                 // E
+    float* hp = xe + E;                     // S   h_prev
+    float* g = hp + S;                      // 6S  gi | gh
+    float* dgi = g + 6 * S;                 // 3S
+    float* dgh = dgi + 3 * S;               // 3S
+    float* dh = dgh + 3 * S;                // S
+    for (int i = tid; i < 3 * S * E; i += nt) { Wi[i] = w_ih[i]; gWi[i] = 0.f; }
+    for (int i = tid; i < 3 * S * S; i += nt) { Wh[i] = w_hh[i]; gWh[i] = 0.f; }
+    for (int i = tid; i < 3 * S; i += nt) { bi[i] = b_ih[i]; bh[i] = b_hh[i]; gbi[i] = 0.f; gbh[i] = 0.f; }
+    for (int i = tid; i < S; i += nt) dh[i] = dout[(long)b * lddo + col0 + dir * S + i];
+    int len = (int)lengths[(long)b * len_stride];
+    len = max(0, min(len, maxlen));
+    __syncthreads();
+    for (int s = len - 1; s >= 0; --s) {
+        const int t = dir ? len - 1 - s : s;
+        const long id = ids64 ? ids64[(long)b * id_bstride + t] : ids32[(long)b * id_bstride + t];
+        for (int i = tid; i < E; i += nt) xe[i] = note_emb[id * E + i];
+        for (int i = tid; i < S; i += nt) hp[i] = s > 0 ? hsave[(((long)b * 2 + dir) * maxlen + s - 1) * S + i] : 0.f;
+        __syncthreads();
+        for (int r = tid; r < 6 * S; r += nt) {          // recompute the pre-activations of this step
+            float acc;
+            if (r < 3 * S) { acc = bi[r]; for (int k = 0; k < E; ++k) acc = fmaf(Wi[r * E + k], xe[k], acc); }
+            else { const int rr = r - 3 * S; acc = bh[rr]; for (int k = 0; k < S; ++k) acc = fmaf(Wh[rr * S + k], hp[k], acc); }
+            g[r] = acc;
+        }
+        __syncthreads();
+        if (tid < S) {
+            const float rg = fast_sigmoid(g[tid] + g[3 * S + tid]);
+            const float zg = fast_sigmoid(g[S + tid] + g[4 * S + tid]);
+            const float ghn = g[5 * S + tid];
+            const float ng = fast_tanh(g[2 * S + tid] + rg * ghn);
+            const float d = dh[tid];
+            const float dn = d * (1.f - zg) * (1.f - ng * ng);
+            const float dz = d * (hp[tid] - ng) * zg * (1.f - zg);
+            const float dr = dn * ghn * rg * (1.f - rg);
+            dgi[tid] = dr; dgi[S + tid] = dz; dgi[2 * S + tid] = dn;
+            dgh[tid] = dr; dgh[S + tid] = dz; dgh[2 * S + tid] = dn * rg;
+            dh[tid] = d * zg;                              // direct path; recurrent path added below
+        }
+        __syncthreads();
+        for (int i = tid; i < 3 * S * E; i += nt) gWi[i] = fmaf(dgi[i / E], xe[i % E], gWi[i]);
+        for (int i = tid; i < 3 * S * S; i += nt) gWh[i] = fmaf(dgh[i / S], hp[i % S], gWh[i]);
+        for (int i = tid; i < 3 * S; i += nt) { gbi[i] += dgi[i]; gbh[i] += dgh[i]; }
+        for (int k = tid; k < E; k += nt) {                // dx -> embedding row of this token
+            float acc = 0.f;
+            for (int r = 0; r < 3 * S; ++r) acc = fmaf(dgi[r], Wi[r * E + k], acc);
+            atomicAdd(note_emb_grad + id * E + k, acc);
+        }
+        float add = 0.f;
+        if (tid < S) for (int r = 0; r < 3 * S; ++r) add = fmaf(dgh[r], Wh[r * S + tid], add);
+        __syncthreads();
+        if (tid < S) dh[tid] += add;
+        __syncthreads();
+    }
+    float* gwi = grads[dir * 4 + 0]; float* gwh = grads[dir * 4 + 1]; float* gb1 = grads[dir * 4 + 2]; float* gb2 = grads[dir * 4 + 3];
+    for (int i = tid; i < 3 * S * E; i += nt) atomicAdd(gwi + i, gWi[i]);
+    for (int i = tid; i < 3 * S * S; i += nt) atomicAdd(gwh + i, gWh[i]);
+    for (int i = tid; i < 3 * S; i += nt) { atomicAdd(gb1 + i, gbi[i]); atomicAdd(gb2 + i, gbh[i]); }
+}
+
+int a2s_staff_emb_bwd_impl(hipStream_t st, const float* note_emb, const float* const* w, float* const* grads_dev, float* note_emb_grad,
+                           const long long* ids64, const int* ids32, long id_bstride, const long long* lengths, long len_stride,
+                           const float* dout, long lddo, int col0, const float* hsave, int R, int maxlen, int E, int S) {
+    A2S_REQUIRE((ids64 != nullptr) != (ids32 != nullptr), "staff_emb_bwd: exactly one of ids64/ids32");
+    A2S_REQUIRE(hsave && grads_dev && note_emb_grad && dout, "staff_emb_bwd: null tensor");
+    const size_t shm = sizeof(float) * (2 * (3 * S * E + 3 * S * S) + 4 * 3 * S + E + S + 6 * S + 6 * S + S);
+    hipLaunchKernelGGL(staff_emb_bwd, dim3(R, 2), dim3(128), shm, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
+                       grads_dev, note_emb_grad, ids64, ids32, id_bstride, lengths, len_stride, dout, lddo, col0, hsave, maxlen, E, S);
+    A2S_CHECK_LAUNCH("staff_emb_bwd");
+    return A2S_OK;
+}

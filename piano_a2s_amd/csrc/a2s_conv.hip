@@ -332,3 +332,251 @@ int a2s_bn1d_relu_dropout_impl(hipStream_t st, const float* x, float* y, const f
     A2S_CHECK_LAUNCH("bn1d_relu_dropout");
     return A2S_OK;
 }
+
+// =========================================================================================== backward
+// BatchNorm (+ReLU, + optional dropout) backward in three steps, with y = x*scale + shift, xh = (x-mean)*invstd:
+//   g' = g * [y > 0] (* keep*inv_keep);  s1 = sum g', s2 = sum g' xh  (per channel, fixed-order reduction);
+//   dbeta += s1, dgamma += s2;  dx = gamma*invstd * (g' - s1/N - xh * s2/N).
+// Plane layout (rows, C, F): block = one row, wave per channel plane.  Matrix layout (rows, C): see *_cols.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_planes(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ partial, int C, int F) {
+    const long row = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C; c += 4) {
+        const float* gp = g + (row * C + c) * F;
+        const float* xp = x + (row * C + c) * F;
+        const float m = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+        float s1 = 0.f, s2 = 0.f;
+        for (int f = lane; f < F; f += 64) {
+            const float xv = xp[f];
+            const float gv = (xv * sc + sh > 0.f) ? gp[f] : 0.f;
+            s1 += gv; s2 += gv * (xv - m) * is;
+        }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { partial[(row * C + c) * 2 + 0] = s1; partial[(row * C + c) * 2 + 1] = s2; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_cols(const float* __restrict__ g, const float* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const uint8_t* __restrict__ mask, float inv_keep,
+                                                          float* __restrict__ partial, long rows, int C, int rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float m = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+        float s1 = 0.f, s2 = 0.f;
+        for (long r = r0; r < r1; ++r) {
+            const float xv = x[r * C + c];
+            float gv = (xv * sc + sh > 0.f) ? g[r * C + c] : 0.f;
+            if (mask) gv = mask[r * C + c] ? gv * inv_keep : 0.f;
+            s1 += gv; s2 += gv * (xv - m) * is;
+        }
+        partial[((long)blockIdx.x * C + c) * 2 + 0] = s1;
+        partial[((long)blockIdx.x * C + c) * 2 + 1] = s2;
+    }
+}
+
+// one block per channel: fixed-order double reduction of the partials -> dgamma/dbeta (+=) and c1 = s1/N, c2 = s2/N
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ partial, int nblocks, int C, double count,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ c12) {
+    const int c = blockIdx.x;
+    __shared__ double r1[256], r2[256];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        s1 += (double)partial[((long)i * C + c) * 2 + 0];
+        s2 += (double)partial[((long)i * C + c) * 2 + 1];
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dbeta[c] += (float)r1[0];
+        dgamma[c] += (float)r2[0];
+        c12[2 * c + 0] = (float)(r1[0] / count);
+        c12[2 * c + 1] = (float)(r2[0] / count);
+    }
+}
+
+// dx = scale_c * (g' - c1 - xh*c2), element i has channel (i / F) % C; may run in place (dx == g)
+__global__ void bn_bwd_apply(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean,
+                             const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+                             const float* __restrict__ c12, const uint8_t* __restrict__ mask, float inv_keep,
+                             float* __restrict__ dx, long n, int C, int F) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = (int)((i / F) % C);
+        const float xv = x[i];
+        float gv = (xv * scale[c] + shift[c] > 0.f) ? g[i] : 0.f;
+        if (mask) gv = mask[i] ? gv * inv_keep : 0.f;
+        dx[i] = scale[c] * (gv - c12[2 * c] - (xv - mean[c]) * invstd[c] * c12[2 * c + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- conv weight gradient
+// dW[co][ci][tap] += sum_{b,t,f} dy[b,t,co,f] * in[b, t+dt-1, ci, f+df-1],  in = relu(x*scale+shift) (or x).
+// GEMM view on v_mfma_f32_16x16x4_f32: M = co, N = (ci_local, tap) of one 20-channel chunk (blockIdx.y), K = positions
+// (4 consecutive f per MFMA).  gridDim.x persistent workgroups walk the (b, 4-row strip, 32-column) tiles; each writes
+// ONE partial slab [Cout][180]; wgrad_reduce sums the slabs in fixed order (deterministic).
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                     float* __restrict__ partial, int B, int T, int F, int Cin) {
+    constexpr int MT = (COUT + 15) / 16;
+    constexpr int NTW = 3;                               // n-tiles per wave: 4 waves x 3 x 16 = 192 >= 180
+    constexpr int DRS = CV_FT + 4;                       // dy row stride in LDS
+    __shared__ __attribute__((aligned(16))) float lin[CV_CK * CV_PLANE];
+    __shared__ __attribute__((aligned(16))) float ldy[MT * 16 * CV_TR * DRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int c0 = blockIdx.y * CV_CK;
+    const int tilesF = (F + CV_FT - 1) / CV_FT, tilesT = (T + CV_TR - 1) / CV_TR;
+    const long ntiles = (long)B * tilesT * tilesF;
+
+    int boff[NTW];                                       // LDS offset of this lane's (ci, dt, df) column per n-tile
+    bool bok[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = (wave * NTW + j) * 16 + li;
+        bok[j] = n < CV_CK * 9 && (c0 + n / 9) < Cin;
+        const int c = n / 9, tap = n % 9;
+        boff[j] = bok[j] ? c * CV_PLANE + (tap / 3) * CV_RS + (tap % 3) : 0;
+    }
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long bid = tile;
+        const int ft = (int)(bid % tilesF); bid /= tilesF;
+        const int tt = (int)(bid % tilesT); const int b = (int)(bid / tilesT);
+        const int t0 = tt * CV_TR, f0 = ft * CV_FT;
+        __syncthreads();
+        for (int e = tid; e < CV_CK * (CV_TR + 2) * (CV_FT + 2); e += 256) {
+            const int fc = e % (CV_FT + 2);
+            const int r = (e / (CV_FT + 2)) % (CV_TR + 2);
+            const int c = e / ((CV_FT + 2) * (CV_TR + 2));
+            const int t = t0 + r - 1, f = f0 + fc - 1, ci = c0 + c;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F && ci < Cin) {
+                v = x[(((long)b * T + t) * Cin + ci) * F + f];
+                if (in_scale) v = fmaxf(v * in_scale[ci] + in_shift[ci], 0.f);
+            }
+            lin[c * CV_PLANE + r * CV_RS + fc] = v;
+        }
+        for (int e = tid; e < MT * 16 * CV_TR * CV_FT; e += 256) {
+            const int fc = e % CV_FT;
+            const int r = (e / CV_FT) % CV_TR;
+            const int co = e / (CV_FT * CV_TR);
+            const int t = t0 + r, f = f0 + fc;
+            float v = 0.f;
+            if (co < COUT && t < T && f < F) v = dy[(((long)b * T + t) * COUT + co) * F + f];
+            ldy[(co * CV_TR + r) * DRS + fc] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CV_TR; ++r) {
+#pragma unroll
+            for (int ks = 0; ks < CV_FT / 4; ++ks) {
+                float a[MT], bv[NTW];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = ldy[((i * 16 + li) * CV_TR + r) * DRS + ks * 4 + lk];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) bv[j] = bok[j] ? lin[boff[j] + r * CV_RS + ks * 4 + lk] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = co (lk*4+r)][col = n (li)]
+    float* slab = partial + ((long)blockIdx.y * gridDim.x + blockIdx.x) * COUT * (CV_CK * 9);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = (wave * NTW + j) * 16 + li;
+            if (n >= CV_CK * 9) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = i * 16 + lk * 4 + r;
+                if (co < COUT) slab[(long)co * (CV_CK * 9) + n] = acc[i][j][r];
+            }
+        }
+}
+
+// dW[co][c0+ci][tap] += sum over slabs (fixed order)
+__global__ void wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dW, int nslabs, int Cout, int Cin, int chunks) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = Cout * CV_CK * 9;
+    if (idx >= per * chunks) return;
+    const int chunk = idx / per, rem = idx % per;
+    const int co = rem / (CV_CK * 9), n = rem % (CV_CK * 9);
+    const int ci = chunk * CV_CK + n / 9, tap = n % 9;
+    if (ci >= Cin) return;
+    const float* p = partial + (long)chunk * nslabs * per + rem;
+    float s = 0.f;
+    for (int i = 0; i < nslabs; ++i) s += p[(long)i * per];
+    dW[((long)co * Cin + ci) * 9 + tap] += s;
+}
+
+#define WGRAD_SLABS 512
+
+size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
+    const int chunks = (Cin + CV_CK - 1) / CV_CK;
+    return (size_t)chunks * WGRAD_SLABS * Cout * CV_CK * 9 * sizeof(float);
+}
+
+int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
+                           float* ws, size_t ws_bytes, int B, int T, int F, int Cin, int Cout) {
+    A2S_REQUIRE(dy && x && dW && ws, "conv3x3_wgrad: null tensor");
+    A2S_REQUIRE(ws_bytes >= a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout), "conv3x3_wgrad: workspace too small");
+    const int chunks = (Cin + CV_CK - 1) / CV_CK;
+    dim3 grid(WGRAD_SLABS, chunks);
+    if (Cout == 20) hipLaunchKernelGGL(conv3x3_wgrad<20>, grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
+    else if (Cout == 40) hipLaunchKernelGGL(conv3x3_wgrad<40>, grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
+    else A2S_FAIL(A2S_ERR_ARG, "conv3x3_wgrad: Cout must be 20 or 40 (got %d)", Cout);
+    A2S_CHECK_LAUNCH("conv3x3_wgrad");
+    const int n = Cout * CV_CK * 9 * chunks;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(a2s_cdiv(n, 256)), dim3(256), 0, st, ws, dW, WGRAD_SLABS, Cout, Cin, chunks);
+    A2S_CHECK_LAUNCH("wgrad_reduce");
+    return A2S_OK;
+}
+
+int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+                    const float* shift, const uint8_t* mask, float inv_keep, float* dgamma, float* dbeta, float* dx, float* partial,
+                    float* c12, long rows, int C, int F) {
+    A2S_REQUIRE(g && x && mean && invstd && scale && shift && dgamma && dbeta && dx && partial && c12, "bn_bwd: null tensor");
+    int nblocks;
+    if (F > 1) {
+        A2S_REQUIRE(!mask, "bn_bwd: dropout mask only supported on the (rows, C) layout");
+        nblocks = (int)rows;
+        hipLaunchKernelGGL(bn_bwd_reduce_planes, dim3(nblocks), dim3(256), 0, st, g, x, mean, invstd, scale, shift, partial, C, F);
+    } else {
+        const int rpb = 64;
+        nblocks = a2s_cdiv(rows, rpb);
+        hipLaunchKernelGGL(bn_bwd_reduce_cols, dim3(nblocks), dim3(256), 0, st, g, x, mean, invstd, scale, shift, mask, inv_keep, partial, rows, C, rpb);
+    }
+    A2S_CHECK_LAUNCH("bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, st, partial, nblocks, C, (double)rows * F, dgamma, dbeta, c12);
+    A2S_CHECK_LAUNCH("bn_bwd_finalize");
+    const long n = rows * C * F;
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, mask,
+                       inv_keep, dx, n, C, F);
+    A2S_CHECK_LAUNCH("bn_bwd_apply");
+    return A2S_OK;
+}
+
+size_t a2s_bn_bwd_partial_floats_impl(long rows, int C, int F) {
+    const long nblocks = F > 1 ? rows : (rows + 63) / 64;
+    return (size_t)nblocks * C * 2;
+}

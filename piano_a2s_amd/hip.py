@@ -37,7 +37,8 @@ def lib():
                            "There is no CPU fallback for the transcription hot path.")
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
-        _lib.a2s_gemm_workspace_bytes.restype = C.c_size_t
+        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes"):
+            getattr(_lib, fn).restype = C.c_size_t
     return _lib
 
 

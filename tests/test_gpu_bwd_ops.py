@@ -1,0 +1,307 @@
+"""Per-kernel parity of the backward kernels on the MI355X against torch.autograd (CPU, fp32) of the oracle's
+primitives.  NB raw pointers do not keep tensors alive: every device operand is bound to a local name."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+NULL = C.c_void_p(0)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _report(name, err):
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/op_errors.txt", "a") as f:
+        f.write(f"bwd {name}: {err:.3e}\n")
+
+
+def test_gru_gates_bwd(dev):
+    from oracle import model_ref
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(1)
+    R, I, H = 5, 12, 32
+    x = torch.randn(R, I, generator=g)
+    h = torch.randn(R, H, generator=g, requires_grad=True)
+    w_ih, w_hh = torch.randn(3 * H, I, generator=g) * 0.3, torch.randn(3 * H, H, generator=g) * 0.3
+    b_ih, b_hh = torch.randn(3 * H, generator=g) * 0.1, torch.randn(3 * H, generator=g) * 0.1
+    gi = (x @ w_ih.t() + b_ih).requires_grad_(True)
+    gh = (h.detach() @ w_hh.t() + b_hh).requires_grad_(True)
+    Hh = H
+    r = torch.sigmoid(gi[:, :Hh] + gh[:, :Hh]); z = torch.sigmoid(gi[:, Hh:2 * Hh] + gh[:, Hh:2 * Hh])
+    n = torch.tanh(gi[:, 2 * Hh:] + r * gh[:, 2 * Hh:])
+    hn = (1 - z) * n + z * h
+    dh = torch.randn(R, H, generator=g)
+    hn.backward(dh)
+    # forward on the device to produce the saved gates, then backward
+    gid, ghd, hd = gi.detach().to(dev), gh.detach().to(dev), h.detach().to(dev)
+    hout, save = torch.empty(R, H, device=dev), torch.empty(R, 4 * H, device=dev)
+    hip.check(L.a2s_gru_gates_fwd(hip.stream(), hip._p(gid), C.c_long(3 * H), hip._p(ghd), C.c_long(3 * H), hip._p(hd), C.c_long(H),
+                                  hip._p(hout), C.c_long(H), NULL, C.c_long(0), hip._p(save), R, H), "gates fwd")
+    dhd = dh.to(dev)
+    dgi, dgh, dhp = torch.empty(R, 3 * H, device=dev), torch.empty(R, 3 * H, device=dev), torch.empty(R, H, device=dev)
+    hip.check(L.a2s_gru_gates_bwd(hip.stream(), hip._p(dhd), C.c_long(H), NULL, C.c_long(0), hip._p(save), hip._p(hd), C.c_long(H),
+                                  hip._p(dgi), C.c_long(3 * H), hip._p(dgh), C.c_long(3 * H), NULL, C.c_long(0), hip._p(dhp), C.c_long(H), R, H), "gates bwd")
+    torch.cuda.synchronize()
+    e = max(_rel(hout, hn), _rel(dgi, gi.grad), _rel(dgh, gh.grad), _rel(dhp, h.grad))
+    _report("gru_gates", e)
+    assert e < 1e-5, e
+
+
+@pytest.mark.parametrize("H,T,B,S", [(32, 41, 3, 4), (256, 1201, 2, 3)])
+def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S):
+    """S steps with different queries through one attention layer: dq per step, deferred dK / dv / dEnc."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(H + S)
+    enc = torch.randn(B, T, 2 * H, generator=g, requires_grad=True)
+    K = (torch.randn(B, T, H, generator=g) * 0.7).requires_grad_(True)
+    v = (torch.randn(H, generator=g) * 0.5).requires_grad_(True)
+    qs = [(torch.randn(B, H, generator=g) * 0.7).requires_grad_(True) for _ in range(S)]
+    dctxs = [torch.randn(B, 2 * H, generator=g) for _ in range(S)]
+    loss = 0
+    ctxs, aws = [], []
+    for q, dc in zip(qs, dctxs):
+        a = torch.softmax((torch.tanh(K + q.unsqueeze(1)) * v).sum(-1), dim=1)
+        ctx = torch.bmm(a.unsqueeze(1), enc).squeeze(1)
+        ctxs.append(ctx.detach()); aws.append(a.detach())
+        loss = loss + (ctx * dc).sum()
+    loss.backward()
+    Kd, encd, vd = K.detach().to(dev), enc.detach().to(dev), v.detach().to(dev)
+    q_all = torch.stack([q.detach() for q in qs]).to(dev)                    # (S,B,H)
+    attw = torch.stack(aws).to(dev)
+    ctx_all = torch.stack(ctxs).to(dev)
+    dctx_all = torch.stack(dctxs).to(dev)
+    dq_all, ds_all = torch.empty(S, B, H, device=dev), torch.empty(S, B, T, device=dev)
+    for s in range(S):
+        hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(Kd), hip._p(encd), C.c_void_p(q_all[s].data_ptr()), C.c_long(H), hip._p(vd),
+                                      C.c_void_p(attw[s].data_ptr()), C.c_void_p(ctx_all[s].data_ptr()), C.c_long(2 * H),
+                                      C.c_void_p(dctx_all[s].data_ptr()), C.c_long(2 * H), NULL, C.c_long(0), NULL, C.c_long(0),
+                                      C.c_void_p(dq_all[s].data_ptr()), C.c_long(H), C.c_void_p(ds_all[s].data_ptr()), B, T, H), "attn bwd")
+    dK = torch.zeros(B, T, H, device=dev)
+    nblk = L.a2s_attn_dk_blocks(B, T)
+    dvp = torch.zeros(nblk, H, device=dev)
+    hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(Kd), hip._p(q_all), hip._p(ds_all), hip._p(vd), hip._p(dK), hip._p(dvp), B, T, S, H), "dk")
+    dv = torch.zeros(H, device=dev)
+    hip.check(L.a2s_col_sum(hip.stream(), hip._p(dvp), C.c_long(H), hip._p(dv), C.c_long(nblk), H, hip.f32(1.0), hip.f32(0.0)), "col_sum")
+    # deferred dEnc[b] = sum_s a_s[b]^T dctx_s[b]  as one batched GEMM (T x S)(S x 2H)
+    dEnc = torch.zeros(B, T, 2 * H, device=dev)
+    hip.gemm(attw, 1, B * T, dctx_all, B * 2 * H, 1, dEnc, 2 * H, T, 2 * H, S, batch=B, bsA=T, bsB=2 * H, bsC=T * 2 * H)
+    torch.cuda.synchronize()
+    errs = {"dq": max(_rel(dq_all[s], qs[s].grad) for s in range(S)), "dK": _rel(dK, K.grad), "dv": _rel(dv, v.grad), "dEnc": _rel(dEnc, enc.grad)}
+    for k, e in errs.items():
+        _report(f"attention H{H} {k}", e)
+    assert max(errs.values()) < 5e-5, errs
+
+
+def test_log_softmax_bwd_colsum_scatter(dev):
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(4)
+    B, bars, U, V, steps, bar = 3, 5, 12, 173, 7, 2
+    x = torch.randn(B, bars, U, V, generator=g, requires_grad=True)
+    y = torch.log_softmax(x, dim=-1)
+    gy = torch.randn(B, bars, U, V, generator=g)
+    y.backward(gy)
+    yd, gd = y.detach().to(dev), gy.to(dev)
+    dx = torch.empty(steps, B, V, device=dev)
+    off = 4 * bar * U * V
+    hip.check(L.a2s_log_softmax_bwd_rows(hip.stream(), C.c_void_p(gd.data_ptr() + off), C.c_void_p(yd.data_ptr() + off), C.c_long(bars * U * V),
+                                         steps, hip._p(dx), B * steps, V, B, 1), "lsm bwd")
+    ref = x.grad[:, bar, :steps].permute(1, 0, 2)
+    cs = torch.zeros(V, device=dev)
+    hip.check(L.a2s_col_sum(hip.stream(), hip._p(dx), C.c_long(V), hip._p(cs), C.c_long(steps * B), V, hip.f32(1.0), hip.f32(0.0)), "col_sum")
+    # embedding scatter with duplicate ids and a keep mask
+    E, R = 16, 40
+    ids = torch.randint(0, 9, (R,), generator=g)
+    gt = torch.randn(R, 24, generator=g)
+    keep = (torch.rand(R, E, generator=g) > 0.3).to(torch.uint8)
+    tab_ref = torch.zeros(173, E).index_add_(0, ids, gt[:, 4:4 + E] * keep * 2.0)
+    tab = torch.zeros(173, E, device=dev)
+    idsd, gtd, keepd = ids.to(dev), gt.to(dev), keep.to(dev)
+    hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(tab), hip._p(idsd), NULL, C.c_long(1), 0, hip._p(gtd), C.c_long(24), 4, R, E,
+                                      hip._p(keepd), hip.f32(2.0)), "scatter")
+    torch.cuda.synchronize()
+    e = max(_rel(dx, ref), _rel(cs, ref.sum((0, 1))), _rel(tab, tab_ref))
+    _report("lsm_bwd/col_sum/scatter", e)
+    assert e < 1e-5, e
+
+
+@pytest.mark.parametrize("layout", ["planes", "cols"])
+def test_bn_relu_dropout_backward(dev, layout):
+    from oracle import model_ref
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(8)
+    Cc = 20
+    if layout == "planes":
+        rows, F = 14, 24
+        x = (torch.randn(rows, Cc, F, generator=g) * 1.5 + 0.5).requires_grad_(True)       # (rows, C, F)
+        xin, cdim, mask = x, 1, None
+    else:
+        rows, F = 300, 1
+        x = (torch.randn(rows, Cc, generator=g) * 1.5 + 0.5).requires_grad_(True)
+        xin, cdim = x, 1
+        mask = (torch.rand(rows, Cc, generator=g) > 0.2).to(torch.uint8)
+    P = {"bn.weight": (torch.rand(Cc, generator=g) + 0.5).requires_grad_(True), "bn.bias": (torch.randn(Cc, generator=g) * 0.3).requires_grad_(True)}
+    Bf = {"bn.running_mean": torch.zeros(Cc), "bn.running_var": torch.ones(Cc), "bn.num_batches_tracked": torch.tensor(0)}
+    y = torch.relu(model_ref.batch_norm(xin, P, Bf, "bn", True, channel_dim=cdim))
+    if mask is not None:
+        y = y * mask / 0.8
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, gyd = x.detach().to(dev), gy.to(dev)
+    dims = [d for d in range(x.dim()) if d != 1]
+    mean = x.detach().mean(dims); var = x.detach().var(dims, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    scale = P["bn.weight"].detach() * invstd; shift = P["bn.bias"].detach() - mean * scale
+    md, isd, scd, shd = mean.to(dev), invstd.to(dev), scale.to(dev), shift.to(dev)
+    dgam, dbet, dx = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev), torch.empty_like(xd)
+    part = torch.empty(L.a2s_bn_bwd_partial_floats(C.c_long(rows), Cc, F), device=dev)
+    c12 = torch.empty(2 * Cc, device=dev)
+    maskd = mask.to(dev) if mask is not None else None
+    hip.check(L.a2s_bn_bwd(hip.stream(), hip._p(gyd), hip._p(xd), hip._p(md), hip._p(isd), hip._p(scd), hip._p(shd), hip._p(maskd),
+                           hip.f32(1 / 0.8), hip._p(dgam), hip._p(dbet), hip._p(dx), hip._p(part), hip._p(c12), C.c_long(rows), Cc, F), "bn_bwd")
+    torch.cuda.synchronize()
+    errs = {"dx": _rel(dx, x.grad), "dgamma": _rel(dgam, P["bn.weight"].grad), "dbeta": _rel(dbet, P["bn.bias"].grad)}
+    for k, e in errs.items():
+        _report(f"bn_bwd {layout} {k}", e)
+    assert max(errs.values()) < 2e-5, errs
+
+
+@pytest.mark.parametrize("Cin,Cout", [(1, 20), (20, 20), (20, 40), (40, 40)])
+def test_conv_weight_gradient(dev, Cin, Cout):
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(Cin + Cout)
+    B, T, F = 2, 11, 56
+    x = torch.randn(B, T, Cin, F, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    use_affine = Cin != 1
+    xin = x.permute(0, 2, 1, 3)
+    if use_affine:
+        xin = torch.relu(xin * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    dy = torch.randn(B, Cout, T, F, generator=g)
+    torch.nn.functional.conv2d(xin, w, padding=1).backward(dy)
+    xd, dyd = x.to(dev), dy.permute(0, 2, 1, 3).contiguous().to(dev)
+    scd, shd = scale.to(dev), shift.to(dev)
+    dW = torch.zeros(Cout, Cin, 3, 3, device=dev)
+    nb = L.a2s_conv3x3_wgrad_workspace_bytes(Cin, Cout)
+    ws = torch.empty(nb // 4, device=dev)
+    hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dyd), hip._p(xd), hip._p(scd) if use_affine else NULL, hip._p(shd) if use_affine else NULL,
+                                  hip._p(dW), hip._p(ws), C.c_size_t(nb), B, T, F, Cin, Cout), "wgrad")
+    torch.cuda.synchronize()
+    e = _rel(dW, w.grad)
+    _report(f"conv wgrad {Cin}->{Cout}", e)
+    assert e < 2e-5, e
+
+
+def test_gru_sequence_bptt(dev):
+    """One direction pair: dX, dW_ih, dW_hh, db_ih, db_hh and the h_n gradient path, vs autograd of the oracle GRU."""
+    from oracle import model_ref
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(21)
+    B, T, I, H = 3, 17, 24, 32
+    x = torch.randn(B, T, I, generator=g, requires_grad=True)
+    P = {}
+    for sfx in ("l0", "l0_reverse"):
+        P[f"g.weight_ih_{sfx}"] = (torch.randn(3 * H, I, generator=g) * 0.3).requires_grad_(True)
+        P[f"g.weight_hh_{sfx}"] = (torch.randn(3 * H, H, generator=g) * 0.3).requires_grad_(True)
+        P[f"g.bias_ih_{sfx}"] = (torch.randn(3 * H, generator=g) * 0.1).requires_grad_(True)
+        P[f"g.bias_hh_{sfx}"] = (torch.randn(3 * H, generator=g) * 0.1).requires_grad_(True)
+    of, hf = model_ref.gru_direction(x, P, "g", "l0")
+    orr, hr = model_ref.gru_direction(x, P, "g", "l0_reverse", reverse=True)
+    dout = torch.randn(B, T, 2 * H, generator=g)
+    dhn = [torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)]
+    ((torch.cat([of, orr], 2) * dout).sum() + (hf * dhn[0]).sum() + (hr * dhn[1]).sum()).backward()
+    Pd = {k: v.detach().to(dev) for k, v in P.items()}
+    xd = x.detach().to(dev).reshape(B * T, I)
+    out = torch.empty(B, T, 2 * H, device=dev)
+    doutd = dout.to(dev)
+    dX = torch.zeros(B * T, I, device=dev)
+    worst = 0.0
+    for d, sfx in enumerate(("l0", "l0_reverse")):
+        gi = hip.linear(xd, Pd[f"g.weight_ih_{sfx}"], Pd[f"g.bias_ih_{sfx}"])
+        hbuf, gh, hn = torch.empty(2, B, H, device=dev), torch.empty(B, 3 * H, device=dev), torch.empty(B, H, device=dev)
+        gates = torch.empty(T, B, 4 * H, device=dev)
+        hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H), hip._p(Pd[f"g.weight_hh_{sfx}"]),
+                                    hip._p(Pd[f"g.bias_hh_{sfx}"]), C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
+                                    hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d), "fwd")
+        dgi = torch.empty(B, T, 3 * H, device=dev); dghs = torch.empty(B, T, 3 * H, device=dev)
+        dgh_first, dhbuf, dgh_tmp = torch.empty(B, 3 * H, device=dev), torch.empty(2, B, H, device=dev), torch.empty(B, 3 * H, device=dev)
+        dhnd = dhn[d].to(dev)
+        hip.check(L.a2s_gru_seq_bwd(hip.stream(), C.c_void_p(doutd.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
+                                    C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H), hip._p(gates),
+                                    hip._p(Pd[f"g.weight_hh_{sfx}"]), hip._p(dhnd), hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf),
+                                    hip._p(dgh_tmp), B, T, H, d), "bwd")
+        dgi2 = dgi.view(B * T, 3 * H)
+        dWih = torch.zeros(3 * H, I, device=dev)
+        hip.gemm(dgi2, 1, 3 * H, xd, I, 1, dWih, I, 3 * H, I, B * T)                      # dW_ih = dgi^T x
+        dWhh = torch.zeros(3 * H, H, device=dev)
+        hip.gemm(dghs.view(B * T, 3 * H), 1, 3 * H, out, 2 * H, 1, dWhh, H, 3 * H, H, B * T, b_off=d * H)   # dW_hh = dgh_shift^T out[:, dir half]
+        dbih, dbhh = torch.zeros(3 * H, device=dev), torch.zeros(3 * H, device=dev)
+        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dgi2), C.c_long(3 * H), hip._p(dbih), C.c_long(B * T), 3 * H, hip.f32(1.0), hip.f32(0.0)), "cs")
+        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dghs), C.c_long(3 * H), hip._p(dbhh), C.c_long(B * T), 3 * H, hip.f32(1.0), hip.f32(0.0)), "cs")
+        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dgh_first), C.c_long(3 * H), hip._p(dbhh), C.c_long(B), 3 * H, hip.f32(1.0), hip.f32(1.0)), "cs")
+        hip.gemm(dgi2, 3 * H, 1, Pd[f"g.weight_ih_{sfx}"], I, 1, dX, I, B * T, I, 3 * H, beta=1.0)       # dX += dgi W_ih
+        torch.cuda.synchronize()
+        errs = {"dW_ih": _rel(dWih, P[f"g.weight_ih_{sfx}"].grad), "dW_hh": _rel(dWhh, P[f"g.weight_hh_{sfx}"].grad),
+                "db_ih": _rel(dbih, P[f"g.bias_ih_{sfx}"].grad), "db_hh": _rel(dbhh, P[f"g.bias_hh_{sfx}"].grad)}
+        for k, e in errs.items():
+            _report(f"gru_bptt {sfx} {k}", e)
+        worst = max(worst, *errs.values())
+    e = _rel(dX, x.grad.reshape(B * T, I))
+    _report("gru_bptt dX", e)
+    assert max(worst, e) < 2e-5, (worst, e)
+
+
+def test_staff_embedding_backward(dev):
+    from oracle import model_ref
+    from piano_a2s_amd import hip, spec
+    L = hip.lib()
+    cfg = spec.default_cfg(freq_bins=24, conv_feature_size=32, hidden_size=32, max_length=(12, 8))
+    st = spec.procedural_state(cfg, 11)
+    P, _ = spec.split_state(st)
+    names = [f"decoder.staff_emb.{w}_{sfx}" for sfx in ("l0", "l0_reverse") for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    P = {k: (v.clone().requires_grad_(True) if (k in names or k == "decoder.note_emb.weight") else v) for k, v in P.items()}
+    g = torch.Generator().manual_seed(6)
+    R, maxlen, E, S = 4, 12, 16, 32
+    ids = torch.randint(0, 20, (R, maxlen), generator=g)                 # duplicates on purpose
+    lengths = torch.tensor([1, 12, 5, 7])
+    tok = model_ref._staff_token(ids, lengths, P).squeeze(1)              # (R, 64)
+    dtok = torch.randn(R, 2 * S, generator=g)
+    (tok * dtok).sum().backward()
+    Sd = {k: v.detach().to(dev) for k, v in P.items()}
+    idsd, lend, dtokd = ids.to(dev), lengths.to(dev), dtok.to(dev)
+    out = torch.zeros(R, 2 * S, device=dev)
+    hsave = torch.zeros(R, 2, maxlen, S, device=dev)
+    warr = (C.c_void_p * 8)(*[Sd[n].data_ptr() for n in names])
+    hip.check(L.a2s_staff_emb_fwd(hip.stream(), hip._p(Sd["decoder.note_emb.weight"]), warr, hip._p(idsd), NULL, C.c_long(maxlen), hip._p(lend),
+                                  C.c_long(1), hip._p(out), C.c_long(2 * S), 0, hip._p(hsave), R, maxlen, E, S), "fwd")
+    grads = [torch.zeros_like(Sd[n]) for n in names]
+    gptrs = torch.tensor([t.data_ptr() for t in grads], dtype=torch.int64, device=dev)      # DEVICE array of pointers
+    emb_grad = torch.zeros_like(Sd["decoder.note_emb.weight"])
+    hip.check(L.a2s_staff_emb_bwd(hip.stream(), hip._p(Sd["decoder.note_emb.weight"]), warr, hip._p(gptrs), hip._p(emb_grad), hip._p(idsd), NULL,
+                                  C.c_long(maxlen), hip._p(lend), C.c_long(1), hip._p(dtokd), C.c_long(2 * S), 0, hip._p(hsave), R, maxlen, E, S), "bwd")
+    torch.cuda.synchronize()
+    errs = {n.split(".")[-1]: _rel(gr, P[n].grad) for n, gr in zip(names, grads)}
+    errs["note_emb"] = _rel(emb_grad, P["decoder.note_emb.weight"].grad)
+    errs["fwd"] = _rel(out, tok)
+    for k, e in errs.items():
+        _report(f"staff_emb_bwd {k}", e)
+    assert max(errs.values()) < 2e-5, errs
