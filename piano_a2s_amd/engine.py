@@ -140,16 +140,21 @@ class Engine:
         hip.gemm(enc2d, 2 * H, 1, W, 1, 4 * H, K, H, enc2d.shape[0], H, 2 * H, b_off=2 * H)
         return K
 
-    def _staff_token(self, S, ids, lengths, len_stride, out, col0, maxlen, id_bstride, ids_are_i64):
+    def _staff_token(self, S, ids, lengths, len_stride, out, col0, maxlen, id_bstride, ids_are_i64, record=None):
+        """record: list that receives what the backward pass needs to replay this call (training only)."""
         L = hip.lib()
         names = [f"decoder.staff_emb.{w}_{sfx}" for sfx in ("l0", "l0_reverse") for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
         arr = (C.c_void_p * 8)(*[S[n].data_ptr() for n in names])
         R = out.shape[0]
         E, Sz = self.cfg["note_emb_size"], self.cfg["staff_emb_size"]
+        hsave = torch.empty((R, 2, maxlen, Sz), dtype=torch.float32, device=out.device) if record is not None else None
         hip.check(L.a2s_staff_emb_fwd(hip.stream(), hip._p(S["decoder.note_emb.weight"]), arr,
                                       hip._p(ids) if ids_are_i64 else C.c_void_p(0), C.c_void_p(0) if ids_are_i64 else hip._p(ids),
                                       C.c_long(id_bstride), hip._p(lengths), C.c_long(len_stride), hip._p(out), C.c_long(out.stride(0)),
-                                      col0, C.c_void_p(0), R, maxlen, E, Sz), "a2s_staff_emb_fwd")
+                                      col0, hip._p(hsave), R, maxlen, E, Sz), "a2s_staff_emb_fwd")
+        if record is not None:
+            record.append(dict(ids=ids, lengths=lengths, len_stride=len_stride, col0=col0, maxlen=maxlen, id_bstride=id_bstride,
+                               i64=ids_are_i64, hsave=hsave))
 
     def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T):
         """One NoteDecoder.decode_notes call.  probs_bar: view (B, max_steps, V) of the output tensor (strided)."""
@@ -203,7 +208,8 @@ class Engine:
         # steps the reference would have executed: known from the plan with ground truth; read back from the device
         # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
         executed = n if gt_bar is not None else int(steps_exec.item())
-        saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags))
+        saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
+                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p)
         return ids, lengths, saved
 
     # ------------------------------------------------------------------ full forward
@@ -244,7 +250,8 @@ class Engine:
         token = self._empty(B, tokw, dev=dev)
         sos_ids = torch.tensor([[SOS, EOS]], dtype=torch.long, device=dev).repeat(B, 1)
         two = torch.full((B,), 2, dtype=torch.long, device=dev)
-        self._staff_token(S, sos_ids, two, 1, token, 0, 2, 2, True)
+        sos_rec = [] if training else None
+        self._staff_token(S, sos_ids, two, 1, token, 0, 2, 2, True, sos_rec)
         token[:, 2 * Sz:4 * Sz].copy_(token[:, :2 * Sz])
         hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S["decoder.time_sig_emb.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0),
                                    cfg["num_time_sig"], hip._p(token), C.c_long(tokw), 4 * Sz, B, te, C.c_void_p(0), hip.f32(1.0)), "embed ts")
@@ -306,22 +313,26 @@ class Engine:
             # next bar token (models.py:289-311): one draw per bar, after both staves
             teacher_force = rng.random() < teacher_forcing_ratio
             token = self._empty(B, tokw, dev=dev)
+            tok_rec = [] if training else None
             if teacher_force and not inference:
                 if int(gt_cpu[2][:, bar].min()) <= 0 or int(gt_cpu[3][:, bar].min()) <= 0:
                     raise RuntimeError("Length of all samples has to be greater than 0")     # pack_padded_sequence
-                self._staff_token(S, up_gt[:, bar], up_len_gt[:, bar], bars, token, 0, U, bars * U, True)
-                self._staff_token(S, lo_gt[:, bar], lo_len_gt[:, bar], bars, token, 2 * Sz, Lo, bars * Lo, True)
+                self._staff_token(S, up_gt[:, bar], up_len_gt[:, bar], bars, token, 0, U, bars * U, True, tok_rec)
+                self._staff_token(S, lo_gt[:, bar], lo_len_gt[:, bar], bars, token, 2 * Sz, Lo, bars * Lo, True, tok_rec)
                 ts_ids, key_ids, i64, stride = ts_gt[:, bar], key_gt[:, bar], True, bars
             else:
-                self._staff_token(S, staff["up"][0], staff["up"][1], 1, token, 0, U, U, False)
-                self._staff_token(S, staff["lo"][0], staff["lo"][1], 1, token, 2 * Sz, Lo, Lo, False)
+                self._staff_token(S, staff["up"][0], staff["up"][1], 1, token, 0, U, U, False, tok_rec)
+                self._staff_token(S, staff["lo"][0], staff["lo"][1], 1, token, 2 * Sz, Lo, Lo, False, tok_rec)
                 ts_ids, key_ids, i64, stride = heads["time_sig_out"][3], heads["key_out"][3], False, 1
             for table, ids_, col, width in ((S["decoder.time_sig_emb.weight"], ts_ids, 4 * Sz, te), (S["decoder.key_emb.weight"], key_ids, 4 * Sz + te, ke)):
                 hip.check(L.a2s_embed_rows(hip.stream(), hip._p(table), hip._p(ids_) if i64 else C.c_void_p(0),
                                            C.c_void_p(0) if i64 else hip._p(ids_), C.c_long(stride), 0, hip._p(token), C.c_long(tokw), col, B,
                                            width, C.c_void_p(0), hip.f32(1.0)), "embed next token")
             bar_saved.append(dict(xbar=xbar, headin=headin, qb=qb, attw=attw, gates=gates, hprev=hidden, hnew=hnew, staff=staff,
-                                  heads=heads, keep=keep, teacher_force=teacher_force))
+                                  heads=heads, keep=keep, teacher_force=teacher_force, tok_rec=tok_rec,
+                                  next_ids=(ts_ids, key_ids, i64, stride)))
             hidden = hnew
-        self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, enc_out=enc)
+        self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, enc_out=enc, sos_rec=sos_rec, training=training,
+                          outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
+                          shape=(B, T, F), drop_on=drop_on)
         return ts_out, key_out, up_out, lo_out

@@ -1,0 +1,313 @@
+"""Backward pass of the transcription model on liba2s_hip.so: the manual reverse of piano_a2s_amd.engine.Engine.forward.
+
+What torch.autograd would compute for the reference graph (models.py:26-51 and everything below it), composed from
+the C-ABI backward kernels.  Sequential parts (note-decoder steps, encoder GRU steps) run in C++ loops; everything that
+does not depend on the recurrence is deferred and batched over all steps of a (bar, staff):
+  * output projection: ONE GEMM for dlogits_all W_out and ONE for dW_out,
+  * GRU / attention-query weight gradients: ONE GEMM each over all steps,
+  * attention key/value side: dEnc via a batched (T x steps)(steps x 2H) GEMM, dK via a tanh-recompute kernel.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .spec import SOS, VOCAB_SIZE
+
+NULL = C.c_void_p(0)
+
+
+def _ptr(t, off=0):
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def _colsum(x, ld, out, rows, ncol, x_off=0, out_off=0, beta=1.0):
+    hip.check(hip.lib().a2s_col_sum(hip.stream(), _ptr(x, x_off), C.c_long(ld), _ptr(out, out_off), C.c_long(rows), ncol,
+                                    hip.f32(1.0), hip.f32(beta)), "a2s_col_sum")
+
+
+def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0):
+    """y = x W^T + b  (x (M,K) contiguous, W (N,K)):  dW += dy^T x ; db += colsum(dy) ; dx (+)= dy W."""
+    M, K = x.shape
+    N = W.shape[0]
+    sk = hip.lib().a2s_gemm_pick_splitk(N, K, M, 1)
+    hip.gemm(dy, 1, N, x, K, 1, G[wname], K, N, K, M, beta=1.0, splitk=sk)
+    if bname is not None:
+        _colsum(dy, N, G[bname], M, N)
+    if dx is not None:
+        hip.gemm(dy, N, 1, W, K, 1, dx, dx.stride(0), M, K, N, beta=dx_beta)
+    return dx
+
+
+def _staff_token_bwd(eng, S, G, rec, dtok):
+    """Backward of one _staff_token call; dtok: (R, >= col0+2S) gradient buffer holding the token gradient."""
+    L = hip.lib()
+    names = [f"decoder.staff_emb.{w}_{sfx}" for sfx in ("l0", "l0_reverse") for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    warr = (C.c_void_p * 8)(*[S[n].data_ptr() for n in names])
+    gptrs = torch.tensor([G[n].data_ptr() for n in names], dtype=torch.int64, device=dtok.device)
+    E, Sz = eng.cfg["note_emb_size"], eng.cfg["staff_emb_size"]
+    ids = rec["ids"]
+    hip.check(L.a2s_staff_emb_bwd(hip.stream(), hip._p(S["decoder.note_emb.weight"]), warr, hip._p(gptrs), hip._p(G["decoder.note_emb.weight"]),
+                                  hip._p(ids) if rec["i64"] else NULL, NULL if rec["i64"] else hip._p(ids), C.c_long(rec["id_bstride"]),
+                                  hip._p(rec["lengths"]), C.c_long(rec["len_stride"]), hip._p(dtok), C.c_long(dtok.stride(0)), rec["col0"],
+                                  hip._p(rec["hsave"]), dtok.shape[0], rec["maxlen"], E, Sz), "a2s_staff_emb_bwd")
+    return gptrs     # keep alive until the caller returns
+
+
+def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_all, dK, dEnc, B, T, H, steps):
+    """Key/value side of `steps` attention calls of one layer: dEnc += A^T dCtx (per clip), dK += ..., dv += ..."""
+    L = hip.lib()
+    # dEnc[b] += sum_s a_s[b,:]^T dctx_s[b,:]   -- batched over clips: (T x steps)(steps x 2H)
+    hip.gemm(attw_all, 1, B * T, dctx_all, B * 2 * H, 1, dEnc, 2 * H, T, 2 * H, steps, beta=1.0, batch=B, bsA=T, bsB=2 * H, bsC=T * 2 * H)
+    nblk = L.a2s_attn_dk_blocks(B, T)
+    dvp = torch.empty((nblk, H), dtype=torch.float32, device=enc.device)
+    hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(keys), hip._p(q_all), hip._p(ds_all), hip._p(S[prefix + ".v.weight"]), hip._p(dK),
+                                  hip._p(dvp), B, T, steps, H), "a2s_attn_dk_accum")
+    _colsum(dvp, H, G[prefix + ".v.weight"], nblk, H)
+
+
+def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, B, T):
+    """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (B, 2H)."""
+    L = hip.lib()
+    cfg = eng.cfg
+    H, E, V = cfg["hidden_size"], cfg["note_emb_size"], VOCAB_SIZE
+    H2, ldx = 2 * H, E + 2 * H
+    n, prefix, dev = sv["steps"], sv["prefix"], enc.device
+    R = n * B
+    # (a) dlogits for all executed steps, step-major (n, B, V)
+    dlog = torch.empty((n, B, V), dtype=torch.float32, device=dev)
+    hip.check(L.a2s_log_softmax_bwd_rows(hip.stream(), hip._p(dprobs_bar), hip._p(probs_bar), C.c_long(probs_bar.stride(0)), n, hip._p(dlog),
+                                         R, V, B, 1), "a2s_log_softmax_bwd_rows")
+    # (b) output projection, all steps at once: do_all = dlog W_out ; dW_out += dlog^T o ; db_out += colsum
+    o2d, dlog2d = sv["o"].view(R, 2 * H2), dlog.view(R, V)
+    do_all = torch.empty((n, B, 2 * H2), dtype=torch.float32, device=dev)
+    _linear_bwd(o2d, S[prefix + ".out.weight"], dlog2d, G, prefix + ".out.weight", prefix + ".out.bias", dx=do_all.view(R, 2 * H2))
+    # (c) reverse recurrence
+    dgi_all = torch.empty((n, B, 3 * H2), dtype=torch.float32, device=dev)
+    dgh_all = torch.empty((n, B, 3 * H2), dtype=torch.float32, device=dev)
+    dq_all = torch.empty((n, B, H), dtype=torch.float32, device=dev)
+    ds_all = torch.empty((n, B, T), dtype=torch.float32, device=dev)
+    dctx_all = torch.empty((n, B, H2), dtype=torch.float32, device=dev)
+    dx = torch.empty((n, B, ldx), dtype=torch.float32, device=dev)
+    dh = torch.empty((2, B, H2), dtype=torch.float32, device=dev)
+    a = hip.NoteDecBwdArgs()
+    for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),
+                    ("w_hh", S[prefix + ".gru.weight_hh_l0"]), ("keys", keys), ("enc", enc), ("h", sv["h"]), ("x", sv["x"]), ("q", sv["q"]),
+                    ("gates", sv["gates"]), ("attw", sv["attw"]), ("do_all", do_all), ("dgi_all", dgi_all), ("dgh_all", dgh_all),
+                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh)):
+        setattr(a, name, t.data_ptr())
+    a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
+    hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
+    # (d) deferred weight gradients over all steps
+    x2d, h2d = sv["x"][:n].view(R, ldx), sv["h"][:n].view(R, H2)
+    _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_all.view(R, 3 * H2), G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0")
+    _linear_bwd(h2d, S[prefix + ".gru.weight_hh_l0"], dgh_all.view(R, 3 * H2), G, prefix + ".gru.weight_hh_l0", prefix + ".gru.bias_hh_l0")
+    # attention query half: dW[:, :2H] += dq^T h ; db += colsum(dq)
+    Gw = G[prefix + ".attn.attn.weight"]
+    sk = L.a2s_gemm_pick_splitk(H, H2, R, 1)
+    hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk)
+    _colsum(dq_all, H, G[prefix + ".attn.attn.bias"], R, H)
+    _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, B, T, H, n)
+    # embedding rows of the tokens consumed at each step: <sos> at step 0, then gt or argmax of the previous step
+    tok = torch.full((n, B), SOS, dtype=torch.int32, device=dev)
+    if n > 1:
+        prev = sv["ids"][:, :n - 1].t()
+        if sv["gt_bar"] is not None:
+            flags = torch.tensor(sv["flags"][:n - 1], dtype=torch.bool, device=dev).unsqueeze(1)
+            prev = torch.where(flags, sv["gt_bar"][:, :n - 1].t().to(torch.int32), prev)
+        tok[1:] = prev
+    drop = sv["drop"]
+    hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[prefix + ".embedding.weight"]), NULL, hip._p(tok), C.c_long(1), 0, hip._p(dx),
+                                      C.c_long(ldx), 0, R, E, hip._p(drop), hip.f32(1.0 / (1.0 - sv["drop_p"]) if drop is not None else 1.0)),
+              "a2s_embed_scatter_add")
+    return dh[0]
+
+
+def backward(eng, S, grad_outputs):
+    """Gradients of sum_i <out_i, grad_outputs_i> wrt every parameter.  Returns dict name -> tensor (views of ONE flat buffer,
+    also returned as `flat` under key None) in state_dict parameter order."""
+    from .spec import is_buffer
+    sv = eng.saved
+    assert sv["training"], "backward needs a forward run with training=True (batch statistics / saved activations)"
+    L = hip.lib()
+    cfg = eng.cfg
+    H, Sz = cfg["hidden_size"], cfg["staff_emb_size"]
+    te, ke, bars = cfg["time_sig_emb_size"], cfg["key_emb_size"], cfg["max_bars"]
+    tokw = 4 * Sz + te + ke
+    B, T, F = sv["shape"]
+    H2 = 2 * H
+    enc = sv["enc_out"]
+    dev = enc.device
+    names = [k for k in S if not is_buffer(k)]
+    flat = torch.zeros(sum(S[k].numel() for k in names), dtype=torch.float32, device=dev)
+    G, off = {}, 0
+    for k in names:
+        G[k] = flat[off:off + S[k].numel()].view(S[k].shape)
+        off += S[k].numel()
+    dts, dkey, dup, dlo = [g.contiguous() for g in grad_outputs]
+    ts_out, key_out, up_out, lo_out = sv["outs"]
+    dEnc = torch.zeros((B, T, H2), dtype=torch.float32, device=dev)
+    dK = {p: torch.zeros((B, T, H), dtype=torch.float32, device=dev) for p in sv["keys"]}
+    keep_alive = []
+
+    d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
+    d_token_next = None         # gradient wrt the (pre-dropout) token that bar k produced for bar k+1
+    for bar in reversed(range(bars)):
+        b = sv["bars"][bar]
+        # ---- (1) the token this bar produced for the next one
+        if d_token_next is not None:
+            for rec in b["tok_rec"]:
+                keep_alive.append(_staff_token_bwd(eng, S, G, rec, d_token_next))
+            ts_ids, key_ids, i64, stride = b["next_ids"]
+            for table, ids_, col, width in (("decoder.time_sig_emb.weight", ts_ids, 4 * Sz, te), ("decoder.key_emb.weight", key_ids, 4 * Sz + te, ke)):
+                hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[table]), hip._p(ids_) if i64 else NULL, NULL if i64 else hip._p(ids_),
+                                                  C.c_long(stride), 0, hip._p(d_token_next), C.c_long(tokw), col, B, width, NULL, hip.f32(1.0)), "scatter ts/key")
+        # ---- (2) heads: log_softmax + 3-layer MLP on headin = [bar_summary | ctx]
+        d_headin = torch.zeros((B, 4 * H), dtype=torch.float32, device=dev)
+        for hname, dout, out_t, nc in (("time_sig_out", dts, ts_out, cfg["num_time_sig"]), ("key_out", dkey, key_out, cfg["num_keys"])):
+            t1, t2, lg, _ = b["heads"][hname]
+            dlg = torch.empty((B, nc), dtype=torch.float32, device=dev)
+            hip.check(L.a2s_log_softmax_bwd_rows(hip.stream(), _ptr(dout, bar * nc), _ptr(out_t, bar * nc), C.c_long(bars * nc), 1, hip._p(dlg),
+                                                 B, nc, B, 0), "lsm bwd head")
+            p = f"decoder.{hname}"
+            dt2 = torch.empty_like(t2)
+            _linear_bwd(t2, S[p + ".4.weight"], dlg, G, p + ".4.weight", p + ".4.bias", dx=dt2)
+            hip.check(L.a2s_ew_act_bwd(hip.stream(), hip._p(dt2), hip._p(t2), hip._p(dt2), C.c_long(dt2.numel()), 1), "relu bwd")
+            dt1 = torch.empty_like(t1)
+            _linear_bwd(t1, S[p + ".2.weight"], dt2, G, p + ".2.weight", p + ".2.bias", dx=dt1)
+            hip.check(L.a2s_ew_act_bwd(hip.stream(), hip._p(dt1), hip._p(t1), hip._p(dt1), C.c_long(dt1.numel()), 1), "relu bwd")
+            _linear_bwd(b["headin"], S[p + ".0.weight"], dt1, G, p + ".0.weight", p + ".0.bias", dx=d_headin, dx_beta=1.0)
+        # ---- (3) note decoders: both start from bar_summary
+        d_hnew = torch.zeros((B, H2), dtype=torch.float32, device=dev)
+        for name, prefix, dout, out_t in (("lo", "decoder.lower_decoder", dlo, lo_out), ("up", "decoder.upper_decoder", dup, up_out)):
+            dh0 = _note_decoder_bwd(eng, S, G, b["staff"][name][2], sv["keys"][prefix], enc, dout[:, bar], out_t[:, bar], dK[prefix], dEnc, B, T)
+            d_hnew.add_(dh0)
+        d_hnew.add_(d_headin[:, :H2])
+        if d_hid_carry is not None:
+            d_hnew.add_(d_hid_carry)
+        # ---- (4) bar-level GRU step + attention
+        ldxb = tokw + H2
+        dgi, dgh = torch.empty((B, 3 * H2), device=dev), torch.empty((B, 3 * H2), device=dev)
+        dhp = torch.empty((B, H2), device=dev)
+        hip.check(L.a2s_gru_gates_bwd(hip.stream(), hip._p(d_hnew), C.c_long(H2), NULL, C.c_long(0), hip._p(b["gates"]), hip._p(b["hprev"]), C.c_long(H2),
+                                      hip._p(dgi), C.c_long(3 * H2), hip._p(dgh), C.c_long(3 * H2), NULL, C.c_long(0), hip._p(dhp), C.c_long(H2), B, H2),
+                  "gates bwd bar")
+        d_xbar = torch.empty((B, ldxb), device=dev)
+        _linear_bwd(b["xbar"], S["decoder.gru.weight_ih_l0"], dgi, G, "decoder.gru.weight_ih_l0", "decoder.gru.bias_ih_l0", dx=d_xbar)
+        _linear_bwd(b["hprev"], S["decoder.gru.weight_hh_l0"], dgh, G, "decoder.gru.weight_hh_l0", "decoder.gru.bias_hh_l0", dx=dhp, dx_beta=1.0)
+        dq, ds = torch.empty((B, H), device=dev), torch.empty((1, B, T), device=dev)
+        dctx = torch.empty((1, B, H2), device=dev)
+        hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(sv["keys"]["decoder"]), hip._p(enc), hip._p(b["qb"]), C.c_long(H), hip._p(S["decoder.attn.v.weight"]),
+                                      hip._p(b["attw"]), _ptr(b["xbar"], tokw), C.c_long(ldxb), _ptr(d_xbar, tokw), C.c_long(ldxb), _ptr(d_headin, H2),
+                                      C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), B, T, H), "attn bwd bar")
+        Wa = S["decoder.attn.attn.weight"]
+        hip.gemm(dq, H, 1, Wa, 4 * H, 1, dhp, H2, B, H2, H, beta=1.0)                              # d hprev += dq W_h
+        hip.gemm(dq, 1, H, b["hprev"], H2, 1, G["decoder.attn.attn.weight"], 4 * H, H, H2, B, beta=1.0)   # dW_h += dq^T hprev
+        _colsum(dq, H, G["decoder.attn.attn.bias"], B, H)
+        _attn_deferred(eng, S, G, "decoder.attn", sv["keys"]["decoder"], enc, b["qb"].view(1, B, H), ds, b["attw"].view(1, B, T), dctx,
+                       dK["decoder"], dEnc, B, T, H, 1)
+        d_hid_carry = dhp
+        d_token = d_xbar[:, :tokw].contiguous()
+        if b["keep"] is not None:
+            d_token = d_token * b["keep"] / 0.9
+        d_token_next = d_token
+    # ---- initial token: <sos>/<eos> staff token (used for both staves) + time-signature / key <sos> rows
+    d_sos = d_token_next.clone()
+    d_sos[:, :2 * Sz] += d_sos[:, 2 * Sz:4 * Sz]
+    keep_alive.append(_staff_token_bwd(eng, S, G, sv["sos_rec"][0], d_sos))
+    for table, cid, col, width in (("decoder.time_sig_emb.weight", cfg["num_time_sig"], 4 * Sz, te), ("decoder.key_emb.weight", cfg["num_keys"], 4 * Sz + te, ke)):
+        hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[table]), NULL, NULL, C.c_long(0), cid, hip._p(d_token_next), C.c_long(tokw), col, B, width,
+                                          NULL, hip.f32(1.0)), "scatter sos ts/key")
+    # ---- attention keys: K = enc W_e^T  ->  dW_e += dK^T enc ; dEnc += dK W_e
+    enc2d = enc.view(B * T, H2)
+    for p, dKp in dK.items():
+        Wn = p + ".attn.attn.weight"
+        sk = L.a2s_gemm_pick_splitk(H, H2, B * T, 1)
+        hip.gemm(dKp, 1, H, enc2d, H2, 1, G[Wn], 4 * H, H, H2, B * T, beta=1.0, splitk=sk, c_off=H2)
+        hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2)
+    d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T)
+    _convstack_bwd(eng, S, G, sv["conv"], d_conv, B, T, F)
+    G[None] = flat
+    eng._keep_alive = keep_alive
+    return G
+
+
+def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
+    L = hip.lib()
+    H = eng.cfg["hidden_size"]
+    dev = dEnc.device
+    W = S["encoder.fc.weight"]
+    # bridge: hidden = tanh(pre); pre_l = fc([hf_l ; hr_l])
+    dpre = torch.empty_like(d_hidden)
+    hip.check(L.a2s_ew_act_bwd(hip.stream(), hip._p(d_hidden), hip._p(es["hidden"]), hip._p(dpre), C.c_long(dpre.numel()), 2), "tanh bwd")
+    dhn = []
+    for l in (0, 1):
+        for half, hfin in enumerate((es["finals"][2 * l], es["finals"][2 * l + 1])):
+            d = torch.empty((B, H), device=dev)
+            hip.gemm(dpre, 2 * H, 1, W, 2 * H, 1, d, H, B, H, H, a_off=l * H, b_off=half * H)                       # d h_fin = dpre_l W[:, half]
+            hip.gemm(dpre, 1, 2 * H, hfin, H, 1, G["encoder.fc.weight"], 2 * H, H, H, B, beta=1.0, a_off=l * H, c_off=half * H)   # dW += dpre_l^T h_fin
+            dhn.append(d)
+        _colsum(dpre, 2 * H, G["encoder.fc.bias"], B, H, x_off=l * H)
+    dout = dEnc                                              # gradient wrt layer-1 outputs (B,T,2H)
+    for layer in (1, 0):
+        ls = es["layers"][layer]
+        inp = ls["in"]                                       # (B*T, I)
+        I = inp.shape[1]
+        out = ls["out"]
+        dX = torch.empty((B * T, I), device=dev)
+        for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
+            dgi = torch.empty((B, T, 3 * H), device=dev)
+            dghs = torch.empty((B, T, 3 * H), device=dev)
+            dgh_first, dhbuf, dgh_tmp = torch.empty((B, 3 * H), device=dev), torch.empty((2, B, H), device=dev), torch.empty((B, 3 * H), device=dev)
+            hip.check(L.a2s_gru_seq_bwd(hip.stream(), _ptr(dout, d * H), C.c_long(T * 2 * H), C.c_long(2 * H), _ptr(out, d * H), C.c_long(T * 2 * H),
+                                        C.c_long(2 * H), hip._p(ls["dirs"][d]["gates"]), hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(dhn[2 * layer + d]),
+                                        hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf), hip._p(dgh_tmp), B, T, H, d), "a2s_gru_seq_bwd")
+            dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)
+            _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}", dx=dX,
+                        dx_beta=0.0 if d == 0 else 1.0)
+            sk = L.a2s_gemm_pick_splitk(3 * H, H, B * T, 1)
+            hip.gemm(dghs2, 1, 3 * H, out, 2 * H, 1, G[f"encoder.gru.weight_hh_{sfx}"], H, 3 * H, H, B * T, beta=1.0, splitk=sk, b_off=d * H)
+            _colsum(dghs2, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B * T, 3 * H)
+            _colsum(dgh_first, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B, 3 * H)
+        dout = dX.view(B, T, I)
+    return dout                                              # (B, T, conv_feature_size)
+
+
+def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
+    L = hip.lib()
+    dev = d_out.device
+    Cf = eng.cfg["conv_feature_size"]
+    rows = B * T
+
+    def bn_bwd(g, x, bn, name, mask, n_rows, C_, F_):
+        mean, invstd, scale, shift = bn
+        part = torch.empty(L.a2s_bn_bwd_partial_floats(C.c_long(n_rows), C_, F_), dtype=torch.float32, device=dev)
+        c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+        hip.check(L.a2s_bn_bwd(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(mask), hip.f32(1.0 / 0.8),
+                               hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), hip._p(g), hip._p(part), hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd")
+        return g                                              # in place: g now holds dx
+
+    # dropout + ReLU + BatchNorm1d over the (B*T, Cf) Linear output
+    g = d_out.reshape(rows, Cf).contiguous()
+    dz = bn_bwd(g, cs["z"], cs["out_bn"], "convstack.out_bn", cs["drop"], rows, Cf, 1)
+    # Linear 19200 -> Cf, no bias:  dW += dz^T a4 ; da4 = dz W
+    a4 = cs["a4"]
+    da = torch.empty_like(a4)
+    _linear_bwd(a4, S["convstack.out.weight"], dz, G, "convstack.out.weight", None, dx=da)
+    chans = [(1, 20), (20, 20), (20, 40), (40, 40)]
+    g = da.view(B, T, 40, F)
+    for i in (4, 3, 2, 1):
+        ci, co = chans[i - 1]
+        y = cs["y"][i - 1]                                    # pre-BN conv output of this layer
+        dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F)
+        x_in = cs["y"][i - 2] if i > 1 else cs["x0"]
+        in_bn = cs["bn"][i - 2] if i > 1 else None
+        nb = L.a2s_conv3x3_wgrad_workspace_bytes(ci, co)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+        hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
+                                      hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
+        if i > 1:
+            gprev = torch.empty((B, T, ci, F), dtype=torch.float32, device=dev)
+            hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), NULL, NULL, NULL, B, T, F, co, ci, 1),
+                      "a2s_conv3x3 dgrad")
+            g = gprev

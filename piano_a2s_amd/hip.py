@@ -29,6 +29,14 @@ class NoteDecArgs(C.Structure):
         ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int)]
 
 
+class NoteDecBwdArgs(C.Structure):
+    """Mirror of `a2s_note_dec_bwd_args` (include/a2s.h) -- same members, same order."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "attn_w", "attn_v", "w_ih", "w_hh", "keys", "enc", "h", "x", "q", "gates", "attw", "do_all",
+        "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh")] + [
+        ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int)]
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -29,19 +29,21 @@ def test_exports_every_declared_symbol(libpath):
     assert lib.a2s_version() >= 1 and isinstance(lib.a2s_last_error(), bytes)
 
 
-def test_note_dec_args_layout_matches_c(libpath, tmp_path):
-    """sizeof / offsetof of a2s_note_dec_args as the C compiler sees them == the ctypes mirror."""
+@pytest.mark.parametrize("cname,pyname", [("a2s_note_dec_args", "NoteDecArgs"), ("a2s_note_dec_bwd_args", "NoteDecBwdArgs")])
+def test_arg_block_layout_matches_c(libpath, tmp_path, cname, pyname):
+    """sizeof / offsetof of the argument blocks as the C compiler sees them == the ctypes mirrors."""
     from piano_a2s_amd import hip
-    fields = [f[0] for f in hip.NoteDecArgs._fields_]
+    cls = getattr(hip, pyname)
+    fields = [f[0] for f in cls._fields_]
     src = tmp_path / "layout.c"
-    body = "\n".join(f'printf("{f} %zu\\n", offsetof(a2s_note_dec_args, {f}));' for f in fields)
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "a2s.h"\nint main(){printf("sizeof %zu\\n", sizeof(a2s_note_dec_args));\n' + body + "\nreturn 0;}\n")
+    body = "\n".join(f'printf("{f} %zu\\n", offsetof({cname}, {f}));' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "a2s.h"\nint main(){printf("sizeof %zu\\n", sizeof(' + cname + '));\n' + body + "\nreturn 0;}\n")
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
-    assert int(out["sizeof"]) == C.sizeof(hip.NoteDecArgs)
+    assert int(out["sizeof"]) == C.sizeof(cls)
     for f in fields:
-        assert int(out[f]) == getattr(hip.NoteDecArgs, f).offset, f
+        assert int(out[f]) == getattr(cls, f).offset, f
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,120 @@
+"""Full training-step gradient parity on the MI355X: HIP forward + manual HIP backward vs the REFERENCE's gradients
+(fixtures from tests/golden/make_golden.py: all 83 parameter gradients at reduced size, norms + samples at full size)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SMALL_BATCH = dict(frames=41, upper_range=(3, 10), lower_range=(2, 7), full_tail=0.1)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _loss_grads(outs, batch, dev):
+    """d(total loss)/d(outputs) with the reference's objective (pretrain.py:72-88), evaluated by torch on the device."""
+    leaves = [o.detach().clone().requires_grad_(True) for o in outs]
+    nll, nll_pad = torch.nn.NLLLoss(), torch.nn.NLLLoss(ignore_index=147)
+    ts_t, key_t, up_t, lo_t = batch[1].to(dev), batch[2].to(dev), batch[3].to(dev), batch[5].to(dev)
+    ts_o, key_o, up_o, lo_o = leaves
+    terms = [nll(ts_o.permute(0, 2, 1), ts_t), nll(key_o.permute(0, 2, 1), key_t),
+             nll_pad(up_o.view(-1, up_o.shape[2], up_o.shape[3]).permute(0, 2, 1), up_t.view(-1, up_t.shape[2])),
+             nll_pad(lo_o.view(-1, lo_o.shape[2], lo_o.shape[3]).permute(0, 2, 1), lo_t.view(-1, lo_t.shape[2]))]
+    total = sum(terms)
+    total.backward()
+    return [float(total)] + [float(t) for t in terms], [l.grad for l in leaves]
+
+
+def _log(line):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_errors.txt", "a") as f:
+        f.write(line + "\n")
+
+
+@pytest.mark.parametrize("name", ["train_tf1", "train_tf05"])
+def test_small_model_all_gradients(golden_dir, dev, name):
+    from piano_a2s_amd import engine, engine_bwd, spec, synthetic
+    data = np.load(os.path.join(golden_dir, "g1_small.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g1_small.json")))
+    cfg = spec.default_cfg(**meta["cfg"])
+    case = meta["cases"][name]
+    batch = synthetic.make_batch(3, cfg, meta["batch_seed"], **SMALL_BATCH)
+    S = {k: v.to(dev) for k, v in spec.procedural_state(cfg, case["weights_seed"], eos_bias=case["eos_bias"], lively=True).items()}
+    gt = [b.to(dev) for b in batch[1:7]]
+    rng = random.Random()
+    if case["random_seed"] is not None:
+        rng.seed(case["random_seed"])
+    eng = engine.Engine(cfg)
+    outs = eng.forward(S, batch[0].to(dev), inference=False, ground_truth=gt, teacher_forcing_ratio=case["tf"], training=True, rng=rng, dropout=False)
+    losses, gouts = _loss_grads(outs, batch, dev)
+    ref_losses = data[f"{name}.losses"]
+    for i, (l, r) in enumerate(zip(losses, ref_losses)):
+        assert abs(l - r) <= 1e-4 * abs(r), f"loss term {i}: {l} vs reference {r}"
+    G = engine_bwd.backward(eng, S, gouts)
+    torch.cuda.synchronize()
+    worst = 0.0
+    failures = []
+    for k in S:
+        if spec.is_buffer(k):
+            continue
+        g = G[k].cpu().numpy().astype(np.float64)
+        if name == "train_tf1":
+            ref = data[f"{name}.grad.{k}"].astype(np.float64)
+            err = np.abs(g - ref).max() / max(np.abs(ref).max(), 1e-12)
+        else:
+            ref = float(data[f"{name}.gradnorm.{k}"])
+            err = abs(np.linalg.norm(g) - ref) / max(ref, 1e-12)
+        _log(f"{name} {k}: {err:.3e}")
+        worst = max(worst, err)
+        if err > 2e-4:
+            failures.append((k, err))
+    assert not failures, f"{len(failures)} parameter gradients off: {failures[:8]}"
+
+
+def test_full_size_gradient_norms(golden_dir, dev):
+    from piano_a2s_amd import engine, engine_bwd, spec, synthetic
+    data = np.load(os.path.join(golden_dir, "g2_full.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g2_full.json")))
+    cfg = spec.default_cfg()
+    st = spec.procedural_state(cfg, meta["weights_seed"], eos_bias=meta["eos_bias"], lively=meta["lively"])
+    kw = dict(meta["batch_kwargs"])
+    kw["upper_range"], kw["lower_range"] = tuple(kw["upper_range"]), tuple(kw["lower_range"])
+    batch = synthetic.make_batch(2, cfg, meta["batch_seed"], **kw)
+    S = {k: v.to(dev) for k, v in st.items()}
+    gt = [b.to(dev) for b in batch[1:7]]
+    eng = engine.Engine(cfg)
+    outs = eng.forward(S, batch[0].to(dev), inference=False, ground_truth=gt, teacher_forcing_ratio=1.0, training=True, dropout=False)
+    losses, gouts = _loss_grads(outs, batch, dev)
+    for i, (l, r) in enumerate(zip(losses, data["train_tf1.losses"])):
+        _log(f"full loss term {i}: {l} vs {r} rel {abs(l - r) / abs(r):.3e}")
+        assert abs(l - r) <= 1e-4 * abs(r), f"loss term {i}: {l} vs reference {r}"     # north-star: loss within 1e-4 rel
+    G = engine_bwd.backward(eng, S, gouts)
+    torch.cuda.synchronize()
+    failures = []
+    for k, rn in zip(meta["grad_names"], data["train_tf1.gradnorms"]):
+        g = G[k]
+        gn = float(g.double().norm())
+        idx = torch.from_numpy(data[f"train_tf1.gsample_idx.{k}"]).to(dev)
+        got = g.flatten()[idx].cpu().numpy()
+        rs = data[f"train_tf1.gsample.{k}"]
+        e_norm = abs(gn - rn) / max(rn, 1e-12)
+        e_samp = np.abs(got - rs).max() / max(np.abs(rs).max(), rn / np.sqrt(g.numel()))
+        _log(f"full {k}: norm {e_norm:.3e} samples {e_samp:.3e}")
+        # Bars: norm 2e-4 (measured worst 1.5e-4, typical 1e-6).  Sampled elements 3e-3 of the tensor's max: the ConvStack
+        # BN/conv gradients are sums over 2 x 1201 x 480 positions with heavy cancellation after ~2900 decoder steps and
+        # 4 x 1201 GRU steps of back-propagation; two fp32 evaluations that only differ in summation grouping already
+        # disagree by 4.5e-4 there (oracle vs reference, tests/test_oracle_full.py) and this path (MFMA tiles, split-K slabs,
+        # per-block BN partials) by up to 1.2e-3 on one element of bn4.bias while its norm agrees to 8e-5.  Everything
+        # outside the ConvStack is <= 1e-5.  The tight element-wise gate is the reduced-size test above (all 83 tensors, 2e-4,
+        # measured 1.2e-5), where round-off does not accumulate over 1.15 M positions.
+        if e_norm > 2e-4 or e_samp > 3e-3:
+            failures.append((k, e_norm, e_samp))
+    assert not failures, f"{len(failures)} gradients off: {failures[:8]}"
