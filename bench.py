@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training clips/s of the piano-a2s hot path on MI355X (BASELINE.json metric).
+
+A "step" = one full optimizer step of the recipe on one minibatch of synthetic 12 s / 5-bar clips with the
+hparams/pretrain.yaml model (16.36 M parameters, 1201 x 480 spectrogram frames): forward, 4-term NLL objective,
+backward, (gradient all-reduce,) clip_grad_norm_(5.0) + Adadelta -- piano_a2s_amd.train.TrainStep, all on liba2s_hip.so.
+
+  python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (one rank per GPU, RCCL)
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (additive-attention step, HBM-bound: it streams the
+clip's keys and encoder outputs once per decode step); `cpu_baseline` is the oracle's as-written CPU restatement of the
+same training step timed on this box's host cores on a bounded sample (a reported baseline, not the target).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+TF_RATIO = 0.7                 # hparams/pretrain.yaml teacher_forcing_ratio at epoch 0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("A2S_BENCH_BATCH", "64")), help="clips per GPU per step")
+    ap.add_argument("--full-tail", type=float, default=0.0, help="probability of a full-length (no <eos>) row per (clip,bar,staff)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=1)
+    return ap.parse_args()
+
+
+def attention_roofline(step, batch_dev, B, T, H, iters=50):
+    """Average launch duration of the dominant kernel (attn_step_fwd) at the step's own shapes, HIP events on the launch stream."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    dev = batch_dev[0].device
+    keys = torch.randn(B, T, H, device=dev) * 0.5
+    enc = torch.randn(B, T, 2 * H, device=dev)
+    q = torch.randn(B, H, device=dev) * 0.5
+    v = torch.randn(H, device=dev) * 0.3
+    ctx = torch.empty(B, 2 * H, device=dev)
+    attw = torch.empty(B, T, device=dev)
+
+    def launch():
+        hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys), hip._p(enc), hip._p(q), C.c_long(H), hip._p(v), hip._p(ctx), C.c_long(2 * H),
+                                      C.c_void_p(0), C.c_long(0), hip._p(attw), B, T, H, C.c_void_p(0), 0), "attn_step_fwd")
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    avg_s = e0.elapsed_time(e1) / iters / 1e3
+    algo_bytes = B * (T * H + T * 2 * H) * 4.0          # keys + encoder outputs of every clip, read once per step (fp32)
+    achieved = algo_bytes / avg_s / 1e9
+    return {"bound": "hbm", "kernel": "attn_step_fwd<256>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 1),
+            "algorithmic_bytes_per_launch": int(algo_bytes)}
+
+
+def cpu_baseline(cfg, n_clips, seed):
+    """One training step of the oracle (as-written CPU restatement of the reference path) on the host cores."""
+    from oracle import model_ref, recipe_ref
+    from piano_a2s_amd import spec, synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = spec.procedural_state(cfg, 1)
+    P, Bf = spec.split_state(st)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    batch = synthetic.make_batch(n_clips, cfg, seed, full_tail=0.0)
+    gt = [batch[i] for i in range(1, 7)]
+    rng = random.Random(1234)
+    t0 = time.time()
+    outs = model_ref.forward(P, Bf, cfg, batch[0], inference=False, ground_truth=gt, teacher_forcing_ratio=TF_RATIO, training=True, rng=rng, dropout=True)
+    losses = recipe_ref.objectives(outs, (batch[1], batch[2], batch[3], batch[5]))
+    losses[0].backward()
+    grads = {k: p.grad for k, p in P.items()}
+    with torch.no_grad():
+        recipe_ref.train_step({k: p.data for k, p in P.items()}, grads, {}, float(losses[0]))
+    dt = time.time() - t0
+    return {"value": round(n_clips / dt, 5), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step (fwd+loss+bwd+clip+Adadelta) of the oracle on {n_clips} synthetic 12 s clip(s), fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")           # nccl == RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X: the transcription hot path has no CPU implementation"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234)
+    random.seed(1234 + rank)                               # python-random coin flips are per process
+
+    import models
+    from piano_a2s_amd import spec, synthetic, train
+    cfg = spec.default_cfg()
+    model = models.ScoreTranscription(**cfg).to(dev)
+    model.train()
+    if world > 1:                                          # identical replicas: broadcast rank 0's initial parameters
+        flat = model.flatten_()
+        dist.broadcast(flat, src=0)
+    step = train.TrainStep(model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True)
+    B = args.batch
+    batches = []
+    for i in range(min(2, args.steps + args.warmup)):      # a couple of distinct minibatches, resident in HBM before timing
+        b = synthetic.make_batch(B, cfg, 1234 + 1000 * rank + i, full_tail=args.full_tail)
+        batches.append([t.to(dev) if torch.is_tensor(t) else t for t in b])
+
+    def run(n):
+        for i in range(n):
+            step(batches[i % len(batches)], TF_RATIO)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(step.total)
+    if rank == 0:
+        clips = B * world * args.steps
+        out = {"metric": "training clips/sec (12 s, 5-bar)", "value": round(clips / elapsed, 3), "unit": "clips/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "pretrain.yaml model (16.36M params), 12 s clips = 1201x480 frames, 5 bars, max 398/189 tokens; "
+                                      "random-init weights; tf_ratio 0.7; dropout on; fwd+loss+bwd+clip+Adadelta",
+                          "per_gpu_batch": B, "global_batch": B * world, "upper_len": "U{20..120}", "lower_len": "U{10..80}",
+                          "full_length_tail": args.full_tail, "parallelism": f"dp{world}", "batchnorm": "per-rank statistics",
+                          "final_loss": round(loss, 4), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}}
+        out["roofline"] = attention_roofline(step, batches[0], B, 1201, cfg["hidden_size"])
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_clips, 1234)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,16 @@ int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float
                       float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
 
+/* ---- objective and optimizer of the recipe (pretrain.py:72-88,:125-128; pretrain.yaml:44-54)
+ * NLL, mean over targets != ignore_index (pass -1 for "none"): loss_out[0] = loss, loss_out[1] = 1/count;
+ * dlogp (zero-filled by the caller, or NULL) receives d(gscale*loss)/dlogp.  partial: 2*nblocks doubles. */
+int a2s_nll_loss(void* stream, const float* logp, const long long* target, long rows, int V, long long ignore_index,
+                 float* loss_out, float* dlogp, float gscale, double* partial, int nblocks);
+/* clip_grad_norm_(max_norm) + Adadelta over one flat buffer; skipped when *loss is not finite (NULL: always apply).
+ * ctl[0..2] = {total norm, clip coefficient, applied flag}; partial: nblocks doubles; zero_grad clears the gradients. */
+int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_avg, float* acc_delta, long n, const float* loss,
+                      float max_norm, float lr, float rho, float eps, float* ctl, double* partial, int nblocks, int zero_grad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,9 @@ size_t a2s_bn_bwd_partial_floats_impl(long, int, int);
 int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int);
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int, int);
 
+int a2s_nll_loss_impl(hipStream_t, const float*, const long long*, long, int, long long, float*, float*, float, double*, int);
+int a2s_clip_adadelta_impl(hipStream_t, float*, float*, float*, float*, long, const float*, float, float, float, float, float*, double*, int, int);
+
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -173,5 +176,14 @@ int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float
     return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout);
 }
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) { return a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout); }
+
+int a2s_nll_loss(void* stream, const float* logp, const long long* target, long rows, int V, long long ignore_index, float* loss_out,
+                 float* dlogp, float gscale, double* partial, int nblocks) {
+    return a2s_nll_loss_impl(ST, logp, target, rows, V, ignore_index, loss_out, dlogp, gscale, partial, nblocks);
+}
+int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_avg, float* acc_delta, long n, const float* loss, float max_norm,
+                      float lr, float rho, float eps, float* ctl, double* partial, int nblocks, int zero_grad) {
+    return a2s_clip_adadelta_impl(ST, params, grads, square_avg, acc_delta, n, loss, max_norm, lr, rho, eps, ctl, partial, nblocks, zero_grad);
+}
 
 }  // extern "C"

@@ -1,0 +1,111 @@
+"""The drop-in module and the fused training step on the MI355X vs the reference (golden fixtures):
+  * models.ScoreTranscription through plain torch autograd (loss.backward()) -> parameter .grad == reference gradients;
+  * piano_a2s_amd.train.TrainStep (HIP loss, backward, clip + Adadelta) -> parameters after ONE step == parameters after
+    the reference's step (torch.nn.utils.clip_grad_norm_(5.0) + torch.optim.Adadelta run on the reference model);
+  * non-finite loss skips the update (SpeechBrain check_gradients semantics)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SMALL_BATCH = dict(frames=41, upper_range=(3, 10), lower_range=(2, 7), full_tail=0.1)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def case(golden_dir):
+    from piano_a2s_amd import spec, synthetic
+    data = np.load(os.path.join(golden_dir, "g1_small.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g1_small.json")))
+    cfg = spec.default_cfg(**meta["cfg"])
+    batch = synthetic.make_batch(3, cfg, meta["batch_seed"], **SMALL_BATCH)
+    st = spec.procedural_state(cfg, 11, eos_bias=3.0, lively=True)
+    return data, cfg, batch, st
+
+
+def _model(cfg, st, dev):
+    import models
+    m = models.ScoreTranscription(**cfg)
+    m.load_state_dict(st)
+    return m.to(dev)
+
+
+def test_module_state_dict_and_autograd(case, dev, monkeypatch):
+    import torch.nn.functional as F
+    from piano_a2s_amd import spec
+    data, cfg, batch, st = case
+    m = _model(cfg, st, dev)
+    assert list(m.state_dict().keys()) == list(spec.state_spec(cfg).keys())
+    m.train()
+    # dropout off on the product side for this comparison: the engine draws masks itself, so patch its switch
+    from piano_a2s_amd import engine
+    orig = engine.Engine.forward
+    monkeypatch.setattr(engine.Engine, "forward", lambda self, *a, **k: orig(self, *a, **{**k, "dropout": False}))
+    gt = [b.to(dev) for b in batch[1:7]]
+    ts, key, up, lo = m(spectrogram=batch[0].to(dev), inference=False, ground_truth=gt, teacher_forcing_ratio=1.0, device=dev)
+    nll, nll_pad = torch.nn.NLLLoss(), torch.nn.NLLLoss(ignore_index=147)
+    loss = (nll(ts.permute(0, 2, 1), gt[0]) + nll(key.permute(0, 2, 1), gt[1])
+            + nll_pad(up.view(-1, up.shape[2], up.shape[3]).permute(0, 2, 1), gt[2].view(-1, gt[2].shape[2]))
+            + nll_pad(lo.view(-1, lo.shape[2], lo.shape[3]).permute(0, 2, 1), gt[4].view(-1, gt[4].shape[2])))
+    assert abs(float(loss) - data["train_tf1.losses"][0]) <= 1e-4 * data["train_tf1.losses"][0]
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        ref = data[f"train_tf1.grad.{k}"]
+        err = np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)
+        assert err <= 2e-4, f"{k}: {err:.3e}"
+
+
+def test_fused_step_matches_reference_step(case, dev):
+    from piano_a2s_amd import train
+    data, cfg, batch, st = case
+    m = _model(cfg, st, dev)
+    m.train()
+    step = train.TrainStep(m, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=False)
+    dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
+    losses = step(dbatch, teacher_forcing_ratio=1.0)
+    torch.cuda.synchronize()
+    got = losses[:, 0].cpu().numpy()
+    ref = data["train_tf1.losses"]
+    for i in range(4):
+        assert abs(got[i] - ref[i + 1]) <= 1e-4 * abs(ref[i + 1]), f"loss term {i}: {got[i]} vs {ref[i + 1]}"
+    ctl = step.opt.ctl.cpu().numpy()
+    assert abs(ctl[0] - float(data["step.total_norm"])) <= 2e-4 * float(data["step.total_norm"]), f"grad norm {ctl[0]}"
+    assert ctl[2] == 1.0
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref_p = data[f"step.param.{k}"]
+        err = np.abs(p.detach().cpu().numpy() - ref_p).max() / max(np.abs(ref_p).max(), 1e-12)
+        worst = max(worst, err)
+        assert err <= 1e-4, f"updated {k}: {err:.3e}"
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_errors.txt", "a") as f:
+        f.write(f"fused step: worst updated-parameter error {worst:.3e}, grad norm {ctl[0]} vs {float(data['step.total_norm'])}\n")
+
+
+def test_nonfinite_loss_skips_update(case, dev):
+    from piano_a2s_amd import train
+    data, cfg, batch, st = case
+    m = _model(cfg, st, dev)
+    flat = m.flatten_()
+    opt = train.FusedAdadelta(flat)
+    before = flat.clone()
+    g = torch.randn_like(flat)
+    bad = torch.tensor([float("nan")], device=dev)
+    opt.step(g, bad, zero_grad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, before) and float(opt.ctl[2]) == 0.0 and float(g.abs().sum()) == 0.0
+    good = torch.tensor([1.0], device=dev)
+    g = torch.randn_like(flat)
+    opt.step(g, good, zero_grad=False)
+    torch.cuda.synchronize()
+    assert not torch.equal(flat, before) and float(opt.ctl[2]) == 1.0
