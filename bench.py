@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--full-tail", type=float, default=0.0, help="probability of a full-length (no <eos>) row per (clip,bar,staff)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=1)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -73,11 +74,31 @@ def attention_roofline(step, batch_dev, B, T, H, iters=50):
             "algorithmic_bytes_per_launch": int(algo_bytes)}
 
 
+CPU_BASELINE_THREADS = 16      # intra-op threads for the oracle: its per-step ops are small, more threads only add sync cost
+CPU_BASELINE_TIMEOUT_S = 240   # hard bound: the default bench must finish in minutes whatever the host looks like
+
+
 def cpu_baseline(cfg, n_clips, seed):
+    """Run _cpu_baseline_child in a subprocess with a hard timeout (a slow or oversubscribed host must not stall the bench)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-clips", str(n_clips)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(min(os.cpu_count() or 1, CPU_BASELINE_THREADS)))
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=CPU_BASELINE_TIMEOUT_S, env=env, cwd=ROOT)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "clips/s", "cores": 0, "kind": "port", "sample": "child produced no result: " + r.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "clips/s", "cores": min(os.cpu_count() or 1, CPU_BASELINE_THREADS), "kind": "port",
+                "sample": f"oracle training step on {n_clips} clip(s) did not finish within {CPU_BASELINE_TIMEOUT_S} s"}
+
+
+def _cpu_baseline_child(cfg, n_clips, seed):
     """One training step of the oracle (as-written CPU restatement of the reference path) on the host cores."""
     from oracle import model_ref, recipe_ref
     from piano_a2s_amd import spec, synthetic
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(cores)
     st = spec.procedural_state(cfg, 1)
     P, Bf = spec.split_state(st)
@@ -99,6 +120,10 @@ def cpu_baseline(cfg, n_clips, seed):
 
 def main():
     args = parse()
+    if args.cpu_baseline_child:                            # CPU-only helper process: never touches the GPU
+        from piano_a2s_amd import spec
+        print(json.dumps(_cpu_baseline_child(spec.default_cfg(), args.cpu_clips, 1234)), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
