@@ -143,8 +143,7 @@ def main():
     model = models.ScoreTranscription(**cfg).to(dev)
     model.train()
     if world > 1:                                          # identical replicas: broadcast rank 0's initial parameters
-        flat = model.flatten_()
-        dist.broadcast(flat, src=0)
+        train.broadcast_parameters(model.flatten_(), src=0)
     step = train.TrainStep(model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True)
     B = args.batch
     batches = []

@@ -19,6 +19,22 @@ from . import engine, engine_bwd, hip
 from .spec import PAD, VOCAB_SIZE
 
 
+def average_gradients(flat_g, world):
+    """Data-parallel gradient exchange: SUM all-reduce of the flat gradient buffer, then / world (DDP semantics: every rank
+    contributes the gradient of ITS minibatch mean).  Backend-agnostic: RCCL (nccl) on GPUs, gloo in the CPU tests."""
+    if world > 1:
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+        flat_g.div_(world)
+    return flat_g
+
+
+def broadcast_parameters(flat_p, src=0):
+    """Make every replica start from rank `src`'s parameters (what DDP's constructor does)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_p, src=src)
+    return flat_p
+
+
 class Objective:
     """reference compute_objectives: NLLLoss on time signature and key, NLLLoss(ignore_index=<pad>) on both staves; total = sum."""
 
@@ -95,9 +111,7 @@ class TrainStep:
         losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
         G = engine_bwd.backward(eng, S, gouts)
         flat_g = G[None]
-        if self.world > 1:
-            dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
-            flat_g.div_(self.world)
+        average_gradients(flat_g, self.world)
         torch.sum(losses[:, 0], dim=0, keepdim=True, out=self.total)          # total loss stays on the device
         self.opt.step(flat_g, self.total, zero_grad=False)
         eng.saved = None
