@@ -70,7 +70,10 @@ int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_
  * score_t = v . tanh(K[b,t,:] + q[b,:]); a = softmax_t; ctx = sum_t a_t enc[b,t,:]. */
 int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v,
                       float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
-                      const int* n_done, int n_rows_total);
+                      const int* n_done, int n_rows_total, float* workspace);
+/* workspace (a2s_attn_workspace_floats floats, shared by forward and backward) selects the split-T kernels: the frames of a
+ * clip are spread over several workgroups and merged by a combine kernel; NULL (or hidden_size != 256) = one workgroup per clip. */
+size_t a2s_attn_workspace_floats(int B, int T, int H);
 
 int a2s_log_softmax_rows(void* stream, const float* x, long ldx, float* y, long ldy, int* argmax_out, int R, int V);
 int a2s_embed_rows(void* stream, const float* table, const long long* ids64, const int* ids32, long id_stride,
@@ -91,6 +94,7 @@ typedef struct a2s_note_dec_args {
     int* argmax_out; long am_bstride;
     int* eos_seen; long long* lengths; int* n_done;
     int* steps_exec;                  /* device counter: +1 per step that actually decoded (greedy early break) */
+    float* attn_ws;                   /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
     int R, T, H, E, V, steps, poll, eos_id;
 } a2s_note_dec_args;
 int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done);
@@ -115,7 +119,7 @@ int a2s_gru_gates_bwd(void* stream, const float* dh_a, long lda, const float* dh
 /* one attention step backward: dq, ds (T per row) and the summed dctx (see csrc/a2s_bwd.hip) */
 int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v,
                       const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
-                      long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H);
+                      long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* workspace);
 /* deferred key gradient of S steps: dK += ..., dv partials [B*ceil(T/16)][H] (reduce with a2s_col_sum) */
 int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
                       float* dv_partial, int B, int T, int S, int H);
@@ -132,6 +136,7 @@ typedef struct a2s_note_dec_bwd_args {
     const float* do_all;                 /* (steps, R, 4H): dlogits_all W_out = [dh | dctx] of the output projection */
     float* dgi_all; float* dgh_all; float* dq_all; float* ds_all; float* dctx_all; float* dx;
     float* dh;                           /* (2, R, 2H) carry; dh[0] = gradient wrt the initial hidden on return */
+    float* attn_ws;                      /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
     int R, T, H, E, steps;
 } a2s_note_dec_bwd_args;
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);

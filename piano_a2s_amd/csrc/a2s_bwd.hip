@@ -123,9 +123,15 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
     }
 }
 
+int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                                 const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
+                                 long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H);
+
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
-                           long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H) {
+                           long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws) {
+    if (H == 256 && ws)
+        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H);
     const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
     if (H == 256) hipLaunchKernelGGL(attn_step_bwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
     else if (H == 32) hipLaunchKernelGGL(attn_step_bwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
@@ -247,9 +253,6 @@ int a2s_ew_act_bwd_impl(hipStream_t st, const float* g, const float* y, float* d
 // Reverse of a2s_note_decoder_fwd for one (bar, staff); `steps` = steps the forward executed.
 // argument block: a2s_note_dec_bwd_args (single definition in include/a2s.h)
 
-int a2s_attn_step_bwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, const float*, const float*, long,
-                           const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int);
-
 int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
     hipError_t e = hipMemsetAsync(a.dh, 0, sizeof(float) * 2 * R * H2, st);
@@ -274,7 +277,7 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
         rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
                                     a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
                                     a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
-                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H);
+                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws);
         if (rc) return rc;
         // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
         rc = a2s_gemm_impl(st, R, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0);
@@ -420,5 +423,136 @@ int a2s_staff_emb_bwd_impl(hipStream_t st, const float* note_emb, const float* c
     hipLaunchKernelGGL(staff_emb_bwd, dim3(R, 2), dim3(128), shm, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
                        grads_dev, note_emb_grad, ids64, ids32, id_bstride, lengths, len_stride, dout, lddo, col0, hsave, maxlen, E, S);
     A2S_CHECK_LAUNCH("staff_emb_bwd");
+    return A2S_OK;
+}
+
+// =========================================================================================== split-T attention backward (H = 256)
+// Same decomposition as attn_fwd_split256: G workgroups per clip, each streams its chunk of enc (for da_t) and of K (for dq) once
+// with 16-byte loads; partial dq per (clip, g) merged by a small combine kernel.
+__global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                         const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                         const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
+                                                         const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
+                                                         float* __restrict__ dctx_out, long lddo, float* __restrict__ dq_partial,
+                                                         float* __restrict__ ds_out, int T, int G, int chunk) {
+    constexpr int H = 256;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dsv = sm;                                   // chunk
+    f32x4* red4 = reinterpret_cast<f32x4*>(sm + chunk);   // 3 * 64 float4
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Kb = Kmat + ((long)b * T + t0) * H;
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    // dctx held by every wave: lane owns columns [4*lane, 4*lane+4) and [256 + 4*lane, ...)
+    f32x4 dc0 = *reinterpret_cast<const f32x4*>(dctx_a + (long)b * ldda + lane * 4);
+    f32x4 dc1 = *reinterpret_cast<const f32x4*>(dctx_a + (long)b * ldda + H + lane * 4);
+    if (dctx_b) {
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(dctx_b + (long)b * lddb + lane * 4);
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(dctx_b + (long)b * lddb + H + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { dc0[c] += o0[c]; dc1[c] += o1[c]; }
+    }
+    if (dctx_out && g == 0 && wave == 0) {
+        *reinterpret_cast<f32x4*>(dctx_out + (long)b * lddo + lane * 4) = dc0;
+        *reinterpret_cast<f32x4*>(dctx_out + (long)b * lddo + H + lane * 4) = dc1;
+    }
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctx + (long)b * ldctx + lane * 4);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctx + (long)b * ldctx + H + lane * 4);
+    float dot_ctx = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dot_ctx += dc0[c] * c0[c] + dc1[c] * c1[c];
+    dot_ctx = wave_sum(dot_ctx);
+    // ---- pass A: da_t = dctx . enc_t, one wave per frame, 4 frames in flight
+    for (int r = wave * 4; r < n; r += 16) {
+        float s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[u] = 0.f;
+            if (r + u < n) {
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + lane * 4);
+                const f32x4 e1 = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + H + lane * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[u] += dc0[c] * e0[c] + dc1[c] * e1[c];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + u < n) {
+                    const float d_s = attw[(long)b * T + t0 + r + u] * (s[u] - dot_ctx);
+                    dsv[r + u] = d_s;
+                    if (ds_out) ds_out[(long)b * T + t0 + r + u] = d_s;
+                }
+        }
+    }
+    __syncthreads();
+    // ---- pass B: dq_j += ds_t (1 - tanh^2(K_tj + q_j)); thread = (float4 column, row group of 4)
+    const int c4 = tid & 63, rg = tid >> 6;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)b * ldq + c4 * 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int i = rg;
+    for (; i + 12 < n; i += 16) {
+        f32x4 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = *reinterpret_cast<const f32x4*>(Kb + (long)(i + 4 * u) * H + c4 * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float w = dsv[i + 4 * u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k[u][c] + q4[c]); acc[c] = fmaf(w, 1.f - e * e, acc[c]); }
+        }
+    }
+    for (; i < n; i += 4) {
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(Kb + (long)i * H + c4 * 4);
+        const float w = dsv[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k0[c] + q4[c]); acc[c] = fmaf(w, 1.f - e * e, acc[c]); }
+    }
+    if (rg > 0) red4[(rg - 1) * 64 + c4] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + c4 * 4);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const f32x4 o = red4[u * 64 + c4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += o[c]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] *= v4[c];
+        *reinterpret_cast<f32x4*>(dq_partial + ((long)b * G + g) * H + c4 * 4) = acc;
+    }
+}
+
+__global__ void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int B, int G) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 256) return;
+    const int b = idx >> 8, j = idx & 255;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += dq_partial[((long)b * G + g) * 256 + j];
+    dq[(long)b * lddq + j] = s;
+}
+
+
+int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                                 const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
+                                 long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H) {
+    A2S_REQUIRE(H == 256 && ws, "attn_step_bwd_split: needs hidden_size 256 and a workspace");
+    A2S_REQUIRE(ldq % 4 == 0 && ldctx % 4 == 0 && ldda % 4 == 0 && (!dctx_b || lddb % 4 == 0) && (!dctx_out || lddo % 4 == 0),
+                "attn_step_bwd_split: row strides must be multiples of 4 floats");
+    A2S_REQUIRE(((uintptr_t)q | (uintptr_t)ctx | (uintptr_t)dctx_a | (uintptr_t)dctx_b | (uintptr_t)dctx_out | (uintptr_t)Kmat | (uintptr_t)enc) % 16 == 0,
+                "attn_step_bwd_split: 16-byte alignment");
+    int G, chunk;
+    a2s_attn_split_geometry(B, T, &G, &chunk);
+    const size_t shm = (chunk + 3 * 64 * 4) * sizeof(float);
+    hipLaunchKernelGGL(attn_bwd_split256, dim3(B * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                       dctx_out, lddo, ws, ds_out, T, G, chunk);
+    A2S_CHECK_LAUNCH("attn_bwd_split256");
+    hipLaunchKernelGGL(attn_bwd_combine256, dim3(a2s_cdiv(B * 256, 256)), dim3(256), 0, st, ws, dq, lddq, B, G);
+    A2S_CHECK_LAUNCH("attn_bwd_combine256");
     return A2S_OK;
 }

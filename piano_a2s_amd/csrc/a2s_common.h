@@ -36,6 +36,18 @@ static inline int a2s_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Split of the T frames of a clip over G workgroups for the attention kernels (forward and backward must agree):
+// aim at ~768 workgroups (3 per CU) but never more than 16 chunks; chunk is a multiple of 4 frames.
+static inline void a2s_attn_split_geometry(int B, int T, int* G, int* chunk) {
+    int g = (768 + B - 1) / B;
+    if (g > 16) g = 16;
+    if (g < 1) g = 1;
+    int c = (T + g - 1) / g;
+    c = (c + 3) & ~3;
+    *G = (T + c - 1) / c;
+    *chunk = c;
+}
+
 // ----------------------------------------------------------------------------- device helpers
 #ifdef __HIPCC__
 #define A2S_WAVE 64

@@ -136,9 +136,15 @@ __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ K
     }
 }
 
+int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                                 float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
+                                 const int* n_done, int n_rows_total);
+
 int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
-                           const int* n_done, int n_rows_total) {
+                           const int* n_done, int n_rows_total, float* ws) {
+    if (H == 256 && ws)
+        return a2s_attn_step_fwd_split_impl(st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, ws, B, T, H, n_done, n_rows_total);
     const size_t shm = (((T + 3) & ~3) + 16) * sizeof(float);
     if (H == 256) hipLaunchKernelGGL(attn_step_fwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
     else if (H == 32) hipLaunchKernelGGL(attn_step_fwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
@@ -280,7 +286,7 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
         if (rc) return rc;
         // attention -> ctx into x[s][:, E:] and o[s][:, 2H:]
         rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
-                                    a.attw ? a.attw + (long)s * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R);
+                                    a.attw ? a.attw + (long)s * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws);
         if (rc) return rc;
         // gi = x W_ih^T + b_ih
         rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 1, nullptr, 0);
@@ -378,5 +384,139 @@ int a2s_staff_emb_fwd_impl(hipStream_t st, const float* note_emb, const float* c
     hipLaunchKernelGGL(staff_emb_fwd, dim3(R, 2), dim3(128), shm, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
                        ids64, ids32, id_bstride, lengths, len_stride, out, ldo, col0, hsave, maxlen, E, S);
     A2S_CHECK_LAUNCH("staff_emb_fwd");
+    return A2S_OK;
+}
+
+// =========================================================================================== split-T attention (H = 256)
+// The one-workgroup-per-clip kernel above is latency-bound (3.69 MB per workgroup, measured 15 GB/s per workgroup, 253 us per
+// launch whatever the batch).  Here the 1201 frames of a clip are split over G workgroups (flash-decoding style): each
+// streams its chunk of K and enc ONCE with 16-byte loads and produces a partial softmax (m_g, l_g, ctx_g); a small combine
+// kernel merges the G partials per clip.  Grid = B*G workgroups, G chosen so the grid is a few waves of the 256 CUs.
+//   partial layout per (clip, g): [m, l, pad, pad, ctx(2H)]  -> (2H + 4) floats
+__global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                         const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                         float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
+                                                         const int* __restrict__ n_done, int n_rows_total) {
+    if (n_done && *n_done >= n_rows_total) return;
+    constexpr int H = 256;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pw = sm;                                   // chunk weights exp(s - m_g)
+    float* red = sm + chunk;                          // 16 + 2 * 128 * 4 floats (reduction scratch)
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Kb = Kmat + ((long)b * T + t0) * H;
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)b * ldq + lane * 4);
+    const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + lane * 4);
+    // ---- pass 1: scores of the chunk; one wave per frame, 4 frames in flight per wave
+    for (int r = wave * 4; r < n; r += 16) {
+        f32x4 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            k[u] = (r + u < n) ? *reinterpret_cast<const f32x4*>(Kb + (long)(r + u) * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        float s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[u] = v4[0] * fast_tanh(k[u][0] + q4[0]) + v4[1] * fast_tanh(k[u][1] + q4[1])
+                 + v4[2] * fast_tanh(k[u][2] + q4[2]) + v4[3] * fast_tanh(k[u][3] + q4[3]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (r + u < n) pw[r + u] = s[u];
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, pw[i]);
+    m = block_max(m, red);
+    float l = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float sc = pw[i];
+        if (scores) scores[(long)b * T + t0 + i] = sc;       // raw score; normalised by the combine kernel
+        const float p = __expf(sc - m);
+        pw[i] = p; l += p;
+    }
+    l = block_sum(l, red);
+    __syncthreads();
+    // ---- pass 2: ctx_g = sum_i pw[i] * enc[i, :]; thread = (float4 column c4, row parity)
+    const int c4 = tid & 127, rp = tid >> 7;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int i = rp;
+    for (; i + 6 < n; i += 8) {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 0) * 2 * H + c4 * 4);
+        const f32x4 e1 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 2) * 2 * H + c4 * 4);
+        const f32x4 e2 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 4) * 2 * H + c4 * 4);
+        const f32x4 e3 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 6) * 2 * H + c4 * 4);
+        const float w0 = pw[i], w1 = pw[i + 2], w2 = pw[i + 4], w3 = pw[i + 6];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += w0 * e0[c] + w1 * e1[c] + w2 * e2[c] + w3 * e3[c];
+    }
+    for (; i < n; i += 2) {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)i * 2 * H + c4 * 4);
+        const float w0 = pw[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += w0 * e0[c];
+    }
+    f32x4* red4 = reinterpret_cast<f32x4*>(red + 16);
+    if (rp == 1) red4[c4] = acc;
+    __syncthreads();
+    float* pout = partial + ((long)b * G + g) * (2 * H + 4);
+    if (rp == 0) {
+        const f32x4 o = red4[c4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += o[c];
+        *reinterpret_cast<f32x4*>(pout + 4 + c4 * 4) = acc;
+    }
+    if (tid == 0) { pout[0] = m; pout[1] = l; }
+}
+
+// merge the G partials of a clip: ctx = sum_g ctx_g e^{m_g-m} / l ; optional normalisation of the saved weights
+__global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restrict__ partial, float* __restrict__ ctx, long ldctx,
+                                                           float* __restrict__ ctx2, long ldctx2, float* __restrict__ attw, int T, int G,
+                                                           const int* __restrict__ n_done, int n_rows_total) {
+    if (n_done && *n_done >= n_rows_total) return;
+    constexpr int H = 256;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pb = partial + (long)b * G * (2 * H + 4);
+    float m = -INFINITY;
+    for (int g = 0; g < G; ++g) m = fmaxf(m, pb[(long)g * (2 * H + 4)]);
+    float l = 0.f;
+    for (int g = 0; g < G; ++g) l += pb[(long)g * (2 * H + 4) + 1] * __expf(pb[(long)g * (2 * H + 4)] - m);
+    const float inv = 1.f / l;
+    for (int d = tid; d < 2 * H; d += 256) {
+        float acc = 0.f;
+        for (int g = 0; g < G; ++g) acc += pb[(long)g * (2 * H + 4) + 4 + d] * __expf(pb[(long)g * (2 * H + 4)] - m);
+        acc *= inv;
+        ctx[(long)b * ldctx + d] = acc;
+        if (ctx2) ctx2[(long)b * ldctx2 + d] = acc;
+    }
+    if (attw) for (int t = tid; t < T; t += 256) attw[(long)b * T + t] = __expf(attw[(long)b * T + t] - m) * inv;
+}
+
+
+size_t a2s_attn_workspace_floats_impl(int B, int T, int H) {
+    int G, chunk;
+    a2s_attn_split_geometry(B, T, &G, &chunk);
+    return (size_t)B * G * (2 * H + 4);
+}
+
+int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                                 float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
+                                 const int* n_done, int n_rows_total) {
+    A2S_REQUIRE(H == 256 && ws, "attn_step_fwd_split: needs hidden_size 256 and a workspace");
+    A2S_REQUIRE(ldq % 4 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)Kmat % 16 == 0) && ((uintptr_t)enc % 16 == 0), "attn_step_fwd_split: 16-byte alignment");
+    int G, chunk;
+    a2s_attn_split_geometry(B, T, &G, &chunk);
+    const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
+    hipLaunchKernelGGL(attn_fwd_split256, dim3(B * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, n_done, n_rows_total);
+    A2S_CHECK_LAUNCH("attn_fwd_split256");
+    hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, ws, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total);
+    A2S_CHECK_LAUNCH("attn_fwd_combine256");
     return A2S_OK;
 }

@@ -156,7 +156,7 @@ class Engine:
             record.append(dict(ids=ids, lengths=lengths, len_stride=len_stride, col0=col0, maxlen=maxlen, id_bstride=id_bstride,
                                i64=ids_are_i64, hsave=hsave))
 
-    def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T):
+    def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None):
         """One NoteDecoder.decode_notes call.  probs_bar: view (B, max_steps, V) of the output tensor (strided)."""
         L = hip.lib()
         H, E, V = self.cfg["hidden_size"], self.cfg["note_emb_size"], VOCAB_SIZE
@@ -192,7 +192,7 @@ class Engine:
                         ("b_hh", S[prefix + ".gru.bias_hh_l0"]), ("out_w", S[prefix + ".out.weight"]), ("out_b", S[prefix + ".out.bias"]),
                         ("emb", S[prefix + ".embedding.weight"]), ("keys", keys), ("enc", enc), ("h", h), ("x", x), ("q", q),
                         ("gates", gates), ("attw", attw), ("o", o), ("gh", gh), ("gi", gi), ("logits", logits),
-                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop)):
+                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws)):
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
         if gt_bar is not None:
@@ -260,6 +260,8 @@ class Engine:
 
         ldxb = tokw + 2 * H
         bar_saved = []
+        attn_ws = hip.attn_workspace(B, T, H, dev)          # scratch of the split-T attention kernels (reused by every step)
+        self._attn_ws = attn_ws
         for bar in range(bars):
             xbar = self._empty(B, ldxb, dev=dev)
             headin = self._empty(B, 4 * H, dev=dev)
@@ -277,7 +279,8 @@ class Engine:
             hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys["decoder"]), hip._p(enc), hip._p(qb), C.c_long(H),
                                           hip._p(S["decoder.attn.v.weight"]), C.c_void_p(xbar.data_ptr() + 4 * tokw), C.c_long(ldxb),
                                           C.c_void_p(headin.data_ptr() + 4 * 2 * H), C.c_long(4 * H), hip._p(attw), B, T, H,
-                                          C.c_void_p(0), 0), "a2s_attn_step_fwd")
+                                          C.c_void_p(0), 0, C.c_void_p(0)), "a2s_attn_step_fwd")   # 5 calls per forward: one-WG-per-clip kernel
+            # (the bar-level GRU input row [token(141) | ctx] has an odd stride, which the 16-byte-load split kernels reject)
             gi = hip.linear(xbar, S["decoder.gru.weight_ih_l0"], S["decoder.gru.bias_ih_l0"])
             gh = hip.linear(hidden, S["decoder.gru.weight_hh_l0"], S["decoder.gru.bias_hh_l0"])
             hnew = self._empty(B, 2 * H, dev=dev)
@@ -295,7 +298,7 @@ class Engine:
                 else:
                     steps, plan_len, flags, gt_bar = maxs, None, None, None
                 ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
-                                                      training, 0.1 if drop_on else 0.0, B, T)
+                                                      training, 0.1 if drop_on else 0.0, B, T, attn_ws)
                 if gt_cpu is None:
                     for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference
                         rng.random()
@@ -333,6 +336,6 @@ class Engine:
                                   next_ids=(ts_ids, key_ids, i64, stride)))
             hidden = hnew
         self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, enc_out=enc, sos_rec=sos_rec, training=training,
-                          outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
+                          attn_ws=attn_ws, outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
                           shape=(B, T, F), drop_on=drop_on)
         return ts_out, key_out, up_out, lo_out

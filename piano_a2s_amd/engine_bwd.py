@@ -94,8 +94,8 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),
                     ("w_hh", S[prefix + ".gru.weight_hh_l0"]), ("keys", keys), ("enc", enc), ("h", sv["h"]), ("x", sv["x"]), ("q", sv["q"]),
                     ("gates", sv["gates"]), ("attw", sv["attw"]), ("do_all", do_all), ("dgi_all", dgi_all), ("dgh_all", dgh_all),
-                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh)):
-        setattr(a, name, t.data_ptr())
+                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", eng.saved["attn_ws"])):
+        setattr(a, name, t.data_ptr() if t is not None else None)
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) deferred weight gradients over all steps
@@ -199,7 +199,7 @@ def backward(eng, S, grad_outputs):
         dctx = torch.empty((1, B, H2), device=dev)
         hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(sv["keys"]["decoder"]), hip._p(enc), hip._p(b["qb"]), C.c_long(H), hip._p(S["decoder.attn.v.weight"]),
                                       hip._p(b["attw"]), _ptr(b["xbar"], tokw), C.c_long(ldxb), _ptr(d_xbar, tokw), C.c_long(ldxb), _ptr(d_headin, H2),
-                                      C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), B, T, H), "attn bwd bar")
+                                      C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), B, T, H, NULL), "attn bwd bar")
         Wa = S["decoder.attn.attn.weight"]
         hip.gemm(dq, H, 1, Wa, 4 * H, 1, dhp, H2, B, H2, H, beta=1.0)                              # d hprev += dq W_h
         hip.gemm(dq, 1, H, b["hprev"], H2, 1, G["decoder.attn.attn.weight"], 4 * H, H, H2, B, beta=1.0)   # dW_h += dq^T hprev

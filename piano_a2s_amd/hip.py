@@ -24,7 +24,7 @@ class NoteDecArgs(C.Structure):
         ("tf_flags", C.c_void_p),
         ("drop", C.c_void_p), ("inv_keep", C.c_float),
         ("argmax_out", C.c_void_p), ("am_bstride", C.c_long),
-        ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p),
+        ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p), ("attn_ws", C.c_void_p),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
         ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int)]
 
@@ -33,7 +33,7 @@ class NoteDecBwdArgs(C.Structure):
     """Mirror of `a2s_note_dec_bwd_args` (include/a2s.h) -- same members, same order."""
     _fields_ = [(n, C.c_void_p) for n in (
         "attn_w", "attn_v", "w_ih", "w_hh", "keys", "enc", "h", "x", "q", "gates", "attw", "do_all",
-        "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh")] + [
+        "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh", "attn_ws")] + [
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int)]
 
 
@@ -45,7 +45,7 @@ def lib():
                            "There is no CPU fallback for the transcription hot path.")
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
-        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes"):
+        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
     return _lib
 
@@ -59,6 +59,13 @@ def _p(t):
     if not t.is_cuda:
         raise A2SError("liba2s_hip operates on device memory only: got a CPU tensor (no CPU fallback exists)")
     return C.c_void_p(t.data_ptr())
+
+
+def attn_workspace(B, T, H, device):
+    """Scratch for the split-T attention kernels (None when the one-workgroup-per-clip kernels are used)."""
+    if H != 256:
+        return None
+    return torch.empty(lib().a2s_attn_workspace_floats(B, T, H), dtype=torch.float32, device=device)
 
 
 def stream():

@@ -61,8 +61,8 @@ def test_gru_gates_bwd(dev):
     assert e < 1e-5, e
 
 
-@pytest.mark.parametrize("H,T,B,S", [(32, 41, 3, 4), (256, 1201, 2, 3)])
-def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S):
+@pytest.mark.parametrize("H,T,B,S,split", [(32, 41, 3, 4, False), (256, 1201, 2, 3, False), (256, 1201, 2, 3, True), (256, 1201, 70, 2, True), (256, 37, 300, 2, True)])
+def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S, split):
     """S steps with different queries through one attention layer: dq per step, deferred dK / dv / dEnc."""
     from piano_a2s_amd import hip
     L = hip.lib()
@@ -86,11 +86,12 @@ def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S):
     ctx_all = torch.stack(ctxs).to(dev)
     dctx_all = torch.stack(dctxs).to(dev)
     dq_all, ds_all = torch.empty(S, B, H, device=dev), torch.empty(S, B, T, device=dev)
+    ws = hip.attn_workspace(B, T, H, dev) if split else None
     for s in range(S):
         hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(Kd), hip._p(encd), C.c_void_p(q_all[s].data_ptr()), C.c_long(H), hip._p(vd),
                                       C.c_void_p(attw[s].data_ptr()), C.c_void_p(ctx_all[s].data_ptr()), C.c_long(2 * H),
                                       C.c_void_p(dctx_all[s].data_ptr()), C.c_long(2 * H), NULL, C.c_long(0), NULL, C.c_long(0),
-                                      C.c_void_p(dq_all[s].data_ptr()), C.c_long(H), C.c_void_p(ds_all[s].data_ptr()), B, T, H), "attn bwd")
+                                      C.c_void_p(dq_all[s].data_ptr()), C.c_long(H), C.c_void_p(ds_all[s].data_ptr()), B, T, H, hip._p(ws)), "attn bwd")
     dK = torch.zeros(B, T, H, device=dev)
     nblk = L.a2s_attn_dk_blocks(B, T)
     dvp = torch.zeros(nblk, H, device=dev)
@@ -103,7 +104,7 @@ def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S):
     torch.cuda.synchronize()
     errs = {"dq": max(_rel(dq_all[s], qs[s].grad) for s in range(S)), "dK": _rel(dK, K.grad), "dv": _rel(dv, v.grad), "dEnc": _rel(dEnc, enc.grad)}
     for k, e in errs.items():
-        _report(f"attention H{H} {k}", e)
+        _report(f"attention H{H} B{B} T{T} split={split} {k}", e)
     assert max(errs.values()) < 5e-5, errs
 
 

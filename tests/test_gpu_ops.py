@@ -166,8 +166,8 @@ def test_bn_finalize_matches_oracle_batch_norm(dev, training):
         assert _rel(Bd[k].float(), Bf[k].float()) < 1e-5, k
 
 
-@pytest.mark.parametrize("H,T,B", [(32, 41, 3), (256, 1201, 2)])
-def test_attention_step(dev, H, T, B):
+@pytest.mark.parametrize("H,T,B,split", [(32, 41, 3, False), (256, 1201, 2, False), (256, 1201, 2, True), (256, 1201, 70, True), (256, 37, 300, True)])
+def test_attention_step(dev, H, T, B, split):
     from piano_a2s_amd import hip
     L = hip.lib()
     g = torch.Generator().manual_seed(H + T)
@@ -188,12 +188,13 @@ def test_attention_step(dev, H, T, B):
     hip.gemm(hd, 2 * H, 1, Wd, 1, 4 * H, q, H, B, H, 2 * H, bias=biasd)
     ctx = torch.empty(B, 2 * H, device=dev)
     attw = torch.empty(B, T, device=dev)
+    ws = hip.attn_workspace(B, T, H, dev) if split else None
     hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys), hip._p(encd), hip._p(q), C.c_long(H), hip._p(vd), hip._p(ctx),
-                                  C.c_long(2 * H), C.c_void_p(0), C.c_long(0), hip._p(attw), B, T, H, C.c_void_p(0), 0), "attn")
+                                  C.c_long(2 * H), C.c_void_p(0), C.c_long(0), hip._p(attw), B, T, H, C.c_void_p(0), 0, hip._p(ws)), "attn")
     torch.cuda.synchronize()
     e1, e2 = _rel(attw, a_ref), _rel(ctx, ctx_ref)
-    _report(f"attention H{H} T{T} weights", e1)
-    _report(f"attention H{H} T{T} context", e2)
+    _report(f"attention H{H} T{T} B{B} split={split} weights", e1)
+    _report(f"attention H{H} T{T} B{B} split={split} context", e2)
     assert e1 < 2e-5 and e2 < 2e-5, (e1, e2)
 
 
