@@ -33,7 +33,8 @@ int a2s_version(void);
 
 /* ---- dense contraction: every nn.Linear / GRU projection of models.py (:68,:123-132,:359,:444-445,:504) and
  * their backward forms.  C[m,n] = act(alpha * sum_k A(m,k) B(k,n) + beta*C + bias[n]);
- * A(m,k)=A[m*sAm+k*sAk], B(k,n)=B[k*sBk+n*sBn]; act 0 none / 1 relu / 2 tanh; split-K is deterministic. */
+ * A(m,k)=A[m*sAm+k*sAk], B(k,n)=B[k*sBk+n*sBn]; act 0 none / 1 relu / 2 tanh; split-K is deterministic
+ * (splitk 0 = pick automatically for skinny problems when a workspace is supplied). */
 int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
                  int batch, long bsA, long bsB, long bsC, int splitk, float* workspace, size_t workspace_bytes);
@@ -95,6 +96,7 @@ typedef struct a2s_note_dec_args {
     int* eos_seen; long long* lengths; int* n_done;
     int* steps_exec;                  /* device counter: +1 per step that actually decoded (greedy early break) */
     float* attn_ws;                   /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
+    float* gemm_ws; size_t gemm_ws_bytes;   /* split-K scratch for the per-step skinny GEMMs (NULL: no split-K) */
     int R, T, H, E, V, steps, poll, eos_id;
 } a2s_note_dec_args;
 int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done);
@@ -137,6 +139,7 @@ typedef struct a2s_note_dec_bwd_args {
     float* dgi_all; float* dgh_all; float* dq_all; float* ds_all; float* dctx_all; float* dx;
     float* dh;                           /* (2, R, 2H) carry; dh[0] = gradient wrt the initial hidden on return */
     float* attn_ws;                      /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
+    float* gemm_ws; size_t gemm_ws_bytes;   /* split-K scratch for the per-step skinny GEMMs (NULL: no split-K) */
     int R, T, H, E, steps;
 } a2s_note_dec_bwd_args;
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);

@@ -220,7 +220,21 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
                   int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes) {
     if (M <= 0 || N <= 0 || batch <= 0) return A2S_OK;
     A2S_REQUIRE(K >= 0 && A && B && C, "gemm: null operand or negative K");
-    A2S_REQUIRE(splitk >= 1, "gemm: splitk must be >= 1");
+    A2S_REQUIRE(splitk >= 0, "gemm: splitk must be >= 0 (0 = choose automatically when a workspace is given)");
+    if (splitk == 0) {
+        // Skinny per-step products (M = batch rows, K up to 1792): a handful of output tiles would leave most of the 256 CUs
+        // idle and serialise 50+ K-tiles behind one barrier each; spread K over workgroups instead (deterministic reduce).
+        splitk = 1;
+        const long bm = M <= 16 ? 16 : (M <= 32 ? 32 : 64), bn = M <= 64 ? (M <= 16 ? 64 : (M <= 32 ? 64 : 32)) : 64;
+        const long tiles = (long)a2s_cdiv(M, bm) * a2s_cdiv(N, bn) * batch;
+        if (ws && M <= 64 && tiles < 192 && K >= 256) {
+            long s = (256 + tiles - 1) / tiles;
+            if (s > K / 64) s = K / 64;
+            if (s > 16) s = 16;
+            while (s > 1 && a2s_gemm_workspace_bytes_impl(M, N, batch, (int)s) > ws_bytes) --s;
+            if (s > 1) splitk = (int)s;
+        }
+    }
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.act = act;
@@ -239,6 +253,7 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
 
     if (M <= 16) launch_cfg<16, 64, 1, 4>(g, akc, bkc, st);
     else if (M <= 32) launch_cfg<32, 64, 2, 2>(g, akc, bkc, st);
+    else if (M <= 64) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);
     else if ((long)a2s_cdiv(M, 128) * a2s_cdiv(N, 128) * batch * splitk >= 192) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);
     else launch_cfg<64, 64, 2, 2>(g, akc, bkc, st);
     A2S_CHECK_LAUNCH("gemm_f32_kernel");

@@ -279,24 +279,24 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
         float* os = a.o + (long)s * a.R * 2 * H2;
         int rc;
         // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
-        rc = a2s_gemm_impl(st, a.R, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        rc = a2s_gemm_impl(st, a.R, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         // gh = h W_hh^T + b_hh
-        rc = a2s_gemm_impl(st, a.R, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        rc = a2s_gemm_impl(st, a.R, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         // attention -> ctx into x[s][:, E:] and o[s][:, 2H:]
         rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
                                     a.attw ? a.attw + (long)s * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws);
         if (rc) return rc;
         // gi = x W_ih^T + b_ih
-        rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         // h' -> h[s+1] and o[s][:, :2H]
         rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
                                     a.gates ? a.gates + (long)s * a.R * 4 * H2 : nullptr, a.R, H2);
         if (rc) return rc;
         // logits = o W_out^T + b_out
-        rc = a2s_gemm_impl(st, a.R, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        rc = a2s_gemm_impl(st, a.R, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         StepFinArgs f;
         f.logits = a.logits; f.ldl = a.V; f.probs = a.probs; f.probs_bstride = a.probs_bstride;

@@ -192,8 +192,9 @@ class Engine:
                         ("b_hh", S[prefix + ".gru.bias_hh_l0"]), ("out_w", S[prefix + ".out.weight"]), ("out_b", S[prefix + ".out.bias"]),
                         ("emb", S[prefix + ".embedding.weight"]), ("keys", keys), ("enc", enc), ("h", h), ("x", x), ("q", q),
                         ("gates", gates), ("attw", attw), ("o", o), ("gh", gh), ("gi", gi), ("logits", logits),
-                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws)):
+                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", self._gemm_ws)):
             setattr(a, name, t.data_ptr() if t is not None else None)
+        a.gemm_ws_bytes = self._gemm_ws.numel() * 4
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
         if gt_bar is not None:
             a.gt, a.gt_bstride = gt_bar.data_ptr(), gt_bar.stride(0)
@@ -262,6 +263,7 @@ class Engine:
         bar_saved = []
         attn_ws = hip.attn_workspace(B, T, H, dev)          # scratch of the split-T attention kernels (reused by every step)
         self._attn_ws = attn_ws
+        self._gemm_ws = hip.gemm_workspace(B, dev)
         for bar in range(bars):
             xbar = self._empty(B, ldxb, dev=dev)
             headin = self._empty(B, 4 * H, dev=dev)
@@ -336,6 +338,6 @@ class Engine:
                                   next_ids=(ts_ids, key_ids, i64, stride)))
             hidden = hnew
         self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, enc_out=enc, sos_rec=sos_rec, training=training,
-                          attn_ws=attn_ws, outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
+                          attn_ws=attn_ws, gemm_ws=self._gemm_ws, outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
                           shape=(B, T, F), drop_on=drop_on)
         return ts_out, key_out, up_out, lo_out

@@ -94,8 +94,9 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),
                     ("w_hh", S[prefix + ".gru.weight_hh_l0"]), ("keys", keys), ("enc", enc), ("h", sv["h"]), ("x", sv["x"]), ("q", sv["q"]),
                     ("gates", sv["gates"]), ("attw", sv["attw"]), ("do_all", do_all), ("dgi_all", dgi_all), ("dgh_all", dgh_all),
-                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", eng.saved["attn_ws"])):
+                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", eng.saved["attn_ws"]), ("gemm_ws", eng.saved["gemm_ws"])):
         setattr(a, name, t.data_ptr() if t is not None else None)
+    a.gemm_ws_bytes = eng.saved["gemm_ws"].numel() * 4
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) deferred weight gradients over all steps

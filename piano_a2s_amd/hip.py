@@ -25,6 +25,7 @@ class NoteDecArgs(C.Structure):
         ("drop", C.c_void_p), ("inv_keep", C.c_float),
         ("argmax_out", C.c_void_p), ("am_bstride", C.c_long),
         ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p), ("attn_ws", C.c_void_p),
+        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
         ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int)]
 
@@ -33,7 +34,8 @@ class NoteDecBwdArgs(C.Structure):
     """Mirror of `a2s_note_dec_bwd_args` (include/a2s.h) -- same members, same order."""
     _fields_ = [(n, C.c_void_p) for n in (
         "attn_w", "attn_v", "w_ih", "w_hh", "keys", "enc", "h", "x", "q", "gates", "attw", "do_all",
-        "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh", "attn_ws")] + [
+        "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh", "attn_ws", "gemm_ws")] + [
+        ("gemm_ws_bytes", C.c_size_t),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int)]
 
 
@@ -66,6 +68,11 @@ def attn_workspace(B, T, H, device):
     if H != 256:
         return None
     return torch.empty(lib().a2s_attn_workspace_floats(B, T, H), dtype=torch.float32, device=device)
+
+
+def gemm_workspace(rows, device):
+    """Split-K scratch for the per-step skinny GEMMs of the decoder loops (16 slabs of rows x 2048 floats)."""
+    return torch.empty(16 * max(rows, 1) * 2048, dtype=torch.float32, device=device)
 
 
 def stream():
