@@ -126,7 +126,9 @@ int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const f
 int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
                       float* dv_partial, int B, int T, int S, int H);
 int a2s_attn_dk_blocks(int B, int T);
-int a2s_col_sum(void* stream, const float* x, long ld, float* out, long rows, int C, float alpha, float beta);
+/* out[c] = alpha * sum_r x[r*ld+c] + beta*out[c]; with a workspace (>= 2*C floats, ideally 1024*C) long matrices are reduced in two
+ * stages over many workgroups (fixed partition: deterministic). */
+int a2s_col_sum(void* stream, const float* x, long ld, float* out, long rows, int C, float alpha, float beta, float* workspace, size_t workspace_floats);
 int a2s_embed_scatter_add(void* stream, float* table_grad, const long long* ids64, const int* ids32, long id_stride,
                           int const_id, const float* g, long ldg, int col0, int R, int E, const uint8_t* keep_mask, float inv_keep);
 int a2s_ew_act_bwd(void* stream, const float* g, const float* y, float* dx, long n, int act);

@@ -35,7 +35,7 @@ int a2s_gru_gates_bwd_impl(hipStream_t, const float*, long, const float*, long, 
 int a2s_attn_step_bwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, const float*, const float*, long,
                            const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int, float*);
 int a2s_attn_dk_accum_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int);
-int a2s_col_sum_impl(hipStream_t, const float*, long, float*, long, int, float, float);
+int a2s_col_sum_impl(hipStream_t, const float*, long, float*, long, int, float, float, float*, size_t);
 int a2s_embed_scatter_add_impl(hipStream_t, float*, const long long*, const int*, long, int, const float*, long, int, int, int, const uint8_t*, float);
 int a2s_ew_act_bwd_impl(hipStream_t, const float*, const float*, float*, long, int);
 int a2s_note_decoder_bwd_impl(hipStream_t, const a2s_note_dec_bwd_args&);
@@ -142,8 +142,8 @@ int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const
     return a2s_attn_dk_accum_impl(ST, keys, q_all, ds_all, v, dK, dv_partial, B, T, S, H);
 }
 int a2s_attn_dk_blocks(int B, int T) { return B * ((T + 15) / 16); }
-int a2s_col_sum(void* stream, const float* x, long ld, float* out, long rows, int C, float alpha, float beta) {
-    return a2s_col_sum_impl(ST, x, ld, out, rows, C, alpha, beta);
+int a2s_col_sum(void* stream, const float* x, long ld, float* out, long rows, int C, float alpha, float beta, float* workspace, size_t workspace_floats) {
+    return a2s_col_sum_impl(ST, x, ld, out, rows, C, alpha, beta, workspace, workspace_floats);
 }
 int a2s_embed_scatter_add(void* stream, float* table_grad, const long long* ids64, const int* ids32, long id_stride, int const_id,
                           const float* g, long ldg, int col0, int R, int E, const uint8_t* keep_mask, float inv_keep) {

@@ -208,7 +208,34 @@ __global__ __launch_bounds__(256) void col_sum(const float* __restrict__ x, long
     }
 }
 
-int a2s_col_sum_impl(hipStream_t st, const float* x, long ld, float* out, long rows, int C, float alpha, float beta) {
+// stage 1 of the two-stage form: partial[rb][c] = sum of rows [rb*rpb, (rb+1)*rpb) -- grid (column blocks, row blocks)
+__global__ __launch_bounds__(256) void col_sum_partial(const float* __restrict__ x, long ld, float* __restrict__ partial, long rows, int C, long rpb) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+    __shared__ float red[4][64];
+    float s = 0.f;
+    if (c < C) for (long r = r0 + part; r < r1; r += 4) s += x[r * ld + c];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < C)
+        partial[(long)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+int a2s_col_sum_impl(hipStream_t st, const float* x, long ld, float* out, long rows, int C, float alpha, float beta, float* ws, size_t ws_floats) {
+    // long matrices: spread the rows over many workgroups first (fixed partition -> deterministic), then sum the partials
+    if (ws && rows >= 2048 && ws_floats >= (size_t)2 * C) {
+        long nb = (rows + 511) / 512;
+        if (nb > 1024) nb = 1024;
+        if ((size_t)nb * C > ws_floats) nb = (long)(ws_floats / C);
+        const long rpb = (rows + nb - 1) / nb;
+        nb = (rows + rpb - 1) / rpb;
+        hipLaunchKernelGGL(col_sum_partial, dim3(a2s_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, x, ld, ws, rows, C, rpb);
+        A2S_CHECK_LAUNCH("col_sum_partial");
+        hipLaunchKernelGGL(col_sum, dim3(a2s_cdiv(C, 64)), dim3(256), 0, st, ws, (long)C, out, nb, C, alpha, beta);
+        A2S_CHECK_LAUNCH("col_sum");
+        return A2S_OK;
+    }
     hipLaunchKernelGGL(col_sum, dim3(a2s_cdiv(C, 64)), dim3(256), 0, st, x, ld, out, rows, C, alpha, beta);
     A2S_CHECK_LAUNCH("col_sum");
     return A2S_OK;

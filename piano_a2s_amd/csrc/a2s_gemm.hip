@@ -227,7 +227,7 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
         splitk = 1;
         const long bm = M <= 16 ? 16 : (M <= 32 ? 32 : 64), bn = M <= 64 ? (M <= 16 ? 64 : (M <= 32 ? 64 : 32)) : 64;
         const long tiles = (long)a2s_cdiv(M, bm) * a2s_cdiv(N, bn) * batch;
-        if (ws && M <= 64 && tiles < 192 && K >= 256) {
+        if (ws && tiles < 192 && K >= 256) {
             long s = (256 + tiles - 1) / tiles;
             if (s > K / 64) s = K / 64;
             if (s > 16) s = 16;

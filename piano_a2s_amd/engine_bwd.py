@@ -21,9 +21,17 @@ def _ptr(t, off=0):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
+_COLSUM_WS = {}
+
+
 def _colsum(x, ld, out, rows, ncol, x_off=0, out_off=0, beta=1.0):
+    ws = None
+    if rows >= 2048:                                  # two-stage reduction scratch, one buffer per device, reused
+        ws = _COLSUM_WS.get(x.device)
+        if ws is None or ws.numel() < 1024 * ncol:
+            ws = _COLSUM_WS[x.device] = torch.empty(1024 * max(ncol, 2048), dtype=torch.float32, device=x.device)
     hip.check(hip.lib().a2s_col_sum(hip.stream(), _ptr(x, x_off), C.c_long(ld), _ptr(out, out_off), C.c_long(rows), ncol,
-                                    hip.f32(1.0), hip.f32(beta)), "a2s_col_sum")
+                                    hip.f32(1.0), hip.f32(beta), hip._p(ws), C.c_size_t(ws.numel() if ws is not None else 0)), "a2s_col_sum")
 
 
 def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0):

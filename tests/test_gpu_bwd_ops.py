@@ -97,7 +97,7 @@ def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S, split):
     dvp = torch.zeros(nblk, H, device=dev)
     hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(Kd), hip._p(q_all), hip._p(ds_all), hip._p(vd), hip._p(dK), hip._p(dvp), B, T, S, H), "dk")
     dv = torch.zeros(H, device=dev)
-    hip.check(L.a2s_col_sum(hip.stream(), hip._p(dvp), C.c_long(H), hip._p(dv), C.c_long(nblk), H, hip.f32(1.0), hip.f32(0.0)), "col_sum")
+    hip.check(L.a2s_col_sum(hip.stream(), hip._p(dvp), C.c_long(H), hip._p(dv), C.c_long(nblk), H, hip.f32(1.0), hip.f32(0.0), NULL, C.c_size_t(0)), "col_sum")
     # deferred dEnc[b] = sum_s a_s[b]^T dctx_s[b]  as one batched GEMM (T x S)(S x 2H)
     dEnc = torch.zeros(B, T, 2 * H, device=dev)
     hip.gemm(attw, 1, B * T, dctx_all, B * 2 * H, 1, dEnc, 2 * H, T, 2 * H, S, batch=B, bsA=T, bsB=2 * H, bsC=T * 2 * H)
@@ -106,6 +106,25 @@ def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S, split):
     for k, e in errs.items():
         _report(f"attention H{H} B{B} T{T} split={split} {k}", e)
     assert max(errs.values()) < 5e-5, errs
+
+
+def test_col_sum_two_stage(dev):
+    """Long matrices go through the two-stage (partial slabs + final) reduction; alpha/beta semantics must be unchanged."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(12)
+    rows, Cc, ld = 50011, 300, 320
+    x = torch.randn(rows, ld, generator=g)
+    out0 = torch.randn(Cc, generator=g)
+    ref = 0.5 * x[:, :Cc].double().sum(0) + 2.0 * out0.double()
+    xd, outd = x.to(dev), out0.to(dev)
+    ws = torch.empty(1024 * Cc, device=dev)
+    hip.check(L.a2s_col_sum(hip.stream(), hip._p(xd), C.c_long(ld), hip._p(outd), C.c_long(rows), Cc, hip.f32(0.5), hip.f32(2.0), hip._p(ws),
+                            C.c_size_t(ws.numel())), "col_sum 2-stage")
+    torch.cuda.synchronize()
+    e = _rel(outd, ref.float())
+    _report("col_sum two-stage", e)
+    assert e < 2e-5, e
 
 
 def test_log_softmax_bwd_colsum_scatter(dev):
@@ -124,7 +143,7 @@ def test_log_softmax_bwd_colsum_scatter(dev):
                                          steps, hip._p(dx), B * steps, V, B, 1), "lsm bwd")
     ref = x.grad[:, bar, :steps].permute(1, 0, 2)
     cs = torch.zeros(V, device=dev)
-    hip.check(L.a2s_col_sum(hip.stream(), hip._p(dx), C.c_long(V), hip._p(cs), C.c_long(steps * B), V, hip.f32(1.0), hip.f32(0.0)), "col_sum")
+    hip.check(L.a2s_col_sum(hip.stream(), hip._p(dx), C.c_long(V), hip._p(cs), C.c_long(steps * B), V, hip.f32(1.0), hip.f32(0.0), NULL, C.c_size_t(0)), "col_sum")
     # embedding scatter with duplicate ids and a keep mask
     E, R = 16, 40
     ids = torch.randint(0, 9, (R,), generator=g)
@@ -256,9 +275,9 @@ def test_gru_sequence_bptt(dev):
         dWhh = torch.zeros(3 * H, H, device=dev)
         hip.gemm(dghs.view(B * T, 3 * H), 1, 3 * H, out, 2 * H, 1, dWhh, H, 3 * H, H, B * T, b_off=d * H)   # dW_hh = dgh_shift^T out[:, dir half]
         dbih, dbhh = torch.zeros(3 * H, device=dev), torch.zeros(3 * H, device=dev)
-        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dgi2), C.c_long(3 * H), hip._p(dbih), C.c_long(B * T), 3 * H, hip.f32(1.0), hip.f32(0.0)), "cs")
-        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dghs), C.c_long(3 * H), hip._p(dbhh), C.c_long(B * T), 3 * H, hip.f32(1.0), hip.f32(0.0)), "cs")
-        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dgh_first), C.c_long(3 * H), hip._p(dbhh), C.c_long(B), 3 * H, hip.f32(1.0), hip.f32(1.0)), "cs")
+        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dgi2), C.c_long(3 * H), hip._p(dbih), C.c_long(B * T), 3 * H, hip.f32(1.0), hip.f32(0.0), NULL, C.c_size_t(0)), "cs")
+        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dghs), C.c_long(3 * H), hip._p(dbhh), C.c_long(B * T), 3 * H, hip.f32(1.0), hip.f32(0.0), NULL, C.c_size_t(0)), "cs")
+        hip.check(L.a2s_col_sum(hip.stream(), hip._p(dgh_first), C.c_long(3 * H), hip._p(dbhh), C.c_long(B), 3 * H, hip.f32(1.0), hip.f32(1.0), NULL, C.c_size_t(0)), "cs")
         hip.gemm(dgi2, 3 * H, 1, Pd[f"g.weight_ih_{sfx}"], I, 1, dX, I, B * T, I, 3 * H, beta=1.0)       # dX += dgi W_ih
         torch.cuda.synchronize()
         errs = {"dW_ih": _rel(dWih, P[f"g.weight_ih_{sfx}"].grad), "dW_hh": _rel(dWhh, P[f"g.weight_hh_{sfx}"].grad),
