@@ -1,0 +1,161 @@
+"""The training recipe: a Brain subclass with the reference's hooks (reference pretrain.py:31-214 / finetune.py:30-193).
+
+Shared by pretrain.py and finetune.py (they differ in the teacher-forcing schedule, the clip id and the result record).
+`fit_batch` keeps the reference's semantics (forward, 4-term NLL, backward, check_gradients, optimizer step, zero_grad) but, when the
+transcription module is the HIP model, runs them as the fused step of piano_a2s_amd.train (loss terms stay on the device)."""
+import os
+
+import numpy as np
+import torch
+
+try:                                    # the real thing when present, the compat slice otherwise
+    import speechbrain as sb
+except Exception:                       # noqa: BLE001
+    from piano_a2s_amd import sb_compat as sb
+
+from data_processing.humdrum import LabelsMultiple
+from piano_a2s_amd import metrics
+from utilities import load, mkdirs, save
+
+labels = LabelsMultiple(extended=True)
+
+
+def _to_device(batch, device):
+    return [t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch]
+
+
+class ASR(sb.Brain):
+    finetune = False
+
+    # ------------------------------------------------------------------ forward / objective
+    def compute_forward(self, batch, stage):
+        batch = _to_device(batch, self.device)
+        spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = batch[:7]
+        if stage == sb.Stage.TRAIN:
+            return self.modules.transcription(spectrogram=spectrogram, inference=False,
+                                              ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len],
+                                              teacher_forcing_ratio=self.teacher_forcing_ratio, device=self.device)
+        return self.modules.transcription(spectrogram=spectrogram, inference=True, ground_truth=None,
+                                          teacher_forcing_ratio=0., device=self.device)
+
+    def compute_objectives(self, predictions, batch, stage):
+        batch = _to_device(batch, self.device)
+        _, ts_t, key_t, up_t, _, lo_t, _, names, versions = batch
+        ts_o, key_o, up_o, lo_o = predictions
+        hp = self.hparams
+        time_loss = hp.loss_time_sig(ts_o.permute(0, 2, 1), ts_t)
+        key_loss = hp.loss_key(key_o.permute(0, 2, 1), key_t)
+        flat = lambda o, t: (o.reshape(o.shape[0] * o.shape[1], -1, o.shape[3]).permute(0, 2, 1), t.reshape(t.shape[0] * t.shape[1], -1))
+        upper_loss = hp.loss_score(*flat(up_o, up_t))
+        lower_loss = hp.loss_score(*flat(lo_o, lo_t))
+        self._record_losses(time_loss, key_loss, upper_loss, lower_loss)
+        if stage != sb.Stage.TRAIN:
+            self._record_predictions(predictions, (ts_t, key_t, up_t, lo_t), names, versions)
+        return time_loss + key_loss + upper_loss + lower_loss
+
+    def _record_losses(self, *terms):
+        for store, t in zip((self.time_losses, self.key_losses, self.upper_losses, self.lower_losses), terms):
+            store.append(float(t.detach()))
+
+    def _clip_id(self, name, version):
+        return name if self.finetune else "~".join([str(int(version)), name])
+
+    def _record_predictions(self, predictions, targets, names, versions):
+        ts_o, key_o, up_o, lo_o = predictions
+        ts_t, key_t, up_t, lo_t = targets
+        up_ids, lo_ids = up_o.argmax(-1).cpu().numpy(), lo_o.argmax(-1).cpu().numpy()
+        ts_ids, key_ids = ts_o.argmax(-1).cpu().numpy(), key_o.argmax(-1).cpu().numpy()
+        up_t, lo_t, ts_t, key_t = up_t.cpu().numpy(), lo_t.cpu().numpy(), ts_t.cpu().numpy(), key_t.cpu().numpy()
+        for b, name in enumerate(names):
+            cid = self._clip_id(name, versions[b])
+            self.upper_pred[cid] = [metrics.unpad(r).tolist() for r in up_ids[b]]
+            self.upper_target[cid] = [metrics.unpad(r).tolist() for r in up_t[b]]
+            self.lower_pred[cid] = [metrics.unpad(r).tolist() for r in lo_ids[b]]
+            self.lower_target[cid] = [metrics.unpad(r).tolist() for r in lo_t[b]]
+            self.key_pred[cid], self.key_target[cid] = key_ids[b].tolist(), key_t[b].tolist()
+            self.time_sig_pred[cid], self.time_sig_target[cid] = ts_ids[b].tolist(), ts_t[b].tolist()
+
+    # ------------------------------------------------------------------ training step
+    def _fused_step(self):
+        """The fused HIP step needs the HIP model, Adadelta and the yaml's NLL objective; otherwise fall back to the generic path."""
+        if getattr(self, "_fused", None) is None:
+            self._fused = False
+            model = self.modules.transcription
+            opt = self.optimizer
+            if hasattr(model, "flatten_") and isinstance(opt, torch.optim.Adadelta) and str(self.device).startswith("cuda"):
+                from piano_a2s_amd import train
+                g = opt.param_groups[0]
+                self._fused = train.TrainStep(model, lr=g["lr"], rho=g["rho"], eps=g["eps"], max_grad_norm=self.max_grad_norm)
+        return self._fused
+
+    def fit_batch(self, batch):
+        fused = self._fused_step()
+        if not fused:
+            return super().fit_batch(batch)
+        fused.opt.lr = self.optimizer.param_groups[0]["lr"]          # NewBob annealing acts on the torch optimizer object
+        losses = fused(_to_device(batch, self.device), self.teacher_forcing_ratio)
+        terms = losses[:, 0].tolist()                                 # one small D2H per step (the reference does four)
+        self._record_losses(*[torch.tensor(t) for t in terms])
+        return torch.tensor(sum(terms))
+
+    def evaluate_batch(self, batch, stage):
+        with torch.no_grad():
+            predictions = self.compute_forward(batch, stage=stage)
+            loss = self.compute_objectives(predictions, batch, stage=stage)
+        return loss.detach()
+
+    # ------------------------------------------------------------------ stage hooks
+    def on_stage_start(self, stage, epoch):
+        self.time_losses, self.key_losses, self.upper_losses, self.lower_losses = [], [], [], []
+        if stage != sb.Stage.TRAIN:
+            self.upper_pred, self.upper_target, self.lower_pred, self.lower_target = {}, {}, {}, {}
+            self.key_pred, self.key_target, self.time_sig_pred, self.time_sig_target = {}, {}, {}, {}
+            for split in ("valid", "test"):
+                mkdirs(os.path.join(self.hparams.output_folder, "results", split))
+        self.time_sig_list = load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                               "data_processing", "metadata", "time_signature_list.json"))
+        if stage != sb.Stage.TRAIN:
+            self.teacher_forcing_ratio = 0.
+        elif self.finetune:
+            self.teacher_forcing_ratio = self.hparams.teacher_forcing_ratio
+        else:                                                          # exponential decay per epoch (pretrain.py:151)
+            self.teacher_forcing_ratio = self.hparams.teacher_forcing_ratio * self.hparams.teacher_forcing_decay ** epoch
+
+    def on_stage_end(self, stage, stage_loss, epoch):
+        stats = {"loss": stage_loss, "time_loss": np.mean(self.time_losses), "key_loss": np.mean(self.key_losses),
+                 "upper_loss": np.mean(self.upper_losses), "lower_loss": np.mean(self.lower_losses)}
+        if not self.finetune:
+            stats["teacher_forcing_ratio"] = self.teacher_forcing_ratio
+        if stage == sb.Stage.TRAIN:
+            self.train_stats = stats
+            return
+        if not hasattr(self, "train_stats"):
+            self.train_stats = {"loss": -1}
+        inv = labels.labels_map_inv
+        wer_up, wer_up_d = metrics.corpus_wer(self.upper_pred, self.upper_target, inv)
+        wer_lo, wer_lo_d = metrics.corpus_wer(self.lower_pred, self.lower_target, inv)
+        key_f1, key_f1_d = metrics.corpus_f1(self.key_pred, self.key_target)
+        time_f1, time_f1_d = metrics.corpus_f1(self.time_sig_pred, self.time_sig_target)
+        stats.update(key_f1=key_f1, time_f1=time_f1, WER_upper=wer_up, WER_lower=wer_lo, WER=(wer_up + wer_lo) / 2)
+        old_lr, new_lr = self.hparams.lr_annealing(stats["WER"])
+        sb.nnet.schedulers.update_learning_rate(self.optimizer, new_lr)
+        self.hparams.train_logger.log_stats(stats_meta={"epoch": epoch, "lr": old_lr}, train_stats=self.train_stats, valid_stats=stats)
+        self.checkpointer.save_and_keep_only(meta={"loss": stats["loss"], "WER": stats["WER"]}, min_keys=["WER"])
+        self.last_stats = stats
+        split = "test" if stage == sb.Stage.TEST else "valid"
+        for cid in self.upper_pred:
+            pred = [[self.key_pred[cid][i] - 6, self.time_sig_list[self.time_sig_pred[cid][i]], self.lower_pred[cid][i], self.upper_pred[cid][i]]
+                    for i in range(len(self.upper_pred[cid]))]
+            record = {"pred": pred, "wer_upper": wer_up_d[cid], "wer_lower": wer_lo_d[cid], "key_f1": key_f1_d[cid], "time_f1": time_f1_d[cid]}
+            record.update(self._clip_record(cid, split))
+            save(record, os.path.join(self.hparams.output_folder, "results", split, f"{cid}.json"))
+
+    def _clip_record(self, cid, split):
+        ff = self.hparams.feature_folder
+        if self.finetune:
+            return {"target_path": os.path.join(ff, "test", "target", f"{cid}.pkl")}
+        version, chunk, soundfont = (cid.split("~") + ["", ""])[:3]
+        info_path = os.path.join(ff, split, version, "info", f"{chunk}.json")
+        composer = load(info_path).get("composer") if os.path.exists(info_path) else None
+        return {"style": "classical" if chunk[:1].islower() else "pop", "soundfont": soundfont, "composer": composer,
+                "target_path": os.path.join(ff, split, version, "target", f"{chunk}.pkl")}
