@@ -21,8 +21,9 @@ def test_pretrain_on_gpu(tmp_path):
     brain = pretrain.main(args)
     assert brain._fused, "the recipe must run the fused HIP training step on the GPU"
     out = os.path.join(str(tmp_path), "1234", "pretrain.epr")
-    lines = [l for l in open(os.path.join(out, "train_log.txt")).read().splitlines() if l.startswith("epoch")]
-    assert len(lines) == 3
+    all_lines = [l for l in open(os.path.join(out, "train_log.txt")).read().splitlines() if l.startswith("epoch")]
+    assert len(all_lines) == 4 and all_lines[-1].startswith("epoch: None")      # 3 epochs (train+valid) + the final TEST evaluation
+    lines = all_lines[:3]
     train_loss = [float(l.split("train loss: ")[1].split(",")[0]) for l in lines]
     assert train_loss[-1] < train_loss[0], f"training loss did not go down: {train_loss}"
     assert len(os.listdir(os.path.join(out, "save"))) == 1
