@@ -46,8 +46,9 @@ int a2s_gemm_pick_splitk(int M, int N, int K, int batch);
  * stat_partial [blocks][Cout][2] receives per-block sum / sum-of-squares of y (NULL to skip);
  * flip=1 runs the data-gradient form with w read as w'[ci][co][2-dt][2-df]. */
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
-                float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip);
+                float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace);
 int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin);
+size_t a2s_conv3x3_workspace_floats(int Cin);   /* scratch for the packed weight image (0 for Cin = 1) */
 /* BatchNorm2d/1d statistics -> affine (models.py:499-505): reduces the partials in fixed order (double),
  * updates running stats (momentum, unbiased var) and num_batches_tracked when training, emits mean/invstd
  * (for backward) and scale/shift with y = x*scale+shift.  training=0: uses the running statistics. */

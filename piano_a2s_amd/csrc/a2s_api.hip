@@ -9,7 +9,8 @@ thread_local char a2s_err_msg[512] = {0};
 int a2s_gemm_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long,
                   const float*, int, int, long, long, long, int, float*, size_t);
 size_t a2s_gemm_workspace_bytes_impl(int, int, int, int);
-int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int);
+int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*);
+size_t a2s_conv3x3_workspace_floats_impl(int);
 int a2s_conv3x3_stat_blocks_impl(int, int, int, int);
 int a2s_bn_finalize_impl(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*,
                          float*, float*, float*, float*, float, float, int);
@@ -70,9 +71,10 @@ size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk) { return a2
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch) { return a2s_gemm_pick_splitk_impl(M, N, K, batch); }
 
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
-                float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip) {
-    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip);
+                float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace) {
+    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, workspace);
 }
+size_t a2s_conv3x3_workspace_floats(int Cin) { return a2s_conv3x3_workspace_floats_impl(Cin); }
 int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin) { return a2s_conv3x3_stat_blocks_impl(B, T, F, Cin); }
 int a2s_bn_finalize(void* stream, const float* partial, int nblocks, int C, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, long long* nbt, float* mean, float* invstd, float* scale,

@@ -34,72 +34,111 @@ struct ConvArgs {
     int flip;            // 1: use w as a transposed/flipped kernel (dgrad): w'[ci][co][2-dt][2-df]
 };
 
+// ---- v2 geometry (round 1, after profiling: the first version spent more time staging than multiplying -- scalar loads with
+// div/mod per element and a 34 KB weight slice re-derived from the (Cout,Cin,3,3) layout per 128 outputs).
+//   * tile = 4 rows x 64 columns (4 m-tiles per wave): the weight slice is amortised over twice the outputs;
+//   * weights are pre-packed ONCE per call into the LDS image [chunk][9*CK][48] (conv_pack_weights) -> straight 16-byte copies;
+//   * the input tile is staged with 16-byte loads (interior) + 2 halo scalars per row; interior starts at column 4 of a 72-float
+//     LDS row so the vector stores are aligned; plane stride 6*72 = 432 == 16 (mod 32) keeps the k-pair fragment reads conflict-free.
+#define C2_FT 64
+#define C2_RS 72
+#define C2_PLANE (6 * C2_RS)
+#define C2_WCHUNK (9 * CV_CK * CV_WS)      // floats per packed weight chunk
+
+__global__ void conv_pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int flip, int chunks) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= chunks * C2_WCHUNK) return;
+    const int chunk = e / C2_WCHUNK, rem = e % C2_WCHUNK;
+    const int n = rem % CV_WS, k = rem / CV_WS;
+    const int c = k % CV_CK, tap = k / CV_CK;
+    const int ci = chunk * CV_CK + c;
+    float v = 0.f;
+    if (n < Cout && ci < Cin) v = flip ? w[((long)ci * Cout + n) * 9 + (8 - tap)] : w[((long)n * Cin + ci) * 9 + tap];
+    wp[e] = v;
+}
+
 template <int COUT>
-__global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a, const float* __restrict__ wpack) {
     constexpr int NT = (COUT + 15) / 16;               // n-tiles: 2 (Cout 20) or 3 (Cout 40)
-    __shared__ __attribute__((aligned(16))) float lin[CV_CK * CV_PLANE];       // 19200 B
-    __shared__ __attribute__((aligned(16))) float lw[9 * CV_CK * CV_WS];       // 34560 B
+    __shared__ __attribute__((aligned(16))) float lin[CV_CK * C2_PLANE];       // 34560 B
+    __shared__ __attribute__((aligned(16))) float lw[C2_WCHUNK];               // 34560 B
     __shared__ float red[4][NT * 16][2];
 
-    const int tilesF = (a.F + CV_FT - 1) / CV_FT;
+    const int tilesF = (a.F + C2_FT - 1) / C2_FT;
     const int tilesT = (a.T + CV_TR - 1) / CV_TR;
     int bid = blockIdx.x;
     const int ft = bid % tilesF; bid /= tilesF;
     const int tt = bid % tilesT; const int b = bid / tilesT;
-    const int t0 = tt * CV_TR, f0 = ft * CV_FT;
+    const int t0 = tt * CV_TR, f0 = ft * C2_FT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    const bool vec_ok = (a.F % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
 
-    // wave w owns output row t0+w: two m-tiles (f0..f0+15, f0+16..f0+31) x NT n-tiles
-    f32x4 acc[2][NT];
+    f32x4 acc[4][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CV_CK) {
+    const int nchunks = a.Cin / CV_CK;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CV_CK;
         __syncthreads();      // previous chunk fully consumed
-        // ---- stage input planes [CK][TR+2][FT+2] with the producer's BN+ReLU folded in; zero = padding
-        for (int e = tid; e < CV_CK * (CV_TR + 2) * (CV_FT + 2); e += 256) {
-            const int fc = e % (CV_FT + 2);
-            const int r = (e / (CV_FT + 2)) % (CV_TR + 2);
-            const int c = e / ((CV_FT + 2) * (CV_TR + 2));
-            const int t = t0 + r - 1, f = f0 + fc - 1, ci = c0 + c;
+        // ---- weights: straight copy of the pre-packed slice
+        const f32x4* wsrc4 = reinterpret_cast<const f32x4*>(wpack + (long)ch * C2_WCHUNK);
+        for (int e = tid; e < C2_WCHUNK / 4; e += 256) reinterpret_cast<f32x4*>(lw)[e] = wsrc4[e];
+        // ---- input interior: (c, r) rows of 64 floats = 16 float4; BN+ReLU of the producer folded in; zero = padding
+        for (int e = tid; e < CV_CK * (CV_TR + 2) * (C2_FT / 4); e += 256) {
+            const int j = e % (C2_FT / 4);
+            const int row = e / (C2_FT / 4);
+            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+            const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < a.T && f < a.F) {
+                const float* src = a.x + (((long)b * a.T + t) * a.Cin + ci) * a.F + f;
+                if (vec_ok && f + 3 < a.F) v = *reinterpret_cast<const f32x4*>(src);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (f + q < a.F) v[q] = src[q];
+                }
+                if (a.in_scale) {
+                    const float sc = a.in_scale[ci], sh = a.in_shift[ci];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (f + q < a.F) ? fmaxf(v[q] * sc + sh, 0.f) : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4*>(lin + c * C2_PLANE + r * C2_RS + 4 + 4 * j) = v;
+        }
+        // ---- halo columns f0-1 (LDS col 3) and f0+64 (LDS col 68)
+        for (int e = tid; e < CV_CK * (CV_TR + 2) * 2; e += 256) {
+            const int side = e & 1, row = e >> 1;
+            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+            const int t = t0 + r - 1, f = side ? f0 + C2_FT : f0 - 1, ci = c0 + c;
             float v = 0.f;
-            if (t >= 0 && t < a.T && f >= 0 && f < a.F && ci < a.Cin) {
+            if (t >= 0 && t < a.T && f >= 0 && f < a.F) {
                 v = a.x[(((long)b * a.T + t) * a.Cin + ci) * a.F + f];
                 if (a.in_scale) v = fmaxf(v * a.in_scale[ci] + a.in_shift[ci], 0.f);
             }
-            lin[c * CV_PLANE + r * CV_RS + fc] = v;
-        }
-        // ---- stage the weight slice as B[k][n], k = (dt*3+df)*CK + c, n = output channel (zero padded)
-        for (int e = tid; e < 9 * CV_CK * CV_WS; e += 256) {
-            const int n = e % CV_WS, k = e / CV_WS;
-            const int c = k % CV_CK, tap = k / CV_CK;
-            const int ci = c0 + c;
-            float v = 0.f;
-            if (n < COUT && ci < a.Cin) {
-                if (!a.flip) v = a.w[((long)n * a.Cin + ci) * 9 + tap];
-                else         v = a.w[((long)ci * COUT + n) * 9 + (8 - tap)];   // w'[n<-ci] flipped: dgrad
-            }
-            lw[k * CV_WS + n] = v;
+            lin[c * C2_PLANE + r * C2_RS + (side ? 4 + C2_FT : 3)] = v;
         }
         __syncthreads();
-        // ---- multiply: 9 taps x CK/4 k-steps
+        // ---- multiply: 9 taps x CK/4 k-steps, 4 m-tiles x NT n-tiles per wave
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dt = tap / 3, df = tap % 3;
 #pragma unroll
             for (int cs = 0; cs < CV_CK / 4; ++cs) {
                 const int c = cs * 4 + lk;
-                const float* src = lin + c * CV_PLANE + (wave + dt) * CV_RS + df + li;
-                const float a0 = src[0], a1 = src[16];
+                const float* src = lin + c * C2_PLANE + (wave + dt) * C2_RS + 3 + df + li;
+                float av[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[i] = src[i * 16];
                 const float* wsrc = lw + (tap * CV_CK + c) * CV_WS + li;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const float bv = wsrc[j * 16];
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -113,7 +152,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a) {
         const int co = j * 16 + li;
         float s = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int f = f0 + i * 16 + lk * 4;
             if (row_ok && co < COUT) {
                 float* dst = a.y + (((long)b * a.T + t) * COUT + co) * a.F + f;
@@ -129,7 +168,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a) {
             }
         }
         if (a.stat_partial) {
-            // reduce over the 4 lane groups (lk) -> lanes 0..15 hold the wave's per-channel sums
             s += __shfl_xor(s, 16, 64); s2 += __shfl_xor(s2, 16, 64);
             s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64);
             if (lk == 0) { red[wave][j * 16 + li][0] = s; red[wave][j * 16 + li][1] = s2; }
@@ -280,8 +318,10 @@ __global__ void bn1d_relu_dropout(const float* __restrict__ x, float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------- launchers
+size_t a2s_conv3x3_workspace_floats_impl(int Cin) { return Cin == 1 ? 0 : (size_t)(Cin / CV_CK) * C2_WCHUNK; }
+
 int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, const float* in_scale,
-                     const float* in_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip) {
+                     const float* in_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* ws) {
     A2S_REQUIRE(x && w && y, "conv3x3: null tensor");
     A2S_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip};
@@ -290,17 +330,21 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
         hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_cdiv((long)B * T * F, 256)), dim3(256), 0, st, a);
     } else {
         A2S_REQUIRE(Cin % 4 == 0 && Cin % CV_CK == 0, "conv3x3: Cin must be a multiple of %d", CV_CK);
-        const int nblk = B * a2s_cdiv(T, CV_TR) * a2s_cdiv(F, CV_FT);
-        if (Cout == 20) hipLaunchKernelGGL(conv3x3_mfma<20>, dim3(nblk), dim3(256), 0, st, a);
-        else if (Cout == 40) hipLaunchKernelGGL(conv3x3_mfma<40>, dim3(nblk), dim3(256), 0, st, a);
-        else A2S_FAIL(A2S_ERR_ARG, "conv3x3: Cout must be 20 or 40 (got %d)", Cout);
+        A2S_REQUIRE(ws, "conv3x3: needs a workspace of a2s_conv3x3_workspace_floats(Cin) floats for the packed weights");
+        A2S_REQUIRE(Cout == 20 || Cout == 40, "conv3x3: Cout must be 20 or 40 (got %d)", Cout);
+        const int chunks = Cin / CV_CK;
+        hipLaunchKernelGGL(conv_pack_weights, dim3(a2s_cdiv(chunks * C2_WCHUNK, 256)), dim3(256), 0, st, w, ws, Cin, Cout, flip, chunks);
+        A2S_CHECK_LAUNCH("conv_pack_weights");
+        const int nblk = B * a2s_cdiv(T, CV_TR) * a2s_cdiv(F, C2_FT);
+        if (Cout == 20) hipLaunchKernelGGL(conv3x3_mfma<20>, dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
+        else hipLaunchKernelGGL(conv3x3_mfma<40>, dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
     }
     A2S_CHECK_LAUNCH("conv3x3");
     return A2S_OK;
 }
 
 int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin) {
-    return Cin == 1 ? a2s_cdiv((long)B * T * F, 256) : B * a2s_cdiv(T, CV_TR) * a2s_cdiv(F, CV_FT);
+    return Cin == 1 ? a2s_cdiv((long)B * T * F, 256) : B * a2s_cdiv(T, CV_TR) * a2s_cdiv(F, C2_FT);
 }
 
 int a2s_bn_finalize_impl(hipStream_t st, const float* partial, int nblocks, int C, double count, const float* gamma,

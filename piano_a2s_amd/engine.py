@@ -68,8 +68,9 @@ class Engine:
             y = self._empty(B, T, co, F, dev=dev)
             nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
             partial = self._empty(nblk, co, 2, dev=dev) if training else None
+            cws = hip.conv_workspace(ci, dev)
             hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(y), hip._p(scale),
-                                    hip._p(shift), hip._p(partial), B, T, F, ci, co, 0), "a2s_conv3x3")
+                                    hip._p(shift), hip._p(partial), B, T, F, ci, co, 0, hip._p(cws)), "a2s_conv3x3")
             mean, invstd, scale, shift = self._bn(S, f"convstack.bn{i}", partial, nblk, co, float(B) * T * F, training)
             saved["y"].append(y)
             saved["bn"].append((mean, invstd, scale, shift))

@@ -317,6 +317,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                                       hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
         if i > 1:
             gprev = torch.empty((B, T, ci, F), dtype=torch.float32, device=dev)
-            hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), NULL, NULL, NULL, B, T, F, co, ci, 1),
-                      "a2s_conv3x3 dgrad")
+            cws = hip.conv_workspace(co, dev)
+            hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), NULL, NULL, NULL, B, T, F, co, ci, 1,
+                                    hip._p(cws)), "a2s_conv3x3 dgrad")
             g = gprev

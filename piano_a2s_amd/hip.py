@@ -47,7 +47,7 @@ def lib():
                            "There is no CPU fallback for the transcription hot path.")
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
-        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats"):
+        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
     return _lib
 
@@ -68,6 +68,11 @@ def attn_workspace(B, T, H, device):
     if H != 256:
         return None
     return torch.empty(lib().a2s_attn_workspace_floats(B, T, H), dtype=torch.float32, device=device)
+
+
+def conv_workspace(cin, device):
+    n = lib().a2s_conv3x3_workspace_floats(cin)
+    return torch.empty(n, dtype=torch.float32, device=device) if n else None
 
 
 def gemm_workspace(rows, device):

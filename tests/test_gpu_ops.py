@@ -79,7 +79,7 @@ def test_gemm_strided_forms(dev):
 
 
 @pytest.mark.parametrize("Cin,Cout", [(1, 20), (20, 20), (20, 40), (40, 40)])
-@pytest.mark.parametrize("B,T,F", [(2, 9, 24), (1, 41, 480)])
+@pytest.mark.parametrize("B,T,F", [(2, 9, 24), (1, 41, 480), (1, 6, 100)])
 def test_conv3x3_with_input_affine_and_stats(dev, Cin, Cout, B, T, F):
     from piano_a2s_amd import hip
     L = hip.lib()
@@ -98,9 +98,10 @@ def test_conv3x3_with_input_affine_and_stats(dev, Cin, Cout, B, T, F):
     part = torch.zeros(nblk, Cout, 2, device=dev)
     # NB: raw pointers do not keep tensors alive -- every device operand is bound to a name for the whole call
     xd, wd, scd, shd = x.to(dev), w.to(dev), scale.to(dev), shift.to(dev)
+    cws = hip.conv_workspace(Cin, dev)
     hip.check(L.a2s_conv3x3(hip.stream(), hip._p(xd), hip._p(wd), hip._p(y),
                             hip._p(scd) if use_affine else C.c_void_p(0),
-                            hip._p(shd) if use_affine else C.c_void_p(0), hip._p(part), B, T, F, Cin, Cout, 0), "conv")
+                            hip._p(shd) if use_affine else C.c_void_p(0), hip._p(part), B, T, F, Cin, Cout, 0, hip._p(cws)), "conv")
     torch.cuda.synchronize()
     err = _rel(y, ref)
     _report(f"conv3x3 {Cin}->{Cout} B{B} T{T} F{F}", err)
@@ -125,8 +126,9 @@ def test_conv3x3_flip_is_data_gradient(dev):
     dyl = dy.permute(0, 2, 1, 3).contiguous().to(dev)                # (B,T,Cout,F)
     dx = torch.empty(B, T, Cin, F, device=dev)
     wd = w.to(dev)
+    cws = hip.conv_workspace(Cout, dev)
     hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dyl), hip._p(wd), hip._p(dx), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0),
-                            B, T, F, Cout, Cin, 1), "conv flip")
+                            B, T, F, Cout, Cin, 1, hip._p(cws)), "conv flip")
     torch.cuda.synchronize()
     err = _rel(dx, ref)
     _report("conv3x3 dgrad(flip)", err)
