@@ -473,14 +473,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
                                                      float* __restrict__ partial, int B, int T, int F, int Cin) {
     constexpr int MT = (COUT + 15) / 16;
     constexpr int NTW = 3;                               // n-tiles per wave: 4 waves x 3 x 16 = 192 >= 180
-    constexpr int DRS = CV_FT + 4;                       // dy row stride in LDS
-    __shared__ __attribute__((aligned(16))) float lin[CV_CK * CV_PLANE];
+    constexpr int DRS = CV_FT + 4;                       // dy row stride in LDS (rows 16-byte aligned)
+    constexpr int WRS = 40;                              // input row stride: interior at column 4 (aligned 16-byte stores), halos at 3 / 36
+    constexpr int WPL = 6 * WRS;                         // 240 == 16 (mod 32)
+    __shared__ __attribute__((aligned(16))) float lin[CV_CK * WPL];
     __shared__ __attribute__((aligned(16))) float ldy[MT * 16 * CV_TR * DRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int c0 = blockIdx.y * CV_CK;
     const int tilesF = (F + CV_FT - 1) / CV_FT, tilesT = (T + CV_TR - 1) / CV_TR;
     const long ntiles = (long)B * tilesT * tilesF;
+    const bool vec_ok = (F % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
 
     int boff[NTW];                                       // LDS offset of this lane's (ci, dt, df) column per n-tile
     bool bok[NTW];
@@ -489,13 +492,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
         const int n = (wave * NTW + j) * 16 + li;
         bok[j] = n < CV_CK * 9 && (c0 + n / 9) < Cin;
         const int c = n / 9, tap = n % 9;
-        boff[j] = bok[j] ? c * CV_PLANE + (tap / 3) * CV_RS + (tap % 3) : 0;
+        boff[j] = bok[j] ? c * WPL + (tap / 3) * WRS + (tap % 3) + 3 : 0;
     }
     f32x4 acc[MT][NTW];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // rows of the dy image that belong to padded output channels (co >= COUT) stay zero for the whole kernel
+    for (int e = tid; e < (MT * 16 - COUT) * CV_TR * DRS; e += 256) ldy[COUT * CV_TR * DRS + e] = 0.f;
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         long bid = tile;
@@ -503,26 +508,55 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
         const int tt = (int)(bid % tilesT); const int b = (int)(bid / tilesT);
         const int t0 = tt * CV_TR, f0 = ft * CV_FT;
         __syncthreads();
-        for (int e = tid; e < CV_CK * (CV_TR + 2) * (CV_FT + 2); e += 256) {
-            const int fc = e % (CV_FT + 2);
-            const int r = (e / (CV_FT + 2)) % (CV_TR + 2);
-            const int c = e / ((CV_FT + 2) * (CV_TR + 2));
-            const int t = t0 + r - 1, f = f0 + fc - 1, ci = c0 + c;
+        // ---- input interior: (c, r) rows of 32 floats = 8 float4 (producer's BN+ReLU folded in)
+        for (int e = tid; e < CV_CK * (CV_TR + 2) * (CV_FT / 4); e += 256) {
+            const int j = e % (CV_FT / 4);
+            const int row = e / (CV_FT / 4);
+            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+            const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < T && f < F && ci < Cin) {
+                const float* src = x + (((long)b * T + t) * Cin + ci) * F + f;
+                if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+                }
+                if (in_scale) {
+                    const float sc = in_scale[ci], sh = in_shift[ci];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (f + q < F) ? fmaxf(v[q] * sc + sh, 0.f) : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4*>(lin + c * WPL + r * WRS + 4 + 4 * j) = v;
+        }
+        for (int e = tid; e < CV_CK * (CV_TR + 2) * 2; e += 256) {      // halo columns
+            const int side = e & 1, row = e >> 1;
+            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+            const int t = t0 + r - 1, f = side ? f0 + CV_FT : f0 - 1, ci = c0 + c;
             float v = 0.f;
             if (t >= 0 && t < T && f >= 0 && f < F && ci < Cin) {
                 v = x[(((long)b * T + t) * Cin + ci) * F + f];
                 if (in_scale) v = fmaxf(v * in_scale[ci] + in_shift[ci], 0.f);
             }
-            lin[c * CV_PLANE + r * CV_RS + fc] = v;
+            lin[c * WPL + r * WRS + (side ? 4 + CV_FT : 3)] = v;
         }
-        for (int e = tid; e < MT * 16 * CV_TR * CV_FT; e += 256) {
-            const int fc = e % CV_FT;
-            const int r = (e / CV_FT) % CV_TR;
-            const int co = e / (CV_FT * CV_TR);
-            const int t = t0 + r, f = f0 + fc;
-            float v = 0.f;
-            if (co < COUT && t < T && f < F) v = dy[(((long)b * T + t) * COUT + co) * F + f];
-            ldy[(co * CV_TR + r) * DRS + fc] = v;
+        // ---- dy tile: (co, r) rows of 32 floats = 8 float4
+        for (int e = tid; e < COUT * CV_TR * (CV_FT / 4); e += 256) {
+            const int j = e % (CV_FT / 4);
+            const int row = e / (CV_FT / 4);
+            const int r = row % CV_TR, co = row / CV_TR;
+            const int t = t0 + r, f = f0 + 4 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < T && f < F) {
+                const float* src = dy + (((long)b * T + t) * COUT + co) * F + f;
+                if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+                }
+            }
+            *reinterpret_cast<f32x4*>(ldy + (co * CV_TR + r) * DRS + 4 * j) = v;
         }
         __syncthreads();
 #pragma unroll
@@ -533,7 +567,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
 #pragma unroll
                 for (int i = 0; i < MT; ++i) a[i] = ldy[((i * 16 + li) * CV_TR + r) * DRS + ks * 4 + lk];
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) bv[j] = bok[j] ? lin[boff[j] + r * CV_RS + ks * 4 + lk] : 0.f;
+                for (int j = 0; j < NTW; ++j) bv[j] = bok[j] ? lin[boff[j] + r * WRS + ks * 4 + lk] : 0.f;
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -573,7 +607,7 @@ __global__ void wgrad_reduce(const float* __restrict__ partial, float* __restric
     dW[((long)co * Cin + ci) * 9 + tap] += s;
 }
 
-#define WGRAD_SLABS 512
+#define WGRAD_SLABS 768
 
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
