@@ -66,7 +66,8 @@ int a2s_gru_gates_fwd(void* stream, const float* gi, long ldgi, const float* gh,
 /* one direction of one encoder layer over T steps, h0 = 0 (Encoder.forward, models.py:77) */
 int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh,
                     const float* b_hh, float* out, long out_bstride, long out_tstride, float* hbuf, float* gh,
-                    float* save, float* hn, int B, int T, int H, int reverse);
+                    float* save, float* hn, int B, int T, int H, int reverse, float* workspace, size_t workspace_bytes);
+/* workspace (optional): split-K scratch for the per-step recurrent GEMM (M = B rows, few output tiles) */
 
 /* ---- additive attention step (AttentionLayer.forward models.py:452-461 + bmm :242,:394), keys hoisted:
  * score_t = v . tanh(K[b,t,:] + q[b,:]); a = softmax_t; ctx = sum_t a_t enc[b,t,:]. */
@@ -150,7 +151,7 @@ int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);
 /* BPTT of one encoder GRU direction (reverse of a2s_gru_seq_fwd) */
 int a2s_gru_seq_bwd(void* stream, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride,
                     long out_tstride, const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift,
-                    float* dgh_first, float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse);
+                    float* dgh_first, float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse, float* workspace, size_t workspace_bytes);
 /* BPTT of the packed staff-embedding bi-GRU; grads: DEVICE array of 8 pointers (same order as gru_w) */
 int a2s_staff_emb_bwd(void* stream, const float* note_emb, const float* const* gru_w, float* const* grads, float* note_emb_grad,
                       const long long* ids64, const int* ids32, long id_bstride, const long long* lengths, long len_stride,

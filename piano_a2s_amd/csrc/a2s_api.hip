@@ -19,7 +19,7 @@ int a2s_col_stats_impl(hipStream_t, const float*, float*, long, int, int);
 int a2s_bn1d_relu_dropout_impl(hipStream_t, const float*, float*, const float*, const float*, const uint8_t*, float, long, int);
 int a2s_gru_gates_fwd_impl(hipStream_t, const float*, long, const float*, long, const float*, long, float*, long, float*, long, float*, int, int);
 int a2s_gru_seq_fwd_impl(hipStream_t, const float*, long, long, const float*, const float*, float*, long, long, float*, float*,
-                         float*, float*, int, int, int, int);
+                         float*, float*, int, int, int, int, float*, size_t);
 int a2s_attn_step_fwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, float*, long, float*, long,
                            float*, int, int, int, const int*, int, float*);
 size_t a2s_attn_workspace_floats_impl(int, int, int);
@@ -41,7 +41,7 @@ int a2s_embed_scatter_add_impl(hipStream_t, float*, const long long*, const int*
 int a2s_ew_act_bwd_impl(hipStream_t, const float*, const float*, float*, long, int);
 int a2s_note_decoder_bwd_impl(hipStream_t, const a2s_note_dec_bwd_args&);
 int a2s_gru_seq_bwd_impl(hipStream_t, const float*, long, long, const float*, long, long, const float*, const float*, const float*, float*,
-                         float*, float*, float*, float*, int, int, int, int);
+                         float*, float*, float*, float*, int, int, int, int, float*, size_t);
 int a2s_staff_emb_bwd_impl(hipStream_t, const float*, const float* const*, float* const*, float*, const long long*, const int*, long,
                            const long long*, long, const float*, long, int, const float*, int, int, int, int);
 
@@ -98,9 +98,9 @@ int a2s_gru_gates_fwd(void* stream, const float* gi, long ldgi, const float* gh,
 }
 int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh, const float* b_hh,
                     float* out, long out_bstride, long out_tstride, float* hbuf, float* gh, float* save, float* hn, int B, int T,
-                    int H, int reverse) {
+                    int H, int reverse, float* workspace, size_t workspace_bytes) {
     return a2s_gru_seq_fwd_impl(ST, gi_all, gi_bstride, gi_tstride, w_hh, b_hh, out, out_bstride, out_tstride, hbuf, gh, save, hn,
-                                B, T, H, reverse);
+                                B, T, H, reverse, workspace, workspace_bytes);
 }
 int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, float* ctx,
                       long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H, const int* n_done, int n_rows_total, float* workspace) {
@@ -158,9 +158,9 @@ int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args) {
 }
 int a2s_gru_seq_bwd(void* stream, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride, long out_tstride,
                     const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift, float* dgh_first,
-                    float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse) {
+                    float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse, float* workspace, size_t workspace_bytes) {
     return a2s_gru_seq_bwd_impl(ST, dout, do_bstride, do_tstride, out, out_bstride, out_tstride, gates, w_hh, dhn, dgi_all, dgh_shift,
-                                dgh_first, dhbuf, dgh_tmp, B, T, H, reverse);
+                                dgh_first, dhbuf, dgh_tmp, B, T, H, reverse, workspace, workspace_bytes);
 }
 int a2s_staff_emb_bwd(void* stream, const float* note_emb, const float* const* gru_w, float* const* grads, float* note_emb_grad,
                       const long long* ids64, const int* ids32, long id_bstride, const long long* lengths, long len_stride,

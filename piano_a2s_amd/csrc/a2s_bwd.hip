@@ -328,7 +328,7 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
 //   dgh_first (B,3H)   <- dgh of the first processed step (h_prev = 0): only contributes to db_hh
 int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride,
                          long out_tstride, const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift,
-                         float* dgh_first, float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse) {
+                         float* dgh_first, float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse, float* ws, size_t ws_bytes) {
     A2S_REQUIRE(dout && out && gates && w_hh && dgi_all && dgh_shift && dgh_first && dhbuf && dgh_tmp, "gru_seq_bwd: null tensor");
     hipError_t e;
     if (dhn) e = hipMemcpyAsync(dhbuf, dhn, sizeof(float) * B * H, hipMemcpyDeviceToDevice, st);
@@ -349,7 +349,7 @@ int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, lon
                                         s == 0 ? nullptr : dgh_shift + (long)tp * 3 * H, (long)T * 3 * H, dh_out, H, B, H);
         if (rc) return rc;
         if (s > 0) {   // dh_prev += dgh W_hh
-            rc = a2s_gemm_impl(st, B, H, 3 * H, 1.f, dgh, 3 * H, 1, w_hh, H, 1, 1.f, dh_out, H, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0);
+            rc = a2s_gemm_impl(st, B, H, 3 * H, 1.f, dgh, 3 * H, 1, w_hh, H, 1, 1.f, dh_out, H, nullptr, 0, 1, 0, 0, 0, 0, ws, ws_bytes);
             if (rc) return rc;
         }
         cur ^= 1;

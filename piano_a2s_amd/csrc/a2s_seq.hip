@@ -55,7 +55,7 @@ int a2s_gru_gates_fwd_impl(hipStream_t st, const float* gi, long ldgi, const flo
 //   hn     : (B, H) final state
 int a2s_gru_seq_fwd_impl(hipStream_t st, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh,
                          const float* b_hh, float* out, long out_bstride, long out_tstride, float* hbuf, float* gh,
-                         float* save, float* hn, int B, int T, int H, int reverse) {
+                         float* save, float* hn, int B, int T, int H, int reverse, float* ws, size_t ws_bytes) {
     A2S_REQUIRE(gi_all && w_hh && b_hh && out && hbuf && gh && hn, "gru_seq_fwd: null tensor");
     hipError_t e = hipMemsetAsync(hbuf, 0, sizeof(float) * B * H, st);
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gru_seq_fwd memset: %s", hipGetErrorString(e));
@@ -64,7 +64,7 @@ int a2s_gru_seq_fwd_impl(hipStream_t st, const float* gi_all, long gi_bstride, l
         const float* hp = hbuf + (long)(s & 1) * B * H;
         float* hq = (s == T - 1) ? hn : hbuf + (long)((s + 1) & 1) * B * H;
         // gh = h W_hh^T + b_hh   (M=B, N=3H, K=H; W_hh is (3H, H): B(k,n) = W[n*H + k])
-        int rc = a2s_gemm_impl(st, B, 3 * H, H, 1.f, hp, H, 1, w_hh, 1, H, 0.f, gh, 3 * H, b_hh, 0, 1, 0, 0, 0, 1, nullptr, 0);
+        int rc = a2s_gemm_impl(st, B, 3 * H, H, 1.f, hp, H, 1, w_hh, 1, H, 0.f, gh, 3 * H, b_hh, 0, 1, 0, 0, 0, 0, ws, ws_bytes);
         if (rc) return rc;
         rc = a2s_gru_gates_fwd_impl(st, gi_all + (long)t * gi_tstride, gi_bstride, gh, 3 * H, hp, H, hq, H,
                                     out + (long)t * out_tstride, out_bstride, save ? save + (long)t * B * 4 * H : nullptr, B, H);

@@ -101,6 +101,7 @@ class Engine:
         H = self.cfg["hidden_size"]
         dev = x.device
         saved = {"layers": []}
+        gws = hip.gemm_workspace(B, dev)
         inp = x.reshape(B * T, -1)
         finals = []
         for layer in (0, 1):
@@ -115,7 +116,7 @@ class Engine:
                 hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H),
                                             hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(S[f"encoder.gru.bias_hh_{sfx}"]),
                                             C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
-                                            hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d), "a2s_gru_seq_fwd")
+                                            hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d, hip._p(gws), C.c_size_t(gws.numel() * 4)), "a2s_gru_seq_fwd")
                 finals.append(hn)
                 lsave["dirs"].append({"gi": gi, "gates": gates, "hn": hn})
             lsave["out"] = out

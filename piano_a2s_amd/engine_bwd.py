@@ -257,6 +257,7 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
             hip.gemm(dpre, 1, 2 * H, hfin, H, 1, G["encoder.fc.weight"], 2 * H, H, H, B, beta=1.0, a_off=l * H, c_off=half * H)   # dW += dpre_l^T h_fin
             dhn.append(d)
         _colsum(dpre, 2 * H, G["encoder.fc.bias"], B, H, x_off=l * H)
+    gws = hip.gemm_workspace(B, dev)
     dout = dEnc                                              # gradient wrt layer-1 outputs (B,T,2H)
     for layer in (1, 0):
         ls = es["layers"][layer]
@@ -270,7 +271,8 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
             dgh_first, dhbuf, dgh_tmp = torch.empty((B, 3 * H), device=dev), torch.empty((2, B, H), device=dev), torch.empty((B, 3 * H), device=dev)
             hip.check(L.a2s_gru_seq_bwd(hip.stream(), _ptr(dout, d * H), C.c_long(T * 2 * H), C.c_long(2 * H), _ptr(out, d * H), C.c_long(T * 2 * H),
                                         C.c_long(2 * H), hip._p(ls["dirs"][d]["gates"]), hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(dhn[2 * layer + d]),
-                                        hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf), hip._p(dgh_tmp), B, T, H, d), "a2s_gru_seq_bwd")
+                                        hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf), hip._p(dgh_tmp), B, T, H, d, hip._p(gws), C.c_size_t(gws.numel() * 4)),
+                      "a2s_gru_seq_bwd")
             dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)
             _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}", dx=dX,
                         dx_beta=0.0 if d == 0 else 1.0)

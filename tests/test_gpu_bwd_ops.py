@@ -261,14 +261,14 @@ def test_gru_sequence_bptt(dev):
         gates = torch.empty(T, B, 4 * H, device=dev)
         hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H), hip._p(Pd[f"g.weight_hh_{sfx}"]),
                                     hip._p(Pd[f"g.bias_hh_{sfx}"]), C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
-                                    hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d), "fwd")
+                                    hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d, NULL, C.c_size_t(0)), "fwd")
         dgi = torch.empty(B, T, 3 * H, device=dev); dghs = torch.empty(B, T, 3 * H, device=dev)
         dgh_first, dhbuf, dgh_tmp = torch.empty(B, 3 * H, device=dev), torch.empty(2, B, H, device=dev), torch.empty(B, 3 * H, device=dev)
         dhnd = dhn[d].to(dev)
         hip.check(L.a2s_gru_seq_bwd(hip.stream(), C.c_void_p(doutd.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
                                     C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H), hip._p(gates),
                                     hip._p(Pd[f"g.weight_hh_{sfx}"]), hip._p(dhnd), hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf),
-                                    hip._p(dgh_tmp), B, T, H, d), "bwd")
+                                    hip._p(dgh_tmp), B, T, H, d, NULL, C.c_size_t(0)), "bwd")
         dgi2 = dgi.view(B * T, 3 * H)
         dWih = torch.zeros(3 * H, I, device=dev)
         hip.gemm(dgi2, 1, 3 * H, xd, I, 1, dWih, I, 3 * H, I, B * T)                      # dW_ih = dgi^T x

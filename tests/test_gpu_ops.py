@@ -224,7 +224,7 @@ def test_gru_sequence_both_directions(dev):
         hbuf, gh, hn = torch.empty(2, B, H, device=dev), torch.empty(B, 3 * H, device=dev), torch.empty(B, H, device=dev)
         hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H), hip._p(Pd[f"g.weight_hh_{sfx}"]),
                                     hip._p(Pd[f"g.bias_hh_{sfx}"]), C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H),
-                                    C.c_long(2 * H), hip._p(hbuf), hip._p(gh), C.c_void_p(0), hip._p(hn), B, T, H, d), "gru_seq")
+                                    C.c_long(2 * H), hip._p(hbuf), hip._p(gh), C.c_void_p(0), hip._p(hn), B, T, H, d, C.c_void_p(0), C.c_size_t(0)), "gru_seq")
         hns.append(hn)
     torch.cuda.synchronize()
     e = max(_rel(out[..., :H], of), _rel(out[..., H:], orr), _rel(hns[0], hf), _rel(hns[1], hr))
