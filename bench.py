@@ -70,8 +70,16 @@ def attention_roofline(step, batch_dev, B, T, H, iters=50):
     avg_s = e0.elapsed_time(e1) / iters / 1e3
     algo_bytes = B * (T * H + T * 2 * H) * 4.0          # keys + encoder outputs of every clip, read once per step (fp32)
     achieved = algo_bytes / avg_s / 1e9
+    traffic, traffic_src = None, None                    # PMC counters cannot be collected from inside the bench: use the committed
+    try:                                                 # rocprofv3 --pmc measurement when it was taken at this batch size
+        with open(os.path.join(ROOT, "profiles", "attn_traffic.json")) as f:
+            m = json.load(f)
+        if m.get("per_gpu_batch") == B:
+            traffic, traffic_src = m["traffic_bytes_per_launch"], m["source"]
+    except Exception:  # noqa: BLE001
+        pass
     return {"bound": "hbm", "kernel": "attn_fwd_split256 (+attn_fwd_combine256)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 1),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(avg_s * 1e6, 1),
             "algorithmic_bytes_per_launch": int(algo_bytes)}
 
 
