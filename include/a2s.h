@@ -179,6 +179,11 @@ int a2s_nll_loss(void* stream, const float* logp, const long long* target, long 
 int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_avg, float* acc_delta, long n, const float* loss,
                       float max_norm, float lr, float rho, float eps, float* ctl, double* partial, int nblocks, int zero_grad);
 
+/* ---- VQT front-end epilogue (utilities.get_VQT, utilities.py:240-254): C (B, rows, 2*bins) = [re | im] of the framed complex GEMM
+ * (run with a2s_gemm_f32, A row stride = hop) -> out (B, rows, bins) = dB relative to the clip maximum, floor 1e-5, top_db, /80 + 1.
+ * partial: B*64 floats of scratch. */
+int a2s_vqt_logmag(void* stream, const float* C, float* out, float* partial, int B, long rows, int bins, float top_db);
+
 #ifdef __cplusplus
 }
 #endif

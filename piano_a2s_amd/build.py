@@ -5,7 +5,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liba2s_hip.so")
-SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip"]
+SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip", "a2s_vqt.hip"]
 
 
 def needs_build():

@@ -54,6 +54,8 @@ size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int, int);
 int a2s_nll_loss_impl(hipStream_t, const float*, const long long*, long, int, long long, float*, float*, float, double*, int);
 int a2s_clip_adadelta_impl(hipStream_t, float*, float*, float*, float*, long, const float*, float, float, float, float, float*, double*, int, int);
 
+int a2s_vqt_logmag_impl(hipStream_t, const float*, float*, float*, int, long, int, float);
+
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -188,6 +190,10 @@ int a2s_nll_loss(void* stream, const float* logp, const long long* target, long 
 int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_avg, float* acc_delta, long n, const float* loss, float max_norm,
                       float lr, float rho, float eps, float* ctl, double* partial, int nblocks, int zero_grad) {
     return a2s_clip_adadelta_impl(ST, params, grads, square_avg, acc_delta, n, loss, max_norm, lr, rho, eps, ctl, partial, nblocks, zero_grad);
+}
+
+int a2s_vqt_logmag(void* stream, const float* C, float* out, float* partial, int B, long rows, int bins, float top_db) {
+    return a2s_vqt_logmag_impl(ST, C, out, partial, B, rows, bins, top_db);
 }
 
 }  // extern "C"
