@@ -136,8 +136,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("A2S_FORCE_DIST") == "1"     # the latter: exercise the RCCL path on one GPU (debug)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl")           # nccl == RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs the MI355X: the transcription hot path has no CPU implementation"
@@ -151,7 +156,7 @@ def main():
     cfg = spec.default_cfg()
     model = models.ScoreTranscription(**cfg).to(dev)
     model.train()
-    if world > 1:                                          # identical replicas: broadcast rank 0's initial parameters
+    if use_dist:                                           # identical replicas: broadcast rank 0's initial parameters
         train.broadcast_parameters(model.flatten_(), src=0)
     step = train.TrainStep(model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True)
     B = args.batch
@@ -166,15 +171,15 @@ def main():
 
     run(args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.time()
     run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -193,7 +198,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_clips, 1234)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -19,18 +19,23 @@ from . import engine, engine_bwd, hip
 from .spec import PAD, VOCAB_SIZE
 
 
+import os as _os
+_FORCE_COLLECTIVES = _os.environ.get("A2S_FORCE_DIST") == "1"      # debug: run the collectives even with a single rank
+
+
 def average_gradients(flat_g, world):
     """Data-parallel gradient exchange: SUM all-reduce of the flat gradient buffer, then / world (DDP semantics: every rank
     contributes the gradient of ITS minibatch mean).  Backend-agnostic: RCCL (nccl) on GPUs, gloo in the CPU tests."""
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized() and world == 1 and _FORCE_COLLECTIVES):
         dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
-        flat_g.div_(world)
+        if world > 1:
+            flat_g.div_(world)
     return flat_g
 
 
 def broadcast_parameters(flat_p, src=0):
     """Make every replica start from rank `src`'s parameters (what DDP's constructor does)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES):
         dist.broadcast(flat_p, src=src)
     return flat_p
 
