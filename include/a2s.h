@@ -164,6 +164,13 @@ int a2s_bn_bwd(void* stream, const float* g, const float* x, const float* mean, 
                const float* shift, const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx,
                float* partial, float* c12, long rows, int C, int F);
 size_t a2s_bn_bwd_partial_floats(long rows, int C, int F);
+/* the same in two halves for synchronised BatchNorm: (1) this rank's per-channel {sum g', sum g' xhat} -> sums[2C];
+ * [host: all-reduce];  (2) dgamma/dbeta += LOCAL sums, dx from the GLOBAL sums / global element count. */
+int a2s_bn_bwd_stats(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+                     const float* shift, const uint8_t* keep_mask, float inv_keep, float* partial, float* sums, long rows, int C, int F);
+int a2s_bn_bwd_apply(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+                     const float* shift, const uint8_t* keep_mask, float inv_keep, const float* sums_local, const float* sums_global,
+                     double count_global, float* dgamma, float* dbeta, float* dx, float* c12, long rows, int C, int F);
 /* conv weight gradient dW += dy (*) relu(x*in_scale+in_shift)  (deterministic two-stage reduction) */
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
                       float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);

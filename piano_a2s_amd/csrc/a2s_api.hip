@@ -56,6 +56,11 @@ int a2s_clip_adadelta_impl(hipStream_t, float*, float*, float*, float*, long, co
 
 int a2s_vqt_logmag_impl(hipStream_t, const float*, float*, float*, int, long, int, float);
 
+int a2s_bn_bwd_stats_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
+                          float*, float*, long, int, int);
+int a2s_bn_bwd_apply_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
+                          const float*, const float*, double, float*, float*, float*, float*, long, int, int);
+
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -194,6 +199,17 @@ int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_a
 
 int a2s_vqt_logmag(void* stream, const float* C, float* out, float* partial, int B, long rows, int bins, float top_db) {
     return a2s_vqt_logmag_impl(ST, C, out, partial, B, rows, bins, top_db);
+}
+
+int a2s_bn_bwd_stats(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                     const uint8_t* keep_mask, float inv_keep, float* partial, float* sums, long rows, int C, int F) {
+    return a2s_bn_bwd_stats_impl(ST, g, x, mean, invstd, scale, shift, keep_mask, inv_keep, partial, sums, rows, C, F);
+}
+int a2s_bn_bwd_apply(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                     const uint8_t* keep_mask, float inv_keep, const float* sums_local, const float* sums_global, double count_global,
+                     float* dgamma, float* dbeta, float* dx, float* c12, long rows, int C, int F) {
+    return a2s_bn_bwd_apply_impl(ST, g, x, mean, invstd, scale, shift, keep_mask, inv_keep, sums_local, sums_global, count_global, dgamma, dbeta,
+                                 dx, c12, rows, C, F);
 }
 
 }  // extern "C"

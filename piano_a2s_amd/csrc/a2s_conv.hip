@@ -654,6 +654,66 @@ int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float*
     return A2S_OK;
 }
 
+// ---- split form for synchronised BatchNorm (statistics exchanged between ranks by the host between the two calls)
+// sums[c] = {s1, s2} of THIS rank (fixed-order double reduction of the partials)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_sums(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ sums) {
+    const int c = blockIdx.x;
+    __shared__ double r1[256], r2[256];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        s1 += (double)partial[((long)i * C + c) * 2 + 0];
+        s2 += (double)partial[((long)i * C + c) * 2 + 1];
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[2 * c] = (float)r1[0]; sums[2 * c + 1] = (float)r2[0]; }
+}
+// dgamma/dbeta += LOCAL sums (what torch.nn.SyncBatchNorm does: parameter gradients are rank-local, DDP averages them);
+// c12 = GLOBAL sums / global count (the input gradient sees the statistics of the whole global batch)
+__global__ void bn_bwd_c12_from_sums(const float* __restrict__ local, const float* __restrict__ global, double count, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ c12, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] += local[2 * c]; dgamma[c] += local[2 * c + 1];
+    c12[2 * c] = (float)((double)global[2 * c] / count); c12[2 * c + 1] = (float)((double)global[2 * c + 1] / count);
+}
+
+int a2s_bn_bwd_stats_impl(hipStream_t st, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+                          const float* shift, const uint8_t* mask, float inv_keep, float* partial, float* sums, long rows, int C, int F) {
+    A2S_REQUIRE(g && x && mean && invstd && scale && shift && partial && sums, "bn_bwd_stats: null tensor");
+    int nblocks;
+    if (F > 1) {
+        A2S_REQUIRE(!mask, "bn_bwd_stats: dropout mask only supported on the (rows, C) layout");
+        nblocks = (int)rows;
+        hipLaunchKernelGGL(bn_bwd_reduce_planes, dim3(nblocks), dim3(256), 0, st, g, x, mean, invstd, scale, shift, partial, C, F);
+    } else {
+        const int rpb = 64;
+        nblocks = a2s_cdiv(rows, rpb);
+        hipLaunchKernelGGL(bn_bwd_reduce_cols, dim3(nblocks), dim3(256), 0, st, g, x, mean, invstd, scale, shift, mask, inv_keep, partial, rows, C, rpb);
+    }
+    A2S_CHECK_LAUNCH("bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_sums, dim3(C), dim3(256), 0, st, partial, nblocks, C, sums);
+    A2S_CHECK_LAUNCH("bn_bwd_finalize_sums");
+    return A2S_OK;
+}
+
+int a2s_bn_bwd_apply_impl(hipStream_t st, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+                          const float* shift, const uint8_t* mask, float inv_keep, const float* sums_local, const float* sums_global,
+                          double count_global, float* dgamma, float* dbeta, float* dx, float* c12, long rows, int C, int F) {
+    A2S_REQUIRE(g && x && sums_local && sums_global && dgamma && dbeta && dx && c12, "bn_bwd_apply: null tensor");
+    hipLaunchKernelGGL(bn_bwd_c12_from_sums, dim3(a2s_cdiv(C, 256)), dim3(256), 0, st, sums_local, sums_global, count_global, dgamma, dbeta, c12, C);
+    A2S_CHECK_LAUNCH("bn_bwd_c12_from_sums");
+    const long n = rows * C * F;
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, mask,
+                       inv_keep, dx, n, C, F);
+    A2S_CHECK_LAUNCH("bn_bwd_apply");
+    return A2S_OK;
+}
+
 size_t a2s_bn_bwd_partial_floats_impl(long rows, int C, int F) {
     const long nblocks = F > 1 ? rows : (rows + 63) / 64;
     return (size_t)nblocks * C * 2;

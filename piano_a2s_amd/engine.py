@@ -35,10 +35,30 @@ def plan_note_steps(gt_rows, max_steps):
     return steps, lengths
 
 
+def _dist_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0     # 0 = no process group
+
+
 class Engine:
-    def __init__(self, cfg):
+    def __init__(self, cfg, sync_bn=False):
         self.cfg = cfg
         self.poll = 16            # greedy decode: host looks at the device-side done counter every `poll` steps
+        # Synchronised BatchNorm (what SpeechBrain's DDP wrapping gives the reference): batch statistics over the
+        # GLOBAL minibatch -- per-channel (sum, sum of squares, count) are all-reduced between the ranks.  Off by default:
+        # per-rank statistics (plain DDP semantics).  Needs an initialised process group.
+        self.sync_bn = bool(sync_bn) and _dist_world() >= 1
+
+    def _global_stats(self, partial, nblocks, C_, count):
+        """(nblocks, C, 2) per-block partial sums of this rank -> (1, C, 2) sums of ALL ranks, global element count."""
+        import torch.distributed as dist
+        sums = torch.empty(2 * C_, dtype=torch.float32, device=partial.device)
+        hip.check(hip.lib().a2s_col_sum(hip.stream(), hip._p(partial), C.c_long(2 * C_), hip._p(sums), C.c_long(nblocks), 2 * C_,
+                                        hip.f32(1.0), hip.f32(0.0), C.c_void_p(0), C.c_size_t(0)), "a2s_col_sum (bn stats)")
+        cnt = torch.tensor([count], dtype=torch.float64, device=partial.device)
+        dist.all_reduce(sums)
+        dist.all_reduce(cnt)
+        return sums, float(cnt.item())
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -49,6 +69,11 @@ class Engine:
         dev = S[name + ".weight"].device
         mean, invstd, scale, shift = (self._empty(C_, dev=dev) for _ in range(4))
         L = hip.lib()
+        self.bn_counts = getattr(self, "bn_counts", {})
+        if training and self.sync_bn:
+            partial, count = self._global_stats(partial, nblocks, C_, count)
+            nblocks = 1
+        self.bn_counts[name] = count
         hip.check(L.a2s_bn_finalize(hip.stream(), hip._p(partial), nblocks, C_, C.c_double(count), hip._p(S[name + ".weight"]),
                                     hip._p(S[name + ".bias"]), hip._p(S[name + ".running_mean"]), hip._p(S[name + ".running_var"]),
                                     hip._p(S[name + ".num_batches_tracked"]), hip._p(mean), hip._p(invstd), hip._p(scale),

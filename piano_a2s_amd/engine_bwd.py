@@ -294,6 +294,17 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         mean, invstd, scale, shift = bn
         part = torch.empty(L.a2s_bn_bwd_partial_floats(C.c_long(n_rows), C_, F_), dtype=torch.float32, device=dev)
         c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+        if eng.sync_bn:                                       # statistics of the global minibatch (see Engine.__init__)
+            import torch.distributed as dist
+            local = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+            hip.check(L.a2s_bn_bwd_stats(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(mask),
+                                         hip.f32(1.0 / 0.8), hip._p(part), hip._p(local), C.c_long(n_rows), C_, F_), "a2s_bn_bwd_stats")
+            glob = local.clone()
+            dist.all_reduce(glob)
+            hip.check(L.a2s_bn_bwd_apply(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(mask),
+                                         hip.f32(1.0 / 0.8), hip._p(local), hip._p(glob), C.c_double(eng.bn_counts[name]), hip._p(G[name + ".weight"]),
+                                         hip._p(G[name + ".bias"]), hip._p(g), hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd_apply")
+            return g
         hip.check(L.a2s_bn_bwd(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(mask), hip.f32(1.0 / 0.8),
                                hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), hip._p(g), hip._p(part), hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd")
         return g                                              # in place: g now holds dx

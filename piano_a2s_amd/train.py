@@ -92,8 +92,9 @@ class FusedAdadelta:
 class TrainStep:
     """model: models.ScoreTranscription on a GPU.  One call = one optimizer step on one minibatch."""
 
-    def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True):
+    def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True, sync_bn=None):
         self.model = model
+        self.sync_bn = (_os.environ.get("A2S_SYNC_BN") == "1") if sync_bn is None else bool(sync_bn)
         self.flat = model.flatten_()
         self.opt = FusedAdadelta(self.flat, lr, rho, eps, max_grad_norm)
         self.objective = Objective(self.flat.device)
@@ -109,7 +110,7 @@ class TrainStep:
     def __call__(self, batch, teacher_forcing_ratio, rng=_py_random):
         """batch: the reference's 9-tuple (device tensors).  Returns the (4,2) device tensor of loss terms (col 0)."""
         spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = batch[:7]
-        eng = engine.Engine(self.model.cfg)
+        eng = engine.Engine(self.model.cfg, sync_bn=self.sync_bn)
         S = self.state()
         outs = eng.forward(S, spectrogram, inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len],
                            teacher_forcing_ratio=teacher_forcing_ratio, training=True, rng=rng, dropout=self.dropout)

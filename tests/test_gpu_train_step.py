@@ -109,3 +109,32 @@ def test_nonfinite_loss_skips_update(case, dev):
     opt.step(g, good, zero_grad=False)
     torch.cuda.synchronize()
     assert not torch.equal(flat, before) and float(opt.ctl[2]) == 1.0
+
+
+def test_sync_bn_single_rank_equals_local_bn(case, dev):
+    """Synchronised-BatchNorm code path (all-reduced statistics, split backward) with a 1-rank RCCL group must reproduce the per-rank
+    path: same loss, same updated parameters.  (With N ranks it makes the N-GPU step equal to one GPU on the N-fold batch.)"""
+    import torch.distributed as dist
+    from piano_a2s_amd import train
+    data, cfg, batch, st = case
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        results = []
+        for sync in (False, True):
+            m = _model(cfg, st, dev)
+            m.train()
+            step = train.TrainStep(m, dropout=False, sync_bn=sync)
+            dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
+            losses = step(dbatch, teacher_forcing_ratio=1.0)
+            torch.cuda.synchronize()
+            results.append((losses[:, 0].cpu().clone(), m.flatten_().cpu().clone(), {k: v.cpu().clone() for k, v in m.named_buffers()}))
+        (l0, p0, b0), (l1, p1, b1) = results
+        assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0, l1)
+        assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max())
+        for k in b0:
+            assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-5, atol=1e-6), k
+    finally:
+        dist.destroy_process_group()
