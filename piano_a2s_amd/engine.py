@@ -35,6 +35,19 @@ def plan_note_steps(gt_rows, max_steps):
     return steps, lengths
 
 
+_SIDE_STREAMS = {}
+
+
+def side_streams(device):
+    """Two extra HIP streams per device: the upper- and lower-staff note decoders of a bar are independent given the bar summary
+    (reference models.py:261-275 runs them one after the other), so their step loops are enqueued on separate streams and overlap
+    -- one staff's latency-bound kernels (skinny GEMMs, gates, epilogues) run under the other's bandwidth-bound attention."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=key), torch.cuda.Stream(device=key))
+    return _SIDE_STREAMS[key]
+
+
 def _dist_world():
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0     # 0 = no process group
@@ -183,7 +196,7 @@ class Engine:
             record.append(dict(ids=ids, lengths=lengths, len_stride=len_stride, col0=col0, maxlen=maxlen, id_bstride=id_bstride,
                                i64=ids_are_i64, hsave=hsave))
 
-    def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None):
+    def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None):
         """One NoteDecoder.decode_notes call.  probs_bar: view (B, max_steps, V) of the output tensor (strided)."""
         L = hip.lib()
         H, E, V = self.cfg["hidden_size"], self.cfg["note_emb_size"], VOCAB_SIZE
@@ -219,9 +232,9 @@ class Engine:
                         ("b_hh", S[prefix + ".gru.bias_hh_l0"]), ("out_w", S[prefix + ".out.weight"]), ("out_b", S[prefix + ".out.bias"]),
                         ("emb", S[prefix + ".embedding.weight"]), ("keys", keys), ("enc", enc), ("h", h), ("x", x), ("q", q),
                         ("gates", gates), ("attw", attw), ("o", o), ("gh", gh), ("gi", gi), ("logits", logits),
-                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", self._gemm_ws)):
+                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", gemm_ws)):
             setattr(a, name, t.data_ptr() if t is not None else None)
-        a.gemm_ws_bytes = self._gemm_ws.numel() * 4
+        a.gemm_ws_bytes = gemm_ws.numel() * 4 if gemm_ws is not None else 0
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
         if gt_bar is not None:
             a.gt, a.gt_bstride = gt_bar.data_ptr(), gt_bar.stride(0)
@@ -237,7 +250,7 @@ class Engine:
         # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
         executed = n if gt_bar is not None else int(steps_exec.item())
         saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
-                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p)
+                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws)
         return ids, lengths, saved
 
     # ------------------------------------------------------------------ full forward
@@ -288,9 +301,11 @@ class Engine:
 
         ldxb = tokw + 2 * H
         bar_saved = []
-        attn_ws = hip.attn_workspace(B, T, H, dev)          # scratch of the split-T attention kernels (reused by every step)
-        self._attn_ws = attn_ws
-        self._gemm_ws = hip.gemm_workspace(B, dev)
+        # per-staff scratch (split-T attention partials, split-K slabs): the two staves run concurrently on two streams
+        attn_ws = [hip.attn_workspace(B, T, H, dev) for _ in range(2)]
+        gemm_ws = [hip.gemm_workspace(B, dev) for _ in range(2)]
+        concurrent = gt_cpu is not None and getattr(self, "concurrent_staves", True)    # greedy decode polls the device: sequential
+        streams = side_streams(dev) if concurrent else None
         for bar in range(bars):
             xbar = self._empty(B, ldxb, dev=dev)
             headin = self._empty(B, 4 * H, dev=dev)
@@ -319,6 +334,10 @@ class Engine:
                                           hip._p(gates), B, 2 * H), "a2s_gru_gates_fwd")
             # note decoders (models.py:261-275)
             staff = {}
+            joins = []
+            if concurrent:
+                fork = torch.cuda.Event()
+                fork.record()
             for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out, 0), ("lo", "decoder.lower_decoder", Lo, lo_out, 1)):
                 if gt_cpu is not None:
                     steps, plan_len = plan_note_steps(gt_cpu[gi_idx][:, bar, :], maxs)
@@ -326,13 +345,23 @@ class Engine:
                     gt_bar = (up_gt if gi_idx == 0 else lo_gt)[:, bar, :]
                 else:
                     steps, plan_len, flags, gt_bar = maxs, None, None, None
-                ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
-                                                      training, 0.1 if drop_on else 0.0, B, T, attn_ws)
+                if concurrent:
+                    st = streams[gi_idx]
+                    st.wait_event(fork)                    # everything the decoder reads (enc, keys, hnew, zeroed outputs) is ready
+                    with torch.cuda.stream(st):
+                        ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
+                                                              training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx])
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    joins.append(done)
+                else:
+                    ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
+                                                          training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx])
                 if gt_cpu is None:
                     for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference
                         rng.random()
                 staff[name] = (ids, lengths, sv)
-            # heads (models.py:281-286)
+            # heads (models.py:281-286) do not depend on the note decoders: they overlap with them on the main stream
             heads = {}
             for hname, out_t, nc in (("time_sig_out", ts_out, cfg["num_time_sig"]), ("key_out", key_out, cfg["num_keys"])):
                 t1 = hip.linear(headin, S[f"decoder.{hname}.0.weight"], S[f"decoder.{hname}.0.bias"], act=1)
@@ -342,6 +371,8 @@ class Engine:
                 hip.check(L.a2s_log_softmax_rows(hip.stream(), hip._p(lg), C.c_long(nc), C.c_void_p(out_t.data_ptr() + 4 * bar * nc),
                                                  C.c_long(bars * nc), hip._p(am), B, nc), "a2s_log_softmax_rows")
                 heads[hname] = (t1, t2, lg, am)
+            for ev in joins:                               # the next token / next bar may read what the staves produced
+                torch.cuda.current_stream().wait_event(ev)
             # next bar token (models.py:289-311): one draw per bar, after both staves
             teacher_force = rng.random() < teacher_forcing_ratio
             token = self._empty(B, tokw, dev=dev)
@@ -365,6 +396,6 @@ class Engine:
                                   next_ids=(ts_ids, key_ids, i64, stride)))
             hidden = hnew
         self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, enc_out=enc, sos_rec=sos_rec, training=training,
-                          attn_ws=attn_ws, gemm_ws=self._gemm_ws, outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
+                          concurrent=concurrent, outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
                           shape=(B, T, F), drop_on=drop_on)
         return ts_out, key_out, up_out, lo_out

@@ -26,10 +26,11 @@ _COLSUM_WS = {}
 
 def _colsum(x, ld, out, rows, ncol, x_off=0, out_off=0, beta=1.0):
     ws = None
-    if rows >= 2048:                                  # two-stage reduction scratch, one buffer per device, reused
-        ws = _COLSUM_WS.get(x.device)
+    if rows >= 2048:                                  # two-stage reduction scratch, one buffer per (device, stream), reused
+        key = (x.device, torch.cuda.current_stream().cuda_stream)
+        ws = _COLSUM_WS.get(key)
         if ws is None or ws.numel() < 1024 * ncol:
-            ws = _COLSUM_WS[x.device] = torch.empty(1024 * max(ncol, 2048), dtype=torch.float32, device=x.device)
+            ws = _COLSUM_WS[key] = torch.empty(1024 * max(ncol, 2048), dtype=torch.float32, device=x.device)
     hip.check(hip.lib().a2s_col_sum(hip.stream(), _ptr(x, x_off), C.c_long(ld), _ptr(out, out_off), C.c_long(rows), ncol,
                                     hip.f32(1.0), hip.f32(beta), hip._p(ws), C.c_size_t(ws.numel() if ws is not None else 0)), "a2s_col_sum")
 
@@ -102,9 +103,9 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),
                     ("w_hh", S[prefix + ".gru.weight_hh_l0"]), ("keys", keys), ("enc", enc), ("h", sv["h"]), ("x", sv["x"]), ("q", sv["q"]),
                     ("gates", sv["gates"]), ("attw", sv["attw"]), ("do_all", do_all), ("dgi_all", dgi_all), ("dgh_all", dgh_all),
-                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", eng.saved["attn_ws"]), ("gemm_ws", eng.saved["gemm_ws"])):
+                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", sv["attn_ws"]), ("gemm_ws", sv["gemm_ws"])):
         setattr(a, name, t.data_ptr() if t is not None else None)
-    a.gemm_ws_bytes = eng.saved["gemm_ws"].numel() * 4
+    a.gemm_ws_bytes = sv["gemm_ws"].numel() * 4 if sv["gemm_ws"] is not None else 0
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) deferred weight gradients over all steps
@@ -158,6 +159,12 @@ def backward(eng, S, grad_outputs):
     dEnc = torch.zeros((B, T, H2), dtype=torch.float32, device=dev)
     dK = {p: torch.zeros((B, T, H), dtype=torch.float32, device=dev) for p in sv["keys"]}
     keep_alive = []
+    # the two note decoders of a bar back-propagate concurrently on two side streams (see engine.side_streams); each accumulates its
+    # encoder-output gradient in its own buffer (summed once at the end), everything else they write is per-staff already
+    from .engine import side_streams
+    concurrent = bool(sv.get("concurrent"))
+    streams = side_streams(dev) if concurrent else None
+    dEnc_staff = [torch.zeros_like(dEnc), torch.zeros_like(dEnc)] if concurrent else [dEnc, dEnc]
 
     d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
     d_token_next = None         # gradient wrt the (pre-dropout) token that bar k produced for bar k+1
@@ -188,8 +195,26 @@ def backward(eng, S, grad_outputs):
             _linear_bwd(b["headin"], S[p + ".0.weight"], dt1, G, p + ".0.weight", p + ".0.bias", dx=d_headin, dx_beta=1.0)
         # ---- (3) note decoders: both start from bar_summary
         d_hnew = torch.zeros((B, H2), dtype=torch.float32, device=dev)
-        for name, prefix, dout, out_t in (("lo", "decoder.lower_decoder", dlo, lo_out), ("up", "decoder.upper_decoder", dup, up_out)):
-            dh0 = _note_decoder_bwd(eng, S, G, b["staff"][name][2], sv["keys"][prefix], enc, dout[:, bar], out_t[:, bar], dK[prefix], dEnc, B, T)
+        dh0s, joins = [], []
+        if concurrent:
+            fork = torch.cuda.Event()
+            fork.record()
+        for si, (name, prefix, dout, out_t) in enumerate((("up", "decoder.upper_decoder", dup, up_out), ("lo", "decoder.lower_decoder", dlo, lo_out))):
+            if concurrent:
+                st = streams[si]
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    dh0s.append(_note_decoder_bwd(eng, S, G, b["staff"][name][2], sv["keys"][prefix], enc, dout[:, bar], out_t[:, bar], dK[prefix],
+                                                  dEnc_staff[si], B, T))
+                done = torch.cuda.Event()
+                done.record(st)
+                joins.append(done)
+            else:
+                dh0s.append(_note_decoder_bwd(eng, S, G, b["staff"][name][2], sv["keys"][prefix], enc, dout[:, bar], out_t[:, bar], dK[prefix],
+                                              dEnc_staff[si], B, T))
+        for ev in joins:
+            torch.cuda.current_stream().wait_event(ev)
+        for dh0 in dh0s:
             d_hnew.add_(dh0)
         d_hnew.add_(d_headin[:, :H2])
         if d_hid_carry is not None:
@@ -227,6 +252,8 @@ def backward(eng, S, grad_outputs):
     for table, cid, col, width in (("decoder.time_sig_emb.weight", cfg["num_time_sig"], 4 * Sz, te), ("decoder.key_emb.weight", cfg["num_keys"], 4 * Sz + te, ke)):
         hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[table]), NULL, NULL, C.c_long(0), cid, hip._p(d_token_next), C.c_long(tokw), col, B, width,
                                           NULL, hip.f32(1.0)), "scatter sos ts/key")
+    if concurrent:
+        dEnc.add_(dEnc_staff[0]).add_(dEnc_staff[1])
     # ---- attention keys: K = enc W_e^T  ->  dW_e += dK^T enc ; dEnc += dK W_e
     enc2d = enc.view(B * T, H2)
     for p, dKp in dK.items():
