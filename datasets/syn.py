@@ -92,3 +92,12 @@ class SyntheticClips(Dataset):
     def __getitem__(self, idx):
         b = synthetic.make_batch(1, self.cfg, self.seed + idx, frames=self.frames, **self.kw)
         return tuple(t[0] for t in b[:7]) + (b[7][0], int(b[8][0]))
+
+
+class SyntheticWaveClips(SyntheticClips):
+    """As SyntheticClips but the first element is a raw 16 kHz waveform (N,) -- exercises the online VQT front-end."""
+
+    def __getitem__(self, idx):
+        item = super().__getitem__(idx)
+        wave = synthetic.make_waveforms(1, self.seed + idx, seconds=(self.frames - 1) / 100.0)[0]
+        return (wave,) + item[1:]

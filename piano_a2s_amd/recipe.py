@@ -24,12 +24,27 @@ def _to_device(batch, device):
     return [t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch]
 
 
+_VQT = {}
+
+
+def _features(batch, device):
+    """Online front-end: when the loader yields raw 16 kHz waveforms (B, N) instead of cached spectrograms
+    (B, 1, T, F), the VQT runs on the GPU in front of the model (piano_a2s_amd.vqt; the reference caches librosa features offline)."""
+    batch = _to_device(batch, device)
+    if torch.is_tensor(batch[0]) and batch[0].dim() == 2:
+        from piano_a2s_amd.vqt import VQT
+        if device not in _VQT:
+            _VQT[device] = VQT(torch.device(device))
+        batch[0] = _VQT[device](batch[0])
+    return batch
+
+
 class ASR(sb.Brain):
     finetune = False
 
     # ------------------------------------------------------------------ forward / objective
     def compute_forward(self, batch, stage):
-        batch = _to_device(batch, self.device)
+        batch = _features(batch, self.device)
         spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = batch[:7]
         if stage == sb.Stage.TRAIN:
             return self.modules.transcription(spectrogram=spectrogram, inference=False,
@@ -93,7 +108,7 @@ class ASR(sb.Brain):
         if not fused:
             return super().fit_batch(batch)
         fused.opt.lr = self.optimizer.param_groups[0]["lr"]          # NewBob annealing acts on the torch optimizer object
-        losses = fused(_to_device(batch, self.device), self.teacher_forcing_ratio)
+        losses = fused(_features(batch, self.device), self.teacher_forcing_ratio)
         terms = losses[:, 0].tolist()                                 # one small D2H per step (the reference does four)
         self._record_losses(*[torch.tensor(t) for t in terms])
         return torch.tensor(sum(terms))

@@ -88,3 +88,24 @@ def make_batch(batch, cfg, seed, frames=1201, upper_range=(20, 120), lower_range
     names = [f"syn{seed}_{b}~synthetic" for b in range(batch)]
     return (t(spec), t(ts), t(key), t(up), t(up_len), t(lo), t(lo_len), names,
             torch.zeros(batch, dtype=torch.long))
+
+
+def make_waveforms(batch, seed, seconds=12.0, sr=16000, device="cpu"):
+    """Synthetic 16 kHz clips for the online VQT front-end: up to 6 simultaneous decaying harmonic tones at MIDI 21-108,
+    peak-normalised to 0.9.  Returns (batch, seconds*sr) float32."""
+    rng = np.random.default_rng(seed)
+    n = int(seconds * sr)
+    t = np.arange(n, dtype=np.float64) / sr
+    out = np.zeros((batch, n), dtype=np.float64)
+    for b in range(batch):
+        for _ in range(int(rng.integers(12, 40))):
+            midi = int(rng.integers(21, 109))
+            f0 = 440.0 * 2.0 ** ((midi - 69) / 12.0)
+            t0 = float(rng.uniform(0, seconds * 0.95))
+            dur = float(rng.uniform(0.15, 2.0))
+            env = np.where(t >= t0, np.exp(-(t - t0) / (0.35 * dur)), 0.0) * (t < t0 + 2.5 * dur)
+            for h, a in ((1, 1.0), (2, 0.5), (3, 0.25), (4, 0.12)):
+                if f0 * h < sr / 2:
+                    out[b] += a * env * np.sin(2 * np.pi * f0 * h * (t - t0))
+        out[b] *= 0.9 / max(np.abs(out[b]).max(), 1e-9)
+    return torch.from_numpy(out.astype(np.float32)).to(device)

@@ -23,7 +23,9 @@ def main(argv):
 
     n_syn = int(hparams.get("synthetic_clips", 0) or 0)
     if n_syn:
-        from datasets.syn import SyntheticClips
+        from datasets.syn import SyntheticClips, SyntheticWaveClips
+        if hparams.get("online_vqt"):                      # raw waveforms -> GPU VQT -> model (instead of cached spectrograms)
+            SyntheticClips = SyntheticWaveClips
         cfg = hparams["transcription"].cfg
         syn = dict(frames=int(hparams.get("synthetic_frames") or hparams["max_frame_num"]))
         if hparams.get("synthetic_lengths"):

@@ -29,3 +29,16 @@ def test_pretrain_on_gpu(tmp_path):
     assert len(os.listdir(os.path.join(out, "save"))) == 1
     rec = json.load(open(os.path.join(out, "results", "test", os.listdir(os.path.join(out, "results", "test"))[0])))
     assert len(rec["pred"]) == 5
+
+
+def test_pretrain_with_online_vqt(tmp_path):
+    """waveform -> GPU VQT (480 bins) -> model: full-width front-end, reduced model behind it, 1 epoch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pretrain
+    args = [os.path.join(ROOT, "hparams", "pretrain.yaml"), "--device=cuda:0", f"--workspace={tmp_path}", "--soundfont_folder=/none",
+            "--synthetic_clips=4", "--online_vqt=True", "--hidden_size=32", "--conv_feature_size=32", "--max_length=(12, 8)",
+            "--synthetic_frames=101", "--synthetic_lengths=[[3, 10], [2, 7]]", "--batch_size=2", "--number_of_epochs=1"]
+    brain = pretrain.main(args)
+    assert brain._fused and brain.modules.transcription.cfg["freq_bins"] == 480
+    assert os.path.exists(os.path.join(str(tmp_path), "1234", "pretrain.epr", "train_log.txt"))
