@@ -99,7 +99,9 @@ typedef struct a2s_note_dec_args {
     int* steps_exec;                  /* device counter: +1 per step that actually decoded (greedy early break) */
     float* attn_ws;                   /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
     float* gemm_ws; size_t gemm_ws_bytes;   /* split-K scratch for the per-step skinny GEMMs (NULL: no split-K) */
+    int* t_base;                      /* device int (graph mode): base step index of the chunk being replayed */
     int R, T, H, E, V, steps, poll, eos_id;
+    int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
 } a2s_note_dec_args;
 int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done);
 

@@ -167,13 +167,16 @@ struct StepFinArgs {
     const uint8_t* drop; float inv_keep;  // (R, E) keep mask for the NEXT token or null
     int* argmax_out; long am_bstride;     // ids[b*am_bstride + t] (int32) or null
     int* eos_seen; long long* lengths; int* n_done; int* steps_exec;
-    int R, V, E, t, teacher_force, eos_id;
+    const int* t_base;                    // graph replay: step index = t + *t_base (null: t)
+    int R, V, E, t, teacher_force, eos_id, max_t;
 };
 
 __global__ __launch_bounds__(256) void note_step_finalize(StepFinArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.R) return;
     if (*a.n_done >= a.R && a.gt == nullptr) return;
+    const int t = a.t + (a.t_base ? *a.t_base : 0);
+    if (t >= a.max_t) return;                                   // a replayed chunk may overshoot the step budget
     const float* lg = a.logits + (long)row * a.ldl;
     float m = -INFINITY; int mi = 0x7fffffff;
     for (int j = lane; j < a.V; j += 64) { const float x = lg[j]; if (x > m) { m = x; mi = j; } }
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(256) void note_step_finalize(StepFinArgs a) {
     for (int j = lane; j < a.V; j += 64) s += expf(lg[j] - m);
     s = wave_sum(s);
     const float lse = m + logf(s);
-    float* pr = a.probs + (long)row * a.probs_bstride + (long)a.t * a.V;
+    float* pr = a.probs + (long)row * a.probs_bstride + (long)t * a.V;
     for (int j = lane; j < a.V; j += 64) pr[j] = lg[j] - lse;
-    const long long g = a.gt ? a.gt[(long)row * a.gt_bstride + a.t] : -1;
+    const long long g = a.gt ? a.gt[(long)row * a.gt_bstride + t] : -1;
     const int next_id = (a.gt && a.teacher_force) ? (int)g : mi;
     for (int j = lane; j < a.E; j += 64) {
         float e = a.emb[(long)next_id * a.E + j];
@@ -196,12 +199,12 @@ __global__ __launch_bounds__(256) void note_step_finalize(StepFinArgs a) {
         a.xnext[(long)row * a.ldx + j] = e;
     }
     if (lane == 0) {
-        if (row == 0 && a.steps_exec) *a.steps_exec = a.t + 1;      // steps run in order on one stream
-        if (a.argmax_out) a.argmax_out[(long)row * a.am_bstride + a.t] = mi;
+        if (row == 0 && a.steps_exec) *a.steps_exec = t + 1;      // steps run in order on one stream
+        if (a.argmax_out) a.argmax_out[(long)row * a.am_bstride + t] = mi;
         const bool hit = a.gt ? (g == a.eos_id) : (mi == a.eos_id);
         if (hit) {
             if (!a.eos_seen[row]) { a.eos_seen[row] = 1; atomicAdd(a.n_done, 1); }
-            a.lengths[row] = a.t + 1;
+            a.lengths[row] = t + 1;
         }
     }
 }
@@ -268,45 +271,93 @@ int a2s_embed_rows_impl(hipStream_t st, const float* table, const long long* ids
 // no-op once n_done == R, and the host polls n_done every `poll` steps to stop launching.
 typedef a2s_note_dec_args NoteDecArgs;   // one definition only: the public C struct (include/a2s.h)
 
-int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_done) {
+// one decode step: state read from slot `si`, written to slot `so` (slot = step index, or step parity in graph mode);
+// per-step saved tensors (q, o, gates, attention weights) go to index `sv`
+static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int so, int sv, int t, const int* t_base, int tf) {
     const int H2 = 2 * a.H, ldx = a.E + H2;
+    const float* hp = a.h + (long)si * a.R * H2;
+    float* hq = a.h + (long)so * a.R * H2;
+    float* xs = a.x + (long)si * a.R * ldx;
+    float* qs = a.q + (long)sv * a.R * a.H;
+    float* os = a.o + (long)sv * a.R * 2 * H2;
+    int rc;
+    // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
+    rc = a2s_gemm_impl(st, a.R, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    if (rc) return rc;
+    // gh = h W_hh^T + b_hh
+    rc = a2s_gemm_impl(st, a.R, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    if (rc) return rc;
+    // attention -> ctx into x[si][:, E:] and o[sv][:, 2H:]
+    rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
+                                a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws);
+    if (rc) return rc;
+    // gi = x W_ih^T + b_ih
+    rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    if (rc) return rc;
+    // h' -> h[so] and o[sv][:, :2H]
+    rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
+                                a.gates ? a.gates + (long)sv * a.R * 4 * H2 : nullptr, a.R, H2);
+    if (rc) return rc;
+    // logits = o W_out^T + b_out
+    rc = a2s_gemm_impl(st, a.R, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    if (rc) return rc;
+    StepFinArgs f;
+    f.logits = a.logits; f.ldl = a.V; f.probs = a.probs; f.probs_bstride = a.probs_bstride;
+    f.gt = a.gt; f.gt_bstride = a.gt_bstride; f.emb = a.emb;
+    f.xnext = a.x + (long)so * a.R * ldx; f.ldx = ldx;
+    f.drop = a.drop ? a.drop + (long)so * a.R * a.E : nullptr; f.inv_keep = a.inv_keep;
+    f.argmax_out = a.argmax_out; f.am_bstride = a.am_bstride;
+    f.eos_seen = a.eos_seen; f.lengths = a.lengths; f.n_done = a.n_done; f.steps_exec = a.steps_exec;
+    f.t_base = t_base;
+    f.R = a.R; f.V = a.V; f.E = a.E; f.t = t; f.teacher_force = tf; f.eos_id = a.eos_id; f.max_t = a.steps;
+    return a2s_note_step_finalize_impl(st, f);
+}
+
+__global__ void advance_counter(int* p, int inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += inc; }
+
+// Greedy decode as a replayed hipGraph: the state ping-pongs between two slots (nothing is kept for a backward pass), the step
+// index comes from a device counter, so ONE captured chunk of `chunk` steps serves the whole sequence; the host replays it and
+// looks at the done counter after every replay.  Removes the per-launch host cost that dominates small-batch decoding.
+static int note_decoder_greedy_graph(hipStream_t st, const NoteDecArgs& a, int* steps_done) {
+    int chunk = a.poll > 0 ? a.poll : 16;
+    if (chunk & 1) ++chunk;                                   // even: the state is back in slot 0 after every replay
+    hipError_t e = hipMemsetAsync(a.t_base, 0, sizeof(int), st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "greedy graph memset: %s", hipGetErrorString(e));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    int rc = A2S_OK;
+    for (int j = 0; j < chunk && rc == A2S_OK; ++j) rc = enqueue_note_step(st, a, j & 1, (j + 1) & 1, 0, j, a.t_base, 0);
+    if (rc == A2S_OK) hipLaunchKernelGGL(advance_counter, dim3(1), dim3(64), 0, st, a.t_base, chunk);
+    e = hipStreamEndCapture(st, &graph);
+    if (rc != A2S_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); A2S_FAIL(A2S_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    int launched = 0;
+    while (launched < a.steps) {
+        e = hipGraphLaunch(exec, st);
+        if (e != hipSuccess) break;
+        launched += chunk;
+        int done = 0;
+        e = hipMemcpyAsync(&done, a.n_done, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess || done >= a.R) break;
+    }
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "greedy graph replay: %s", hipGetErrorString(e));
+    if (steps_done) *steps_done = launched < a.steps ? launched : a.steps;
+    return A2S_OK;
+}
+
+int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_done) {
+    // stream capture is not allowed on the legacy default stream: callers that want the graph path run on a created stream
+    if (!a.gt && a.use_graph && a.t_base && !a.gates && !a.attw && !a.drop && st != nullptr) return note_decoder_greedy_graph(st, a, steps_done);
     int s = 0;
     for (; s < a.steps; ++s) {
-        const float* hp = a.h + (long)s * a.R * H2;
-        float* hq = a.h + (long)(s + 1) * a.R * H2;
-        float* xs = a.x + (long)s * a.R * ldx;
-        float* qs = a.q + (long)s * a.R * a.H;
-        float* os = a.o + (long)s * a.R * 2 * H2;
-        int rc;
-        // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
-        rc = a2s_gemm_impl(st, a.R, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
-        // gh = h W_hh^T + b_hh
-        rc = a2s_gemm_impl(st, a.R, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
-        // attention -> ctx into x[s][:, E:] and o[s][:, 2H:]
-        rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
-                                    a.attw ? a.attw + (long)s * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws);
-        if (rc) return rc;
-        // gi = x W_ih^T + b_ih
-        rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
-        // h' -> h[s+1] and o[s][:, :2H]
-        rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
-                                    a.gates ? a.gates + (long)s * a.R * 4 * H2 : nullptr, a.R, H2);
-        if (rc) return rc;
-        // logits = o W_out^T + b_out
-        rc = a2s_gemm_impl(st, a.R, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
-        StepFinArgs f;
-        f.logits = a.logits; f.ldl = a.V; f.probs = a.probs; f.probs_bstride = a.probs_bstride;
-        f.gt = a.gt; f.gt_bstride = a.gt_bstride; f.emb = a.emb;
-        f.xnext = a.x + (long)(s + 1) * a.R * ldx; f.ldx = ldx;
-        f.drop = a.drop ? a.drop + (long)(s + 1) * a.R * a.E : nullptr; f.inv_keep = a.inv_keep;
-        f.argmax_out = a.argmax_out; f.am_bstride = a.am_bstride;
-        f.eos_seen = a.eos_seen; f.lengths = a.lengths; f.n_done = a.n_done; f.steps_exec = a.steps_exec;
-        f.R = a.R; f.V = a.V; f.E = a.E; f.t = s; f.teacher_force = a.tf_flags ? a.tf_flags[s] : 0; f.eos_id = a.eos_id;
-        rc = a2s_note_step_finalize_impl(st, f);
+        int rc = enqueue_note_step(st, a, s, s + 1, s, s, nullptr, a.tf_flags ? a.tf_flags[s] : 0);
         if (rc) return rc;
         if (!a.gt && a.poll > 0 && ((s + 1) % a.poll == 0) && s + 1 < a.steps) {
             int done = 0;   // greedy only: one small D2H + sync per `poll` steps

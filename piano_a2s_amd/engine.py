@@ -35,6 +35,12 @@ def plan_note_steps(gt_rows, max_steps):
     return steps, lengths
 
 
+import os as _os
+
+# hipGraph replay of the greedy decoder (configs[4] of BASELINE.json asks for it): built and parity-tested, but measured no faster
+# than eager launches on MI355X (B=8: 0.232 s vs 0.212 s for 2223 steps) -- the step is bound by the GPU-side execution of ~13 small
+# kernels, not by host launch cost -- so it is opt-in.
+_GREEDY_GRAPH = _os.environ.get("A2S_GREEDY_GRAPH") == "1"
 _SIDE_STREAMS = {}
 
 
@@ -203,6 +209,8 @@ class Engine:
         H2, ldx = 2 * H, E + 2 * H
         dev = enc.device
         n = steps
+        graph = gt_bar is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH)     # greedy decode: replayed hipGraph
+        t_base = torch.zeros(1, dtype=torch.int32, device=dev) if graph else None
         h = self._empty(n + 1, B, H2, dev=dev)
         h[0].copy_(h0)
         x = self._empty(n + 1, B, ldx, dev=dev)
@@ -232,7 +240,7 @@ class Engine:
                         ("b_hh", S[prefix + ".gru.bias_hh_l0"]), ("out_w", S[prefix + ".out.weight"]), ("out_b", S[prefix + ".out.bias"]),
                         ("emb", S[prefix + ".embedding.weight"]), ("keys", keys), ("enc", enc), ("h", h), ("x", x), ("q", q),
                         ("gates", gates), ("attw", attw), ("o", o), ("gh", gh), ("gi", gi), ("logits", logits),
-                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", gemm_ws)):
+                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", gemm_ws), ("t_base", t_base)):
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.gemm_ws_bytes = gemm_ws.numel() * 4 if gemm_ws is not None else 0
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
@@ -244,6 +252,7 @@ class Engine:
         a.inv_keep = 1.0 / (1.0 - drop_p) if drop is not None else 1.0
         a.am_bstride = max_steps
         a.R, a.T, a.H, a.E, a.V, a.steps, a.poll, a.eos_id = B, T, H, E, V, n, (self.poll if gt_bar is None else 0), EOS
+        a.use_graph = 1 if graph else 0
         done = C.c_int(0)
         hip.check(L.a2s_note_decoder_fwd(hip.stream(), C.byref(a), C.byref(done)), "a2s_note_decoder_fwd")
         # steps the reference would have executed: known from the plan with ground truth; read back from the device
@@ -354,6 +363,14 @@ class Engine:
                     done = torch.cuda.Event()
                     done.record(st)
                     joins.append(done)
+                elif gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH):
+                    # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
+                    st = side_streams(dev)[0]
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
+                                                              training, 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx])
+                    torch.cuda.current_stream().wait_stream(st)
                 else:
                     ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
                                                           training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx])

@@ -25,9 +25,9 @@ class NoteDecArgs(C.Structure):
         ("drop", C.c_void_p), ("inv_keep", C.c_float),
         ("argmax_out", C.c_void_p), ("am_bstride", C.c_long),
         ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p), ("attn_ws", C.c_void_p),
-        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t),
+        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("t_base", C.c_void_p),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
-        ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int)]
+        ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int), ("use_graph", C.c_int)]
 
 
 class NoteDecBwdArgs(C.Structure):

@@ -135,3 +135,21 @@ def test_full_size_greedy_ids_exact(golden_dir, dev):
         assert np.abs(got - rs).max() <= TOL * max(1.0, np.abs(rs).max()), f"{nm} log-probs {np.abs(got - rs).max():.3e}"
     assert np.abs(ts.cpu().numpy() - data["greedy.ts"]).max() <= TOL
     assert np.abs(key.cpu().numpy() - data["greedy.key"]).max() <= TOL
+
+
+def test_greedy_graph_replay_matches_eager(g1, dev):
+    """The hipGraph-replayed greedy decoder (opt-in) must give the same token ids, log-probs and executed-step counts as eager launches."""
+    from piano_a2s_amd import engine
+    data, meta, cfg, batch = g1
+    S = _state(cfg, meta["cases"]["greedy_s11"], dev)
+    outs = []
+    for graph in (False, True):
+        eng = engine.Engine(cfg)
+        eng.greedy_graph = graph
+        o = eng.forward(S, batch[0].to(dev), inference=True)
+        torch.cuda.synchronize()
+        outs.append(([t.cpu() for t in o], [b["staff"][k][2]["steps"] for b in eng.saved["bars"] for k in ("up", "lo")]))
+    assert outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    _check(outs[1][0], data, "greedy_s11")
