@@ -1,7 +1,7 @@
 """Forward-only timing probe (round-1 development aid): training-mode teacher-forced forward at full model size."""
 import sys, time, random
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from piano_a2s_amd import engine, spec, synthetic
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
