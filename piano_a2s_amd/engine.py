@@ -54,6 +54,14 @@ def side_streams(device):
     return _SIDE_STREAMS[key]
 
 
+def encoder_streams(device):
+    """Streams for the two directions of an encoder GRU layer (A2S_ENC_SERIAL=1: both on the current stream, for A/B measurements)."""
+    if _os.environ.get("A2S_ENC_SERIAL") == "1":
+        cur = torch.cuda.current_stream()
+        return (cur, cur)
+    return side_streams(device)
+
+
 def _dist_world():
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0     # 0 = no process group
@@ -145,24 +153,38 @@ class Engine:
         H = self.cfg["hidden_size"]
         dev = x.device
         saved = {"layers": []}
-        gws = hip.gemm_workspace(B, dev)
+        gws = [hip.gemm_workspace(B, dev), hip.gemm_workspace(B, dev)]
+        streams = encoder_streams(dev)           # the two directions of a layer are independent 1201-step chains: one stream each
         inp = x.reshape(B * T, -1)
         finals = []
         for layer in (0, 1):
             out = self._empty(B, T, 2 * H, dev=dev)
             lsave = {"in": inp, "dirs": []}
+            gis = [hip.linear(inp, S[f"encoder.gru.weight_ih_{sfx}"], S[f"encoder.gru.bias_ih_{sfx}"])      # (B*T, 3H) per direction
+                   for sfx in (f"l{layer}", f"l{layer}_reverse")]
+            fork = torch.cuda.Event()
+            fork.record()
+            joins = []
             for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
-                gi = hip.linear(inp, S[f"encoder.gru.weight_ih_{sfx}"], S[f"encoder.gru.bias_ih_{sfx}"])      # (B*T, 3H)
-                hbuf = self._empty(2, B, H, dev=dev)
-                gh = self._empty(B, 3 * H, dev=dev)
-                hn = self._empty(B, H, dev=dev)
-                gates = self._empty(T, B, 4 * H, dev=dev) if training else None
-                hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H),
-                                            hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(S[f"encoder.gru.bias_hh_{sfx}"]),
-                                            C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
-                                            hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d, hip._p(gws), C.c_size_t(gws.numel() * 4)), "a2s_gru_seq_fwd")
+                gi = gis[d]
+                streams[d].wait_event(fork)
+                with torch.cuda.stream(streams[d]):
+                    hbuf = self._empty(2, B, H, dev=dev)
+                    gh = self._empty(B, 3 * H, dev=dev)
+                    hn = self._empty(B, H, dev=dev)
+                    gates = self._empty(T, B, 4 * H, dev=dev) if training else None
+                    hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H),
+                                                hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(S[f"encoder.gru.bias_hh_{sfx}"]),
+                                                C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
+                                                hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d, hip._p(gws[d]),
+                                                C.c_size_t(gws[d].numel() * 4)), "a2s_gru_seq_fwd")
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    joins.append(ev)
                 finals.append(hn)
-                lsave["dirs"].append({"gi": gi, "gates": gates, "hn": hn})
+                lsave["dirs"].append({"gi": gi, "gates": gates, "hn": hn, "scratch": (hbuf, gh)})
+            for ev in joins:
+                torch.cuda.current_stream().wait_event(ev)
             lsave["out"] = out
             saved["layers"].append(lsave)
             inp = out.view(B * T, 2 * H)

@@ -284,7 +284,7 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
             hip.gemm(dpre, 1, 2 * H, hfin, H, 1, G["encoder.fc.weight"], 2 * H, H, H, B, beta=1.0, a_off=l * H, c_off=half * H)   # dW += dpre_l^T h_fin
             dhn.append(d)
         _colsum(dpre, 2 * H, G["encoder.fc.bias"], B, H, x_off=l * H)
-    gws = hip.gemm_workspace(B, dev)
+    gws = [hip.gemm_workspace(B, dev), hip.gemm_workspace(B, dev)]
     dout = dEnc                                              # gradient wrt layer-1 outputs (B,T,2H)
     for layer in (1, 0):
         ls = es["layers"][layer]
@@ -292,14 +292,29 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
         I = inp.shape[1]
         out = ls["out"]
         dX = torch.empty((B * T, I), device=dev)
+        from .engine import encoder_streams
+        streams = encoder_streams(dev)                    # the two directions' BPTT chains are independent: one stream each
+        fork = torch.cuda.Event()
+        fork.record()
+        res, joins = [], []
         for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
-            dgi = torch.empty((B, T, 3 * H), device=dev)
-            dghs = torch.empty((B, T, 3 * H), device=dev)
-            dgh_first, dhbuf, dgh_tmp = torch.empty((B, 3 * H), device=dev), torch.empty((2, B, H), device=dev), torch.empty((B, 3 * H), device=dev)
-            hip.check(L.a2s_gru_seq_bwd(hip.stream(), _ptr(dout, d * H), C.c_long(T * 2 * H), C.c_long(2 * H), _ptr(out, d * H), C.c_long(T * 2 * H),
-                                        C.c_long(2 * H), hip._p(ls["dirs"][d]["gates"]), hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(dhn[2 * layer + d]),
-                                        hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf), hip._p(dgh_tmp), B, T, H, d, hip._p(gws), C.c_size_t(gws.numel() * 4)),
-                      "a2s_gru_seq_bwd")
+            streams[d].wait_event(fork)
+            with torch.cuda.stream(streams[d]):
+                dgi = torch.empty((B, T, 3 * H), device=dev)
+                dghs = torch.empty((B, T, 3 * H), device=dev)
+                dgh_first, dhbuf, dgh_tmp = torch.empty((B, 3 * H), device=dev), torch.empty((2, B, H), device=dev), torch.empty((B, 3 * H), device=dev)
+                hip.check(L.a2s_gru_seq_bwd(hip.stream(), _ptr(dout, d * H), C.c_long(T * 2 * H), C.c_long(2 * H), _ptr(out, d * H), C.c_long(T * 2 * H),
+                                            C.c_long(2 * H), hip._p(ls["dirs"][d]["gates"]), hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(dhn[2 * layer + d]),
+                                            hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf), hip._p(dgh_tmp), B, T, H, d, hip._p(gws[d]),
+                                            C.c_size_t(gws[d].numel() * 4)), "a2s_gru_seq_bwd")
+                ev = torch.cuda.Event()
+                ev.record()
+                joins.append(ev)
+            res.append((dgi, dghs, dgh_first, dhbuf, dgh_tmp))
+        for ev in joins:
+            torch.cuda.current_stream().wait_event(ev)
+        for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):      # deferred weight / input gradients (main stream, ordered)
+            dgi, dghs, dgh_first = res[d][:3]
             dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)
             _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}", dx=dX,
                         dx_beta=0.0 if d == 0 else 1.0)
