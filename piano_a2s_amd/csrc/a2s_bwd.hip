@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
     if (rg > 0) red4[(rg - 1) * 64 + c4] = acc;
     __syncthreads();
     if (rg == 0) {
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + c4 * 4);
+        const f32x4 v4 = {v[c4 * 4], v[c4 * 4 + 1], v[c4 * 4 + 2], v[c4 * 4 + 3]};            // parameter: 4-byte aligned only
 #pragma unroll
         for (int u = 0; u < 3; ++u) { const f32x4 o = red4[u * 64 + c4];
 #pragma unroll

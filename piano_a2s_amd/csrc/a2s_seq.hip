@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
     const float* Kb = Kmat + ((long)b * T + t0) * H;
     const float* Eb = enc + ((long)b * T + t0) * 2 * H;
     const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)b * ldq + lane * 4);
-    const f32x4 v4 = *reinterpret_cast<const f32x4*>(v + lane * 4);
+    const f32x4 v4 = {v[lane * 4], v[lane * 4 + 1], v[lane * 4 + 2], v[lane * 4 + 3]};      // parameter (view of the flat buffer): 4-byte aligned only
     // ---- pass 1: scores of the chunk; one wave per frame, 4 frames in flight per wave
     for (int r = wave * 4; r < n; r += 16) {
         f32x4 k[4];

@@ -138,3 +138,21 @@ def test_sync_bn_single_rank_equals_local_bn(case, dev):
             assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-5, atol=1e-6), k
     finally:
         dist.destroy_process_group()
+
+
+def test_full_width_step_with_flat_parameters(dev):
+    """The fused training step on the 256-wide model whose parameters are views of ONE flat buffer (arbitrary 4-byte offsets): exercises
+    the 16-byte-load kernels' alignment handling on the real parameter layout (separately allocated test tensors are always aligned)."""
+    import models
+    from piano_a2s_amd import spec, synthetic, train
+    cfg = spec.default_cfg(max_length=(12, 8), max_bars=2)
+    m = models.ScoreTranscription(**cfg).to(dev)
+    m.train()
+    step = train.TrainStep(m, dropout=True)
+    batch = synthetic.make_batch(3, cfg, 9, frames=57, upper_range=(3, 10), lower_range=(2, 7), full_tail=0.2)
+    dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
+    before = step.flat.clone()
+    losses = step(dbatch, teacher_forcing_ratio=0.7)
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses).all() and float(step.opt.ctl[2]) == 1.0
+    assert not torch.equal(before, step.flat)
