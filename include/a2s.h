@@ -100,6 +100,11 @@ typedef struct a2s_note_dec_args {
     float* attn_ws;                   /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
     float* gemm_ws; size_t gemm_ws_bytes;   /* split-K scratch for the per-step skinny GEMMs (NULL: no split-K) */
     int* t_base;                      /* device int (graph mode): base step index of the chunk being replayed */
+    /* optional, training only -- skip the attention of finished rows (context = 0): once a row's remaining targets are all <pad>
+       nothing reaching the loss depends on it.  Rows sorted by the step they finish at, latest first: */
+    const int* row_order;             /* device, R ints: row ids in that order */
+    const int* row_rank;              /* device, R ints: inverse permutation */
+    const int* n_active;              /* HOST, `steps` ints: rows still unfinished at step t (= the prefix of row_order computed) */
     int R, T, H, E, V, steps, poll, eos_id;
     int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
 } a2s_note_dec_args;
@@ -128,7 +133,7 @@ int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const f
                       long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* workspace);
 /* deferred key gradient of S steps: dK += ..., dv partials [B*ceil(T/16)][H] (reduce with a2s_col_sum) */
 int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
-                      float* dv_partial, int B, int T, int S, int H);
+                      float* dv_partial, int B, int T, int S, int H, const int* active_until /* optional, B ints: clip b's ds rows are zero from step active_until[b] on */);
 int a2s_attn_dk_blocks(int B, int T);
 /* out[c] = alpha * sum_r x[r*ld+c] + beta*out[c]; with a workspace (>= 2*C floats, ideally 1024*C) long matrices are reduced in two
  * stages over many workgroups (fixed partition: deterministic). */
@@ -146,6 +151,9 @@ typedef struct a2s_note_dec_bwd_args {
     float* dh;                           /* (2, R, 2H) carry; dh[0] = gradient wrt the initial hidden on return */
     float* attn_ws;                      /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
     float* gemm_ws; size_t gemm_ws_bytes;   /* split-K scratch for the per-step skinny GEMMs (NULL: no split-K) */
+    const int* row_order;                /* the forward's row compaction (or NULL): see a2s_note_dec_args */
+    const int* row_rank;
+    const int* n_active;                 /* HOST */
     int R, T, H, E, steps;
 } a2s_note_dec_bwd_args;
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);

@@ -125,13 +125,16 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
 
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
-                                 long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H);
+                                 long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
+                                 const int* row_order, const int* row_rank, int n_active);
 
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
-                           long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws) {
+                           long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws,
+                           const int* row_order = nullptr, const int* row_rank = nullptr, int n_active = 0) {
     if (H == 256 && ws)
-        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H);
+        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H,
+                                            row_order, row_rank, n_active);
     const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
     if (H == 256) hipLaunchKernelGGL(attn_step_bwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
     else if (H == 32) hipLaunchKernelGGL(attn_step_bwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
@@ -147,7 +150,8 @@ int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, 
 template <int H>
 __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ Kmat, const float* __restrict__ q_all,
                                                      const float* __restrict__ ds_all, const float* __restrict__ v,
-                                                     float* __restrict__ dK, float* __restrict__ dv_partial, int B, int T, int S) {
+                                                     float* __restrict__ dK, float* __restrict__ dv_partial, int B, int T, int S,
+                                                     const int* __restrict__ active_until) {
     constexpr int TT = 16;
     const int tiles = (T + TT - 1) / TT;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * TT;
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ K
 #pragma unroll
         for (int i = 0; i < TT; ++i) { kreg[i] = (t0 + i < T) ? Kmat[((long)b * T + t0 + i) * H + j] : 0.f; acc[i] = 0.f; }
     }
+    if (active_until) S = min(S, active_until[b]);          // ds is exactly zero for the steps this clip's row was skipped
     for (int s = 0; s < S; ++s) {
         __syncthreads();
         if (threadIdx.x < TT) dss[threadIdx.x] = (t0 + threadIdx.x < T) ? ds_all[((long)s * B + b) * T + t0 + threadIdx.x] : 0.f;
@@ -183,10 +188,10 @@ __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ K
 }
 
 int a2s_attn_dk_accum_impl(hipStream_t st, const float* Kmat, const float* q_all, const float* ds_all, const float* v,
-                           float* dK, float* dv_partial, int B, int T, int S, int H) {
+                           float* dK, float* dv_partial, int B, int T, int S, int H, const int* active_until) {
     const int nblk = B * a2s_cdiv(T, 16);
-    if (H == 256) hipLaunchKernelGGL(attn_dk_accum<256>, dim3(nblk), dim3(256), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S);
-    else if (H == 32) hipLaunchKernelGGL(attn_dk_accum<32>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S);
+    if (H == 256) hipLaunchKernelGGL(attn_dk_accum<256>, dim3(nblk), dim3(256), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, active_until);
+    else if (H == 32) hipLaunchKernelGGL(attn_dk_accum<32>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, active_until);
     else A2S_FAIL(A2S_ERR_ARG, "attn_dk_accum: hidden_size must be 256 or 32 (got %d)", H);
     A2S_CHECK_LAUNCH("attn_dk_accum");
     return A2S_OK;
@@ -304,7 +309,7 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
         rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
                                     a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
                                     a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
-                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws);
+                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, a.row_order, a.row_rank, a.row_order ? a.n_active[s] : 0);
         if (rc) return rc;
         // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
         rc = a2s_gemm_impl(st, R, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
@@ -461,12 +466,14 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
                                                          const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
                                                          const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
                                                          float* __restrict__ dctx_out, long lddo, float* __restrict__ dq_partial,
-                                                         float* __restrict__ ds_out, int T, int G, int chunk) {
+                                                         float* __restrict__ ds_out, int T, int G, int chunk,
+                                                         const int* __restrict__ row_order) {
     constexpr int H = 256;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dsv = sm;                                   // chunk
     f32x4* red4 = reinterpret_cast<f32x4*>(sm + chunk);   // 3 * 64 float4
-    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = row_order ? row_order[slot] : slot;
     const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Kb = Kmat + ((long)b * T + t0) * H;
@@ -551,35 +558,49 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
             for (int c = 0; c < 4; ++c) acc[c] += o[c]; }
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] *= v4[c];
-        *reinterpret_cast<f32x4*>(dq_partial + ((long)b * G + g) * H + c4 * 4) = acc;
+        *reinterpret_cast<f32x4*>(dq_partial + ((long)slot * G + g) * H + c4 * 4) = acc;
     }
 }
 
-__global__ void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int B, int G) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * 256) return;
-    const int b = idx >> 8, j = idx & 255;
+// one workgroup (256 threads) per clip: dq = sum of the G partials; rows the forward pass skipped (upstream gradient exactly zero) get
+// zeros in everything the deferred GEMMs read (dq, ds, dctx)
+__global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int G,
+                                                           const int* __restrict__ row_rank, int n_active, float* __restrict__ ds_out,
+                                                           int T, float* __restrict__ dctx_out, long lddo) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int slot = row_rank ? row_rank[b] : b;
+    if (slot >= n_active) {
+        dq[(long)b * lddq + j] = 0.f;
+        if (ds_out) for (int t = j; t < T; t += 256) ds_out[(long)b * T + t] = 0.f;
+        if (dctx_out) for (int d = j; d < 512; d += 256) dctx_out[(long)b * lddo + d] = 0.f;
+        return;
+    }
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += dq_partial[((long)b * G + g) * 256 + j];
+    for (int g = 0; g < G; ++g) s += dq_partial[((long)slot * G + g) * 256 + j];
     dq[(long)b * lddq + j] = s;
 }
 
 
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
-                                 long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H) {
+                                 long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
+                                 const int* row_order, const int* row_rank, int n_active) {
     A2S_REQUIRE(H == 256 && ws, "attn_step_bwd_split: needs hidden_size 256 and a workspace");
     A2S_REQUIRE(ldq % 4 == 0 && ldctx % 4 == 0 && ldda % 4 == 0 && (!dctx_b || lddb % 4 == 0) && (!dctx_out || lddo % 4 == 0),
                 "attn_step_bwd_split: row strides must be multiples of 4 floats");
     A2S_REQUIRE(((uintptr_t)q | (uintptr_t)ctx | (uintptr_t)dctx_a | (uintptr_t)dctx_b | (uintptr_t)dctx_out | (uintptr_t)Kmat | (uintptr_t)enc) % 16 == 0,
                 "attn_step_bwd_split: 16-byte alignment");
-    int G, chunk;
-    a2s_attn_split_geometry(B, T, &G, &chunk);
-    const size_t shm = (chunk + 3 * 64 * 4) * sizeof(float);
-    hipLaunchKernelGGL(attn_bwd_split256, dim3(B * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
-                       dctx_out, lddo, ws, ds_out, T, G, chunk);
-    A2S_CHECK_LAUNCH("attn_bwd_split256");
-    hipLaunchKernelGGL(attn_bwd_combine256, dim3(a2s_cdiv(B * 256, 256)), dim3(256), 0, st, ws, dq, lddq, B, G);
+    if (!row_order) n_active = B;
+    A2S_REQUIRE(n_active >= 0 && n_active <= B && (!row_order || row_rank), "attn_step_bwd_split: bad row compaction");
+    int G = 1, chunk = T;
+    if (n_active > 0) {
+        a2s_attn_split_geometry(n_active, T, &G, &chunk);
+        const size_t shm = (chunk + 3 * 64 * 4) * sizeof(float);
+        hipLaunchKernelGGL(attn_bwd_split256, dim3(n_active * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                           dctx_out, lddo, ws, ds_out, T, G, chunk, row_order);
+        A2S_CHECK_LAUNCH("attn_bwd_split256");
+    }
+    hipLaunchKernelGGL(attn_bwd_combine256, dim3(B), dim3(256), 0, st, ws, dq, lddq, G, row_rank, n_active, ds_out, T, dctx_out, lddo);
     A2S_CHECK_LAUNCH("attn_bwd_combine256");
     return A2S_OK;
 }

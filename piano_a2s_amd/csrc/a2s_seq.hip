@@ -138,13 +138,17 @@ __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ K
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
-                                 const int* n_done, int n_rows_total);
+                                 const int* n_done, int n_rows_total, const int* row_order, const int* row_rank, int n_active);
 
+// Row compaction (optional, split kernels only): only rows row_order[0 .. n_active) are computed, the others get context 0.  Used by
+// the fused training step: once a row's remaining targets are all <pad> nothing that reaches the loss depends on it any more.
 int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
-                           const int* n_done, int n_rows_total, float* ws) {
+                           const int* n_done, int n_rows_total, float* ws, const int* row_order = nullptr, const int* row_rank = nullptr,
+                           int n_active = 0) {
     if (H == 256 && ws)
-        return a2s_attn_step_fwd_split_impl(st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, ws, B, T, H, n_done, n_rows_total);
+        return a2s_attn_step_fwd_split_impl(st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, ws, B, T, H, n_done, n_rows_total,
+                                            row_order, row_rank, n_active);
     const size_t shm = (((T + 3) & ~3) + 16) * sizeof(float);
     if (H == 256) hipLaunchKernelGGL(attn_step_fwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
     else if (H == 32) hipLaunchKernelGGL(attn_step_fwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
@@ -289,7 +293,8 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     if (rc) return rc;
     // attention -> ctx into x[si][:, E:] and o[sv][:, 2H:]
     rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
-                                a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws);
+                                a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws,
+                                a.row_order, a.row_rank, a.row_order ? a.n_active[t] : 0);
     if (rc) return rc;
     // gi = x W_ih^T + b_ih
     rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
@@ -447,13 +452,15 @@ int a2s_staff_emb_fwd_impl(hipStream_t st, const float* note_emb, const float* c
 __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                          const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                          float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
-                                                         const int* __restrict__ n_done, int n_rows_total) {
+                                                         const int* __restrict__ n_done, int n_rows_total,
+                                                         const int* __restrict__ row_order) {
     if (n_done && *n_done >= n_rows_total) return;
     constexpr int H = 256;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* pw = sm;                                   // chunk weights exp(s - m_g)
     float* red = sm + chunk;                          // 16 + 2 * 128 * 4 floats (reduction scratch)
-    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;          // slot: position among the rows this launch covers
+    const int b = row_order ? row_order[slot] : slot;
     const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Kb = Kmat + ((long)b * T + t0) * H;
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
     f32x4* red4 = reinterpret_cast<f32x4*>(red + 16);
     if (rp == 1) red4[c4] = acc;
     __syncthreads();
-    float* pout = partial + ((long)b * G + g) * (2 * H + 4);
+    float* pout = partial + ((long)slot * G + g) * (2 * H + 4);
     if (rp == 0) {
         const f32x4 o = red4[c4];
 #pragma unroll
@@ -530,11 +537,18 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
 // merge the G partials of a clip: ctx = sum_g ctx_g e^{m_g-m} / l ; optional normalisation of the saved weights
 __global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restrict__ partial, float* __restrict__ ctx, long ldctx,
                                                            float* __restrict__ ctx2, long ldctx2, float* __restrict__ attw, int T, int G,
-                                                           const int* __restrict__ n_done, int n_rows_total) {
+                                                           const int* __restrict__ n_done, int n_rows_total,
+                                                           const int* __restrict__ row_rank, int n_active) {
     if (n_done && *n_done >= n_rows_total) return;
     constexpr int H = 256;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* pb = partial + (long)b * G * (2 * H + 4);
+    const int slot = row_rank ? row_rank[b] : b;
+    if (slot >= n_active) {      // skipped row: a finite, well-defined context (zeros) keeps the recurrence finite
+        for (int d = tid; d < 2 * H; d += 256) { ctx[(long)b * ldctx + d] = 0.f; if (ctx2) ctx2[(long)b * ldctx2 + d] = 0.f; }
+        if (attw) for (int t = tid; t < T; t += 256) attw[(long)b * T + t] = 0.f;
+        return;
+    }
+    const float* pb = partial + (long)slot * G * (2 * H + 4);
     float m = -INFINITY;
     for (int g = 0; g < G; ++g) m = fmaxf(m, pb[(long)g * (2 * H + 4)]);
     float l = 0.f;
@@ -552,22 +566,32 @@ __global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restri
 
 
 size_t a2s_attn_workspace_floats_impl(int B, int T, int H) {
-    int G, chunk;
-    a2s_attn_split_geometry(B, T, &G, &chunk);
-    return (size_t)B * G * (2 * H + 4);
+    // a launch may cover any n <= B rows (finished rows skipped), each split G(n) ways: size for the largest n * G(n)
+    size_t rows = 0;
+    for (int n = 1; n <= B; ++n) {
+        int G, chunk;
+        a2s_attn_split_geometry(n, T, &G, &chunk);
+        if ((size_t)n * G > rows) rows = (size_t)n * G;
+    }
+    return rows * (2 * H + 4);
 }
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
-                                 const int* n_done, int n_rows_total) {
+                                 const int* n_done, int n_rows_total, const int* row_order, const int* row_rank, int n_active) {
     A2S_REQUIRE(H == 256 && ws, "attn_step_fwd_split: needs hidden_size 256 and a workspace");
     A2S_REQUIRE(ldq % 4 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)Kmat % 16 == 0) && ((uintptr_t)enc % 16 == 0), "attn_step_fwd_split: 16-byte alignment");
-    int G, chunk;
-    a2s_attn_split_geometry(B, T, &G, &chunk);
-    const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
-    hipLaunchKernelGGL(attn_fwd_split256, dim3(B * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, n_done, n_rows_total);
-    A2S_CHECK_LAUNCH("attn_fwd_split256");
-    hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, ws, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total);
+    if (!row_order) n_active = B;
+    A2S_REQUIRE(n_active >= 0 && n_active <= B && (!row_order || row_rank), "attn_step_fwd_split: bad row compaction");
+    int G = 1, chunk = T;
+    if (n_active > 0) {
+        // the grid covers the n_active unfinished rows only, re-split so that it still fills the chip
+        a2s_attn_split_geometry(n_active, T, &G, &chunk);
+        const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
+        hipLaunchKernelGGL(attn_fwd_split256, dim3(n_active * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, n_done, n_rows_total, row_order);
+        A2S_CHECK_LAUNCH("attn_fwd_split256");
+    }
+    hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, ws, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total, row_rank, n_active);
     A2S_CHECK_LAUNCH("attn_fwd_combine256");
     return A2S_OK;
 }

@@ -12,7 +12,7 @@ import random as _py_random
 import torch
 
 from . import hip
-from .spec import EOS, SOS, VOCAB_SIZE
+from .spec import EOS, PAD, SOS, VOCAB_SIZE
 
 
 def plan_note_steps(gt_rows, max_steps):
@@ -224,8 +224,11 @@ class Engine:
             record.append(dict(ids=ids, lengths=lengths, len_stride=len_stride, col0=col0, maxlen=maxlen, id_bstride=id_bstride,
                                i64=ids_are_i64, hsave=hsave))
 
-    def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None):
-        """One NoteDecoder.decode_notes call.  probs_bar: view (B, max_steps, V) of the output tensor (strided)."""
+    def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None,
+                      active=None):
+        """One NoteDecoder.decode_notes call.  probs_bar: view (B, max_steps, V) of the output tensor (strided).
+        active: optional dict(until, order, rank: (B,) int32 device tensors; n_active: host int array per step) -- row b's attention
+        is skipped from step until[b] on (see Engine.skip_finished_rows)."""
         L = hip.lib()
         H, E, V = self.cfg["hidden_size"], self.cfg["note_emb_size"], VOCAB_SIZE
         H2, ldx = 2 * H, E + 2 * H
@@ -262,9 +265,11 @@ class Engine:
                         ("b_hh", S[prefix + ".gru.bias_hh_l0"]), ("out_w", S[prefix + ".out.weight"]), ("out_b", S[prefix + ".out.bias"]),
                         ("emb", S[prefix + ".embedding.weight"]), ("keys", keys), ("enc", enc), ("h", h), ("x", x), ("q", q),
                         ("gates", gates), ("attw", attw), ("o", o), ("gh", gh), ("gi", gi), ("logits", logits),
-                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", gemm_ws), ("t_base", t_base)):
+                        ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", gemm_ws), ("t_base", t_base),
+                        ("row_order", active and active["order"]), ("row_rank", active and active["rank"])):
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.gemm_ws_bytes = gemm_ws.numel() * 4 if gemm_ws is not None else 0
+        a.n_active = C.cast(active["n_active"], C.c_void_p).value if active else None
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
         if gt_bar is not None:
             a.gt, a.gt_bstride = gt_bar.data_ptr(), gt_bar.stride(0)
@@ -281,7 +286,7 @@ class Engine:
         # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
         executed = n if gt_bar is not None else int(steps_exec.item())
         saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
-                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws)
+                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active)
         return ids, lengths, saved
 
     # ------------------------------------------------------------------ full forward
@@ -312,6 +317,27 @@ class Engine:
         if ground_truth is not None:
             ts_gt, key_gt, up_gt, up_len_gt, lo_gt, lo_len_gt = [g.contiguous() for g in ground_truth]
             gt_cpu = (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())      # ONE host sync per forward
+        # Fused training step only (train.TrainStep sets skip_finished_rows): a row whose remaining targets are all <pad> no longer
+        # reaches the loss (ignore_index) nor the next bar token (its staff embedding reads ids[:length] only), so its attention --
+        # the HBM-bound part of a step -- is skipped.  Never set on the drop-in module path, whose output rows past <eos> must equal
+        # the reference's.
+        active_all = None
+        if gt_cpu is not None and training and getattr(self, "skip_finished_rows", False):
+            active_all = []
+            for g, maxs in zip(gt_cpu[:2], (U, Lo)):
+                idx = torch.arange(1, g.shape[-1] + 1, dtype=torch.int32)
+                until = ((g != PAD).to(torch.int32) * idx).amax(dim=-1).to(torch.int32).t().contiguous()       # (bars, B): last real target + 1
+                order = torch.argsort(until, dim=1, descending=True, stable=True).to(torch.int32)           # rows that finish last come first
+                rank = torch.empty_like(order)
+                rank.scatter_(1, order.long(), torch.arange(B, dtype=torch.int32).repeat(bars, 1))
+                d_until, d_order, d_rank = until.to(dev), order.to(dev), rank.to(dev)                       # before the stream fork below
+                per_bar = []
+                for bar in range(bars):
+                    cnt = torch.bincount(until[bar].long(), minlength=maxs + 1)                              # rows finishing at step s
+                    n_act = B - torch.cumsum(cnt, 0)[:maxs]                                                  # rows with until > t
+                    per_bar.append(dict(until=d_until[bar], order=d_order[bar], rank=d_rank[bar],
+                                        n_active=(C.c_int * maxs)(*n_act.tolist())))
+                active_all.append(per_bar)
 
         ts_out = torch.zeros((B, bars, cfg["num_time_sig"]), device=dev)
         key_out = torch.zeros((B, bars, cfg["num_keys"]), device=dev)
@@ -374,14 +400,15 @@ class Engine:
                     steps, plan_len = plan_note_steps(gt_cpu[gi_idx][:, bar, :], maxs)
                     flags = [rng.random() < teacher_forcing_ratio for _ in range(steps)]      # one draw per executed step
                     gt_bar = (up_gt if gi_idx == 0 else lo_gt)[:, bar, :]
+                    active = active_all[gi_idx][bar] if active_all is not None else None
                 else:
-                    steps, plan_len, flags, gt_bar = maxs, None, None, None
+                    steps, plan_len, flags, gt_bar, active = maxs, None, None, None, None
                 if concurrent:
                     st = streams[gi_idx]
                     st.wait_event(fork)                    # everything the decoder reads (enc, keys, hnew, zeroed outputs) is ready
                     with torch.cuda.stream(st):
                         ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
-                                                              training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx])
+                                                              training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx], active)
                     done = torch.cuda.Event()
                     done.record(st)
                     joins.append(done)
@@ -395,7 +422,7 @@ class Engine:
                     torch.cuda.current_stream().wait_stream(st)
                 else:
                     ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
-                                                          training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx])
+                                                          training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx], active)
                 if gt_cpu is None:
                     for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference
                         rng.random()

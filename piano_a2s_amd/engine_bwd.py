@@ -63,7 +63,7 @@ def _staff_token_bwd(eng, S, G, rec, dtok):
     return gptrs     # keep alive until the caller returns
 
 
-def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_all, dK, dEnc, B, T, H, steps):
+def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_all, dK, dEnc, B, T, H, steps, active=None):
     """Key/value side of `steps` attention calls of one layer: dEnc += A^T dCtx (per clip), dK += ..., dv += ..."""
     L = hip.lib()
     # dEnc[b] += sum_s a_s[b,:]^T dctx_s[b,:]   -- batched over clips: (T x steps)(steps x 2H)
@@ -71,7 +71,7 @@ def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_a
     nblk = L.a2s_attn_dk_blocks(B, T)
     dvp = torch.empty((nblk, H), dtype=torch.float32, device=enc.device)
     hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(keys), hip._p(q_all), hip._p(ds_all), hip._p(S[prefix + ".v.weight"]), hip._p(dK),
-                                  hip._p(dvp), B, T, steps, H), "a2s_attn_dk_accum")
+                                  hip._p(dvp), B, T, steps, H, hip._p(active["until"] if active else None)), "a2s_attn_dk_accum")
     _colsum(dvp, H, G[prefix + ".v.weight"], nblk, H)
 
 
@@ -103,9 +103,11 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),
                     ("w_hh", S[prefix + ".gru.weight_hh_l0"]), ("keys", keys), ("enc", enc), ("h", sv["h"]), ("x", sv["x"]), ("q", sv["q"]),
                     ("gates", sv["gates"]), ("attw", sv["attw"]), ("do_all", do_all), ("dgi_all", dgi_all), ("dgh_all", dgh_all),
-                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", sv["attn_ws"]), ("gemm_ws", sv["gemm_ws"])):
+                    ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", sv["attn_ws"]), ("gemm_ws", sv["gemm_ws"]),
+                    ("row_order", sv.get("active") and sv["active"]["order"]), ("row_rank", sv.get("active") and sv["active"]["rank"])):
         setattr(a, name, t.data_ptr() if t is not None else None)
     a.gemm_ws_bytes = sv["gemm_ws"].numel() * 4 if sv["gemm_ws"] is not None else 0
+    a.n_active = C.cast(sv["active"]["n_active"], C.c_void_p).value if sv.get("active") else None
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) deferred weight gradients over all steps
@@ -117,7 +119,7 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     sk = L.a2s_gemm_pick_splitk(H, H2, R, 1)
     hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk)
     _colsum(dq_all, H, G[prefix + ".attn.attn.bias"], R, H)
-    _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, B, T, H, n)
+    _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, B, T, H, n, sv.get("active"))
     # embedding rows of the tokens consumed at each step: <sos> at step 0, then gt or argmax of the previous step
     tok = torch.full((n, B), SOS, dtype=torch.int32, device=dev)
     if n > 1:

@@ -25,7 +25,8 @@ class NoteDecArgs(C.Structure):
         ("drop", C.c_void_p), ("inv_keep", C.c_float),
         ("argmax_out", C.c_void_p), ("am_bstride", C.c_long),
         ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p), ("attn_ws", C.c_void_p),
-        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("t_base", C.c_void_p),
+        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("t_base", C.c_void_p), ("row_order", C.c_void_p), ("row_rank", C.c_void_p),
+        ("n_active", C.c_void_p),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
         ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int), ("use_graph", C.c_int)]
 
@@ -35,7 +36,7 @@ class NoteDecBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "attn_w", "attn_v", "w_ih", "w_hh", "keys", "enc", "h", "x", "q", "gates", "attw", "do_all",
         "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh", "attn_ws", "gemm_ws")] + [
-        ("gemm_ws_bytes", C.c_size_t),
+        ("gemm_ws_bytes", C.c_size_t), ("row_order", C.c_void_p), ("row_rank", C.c_void_p), ("n_active", C.c_void_p),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int)]
 
 

@@ -92,9 +92,13 @@ class FusedAdadelta:
 class TrainStep:
     """model: models.ScoreTranscription on a GPU.  One call = one optimizer step on one minibatch."""
 
-    def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True, sync_bn=None):
+    def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True, sync_bn=None, skip_finished_rows=None):
+        """skip_finished_rows (default on; A2S_SKIP_FINISHED=0 turns it off): the note decoders skip the attention of rows whose
+        remaining targets are all <pad>.  Loss, gradients and the update are unchanged (those rows are ignore_index positions and
+        nothing else reads them); only `last_outputs` rows past <eos> differ from the reference's values."""
         self.model = model
         self.sync_bn = (_os.environ.get("A2S_SYNC_BN") == "1") if sync_bn is None else bool(sync_bn)
+        self.skip_finished_rows = (_os.environ.get("A2S_SKIP_FINISHED", "1") != "0") if skip_finished_rows is None else bool(skip_finished_rows)
         self.flat = model.flatten_()
         self.opt = FusedAdadelta(self.flat, lr, rho, eps, max_grad_norm)
         self.objective = Objective(self.flat.device)
@@ -111,6 +115,7 @@ class TrainStep:
         """batch: the reference's 9-tuple (device tensors).  Returns the (4,2) device tensor of loss terms (col 0)."""
         spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = batch[:7]
         eng = engine.Engine(self.model.cfg, sync_bn=self.sync_bn)
+        eng.skip_finished_rows = self.skip_finished_rows
         S = self.state()
         outs = eng.forward(S, spectrogram, inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len],
                            teacher_forcing_ratio=teacher_forcing_ratio, training=True, rng=rng, dropout=self.dropout)

@@ -1,0 +1,54 @@
+"""In-process A/B of a TrainStep attribute (default: skip_finished_rows): alternates the two settings step by step so that box-to-box
+and thermal drift cancel.  usage: python tools/ab_step.py [--batch 256] [--pairs 6] [--attr skip_finished_rows]"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--pairs", type=int, default=6)
+    ap.add_argument("--attr", default="skip_finished_rows")
+    a = ap.parse_args()
+    import models
+    from piano_a2s_amd import spec, synthetic, train
+    dev = torch.device("cuda:0")
+    cfg = spec.default_cfg()
+    torch.manual_seed(1)
+    random.seed(1)
+    m = models.ScoreTranscription(**cfg).to(dev)
+    m.train()
+    step = train.TrainStep(m)
+    b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=0.0)
+    b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
+    for v in (False, True):
+        setattr(step, a.attr, v)
+        step(b, 0.7)
+    torch.cuda.synchronize()
+    tot = {False: [], True: []}
+    for _ in range(a.pairs):
+        for v in (False, True):
+            setattr(step, a.attr, v)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            step(b, 0.7)
+            torch.cuda.synchronize()
+            tot[v].append(time.time() - t0)
+    ms = torch.cuda.memory_stats()
+    print("order False/True per pair (ms):", " ".join(f"{x * 1e3:.0f}/{y * 1e3:.0f}" for x, y in zip(tot[False], tot[True])))
+    print(f"alloc retries {ms['num_alloc_retries']}, reserved {ms['reserved_bytes.all.peak'] / 2**30:.1f} GiB, allocated peak "
+          f"{ms['allocated_bytes.all.peak'] / 2**30:.1f} GiB, hipMalloc calls {ms['segment.all.allocated']}")
+    for v in (False, True):
+        ts = sorted(tot[v])
+        print(f"{a.attr}={v}: median {ts[len(ts) // 2] * 1e3:.1f} ms  min {ts[0] * 1e3:.1f}  max {ts[-1] * 1e3:.1f}  -> {a.batch / ts[len(ts) // 2]:.1f} clips/s")
+
+
+if __name__ == "__main__":
+    main()
