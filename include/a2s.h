@@ -77,6 +77,8 @@ int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const f
 /* workspace (a2s_attn_workspace_floats floats, shared by forward and backward) selects the split-T kernels: the frames of a
  * clip are spread over several workgroups and merged by a combine kernel; NULL (or hidden_size != 256) = one workgroup per clip. */
 size_t a2s_attn_workspace_floats(int B, int T, int H);
+/* the same for a fused-bars decoder call (a2s_note_dec_args.n_clips): `groups` bars of n_clips clips in one call */
+size_t a2s_attn_workspace_floats_fused(int n_clips, int T, int H, int groups);
 
 int a2s_log_softmax_rows(void* stream, const float* x, long ldx, float* y, long ldy, int* argmax_out, int R, int V);
 int a2s_embed_rows(void* stream, const float* table, const long long* ids64, const int* ids32, long id_stride,
@@ -92,19 +94,26 @@ typedef struct a2s_note_dec_args {
     float* gh; float* gi; float* logits;
     float* probs; long probs_bstride;
     const long long* gt; long gt_bstride;
-    const uint8_t* tf_flags;          /* HOST array, one flag per step */
+    const uint8_t* tf_flags;          /* HOST array, one entry per step: bit g = teacher-force the rows of group g (bit 0 when not fused) */
     const uint8_t* drop; float inv_keep;
     int* argmax_out; long am_bstride;
     int* eos_seen; long long* lengths; int* n_done;
     int* steps_exec;                  /* device counter: +1 per step that actually decoded (greedy early break) */
-    float* attn_ws;                   /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
+    float* attn_ws;                   /* a2s_attn_workspace_floats(R,T,H) [_fused(n_clips,T,H,R/n_clips)] floats or NULL */
     float* gemm_ws; size_t gemm_ws_bytes;   /* split-K scratch for the per-step skinny GEMMs (NULL: no split-K) */
     int* t_base;                      /* device int (graph mode): base step index of the chunk being replayed */
-    /* optional, training only -- skip the attention of finished rows (context = 0): once a row's remaining targets are all <pad>
-       nothing reaching the loss depends on it.  Rows sorted by the step they finish at, latest first: */
-    const int* row_order;             /* device, R ints: row ids in that order */
-    const int* row_rank;              /* device, R ints: inverse permutation */
-    const int* n_active;              /* HOST, `steps` ints: rows still unfinished at step t (= the prefix of row_order computed) */
+    /* optional, training only (the fused training step, not the drop-in module):
+       (1) fused bars -- the R rows are R/n_clips bars ("groups", <= 5) of the same n_clips clips, row = group * n_clips + clip; the
+           bars' decoders are independent once the bar-level recurrence is teacher-forced, and rows of one clip share its keys and
+           encoder outputs, which the attention kernels then stream once for all of them;
+       (2) finished rows -- from step row_until[row] on a row's remaining targets are all <pad>: nothing reaching the loss depends
+           on it any more, its attention is skipped (context = 0) and its outputs are left untouched.
+       Clips sorted by the step their last row finishes at, latest first, so the clips still running are a prefix: */
+    const int* clip_order;            /* device, n_clips ints: clip ids in that order */
+    const int* clip_rank;             /* device, n_clips ints: inverse permutation */
+    const int* row_until;             /* device, R ints */
+    const int* n_active;              /* HOST, `steps` ints: clips with an unfinished row at step t; NULL = none of (1)/(2) */
+    int n_clips;                      /* 0 = R (one group) */
     int R, T, H, E, V, steps, poll, eos_id;
     int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
 } a2s_note_dec_args;
@@ -133,7 +142,9 @@ int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const f
                       long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* workspace);
 /* deferred key gradient of S steps: dK += ..., dv partials [B*ceil(T/16)][H] (reduce with a2s_col_sum) */
 int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
-                      float* dv_partial, int B, int T, int S, int H, const int* active_until /* optional, B ints: clip b's ds rows are zero from step active_until[b] on */);
+                      float* dv_partial, int B, int T, int S, int H, const int* row_until, int groups);
+/* q_all / ds_all rows: (step, group, clip) with `groups` fused bars per step (1 = plain); row_until (optional, groups*B ints):
+ * the ds rows of (group, clip) are zero from step row_until[group*B + clip] on and are not read */
 int a2s_attn_dk_blocks(int B, int T);
 /* out[c] = alpha * sum_r x[r*ld+c] + beta*out[c]; with a workspace (>= 2*C floats, ideally 1024*C) long matrices are reduced in two
  * stages over many workgroups (fixed partition: deterministic). */
@@ -149,11 +160,13 @@ typedef struct a2s_note_dec_bwd_args {
     const float* do_all;                 /* (steps, R, 4H): dlogits_all W_out = [dh | dctx] of the output projection */
     float* dgi_all; float* dgh_all; float* dq_all; float* ds_all; float* dctx_all; float* dx;
     float* dh;                           /* (2, R, 2H) carry; dh[0] = gradient wrt the initial hidden on return */
-    float* attn_ws;                      /* a2s_attn_workspace_floats(R,T,H) floats or NULL */
+    float* attn_ws;                      /* as in the forward call */
     float* gemm_ws; size_t gemm_ws_bytes;   /* split-K scratch for the per-step skinny GEMMs (NULL: no split-K) */
-    const int* row_order;                /* the forward's row compaction (or NULL): see a2s_note_dec_args */
-    const int* row_rank;
+    const int* clip_order;               /* the forward's fused-bars / finished-rows description (or NULLs): see a2s_note_dec_args */
+    const int* clip_rank;
+    const int* row_until;
     const int* n_active;                 /* HOST */
+    int n_clips;
     int R, T, H, E, steps;
 } a2s_note_dec_bwd_args;
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);

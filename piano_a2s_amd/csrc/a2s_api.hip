@@ -21,8 +21,8 @@ int a2s_gru_gates_fwd_impl(hipStream_t, const float*, long, const float*, long, 
 int a2s_gru_seq_fwd_impl(hipStream_t, const float*, long, long, const float*, const float*, float*, long, long, float*, float*,
                          float*, float*, int, int, int, int, float*, size_t);
 int a2s_attn_step_fwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, float*, long, float*, long,
-                           float*, int, int, int, const int*, int, float*, const int*, const int*, int);
-size_t a2s_attn_workspace_floats_impl(int, int, int);
+                           float*, int, int, int, const int*, int, float*, const a2s_attn_rows*);
+size_t a2s_attn_workspace_floats_impl(int, int, int, int);
 int a2s_log_softmax_rows_impl(hipStream_t, const float*, long, float*, long, int*, int, int);
 int a2s_embed_rows_impl(hipStream_t, const float*, const long long*, const int*, long, int, float*, long, int, int, int, const uint8_t*, float);
 int a2s_staff_emb_fwd_impl(hipStream_t, const float*, const float* const*, const long long*, const int*, long, const long long*, long,
@@ -34,8 +34,8 @@ int a2s_log_softmax_bwd_rows_impl(hipStream_t, const float*, const float*, long,
 int a2s_gru_gates_bwd_impl(hipStream_t, const float*, long, const float*, long, const float*, const float*, long, float*, long, float*, long,
                            float*, long, float*, long, int, int);
 int a2s_attn_step_bwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, const float*, const float*, long,
-                           const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int, float*, const int*, const int*, int);
-int a2s_attn_dk_accum_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, const int*);
+                           const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int, float*, const a2s_attn_rows*);
+int a2s_attn_dk_accum_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, const int*, int);
 int a2s_col_sum_impl(hipStream_t, const float*, long, float*, long, int, float, float, float*, size_t);
 int a2s_embed_scatter_add_impl(hipStream_t, float*, const long long*, const int*, long, int, const float*, long, int, int, int, const uint8_t*, float);
 int a2s_ew_act_bwd_impl(hipStream_t, const float*, const float*, float*, long, int);
@@ -111,9 +111,10 @@ int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_
 }
 int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, float* ctx,
                       long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H, const int* n_done, int n_rows_total, float* workspace) {
-    return a2s_attn_step_fwd_impl(ST, keys, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, B, T, H, n_done, n_rows_total, workspace, nullptr, nullptr, 0);
+    return a2s_attn_step_fwd_impl(ST, keys, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, B, T, H, n_done, n_rows_total, workspace, nullptr);
 }
-size_t a2s_attn_workspace_floats(int B, int T, int H) { return a2s_attn_workspace_floats_impl(B, T, H); }
+size_t a2s_attn_workspace_floats(int B, int T, int H) { return a2s_attn_workspace_floats_impl(B, T, H, 1); }
+size_t a2s_attn_workspace_floats_fused(int n_clips, int T, int H, int groups) { return a2s_attn_workspace_floats_impl(n_clips, T, H, groups); }
 int a2s_log_softmax_rows(void* stream, const float* x, long ldx, float* y, long ldy, int* argmax_out, int R, int V) {
     return a2s_log_softmax_rows_impl(ST, x, ldx, y, ldy, argmax_out, R, V);
 }
@@ -144,11 +145,11 @@ int a2s_gru_gates_bwd(void* stream, const float* dh_a, long lda, const float* dh
 int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, const float* attw,
                       const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb, float* dctx_out,
                       long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* workspace) {
-    return a2s_attn_step_bwd_impl(ST, keys, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, B, T, H, workspace, nullptr, nullptr, 0);
+    return a2s_attn_step_bwd_impl(ST, keys, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, B, T, H, workspace, nullptr);
 }
 int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
-                      float* dv_partial, int B, int T, int S, int H, const int* active_until) {
-    return a2s_attn_dk_accum_impl(ST, keys, q_all, ds_all, v, dK, dv_partial, B, T, S, H, active_until);
+                      float* dv_partial, int B, int T, int S, int H, const int* row_until, int groups) {
+    return a2s_attn_dk_accum_impl(ST, keys, q_all, ds_all, v, dK, dv_partial, B, T, S, H, row_until, groups);
 }
 int a2s_attn_dk_blocks(int B, int T) { return B * ((T + 15) / 16); }
 int a2s_col_sum(void* stream, const float* x, long ld, float* out, long rows, int C, float alpha, float beta, float* workspace, size_t workspace_floats) {

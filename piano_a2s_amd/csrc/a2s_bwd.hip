@@ -82,14 +82,15 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
                                                      const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
                                                      const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
                                                      float* __restrict__ dctx_out, long lddo, float* __restrict__ dq, long lddq,
-                                                     float* __restrict__ ds_out, int T) {
+                                                     float* __restrict__ ds_out, int T, int n_clips) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dsv = sm;                               // T
     float* dc = sm + ((T + 3) & ~3);               // 2H
     float* red = dc + 2 * H;                       // 16
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* Kb = Kmat + (long)b * T * H;
-    const float* Eb = enc + (long)b * T * 2 * H;
+    const int clip = b % n_clips;                  // fused bars: row = bar * n_clips + clip
+    const float* Kb = Kmat + (long)clip * T * H;
+    const float* Eb = enc + (long)clip * T * 2 * H;
     float part = 0.f;
     for (int d = tid; d < 2 * H; d += 256) {
         float g = dctx_a[(long)b * ldda + d];
@@ -126,18 +127,18 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                                  long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
-                                 const int* row_order, const int* row_rank, int n_active);
+                                 const a2s_attn_rows* rows);
 
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                            long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws,
-                           const int* row_order = nullptr, const int* row_rank = nullptr, int n_active = 0) {
+                           const a2s_attn_rows* rows = nullptr) {
     if (H == 256 && ws)
-        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H,
-                                            row_order, row_rank, n_active);
+        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H, rows);
+    const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
-    if (H == 256) hipLaunchKernelGGL(attn_step_bwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
-    else if (H == 32) hipLaunchKernelGGL(attn_step_bwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T);
+    if (H == 256) hipLaunchKernelGGL(attn_step_bwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
+    else if (H == 32) hipLaunchKernelGGL(attn_step_bwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
     else A2S_FAIL(A2S_ERR_ARG, "attn_step_bwd: hidden_size must be 256 or 32 (got %d)", H);
     A2S_CHECK_LAUNCH("attn_step_bwd");
     return A2S_OK;
@@ -151,7 +152,7 @@ template <int H>
 __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ Kmat, const float* __restrict__ q_all,
                                                      const float* __restrict__ ds_all, const float* __restrict__ v,
                                                      float* __restrict__ dK, float* __restrict__ dv_partial, int B, int T, int S,
-                                                     const int* __restrict__ active_until) {
+                                                     const int* __restrict__ row_until, int groups) {
     constexpr int TT = 16;
     const int tiles = (T + TT - 1) / TT;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * TT;
@@ -163,13 +164,16 @@ __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ K
 #pragma unroll
         for (int i = 0; i < TT; ++i) { kreg[i] = (t0 + i < T) ? Kmat[((long)b * T + t0 + i) * H + j] : 0.f; acc[i] = 0.f; }
     }
-    if (active_until) S = min(S, active_until[b]);          // ds is exactly zero for the steps this clip's row was skipped
-    for (int s = 0; s < S; ++s) {
+    // rows of a step: `groups` bars of the same B clips (row = group * B + b); ds is exactly zero from step row_until[row] on
+    for (int sg = 0; sg < S * groups; ++sg) {
+        const int s = sg / groups, grp = sg % groups;
+        if (row_until && s >= row_until[grp * B + b]) continue;          // uniform over the workgroup
+        const long row = (long)sg * B + b;
         __syncthreads();
-        if (threadIdx.x < TT) dss[threadIdx.x] = (t0 + threadIdx.x < T) ? ds_all[((long)s * B + b) * T + t0 + threadIdx.x] : 0.f;
+        if (threadIdx.x < TT) dss[threadIdx.x] = (t0 + threadIdx.x < T) ? ds_all[row * T + t0 + threadIdx.x] : 0.f;
         __syncthreads();
         if (j < H) {
-            const float qj = q_all[((long)s * B + b) * H + j];
+            const float qj = q_all[row * H + j];
 #pragma unroll
             for (int i = 0; i < TT; ++i) {
                 const float e = fast_tanh(kreg[i] + qj);
@@ -188,10 +192,11 @@ __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ K
 }
 
 int a2s_attn_dk_accum_impl(hipStream_t st, const float* Kmat, const float* q_all, const float* ds_all, const float* v,
-                           float* dK, float* dv_partial, int B, int T, int S, int H, const int* active_until) {
+                           float* dK, float* dv_partial, int B, int T, int S, int H, const int* row_until, int groups) {
     const int nblk = B * a2s_cdiv(T, 16);
-    if (H == 256) hipLaunchKernelGGL(attn_dk_accum<256>, dim3(nblk), dim3(256), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, active_until);
-    else if (H == 32) hipLaunchKernelGGL(attn_dk_accum<32>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, active_until);
+    if (groups < 1) groups = 1;
+    if (H == 256) hipLaunchKernelGGL(attn_dk_accum<256>, dim3(nblk), dim3(256), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
+    else if (H == 32) hipLaunchKernelGGL(attn_dk_accum<32>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
     else A2S_FAIL(A2S_ERR_ARG, "attn_dk_accum: hidden_size must be 256 or 32 (got %d)", H);
     A2S_CHECK_LAUNCH("attn_dk_accum");
     return A2S_OK;
@@ -291,6 +296,8 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd memset: %s", hipGetErrorString(e));
     int cur = 0;
     for (int s = a.steps - 1; s >= 0; --s) {
+        a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : R, a.n_active ? a.n_active[s] : 0, s};
+        const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
         float* dh_in = a.dh + (long)cur * R * H2;
         float* dh_out = a.dh + (long)(cur ^ 1) * R * H2;
         const float* dos = a.do_all + (long)s * R * 2 * H2;
@@ -309,7 +316,7 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
         rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
                                     a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
                                     a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
-                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, a.row_order, a.row_rank, a.row_order ? a.n_active[s] : 0);
+                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
         if (rc) return rc;
         // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
         rc = a2s_gemm_impl(st, R, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
@@ -562,45 +569,217 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
     }
 }
 
-// one workgroup (256 threads) per clip: dq = sum of the G partials; rows the forward pass skipped (upstream gradient exactly zero) get
+// Fused bars (see attn_fwd_split256_mq): NQ rows of one clip per workgroup, the clip's enc and K chunk streamed once for all of them.
+template <int NQ>
+__global__ __launch_bounds__(256) void attn_bwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                            const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                            const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
+                                                            const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
+                                                            float* __restrict__ dctx_out, long lddo, float* __restrict__ dq_partial,
+                                                            float* __restrict__ ds_out, int T, int G, int chunk,
+                                                            const int* __restrict__ clip_order, const int* __restrict__ row_until,
+                                                            int step, int n_clips) {
+    constexpr int H = 256;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dsv = sm;                                         // NQ x chunk
+    f32x4* red4 = reinterpret_cast<f32x4*>(sm + NQ * chunk);    // NQ * 3 * 64 float4
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = clip_order ? clip_order[slot] : slot;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool on[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) on[j] = !row_until || step < row_until[j * n_clips + b];
+    const float* Kb = Kmat + ((long)b * T + t0) * H;
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    f32x4 dc0[NQ], dc1[NQ];
+    float dot_ctx[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        dc0[j] = dc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dot_ctx[j] = 0.f;
+        if (!on[j]) continue;
+        const long row = (long)j * n_clips + b;
+        dc0[j] = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + lane * 4);
+        dc1[j] = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + H + lane * 4);
+        if (dctx_b) {
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + lane * 4);
+            const f32x4 o1 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + H + lane * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { dc0[j][c] += o0[c]; dc1[j][c] += o1[c]; }
+        }
+        if (dctx_out && g == 0 && wave == 0) {
+            *reinterpret_cast<f32x4*>(dctx_out + row * lddo + lane * 4) = dc0[j];
+            *reinterpret_cast<f32x4*>(dctx_out + row * lddo + H + lane * 4) = dc1[j];
+        }
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + lane * 4);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + H + lane * 4);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d += dc0[j][c] * c0[c] + dc1[j][c] * c1[c];
+        dot_ctx[j] = wave_sum(d);
+    }
+    // ---- pass A: da_t = dctx_j . enc_t, one wave per frame, 4 frames in flight
+    for (int r = wave * 4; r < n; r += 16) {
+        f32x4 e0[4], e1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r + u < n) {
+                e0[u] = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + lane * 4);
+                e1[u] = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + H + lane * 4);
+            } else { e0[u] = e1[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            float sj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sj[u] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sj[u] += dc0[j][c] * e0[u][c] + dc1[j][c] * e1[u][c];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sj[u] += __shfl_xor(sj[u], o, 64);
+            }
+            if (lane == 0) {
+                const long row = (long)j * n_clips + b;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (r + u < n) {
+                        const float d_s = attw[row * T + t0 + r + u] * (sj[u] - dot_ctx[j]);
+                        dsv[j * chunk + r + u] = d_s;
+                        if (ds_out) ds_out[row * T + t0 + r + u] = d_s;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass B: dq_j += ds_t (1 - tanh^2(K_tj + q_j)); thread = (float4 column, row group of 4)
+    const int c4 = tid & 63, rg = tid >> 6;
+    f32x4 q4[NQ], acc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        q4[j] = on[j] ? *reinterpret_cast<const f32x4*>(q + ((long)j * n_clips + b) * ldq + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int i = rg;
+    for (; i + 12 < n; i += 16) {
+        f32x4 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = *reinterpret_cast<const f32x4*>(Kb + (long)(i + 4 * u) * H + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = dsv[j * chunk + i + 4 * u];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k[u][c] + q4[j][c]); acc[j][c] = fmaf(w, 1.f - e * e, acc[j][c]); }
+            }
+        }
+    }
+    for (; i < n; i += 4) {
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(Kb + (long)i * H + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            const float w = dsv[j * chunk + i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k0[c] + q4[j][c]); acc[j][c] = fmaf(w, 1.f - e * e, acc[j][c]); }
+        }
+    }
+    if (rg > 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) red4[(j * 3 + rg - 1) * 64 + c4] = acc[j];
+    }
+    __syncthreads();
+    if (rg == 0) {
+        const f32x4 v4 = {v[c4 * 4], v[c4 * 4 + 1], v[c4 * 4 + 2], v[c4 * 4 + 3]};            // parameter: 4-byte aligned only
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            f32x4 a = acc[j];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { const f32x4 o = red4[(j * 3 + u) * 64 + c4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] += o[c]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] *= v4[c];
+            *reinterpret_cast<f32x4*>(dq_partial + (((long)slot * NQ + j) * G + g) * H + c4 * 4) = a;
+        }
+    }
+}
+
+// one workgroup (256 threads) per row: dq = sum of the G partials; rows the forward pass skipped (upstream gradient exactly zero) get
 // zeros in everything the deferred GEMMs read (dq, ds, dctx)
 __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int G,
-                                                           const int* __restrict__ row_rank, int n_active, float* __restrict__ ds_out,
+                                                           const int* __restrict__ clip_rank, const int* __restrict__ row_until,
+                                                           int n_clips, int groups, int n_active, int step, float* __restrict__ ds_out,
                                                            int T, float* __restrict__ dctx_out, long lddo) {
     const int b = blockIdx.x, j = threadIdx.x;
-    const int slot = row_rank ? row_rank[b] : b;
-    if (slot >= n_active) {
+    const int clip = b % n_clips, grp = b / n_clips;
+    const int slot = clip_rank ? clip_rank[clip] : clip;
+    if (slot >= n_active || (row_until && step >= row_until[b])) {
         dq[(long)b * lddq + j] = 0.f;
         if (ds_out) for (int t = j; t < T; t += 256) ds_out[(long)b * T + t] = 0.f;
         if (dctx_out) for (int d = j; d < 512; d += 256) dctx_out[(long)b * lddo + d] = 0.f;
         return;
     }
+    const float* pb = dq_partial + ((long)slot * groups + grp) * G * 256;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += dq_partial[((long)slot * G + g) * 256 + j];
+    for (int g = 0; g < G; ++g) s += pb[(long)g * 256 + j];
     dq[(long)b * lddq + j] = s;
 }
 
+template <int NQ>
+static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                          const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
+                          float* dctx_out, long lddo, float* ws, float* ds_out, int T, int G, int chunk, const a2s_attn_rows& r) {
+    hipLaunchKernelGGL(attn_bwd_split256_mq<NQ>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                       dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
+}
 
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                                  long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
-                                 const int* row_order, const int* row_rank, int n_active) {
+                                 const a2s_attn_rows* rows) {
     A2S_REQUIRE(H == 256 && ws, "attn_step_bwd_split: needs hidden_size 256 and a workspace");
     A2S_REQUIRE(ldq % 4 == 0 && ldctx % 4 == 0 && ldda % 4 == 0 && (!dctx_b || lddb % 4 == 0) && (!dctx_out || lddo % 4 == 0),
                 "attn_step_bwd_split: row strides must be multiples of 4 floats");
     A2S_REQUIRE(((uintptr_t)q | (uintptr_t)ctx | (uintptr_t)dctx_a | (uintptr_t)dctx_b | (uintptr_t)dctx_out | (uintptr_t)Kmat | (uintptr_t)enc) % 16 == 0,
                 "attn_step_bwd_split: 16-byte alignment");
-    if (!row_order) n_active = B;
-    A2S_REQUIRE(n_active >= 0 && n_active <= B && (!row_order || row_rank), "attn_step_bwd_split: bad row compaction");
+    a2s_attn_rows r = {nullptr, nullptr, nullptr, B, B, 0};
+    if (rows) r = *rows;
+    A2S_REQUIRE(r.n_clips > 0 && B % r.n_clips == 0, "attn_step_bwd_split: rows (%d) must be a multiple of the clips (%d)", B, r.n_clips);
+    const int groups = B / r.n_clips;
+    A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_bwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);
+    A2S_REQUIRE(r.n_active >= 0 && r.n_active <= r.n_clips && (!r.clip_order || r.clip_rank), "attn_step_bwd_split: bad row compaction");
     int G = 1, chunk = T;
-    if (n_active > 0) {
-        a2s_attn_split_geometry(n_active, T, &G, &chunk);
-        const size_t shm = (chunk + 3 * 64 * 4) * sizeof(float);
-        hipLaunchKernelGGL(attn_bwd_split256, dim3(n_active * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
-                           dctx_out, lddo, ws, ds_out, T, G, chunk, row_order);
+    if (r.n_active > 0) {
+        a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
+        const int nwg = r.n_active * G;
+        if (groups == 1) {
+            const size_t shm = (chunk + 3 * 64 * 4) * sizeof(float);
+            hipLaunchKernelGGL(attn_bwd_split256, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                               dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
+        } else {
+            const size_t shm = ((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4) * sizeof(float);
+#define A2S_BWD_MQ(N) launch_bwd_mq<N>(st, nwg, shm, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r)
+            switch (groups) {
+                case 2: A2S_BWD_MQ(2); break;
+                case 3: A2S_BWD_MQ(3); break;
+                case 4: A2S_BWD_MQ(4); break;
+                default: A2S_BWD_MQ(5); break;
+            }
+#undef A2S_BWD_MQ
+        }
         A2S_CHECK_LAUNCH("attn_bwd_split256");
     }
-    hipLaunchKernelGGL(attn_bwd_combine256, dim3(B), dim3(256), 0, st, ws, dq, lddq, G, row_rank, n_active, ds_out, T, dctx_out, lddo);
+    hipLaunchKernelGGL(attn_bwd_combine256, dim3(B), dim3(256), 0, st, ws, dq, lddq, G, r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step,
+                       ds_out, T, dctx_out, lddo);
     A2S_CHECK_LAUNCH("attn_bwd_combine256");
     return A2S_OK;
 }

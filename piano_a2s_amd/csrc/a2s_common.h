@@ -55,6 +55,21 @@ static inline void a2s_attn_split_geometry(int B, int T, int* G, int* chunk) {
     *chunk = c;
 }
 
+// Which rows one attention launch of a note decoder covers (training only; NULL = every row, one group).
+// The R rows of a fused decoder call are `groups` bars of the same n_clips clips, row = group * n_clips + clip: rows of one clip
+// share that clip's keys and encoder outputs, so one workgroup serves all of them from a single pass over the clip's chunk.
+// A row is skipped (context 0) from step row_until[row] on: its remaining targets are all <pad>.  Clips sorted by the step their
+// last row finishes at (latest first) so that the clips still running are a prefix of clip_order.
+struct a2s_attn_rows {
+    const int* clip_order;   // device, n_clips ints (NULL: identity)
+    const int* clip_rank;    // device, n_clips ints: inverse permutation
+    const int* row_until;    // device, R ints (NULL: never finished)
+    int n_clips;             // clips per group
+    int n_active;            // clips with at least one unfinished row at this step (prefix of clip_order)
+    int step;
+};
+#define A2S_ATTN_MAX_GROUPS 5
+
 // ----------------------------------------------------------------------------- device helpers
 #ifdef __HIPCC__
 #define A2S_WAVE 64

@@ -80,14 +80,16 @@ template <int H>
 __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                      const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                      float* __restrict__ ctx, long ldctx, float* __restrict__ ctx2, long ldctx2,
-                                                     float* __restrict__ attw, int T, const int* __restrict__ n_done, int n_rows_total) {
+                                                     float* __restrict__ attw, int T, const int* __restrict__ n_done, int n_rows_total,
+                                                     int n_clips) {
     if (n_done && *n_done >= n_rows_total) return;      // greedy decode: every clip already emitted <eos>
     extern __shared__ __attribute__((aligned(16))) float sm[];   // T scores + 16 reduction slots
     float* sc = sm;
     float* red = sm + ((T + 3) & ~3);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* Kb = Kmat + (long)b * T * H;
-    const float* Eb = enc + (long)b * T * 2 * H;
+    const int clip = b % n_clips;                       // fused bars: row = bar * n_clips + clip
+    const float* Kb = Kmat + (long)clip * T * H;
+    const float* Eb = enc + (long)clip * T * 2 * H;
     constexpr int PER = (H + 63) / 64;                   // elements of a K row per lane
     float qv[PER], vv[PER];
 #pragma unroll
@@ -138,20 +140,20 @@ __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ K
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
-                                 const int* n_done, int n_rows_total, const int* row_order, const int* row_rank, int n_active);
+                                 const int* n_done, int n_rows_total, const a2s_attn_rows* rows);
 
-// Row compaction (optional, split kernels only): only rows row_order[0 .. n_active) are computed, the others get context 0.  Used by
-// the fused training step: once a row's remaining targets are all <pad> nothing that reaches the loss depends on it any more.
+// rows (optional, split kernels only): which rows are computed and how they group by clip -- see a2s_attn_rows.  Used by the fused
+// training step: once a row's remaining targets are all <pad> nothing that reaches the loss depends on it any more.
 int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
-                           const int* n_done, int n_rows_total, float* ws, const int* row_order = nullptr, const int* row_rank = nullptr,
-                           int n_active = 0) {
+                           const int* n_done, int n_rows_total, float* ws, const a2s_attn_rows* rows = nullptr) {
     if (H == 256 && ws)
-        return a2s_attn_step_fwd_split_impl(st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, ws, B, T, H, n_done, n_rows_total,
-                                            row_order, row_rank, n_active);
+        return a2s_attn_step_fwd_split_impl(st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, ws, B, T, H, n_done, n_rows_total, rows);
+    // one-workgroup-per-row kernels: every row is computed (no skipping); fused bars only change which clip a row reads
+    const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 16) * sizeof(float);
-    if (H == 256) hipLaunchKernelGGL(attn_step_fwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
-    else if (H == 32) hipLaunchKernelGGL(attn_step_fwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total);
+    if (H == 256) hipLaunchKernelGGL(attn_step_fwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
+    else if (H == 32) hipLaunchKernelGGL(attn_step_fwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
     else A2S_FAIL(A2S_ERR_ARG, "attn_step_fwd: hidden_size must be 256 or 32 (got %d)", H);
     A2S_CHECK_LAUNCH("attn_step_fwd");
     return A2S_OK;
@@ -172,6 +174,8 @@ struct StepFinArgs {
     int* argmax_out; long am_bstride;     // ids[b*am_bstride + t] (int32) or null
     int* eos_seen; long long* lengths; int* n_done; int* steps_exec;
     const int* t_base;                    // graph replay: step index = t + *t_base (null: t)
+    const int* row_until;                 // training: rows finished at this step (t >= row_until[row]) keep their outputs untouched
+    int n_clips;                          // rows per group (fused bars); teacher_force bit g applies to the rows of group g
     int R, V, E, t, teacher_force, eos_id, max_t;
 };
 
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(256) void note_step_finalize(StepFinArgs a) {
     const int t = a.t + (a.t_base ? *a.t_base : 0);
     if (t >= a.max_t) return;                                   // a replayed chunk may overshoot the step budget
     const float* lg = a.logits + (long)row * a.ldl;
+    const bool finished = a.row_until && t >= a.row_until[row];    // its bar's loop has ended in the reference (outputs stay zero) or only <pad> targets remain
     float m = -INFINITY; int mi = 0x7fffffff;
     for (int j = lane; j < a.V; j += 64) { const float x = lg[j]; if (x > m) { m = x; mi = j; } }
 #pragma unroll
@@ -189,20 +194,23 @@ __global__ __launch_bounds__(256) void note_step_finalize(StepFinArgs a) {
         const float om = __shfl_xor(m, o, 64); const int oi = __shfl_xor(mi, o, 64);
         if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
     }
-    float s = 0.f;
-    for (int j = lane; j < a.V; j += 64) s += expf(lg[j] - m);
-    s = wave_sum(s);
-    const float lse = m + logf(s);
-    float* pr = a.probs + (long)row * a.probs_bstride + (long)t * a.V;
-    for (int j = lane; j < a.V; j += 64) pr[j] = lg[j] - lse;
+    if (!finished) {
+        float s = 0.f;
+        for (int j = lane; j < a.V; j += 64) s += expf(lg[j] - m);
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        float* pr = a.probs + (long)row * a.probs_bstride + (long)t * a.V;
+        for (int j = lane; j < a.V; j += 64) pr[j] = lg[j] - lse;
+    }
     const long long g = a.gt ? a.gt[(long)row * a.gt_bstride + t] : -1;
-    const int next_id = (a.gt && a.teacher_force) ? (int)g : mi;
+    const int tf = (a.teacher_force >> (a.n_clips > 0 ? row / a.n_clips : 0)) & 1;
+    const int next_id = (a.gt && tf) ? (int)g : mi;
     for (int j = lane; j < a.E; j += 64) {
         float e = a.emb[(long)next_id * a.E + j];
         if (a.drop) e = a.drop[(long)row * a.E + j] ? e * a.inv_keep : 0.f;
         a.xnext[(long)row * a.ldx + j] = e;
     }
-    if (lane == 0) {
+    if (lane == 0 && !finished) {
         if (row == 0 && a.steps_exec) *a.steps_exec = t + 1;      // steps run in order on one stream
         if (a.argmax_out) a.argmax_out[(long)row * a.am_bstride + t] = mi;
         const bool hit = a.gt ? (g == a.eos_id) : (mi == a.eos_id);
@@ -285,6 +293,8 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     float* qs = a.q + (long)sv * a.R * a.H;
     float* os = a.o + (long)sv * a.R * 2 * H2;
     int rc;
+    a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : a.R, a.n_active ? a.n_active[t] : 0, t};
+    const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
     // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
     rc = a2s_gemm_impl(st, a.R, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
@@ -294,7 +304,7 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     // attention -> ctx into x[si][:, E:] and o[sv][:, 2H:]
     rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
                                 a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws,
-                                a.row_order, a.row_rank, a.row_order ? a.n_active[t] : 0);
+                                rows);
     if (rc) return rc;
     // gi = x W_ih^T + b_ih
     rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
@@ -314,6 +324,7 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     f.argmax_out = a.argmax_out; f.am_bstride = a.am_bstride;
     f.eos_seen = a.eos_seen; f.lengths = a.lengths; f.n_done = a.n_done; f.steps_exec = a.steps_exec;
     f.t_base = t_base;
+    f.row_until = a.n_active ? a.row_until : nullptr; f.n_clips = a.n_clips > 0 ? a.n_clips : a.R;
     f.R = a.R; f.V = a.V; f.E = a.E; f.t = t; f.teacher_force = tf; f.eos_id = a.eos_id; f.max_t = a.steps;
     return a2s_note_step_finalize_impl(st, f);
 }
@@ -534,21 +545,147 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
     if (tid == 0) { pout[0] = m; pout[1] = l; }
 }
 
-// merge the G partials of a clip: ctx = sum_g ctx_g e^{m_g-m} / l ; optional normalisation of the saved weights
+// Fused bars: NQ rows (bars) of one clip per workgroup -- the clip's K and enc chunk is streamed ONCE and applied to every unfinished
+// row of the clip, so the HBM bytes per decoded row drop by the number of rows sharing the clip.  Same two passes and the same
+// partial layout as attn_fwd_split256; partial of (slot, j, g) at ((slot * NQ + j) * G + g).
+template <int NQ>
+__global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                            const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                            float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
+                                                            const int* __restrict__ clip_order, const int* __restrict__ row_until,
+                                                            int step, int n_clips) {
+    constexpr int H = 256;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pw = sm;                                   // NQ x chunk weights
+    float* red = sm + NQ * chunk;                     // 16 + NQ * 128 * 4 floats
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = clip_order ? clip_order[slot] : slot;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool on[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) on[j] = !row_until || step < row_until[j * n_clips + b];
+    const float* Kb = Kmat + ((long)b * T + t0) * H;
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    f32x4 q4[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+        q4[j] = on[j] ? *reinterpret_cast<const f32x4*>(q + ((long)j * n_clips + b) * ldq + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 v4 = {v[lane * 4], v[lane * 4 + 1], v[lane * 4 + 2], v[lane * 4 + 3]};
+    // ---- pass 1: scores; one wave per frame, 4 frames in flight, every frame scored against the NQ queries
+    for (int r = wave * 4; r < n; r += 16) {
+        f32x4 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            k[u] = (r + u < n) ? *reinterpret_cast<const f32x4*>(Kb + (long)(r + u) * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            float sj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                sj[u] = v4[0] * fast_tanh(k[u][0] + q4[j][0]) + v4[1] * fast_tanh(k[u][1] + q4[j][1])
+                      + v4[2] * fast_tanh(k[u][2] + q4[j][2]) + v4[3] * fast_tanh(k[u][3] + q4[j][3]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sj[u] += __shfl_xor(sj[u], o, 64);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (r + u < n) pw[j * chunk + r + u] = sj[u];
+            }
+        }
+    }
+    __syncthreads();
+    float mj[NQ], lj[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        mj[j] = 0.f; lj[j] = 0.f;
+        if (!on[j]) continue;                          // uniform over the workgroup
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += 256) m = fmaxf(m, pw[j * chunk + i]);
+        m = block_max(m, red);
+        float l = 0.f;
+        for (int i = tid; i < n; i += 256) {
+            const float sc = pw[j * chunk + i];
+            if (scores) scores[((long)j * n_clips + b) * T + t0 + i] = sc;
+            const float p = __expf(sc - m);
+            pw[j * chunk + i] = p; l += p;
+        }
+        l = block_sum(l, red);
+        mj[j] = m; lj[j] = l;
+    }
+    __syncthreads();
+    // ---- pass 2: ctx_j = sum_i pw[j][i] * enc[i, :]; thread = (float4 column c4, row parity)
+    const int c4 = tid & 127, rp = tid >> 7;
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int i = rp;
+    for (; i + 6 < n; i += 8) {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 0) * 2 * H + c4 * 4);
+        const f32x4 e1 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 2) * 2 * H + c4 * 4);
+        const f32x4 e2 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 4) * 2 * H + c4 * 4);
+        const f32x4 e3 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 6) * 2 * H + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            const float* pj = pw + j * chunk;
+            const float w0 = pj[i], w1 = pj[i + 2], w2 = pj[i + 4], w3 = pj[i + 6];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] += w0 * e0[c] + w1 * e1[c] + w2 * e2[c] + w3 * e3[c];
+        }
+    }
+    for (; i < n; i += 2) {
+        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)i * 2 * H + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            const float w0 = pw[j * chunk + i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] += w0 * e0[c];
+        }
+    }
+    f32x4* red4 = reinterpret_cast<f32x4*>(red + 16);
+    if (rp == 1) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) red4[j * 128 + c4] = acc[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        if (!on[j]) continue;
+        float* pout = partial + (((long)slot * NQ + j) * G + g) * (2 * H + 4);
+        if (rp == 0) {
+            const f32x4 o = red4[j * 128 + c4];
+            f32x4 a = acc[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] += o[c];
+            *reinterpret_cast<f32x4*>(pout + 4 + c4 * 4) = a;
+        }
+        if (tid == 0) { pout[0] = mj[j]; pout[1] = lj[j]; }
+    }
+}
+
+// merge the G partials of a row: ctx = sum_g ctx_g e^{m_g-m} / l ; optional normalisation of the saved weights.  One workgroup per
+// row (= group * n_clips + clip); rows that are skipped this step get zeros.
 __global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restrict__ partial, float* __restrict__ ctx, long ldctx,
                                                            float* __restrict__ ctx2, long ldctx2, float* __restrict__ attw, int T, int G,
                                                            const int* __restrict__ n_done, int n_rows_total,
-                                                           const int* __restrict__ row_rank, int n_active) {
+                                                           const int* __restrict__ clip_rank, const int* __restrict__ row_until,
+                                                           int n_clips, int groups, int n_active, int step) {
     if (n_done && *n_done >= n_rows_total) return;
     constexpr int H = 256;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int slot = row_rank ? row_rank[b] : b;
-    if (slot >= n_active) {      // skipped row: a finite, well-defined context (zeros) keeps the recurrence finite
+    const int clip = b % n_clips, grp = b / n_clips;
+    const int slot = clip_rank ? clip_rank[clip] : clip;
+    if (slot >= n_active || (row_until && step >= row_until[b])) {   // skipped row: a finite, well-defined context (zeros)
         for (int d = tid; d < 2 * H; d += 256) { ctx[(long)b * ldctx + d] = 0.f; if (ctx2) ctx2[(long)b * ldctx2 + d] = 0.f; }
         if (attw) for (int t = tid; t < T; t += 256) attw[(long)b * T + t] = 0.f;
         return;
     }
-    const float* pb = partial + (long)slot * G * (2 * H + 4);
+    const float* pb = partial + ((long)slot * groups + grp) * G * (2 * H + 4);
     float m = -INFINITY;
     for (int g = 0; g < G; ++g) m = fmaxf(m, pb[(long)g * (2 * H + 4)]);
     float l = 0.f;
@@ -565,33 +702,57 @@ __global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restri
 }
 
 
-size_t a2s_attn_workspace_floats_impl(int B, int T, int H) {
-    // a launch may cover any n <= B rows (finished rows skipped), each split G(n) ways: size for the largest n * G(n)
+size_t a2s_attn_workspace_floats_impl(int B, int T, int H, int groups) {
+    // a launch may cover any n <= B clips (finished rows skipped), each split G(n) ways: size for the largest n * G(n)
     size_t rows = 0;
     for (int n = 1; n <= B; ++n) {
         int G, chunk;
         a2s_attn_split_geometry(n, T, &G, &chunk);
         if ((size_t)n * G > rows) rows = (size_t)n * G;
     }
-    return rows * (2 * H + 4);
+    return rows * (groups > 0 ? groups : 1) * (2 * H + 4);
+}
+
+template <int NQ>
+static void launch_fwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                          float* ws, float* attw, int T, int G, int chunk, const a2s_attn_rows& r) {
+    hipLaunchKernelGGL(attn_fwd_split256_mq<NQ>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk,
+                       r.clip_order, r.row_until, r.step, r.n_clips);
 }
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
-                                 const int* n_done, int n_rows_total, const int* row_order, const int* row_rank, int n_active) {
+                                 const int* n_done, int n_rows_total, const a2s_attn_rows* rows) {
     A2S_REQUIRE(H == 256 && ws, "attn_step_fwd_split: needs hidden_size 256 and a workspace");
     A2S_REQUIRE(ldq % 4 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)Kmat % 16 == 0) && ((uintptr_t)enc % 16 == 0), "attn_step_fwd_split: 16-byte alignment");
-    if (!row_order) n_active = B;
-    A2S_REQUIRE(n_active >= 0 && n_active <= B && (!row_order || row_rank), "attn_step_fwd_split: bad row compaction");
+    a2s_attn_rows r = {nullptr, nullptr, nullptr, B, B, 0};
+    if (rows) r = *rows;
+    A2S_REQUIRE(r.n_clips > 0 && B % r.n_clips == 0, "attn_step_fwd_split: rows (%d) must be a multiple of the clips (%d)", B, r.n_clips);
+    const int groups = B / r.n_clips;
+    A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_fwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);
+    A2S_REQUIRE(r.n_active >= 0 && r.n_active <= r.n_clips && (!r.clip_order || r.clip_rank), "attn_step_fwd_split: bad row compaction");
+    A2S_REQUIRE(groups == 1 || !n_done, "attn_step_fwd_split: fused bars are a training-only path");
     int G = 1, chunk = T;
-    if (n_active > 0) {
-        // the grid covers the n_active unfinished rows only, re-split so that it still fills the chip
-        a2s_attn_split_geometry(n_active, T, &G, &chunk);
-        const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
-        hipLaunchKernelGGL(attn_fwd_split256, dim3(n_active * G), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, n_done, n_rows_total, row_order);
+    if (r.n_active > 0) {
+        // the grid covers the clips that still have unfinished rows, re-split so that it still fills the chip
+        a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
+        const int nwg = r.n_active * G;
+        if (groups == 1) {
+            const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
+            hipLaunchKernelGGL(attn_fwd_split256, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, n_done, n_rows_total, r.clip_order);
+        } else {
+            const size_t shm = ((size_t)groups * chunk + 16 + (size_t)groups * 128 * 4) * sizeof(float);
+            switch (groups) {
+                case 2: launch_fwd_mq<2>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
+                case 3: launch_fwd_mq<3>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
+                case 4: launch_fwd_mq<4>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
+                default: launch_fwd_mq<5>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
+            }
+        }
         A2S_CHECK_LAUNCH("attn_fwd_split256");
     }
-    hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, ws, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total, row_rank, n_active);
+    hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, ws, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total,
+                       r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step);
     A2S_CHECK_LAUNCH("attn_fwd_combine256");
     return A2S_OK;
 }

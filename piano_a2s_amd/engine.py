@@ -226,9 +226,11 @@ class Engine:
 
     def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None,
                       active=None):
-        """One NoteDecoder.decode_notes call.  probs_bar: view (B, max_steps, V) of the output tensor (strided).
-        active: optional dict(until, order, rank: (B,) int32 device tensors; n_active: host int array per step) -- row b's attention
-        is skipped from step until[b] on (see Engine.skip_finished_rows)."""
+        """One NoteDecoder.decode_notes call over B rows.  probs_bar: view (B, max_steps, V) of the output tensor (strided).
+        tf_flags: per step, bit g = teacher-force the rows of group g.
+        active: optional dict(until: (B,) int32, order / rank: (n_clips,) int32 device tensors; n_active: host int array per step;
+        n_clips) -- the rows are B/n_clips fused bars of the same clips and row r's attention is skipped from step until[r] on (see
+        Engine.forward: skip_finished_rows / fuse_bars)."""
         L = hip.lib()
         H, E, V = self.cfg["hidden_size"], self.cfg["note_emb_size"], VOCAB_SIZE
         H2, ldx = 2 * H, E + 2 * H
@@ -266,10 +268,12 @@ class Engine:
                         ("emb", S[prefix + ".embedding.weight"]), ("keys", keys), ("enc", enc), ("h", h), ("x", x), ("q", q),
                         ("gates", gates), ("attw", attw), ("o", o), ("gh", gh), ("gi", gi), ("logits", logits),
                         ("argmax_out", ids), ("eos_seen", eos_seen), ("lengths", lengths), ("n_done", n_done), ("steps_exec", steps_exec), ("drop", drop), ("attn_ws", attn_ws), ("gemm_ws", gemm_ws), ("t_base", t_base),
-                        ("row_order", active and active["order"]), ("row_rank", active and active["rank"])):
+                        ("clip_order", active and active["order"]), ("clip_rank", active and active["rank"]),
+                        ("row_until", active and active["until"])):
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.gemm_ws_bytes = gemm_ws.numel() * 4 if gemm_ws is not None else 0
         a.n_active = C.cast(active["n_active"], C.c_void_p).value if active else None
+        a.n_clips = active["n_clips"] if active else 0
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
         if gt_bar is not None:
             a.gt, a.gt_bstride = gt_bar.data_ptr(), gt_bar.stride(0)
@@ -317,32 +321,62 @@ class Engine:
         if ground_truth is not None:
             ts_gt, key_gt, up_gt, up_len_gt, lo_gt, lo_len_gt = [g.contiguous() for g in ground_truth]
             gt_cpu = (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())      # ONE host sync per forward
-        # Fused training step only (train.TrainStep sets skip_finished_rows): a row whose remaining targets are all <pad> no longer
-        # reaches the loss (ignore_index) nor the next bar token (its staff embedding reads ids[:length] only), so its attention --
-        # the HBM-bound part of a step -- is skipped.  Never set on the drop-in module path, whose output rows past <eos> must equal
-        # the reference's.
-        active_all = None
-        if gt_cpu is not None and training and getattr(self, "skip_finished_rows", False):
-            active_all = []
-            for g, maxs in zip(gt_cpu[:2], (U, Lo)):
+        maxlen = (U, Lo)
+        # ---- host plan.  With ground truth the number of executed steps of every (bar, staff) is known up front, so every coin of
+        # the reference's protocol (one per executed note step, upper then lower, then one per bar: models.py:404,289) is drawn here,
+        # in the reference's order.
+        plan = None
+        if gt_cpu is not None:
+            plan = []
+            for bar in range(bars):
+                p = {}
+                for gi_idx in (0, 1):
+                    steps, _ = plan_note_steps(gt_cpu[gi_idx][:, bar, :], maxlen[gi_idx])
+                    p[gi_idx] = (steps, [rng.random() < teacher_forcing_ratio for _ in range(steps)])
+                p["tf"] = rng.random() < teacher_forcing_ratio
+                plan.append(p)
+        # Fused training step only (train.TrainStep sets these; never the drop-in module path, whose output rows must equal the
+        # reference's everywhere):
+        #  skip_finished_rows -- a row whose remaining targets are all <pad> no longer reaches the loss (ignore_index) nor the next
+        #    bar token (its staff embedding reads ids[:length] only): its attention, the HBM-bound part of a step, is skipped;
+        #  fuse_bars -- when bar k's coin says "teacher-force", bar k+1's input token comes from the ground truth, so the note
+        #    decoders of bar k+1 do not depend on those of bar k: consecutive such bars are decoded in ONE call over bars x B rows
+        #    (fewer, fatter launches; the rows of a clip share its keys / encoder outputs, streamed once for all of them).
+        skip = plan is not None and training and getattr(self, "skip_finished_rows", False)
+        fuse = skip and getattr(self, "fuse_bars", False)
+        segments = [[0]]
+        for bar in range(1, bars):
+            if fuse and plan[bar - 1]["tf"] and not inference and len(segments[-1]) < 5:      # 5 = A2S_ATTN_MAX_GROUPS
+                segments[-1].append(bar)
+            else:
+                segments.append([bar])
+        until_all = None
+        if skip:
+            until_all = []
+            for g in gt_cpu[:2]:
                 idx = torch.arange(1, g.shape[-1] + 1, dtype=torch.int32)
-                until = ((g != PAD).to(torch.int32) * idx).amax(dim=-1).to(torch.int32).t().contiguous()       # (bars, B): last real target + 1
-                order = torch.argsort(until, dim=1, descending=True, stable=True).to(torch.int32)           # rows that finish last come first
-                rank = torch.empty_like(order)
-                rank.scatter_(1, order.long(), torch.arange(B, dtype=torch.int32).repeat(bars, 1))
-                d_until, d_order, d_rank = until.to(dev), order.to(dev), rank.to(dev)                       # before the stream fork below
-                per_bar = []
-                for bar in range(bars):
-                    cnt = torch.bincount(until[bar].long(), minlength=maxs + 1)                              # rows finishing at step s
-                    n_act = B - torch.cumsum(cnt, 0)[:maxs]                                                  # rows with until > t
-                    per_bar.append(dict(until=d_until[bar], order=d_order[bar], rank=d_rank[bar],
-                                        n_active=(C.c_int * maxs)(*n_act.tolist())))
-                active_all.append(per_bar)
+                until_all.append(((g != PAD).to(torch.int32) * idx).amax(dim=-1).to(torch.int32).t().contiguous())   # (bars, B): last real target + 1
 
+        def active_rows(gi_idx, seg, n):
+            """Row / clip bookkeeping of one decoder call over the bars `seg` (n steps launched)."""
+            until = torch.stack([until_all[gi_idx][bar].clamp(max=plan[bar][gi_idx][0]) for bar in seg])        # the bar's loop ends at its own step count
+            clip_until = until.amax(dim=0)
+            order = torch.argsort(clip_until, descending=True, stable=True).to(torch.int32)                     # clips that finish last come first
+            rank = torch.empty_like(order)
+            rank[order.long()] = torch.arange(B, dtype=torch.int32)
+            cnt = torch.bincount(clip_until.long(), minlength=n + 1)
+            n_act = B - torch.cumsum(cnt, 0)[:n]                                                                # clips with until > t
+            return dict(until=until.reshape(-1).contiguous().to(dev), order=order.to(dev), rank=rank.to(dev),
+                        n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=B)
+
+        bar_major = fuse
+        self.bar_major = bar_major
         ts_out = torch.zeros((B, bars, cfg["num_time_sig"]), device=dev)
         key_out = torch.zeros((B, bars, cfg["num_keys"]), device=dev)
-        up_out = torch.zeros((B, bars, U, V), device=dev)
-        lo_out = torch.zeros((B, bars, Lo, V), device=dev)
+        # fused bars: staff outputs bar-major (bars, B, len, V) so that the rows of consecutive bars are uniformly strided
+        up_out = torch.zeros((bars, B, U, V) if bar_major else (B, bars, U, V), device=dev)
+        lo_out = torch.zeros((bars, B, Lo, V) if bar_major else (B, bars, Lo, V), device=dev)
+        gt_bm = (up_gt.transpose(0, 1).contiguous(), lo_gt.transpose(0, 1).contiguous()) if bar_major else None
 
         tokw = 4 * Sz + te + ke
         token = self._empty(B, tokw, dev=dev)
@@ -357,13 +391,16 @@ class Engine:
                                    cfg["num_keys"], hip._p(token), C.c_long(tokw), 4 * Sz + te, B, ke, C.c_void_p(0), hip.f32(1.0)), "embed key")
 
         ldxb = tokw + 2 * H
-        bar_saved = []
+        bar_saved, seg_saved = [], []
+        max_rows = B * max(len(sg) for sg in segments)
         # per-staff scratch (split-T attention partials, split-K slabs): the two staves run concurrently on two streams
-        attn_ws = [hip.attn_workspace(B, T, H, dev) for _ in range(2)]
-        gemm_ws = [hip.gemm_workspace(B, dev) for _ in range(2)]
+        attn_ws = [hip.attn_workspace(B, T, H, dev, groups=max_rows // B) for _ in range(2)]
+        gemm_ws = [hip.gemm_workspace(max_rows, dev) for _ in range(2)]
         concurrent = gt_cpu is not None and getattr(self, "concurrent_staves", True)    # greedy decode polls the device: sequential
         streams = side_streams(dev) if concurrent else None
-        for bar in range(bars):
+
+        def bar_step(bar, token, hidden):
+            """Bar-level attention + GRU step (models.py:241-247) and the two heads (models.py:281-286)."""
             xbar = self._empty(B, ldxb, dev=dev)
             headin = self._empty(B, 4 * H, dev=dev)
             if drop_on:
@@ -372,7 +409,6 @@ class Engine:
             else:
                 keep = None
                 xbar[:, :tokw].copy_(token)
-            # bar-level attention + GRU step (models.py:241-247)
             qb = self._empty(B, H, dev=dev)
             Wa = S["decoder.attn.attn.weight"]
             hip.gemm(hidden, 2 * H, 1, Wa, 1, 4 * H, qb, H, B, H, 2 * H, bias=S["decoder.attn.attn.bias"])
@@ -389,45 +425,9 @@ class Engine:
             hip.check(L.a2s_gru_gates_fwd(hip.stream(), hip._p(gi), C.c_long(6 * H), hip._p(gh), C.c_long(6 * H), hip._p(hidden),
                                           C.c_long(2 * H), hip._p(hnew), C.c_long(2 * H), hip._p(headin), C.c_long(4 * H),
                                           hip._p(gates), B, 2 * H), "a2s_gru_gates_fwd")
-            # note decoders (models.py:261-275)
-            staff = {}
-            joins = []
-            if concurrent:
-                fork = torch.cuda.Event()
-                fork.record()
-            for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out, 0), ("lo", "decoder.lower_decoder", Lo, lo_out, 1)):
-                if gt_cpu is not None:
-                    steps, plan_len = plan_note_steps(gt_cpu[gi_idx][:, bar, :], maxs)
-                    flags = [rng.random() < teacher_forcing_ratio for _ in range(steps)]      # one draw per executed step
-                    gt_bar = (up_gt if gi_idx == 0 else lo_gt)[:, bar, :]
-                    active = active_all[gi_idx][bar] if active_all is not None else None
-                else:
-                    steps, plan_len, flags, gt_bar, active = maxs, None, None, None, None
-                if concurrent:
-                    st = streams[gi_idx]
-                    st.wait_event(fork)                    # everything the decoder reads (enc, keys, hnew, zeroed outputs) is ready
-                    with torch.cuda.stream(st):
-                        ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
-                                                              training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx], active)
-                    done = torch.cuda.Event()
-                    done.record(st)
-                    joins.append(done)
-                elif gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH):
-                    # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
-                    st = side_streams(dev)[0]
-                    st.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(st):
-                        ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
-                                                              training, 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx])
-                    torch.cuda.current_stream().wait_stream(st)
-                else:
-                    ids, lengths, sv = self._decode_staff(S, prefix, keys[prefix], enc, hnew, maxs, out_t[:, bar], gt_bar, steps, flags,
-                                                          training, 0.1 if drop_on else 0.0, B, T, attn_ws[gi_idx], gemm_ws[gi_idx], active)
-                if gt_cpu is None:
-                    for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference
-                        rng.random()
-                staff[name] = (ids, lengths, sv)
-            # heads (models.py:281-286) do not depend on the note decoders: they overlap with them on the main stream
+            return dict(xbar=xbar, headin=headin, qb=qb, attw=attw, gates=gates, hprev=hidden, hnew=hnew, keep=keep)
+
+        def bar_heads(bar, headin):
             heads = {}
             for hname, out_t, nc in (("time_sig_out", ts_out, cfg["num_time_sig"]), ("key_out", key_out, cfg["num_keys"])):
                 t1 = hip.linear(headin, S[f"decoder.{hname}.0.weight"], S[f"decoder.{hname}.0.bias"], act=1)
@@ -437,10 +437,11 @@ class Engine:
                 hip.check(L.a2s_log_softmax_rows(hip.stream(), hip._p(lg), C.c_long(nc), C.c_void_p(out_t.data_ptr() + 4 * bar * nc),
                                                  C.c_long(bars * nc), hip._p(am), B, nc), "a2s_log_softmax_rows")
                 heads[hname] = (t1, t2, lg, am)
-            for ev in joins:                               # the next token / next bar may read what the staves produced
-                torch.cuda.current_stream().wait_event(ev)
-            # next bar token (models.py:289-311): one draw per bar, after both staves
-            teacher_force = rng.random() < teacher_forcing_ratio
+            return heads
+
+        def next_token(bar, teacher_force, staff, heads):
+            """Token bar `bar` hands to the next one (models.py:289-311); staff: {name: (ids, lengths)} of this bar's rows (not needed
+            when teacher-forced)."""
             token = self._empty(B, tokw, dev=dev)
             tok_rec = [] if training else None
             if teacher_force and not inference:
@@ -457,11 +458,82 @@ class Engine:
                 hip.check(L.a2s_embed_rows(hip.stream(), hip._p(table), hip._p(ids_) if i64 else C.c_void_p(0),
                                            C.c_void_p(0) if i64 else hip._p(ids_), C.c_long(stride), 0, hip._p(token), C.c_long(tokw), col, B,
                                            width, C.c_void_p(0), hip.f32(1.0)), "embed next token")
-            bar_saved.append(dict(xbar=xbar, headin=headin, qb=qb, attw=attw, gates=gates, hprev=hidden, hnew=hnew, staff=staff,
-                                  heads=heads, keep=keep, teacher_force=teacher_force, tok_rec=tok_rec,
-                                  next_ids=(ts_ids, key_ids, i64, stride)))
-            hidden = hnew
-        self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, enc_out=enc, sos_rec=sos_rec, training=training,
-                          concurrent=concurrent, outs=(ts_out, key_out, up_out, lo_out), gt=(ground_truth is not None and (up_gt, lo_gt)) or None,
-                          shape=(B, T, F), drop_on=drop_on)
+            return token, tok_rec, (ts_ids, key_ids, i64, stride)
+
+        for seg in segments:
+            nb = len(seg)
+            # (1) bar-level chain of the segment: inside a segment every next token comes from the ground truth
+            for j, bar in enumerate(seg):
+                rec = bar_step(bar, token, hidden)
+                rec["seg"] = (len(seg_saved), j)
+                bar_saved.append(rec)
+                hidden = rec["hnew"]
+                if j + 1 < nb:
+                    token, rec["tok_rec"], rec["next_ids"] = next_token(bar, True, None, None)
+                    rec["teacher_force"] = True
+            h0 = bar_saved[seg[0]]["hnew"] if nb == 1 else torch.cat([bar_saved[bar]["hnew"] for bar in seg], dim=0)
+            R = nb * B
+            # (2) note decoders of the segment (models.py:261-275)
+            staff = {}
+            joins = []
+            if concurrent:
+                fork = torch.cuda.Event()
+                fork.record()
+            for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out, 0), ("lo", "decoder.lower_decoder", Lo, lo_out, 1)):
+                active = None
+                if plan is not None:
+                    steps = max(plan[bar][gi_idx][0] for bar in seg)
+                    flags = [sum(int(t < plan[bar][gi_idx][0] and plan[bar][gi_idx][1][t]) << j for j, bar in enumerate(seg)) for t in range(steps)]
+                    if bar_major:
+                        gt_bar = gt_bm[gi_idx][seg[0]:seg[0] + nb].view(R, maxs)
+                        probs = out_t[seg[0]:seg[0] + nb].view(R, maxs, V)
+                    else:
+                        gt_bar = (up_gt if gi_idx == 0 else lo_gt)[:, seg[0], :]
+                        probs = out_t[:, seg[0]]
+                    if skip:
+                        active = active_rows(gi_idx, seg, steps)
+                else:
+                    steps, flags, gt_bar, probs = maxs, None, None, out_t[:, seg[0]]
+                args = (S, prefix, keys[prefix], enc, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
+                        attn_ws[gi_idx], gemm_ws[gi_idx], active)
+                if concurrent:
+                    st = streams[gi_idx]
+                    st.wait_event(fork)                    # everything the decoder reads (enc, keys, hnew, zeroed outputs) is ready
+                    with torch.cuda.stream(st):
+                        ids, lengths, sv = self._decode_staff(*args)
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    joins.append(done)
+                elif gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH):
+                    # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
+                    st = side_streams(dev)[0]
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        ids, lengths, sv = self._decode_staff(*args)
+                    torch.cuda.current_stream().wait_stream(st)
+                else:
+                    ids, lengths, sv = self._decode_staff(*args)
+                if gt_cpu is None:
+                    for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference
+                        rng.random()
+                sv["groups"] = nb
+                staff[name] = (ids, lengths, sv)
+            # (3) heads do not depend on the note decoders: they overlap with them on the main stream
+            for bar in seg:
+                bar_saved[bar]["heads"] = bar_heads(bar, bar_saved[bar]["headin"])
+            for ev in joins:                               # the next token / next bar may read what the staves produced
+                torch.cuda.current_stream().wait_event(ev)
+            seg_saved.append(dict(bars=seg, staff=staff))
+            for bar in seg:
+                bar_saved[bar]["staff"] = staff            # (shared by the bars of a fused segment)
+            # (4) token for the bar after the segment: one draw per bar, after both staves (drawn in the plan with ground truth)
+            last = seg[-1]
+            teacher_force = plan[last]["tf"] if plan is not None else (rng.random() < teacher_forcing_ratio)
+            rec = bar_saved[last]
+            last_rows = {name: (staff[name][0][(nb - 1) * B:], staff[name][1][(nb - 1) * B:]) for name in staff}
+            token, rec["tok_rec"], rec["next_ids"] = next_token(last, teacher_force, last_rows, rec["heads"])
+            rec["teacher_force"] = teacher_force
+        self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, segments=seg_saved, enc_out=enc, sos_rec=sos_rec,
+                          training=training, concurrent=concurrent, outs=(ts_out, key_out, up_out, lo_out), bar_major=bar_major,
+                          gt=(ground_truth is not None and (up_gt, lo_gt)) or None, shape=(B, T, F), drop_on=drop_on)
         return ts_out, key_out, up_out, lo_out

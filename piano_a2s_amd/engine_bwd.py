@@ -63,21 +63,24 @@ def _staff_token_bwd(eng, S, G, rec, dtok):
     return gptrs     # keep alive until the caller returns
 
 
-def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_all, dK, dEnc, B, T, H, steps, active=None):
-    """Key/value side of `steps` attention calls of one layer: dEnc += A^T dCtx (per clip), dK += ..., dv += ..."""
+def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_all, dK, dEnc, B, T, H, steps, active=None, groups=1):
+    """Key/value side of `steps` attention calls of one layer: dEnc += A^T dCtx (per clip), dK += ..., dv += ...
+    The per-step tensors hold groups*B rows per step, row = group*B + clip (fused bars): (step, group) is one flat reduction index."""
     L = hip.lib()
-    # dEnc[b] += sum_s a_s[b,:]^T dctx_s[b,:]   -- batched over clips: (T x steps)(steps x 2H)
-    hip.gemm(attw_all, 1, B * T, dctx_all, B * 2 * H, 1, dEnc, 2 * H, T, 2 * H, steps, beta=1.0, batch=B, bsA=T, bsB=2 * H, bsC=T * 2 * H)
+    # dEnc[b] += sum_{s,g} a_sg[b,:]^T dctx_sg[b,:]   -- batched over clips: (T x steps*groups)(steps*groups x 2H)
+    hip.gemm(attw_all, 1, B * T, dctx_all, B * 2 * H, 1, dEnc, 2 * H, T, 2 * H, steps * groups, beta=1.0, batch=B, bsA=T, bsB=2 * H, bsC=T * 2 * H)
     nblk = L.a2s_attn_dk_blocks(B, T)
     dvp = torch.empty((nblk, H), dtype=torch.float32, device=enc.device)
     hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(keys), hip._p(q_all), hip._p(ds_all), hip._p(S[prefix + ".v.weight"]), hip._p(dK),
-                                  hip._p(dvp), B, T, steps, H, hip._p(active["until"] if active else None)), "a2s_attn_dk_accum")
+                                  hip._p(dvp), B, T, steps, H, hip._p(active["until"] if active else None), groups), "a2s_attn_dk_accum")
     _colsum(dvp, H, G[prefix + ".v.weight"], nblk, H)
 
 
-def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, B, T):
-    """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (B, 2H)."""
+def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T):
+    """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (rows, 2H); rows = groups * n_clips."""
     L = hip.lib()
+    groups = sv.get("groups", 1)
+    B = groups * n_clips
     cfg = eng.cfg
     H, E, V = cfg["hidden_size"], cfg["note_emb_size"], VOCAB_SIZE
     H2, ldx = 2 * H, E + 2 * H
@@ -104,10 +107,12 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
                     ("w_hh", S[prefix + ".gru.weight_hh_l0"]), ("keys", keys), ("enc", enc), ("h", sv["h"]), ("x", sv["x"]), ("q", sv["q"]),
                     ("gates", sv["gates"]), ("attw", sv["attw"]), ("do_all", do_all), ("dgi_all", dgi_all), ("dgh_all", dgh_all),
                     ("dq_all", dq_all), ("ds_all", ds_all), ("dctx_all", dctx_all), ("dx", dx), ("dh", dh), ("attn_ws", sv["attn_ws"]), ("gemm_ws", sv["gemm_ws"]),
-                    ("row_order", sv.get("active") and sv["active"]["order"]), ("row_rank", sv.get("active") and sv["active"]["rank"])):
+                    ("clip_order", sv.get("active") and sv["active"]["order"]), ("clip_rank", sv.get("active") and sv["active"]["rank"]),
+                    ("row_until", sv.get("active") and sv["active"]["until"])):
         setattr(a, name, t.data_ptr() if t is not None else None)
     a.gemm_ws_bytes = sv["gemm_ws"].numel() * 4 if sv["gemm_ws"] is not None else 0
     a.n_active = C.cast(sv["active"]["n_active"], C.c_void_p).value if sv.get("active") else None
+    a.n_clips = sv["active"]["n_clips"] if sv.get("active") else 0
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) deferred weight gradients over all steps
@@ -119,13 +124,15 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     sk = L.a2s_gemm_pick_splitk(H, H2, R, 1)
     hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk)
     _colsum(dq_all, H, G[prefix + ".attn.attn.bias"], R, H)
-    _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, B, T, H, n, sv.get("active"))
+    _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, n_clips, T, H, n, sv.get("active"), groups)
     # embedding rows of the tokens consumed at each step: <sos> at step 0, then gt or argmax of the previous step
     tok = torch.full((n, B), SOS, dtype=torch.int32, device=dev)
     if n > 1:
         prev = sv["ids"][:, :n - 1].t()
         if sv["gt_bar"] is not None:
-            flags = torch.tensor(sv["flags"][:n - 1], dtype=torch.bool, device=dev).unsqueeze(1)
+            bits = torch.tensor(sv["flags"][:n - 1], dtype=torch.int32, device=dev).unsqueeze(1)                    # bit g: group g teacher-forced
+            grp = (torch.arange(B, dtype=torch.int32, device=dev) // n_clips).unsqueeze(0)
+            flags = ((bits >> grp) & 1).bool()
             prev = torch.where(flags, sv["gt_bar"][:, :n - 1].t().to(torch.int32), prev)
         tok[1:] = prev
     drop = sv["drop"]
@@ -168,6 +175,38 @@ def backward(eng, S, grad_outputs):
     streams = side_streams(dev) if concurrent else None
     dEnc_staff = [torch.zeros_like(dEnc), torch.zeros_like(dEnc)] if concurrent else [dEnc, dEnc]
 
+    bar_major = bool(sv.get("bar_major"))
+    seg_dh0 = {}                # segment index -> [dh0 of the upper call, dh0 of the lower call], rows = (bar in segment, clip)
+
+    def segment_decoders_bwd(si_seg):
+        """Both note decoders of a segment (bars decoded in one call each): they only need the loss gradients."""
+        seg = sv["segments"][si_seg]
+        bar0, nb = seg["bars"][0], len(seg["bars"])
+        dh0s, joins = [], []
+        if concurrent:
+            fork = torch.cuda.Event()
+            fork.record()
+        for si, (name, prefix, dout, out_t) in enumerate((("up", "decoder.upper_decoder", dup, up_out), ("lo", "decoder.lower_decoder", dlo, lo_out))):
+            if bar_major:
+                maxs = out_t.shape[2]
+                dpr, pr = dout[bar0:bar0 + nb].view(nb * B, maxs, -1), out_t[bar0:bar0 + nb].view(nb * B, maxs, -1)
+            else:
+                dpr, pr = dout[:, bar0], out_t[:, bar0]
+            args = (eng, S, G, seg["staff"][name][2], sv["keys"][prefix], enc, dpr, pr, dK[prefix], dEnc_staff[si], B, T)
+            if concurrent:
+                st = streams[si]
+                st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    dh0s.append(_note_decoder_bwd(*args))
+                done = torch.cuda.Event()
+                done.record(st)
+                joins.append(done)
+            else:
+                dh0s.append(_note_decoder_bwd(*args))
+        for ev in joins:
+            torch.cuda.current_stream().wait_event(ev)
+        seg_dh0[si_seg] = dh0s
+
     d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
     d_token_next = None         # gradient wrt the (pre-dropout) token that bar k produced for bar k+1
     for bar in reversed(range(bars)):
@@ -197,27 +236,11 @@ def backward(eng, S, grad_outputs):
             _linear_bwd(b["headin"], S[p + ".0.weight"], dt1, G, p + ".0.weight", p + ".0.bias", dx=d_headin, dx_beta=1.0)
         # ---- (3) note decoders: both start from bar_summary
         d_hnew = torch.zeros((B, H2), dtype=torch.float32, device=dev)
-        dh0s, joins = [], []
-        if concurrent:
-            fork = torch.cuda.Event()
-            fork.record()
-        for si, (name, prefix, dout, out_t) in enumerate((("up", "decoder.upper_decoder", dup, up_out), ("lo", "decoder.lower_decoder", dlo, lo_out))):
-            if concurrent:
-                st = streams[si]
-                st.wait_event(fork)
-                with torch.cuda.stream(st):
-                    dh0s.append(_note_decoder_bwd(eng, S, G, b["staff"][name][2], sv["keys"][prefix], enc, dout[:, bar], out_t[:, bar], dK[prefix],
-                                                  dEnc_staff[si], B, T))
-                done = torch.cuda.Event()
-                done.record(st)
-                joins.append(done)
-            else:
-                dh0s.append(_note_decoder_bwd(eng, S, G, b["staff"][name][2], sv["keys"][prefix], enc, dout[:, bar], out_t[:, bar], dK[prefix],
-                                              dEnc_staff[si], B, T))
-        for ev in joins:
-            torch.cuda.current_stream().wait_event(ev)
-        for dh0 in dh0s:
-            d_hnew.add_(dh0)
+        si_seg, j = b["seg"]
+        if si_seg not in seg_dh0:
+            segment_decoders_bwd(si_seg)
+        for dh0 in seg_dh0[si_seg]:
+            d_hnew.add_(dh0[j * B:(j + 1) * B])
         d_hnew.add_(d_headin[:, :H2])
         if d_hid_carry is not None:
             d_hnew.add_(d_hid_carry)

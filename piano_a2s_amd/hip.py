@@ -25,8 +25,8 @@ class NoteDecArgs(C.Structure):
         ("drop", C.c_void_p), ("inv_keep", C.c_float),
         ("argmax_out", C.c_void_p), ("am_bstride", C.c_long),
         ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p), ("attn_ws", C.c_void_p),
-        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("t_base", C.c_void_p), ("row_order", C.c_void_p), ("row_rank", C.c_void_p),
-        ("n_active", C.c_void_p),
+        ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("t_base", C.c_void_p), ("clip_order", C.c_void_p), ("clip_rank", C.c_void_p),
+        ("row_until", C.c_void_p), ("n_active", C.c_void_p), ("n_clips", C.c_int),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
         ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int), ("use_graph", C.c_int)]
 
@@ -36,7 +36,8 @@ class NoteDecBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "attn_w", "attn_v", "w_ih", "w_hh", "keys", "enc", "h", "x", "q", "gates", "attw", "do_all",
         "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh", "attn_ws", "gemm_ws")] + [
-        ("gemm_ws_bytes", C.c_size_t), ("row_order", C.c_void_p), ("row_rank", C.c_void_p), ("n_active", C.c_void_p),
+        ("gemm_ws_bytes", C.c_size_t), ("clip_order", C.c_void_p), ("clip_rank", C.c_void_p), ("row_until", C.c_void_p),
+        ("n_active", C.c_void_p), ("n_clips", C.c_int),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int)]
 
 
@@ -48,7 +49,8 @@ def lib():
                            "There is no CPU fallback for the transcription hot path.")
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
-        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_conv3x3_workspace_floats"):
+        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
+                   "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
     return _lib
 
@@ -64,11 +66,11 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-def attn_workspace(B, T, H, device):
-    """Scratch for the split-T attention kernels (None when the one-workgroup-per-clip kernels are used)."""
+def attn_workspace(B, T, H, device, groups=1):
+    """Scratch for the split-T attention kernels (None when the one-workgroup-per-clip kernels are used); groups: fused bars per call."""
     if H != 256:
         return None
-    return torch.empty(lib().a2s_attn_workspace_floats(B, T, H), dtype=torch.float32, device=device)
+    return torch.empty(lib().a2s_attn_workspace_floats_fused(B, T, H, groups), dtype=torch.float32, device=device)
 
 
 def conv_workspace(cin, device):

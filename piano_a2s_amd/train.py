@@ -92,13 +92,17 @@ class FusedAdadelta:
 class TrainStep:
     """model: models.ScoreTranscription on a GPU.  One call = one optimizer step on one minibatch."""
 
-    def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True, sync_bn=None, skip_finished_rows=None):
+    def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True, sync_bn=None, skip_finished_rows=None,
+                 fuse_bars=None):
         """skip_finished_rows (default on; A2S_SKIP_FINISHED=0 turns it off): the note decoders skip the attention of rows whose
-        remaining targets are all <pad>.  Loss, gradients and the update are unchanged (those rows are ignore_index positions and
-        nothing else reads them); only `last_outputs` rows past <eos> differ from the reference's values."""
+        remaining targets are all <pad>.  fuse_bars (default on with the former; A2S_FUSE_BARS=0 turns it off): consecutive bars
+        whose bar-level input is teacher-forced are decoded in one call (Engine.forward).  Loss, gradients and the update are
+        unchanged (skipped rows are ignore_index positions and nothing else reads them); only `last_outputs` positions whose target
+        is <pad> differ from the reference's values."""
         self.model = model
         self.sync_bn = (_os.environ.get("A2S_SYNC_BN") == "1") if sync_bn is None else bool(sync_bn)
         self.skip_finished_rows = (_os.environ.get("A2S_SKIP_FINISHED", "1") != "0") if skip_finished_rows is None else bool(skip_finished_rows)
+        self.fuse_bars = (_os.environ.get("A2S_FUSE_BARS", "1") != "0") if fuse_bars is None else bool(fuse_bars)
         self.flat = model.flatten_()
         self.opt = FusedAdadelta(self.flat, lr, rho, eps, max_grad_norm)
         self.objective = Objective(self.flat.device)
@@ -116,10 +120,15 @@ class TrainStep:
         spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = batch[:7]
         eng = engine.Engine(self.model.cfg, sync_bn=self.sync_bn)
         eng.skip_finished_rows = self.skip_finished_rows
+        eng.fuse_bars = self.skip_finished_rows and self.fuse_bars
         S = self.state()
         outs = eng.forward(S, spectrogram, inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len],
                            teacher_forcing_ratio=teacher_forcing_ratio, training=True, rng=rng, dropout=self.dropout)
-        losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
+        if eng.bar_major:            # fused bars: the staff outputs come bar-major (bars, B, len, V); the loss is a mean over rows
+            losses, gouts = self.objective(outs, (ts_t, key_t, up_t.transpose(0, 1), lo_t.transpose(0, 1)))
+            outs = (outs[0], outs[1], outs[2].transpose(0, 1), outs[3].transpose(0, 1))
+        else:
+            losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
         G = engine_bwd.backward(eng, S, gouts)
         flat_g = G[None]
         average_gradients(flat_g, self.world)

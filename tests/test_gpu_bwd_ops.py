@@ -95,7 +95,7 @@ def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S, split):
     dK = torch.zeros(B, T, H, device=dev)
     nblk = L.a2s_attn_dk_blocks(B, T)
     dvp = torch.zeros(nblk, H, device=dev)
-    hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(Kd), hip._p(q_all), hip._p(ds_all), hip._p(vd), hip._p(dK), hip._p(dvp), B, T, S, H, C.c_void_p(0)), "dk")
+    hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(Kd), hip._p(q_all), hip._p(ds_all), hip._p(vd), hip._p(dK), hip._p(dvp), B, T, S, H, C.c_void_p(0), 1), "dk")
     dv = torch.zeros(H, device=dev)
     hip.check(L.a2s_col_sum(hip.stream(), hip._p(dvp), C.c_long(H), hip._p(dv), C.c_long(nblk), H, hip.f32(1.0), hip.f32(0.0), NULL, C.c_size_t(0)), "col_sum")
     # deferred dEnc[b] = sum_s a_s[b]^T dctx_s[b]  as one batched GEMM (T x S)(S x 2H)

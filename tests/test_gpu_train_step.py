@@ -158,34 +158,41 @@ def test_full_width_step_with_flat_parameters(dev):
     assert not torch.equal(before, step.flat)
 
 
-def test_skipping_finished_rows_does_not_change_the_step(dev):
-    """TrainStep(skip_finished_rows=True) (attention skipped for rows whose remaining targets are all <pad>) vs the plain step on the
-    256-wide model (the split-T kernels): identical loss terms, gradient norm and updated parameters; ragged lengths, mixed teacher
-    forcing, full-length rows without <eos> included."""
+@pytest.mark.parametrize("tf_ratio,seed", [(0.6, 4), (1.0, 1), (0.85, 7), (0.0, 2)])
+def test_skipping_rows_and_fusing_bars_do_not_change_the_step(dev, tf_ratio, seed):
+    """TrainStep's two training-only shortcuts vs the plain step on the 256-wide model (the split-T kernels):
+      skip_finished_rows -- attention skipped for rows whose remaining targets are all <pad>;
+      fuse_bars          -- consecutive teacher-forced bars decoded in one call (multi-row-per-clip attention kernels).
+    Identical loss terms, gradient norm and updated parameters; ragged lengths, mixed teacher forcing (tf 1.0: all 5 bars in one call,
+    0.0: never fused), full-length rows without <eos> included."""
     import random
     import models
     from piano_a2s_amd import spec, synthetic, train
-    cfg = spec.default_cfg(max_length=(14, 9), max_bars=3)
+    cfg = spec.default_cfg(max_length=(14, 9), max_bars=5)
     st = spec.procedural_state(cfg, 5, eos_bias=1.0, lively="token")
     batch = synthetic.make_batch(5, cfg, 21, frames=61, upper_range=(1, 14), lower_range=(1, 9), full_tail=0.2, spectrogram="ridges")
     dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
     res = []
-    for skip in (False, True):
+    for skip, fuse in ((False, False), (True, False), (True, True)):
         m = models.ScoreTranscription(**cfg)
         m.load_state_dict(st)
         m = m.to(dev)
         m.train()
-        step = train.TrainStep(m, dropout=False, skip_finished_rows=skip)
-        losses = step(dbatch, teacher_forcing_ratio=0.6, rng=random.Random(4))
+        step = train.TrainStep(m, dropout=False, skip_finished_rows=skip, fuse_bars=fuse)
+        losses = step(dbatch, teacher_forcing_ratio=tf_ratio, rng=random.Random(seed))
         torch.cuda.synchronize()
         res.append((losses[:, 0].cpu().clone(), step.opt.ctl.cpu().clone(), step.flat.cpu().clone(), [o.cpu() for o in step.last_outputs]))
-    (l0, c0, p0, o0), (l1, c1, p1, o1) = res
-    assert torch.isfinite(l0).all() and float(c0[2]) == 1.0 and float(c1[2]) == 1.0
-    assert torch.allclose(l0, l1, rtol=1e-6, atol=0), (l0, l1)
-    assert abs(float(c0[0]) - float(c1[0])) <= 1e-5 * float(c0[0])
-    assert float((p0 - p1).abs().max()) <= 1e-6 * float(p0.abs().max())
-    # rows that count (target != <pad>) are untouched; the skipping really happened (some padded row differs)
-    for out0, out1, gt in ((o0[2], o1[2], batch[3]), (o0[3], o1[3], batch[5])):
-        keep = gt != 147
-        assert torch.allclose(out0[keep], out1[keep], rtol=0, atol=1e-6)
-    assert not torch.equal(o0[2], o1[2])
+    l0, c0, p0, o0 = res[0]
+    assert torch.isfinite(l0).all() and float(c0[2]) == 1.0
+    for l1, c1, p1, o1 in res[1:]:
+        assert float(c1[2]) == 1.0
+        assert torch.allclose(l0, l1, rtol=2e-6, atol=0), (l0, l1)
+        assert abs(float(c0[0]) - float(c1[0])) <= 1e-5 * float(c0[0])
+        assert float((p0 - p1).abs().max()) <= 2e-6 * float(p0.abs().max())
+        # positions that count (target != <pad>) are untouched; the skipping really happened (some padded position differs)
+        for out0, out1, gt in ((o0[2], o1[2], batch[3]), (o0[3], o1[3], batch[5])):
+            assert out0.shape == out1.shape
+            keep = gt != 147
+            assert torch.allclose(out0[keep], out1[keep], rtol=0, atol=2e-6)
+        assert torch.allclose(o0[0], o1[0], atol=2e-6) and torch.allclose(o0[1], o1[1], atol=2e-6)
+        assert not torch.equal(o0[2], o1[2])
