@@ -8,9 +8,11 @@ backward, (gradient all-reduce,) clip_grad_norm_(5.0) + Adadelta -- piano_a2s_am
   python bench.py --gpus 1 --steps K --warmup W                      (single GPU)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (one rank per GPU, RCCL)
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (additive-attention step, HBM-bound: it streams the
-clip's keys and encoder outputs once per decode step); `cpu_baseline` is the oracle's as-written CPU restatement of the
-same training step timed on this box's host cores on a bounded sample (a reported baseline, not the target).
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel by GPU time -- since the decoder's bars are fused that is
+conv3x3_mfma<40> (the 40-channel 3x3 convolutions of the ConvStack, forward and input-gradient; fp32 MFMA-bound), measured here on
+conv4's forward launch; `roofline_attention` keeps the figure of the HBM-bound additive-attention step (streams a clip's keys and
+encoder outputs once per decode step) that led the profile before; `cpu_baseline` is the oracle's as-written CPU restatement
+of the same training step timed on this box's host cores on a bounded sample (a reported baseline, not the target).
 """
 import argparse
 import ctypes as C
@@ -27,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFS = 157.3      # dense fp32-input MFMA peak (same guide: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD)
 TF_RATIO = 0.7                 # hparams/pretrain.yaml teacher_forcing_ratio at epoch 0
 
 
@@ -41,6 +44,41 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=1)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def conv_roofline(B, T, F, iters=6):
+    """Average launch duration of the dominant kernel, conv3x3_mfma<40>, on conv4's forward launch at the step's own shapes
+    (40 -> 40 channels, BN+ReLU of the producer folded into the input staging, batch statistics partials written), HIP events on the
+    launch stream.  Algorithmic flops: 2 * 9 * Cin * Cout per output element, zero padding counted as work (0.4 % at 1201 x 480)."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ci = co = 40
+    x = torch.randn(B, T, ci, F, device=dev)
+    y = torch.empty(B, T, co, F, device=dev)
+    w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+    scale, shift = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+    nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
+    partial = torch.empty(nblk, co, 2, device=dev)
+    cws = hip.conv_workspace(ci, dev)
+
+    def launch():
+        hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(w), hip._p(y), hip._p(scale), hip._p(shift), hip._p(partial), B, T, F, ci, co, 0,
+                                hip._p(cws)), "a2s_conv3x3")
+    for _ in range(2):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    avg_s = e0.elapsed_time(e1) / iters / 1e3
+    flops = 2.0 * 9 * ci * co * B * T * F
+    achieved = flops / avg_s / 1e12
+    return {"bound": "mfma", "kernel": "conv3x3_mfma<40> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
+            "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFS, 4), "traffic": None,
+            "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}
 
 
 def attention_roofline(step, batch_dev, B, T, H, iters=50):
@@ -193,8 +231,13 @@ def main():
                                       "random-init weights; tf_ratio 0.7; dropout on; fwd+loss+bwd+clip+Adadelta",
                           "per_gpu_batch": B, "global_batch": B * world, "upper_len": "U{20..120}", "lower_len": "U{10..80}",
                           "full_length_tail": args.full_tail, "parallelism": f"dp{world}", "batchnorm": "per-rank statistics",
+                          "decoder": "rows whose remaining targets are all <pad> skipped; teacher-forced bars decoded in one call "
+                                     "(loss, gradients and update identical to the per-bar loop)",
                           "final_loss": round(loss, 4), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}}
-        out["roofline"] = attention_roofline(step, batches[0], B, 1201, cfg["hidden_size"])
+        step.last_outputs = None
+        torch.cuda.empty_cache()
+        out["roofline"] = conv_roofline(B, 1201, cfg["freq_bins"])
+        out["roofline_attention"] = attention_roofline(step, batches[0], B, 1201, cfg["hidden_size"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_clips, 1234)
         print(json.dumps(out), flush=True)
