@@ -40,6 +40,10 @@ int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A,
                  int batch, long bsA, long bsB, long bsC, int splitk, float* workspace, size_t workspace_bytes);
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch);
+/* tuning aid (tools/gemm_sweep.py): force the tile configuration for M > 64 (1: 32x64, 2: 64x32, 3: 64x64, 4: 128x128; 0: heuristic) */
+void a2s_gemm_debug_tile(int cfg);
+/* measurement switches for A/B runs (tools/ab_step.py): "gru_fused" 0/1 (one-launch recurrent step), "gemm_tile" as above */
+int a2s_debug_set(const char* key, int value);
 
 /* ---- ConvStack (models.py:475-502,:523-534).  Activations are (B, T, C, F); see csrc/a2s_conv.hip.
  * conv3x3: y = conv(relu(x*in_scale+in_shift)) (scale/shift NULL: plain x), zero padding 1, no bias;

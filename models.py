@@ -164,22 +164,17 @@ class ScoreTranscription(nn.Module):
         clip+Adadelta kernel and the data-parallel all-reduce treat the model as a single tensor.  Idempotent."""
         params = self._param_dict()
         dev = next(iter(params.values())).device
-        total = sum(p.numel() for p in params.values())
+        from piano_a2s_amd.spec import flat_layout
+        offs, total = flat_layout([params[n].numel() for n in self._names])      # every parameter on a 16-byte boundary
         if self._flat is not None and self._flat.device == dev:
-            off, ok = 0, True
-            for n in self._names:
-                ok &= params[n].data_ptr() == self._flat.data_ptr() + 4 * off
-                off += params[n].numel()
-            if ok:
+            if all(params[n].data_ptr() == self._flat.data_ptr() + 4 * off for n, off in zip(self._names, offs)):
                 return self._flat
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
-        off = 0
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for n in self._names:
+            for n, off in zip(self._names, offs):
                 p = params[n]
                 flat[off:off + p.numel()].copy_(p.reshape(-1))
                 p.data = flat[off:off + p.numel()].view(p.shape)
-                off += p.numel()
         self._flat = flat
         return flat
 

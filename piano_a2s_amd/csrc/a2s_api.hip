@@ -28,6 +28,8 @@ int a2s_embed_rows_impl(hipStream_t, const float*, const long long*, const int*,
 int a2s_staff_emb_fwd_impl(hipStream_t, const float*, const float* const*, const long long*, const int*, long, const long long*, long,
                            float*, long, int, float*, int, int, int, int);
 int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch);
+void a2s_gemm_debug_tile_impl(int);
+void a2s_gru_step_fused_set(int);
 int a2s_note_decoder_fwd_impl(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
 
 int a2s_log_softmax_bwd_rows_impl(hipStream_t, const float*, const float*, long, int, float*, int, int, int, int);
@@ -76,6 +78,14 @@ int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A,
 }
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk) { return a2s_gemm_workspace_bytes_impl(M, N, batch, splitk); }
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch) { return a2s_gemm_pick_splitk_impl(M, N, K, batch); }
+void a2s_gemm_debug_tile(int cfg) { a2s_gemm_debug_tile_impl(cfg); }
+int a2s_debug_set(const char* key, int value) {
+    if (!key) return A2S_ERR_ARG;
+    if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
+    if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
+    snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
+    return A2S_ERR_ARG;
+}
 
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
                 float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace) {

@@ -338,6 +338,17 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
 //   dgi_all (B,T,3H) <- per-step input-projection gradients (caller: dW_ih, db_ih, dX via GEMMs)
 //   dgh_shift (B,T,3H) <- dgh of the step whose h_prev is out[:,t]  (row (b,t) pairs with out[b,t]: dW_hh = dgh_shift^T out)
 //   dgh_first (B,3H)   <- dgh of the first processed step (h_prev = 0): only contributes to db_hh
+bool a2s_gru_step_fused_enabled(void);
+int a2s_skinny_gemm_acc_impl(hipStream_t st, const float* A, long lda, const float* Bt, long ldb, float* Cm, long ldc, int R, int N, int K);
+
+// out[c][r] = in[r][c]  (rows x cols -> cols x rows); small parameter matrices only
+__global__ void transpose_f32(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int c = idx / rows, r = idx % rows;          // consecutive threads write consecutive out elements
+    out[idx] = in[(long)r * cols + c];
+}
+
 int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride,
                          long out_tstride, const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift,
                          float* dgh_first, float* dhbuf, float* dgh_tmp, int B, int T, int H, int reverse, float* ws, size_t ws_bytes) {
@@ -348,6 +359,13 @@ int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, lon
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gru_seq_bwd init: %s", hipGetErrorString(e));
     e = hipMemsetAsync(dgh_shift, 0, sizeof(float) * (size_t)B * T * 3 * H, st);
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gru_seq_bwd memset: %s", hipGetErrorString(e));
+    // one launch for dh_prev += dgh W_hh (skinny_gemm_acc, a2s_seq.hip): needs W_hh^T (H x 3H) so that both operands are
+    // K-contiguous rows; the transposed copy lives in the workspace
+    const bool fused = a2s_gru_step_fused_enabled() && H % 32 == 0 && ws && ws_bytes >= sizeof(float) * 3 * H * H && ((uintptr_t)ws % 16 == 0);
+    if (fused) {
+        hipLaunchKernelGGL(transpose_f32, dim3(a2s_cdiv(3 * H * H, 256)), dim3(256), 0, st, w_hh, ws, 3 * H, H);
+        A2S_CHECK_LAUNCH("transpose_f32");
+    }
     int cur = 0;
     for (int s = T - 1; s >= 0; --s) {                 // s = processing index of the forward pass
         const int t = reverse ? T - 1 - s : s;          // time index of this step
@@ -361,7 +379,8 @@ int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, lon
                                         s == 0 ? nullptr : dgh_shift + (long)tp * 3 * H, (long)T * 3 * H, dh_out, H, B, H);
         if (rc) return rc;
         if (s > 0) {   // dh_prev += dgh W_hh
-            rc = a2s_gemm_impl(st, B, H, 3 * H, 1.f, dgh, 3 * H, 1, w_hh, H, 1, 1.f, dh_out, H, nullptr, 0, 1, 0, 0, 0, 0, ws, ws_bytes);
+            if (fused) rc = a2s_skinny_gemm_acc_impl(st, dgh, 3 * H, ws, 3 * H, dh_out, H, B, H, 3 * H);
+            else rc = a2s_gemm_impl(st, B, H, 3 * H, 1.f, dgh, 3 * H, 1, w_hh, H, 1, 1.f, dh_out, H, nullptr, 0, 1, 0, 0, 0, 0, ws, ws_bytes);
             if (rc) return rc;
         }
         cur ^= 1;

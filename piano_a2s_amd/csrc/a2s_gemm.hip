@@ -215,6 +215,10 @@ int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
     return s < 1 ? 1 : (int)s;
 }
 
+// tuning aid (tools/gemm_sweep.py): force a tile configuration for M > 64; 0 = the heuristic below
+static int g_force_tile = 0;
+void a2s_gemm_debug_tile_impl(int cfg) { g_force_tile = cfg; }
+
 int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
                   const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
                   int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes) {
@@ -251,7 +255,15 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
     g.vecA = (akc ? (sAk == 1 && aligned(A, sAm, bsA)) : (sAm == 1 && aligned(A, sAk, bsA))) ? 1 : 0;
     g.vecB = (bkc ? (sBk == 1 && aligned(B, sBn, bsB)) : (sBn == 1 && aligned(B, sBk, bsB))) ? 1 : 0;
 
-    if (M <= 16) launch_cfg<16, 64, 1, 4>(g, akc, bkc, st);
+    if (g_force_tile && M > 64) {
+        switch (g_force_tile) {
+            case 1: launch_cfg<32, 64, 2, 2>(g, akc, bkc, st); break;
+            case 2: launch_cfg<64, 32, 4, 1>(g, akc, bkc, st); break;
+            case 3: launch_cfg<64, 64, 2, 2>(g, akc, bkc, st); break;
+            default: launch_cfg<128, 128, 2, 2>(g, akc, bkc, st); break;
+        }
+    }
+    else if (M <= 16) launch_cfg<16, 64, 1, 4>(g, akc, bkc, st);
     else if (M <= 32) launch_cfg<32, 64, 2, 2>(g, akc, bkc, st);
     else if (M <= 64) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);
     else if ((long)a2s_cdiv(M, 128) * a2s_cdiv(N, 128) * batch * splitk >= 192) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);

@@ -48,6 +48,126 @@ int a2s_gru_gates_fwd_impl(hipStream_t st, const float* gi, long ldgi, const flo
     return A2S_OK;
 }
 
+// ------------------------------------------------------------------------------------------- fused recurrent step
+// The encoder recurrences are 1201 dependent steps of a tiny product (B x H) x (H x 3H): as GEMM + split-K reduce + gate kernel each
+// step costs three launches and ~19 us whatever the batch.  Here one launch does the step: a workgroup owns 32 rows x 16 hidden
+// units (their r, z, n gate columns = 3 n-tiles); both MFMA operands are K-contiguous rows (h and W_hh), so every lane fetches its
+// fragments straight from L2 with 16-byte loads -- no LDS staging, one round trip -- the 4 waves split (row half) x (K half), the
+// K halves are summed through LDS and the gate math runs on the accumulators.  k order inside the dot product: lane group kk owns
+// the kk-th quarter of the wave's K range (any partition is valid as long as A and B agree).
+template <int NT>
+__device__ __forceinline__ void mfma_rows(const float* __restrict__ arow, const float* const (&brow)[NT], int per, f32x4 (&acc)[NT]) {
+    // arow / brow[g]: this lane's operand rows, already advanced to its K quarter of `per` (multiple of 4) consecutive k
+    for (int s0 = 0; s0 < per; s0 += 32) {
+        f32x4 a[8], b[NT][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = s0 + 4 * u < per;
+            a[u] = ok ? *reinterpret_cast<const f32x4*>(arow + s0 + 4 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NT; ++g)
+                b[g][u] = ok ? *reinterpret_cast<const f32x4*>(brow[g] + s0 + 4 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + 4 * u >= per) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < NT; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[g][u][j], acc[g], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gru_step_fwd_fused(const float* __restrict__ gi, long ldgi, const float* __restrict__ w_hh,
+                                                          const float* __restrict__ b_hh, const float* __restrict__ hprev,
+                                                          float* __restrict__ hout, float* __restrict__ hout2, long ldho2,
+                                                          float* __restrict__ save, int R, int H) {
+    __shared__ f32x4 part[2 * 3 * 64];
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4, mt = wave & 1, kh = wave >> 1;
+    const int KW = H / 2, per = KW / 4;
+    const int arow_i = min(row0 + mt * 16 + li, R - 1);
+    const float* arow = hprev + (long)arow_i * H + kh * KW + lk * per;
+    const float* brow[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) brow[g] = w_hh + ((long)g * H + j0 + li) * H + kh * KW + lk * per;
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows<3>(arow, brow, per, acc);
+    if (kh == 1) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) part[(mt * 3 + g) * 64 + lane] = acc[g];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    // accumulator layout: lane holds column n = li (hidden unit j0 + li), rows lk*4 + r of the m-tile
+    const int j = j0 + li;
+    const float br = b_hh[j], bz = b_hh[H + j], bn = b_hh[2 * H + j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + mt * 16 + lk * 4 + r;
+        if (row >= R) continue;
+        const float ghr = acc[0][r] + part[(mt * 3 + 0) * 64 + lane][r] + br;
+        const float ghz = acc[1][r] + part[(mt * 3 + 1) * 64 + lane][r] + bz;
+        const float ghn = acc[2][r] + part[(mt * 3 + 2) * 64 + lane][r] + bn;
+        const float* a = gi + (long)row * ldgi;
+        const float rg = fast_sigmoid(a[j] + ghr);
+        const float zg = fast_sigmoid(a[H + j] + ghz);
+        const float ng = fast_tanh(a[2 * H + j] + rg * ghn);
+        const float hp = hprev[(long)row * H + j];
+        const float hn = (1.f - zg) * ng + zg * hp;
+        hout[(long)row * H + j] = hn;
+        if (hout2) hout2[(long)row * ldho2 + j] = hn;
+        if (save) {
+            float* sv = save + (long)row * 4 * H;
+            sv[j] = rg; sv[H + j] = zg; sv[2 * H + j] = ng; sv[3 * H + j] = ghn;
+        }
+    }
+}
+
+// C[R x N] += A[R x K] Bt[N x K]^T for a skinny recurrent product (both operands K-contiguous rows): same tiling as above with one
+// n-tile per workgroup.  Used by the encoder BPTT: dh_prev += dgh W_hh with Bt = W_hh^T (H x 3H).
+__global__ __launch_bounds__(256) void skinny_gemm_acc(const float* __restrict__ A, long lda, const float* __restrict__ Bt, long ldb,
+                                                       float* __restrict__ Cm, long ldc, int R, int K) {
+    __shared__ f32x4 part[2 * 64];
+    const int n0 = blockIdx.x * 16, row0 = blockIdx.y * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4, mt = wave & 1, kh = wave >> 1;
+    const int KW = K / 2, per = KW / 4;
+    const int arow_i = min(row0 + mt * 16 + li, R - 1);
+    const float* arow = A + (long)arow_i * lda + kh * KW + lk * per;
+    const float* brow[1] = {Bt + (long)(n0 + li) * ldb + kh * KW + lk * per};
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    mfma_rows<1>(arow, brow, per, acc);
+    if (kh == 1) part[mt * 64 + lane] = acc[0];
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + mt * 16 + lk * 4 + r;
+        if (row < R) Cm[(long)row * ldc + n0 + li] += acc[0][r] + part[mt * 64 + lane][r];
+    }
+}
+
+int a2s_skinny_gemm_acc_impl(hipStream_t st, const float* A, long lda, const float* Bt, long ldb, float* Cm, long ldc, int R, int N, int K) {
+    A2S_REQUIRE(N % 16 == 0 && K % 32 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A | (uintptr_t)Bt) % 16 == 0,
+                "skinny_gemm_acc: N %% 16, K %% 32 and 16-byte aligned K-contiguous operands required");
+    hipLaunchKernelGGL(skinny_gemm_acc, dim3(N / 16, a2s_cdiv(R, 32)), dim3(256), 0, st, A, lda, Bt, ldb, Cm, ldc, R, K);
+    A2S_CHECK_LAUNCH("skinny_gemm_acc");
+    return A2S_OK;
+}
+
+static int g_gru_fused = -1;                                 // A2S_GRU_FUSED=0 / a2s_debug_set("gru_fused", 0): the three-launch step (A/B measurements)
+void a2s_gru_step_fused_set(int v) { g_gru_fused = v ? 1 : 0; }
+bool a2s_gru_step_fused_enabled(void) {
+    if (g_gru_fused < 0) { const char* e = getenv("A2S_GRU_FUSED"); g_gru_fused = (e && e[0] == '0') ? 0 : 1; }
+    return g_gru_fused != 0;
+}
+static bool gru_step_fusable(const float* w_hh, int H) { return a2s_gru_step_fused_enabled() && H % 32 == 0 && ((uintptr_t)w_hh % 16 == 0); }
+
 // One direction of one encoder GRU layer over all T steps (h0 = 0).
 //   gi_all : (B, T, 3H) = x W_ih^T + b_ih for this direction (row stride ld_gi between time steps of a clip)
 //   out    : (B, T, ldo) -- h_t is written at column offset `col0` (fwd dir 0, reverse dir H)
@@ -63,6 +183,12 @@ int a2s_gru_seq_fwd_impl(hipStream_t st, const float* gi_all, long gi_bstride, l
         const int t = reverse ? T - 1 - s : s;
         const float* hp = hbuf + (long)(s & 1) * B * H;
         float* hq = (s == T - 1) ? hn : hbuf + (long)((s + 1) & 1) * B * H;
+        if (gru_step_fusable(w_hh, H)) {        // one launch per step (see gru_step_fwd_fused)
+            hipLaunchKernelGGL(gru_step_fwd_fused, dim3(H / 16, a2s_cdiv(B, 32)), dim3(256), 0, st, gi_all + (long)t * gi_tstride, gi_bstride, w_hh, b_hh,
+                               hp, hq, out + (long)t * out_tstride, out_bstride, save ? save + (long)t * B * 4 * H : nullptr, B, H);
+            A2S_CHECK_LAUNCH("gru_step_fwd_fused");
+            continue;
+        }
         // gh = h W_hh^T + b_hh   (M=B, N=3H, K=H; W_hh is (3H, H): B(k,n) = W[n*H + k])
         int rc = a2s_gemm_impl(st, B, 3 * H, H, 1.f, hp, H, 1, w_hh, 1, H, 0.f, gh, 3 * H, b_hh, 0, 1, 0, 0, 0, 0, ws, ws_bytes);
         if (rc) return rc;

@@ -158,11 +158,10 @@ def backward(eng, S, grad_outputs):
     enc = sv["enc_out"]
     dev = enc.device
     names = [k for k in S if not is_buffer(k)]
-    flat = torch.zeros(sum(S[k].numel() for k in names), dtype=torch.float32, device=dev)
-    G, off = {}, 0
-    for k in names:
-        G[k] = flat[off:off + S[k].numel()].view(S[k].shape)
-        off += S[k].numel()
+    from .spec import flat_layout
+    offs, total = flat_layout([S[k].numel() for k in names])          # same layout as models.ScoreTranscription.flatten_()
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    G = {k: flat[off:off + S[k].numel()].view(S[k].shape) for k, off in zip(names, offs)}
     dts, dkey, dup, dlo = [g.contiguous() for g in grad_outputs]
     ts_out, key_out, up_out, lo_out = sv["outs"]
     dEnc = torch.zeros((B, T, H2), dtype=torch.float32, device=dev)

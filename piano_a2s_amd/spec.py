@@ -129,3 +129,14 @@ def split_state(state):
     P = OrderedDict((k, v) for k, v in state.items() if not is_buffer(k))
     B = OrderedDict((k, v) for k, v in state.items() if is_buffer(k))
     return P, B
+
+
+def flat_layout(numels, align=4):
+    """Offsets (in floats) of tensors packed into one flat buffer with every tensor starting on a 16-byte boundary (the HIP kernels
+    fetch weight rows with 16-byte loads); returns (offsets, total).  The padding floats stay zero: parameters, gradients and
+    optimizer state all use this layout, so the fused clip + Adadelta sees zeros there and leaves them zero."""
+    offs, off = [], 0
+    for n in numels:
+        offs.append(off)
+        off += (n + align - 1) // align * align
+    return offs, off

@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--pairs", type=int, default=6)
-    ap.add_argument("--attr", default="skip_finished_rows")
+    ap.add_argument("--attr", default="skip_finished_rows", help="TrainStep attribute, or lib:<key> for an a2s_debug_set switch")
     a = ap.parse_args()
     import models
     from piano_a2s_amd import spec, synthetic, train
@@ -26,19 +26,29 @@ def main():
     m = models.ScoreTranscription(**cfg).to(dev)
     m.train()
     step = train.TrainStep(m)
+    if a.attr.startswith("lib:"):
+        from piano_a2s_amd import hip
+        key = a.attr[4:].encode()
+
+        class _Knob:
+            def __setattr__(self, name, v):
+                hip.check(hip.lib().a2s_debug_set(key, int(v)), "a2s_debug_set")
+        target = _Knob()
+    else:
+        target = step
     b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=0.0)
     b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
     for v in (False, True):
-        setattr(step, a.attr, v)
+        setattr(target, a.attr, v)
         step(b, 0.7)
     torch.cuda.synchronize()
     tot = {False: [], True: []}
-    for _ in range(a.pairs):
+    for k in range(a.pairs):
         for v in (False, True):
-            setattr(step, a.attr, v)
+            setattr(target, a.attr, v)
             torch.cuda.synchronize()
             t0 = time.time()
-            step(b, 0.7)
+            step(b, 0.7, rng=random.Random(100 + k))      # both members of a pair see the same coin flips (same fused segments)
             torch.cuda.synchronize()
             tot[v].append(time.time() - t0)
     ms = torch.cuda.memory_stats()
