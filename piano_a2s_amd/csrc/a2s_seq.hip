@@ -50,31 +50,34 @@ int a2s_gru_gates_fwd_impl(hipStream_t st, const float* gi, long ldgi, const flo
 
 // ------------------------------------------------------------------------------------------- fused recurrent step
 // The encoder recurrences are 1201 dependent steps of a tiny product (B x H) x (H x 3H): as GEMM + split-K reduce + gate kernel each
-// step costs three launches and ~19 us whatever the batch.  Here one launch does the step: a workgroup owns 32 rows x 16 hidden
+// step costs three launches and ~19 us whatever the batch.  Here one launch does the step: a workgroup owns 16 rows x 16 hidden
 // units (their r, z, n gate columns = 3 n-tiles); both MFMA operands are K-contiguous rows (h and W_hh), so every lane fetches its
-// fragments straight from L2 with 16-byte loads -- no LDS staging, one round trip -- the 4 waves split (row half) x (K half), the
-// K halves are summed through LDS and the gate math runs on the accumulators.  k order inside the dot product: lane group kk owns
-// the kk-th quarter of the wave's K range (any partition is valid as long as A and B agree).
-template <int NT>
-__device__ __forceinline__ void mfma_rows(const float* __restrict__ arow, const float* const (&brow)[NT], int per, f32x4 (&acc)[NT]) {
-    // arow / brow[g]: this lane's operand rows, already advanced to its K quarter of `per` (multiple of 4) consecutive k
-    for (int s0 = 0; s0 < per; s0 += 32) {
-        f32x4 a[8], b[NT][8];
+// fragments straight from L2 with 16-byte loads -- no LDS staging, one round trip -- the 4 waves take the 16-wide k-steps round
+// robin, their partial tiles are summed through LDS and the gate math runs on the accumulators (its operands are fetched before the
+// product so that their HBM latency hides behind it).  k order inside a 16-wide step: lane group lk supplies k = 4*lk + j for the
+// j-th MFMA of the step (any partition is valid as long as A and B agree).
+template <int NT, int CH>
+__device__ __forceinline__ void mfma_rows(const float* __restrict__ arow, const float* const (&brow)[NT], int ksteps, int wave, int lk,
+                                          f32x4 (&acc)[NT]) {
+    // arow / brow[g]: this lane's operand rows; k-step u covers k in [16u, 16u+16), this lane reads 4 floats at 16u + 4*lk
+    for (int u0 = wave; u0 < ksteps; u0 += 4 * CH) {
+        f32x4 a[CH], b[NT][CH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = s0 + 4 * u < per;
-            a[u] = ok ? *reinterpret_cast<const f32x4*>(arow + s0 + 4 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < CH; ++c) {
+            const int u = u0 + 4 * c;
+            const bool ok = u < ksteps;
+            a[c] = ok ? *reinterpret_cast<const f32x4*>(arow + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < NT; ++g)
-                b[g][u] = ok ? *reinterpret_cast<const f32x4*>(brow[g] + s0 + 4 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                b[g][c] = ok ? *reinterpret_cast<const f32x4*>(brow[g] + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (s0 + 4 * u >= per) break;
+        for (int c = 0; c < CH; ++c) {
+            if (u0 + 4 * c >= ksteps) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int g = 0; g < NT; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[g][u][j], acc[g], 0, 0, 0);
+                for (int g = 0; g < NT; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[g][c][j], acc[g], 0, 0, 0);
         }
     }
 }
@@ -83,42 +86,54 @@ __global__ __launch_bounds__(256) void gru_step_fwd_fused(const float* __restric
                                                           const float* __restrict__ b_hh, const float* __restrict__ hprev,
                                                           float* __restrict__ hout, float* __restrict__ hout2, long ldho2,
                                                           float* __restrict__ save, int R, int H) {
-    __shared__ f32x4 part[2 * 3 * 64];
-    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 32;
+    __shared__ f32x4 part[3 * 3 * 64];
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4, mt = wave & 1, kh = wave >> 1;
-    const int KW = H / 2, per = KW / 4;
-    const int arow_i = min(row0 + mt * 16 + li, R - 1);
-    const float* arow = hprev + (long)arow_i * H + kh * KW + lk * per;
+    const int li = lane & 15, lk = lane >> 4;
+    // accumulator layout: lane holds column n = li (hidden unit j0 + li), rows lk*4 + r of the tile
+    const int j = j0 + li;
+    float gir[4], giz[4], gin[4], hp[4], br = 0.f, bz = 0.f, bn = 0.f;
+    if (wave == 0) {                       // gate operands of the epilogue: in flight while the product runs
+        br = b_hh[j]; bz = b_hh[H + j]; bn = b_hh[2 * H + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(row0 + lk * 4 + r, R - 1);
+            const float* a = gi + (long)row * ldgi;
+            gir[r] = a[j]; giz[r] = a[H + j]; gin[r] = a[2 * H + j];
+            hp[r] = hprev[(long)row * H + j];
+        }
+    }
+    const float* arow = hprev + (long)min(row0 + li, R - 1) * H;
     const float* brow[3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) brow[g] = w_hh + ((long)g * H + j0 + li) * H + kh * KW + lk * per;
+    for (int g = 0; g < 3; ++g) brow[g] = w_hh + ((long)g * H + j0 + li) * H;
     f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows<3>(arow, brow, per, acc);
-    if (kh == 1) {
+    mfma_rows<3, 4>(arow, brow, H / 16, wave, lk, acc);
+    if (wave > 0) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) part[(mt * 3 + g) * 64 + lane] = acc[g];
+        for (int g = 0; g < 3; ++g) part[((wave - 1) * 3 + g) * 64 + lane] = acc[g];
     }
     __syncthreads();
-    if (kh == 1) return;
-    // accumulator layout: lane holds column n = li (hidden unit j0 + li), rows lk*4 + r of the m-tile
-    const int j = j0 + li;
-    const float br = b_hh[j], bz = b_hh[H + j], bn = b_hh[2 * H + j];
+    if (wave > 0) return;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const f32x4 o = part[(w * 3 + g) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][r] += o[r];
+        }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = row0 + mt * 16 + lk * 4 + r;
+        const int row = row0 + lk * 4 + r;
         if (row >= R) continue;
-        const float ghr = acc[0][r] + part[(mt * 3 + 0) * 64 + lane][r] + br;
-        const float ghz = acc[1][r] + part[(mt * 3 + 1) * 64 + lane][r] + bz;
-        const float ghn = acc[2][r] + part[(mt * 3 + 2) * 64 + lane][r] + bn;
-        const float* a = gi + (long)row * ldgi;
-        const float rg = fast_sigmoid(a[j] + ghr);
-        const float zg = fast_sigmoid(a[H + j] + ghz);
-        const float ng = fast_tanh(a[2 * H + j] + rg * ghn);
-        const float hp = hprev[(long)row * H + j];
-        const float hn = (1.f - zg) * ng + zg * hp;
+        const float ghn = acc[2][r] + bn;
+        const float rg = fast_sigmoid(gir[r] + acc[0][r] + br);
+        const float zg = fast_sigmoid(giz[r] + acc[1][r] + bz);
+        const float ng = fast_tanh(gin[r] + rg * ghn);
+        const float hn = (1.f - zg) * ng + zg * hp[r];
         hout[(long)row * H + j] = hn;
         if (hout2) hout2[(long)row * ldho2 + j] = hn;
         if (save) {
@@ -128,34 +143,37 @@ __global__ __launch_bounds__(256) void gru_step_fwd_fused(const float* __restric
     }
 }
 
-// C[R x N] += A[R x K] Bt[N x K]^T for a skinny recurrent product (both operands K-contiguous rows): same tiling as above with one
-// n-tile per workgroup.  Used by the encoder BPTT: dh_prev += dgh W_hh with Bt = W_hh^T (H x 3H).
+// C[R x N] += A[R x K] Bt[N x K]^T for a skinny recurrent product (both operands K-contiguous rows): same scheme with one n-tile
+// per workgroup.  Used by the encoder BPTT: dh_prev += dgh W_hh with Bt = W_hh^T (H x 3H).
 __global__ __launch_bounds__(256) void skinny_gemm_acc(const float* __restrict__ A, long lda, const float* __restrict__ Bt, long ldb,
                                                        float* __restrict__ Cm, long ldc, int R, int K) {
-    __shared__ f32x4 part[2 * 64];
-    const int n0 = blockIdx.x * 16, row0 = blockIdx.y * 32;
+    __shared__ f32x4 part[3 * 64];
+    const int n0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4, mt = wave & 1, kh = wave >> 1;
-    const int KW = K / 2, per = KW / 4;
-    const int arow_i = min(row0 + mt * 16 + li, R - 1);
-    const float* arow = A + (long)arow_i * lda + kh * KW + lk * per;
-    const float* brow[1] = {Bt + (long)(n0 + li) * ldb + kh * KW + lk * per};
+    const int li = lane & 15, lk = lane >> 4;
+    float c0[4];
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c0[r] = Cm[(long)min(row0 + lk * 4 + r, R - 1) * ldc + n0 + li];
+    }
+    const float* arow = A + (long)min(row0 + li, R - 1) * lda;
+    const float* brow[1] = {Bt + (long)(n0 + li) * ldb};
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows<1>(arow, brow, per, acc);
-    if (kh == 1) part[mt * 64 + lane] = acc[0];
+    mfma_rows<1, 12>(arow, brow, K / 16, wave, lk, acc);
+    if (wave > 0) part[(wave - 1) * 64 + lane] = acc[0];
     __syncthreads();
-    if (kh == 1) return;
+    if (wave > 0) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = row0 + mt * 16 + lk * 4 + r;
-        if (row < R) Cm[(long)row * ldc + n0 + li] += acc[0][r] + part[mt * 64 + lane][r];
+        const int row = row0 + lk * 4 + r;
+        if (row < R) Cm[(long)row * ldc + n0 + li] = c0[r] + acc[0][r] + part[lane][r] + part[64 + lane][r] + part[128 + lane][r];
     }
 }
 
 int a2s_skinny_gemm_acc_impl(hipStream_t st, const float* A, long lda, const float* Bt, long ldb, float* Cm, long ldc, int R, int N, int K) {
-    A2S_REQUIRE(N % 16 == 0 && K % 32 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A | (uintptr_t)Bt) % 16 == 0,
-                "skinny_gemm_acc: N %% 16, K %% 32 and 16-byte aligned K-contiguous operands required");
-    hipLaunchKernelGGL(skinny_gemm_acc, dim3(N / 16, a2s_cdiv(R, 32)), dim3(256), 0, st, A, lda, Bt, ldb, Cm, ldc, R, K);
+    A2S_REQUIRE(N % 16 == 0 && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A | (uintptr_t)Bt) % 16 == 0,
+                "skinny_gemm_acc: N %% 16, K %% 16 and 16-byte aligned K-contiguous operands required");
+    hipLaunchKernelGGL(skinny_gemm_acc, dim3(N / 16, a2s_cdiv(R, 16)), dim3(256), 0, st, A, lda, Bt, ldb, Cm, ldc, R, K);
     A2S_CHECK_LAUNCH("skinny_gemm_acc");
     return A2S_OK;
 }
@@ -166,7 +184,7 @@ bool a2s_gru_step_fused_enabled(void) {
     if (g_gru_fused < 0) { const char* e = getenv("A2S_GRU_FUSED"); g_gru_fused = (e && e[0] == '0') ? 0 : 1; }
     return g_gru_fused != 0;
 }
-static bool gru_step_fusable(const float* w_hh, int H) { return a2s_gru_step_fused_enabled() && H % 32 == 0 && ((uintptr_t)w_hh % 16 == 0); }
+static bool gru_step_fusable(const float* w_hh, int H) { return a2s_gru_step_fused_enabled() && H % 16 == 0 && ((uintptr_t)w_hh % 16 == 0); }
 
 // One direction of one encoder GRU layer over all T steps (h0 = 0).
 //   gi_all : (B, T, 3H) = x W_ih^T + b_ih for this direction (row stride ld_gi between time steps of a clip)
@@ -184,7 +202,7 @@ int a2s_gru_seq_fwd_impl(hipStream_t st, const float* gi_all, long gi_bstride, l
         const float* hp = hbuf + (long)(s & 1) * B * H;
         float* hq = (s == T - 1) ? hn : hbuf + (long)((s + 1) & 1) * B * H;
         if (gru_step_fusable(w_hh, H)) {        // one launch per step (see gru_step_fwd_fused)
-            hipLaunchKernelGGL(gru_step_fwd_fused, dim3(H / 16, a2s_cdiv(B, 32)), dim3(256), 0, st, gi_all + (long)t * gi_tstride, gi_bstride, w_hh, b_hh,
+            hipLaunchKernelGGL(gru_step_fwd_fused, dim3(H / 16, a2s_cdiv(B, 16)), dim3(256), 0, st, gi_all + (long)t * gi_tstride, gi_bstride, w_hh, b_hh,
                                hp, hq, out + (long)t * out_tstride, out_bstride, save ? save + (long)t * B * 4 * H : nullptr, B, H);
             A2S_CHECK_LAUNCH("gru_step_fwd_fused");
             continue;
