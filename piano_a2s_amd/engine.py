@@ -62,6 +62,49 @@ def encoder_streams(device):
     return side_streams(device)
 
 
+_ISSUE_POOL = None
+
+
+def fork_on_streams(device, streams, fns):
+    """Run fns[i]() with streams[i] current, each in its own host thread, forked from the caller's current stream.  The step loops
+    these functions enqueue (encoder directions, the two staves) are bound by the HOST's launch rate (~6 us per kernel, measured:
+    two loops issued from one thread take exactly twice one loop), and ctypes drops the GIL inside liba2s_hip.so, so two threads
+    issue two streams at the same time.  Returns a join() callable: it returns [fns[i]() results] and makes the caller's current
+    stream wait for both.  A2S_ISSUE_THREADS=0: issue inline from the calling thread."""
+    global _ISSUE_POOL
+    fork = torch.cuda.Event()
+    fork.record()
+    dev_index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+
+    def task(st, fn):
+        torch.cuda.set_device(dev_index)
+        if st == torch.cuda.current_stream():
+            return fn(), None
+        st.wait_event(fork)                    # everything the loop reads was enqueued before the fork
+        with torch.cuda.stream(st):
+            r = fn()
+        done = torch.cuda.Event()
+        done.record(st)
+        return r, done
+
+    if _os.environ.get("A2S_ISSUE_THREADS", "1") == "0":
+        results = [task(st, fn) for st, fn in zip(streams, fns)]
+        futures = None
+    else:
+        if _ISSUE_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _ISSUE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="a2s-issue")
+        futures = [_ISSUE_POOL.submit(task, st, fn) for st, fn in zip(streams, fns)]
+
+    def join():
+        res = results if futures is None else [f.result() for f in futures]
+        for _, done in res:
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)
+        return [r for r, _ in res]
+    return join
+
+
 def _dist_world():
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0     # 0 = no process group
@@ -162,29 +205,23 @@ class Engine:
             lsave = {"in": inp, "dirs": []}
             gis = [hip.linear(inp, S[f"encoder.gru.weight_ih_{sfx}"], S[f"encoder.gru.bias_ih_{sfx}"])      # (B*T, 3H) per direction
                    for sfx in (f"l{layer}", f"l{layer}_reverse")]
-            fork = torch.cuda.Event()
-            fork.record()
-            joins = []
-            for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
-                gi = gis[d]
-                streams[d].wait_event(fork)
-                with torch.cuda.stream(streams[d]):
-                    hbuf = self._empty(2, B, H, dev=dev)
-                    gh = self._empty(B, 3 * H, dev=dev)
-                    hn = self._empty(B, H, dev=dev)
-                    gates = self._empty(T, B, 4 * H, dev=dev) if training else None
-                    hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H),
-                                                hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(S[f"encoder.gru.bias_hh_{sfx}"]),
-                                                C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
-                                                hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d, hip._p(gws[d]),
-                                                C.c_size_t(gws[d].numel() * 4)), "a2s_gru_seq_fwd")
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    joins.append(ev)
-                finals.append(hn)
-                lsave["dirs"].append({"gi": gi, "gates": gates, "hn": hn, "scratch": (hbuf, gh)})
-            for ev in joins:
-                torch.cuda.current_stream().wait_event(ev)
+            def direction(d, sfx, gi):
+                hbuf = self._empty(2, B, H, dev=dev)
+                gh = self._empty(B, 3 * H, dev=dev)
+                hn = self._empty(B, H, dev=dev)
+                gates = self._empty(T, B, 4 * H, dev=dev) if training else None
+                hip.check(L.a2s_gru_seq_fwd(hip.stream(), hip._p(gi), C.c_long(T * 3 * H), C.c_long(3 * H),
+                                            hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(S[f"encoder.gru.bias_hh_{sfx}"]),
+                                            C.c_void_p(out.data_ptr() + 4 * d * H), C.c_long(T * 2 * H), C.c_long(2 * H),
+                                            hip._p(hbuf), hip._p(gh), hip._p(gates), hip._p(hn), B, T, H, d, hip._p(gws[d]),
+                                            C.c_size_t(gws[d].numel() * 4)), "a2s_gru_seq_fwd")
+                return {"gi": gi, "gates": gates, "hn": hn, "scratch": (hbuf, gh)}
+
+            join = fork_on_streams(dev, streams, [lambda d=d, sfx=sfx: direction(d, sfx, gis[d])
+                                                  for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse"))])
+            for rec in join():
+                finals.append(rec["hn"])
+                lsave["dirs"].append(rec)
             lsave["out"] = out
             saved["layers"].append(lsave)
             inp = out.view(B * T, 2 * H)
@@ -225,7 +262,7 @@ class Engine:
                                i64=ids_are_i64, hsave=hsave))
 
     def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None,
-                      active=None):
+                      active=None, drop=None):
         """One NoteDecoder.decode_notes call over B rows.  probs_bar: view (B, max_steps, V) of the output tensor (strided).
         tf_flags: per step, bit g = teacher-force the rows of group g.
         active: optional dict(until: (B,) int32, order / rank: (n_clips,) int32 device tensors; n_active: host int array per step;
@@ -252,8 +289,7 @@ class Engine:
         lengths = torch.full((B,), max_steps, dtype=torch.long, device=dev)
         n_done = torch.zeros(1, dtype=torch.int32, device=dev)
         steps_exec = torch.zeros(1, dtype=torch.int32, device=dev)
-        drop = None
-        if training and drop_p > 0:
+        if drop is None and training and drop_p > 0:
             drop = (torch.rand((n + 1, B, E), device=dev) >= drop_p).to(torch.uint8)
         # SOS token embedding -> x[0][:, :E]
         hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S[prefix + ".embedding.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0), SOS,
@@ -475,10 +511,7 @@ class Engine:
             R = nb * B
             # (2) note decoders of the segment (models.py:261-275)
             staff = {}
-            joins = []
-            if concurrent:
-                fork = torch.cuda.Event()
-                fork.record()
+            calls = []
             for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out, 0), ("lo", "decoder.lower_decoder", Lo, lo_out, 1)):
                 active = None
                 if plan is not None:
@@ -494,35 +527,38 @@ class Engine:
                         active = active_rows(gi_idx, seg, steps)
                 else:
                     steps, flags, gt_bar, probs = maxs, None, None, out_t[:, seg[0]]
-                args = (S, prefix, keys[prefix], enc, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
-                        attn_ws[gi_idx], gemm_ws[gi_idx], active)
-                if concurrent:
-                    st = streams[gi_idx]
-                    st.wait_event(fork)                    # everything the decoder reads (enc, keys, hnew, zeroed outputs) is ready
-                    with torch.cuda.stream(st):
-                        ids, lengths, sv = self._decode_staff(*args)
-                    done = torch.cuda.Event()
-                    done.record(st)
-                    joins.append(done)
-                elif gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH):
-                    # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
-                    st = side_streams(dev)[0]
+                # the dropout masks are drawn here, on the caller's thread and stream: one deterministic draw order per seed
+                drop = (torch.rand((steps + 1, R, E), device=dev) >= 0.1).to(torch.uint8) if drop_on else None
+                calls.append((name, (S, prefix, keys[prefix], enc, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
+                                     attn_ws[gi_idx], gemm_ws[gi_idx], active, drop)))
+            if concurrent:
+                join = fork_on_streams(dev, streams, [lambda args=args: self._decode_staff(*args) for _, args in calls])
+            elif gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH):
+                # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
+                st = side_streams(dev)[0]
+                res = []
+                for _, args in calls:
                     st.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(st):
-                        ids, lengths, sv = self._decode_staff(*args)
+                        res.append(self._decode_staff(*args))
                     torch.cuda.current_stream().wait_stream(st)
-                else:
-                    ids, lengths, sv = self._decode_staff(*args)
-                if gt_cpu is None:
-                    for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference
+                    for _ in range(res[-1][2]["steps"]):       # the reference draws once per executed step, also in inference
                         rng.random()
-                sv["groups"] = nb
-                staff[name] = (ids, lengths, sv)
+                join = lambda res=res: res
+            else:
+                res = []
+                for _, args in calls:
+                    res.append(self._decode_staff(*args))
+                    if gt_cpu is None:
+                        for _ in range(res[-1][2]["steps"]):
+                            rng.random()
+                join = lambda res=res: res
             # (3) heads do not depend on the note decoders: they overlap with them on the main stream
             for bar in seg:
                 bar_saved[bar]["heads"] = bar_heads(bar, bar_saved[bar]["headin"])
-            for ev in joins:                               # the next token / next bar may read what the staves produced
-                torch.cuda.current_stream().wait_event(ev)
+            for (name, _), (ids, lengths, sv) in zip(calls, join()):     # the next token / next bar may read what the staves produced
+                sv["groups"] = nb
+                staff[name] = (ids, lengths, sv)
             seg_saved.append(dict(bars=seg, staff=staff))
             for bar in seg:
                 bar_saved[bar]["staff"] = staff            # (shared by the bars of a fused segment)

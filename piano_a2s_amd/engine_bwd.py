@@ -169,7 +169,7 @@ def backward(eng, S, grad_outputs):
     keep_alive = []
     # the two note decoders of a bar back-propagate concurrently on two side streams (see engine.side_streams); each accumulates its
     # encoder-output gradient in its own buffer (summed once at the end), everything else they write is per-staff already
-    from .engine import side_streams
+    from .engine import fork_on_streams, side_streams
     concurrent = bool(sv.get("concurrent"))
     streams = side_streams(dev) if concurrent else None
     dEnc_staff = [torch.zeros_like(dEnc), torch.zeros_like(dEnc)] if concurrent else [dEnc, dEnc]
@@ -181,29 +181,18 @@ def backward(eng, S, grad_outputs):
         """Both note decoders of a segment (bars decoded in one call each): they only need the loss gradients."""
         seg = sv["segments"][si_seg]
         bar0, nb = seg["bars"][0], len(seg["bars"])
-        dh0s, joins = [], []
-        if concurrent:
-            fork = torch.cuda.Event()
-            fork.record()
+        calls = []
         for si, (name, prefix, dout, out_t) in enumerate((("up", "decoder.upper_decoder", dup, up_out), ("lo", "decoder.lower_decoder", dlo, lo_out))):
             if bar_major:
                 maxs = out_t.shape[2]
                 dpr, pr = dout[bar0:bar0 + nb].view(nb * B, maxs, -1), out_t[bar0:bar0 + nb].view(nb * B, maxs, -1)
             else:
                 dpr, pr = dout[:, bar0], out_t[:, bar0]
-            args = (eng, S, G, seg["staff"][name][2], sv["keys"][prefix], enc, dpr, pr, dK[prefix], dEnc_staff[si], B, T)
-            if concurrent:
-                st = streams[si]
-                st.wait_event(fork)
-                with torch.cuda.stream(st):
-                    dh0s.append(_note_decoder_bwd(*args))
-                done = torch.cuda.Event()
-                done.record(st)
-                joins.append(done)
-            else:
-                dh0s.append(_note_decoder_bwd(*args))
-        for ev in joins:
-            torch.cuda.current_stream().wait_event(ev)
+            calls.append((eng, S, G, seg["staff"][name][2], sv["keys"][prefix], enc, dpr, pr, dK[prefix], dEnc_staff[si], B, T))
+        if concurrent:      # one host thread per staff (engine.fork_on_streams)
+            dh0s = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])()
+        else:
+            dh0s = [_note_decoder_bwd(*args) for args in calls]
         seg_dh0[si_seg] = dh0s
 
     d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
@@ -316,27 +305,20 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
         I = inp.shape[1]
         out = ls["out"]
         dX = torch.empty((B * T, I), device=dev)
-        from .engine import encoder_streams
-        streams = encoder_streams(dev)                    # the two directions' BPTT chains are independent: one stream each
-        fork = torch.cuda.Event()
-        fork.record()
-        res, joins = [], []
-        for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
-            streams[d].wait_event(fork)
-            with torch.cuda.stream(streams[d]):
-                dgi = torch.empty((B, T, 3 * H), device=dev)
-                dghs = torch.empty((B, T, 3 * H), device=dev)
-                dgh_first, dhbuf, dgh_tmp = torch.empty((B, 3 * H), device=dev), torch.empty((2, B, H), device=dev), torch.empty((B, 3 * H), device=dev)
-                hip.check(L.a2s_gru_seq_bwd(hip.stream(), _ptr(dout, d * H), C.c_long(T * 2 * H), C.c_long(2 * H), _ptr(out, d * H), C.c_long(T * 2 * H),
-                                            C.c_long(2 * H), hip._p(ls["dirs"][d]["gates"]), hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(dhn[2 * layer + d]),
-                                            hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf), hip._p(dgh_tmp), B, T, H, d, hip._p(gws[d]),
-                                            C.c_size_t(gws[d].numel() * 4)), "a2s_gru_seq_bwd")
-                ev = torch.cuda.Event()
-                ev.record()
-                joins.append(ev)
-            res.append((dgi, dghs, dgh_first, dhbuf, dgh_tmp))
-        for ev in joins:
-            torch.cuda.current_stream().wait_event(ev)
+        from .engine import encoder_streams, fork_on_streams
+        streams = encoder_streams(dev)                    # the two directions' BPTT chains are independent: one stream (and host thread) each
+
+        def direction(d, sfx):
+            dgi = torch.empty((B, T, 3 * H), device=dev)
+            dghs = torch.empty((B, T, 3 * H), device=dev)
+            dgh_first, dhbuf, dgh_tmp = torch.empty((B, 3 * H), device=dev), torch.empty((2, B, H), device=dev), torch.empty((B, 3 * H), device=dev)
+            hip.check(L.a2s_gru_seq_bwd(hip.stream(), _ptr(dout, d * H), C.c_long(T * 2 * H), C.c_long(2 * H), _ptr(out, d * H), C.c_long(T * 2 * H),
+                                        C.c_long(2 * H), hip._p(ls["dirs"][d]["gates"]), hip._p(S[f"encoder.gru.weight_hh_{sfx}"]), hip._p(dhn[2 * layer + d]),
+                                        hip._p(dgi), hip._p(dghs), hip._p(dgh_first), hip._p(dhbuf), hip._p(dgh_tmp), B, T, H, d, hip._p(gws[d]),
+                                        C.c_size_t(gws[d].numel() * 4)), "a2s_gru_seq_bwd")
+            return (dgi, dghs, dgh_first, dhbuf, dgh_tmp)
+
+        res = fork_on_streams(dev, streams, [lambda d=d, sfx=sfx: direction(d, sfx) for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse"))])()
         for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):      # deferred weight / input gradients (main stream, ordered)
             dgi, dghs, dgh_first = res[d][:3]
             dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)

@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--pairs", type=int, default=6)
-    ap.add_argument("--attr", default="skip_finished_rows", help="TrainStep attribute, or lib:<key> for an a2s_debug_set switch")
+    ap.add_argument("--attr", default="skip_finished_rows", help="TrainStep attribute, lib:<key> for an a2s_debug_set switch, or env:<NAME> for an environment switch read per step")
     a = ap.parse_args()
     import models
     from piano_a2s_amd import spec, synthetic, train
@@ -34,6 +34,11 @@ def main():
             def __setattr__(self, name, v):
                 hip.check(hip.lib().a2s_debug_set(key, int(v)), "a2s_debug_set")
         target = _Knob()
+    elif a.attr.startswith("env:"):
+        class _Env:
+            def __setattr__(self, name, v):
+                os.environ[name[4:]] = "1" if v else "0"
+        target = _Env()
     else:
         target = step
     b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=0.0)
