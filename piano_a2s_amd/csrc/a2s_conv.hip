@@ -57,6 +57,18 @@ __global__ void conv_pack_weights(const float* __restrict__ w, float* __restrict
     wp[e] = v;
 }
 
+// ---- v3 (round 1, after measuring that a workgroup spent ~2/3 of a chunk's wall time staging: every one of its ~17 global loads per
+// thread was followed by its own LDS store, i.e. 17 serialised L2 round trips per chunk):
+//   * a workgroup walks C3_TPW consecutive row tiles; the (tile, chunk) pairs form one pipeline of stages;
+//   * the global loads of stage q+1 (input tile, weight slice if it changes) are issued into registers BEFORE the multiply of stage q
+//     and committed to LDS after it -- one round trip per stage, hidden behind ~540 MFMAs per wave;
+//   * with one input chunk (Cin = 20) the packed weights are staged once per workgroup; with two, consecutive tiles visit the chunks
+//     in serpentine order (0,1 | 1,0 | 0,1 ...) so the weight slice changes every other stage only;
+//   * batch-statistics partials are accumulated over the workgroup's tiles and written once.
+#define C3_TPW 8
+#define C3_WIT ((C2_WCHUNK / 4 + 255) / 256)                                  // float4 weight loads per thread and stage (9)
+#define C3_XIT ((CV_CK * (CV_TR + 2) * (C2_FT / 4) + 255) / 256)              // float4 input loads per thread and stage (8)
+
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a, const float* __restrict__ wpack) {
     constexpr int NT = (COUT + 15) / 16;               // n-tiles: 2 (Cout 20) or 3 (Cout 40)
@@ -66,62 +78,114 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a, const float* __r
 
     const int tilesF = (a.F + C2_FT - 1) / C2_FT;
     const int tilesT = (a.T + CV_TR - 1) / CV_TR;
+    const int groupsT = (tilesT + C3_TPW - 1) / C3_TPW;
     int bid = blockIdx.x;
     const int ft = bid % tilesF; bid /= tilesF;
-    const int tt = bid % tilesT; const int b = bid / tilesT;
-    const int t0 = tt * CV_TR, f0 = ft * C2_FT;
+    const int tg = bid % groupsT; const int b = bid / groupsT;
+    const int f0 = ft * C2_FT;
+    const int tile0 = tg * C3_TPW, ntile = min(C3_TPW, tilesT - tile0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const bool vec_ok = (a.F % 4 == 0) && (((uintptr_t)a.x & 15) == 0);
+    const int nchunks = a.Cin / CV_CK;
+    const int nstage = ntile * nchunks;
 
     f32x4 acc[4][NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float st_s[NT], st_s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { st_s[j] = 0.f; st_s2[j] = 0.f; }
 
-    const int nchunks = a.Cin / CV_CK;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * CV_CK;
-        __syncthreads();      // previous chunk fully consumed
-        // ---- weights: straight copy of the pre-packed slice
-        const f32x4* wsrc4 = reinterpret_cast<const f32x4*>(wpack + (long)ch * C2_WCHUNK);
-        for (int e = tid; e < C2_WCHUNK / 4; e += 256) reinterpret_cast<f32x4*>(lw)[e] = wsrc4[e];
-        // ---- input interior: (c, r) rows of 64 floats = 16 float4; BN+ReLU of the producer folded in; zero = padding
-        for (int e = tid; e < CV_CK * (CV_TR + 2) * (C2_FT / 4); e += 256) {
-            const int j = e % (C2_FT / 4);
-            const int row = e / (C2_FT / 4);
-            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
-            const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
+    // stage q -> (tile, chunk): serpentine over the chunks so that consecutive stages share the weight slice where possible
+    auto stage_tile = [&](int q) { return q / nchunks; };
+    auto stage_chunk = [&](int q) { const int i = q / nchunks, c = q % nchunks; return (i & 1) ? nchunks - 1 - c : c; };
+
+    f32x4 wreg[C3_WIT], xreg[C3_XIT];
+    float hreg = 0.f;
+    bool wreg_valid = false;
+    auto issue = [&](int q, int resident_chunk) {
+        const int ch = stage_chunk(q), t0 = (tile0 + stage_tile(q)) * CV_TR, c0 = ch * CV_CK;
+        wreg_valid = ch != resident_chunk;
+        if (wreg_valid) {
+            const f32x4* wsrc4 = reinterpret_cast<const f32x4*>(wpack + (long)ch * C2_WCHUNK);
+#pragma unroll
+            for (int it = 0; it < C3_WIT; ++it) {
+                const int e = tid + 256 * it;
+                wreg[it] = e < C2_WCHUNK / 4 ? wsrc4[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < C3_XIT; ++it) {
+            const int e = tid + 256 * it;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < a.T && f < a.F) {
-                const float* src = a.x + (((long)b * a.T + t) * a.Cin + ci) * a.F + f;
-                if (vec_ok && f + 3 < a.F) v = *reinterpret_cast<const f32x4*>(src);
-                else {
+            if (e < CV_CK * (CV_TR + 2) * (C2_FT / 4)) {
+                const int j = e % (C2_FT / 4), row = e / (C2_FT / 4);
+                const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+                const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
+                if (t >= 0 && t < a.T && f < a.F) {
+                    const float* src = a.x + (((long)b * a.T + t) * a.Cin + ci) * a.F + f;
+                    if (vec_ok && f + 3 < a.F) v = *reinterpret_cast<const f32x4*>(src);
+                    else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (f + q < a.F) v[q] = src[q];
-                }
-                if (a.in_scale) {
-                    const float sc = a.in_scale[ci], sh = a.in_shift[ci];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (f + q < a.F) ? fmaxf(v[q] * sc + sh, 0.f) : 0.f;
+                        for (int qq = 0; qq < 4; ++qq) if (f + qq < a.F) v[qq] = src[qq];
+                    }
                 }
             }
-            *reinterpret_cast<f32x4*>(lin + c * C2_PLANE + r * C2_RS + 4 + 4 * j) = v;
+            xreg[it] = v;
         }
-        // ---- halo columns f0-1 (LDS col 3) and f0+64 (LDS col 68)
-        for (int e = tid; e < CV_CK * (CV_TR + 2) * 2; e += 256) {
-            const int side = e & 1, row = e >> 1;
+        if (tid < CV_CK * (CV_TR + 2) * 2) {           // halo columns f0-1 and f0+64
+            const int side = tid & 1, row = tid >> 1;
             const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
             const int t = t0 + r - 1, f = side ? f0 + C2_FT : f0 - 1, ci = c0 + c;
-            float v = 0.f;
-            if (t >= 0 && t < a.T && f >= 0 && f < a.F) {
-                v = a.x[(((long)b * a.T + t) * a.Cin + ci) * a.F + f];
-                if (a.in_scale) v = fmaxf(v * a.in_scale[ci] + a.in_shift[ci], 0.f);
+            hreg = (t >= 0 && t < a.T && f >= 0 && f < a.F) ? a.x[(((long)b * a.T + t) * a.Cin + ci) * a.F + f] : 0.f;
+        }
+    };
+    auto commit = [&](int q) {     // registers -> LDS; BN+ReLU of the producer folded in; zero = padding (of the ACTIVATED tensor)
+        const int ch = stage_chunk(q), t0 = (tile0 + stage_tile(q)) * CV_TR, c0 = ch * CV_CK;
+        if (wreg_valid) {
+#pragma unroll
+            for (int it = 0; it < C3_WIT; ++it) {
+                const int e = tid + 256 * it;
+                if (e < C2_WCHUNK / 4) reinterpret_cast<f32x4*>(lw)[e] = wreg[it];
             }
+        }
+#pragma unroll
+        for (int it = 0; it < C3_XIT; ++it) {
+            const int e = tid + 256 * it;
+            if (e < CV_CK * (CV_TR + 2) * (C2_FT / 4)) {
+                const int j = e % (C2_FT / 4), row = e / (C2_FT / 4);
+                const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+                const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
+                f32x4 v = xreg[it];
+                if (a.in_scale && t >= 0 && t < a.T && f < a.F) {
+                    const float sc = a.in_scale[ci], sh = a.in_shift[ci];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) v[qq] = (f + qq < a.F) ? fmaxf(v[qq] * sc + sh, 0.f) : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(lin + c * C2_PLANE + r * C2_RS + 4 + 4 * j) = v;
+            }
+        }
+        if (tid < CV_CK * (CV_TR + 2) * 2) {
+            const int side = tid & 1, row = tid >> 1;
+            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+            const int t = t0 + r - 1, f = side ? f0 + C2_FT : f0 - 1, ci = c0 + c;
+            float v = hreg;
+            if (a.in_scale && t >= 0 && t < a.T && f >= 0 && f < a.F) v = fmaxf(v * a.in_scale[ci] + a.in_shift[ci], 0.f);
             lin[c * C2_PLANE + r * C2_RS + (side ? 4 + C2_FT : 3)] = v;
         }
+    };
+
+    int resident = -1;
+    issue(0, resident);
+    for (int q = 0; q < nstage; ++q) {
+        __syncthreads();                      // previous stage fully consumed
+        commit(q);
+        resident = stage_chunk(q);
         __syncthreads();
+        if (q + 1 < nstage) issue(q + 1, resident);      // in flight during the multiply below
         // ---- multiply: 9 taps x CK/4 k-steps, 4 m-tiles x NT n-tiles per wave
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -142,38 +206,40 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a, const float* __r
                 }
             }
         }
-    }
-
-    // ---- epilogue.  C/D map: lane holds column n = li (channel), rows lk*4+r (f positions) of each tile.
-    const int t = t0 + wave;
-    const bool row_ok = t < a.T;
+        if ((q + 1) % nchunks != 0) continue;
+        // ---- tile epilogue.  C/D map: lane holds column n = li (channel), rows lk*4+r (f positions) of each m-tile.
+        const int t = (tile0 + stage_tile(q)) * CV_TR + wave;
+        const bool row_ok = t < a.T;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = j * 16 + li;
-        float s = 0.f, s2 = 0.f;
+        for (int j = 0; j < NT; ++j) {
+            const int co = j * 16 + li;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = f0 + i * 16 + lk * 4;
-            if (row_ok && co < COUT) {
-                float* dst = a.y + (((long)b * a.T + t) * COUT + co) * a.F + f;
-                if (f + 3 < a.F && (a.F % 4 == 0)) {
-                    *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+            for (int i = 0; i < 4; ++i) {
+                const int f = f0 + i * 16 + lk * 4;
+                if (row_ok && co < COUT) {
+                    float* dst = a.y + (((long)b * a.T + t) * COUT + co) * a.F + f;
+                    if (f + 3 < a.F && (a.F % 4 == 0)) {
+                        *reinterpret_cast<f32x4*>(dst) = acc[i][j];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { s += acc[i][j][r]; s2 += acc[i][j][r] * acc[i][j][r]; }
-                } else {
+                        for (int r = 0; r < 4; ++r) { st_s[j] += acc[i][j][r]; st_s2[j] += acc[i][j][r] * acc[i][j][r]; }
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (f + r < a.F) { dst[r] = acc[i][j][r]; s += acc[i][j][r]; s2 += acc[i][j][r] * acc[i][j][r]; }
+                        for (int r = 0; r < 4; ++r)
+                            if (f + r < a.F) { dst[r] = acc[i][j][r]; st_s[j] += acc[i][j][r]; st_s2[j] += acc[i][j][r] * acc[i][j][r]; }
+                    }
                 }
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (a.stat_partial) {
+    }
+    if (a.stat_partial) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = st_s[j], s2 = st_s2[j];
             s += __shfl_xor(s, 16, 64); s2 += __shfl_xor(s2, 16, 64);
             s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64);
             if (lk == 0) { red[wave][j * 16 + li][0] = s; red[wave][j * 16 + li][1] = s2; }
         }
-    }
-    if (a.stat_partial) {
         __syncthreads();
         if (tid < COUT) {
             float s = 0.f, s2 = 0.f;
@@ -335,7 +401,7 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
         const int chunks = Cin / CV_CK;
         hipLaunchKernelGGL(conv_pack_weights, dim3(a2s_cdiv(chunks * C2_WCHUNK, 256)), dim3(256), 0, st, w, ws, Cin, Cout, flip, chunks);
         A2S_CHECK_LAUNCH("conv_pack_weights");
-        const int nblk = B * a2s_cdiv(T, CV_TR) * a2s_cdiv(F, C2_FT);
+        const int nblk = B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
         if (Cout == 20) hipLaunchKernelGGL(conv3x3_mfma<20>, dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
         else hipLaunchKernelGGL(conv3x3_mfma<40>, dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
     }
@@ -344,7 +410,7 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
 }
 
 int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin) {
-    return Cin == 1 ? a2s_cdiv((long)B * T * F, 256) : B * a2s_cdiv(T, CV_TR) * a2s_cdiv(F, C2_FT);
+    return Cin == 1 ? a2s_cdiv((long)B * T * F, 256) : B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
 }
 
 int a2s_bn_finalize_impl(hipStream_t st, const float* partial, int nblocks, int C, double count, const float* gamma,

@@ -7,6 +7,8 @@ import torch
 
 from .build import LIB
 
+LIB = os.environ.get("A2S_LIB", LIB)          # A/B measurements against an older build of the library
+
 _lib = None
 
 

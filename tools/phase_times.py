@@ -1,0 +1,71 @@
+"""Wall time of the phases of one fused training step (HIP events on the main stream around each phase).
+usage: python tools/phase_times.py [--batch 256] [--steps 4]"""
+import argparse
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=4)
+    a = ap.parse_args()
+    import models
+    from piano_a2s_amd import engine, engine_bwd, spec, synthetic, train
+    dev = torch.device("cuda:0")
+    cfg = spec.default_cfg()
+    torch.manual_seed(1)
+    m = models.ScoreTranscription(**cfg).to(dev)
+    m.train()
+    step = train.TrainStep(m)
+    b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=0.0)
+    b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
+    marks = []
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((name, e))
+
+    def wrap(obj, attr, name):
+        orig = getattr(obj, attr)
+
+        def f(*args, **kw):
+            mark("before " + name)
+            r = orig(*args, **kw)
+            mark(name)
+            return r
+        setattr(obj, attr, f)
+
+    wrap(engine.Engine, "convstack", "convstack fwd")
+    wrap(engine.Engine, "encoder", "encoder fwd")
+    wrap(engine.Engine, "forward", "decoder fwd (rest of forward)")
+    wrap(engine_bwd, "_encoder_bwd", "encoder bwd")
+    wrap(engine_bwd, "_convstack_bwd", "convstack bwd")
+    wrap(engine_bwd, "backward", "backward tail")
+    wrap(train.Objective, "__call__", "loss")
+    totals = {}
+    for k in range(a.steps + 1):
+        marks.clear()
+        mark("start")
+        step(b, 0.7, rng=random.Random(100 + k))
+        mark("optimizer")
+        torch.cuda.synchronize()
+        if k == 0:
+            continue
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            name = n1 if not n1.startswith("before ") else {"before encoder bwd": "decoder bwd", "before convstack bwd": "encoder->conv glue"}.get(n1, "(gap) " + n1)
+            totals[name] = totals.get(name, 0.0) + e0.elapsed_time(e1)
+    tot = sum(totals.values())
+    for n, t in totals.items():
+        print(f"{t / a.steps:9.1f} ms  {100 * t / tot:5.1f} %  {n}")
+    print(f"{tot / a.steps:9.1f} ms  total  -> {a.batch / (tot / a.steps) * 1e3:.1f} clips/s")
+
+
+if __name__ == "__main__":
+    main()
