@@ -204,10 +204,24 @@ size_t a2s_gemm_workspace_bytes_impl(int M, int N, int batch, int splitk) {
     return splitk > 1 ? (size_t)batch * splitk * M * N * sizeof(float) : 0;
 }
 
-// Heuristic split count for contractions with a tiny output and a huge K (wgrad forms).
+// Heuristic split count for contractions with a small output and a huge K (wgrad forms).
 int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
     const long tiles = (long)a2s_cdiv(M, 64) * a2s_cdiv(N, 64) * batch;
-    if (tiles >= 256 || K < 4096) return 1;
+    if (K < 4096) return 1;
+    if (tiles >= 256) {
+        // enough 64x64 tiles, but the launch uses 128x128 tiles, two workgroups per CU = 512 slots: a tile count that is not a
+        // multiple of the slots leaves CUs idle for the whole (long) K loop (Linear 19200->256 wgrad: 300 tiles = 59 % of the slots).
+        // Pick the split that fills whole rounds best.
+        const long t128 = (long)a2s_cdiv(M, 128) * a2s_cdiv(N, 128) * batch;
+        if (t128 >= 2048 || K < 32768) return 1;
+        int best = 1; double best_eff = 0.0;
+        for (int s = 1; s <= 8; ++s) {
+            const long wg = t128 * s;
+            const double eff = (double)wg / (double)(a2s_cdiv(wg, 512) * 512);
+            if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+        }
+        return best;
+    }
     long s = 512 / tiles;
     const long maxs = K / 512;
     if (s > maxs) s = maxs;
