@@ -675,6 +675,74 @@ __global__ void wgrad_reduce(const float* __restrict__ partial, float* __restric
 
 #define WGRAD_SLABS 768
 
+// First layer (Cin = 1): dW[co][tap] = sum_{b,t,f} dy[b,t,co,f] * x[b, t+dt-1, f+df-1].  53 GFLOP at B = 256 against 12 GB of dy: a
+// streaming kernel (the MFMA kernel above would spend a full 20-channel chunk on one real input channel).  Persistent workgroups walk
+// the (b,t) rows; a row's dy block (Cout x F) and the 3 x (F+2) input window go through LDS; thread = (co, slice of F) keeps its 9
+// tap sums in registers; one slab [Cout][9] per workgroup, reduced in fixed order by wgrad_reduce_c1.
+#define C1W_PARTS 12
+__global__ __launch_bounds__(256) void conv3x3_wgrad_c1(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
+                                                        int B, int T, int F, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ldy = sm;                            // Cout * F
+    float* lx = sm + Cout * F;                  // 3 * (F + 2)
+    const int tid = threadIdx.x;
+    const int co = tid / C1W_PARTS, part = tid % C1W_PARTS;
+    const int fper = (F + C1W_PARTS - 1) / C1W_PARTS;
+    const int fa = part * fper, fb = min(F, fa + fper);
+    const bool worker = co < Cout;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    const long rows = (long)B * T;
+    const bool vec_ok = (F % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int t = (int)(row % T);
+        const long b = row / T;
+        __syncthreads();
+        const float* drow = dy + row * (long)Cout * F;
+        if (vec_ok) {
+            for (int e = tid; e < Cout * F / 4; e += 256) reinterpret_cast<f32x4*>(ldy)[e] = reinterpret_cast<const f32x4*>(drow)[e];
+        } else {
+            for (int e = tid; e < Cout * F; e += 256) ldy[e] = drow[e];
+        }
+        for (int e = tid; e < 3 * (F + 2); e += 256) {
+            const int r = e / (F + 2), c = e % (F + 2);
+            const int tt = t + r - 1, f = c - 1;
+            lx[e] = (tt >= 0 && tt < T && f >= 0 && f < F) ? x[(b * T + tt) * F + f] : 0.f;
+        }
+        __syncthreads();
+        if (worker) {
+            const float* d = ldy + co * F;
+            for (int f = fa; f < fb; ++f) {
+                const float g = d[f];
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                    for (int df = 0; df < 3; ++df) acc[dt * 3 + df] = fmaf(g, lx[dt * (F + 2) + f + df], acc[dt * 3 + df]);
+            }
+        }
+    }
+    __syncthreads();
+    float* red = sm;                            // 256 * 9 floats (fits: Cout * F >= 2304 for the model's F)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[tid * 9 + k] = worker ? acc[k] : 0.f;
+    __syncthreads();
+    if (tid < Cout * 9) {
+        const int c = tid / 9, k = tid % 9;
+        float s = 0.f;
+        for (int p = 0; p < C1W_PARTS; ++p) s += red[(c * C1W_PARTS + p) * 9 + k];
+        partial[(long)blockIdx.x * Cout * 9 + tid] = s;
+    }
+}
+
+__global__ void wgrad_reduce_c1(const float* __restrict__ partial, float* __restrict__ dW, int nslabs, int n) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int i = 0; i < nslabs; ++i) s += partial[(long)i * n + idx];
+    dW[idx] += s;
+}
+
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
     return (size_t)chunks * WGRAD_SLABS * Cout * CV_CK * 9 * sizeof(float);
@@ -684,6 +752,16 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
                            float* ws, size_t ws_bytes, int B, int T, int F, int Cin, int Cout) {
     A2S_REQUIRE(dy && x && dW && ws, "conv3x3_wgrad: null tensor");
     A2S_REQUIRE(ws_bytes >= a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout), "conv3x3_wgrad: workspace too small");
+    if (Cin == 1 && !in_scale && Cout * C1W_PARTS <= 256 && (size_t)Cout * F >= 256 * 9) {
+        const size_t shm = ((size_t)Cout * F + 3 * (F + 2)) * sizeof(float);
+        if (shm <= 64 * 1024) {
+            hipLaunchKernelGGL(conv3x3_wgrad_c1, dim3(WGRAD_SLABS), dim3(256), shm, st, dy, x, ws, B, T, F, Cout);
+            A2S_CHECK_LAUNCH("conv3x3_wgrad_c1");
+            hipLaunchKernelGGL(wgrad_reduce_c1, dim3(a2s_cdiv(Cout * 9, 256)), dim3(256), 0, st, ws, dW, WGRAD_SLABS, Cout * 9);
+            A2S_CHECK_LAUNCH("wgrad_reduce_c1");
+            return A2S_OK;
+        }
+    }
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
     dim3 grid(WGRAD_SLABS, chunks);
     if (Cout == 20) hipLaunchKernelGGL(conv3x3_wgrad<20>, grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);

@@ -38,13 +38,15 @@ def main():
         fl = 2.0 * 9 * ci * co * B * T * F
         print(f"{what:12s} {ci:2d}->{co:2d}  {ms:8.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s")
         del x, y
-    for ci, co, what in ((20, 20, "conv2 wgrad"), (20, 40, "conv3 wgrad"), (40, 40, "conv4 wgrad")):
+    for ci, co, what in ((1, 20, "conv1 wgrad"), (20, 20, "conv2 wgrad"), (20, 40, "conv3 wgrad"), (40, 40, "conv4 wgrad")):
         x = torch.randn(B, T, ci, F, device=dev)
         dy = torch.randn(B, T, co, F, device=dev)
         dW = torch.zeros(co, ci, 3, 3, device=dev)
         scale, shift = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
         nbytes = L.a2s_conv3x3_wgrad_workspace_bytes(ci, co)
         ws = torch.empty(nbytes // 4, device=dev)
+        if ci == 1:
+            scale = shift = None
         ms = timed(lambda: hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x), hip._p(scale), hip._p(shift), hip._p(dW), hip._p(ws),
                                                          C.c_size_t(nbytes), B, T, F, ci, co), "wgrad"))
         fl = 2.0 * 9 * ci * co * B * T * F
