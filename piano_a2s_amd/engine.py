@@ -27,11 +27,9 @@ def plan_note_steps(gt_rows, max_steps):
     first = torch.where(is_eos.any(1), is_eos.float().argmax(1), torch.full((B,), max_steps))
     steps = int(first.max()) + 1 if bool((first < max_steps).all()) else max_steps
     steps = min(steps, max_steps)
-    lengths = torch.full((B,), max_steps, dtype=torch.long)
-    for b in range(B):
-        hits = is_eos[b, :steps].nonzero()
-        if hits.numel():
-            lengths[b] = int(hits[-1]) + 1
+    idx = torch.arange(1, steps + 1, dtype=torch.long)
+    last = (is_eos[:, :steps].long() * idx).amax(dim=1)          # last <eos> position + 1 among the executed steps, 0 = none
+    lengths = torch.where(last > 0, last, torch.full((B,), max_steps, dtype=torch.long))
     return steps, lengths
 
 
@@ -262,7 +260,7 @@ class Engine:
                                i64=ids_are_i64, hsave=hsave))
 
     def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None,
-                      active=None, drop=None):
+                      active=None, drop=None, flags_dev=None):
         """One NoteDecoder.decode_notes call over B rows.  probs_bar: view (B, max_steps, V) of the output tensor (strided).
         tf_flags: per step, bit g = teacher-force the rows of group g.
         active: optional dict(until: (B,) int32, order / rank: (n_clips,) int32 device tensors; n_active: host int array per step;
@@ -326,7 +324,7 @@ class Engine:
         # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
         executed = n if gt_bar is not None else int(steps_exec.item())
         saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
-                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active)
+                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active, flags_dev=flags_dev)
         return ids, lengths, saved
 
     # ------------------------------------------------------------------ full forward
@@ -347,16 +345,28 @@ class Engine:
         dev = spectrogram.device
         drop_on = training and dropout
 
+        gt_cpu = None
+        if ground_truth is not None:
+            ts_gt, key_gt, up_gt, up_len_gt, lo_gt, lo_len_gt = [g.contiguous() for g in ground_truth]
+            gt_cpu = (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())      # ONE host sync per forward, before anything is enqueued
+
+        # ConvStack + encoder are enqueued first: the host-side planning of the decoder below runs while they execute.  Its small
+        # host->device uploads go through pinned memory without synchronising (a pageable upload would drain the stream each time).
         mask = (torch.rand((B * T, cfg["conv_feature_size"]), device=dev) >= 0.2).to(torch.uint8) if drop_on else None
         conv_out, conv_saved = self.convstack(S, spectrogram, training, mask)
         enc, hidden, enc_saved = self.encoder(S, conv_out, training)
         enc2d = enc.view(B * T, 2 * H)
         keys = {p: self._keys(S, p + ".attn", enc2d, H) for p in ("decoder", "decoder.upper_decoder", "decoder.lower_decoder")}
+        pinned = []                                      # keeps the staging buffers alive until the step is over
 
-        gt_cpu = None
-        if ground_truth is not None:
-            ts_gt, key_gt, up_gt, up_len_gt, lo_gt, lo_len_gt = [g.contiguous() for g in ground_truth]
-            gt_cpu = (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())      # ONE host sync per forward
+        def upload(t):
+            p = t.contiguous().pin_memory()
+            pinned.append(p)
+            return p.to(dev, non_blocking=True)
+
+        sos_ids = torch.full((B, 2), SOS, dtype=torch.long, device=dev)
+        sos_ids[:, 1] = EOS
+        two = torch.full((B,), 2, dtype=torch.long, device=dev)
         maxlen = (U, Lo)
         # ---- host plan.  With ground truth the number of executed steps of every (bar, staff) is known up front, so every coin of
         # the reference's protocol (one per executed note step, upper then lower, then one per bar: models.py:404,289) is drawn here,
@@ -402,8 +412,24 @@ class Engine:
             rank[order.long()] = torch.arange(B, dtype=torch.int32)
             cnt = torch.bincount(clip_until.long(), minlength=n + 1)
             n_act = B - torch.cumsum(cnt, 0)[:n]                                                                # clips with until > t
-            return dict(until=until.reshape(-1).contiguous().to(dev), order=order.to(dev), rank=rank.to(dev),
+            return dict(until=upload(until.reshape(-1)), order=upload(order), rank=upload(rank),
                         n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=B)
+
+        # Every host-side decision of the decoder and every small upload happens HERE, while the GPU is busy with the ConvStack and
+        # the encoder enqueued above -- not once per (segment, staff) in the middle of the decoder.
+        seg_plan = []
+        for seg in segments:
+            sp = {}
+            for gi_idx in (0, 1):
+                if plan is None:
+                    sp[gi_idx] = (maxlen[gi_idx], None, None, None)
+                    continue
+                steps = max(plan[bar][gi_idx][0] for bar in seg)
+                flags = [sum(int(t < plan[bar][gi_idx][0] and plan[bar][gi_idx][1][t]) << j for j, bar in enumerate(seg)) for t in range(steps)]
+                # the backward pass needs the flags on the device (which token each step consumed)
+                flags_dev = upload(torch.tensor(flags[:steps - 1], dtype=torch.int32)) if training and steps > 1 else None
+                sp[gi_idx] = (steps, flags, active_rows(gi_idx, seg, steps) if skip else None, flags_dev)
+            seg_plan.append(sp)
 
         bar_major = fuse
         self.bar_major = bar_major
@@ -416,8 +442,6 @@ class Engine:
 
         tokw = 4 * Sz + te + ke
         token = self._empty(B, tokw, dev=dev)
-        sos_ids = torch.tensor([[SOS, EOS]], dtype=torch.long, device=dev).repeat(B, 1)
-        two = torch.full((B,), 2, dtype=torch.long, device=dev)
         sos_rec = [] if training else None
         self._staff_token(S, sos_ids, two, 1, token, 0, 2, 2, True, sos_rec)
         token[:, 2 * Sz:4 * Sz].copy_(token[:, :2 * Sz])
@@ -496,7 +520,7 @@ class Engine:
                                            width, C.c_void_p(0), hip.f32(1.0)), "embed next token")
             return token, tok_rec, (ts_ids, key_ids, i64, stride)
 
-        for seg in segments:
+        for seg_i, seg in enumerate(segments):
             nb = len(seg)
             # (1) bar-level chain of the segment: inside a segment every next token comes from the ground truth
             for j, bar in enumerate(seg):
@@ -513,24 +537,20 @@ class Engine:
             staff = {}
             calls = []
             for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out, 0), ("lo", "decoder.lower_decoder", Lo, lo_out, 1)):
-                active = None
+                steps, flags, active, flags_dev = seg_plan[seg_i][gi_idx]
                 if plan is not None:
-                    steps = max(plan[bar][gi_idx][0] for bar in seg)
-                    flags = [sum(int(t < plan[bar][gi_idx][0] and plan[bar][gi_idx][1][t]) << j for j, bar in enumerate(seg)) for t in range(steps)]
                     if bar_major:
                         gt_bar = gt_bm[gi_idx][seg[0]:seg[0] + nb].view(R, maxs)
                         probs = out_t[seg[0]:seg[0] + nb].view(R, maxs, V)
                     else:
                         gt_bar = (up_gt if gi_idx == 0 else lo_gt)[:, seg[0], :]
                         probs = out_t[:, seg[0]]
-                    if skip:
-                        active = active_rows(gi_idx, seg, steps)
                 else:
-                    steps, flags, gt_bar, probs = maxs, None, None, out_t[:, seg[0]]
+                    gt_bar, probs = None, out_t[:, seg[0]]
                 # the dropout masks are drawn here, on the caller's thread and stream: one deterministic draw order per seed
                 drop = (torch.rand((steps + 1, R, E), device=dev) >= 0.1).to(torch.uint8) if drop_on else None
                 calls.append((name, (S, prefix, keys[prefix], enc, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
-                                     attn_ws[gi_idx], gemm_ws[gi_idx], active, drop)))
+                                     attn_ws[gi_idx], gemm_ws[gi_idx], active, drop, flags_dev)))
             if concurrent:
                 join = fork_on_streams(dev, streams, [lambda args=args: self._decode_staff(*args) for _, args in calls])
             elif gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH):
@@ -571,5 +591,5 @@ class Engine:
             rec["teacher_force"] = teacher_force
         self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, segments=seg_saved, enc_out=enc, sos_rec=sos_rec,
                           training=training, concurrent=concurrent, outs=(ts_out, key_out, up_out, lo_out), bar_major=bar_major,
-                          gt=(ground_truth is not None and (up_gt, lo_gt)) or None, shape=(B, T, F), drop_on=drop_on)
+                          gt=(ground_truth is not None and (up_gt, lo_gt)) or None, shape=(B, T, F), drop_on=drop_on, pinned=pinned)
         return ts_out, key_out, up_out, lo_out

@@ -53,7 +53,9 @@ def _staff_token_bwd(eng, S, G, rec, dtok):
     L = hip.lib()
     names = [f"decoder.staff_emb.{w}_{sfx}" for sfx in ("l0", "l0_reverse") for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     warr = (C.c_void_p * 8)(*[S[n].data_ptr() for n in names])
-    gptrs = torch.tensor([G[n].data_ptr() for n in names], dtype=torch.int64, device=dtok.device)
+    gptrs = G.get("__staff_emb_ptrs__")
+    if gptrs is None:
+        gptrs = torch.tensor([G[n].data_ptr() for n in names], dtype=torch.int64, device=dtok.device)
     E, Sz = eng.cfg["note_emb_size"], eng.cfg["staff_emb_size"]
     ids = rec["ids"]
     hip.check(L.a2s_staff_emb_bwd(hip.stream(), hip._p(S["decoder.note_emb.weight"]), warr, hip._p(gptrs), hip._p(G["decoder.note_emb.weight"]),
@@ -130,7 +132,10 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     if n > 1:
         prev = sv["ids"][:, :n - 1].t()
         if sv["gt_bar"] is not None:
-            bits = torch.tensor(sv["flags"][:n - 1], dtype=torch.int32, device=dev).unsqueeze(1)                    # bit g: group g teacher-forced
+            bits = sv.get("flags_dev")                                                                            # bit g: group g teacher-forced
+            if bits is None:
+                bits = torch.tensor(sv["flags"][:n - 1], dtype=torch.int32, device=dev)
+            bits = bits[:n - 1].unsqueeze(1)
             grp = (torch.arange(B, dtype=torch.int32, device=dev) // n_clips).unsqueeze(0)
             flags = ((bits >> grp) & 1).bool()
             prev = torch.where(flags, sv["gt_bar"][:, :n - 1].t().to(torch.int32), prev)
@@ -162,11 +167,15 @@ def backward(eng, S, grad_outputs):
     offs, total = flat_layout([S[k].numel() for k in names])          # same layout as models.ScoreTranscription.flatten_()
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     G = {k: flat[off:off + S[k].numel()].view(S[k].shape) for k, off in zip(names, offs)}
+    # device table of the staff-embedding gradient pointers: uploaded once, before the first kernel of the backward pass
+    ptrs_host = torch.tensor([G[f"decoder.staff_emb.{w}_{sfx}"].data_ptr() for sfx in ("l0", "l0_reverse")
+                              for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")], dtype=torch.int64).pin_memory()
+    G["__staff_emb_ptrs__"] = ptrs_host.to(dev, non_blocking=True)          # pinned: no stream synchronisation (the host keeps running ahead)
     dts, dkey, dup, dlo = [g.contiguous() for g in grad_outputs]
     ts_out, key_out, up_out, lo_out = sv["outs"]
     dEnc = torch.zeros((B, T, H2), dtype=torch.float32, device=dev)
     dK = {p: torch.zeros((B, T, H), dtype=torch.float32, device=dev) for p in sv["keys"]}
-    keep_alive = []
+    keep_alive = [ptrs_host]
     # the two note decoders of a bar back-propagate concurrently on two side streams (see engine.side_streams); each accumulates its
     # encoder-output gradient in its own buffer (summed once at the end), everything else they write is per-staff already
     from .engine import fork_on_streams, side_streams
