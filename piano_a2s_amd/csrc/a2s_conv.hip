@@ -539,11 +539,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
                                                      float* __restrict__ partial, int B, int T, int F, int Cin) {
     constexpr int MT = (COUT + 15) / 16;
     constexpr int NTW = 3;                               // n-tiles per wave: 4 waves x 3 x 16 = 192 >= 180
-    constexpr int DRS = CV_FT + 4;                       // dy row stride in LDS (rows 16-byte aligned)
-    constexpr int WRS = 40;                              // input row stride: interior at column 4 (aligned 16-byte stores), halos at 3 / 36
-    constexpr int WPL = 6 * WRS;                         // 240 == 16 (mod 32)
+    // LDS layouts chosen by exhaustive search for conflict-free fragment reads (each half-wave = 16 M/N indices x 2 k-slots must
+    // hit 32 distinct banks; PMC on the first layout: 77 % of the LDS cycles were bank-conflict cycles, 8-way on the dy image):
+    //   dy   : [r][co][34]  -> lane stride 34 floats (== 2 mod 32) between output channels;
+    //   input: [c][6 rows][36], plane 240; interior at column 2 (halos at 1 / 34).  Rows are 8-byte aligned -> float2 stores.
+    constexpr int DRS = CV_FT + 2;                       // 34
+    constexpr int WRS = 36;
+    constexpr int WPL = 240;
+    constexpr int WC0 = 2;                               // LDS column of f0
     __shared__ __attribute__((aligned(16))) float lin[CV_CK * WPL];
-    __shared__ __attribute__((aligned(16))) float ldy[MT * 16 * CV_TR * DRS];
+    __shared__ __attribute__((aligned(16))) float ldy[CV_TR * MT * 16 * DRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int c0 = blockIdx.y * CV_CK;
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
         const int n = (wave * NTW + j) * 16 + li;
         bok[j] = n < CV_CK * 9 && (c0 + n / 9) < Cin;
         const int c = n / 9, tap = n % 9;
-        boff[j] = bok[j] ? c * WPL + (tap / 3) * WRS + (tap % 3) + 3 : 0;
+        boff[j] = bok[j] ? c * WPL + (tap / 3) * WRS + (tap % 3) + WC0 - 1 : 0;
     }
     f32x4 acc[MT][NTW];
 #pragma unroll
@@ -566,63 +571,101 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // rows of the dy image that belong to padded output channels (co >= COUT) stay zero for the whole kernel
-    for (int e = tid; e < (MT * 16 - COUT) * CV_TR * DRS; e += 256) ldy[COUT * CV_TR * DRS + e] = 0.f;
+    for (int e = tid; e < CV_TR * (MT * 16 - COUT) * DRS; e += 256) {
+        const int r = e / ((MT * 16 - COUT) * DRS), rem = e % ((MT * 16 - COUT) * DRS);
+        ldy[(r * MT * 16 + COUT) * DRS + rem] = 0.f;
+    }
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         long bid = tile;
         const int ft = (int)(bid % tilesF); bid /= tilesF;
         const int tt = (int)(bid % tilesT); const int b = (int)(bid / tilesT);
         const int t0 = tt * CV_TR, f0 = ft * CV_FT;
-        __syncthreads();
-        // ---- input interior: (c, r) rows of 32 floats = 8 float4 (producer's BN+ReLU folded in)
-        for (int e = tid; e < CV_CK * (CV_TR + 2) * (CV_FT / 4); e += 256) {
-            const int j = e % (CV_FT / 4);
-            const int row = e / (CV_FT / 4);
-            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
-            const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < T && f < F && ci < Cin) {
-                const float* src = x + (((long)b * T + t) * Cin + ci) * F + f;
-                if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
-                else {
+        // ---- staging: ALL global loads of the tile are issued first (one round trip instead of ~10 dependent ones), then transformed
+        // (producer's BN+ReLU) and stored to LDS
+        constexpr int XIT = (CV_CK * (CV_TR + 2) * (CV_FT / 4) + 255) / 256;      // 4
+        constexpr int DIT = (COUT * CV_TR * (CV_FT / 4) + 255) / 256;             // 5 (Cout 40) / 3 (Cout 20)
+        f32x4 xreg[XIT], dreg[DIT];
+        float hreg = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tid + 256 * it;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < CV_CK * (CV_TR + 2) * (CV_FT / 4)) {
+                const int j = e % (CV_FT / 4), row = e / (CV_FT / 4);
+                const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+                const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
+                if (t >= 0 && t < T && f < F && ci < Cin) {
+                    const float* src = x + (((long)b * T + t) * Cin + ci) * F + f;
+                    if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+                    }
                 }
-                if (in_scale) {
+            }
+            xreg[it] = v;
+        }
+        if (tid < CV_CK * (CV_TR + 2) * 2) {
+            const int side = tid & 1, row = tid >> 1;
+            const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+            const int t = t0 + r - 1, f = side ? f0 + CV_FT : f0 - 1, ci = c0 + c;
+            hreg = (t >= 0 && t < T && f >= 0 && f < F && ci < Cin) ? x[(((long)b * T + t) * Cin + ci) * F + f] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + 256 * it;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < COUT * CV_TR * (CV_FT / 4)) {
+                const int j = e % (CV_FT / 4), row = e / (CV_FT / 4);
+                const int r = row % CV_TR, co = row / CV_TR;
+                const int t = t0 + r, f = f0 + 4 * j;
+                if (t < T && f < F) {
+                    const float* src = dy + (((long)b * T + t) * COUT + co) * F + f;
+                    if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+                    }
+                }
+            }
+            dreg[it] = v;
+        }
+        __syncthreads();                   // previous tile fully consumed (the loads above are already in flight)
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tid + 256 * it;
+            if (e < CV_CK * (CV_TR + 2) * (CV_FT / 4)) {
+                const int j = e % (CV_FT / 4), row = e / (CV_FT / 4);
+                const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
+                const int t = t0 + r - 1, f = f0 + 4 * j, ci = c0 + c;
+                f32x4 v = xreg[it];
+                if (in_scale && t >= 0 && t < T && f < F && ci < Cin) {
                     const float sc = in_scale[ci], sh = in_shift[ci];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = (f + q < F) ? fmaxf(v[q] * sc + sh, 0.f) : 0.f;
                 }
+                float2* dst = reinterpret_cast<float2*>(lin + c * WPL + r * WRS + WC0 + 4 * j);
+                dst[0] = make_float2(v[0], v[1]); dst[1] = make_float2(v[2], v[3]);
             }
-            *reinterpret_cast<f32x4*>(lin + c * WPL + r * WRS + 4 + 4 * j) = v;
         }
-        for (int e = tid; e < CV_CK * (CV_TR + 2) * 2; e += 256) {      // halo columns
-            const int side = e & 1, row = e >> 1;
+        if (tid < CV_CK * (CV_TR + 2) * 2) {
+            const int side = tid & 1, row = tid >> 1;
             const int r = row % (CV_TR + 2), c = row / (CV_TR + 2);
             const int t = t0 + r - 1, f = side ? f0 + CV_FT : f0 - 1, ci = c0 + c;
-            float v = 0.f;
-            if (t >= 0 && t < T && f >= 0 && f < F && ci < Cin) {
-                v = x[(((long)b * T + t) * Cin + ci) * F + f];
-                if (in_scale) v = fmaxf(v * in_scale[ci] + in_shift[ci], 0.f);
-            }
-            lin[c * WPL + r * WRS + (side ? 4 + CV_FT : 3)] = v;
+            float v = hreg;
+            if (in_scale && t >= 0 && t < T && f >= 0 && f < F && ci < Cin) v = fmaxf(v * in_scale[ci] + in_shift[ci], 0.f);
+            lin[c * WPL + r * WRS + (side ? WC0 + CV_FT : WC0 - 1)] = v;
         }
-        // ---- dy tile: (co, r) rows of 32 floats = 8 float4
-        for (int e = tid; e < COUT * CV_TR * (CV_FT / 4); e += 256) {
-            const int j = e % (CV_FT / 4);
-            const int row = e / (CV_FT / 4);
-            const int r = row % CV_TR, co = row / CV_TR;
-            const int t = t0 + r, f = f0 + 4 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t < T && f < F) {
-                const float* src = dy + (((long)b * T + t) * COUT + co) * F + f;
-                if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
-                else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
-                }
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + 256 * it;
+            if (e < COUT * CV_TR * (CV_FT / 4)) {
+                const int j = e % (CV_FT / 4), row = e / (CV_FT / 4);
+                const int r = row % CV_TR, co = row / CV_TR;
+                float2* dst = reinterpret_cast<float2*>(ldy + (r * MT * 16 + co) * DRS + 4 * j);
+                dst[0] = make_float2(dreg[it][0], dreg[it][1]); dst[1] = make_float2(dreg[it][2], dreg[it][3]);
             }
-            *reinterpret_cast<f32x4*>(ldy + (co * CV_TR + r) * DRS + 4 * j) = v;
         }
         __syncthreads();
 #pragma unroll
@@ -631,7 +674,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
             for (int ks = 0; ks < CV_FT / 4; ++ks) {
                 float a[MT], bv[NTW];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = ldy[((i * 16 + li) * CV_TR + r) * DRS + ks * 4 + lk];
+                for (int i = 0; i < MT; ++i) a[i] = ldy[(r * MT * 16 + i * 16 + li) * DRS + ks * 4 + lk];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) bv[j] = bok[j] ? lin[boff[j] + r * WRS + ks * 4 + lk] : 0.f;
 #pragma unroll
@@ -763,13 +806,15 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
         }
     }
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
-    dim3 grid(WGRAD_SLABS, chunks);
+    // persistent workgroups: one full round of the occupancy the kernel reaches (Cout 20: 3 per CU, Cout 40: 2 per CU by registers)
+    const int slabs = Cout == 20 ? WGRAD_SLABS : 512;
+    dim3 grid(slabs, chunks);
     if (Cout == 20) hipLaunchKernelGGL(conv3x3_wgrad<20>, grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
     else if (Cout == 40) hipLaunchKernelGGL(conv3x3_wgrad<40>, grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
     else A2S_FAIL(A2S_ERR_ARG, "conv3x3_wgrad: Cout must be 20 or 40 (got %d)", Cout);
     A2S_CHECK_LAUNCH("conv3x3_wgrad");
     const int n = Cout * CV_CK * 9 * chunks;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(a2s_cdiv(n, 256)), dim3(256), 0, st, ws, dW, WGRAD_SLABS, Cout, Cin, chunks);
+    hipLaunchKernelGGL(wgrad_reduce, dim3(a2s_cdiv(n, 256)), dim3(256), 0, st, ws, dW, slabs, Cout, Cin, chunks);
     A2S_CHECK_LAUNCH("wgrad_reduce");
     return A2S_OK;
 }
