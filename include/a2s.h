@@ -78,6 +78,12 @@ int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_
 int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v,
                       float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
                       const int* n_done, int n_rows_total, float* workspace);
+/* the same step over the R = groups * n_clips rows of a fused-bars decoder call (row = group * n_clips + clip; see a2s_note_dec_args):
+ * rows of a clip share its keys / enc; clip_order / clip_rank / row_until may be NULL (identity, never finished), n_active = clips
+ * computed (prefix of clip_order), step = decode step compared with row_until.  Skipped rows get ctx = 0, attw = 0. */
+int a2s_attn_step_fwd_rows(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, float* ctx,
+                           long ldctx, float* ctx2, long ldctx2, float* attw, int R, int T, int H, float* workspace, int n_clips,
+                           const int* clip_order, const int* clip_rank, const int* row_until, int n_active, int step);
 /* workspace (a2s_attn_workspace_floats floats, shared by forward and backward) selects the split-T kernels: the frames of a
  * clip are spread over several workgroups and merged by a combine kernel; NULL (or hidden_size != 256) = one workgroup per clip. */
 size_t a2s_attn_workspace_floats(int B, int T, int H);
@@ -144,6 +150,10 @@ int a2s_gru_gates_bwd(void* stream, const float* dh_a, long lda, const float* dh
 int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v,
                       const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                       long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* workspace);
+int a2s_attn_step_bwd_rows(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, const float* attw,
+                           const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb, float* dctx_out,
+                           long lddo, float* dq, long lddq, float* ds_out, int R, int T, int H, float* workspace, int n_clips,
+                           const int* clip_order, const int* clip_rank, const int* row_until, int n_active, int step);
 /* deferred key gradient of S steps: dK += ..., dv partials [B*ceil(T/16)][H] (reduce with a2s_col_sum) */
 int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
                       float* dv_partial, int B, int T, int S, int H, const int* row_until, int groups);

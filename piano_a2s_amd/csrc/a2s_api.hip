@@ -123,6 +123,12 @@ int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const f
                       long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H, const int* n_done, int n_rows_total, float* workspace) {
     return a2s_attn_step_fwd_impl(ST, keys, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, B, T, H, n_done, n_rows_total, workspace, nullptr);
 }
+int a2s_attn_step_fwd_rows(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, float* ctx,
+                           long ldctx, float* ctx2, long ldctx2, float* attw, int R, int T, int H, float* workspace, int n_clips,
+                           const int* clip_order, const int* clip_rank, const int* row_until, int n_active, int step) {
+    a2s_attn_rows rows = {clip_order, clip_rank, row_until, n_clips, n_active, step};
+    return a2s_attn_step_fwd_impl(ST, keys, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, R, T, H, nullptr, 0, workspace, &rows);
+}
 size_t a2s_attn_workspace_floats(int B, int T, int H) { return a2s_attn_workspace_floats_impl(B, T, H, 1); }
 size_t a2s_attn_workspace_floats_fused(int n_clips, int T, int H, int groups) { return a2s_attn_workspace_floats_impl(n_clips, T, H, groups); }
 int a2s_log_softmax_rows(void* stream, const float* x, long ldx, float* y, long ldy, int* argmax_out, int R, int V) {
@@ -156,6 +162,13 @@ int a2s_attn_step_bwd(void* stream, const float* keys, const float* enc, const f
                       const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb, float* dctx_out,
                       long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* workspace) {
     return a2s_attn_step_bwd_impl(ST, keys, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, B, T, H, workspace, nullptr);
+}
+int a2s_attn_step_bwd_rows(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v, const float* attw,
+                           const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb, float* dctx_out,
+                           long lddo, float* dq, long lddq, float* ds_out, int R, int T, int H, float* workspace, int n_clips,
+                           const int* clip_order, const int* clip_rank, const int* row_until, int n_active, int step) {
+    a2s_attn_rows rows = {clip_order, clip_rank, row_until, n_clips, n_active, step};
+    return a2s_attn_step_bwd_impl(ST, keys, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, R, T, H, workspace, &rows);
 }
 int a2s_attn_dk_accum(void* stream, const float* keys, const float* q_all, const float* ds_all, const float* v, float* dK,
                       float* dv_partial, int B, int T, int S, int H, const int* row_until, int groups) {

@@ -112,15 +112,17 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
-// tanh / sigmoid through the hardware exp2 + rcp (abs error ~1e-7: far inside the 1e-4 parity budget).
+// tanh / sigmoid through the hardware exp2 + rcp (abs error ~2e-7: far inside the 1e-4 parity budget).  The reciprocal is the bare
+// v_rcp_f32 (1 ulp): __frcp_rn expands to the full IEEE division sequence (2x v_div_scale, v_rcp, 4 fma, v_div_fmas, v_div_fixup),
+// which made tanh 18 instructions instead of 8 -- the attention kernels with several rows per clip are bound by exactly this.
 __device__ __forceinline__ float fast_tanh(float x) {
     // tanh(x) = 1 - 2 / (exp(2x) + 1); clamp keeps exp finite, tanh(+-15) == +-1 in fp32
     x = fminf(fmaxf(x, -15.f), 15.f);
     const float e = __expf(2.f * x);
-    return 1.f - 2.f * __frcp_rn(e + 1.f);
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 __device__ __forceinline__ float fast_sigmoid(float x) {
     x = fminf(fmaxf(x, -30.f), 30.f);
-    return __frcp_rn(1.f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.f + __expf(-x));
 }
 #endif

@@ -325,3 +325,74 @@ def test_staff_embedding_backward(dev):
     for k, e in errs.items():
         _report(f"staff_emb_bwd {k}", e)
     assert max(errs.values()) < 2e-5, errs
+
+
+@pytest.mark.parametrize("H,T,clips,groups,split", [(256, 1201, 3, 2, True), (256, 333, 70, 3, True), (256, 77, 5, 5, True), (32, 41, 3, 3, False)])
+def test_fused_rows_attention_forward_backward(dev, H, T, clips, groups, split):
+    """The attention step over `groups` bars of the same clips (row = group * clips + clip) with finished rows skipped: forward
+    context / weights, dq, and the deferred dK / dEnc over S steps against torch autograd on the unfinished (row, step) pairs.
+    split=True: the multi-row split-T kernels (hidden 256); split=False: the one-workgroup-per-row kernels (no skipping)."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    S, R = 4, groups * clips
+    g = torch.Generator().manual_seed(H + T + groups)
+    enc = torch.randn(clips, T, 2 * H, generator=g, requires_grad=True)
+    K = (torch.randn(clips, T, H, generator=g) * 0.7).requires_grad_(True)
+    v = (torch.randn(H, generator=g) * 0.5).requires_grad_(True)
+    qs = [(torch.randn(R, H, generator=g) * 0.7).requires_grad_(True) for _ in range(S)]
+    dctxs = [torch.randn(R, 2 * H, generator=g) for _ in range(S)]
+    until = torch.randint(0, S + 1, (R,), generator=g).to(torch.int32)
+    until[0] = S                                               # at least one row runs to the end
+    if not split:
+        until[:] = S                                           # the one-WG-per-row kernels compute every row
+    clip_until = until.view(groups, clips).amax(dim=0)
+    order = torch.argsort(clip_until, descending=True, stable=True).to(torch.int32)
+    rank = torch.empty_like(order)
+    rank[order.long()] = torch.arange(clips, dtype=torch.int32)
+    rep = lambda x: x.repeat(groups, *([1] * (x.dim() - 1)))   # rows of group j read clip r % clips
+    loss = 0
+    ctxs, aws = [], []
+    for s, (q, dc) in enumerate(zip(qs, dctxs)):
+        a = torch.softmax((torch.tanh(rep(K) + q.unsqueeze(1)) * v).sum(-1), dim=1)
+        ctx = torch.bmm(a.unsqueeze(1), rep(enc)).squeeze(1)
+        live = (until > s).float().unsqueeze(1)
+        ctxs.append((ctx * live).detach()); aws.append((a * live).detach())
+        loss = loss + (ctx * dc * live).sum()
+    loss.backward()
+    Kd, encd, vd = K.detach().to(dev), enc.detach().to(dev), v.detach().to(dev)
+    q_all = torch.stack([q.detach() for q in qs]).to(dev)
+    dctx_all = torch.stack(dctxs).to(dev)
+    d_until, d_order, d_rank = until.to(dev), order.to(dev), rank.to(dev)
+    ws = hip.attn_workspace(clips, T, H, dev, groups=groups) if split else None
+    ctx_all, attw = torch.full((S, R, 2 * H), 7.0, device=dev), torch.full((S, R, T), 7.0, device=dev)
+    dq_all, ds_all = torch.full((S, R, H), 7.0, device=dev), torch.full((S, R, T), 7.0, device=dev)
+    dctx_out = torch.full((S, R, 2 * H), 7.0, device=dev)
+    for s in range(S):
+        n_active = int((clip_until > s).sum())
+        hip.check(L.a2s_attn_step_fwd_rows(hip.stream(), hip._p(Kd), hip._p(encd), C.c_void_p(q_all[s].data_ptr()), C.c_long(H), hip._p(vd),
+                                           C.c_void_p(ctx_all[s].data_ptr()), C.c_long(2 * H), NULL, C.c_long(0), C.c_void_p(attw[s].data_ptr()),
+                                           R, T, H, hip._p(ws), clips, hip._p(d_order), hip._p(d_rank), hip._p(d_until), n_active, s), "fwd rows")
+    for s in range(S):
+        n_active = int((clip_until > s).sum())
+        hip.check(L.a2s_attn_step_bwd_rows(hip.stream(), hip._p(Kd), hip._p(encd), C.c_void_p(q_all[s].data_ptr()), C.c_long(H), hip._p(vd),
+                                           C.c_void_p(attw[s].data_ptr()), C.c_void_p(ctx_all[s].data_ptr()), C.c_long(2 * H),
+                                           C.c_void_p(dctx_all[s].data_ptr()), C.c_long(2 * H), NULL, C.c_long(0),
+                                           C.c_void_p(dctx_out[s].data_ptr()), C.c_long(2 * H), C.c_void_p(dq_all[s].data_ptr()), C.c_long(H),
+                                           C.c_void_p(ds_all[s].data_ptr()), R, T, H, hip._p(ws), clips, hip._p(d_order), hip._p(d_rank),
+                                           hip._p(d_until), n_active, s), "bwd rows")
+    dK = torch.zeros(clips, T, H, device=dev)
+    nblk = L.a2s_attn_dk_blocks(clips, T)
+    dvp = torch.zeros(nblk, H, device=dev)
+    hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(Kd), hip._p(q_all), hip._p(ds_all), hip._p(vd), hip._p(dK), hip._p(dvp), clips, T, S, H,
+                                  hip._p(d_until), groups), "dk")
+    dv = torch.zeros(H, device=dev)
+    hip.check(L.a2s_col_sum(hip.stream(), hip._p(dvp), C.c_long(H), hip._p(dv), C.c_long(nblk), H, hip.f32(1.0), hip.f32(0.0), NULL, C.c_size_t(0)), "col_sum")
+    dEnc = torch.zeros(clips, T, 2 * H, device=dev)      # (step, group) is one flat reduction index of the batched GEMM
+    hip.gemm(attw, 1, clips * T, dctx_out, clips * 2 * H, 1, dEnc, 2 * H, T, 2 * H, S * groups, batch=clips, bsA=T, bsB=2 * H, bsC=T * 2 * H)
+    torch.cuda.synchronize()
+    live_dq = torch.stack([(until > s).float() for s in range(S)]).unsqueeze(-1)
+    errs = {"ctx": _rel(ctx_all, torch.stack(ctxs)), "attw": _rel(attw, torch.stack(aws)),
+            "dq": _rel(dq_all, torch.stack([q.grad for q in qs]) * live_dq), "dK": _rel(dK, K.grad), "dv": _rel(dv, v.grad), "dEnc": _rel(dEnc, enc.grad)}
+    for k, e in errs.items():
+        _report(f"fused rows H{H} T{T} clips{clips} groups{groups} split={split} {k}", e)
+    assert max(errs.values()) < 5e-5, errs
