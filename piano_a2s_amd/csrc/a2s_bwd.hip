@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
 
 // Fused bars (see attn_fwd_split256_mq): NQ rows of one clip per workgroup, the clip's enc and K chunk streamed once for all of them.
 template <int NQ>
-__global__ __launch_bounds__(256) void attn_bwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
+__global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                             const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                             const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
                                                             const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
