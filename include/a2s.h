@@ -195,7 +195,8 @@ int a2s_staff_emb_bwd(void* stream, const float* note_emb, const float* const* g
                       const float* dout, long lddo, int col0, const float* hsave, int R, int maxlen, int E, int S);
 
 /* BatchNorm(+ReLU, + optional dropout on the (rows,C) layout) backward, training statistics (models.py:525-541):
- * dgamma/dbeta +=, dx written (may alias g).  rows x C x F elements, channel of element i = (i/F)%C.
+ * dgamma/dbeta +=, dx written (may alias g; NULL = statistics only: c12 is left for a2s_conv3x3_wgrad_bn, which forms dx itself).
+ * rows x C x F elements, channel of element i = (i/F)%C.
  * partial: a2s_bn_bwd_partial_floats() floats of scratch; c12: 2*C floats of scratch. */
 int a2s_bn_bwd(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
                const float* shift, const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx,
@@ -212,6 +213,12 @@ int a2s_bn_bwd_apply(void* stream, const float* g, const float* x, const float* 
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
                       float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
+/* The same with the BatchNorm backward of the layer's output folded into the staging of the dy operand: g = gradient wrt
+ * relu(bn(y)), y = the layer's pre-BN output, c12 from a2s_bn_bwd(..., dx = NULL); dy = scale*(g' - c1 - xhat*c2) is formed on the fly
+ * and also written to dy_out (may be NULL) for the data-gradient convolution that follows -- the separate apply pass disappears. */
+int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                         const float* c12, float* dy_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
+                         size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);
 
 /* ---- objective and optimizer of the recipe (pretrain.py:72-88,:125-128; pretrain.yaml:44-54)
  * NLL, mean over targets != ignore_index (pass -1 for "none"): loss_out[0] = loss, loss_out[1] = 1/count;

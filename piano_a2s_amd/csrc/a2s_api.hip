@@ -50,7 +50,8 @@ int a2s_staff_emb_bwd_impl(hipStream_t, const float*, const float* const*, float
 int a2s_bn_bwd_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
                     float*, float*, float*, float*, float*, long, int, int);
 size_t a2s_bn_bwd_partial_floats_impl(long, int, int);
-int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int);
+int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int,
+                           const float*, const float*, const float*, const float*, const float*, const float*, float*);
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int, int);
 
 int a2s_nll_loss_impl(hipStream_t, const float*, const long long*, long, int, long long, float*, float*, float, double*, int);
@@ -208,7 +209,14 @@ int a2s_bn_bwd(void* stream, const float* g, const float* x, const float* mean, 
 size_t a2s_bn_bwd_partial_floats(long rows, int C, int F) { return a2s_bn_bwd_partial_floats_impl(rows, C, F); }
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
                       size_t workspace_bytes, int B, int T, int F, int Cin, int Cout) {
-    return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout);
+    return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr);
+}
+int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                         const float* c12, float* dy_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
+                         size_t workspace_bytes, int B, int T, int F, int Cin, int Cout) {
+    if (!y) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_wgrad_bn: y is required"); return A2S_ERR_ARG; }
+    return a2s_conv3x3_wgrad_impl(ST, g, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, y, mean, invstd, scale, shift, c12, dy_out);
 }
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) { return a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout); }
 

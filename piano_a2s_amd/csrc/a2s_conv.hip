@@ -529,14 +529,30 @@ __global__ void bn_bwd_apply(const float* __restrict__ g, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------- conv weight gradient
+// Optional fused BatchNorm backward of the layer's OUTPUT side: instead of a ready dy the kernel gets g (gradient wrt the activation
+// relu(bn(y))) and y (the layer's pre-BN output) and forms  dy = scale_c * (g' - c1_c - (y - mean_c) * invstd_c * c2_c),
+// g' = g where bn(y) > 0 else 0  (exactly bn_bwd_apply) while staging -- and writes dy out for the data-gradient convolution that
+// follows.  The weight-gradient kernels are MFMA-bound with HBM bandwidth to spare, so the separate apply pass (read g, y, write dx:
+// 71 GB per 40-channel layer at B = 256) disappears from the step.
+struct BnBwdFuse {
+    const float* y;          // (B, T, Cout, F) pre-BN output of this layer; null = dy is given ready-made
+    const float* mean; const float* invstd; const float* scale; const float* shift;
+    const float* c12;        // [Cout][2] = (sum g', sum g' xhat) / count  (bn_bwd_finalize)
+    float* dy_out;           // (B, T, Cout, F) or null
+};
+__device__ __forceinline__ float bn_bwd_value(float g, float yv, float mean, float invstd, float scale, float shift, float c1, float c2) {
+    const float gm = (yv * scale + shift > 0.f) ? g : 0.f;
+    return scale * (gm - c1 - (yv - mean) * invstd * c2);
+}
+
 // dW[co][ci][tap] += sum_{b,t,f} dy[b,t,co,f] * in[b, t+dt-1, ci, f+df-1],  in = relu(x*scale+shift) (or x).
 // GEMM view on v_mfma_f32_16x16x4_f32: M = co, N = (ci_local, tap) of one 20-channel chunk (blockIdx.y), K = positions
 // (4 consecutive f per MFMA).  gridDim.x persistent workgroups walk the (b, 4-row strip, 32-column) tiles; each writes
 // ONE partial slab [Cout][180]; wgrad_reduce sums the slabs in fixed order (deterministic).
-template <int COUT>
+template <int COUT, bool BN>
 __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                     float* __restrict__ partial, int B, int T, int F, int Cin) {
+                                                     float* __restrict__ partial, int B, int T, int F, int Cin, BnBwdFuse bn) {
     constexpr int MT = (COUT + 15) / 16;
     constexpr int NTW = 3;                               // n-tiles per wave: 4 waves x 3 x 16 = 192 >= 180
     // LDS layouts chosen by exhaustive search for conflict-free fragment reads (each half-wave = 16 M/N indices x 2 k-slots must
@@ -585,7 +601,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
         // (producer's BN+ReLU) and stored to LDS
         constexpr int XIT = (CV_CK * (CV_TR + 2) * (CV_FT / 4) + 255) / 256;      // 4
         constexpr int DIT = (COUT * CV_TR * (CV_FT / 4) + 255) / 256;             // 5 (Cout 40) / 3 (Cout 20)
-        f32x4 xreg[XIT], dreg[DIT];
+        f32x4 xreg[XIT], dreg[DIT], yreg[BN ? DIT : 1];
         float hreg = 0.f;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -620,14 +636,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
                 const int j = e % (CV_FT / 4), row = e / (CV_FT / 4);
                 const int r = row % CV_TR, co = row / CV_TR;
                 const int t = t0 + r, f = f0 + 4 * j;
+                f32x4 yv = {0.f, 0.f, 0.f, 0.f};
                 if (t < T && f < F) {
-                    const float* src = dy + (((long)b * T + t) * COUT + co) * F + f;
-                    if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
-                    else {
+                    const long off = (((long)b * T + t) * COUT + co) * F + f;
+                    if (vec_ok && f + 3 < F) {
+                        v = *reinterpret_cast<const f32x4*>(dy + off);
+                        if (BN) yv = *reinterpret_cast<const f32x4*>(bn.y + off);
+                    } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+                        for (int q = 0; q < 4; ++q) if (f + q < F) { v[q] = dy[off + q]; if (BN) yv[q] = bn.y[off + q]; }
                     }
                 }
+                if (BN) yreg[it] = yv;
             }
             dreg[it] = v;
         }
@@ -663,8 +683,24 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ d
             if (e < COUT * CV_TR * (CV_FT / 4)) {
                 const int j = e % (CV_FT / 4), row = e / (CV_FT / 4);
                 const int r = row % CV_TR, co = row / CV_TR;
+                f32x4 v = dreg[it];
+                if (BN) {                   // fused BatchNorm backward (positions outside the image stay 0)
+                    const int t = t0 + r, f = f0 + 4 * j;
+                    const float mean = bn.mean[co], invstd = bn.invstd[co], sc = bn.scale[co], sh = bn.shift[co];
+                    const float c1 = bn.c12[2 * co], c2 = bn.c12[2 * co + 1];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (t < T && f + q < F) ? bn_bwd_value(v[q], yreg[it][q], mean, invstd, sc, sh, c1, c2) : 0.f;
+                    if (bn.dy_out && blockIdx.y == 0 && t < T && f < F) {
+                        float* dst = bn.dy_out + (((long)b * T + t) * COUT + co) * F + f;
+                        if (vec_ok && f + 3 < F) *reinterpret_cast<f32x4*>(dst) = v;
+                        else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (f + q < F) dst[q] = v[q];
+                        }
+                    }
+                }
                 float2* dst = reinterpret_cast<float2*>(ldy + (r * MT * 16 + co) * DRS + 4 * j);
-                dst[0] = make_float2(dreg[it][0], dreg[it][1]); dst[1] = make_float2(dreg[it][2], dreg[it][3]);
+                dst[0] = make_float2(v[0], v[1]); dst[1] = make_float2(v[2], v[3]);
             }
         }
         __syncthreads();
@@ -724,7 +760,7 @@ __global__ void wgrad_reduce(const float* __restrict__ partial, float* __restric
 // tap sums in registers; one slab [Cout][9] per workgroup, reduced in fixed order by wgrad_reduce_c1.
 #define C1W_PARTS 12
 __global__ __launch_bounds__(256) void conv3x3_wgrad_c1(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
-                                                        int B, int T, int F, int Cout) {
+                                                        int B, int T, int F, int Cout, BnBwdFuse bn) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* ldy = sm;                            // Cout * F
     float* lx = sm + Cout * F;                  // 3 * (F + 2)
@@ -743,7 +779,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c1(const float* __restrict_
         const long b = row / T;
         __syncthreads();
         const float* drow = dy + row * (long)Cout * F;
-        if (vec_ok) {
+        if (bn.y) {                         // fused BatchNorm backward of the dy operand (see BnBwdFuse)
+            const float* yrow = bn.y + row * (long)Cout * F;
+            for (int e = tid; e < Cout * F; e += 256) {
+                const int c = e / F;
+                const float v = bn_bwd_value(drow[e], yrow[e], bn.mean[c], bn.invstd[c], bn.scale[c], bn.shift[c], bn.c12[2 * c], bn.c12[2 * c + 1]);
+                ldy[e] = v;
+                if (bn.dy_out) bn.dy_out[row * (long)Cout * F + e] = v;
+            }
+        } else if (vec_ok) {
             for (int e = tid; e < Cout * F / 4; e += 256) reinterpret_cast<f32x4*>(ldy)[e] = reinterpret_cast<const f32x4*>(drow)[e];
         } else {
             for (int e = tid; e < Cout * F; e += 256) ldy[e] = drow[e];
@@ -792,13 +836,17 @@ size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
 }
 
 int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
-                           float* ws, size_t ws_bytes, int B, int T, int F, int Cin, int Cout) {
+                           float* ws, size_t ws_bytes, int B, int T, int F, int Cin, int Cout, const float* bn_y, const float* bn_mean,
+                           const float* bn_invstd, const float* bn_scale, const float* bn_shift, const float* bn_c12, float* dy_out) {
     A2S_REQUIRE(dy && x && dW && ws, "conv3x3_wgrad: null tensor");
+    A2S_REQUIRE(!bn_y || (bn_mean && bn_invstd && bn_scale && bn_shift && bn_c12), "conv3x3_wgrad: the fused BatchNorm backward needs all of its tensors");
+    A2S_REQUIRE(!dy_out || bn_y, "conv3x3_wgrad: dy_out is only written by the fused BatchNorm backward");
+    const BnBwdFuse bn{bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_c12, dy_out};
     A2S_REQUIRE(ws_bytes >= a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout), "conv3x3_wgrad: workspace too small");
     if (Cin == 1 && !in_scale && Cout * C1W_PARTS <= 256 && (size_t)Cout * F >= 256 * 9) {
         const size_t shm = ((size_t)Cout * F + 3 * (F + 2)) * sizeof(float);
         if (shm <= 64 * 1024) {
-            hipLaunchKernelGGL(conv3x3_wgrad_c1, dim3(WGRAD_SLABS), dim3(256), shm, st, dy, x, ws, B, T, F, Cout);
+            hipLaunchKernelGGL(conv3x3_wgrad_c1, dim3(WGRAD_SLABS), dim3(256), shm, st, dy, x, ws, B, T, F, Cout, bn);
             A2S_CHECK_LAUNCH("conv3x3_wgrad_c1");
             hipLaunchKernelGGL(wgrad_reduce_c1, dim3(a2s_cdiv(Cout * 9, 256)), dim3(256), 0, st, ws, dW, WGRAD_SLABS, Cout * 9);
             A2S_CHECK_LAUNCH("wgrad_reduce_c1");
@@ -809,8 +857,10 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
     // persistent workgroups: one full round of the occupancy the kernel reaches (Cout 20: 3 per CU, Cout 40: 2 per CU by registers)
     const int slabs = Cout == 20 ? WGRAD_SLABS : 512;
     dim3 grid(slabs, chunks);
-    if (Cout == 20) hipLaunchKernelGGL(conv3x3_wgrad<20>, grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
-    else if (Cout == 40) hipLaunchKernelGGL(conv3x3_wgrad<40>, grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
+    if (Cout == 20 && !bn_y) hipLaunchKernelGGL((conv3x3_wgrad<20, false>), grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, bn);
+    else if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad<20, true>), grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, bn);
+    else if (Cout == 40 && !bn_y) hipLaunchKernelGGL((conv3x3_wgrad<40, false>), grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, bn);
+    else if (Cout == 40) hipLaunchKernelGGL((conv3x3_wgrad<40, true>), grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, bn);
     else A2S_FAIL(A2S_ERR_ARG, "conv3x3_wgrad: Cout must be 20 or 40 (got %d)", Cout);
     A2S_CHECK_LAUNCH("conv3x3_wgrad");
     const int n = Cout * CV_CK * 9 * chunks;
@@ -822,7 +872,7 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
 int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
                     const float* shift, const uint8_t* mask, float inv_keep, float* dgamma, float* dbeta, float* dx, float* partial,
                     float* c12, long rows, int C, int F) {
-    A2S_REQUIRE(g && x && mean && invstd && scale && shift && dgamma && dbeta && dx && partial && c12, "bn_bwd: null tensor");
+    A2S_REQUIRE(g && x && mean && invstd && scale && shift && dgamma && dbeta && partial && c12, "bn_bwd: null tensor");
     int nblocks;
     if (F > 1) {
         A2S_REQUIRE(!mask, "bn_bwd: dropout mask only supported on the (rows, C) layout");
@@ -836,6 +886,7 @@ int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float*
     A2S_CHECK_LAUNCH("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, st, partial, nblocks, C, (double)rows * F, dgamma, dbeta, c12);
     A2S_CHECK_LAUNCH("bn_bwd_finalize");
+    if (!dx) return A2S_OK;            // statistics only: the input gradient is formed by the consumer (a2s_conv3x3_wgrad_bn)
     const long n = rows * C * F;
     hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, mask,
                        inv_keep, dx, n, C, F);

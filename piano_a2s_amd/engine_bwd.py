@@ -8,6 +8,7 @@ does not depend on the recurrence is deferred and batched over all steps of a (b
   * attention key/value side: dEnc via a batched (T x steps)(steps x 2H) GEMM, dK via a tanh-recompute kernel.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -341,13 +342,21 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
     return dout                                              # (B, T, conv_feature_size)
 
 
+# A2S_FUSE_BN_APPLY=1: form the BatchNorm input gradient inside the weight-gradient kernel (a2s_conv3x3_wgrad_bn) instead of a separate
+# bn_bwd_apply pass.  Built and parity-tested, but OFF: the extra operand pushes conv3x3_wgrad<40> from 202 to 281 registers
+# (occupancy 2 -> 1) and the ConvStack backward got 19 % slower (409 -> 487 ms at B=256) instead of 14 % faster.
+_FUSE_BN_APPLY = os.environ.get("A2S_FUSE_BN_APPLY", "0") == "1"
+
+
 def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
     L = hip.lib()
     dev = d_out.device
     Cf = eng.cfg["conv_feature_size"]
     rows = B * T
 
-    def bn_bwd(g, x, bn, name, mask, n_rows, C_, F_):
+    def bn_bwd(g, x, bn, name, mask, n_rows, C_, F_, stats_only=False):
+        """stats_only: dgamma / dbeta and the two per-channel means (returned) only -- the input gradient is then formed inside the
+        weight-gradient kernel (a2s_conv3x3_wgrad_bn)."""
         mean, invstd, scale, shift = bn
         part = torch.empty(L.a2s_bn_bwd_partial_floats(C.c_long(n_rows), C_, F_), dtype=torch.float32, device=dev)
         c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
@@ -363,8 +372,9 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                                          hip._p(G[name + ".bias"]), hip._p(g), hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd_apply")
             return g
         hip.check(L.a2s_bn_bwd(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(mask), hip.f32(1.0 / 0.8),
-                               hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), hip._p(g), hip._p(part), hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd")
-        return g                                              # in place: g now holds dx
+                               hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), NULL if stats_only else hip._p(g), hip._p(part), hip._p(c12),
+                               C.c_long(n_rows), C_, F_), "a2s_bn_bwd")
+        return c12 if stats_only else g                       # in place: g now holds dx
 
     # dropout + ReLU + BatchNorm1d over the (B*T, Cf) Linear output
     g = d_out.reshape(rows, Cf).contiguous()
@@ -378,13 +388,23 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
     for i in (4, 3, 2, 1):
         ci, co = chans[i - 1]
         y = cs["y"][i - 1]                                    # pre-BN conv output of this layer
-        dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F)
         x_in = cs["y"][i - 2] if i > 1 else cs["x0"]
         in_bn = cs["bn"][i - 2] if i > 1 else None
         nb = L.a2s_conv3x3_wgrad_workspace_bytes(ci, co)
         ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
-        hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
-                                      hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
+        if eng.sync_bn or not _FUSE_BN_APPLY:
+            dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F)
+            hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
+                                          hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
+        else:
+            # BatchNorm backward: statistics pass only; dy = scale (g' - c1 - xhat c2) is formed by the weight-gradient kernel while
+            # it stages its dy operand (MFMA-bound, HBM to spare) and written out for the data-gradient convolution below
+            bn_i = cs["bn"][i - 1]
+            c12 = bn_bwd(g, y, bn_i, f"convstack.bn{i}", None, rows, co, F, stats_only=True)
+            dy = torch.empty_like(g) if i > 1 else None
+            hip.check(L.a2s_conv3x3_wgrad_bn(hip.stream(), hip._p(g), hip._p(y), hip._p(bn_i[0]), hip._p(bn_i[1]), hip._p(bn_i[2]), hip._p(bn_i[3]),
+                                             hip._p(c12), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
+                                             hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad_bn")
         if i > 1:
             gprev = torch.empty((B, T, ci, F), dtype=torch.float32, device=dev)
             cws = hip.conv_workspace(co, dev)

@@ -396,3 +396,49 @@ def test_fused_rows_attention_forward_backward(dev, H, T, clips, groups, split):
     for k, e in errs.items():
         _report(f"fused rows H{H} T{T} clips{clips} groups{groups} split={split} {k}", e)
     assert max(errs.values()) < 5e-5, errs
+
+
+@pytest.mark.parametrize("Cin,Cout,F", [(20, 40, 48), (40, 40, 40), (1, 20, 480), (1, 20, 24)])
+def test_weight_gradient_with_fused_batchnorm_backward(dev, Cin, Cout, F):
+    """a2s_conv3x3_wgrad_bn (BatchNorm input gradient formed while staging the dy operand, dy written out) against the two-pass form
+    a2s_bn_bwd (statistics + apply) followed by a2s_conv3x3_wgrad: same dW, same dy."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    B, T = 2, 9
+    g0 = torch.Generator().manual_seed(Cin * 100 + Cout + F)
+    gact = torch.randn(B, T, Cout, F, generator=g0).to(dev)
+    y = torch.randn(B, T, Cout, F, generator=g0).to(dev)
+    x = torch.randn(B, T, Cin, F, generator=g0).to(dev)
+    mean, invstd = (torch.randn(Cout, generator=g0) * 0.1).to(dev), (torch.rand(Cout, generator=g0) + 0.5).to(dev)
+    gamma, beta = (torch.rand(Cout, generator=g0) + 0.5).to(dev), (torch.randn(Cout, generator=g0) * 0.1).to(dev)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    in_scale = (torch.rand(Cin, generator=g0) + 0.5).to(dev) if Cin > 1 else None
+    in_shift = (torch.randn(Cin, generator=g0) * 0.1).to(dev) if Cin > 1 else None
+    rows = B * T
+    part = torch.empty(L.a2s_bn_bwd_partial_floats(C.c_long(rows), Cout, F), device=dev)
+    nb = L.a2s_conv3x3_wgrad_workspace_bytes(Cin, Cout)
+    ws = torch.empty(nb // 4, device=dev)
+
+    def stats(dx):
+        dgam, dbet, c12 = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev), torch.empty(2 * Cout, device=dev)
+        hip.check(L.a2s_bn_bwd(hip.stream(), hip._p(gact), hip._p(y), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), NULL, hip.f32(1.0),
+                               hip._p(dgam), hip._p(dbet), hip._p(dx), hip._p(part), hip._p(c12), C.c_long(rows), Cout, F), "bn_bwd")
+        return dgam, dbet, c12
+    # two passes
+    dy_ref = torch.empty_like(gact)
+    dgam_ref, dbet_ref, _ = stats(dy_ref)
+    dW_ref = torch.zeros(Cout, Cin, 3, 3, device=dev)
+    hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy_ref), hip._p(x), hip._p(in_scale), hip._p(in_shift), hip._p(dW_ref), hip._p(ws), C.c_size_t(nb),
+                                  B, T, F, Cin, Cout), "wgrad")
+    # fused
+    dgam, dbet, c12 = stats(None)
+    dy = torch.full_like(gact, 7.0)
+    dW = torch.zeros(Cout, Cin, 3, 3, device=dev)
+    hip.check(L.a2s_conv3x3_wgrad_bn(hip.stream(), hip._p(gact), hip._p(y), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(c12),
+                                     hip._p(dy), hip._p(x), hip._p(in_scale), hip._p(in_shift), hip._p(dW), hip._p(ws), C.c_size_t(nb), B, T, F, Cin, Cout),
+              "wgrad_bn")
+    torch.cuda.synchronize()
+    errs = {"dy": _rel(dy, dy_ref), "dW": _rel(dW, dW_ref), "dgamma": _rel(dgam, dgam_ref), "dbeta": _rel(dbet, dbet_ref)}
+    for k, e in errs.items():
+        _report(f"wgrad+bn fused Cin{Cin} Cout{Cout} F{F} {k}", e)
+    assert max(errs.values()) < 2e-5, errs
