@@ -86,7 +86,7 @@ def attention_roofline(step, batch_dev, B, T, H, iters=50):
     from piano_a2s_amd import hip
     L = hip.lib()
     dev = batch_dev[0].device
-    keys = torch.randn(B, T, H, device=dev) * 0.5
+    keys = torch.exp(2 * torch.randn(B, T, H, device=dev) * 0.5)      # the kernels take the key image exp(2K)
     enc = torch.randn(B, T, 2 * H, device=dev)
     q = torch.randn(B, H, device=dev) * 0.5
     v = torch.randn(H, device=dev) * 0.3

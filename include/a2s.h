@@ -33,7 +33,7 @@ int a2s_version(void);
 
 /* ---- dense contraction: every nn.Linear / GRU projection of models.py (:68,:123-132,:359,:444-445,:504) and
  * their backward forms.  C[m,n] = act(alpha * sum_k A(m,k) B(k,n) + beta*C + bias[n]);
- * A(m,k)=A[m*sAm+k*sAk], B(k,n)=B[k*sBk+n*sBn]; act 0 none / 1 relu / 2 tanh; split-K is deterministic
+ * A(m,k)=A[m*sAm+k*sAk], B(k,n)=B[k*sBk+n*sBn]; act 0 none / 1 relu / 2 tanh / 3 exp(2x) (the attention key image below); split-K is deterministic
  * (splitk 0 = pick automatically for skinny problems when a workspace is supplied). */
 int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
@@ -74,7 +74,10 @@ int a2s_gru_seq_fwd(void* stream, const float* gi_all, long gi_bstride, long gi_
 /* workspace (optional): split-K scratch for the per-step recurrent GEMM (M = B rows, few output tiles) */
 
 /* ---- additive attention step (AttentionLayer.forward models.py:452-461 + bmm :242,:394), keys hoisted:
- * score_t = v . tanh(K[b,t,:] + q[b,:]); a = softmax_t; ctx = sum_t a_t enc[b,t,:]. */
+ * score_t = v . tanh(K[b,t,:] + q[b,:]); a = softmax_t; ctx = sum_t a_t enc[b,t,:].
+ * `keys` of every attention entry point is the KEY IMAGE exp(2 K) (a2s_gemm_f32 with act 3 on K = enc W_e^T; |K| clamped to 43), not K:
+ * tanh(k + q) = 1 - 2 / (1 + exp(2k) exp(2q)) then costs one transcendental per (frame, unit).  q is passed as is; the gradient
+ * a2s_attn_dk_accum returns is the one with respect to K. */
 int a2s_attn_step_fwd(void* stream, const float* keys, const float* enc, const float* q, long ldq, const float* v,
                       float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
                       const int* n_done, int n_rows_total, float* workspace);

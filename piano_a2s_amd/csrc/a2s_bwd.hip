@@ -114,12 +114,9 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
     __syncthreads();
     // pass over K: thread j accumulates dq_j over all frames (H <= 256 threads active)
     if (tid < H) {
-        const float qj = q[(long)b * ldq + tid], vj = v[tid];
+        const float eq = exp2x_clamped(q[(long)b * ldq + tid]), vj = v[tid];      // Kmat holds the key image E_K = exp(2K)
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float e = fast_tanh(Kb[(long)t * H + tid] + qj);
-            acc = fmaf(dsv[t], 1.f - e * e, acc);
-        }
+        for (int t = 0; t < T; ++t) acc = fmaf(dsv[t], sech2_ek(Kb[(long)t * H + tid], eq), acc);
         dq[(long)b * lddq + tid] = acc * vj;
     }
 }
@@ -173,10 +170,10 @@ __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ K
         if (threadIdx.x < TT) dss[threadIdx.x] = (t0 + threadIdx.x < T) ? ds_all[row * T + t0 + threadIdx.x] : 0.f;
         __syncthreads();
         if (j < H) {
-            const float qj = q_all[row * H + j];
+            const float eq = exp2x_clamped(q_all[row * H + j]);               // kreg holds the key image E_K = exp(2K)
 #pragma unroll
             for (int i = 0; i < TT; ++i) {
-                const float e = fast_tanh(kreg[i] + qj);
+                const float e = tanh_ek(kreg[i], eq);
                 acc[i] = fmaf(dss[i], 1.f - e * e, acc[i]);
                 dvj = fmaf(dss[i], e, dvj);
             }
@@ -554,7 +551,9 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
     __syncthreads();
     // ---- pass B: dq_j += ds_t (1 - tanh^2(K_tj + q_j)); thread = (float4 column, row group of 4)
     const int c4 = tid & 63, rg = tid >> 6;
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)b * ldq + c4 * 4);
+    f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)b * ldq + c4 * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = exp2x_clamped(q4[c]);                 // E_q; Kmat holds the key image E_K = exp(2K)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int i = rg;
     for (; i + 12 < n; i += 16) {
@@ -565,14 +564,14 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
         for (int u = 0; u < 4; ++u) {
             const float w = dsv[i + 4 * u];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k[u][c] + q4[c]); acc[c] = fmaf(w, 1.f - e * e, acc[c]); }
+            for (int c = 0; c < 4; ++c) acc[c] = fmaf(w, sech2_ek(k[u][c], q4[c]), acc[c]);
         }
     }
     for (; i < n; i += 4) {
         const f32x4 k0 = *reinterpret_cast<const f32x4*>(Kb + (long)i * H + c4 * 4);
         const float w = dsv[i];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k0[c] + q4[c]); acc[c] = fmaf(w, 1.f - e * e, acc[c]); }
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(w, sech2_ek(k0[c], q4[c]), acc[c]);
     }
     if (rg > 0) red4[(rg - 1) * 64 + c4] = acc;
     __syncthreads();
@@ -683,6 +682,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     for (int j = 0; j < NQ; ++j) {
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         q4[j] = on[j] ? *reinterpret_cast<const f32x4*>(q + ((long)j * n_clips + b) * ldq + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);       // E_q; Kmat holds the key image E_K = exp(2K)
     }
     int i = rg;
     for (; i + 12 < n; i += 16) {
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
             for (int u = 0; u < 4; ++u) {
                 const float w = dsv[j * chunk + i + 4 * u];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k[u][c] + q4[j][c]); acc[j][c] = fmaf(w, 1.f - e * e, acc[j][c]); }
+                for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(k[u][c], q4[j][c]), acc[j][c]);
             }
         }
     }
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
             if (!on[j]) continue;
             const float w = dsv[j * chunk + i];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float e = fast_tanh(k0[c] + q4[j][c]); acc[j][c] = fmaf(w, 1.f - e * e, acc[j][c]); }
+            for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(k0[c], q4[j][c]), acc[j][c]);
         }
     }
     if (rg > 0) {

@@ -121,6 +121,16 @@ __device__ __forceinline__ float fast_tanh(float x) {
     const float e = __expf(2.f * x);
     return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
+// Additive-attention energies through the KEY IMAGE E_K = exp(2 K) (written once per forward by the key projection's GEMM epilogue,
+// act 3) and E_q = exp(2 q) (once per row and step):  tanh(k + q) = 1 - 2 / (1 + E_K E_q)  is 3 instructions with ONE transcendental
+// per (frame, unit) instead of 8 with two -- the attention kernels that serve several rows per clip are bound by exactly this.
+// The clamp keeps both factors finite and normal (|x| <= 43: e^86 < FLT_MAX); a product that overflows gives rcp(inf) = 0 -> tanh = 1.
+__device__ __forceinline__ float exp2x_clamped(float x) { return __expf(2.f * fminf(fmaxf(x, -43.f), 43.f)); }
+__device__ __forceinline__ float tanh_ek(float ek, float eq) { return fmaf(-2.f, __builtin_amdgcn_rcpf(fmaf(ek, eq, 1.f)), 1.f); }
+__device__ __forceinline__ float sech2_ek(float ek, float eq) {      // 1 - tanh^2(k + q) = 4 r (1 - r), r = 1 / (1 + E_K E_q)
+    const float r = __builtin_amdgcn_rcpf(fmaf(ek, eq, 1.f));
+    return 4.f * r * (1.f - r);
+}
 __device__ __forceinline__ float fast_sigmoid(float x) {
     x = fminf(fmaxf(x, -30.f), 30.f);
     return __builtin_amdgcn_rcpf(1.f + __expf(-x));

@@ -19,7 +19,7 @@ struct GemmArgs {
     int M, N, K;
     long sAm, sAk, sBk, sBn, ldc;
     float alpha, beta;
-    int act;                // 0 none, 1 relu, 2 tanh
+    int act;                // 0 none, 1 relu, 2 tanh, 3 exp(2x) (attention key image)
     int batch; long bsA, bsB, bsC;
     int splitk; int kchunk; // kchunk: K range per split (multiple of 32)
     float* partial;         // [batch*splitk][M][N] when splitk > 1
@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                     if (g.beta != 0.f) v += g.beta * C[(long)m * ldc + n];
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = fast_tanh(v);
+    else if (g.act == 3) v = exp2x_clamped(v);
+                    else if (g.act == 3) v = exp2x_clamped(v);
                 }
                 C[(long)m * ldc + n] = v;
             }
@@ -188,6 +190,7 @@ __global__ void gemm_splitk_reduce(GemmArgs g) {
     if (g.beta != 0.f) v += g.beta * *c;
     if (g.act == 1) v = fmaxf(v, 0.f);
     else if (g.act == 2) v = fast_tanh(v);
+    else if (g.act == 3) v = exp2x_clamped(v);
     *c = v;
 }
 

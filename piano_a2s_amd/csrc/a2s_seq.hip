@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ K
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int j = lane + i * 64;
-        qv[i] = j < H ? q[(long)b * ldq + j] : 0.f;
+        qv[i] = j < H ? exp2x_clamped(q[(long)b * ldq + j]) : 0.f;      // E_q; Kmat holds the key image E_K = exp(2K)
         vv[i] = j < H ? v[j] : 0.f;
     }
     for (int t = wave; t < T; t += 4) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ K
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int j = lane + i * 64;
-            if (j < H) s = fmaf(vv[i], fast_tanh(Kb[(long)t * H + j] + qv[i]), s);
+            if (j < H) s = fmaf(vv[i], tanh_ek(Kb[(long)t * H + j], qv[i]), s);
         }
         s = wave_sum(s);
         if (lane == 0) sc[t] = s;
@@ -620,7 +620,9 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Kb = Kmat + ((long)b * T + t0) * H;
     const float* Eb = enc + ((long)b * T + t0) * 2 * H;
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)b * ldq + lane * 4);
+    f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)b * ldq + lane * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = exp2x_clamped(q4[c]);                               // E_q; Kmat holds the key image E_K = exp(2K)
     const f32x4 v4 = {v[lane * 4], v[lane * 4 + 1], v[lane * 4 + 2], v[lane * 4 + 3]};      // parameter (view of the flat buffer): 4-byte aligned only
     // ---- pass 1: scores of the chunk; one wave per frame, 4 frames in flight per wave
     for (int r = wave * 4; r < n; r += 16) {
@@ -631,8 +633,8 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
         float s[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            s[u] = v4[0] * fast_tanh(k[u][0] + q4[0]) + v4[1] * fast_tanh(k[u][1] + q4[1])
-                 + v4[2] * fast_tanh(k[u][2] + q4[2]) + v4[3] * fast_tanh(k[u][3] + q4[3]);
+            s[u] = v4[0] * tanh_ek(k[u][0], q4[0]) + v4[1] * tanh_ek(k[u][1], q4[1])
+                 + v4[2] * tanh_ek(k[u][2], q4[2]) + v4[3] * tanh_ek(k[u][3], q4[3]);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -715,6 +717,10 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
         q4[j] = on[j] ? *reinterpret_cast<const f32x4*>(q + ((long)j * n_clips + b) * ldq + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);                    // E_q; Kmat holds the key image E_K = exp(2K)
     const f32x4 v4 = {v[lane * 4], v[lane * 4 + 1], v[lane * 4 + 2], v[lane * 4 + 3]};
     // ---- pass 1: scores; one wave per frame, 4 frames in flight, every frame scored against the NQ queries
     for (int r = wave * 4; r < n; r += 16) {
@@ -728,8 +734,8 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
             float sj[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                sj[u] = v4[0] * fast_tanh(k[u][0] + q4[j][0]) + v4[1] * fast_tanh(k[u][1] + q4[j][1])
-                      + v4[2] * fast_tanh(k[u][2] + q4[j][2]) + v4[3] * fast_tanh(k[u][3] + q4[j][3]);
+                sj[u] = v4[0] * tanh_ek(k[u][0], q4[j][0]) + v4[1] * tanh_ek(k[u][1], q4[j][1])
+                      + v4[2] * tanh_ek(k[u][2], q4[j][2]) + v4[3] * tanh_ek(k[u][3], q4[j][3]);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll

@@ -237,10 +237,11 @@ class Engine:
 
     # ------------------------------------------------------------------ decoder pieces
     def _keys(self, S, prefix, enc2d, H):
-        """K = enc W_e^T with W_e = attn.weight[:, 2H:]  (step-invariant half of the attention Linear)."""
+        """Key image exp(2 K), K = enc W_e^T with W_e = attn.weight[:, 2H:]  (step-invariant half of the attention Linear); the
+        attention kernels form tanh(K + q) as 1 - 2 / (1 + exp(2K) exp(2q)) -- see include/a2s.h."""
         W = S[prefix + ".attn.weight"]
         K = self._empty(enc2d.shape[0], H, dev=enc2d.device)
-        hip.gemm(enc2d, 2 * H, 1, W, 1, 4 * H, K, H, enc2d.shape[0], H, 2 * H, b_off=2 * H)
+        hip.gemm(enc2d, 2 * H, 1, W, 1, 4 * H, K, H, enc2d.shape[0], H, 2 * H, b_off=2 * H, act=3)
         return K
 
     def _staff_token(self, S, ids, lengths, len_stride, out, col0, maxlen, id_bstride, ids_are_i64, record=None):

@@ -80,7 +80,7 @@ def test_attention_backward_step_and_deferred_keys(dev, H, T, B, S, split):
         ctxs.append(ctx.detach()); aws.append(a.detach())
         loss = loss + (ctx * dc).sum()
     loss.backward()
-    Kd, encd, vd = K.detach().to(dev), enc.detach().to(dev), v.detach().to(dev)
+    Kd, encd, vd = torch.exp(2 * K.detach()).to(dev), enc.detach().to(dev), v.detach().to(dev)      # the kernels take the key image exp(2K)
     q_all = torch.stack([q.detach() for q in qs]).to(dev)                    # (S,B,H)
     attw = torch.stack(aws).to(dev)
     ctx_all = torch.stack(ctxs).to(dev)
@@ -359,7 +359,7 @@ def test_fused_rows_attention_forward_backward(dev, H, T, clips, groups, split):
         ctxs.append((ctx * live).detach()); aws.append((a * live).detach())
         loss = loss + (ctx * dc * live).sum()
     loss.backward()
-    Kd, encd, vd = K.detach().to(dev), enc.detach().to(dev), v.detach().to(dev)
+    Kd, encd, vd = torch.exp(2 * K.detach()).to(dev), enc.detach().to(dev), v.detach().to(dev)      # the kernels take the key image exp(2K)
     q_all = torch.stack([q.detach() for q in qs]).to(dev)
     dctx_all = torch.stack(dctxs).to(dev)
     d_until, d_order, d_rank = until.to(dev), order.to(dev), rank.to(dev)

@@ -184,7 +184,7 @@ def test_attention_step(dev, H, T, B, split):
     ctx_ref = torch.bmm(a_ref.unsqueeze(1), enc).squeeze(1)
     encd, Wd = enc.to(dev), W.to(dev)
     keys = torch.empty(B * T, H, device=dev)
-    hip.gemm(encd, 2 * H, 1, Wd, 1, 4 * H, keys, H, B * T, H, 2 * H, b_off=2 * H)
+    hip.gemm(encd, 2 * H, 1, Wd, 1, 4 * H, keys, H, B * T, H, 2 * H, b_off=2 * H, act=3)      # key image exp(2K), see include/a2s.h
     q = torch.empty(B, H, device=dev)
     hd, biasd, vd = hid[0].to(dev), bias.to(dev), v.to(dev)
     hip.gemm(hd, 2 * H, 1, Wd, 1, 4 * H, q, H, B, H, 2 * H, bias=biasd)

@@ -29,7 +29,7 @@ def main():
     T, H = 1201, 256
     dev = torch.device("cuda:0")
     L = hip.lib()
-    K = torch.randn(clips, T, H, device=dev) * 0.5
+    K = torch.exp(2 * torch.randn(clips, T, H, device=dev) * 0.5)      # key image
     enc = torch.randn(clips, T, 2 * H, device=dev)
     v = torch.randn(H, device=dev) * 0.3
     algo = clips * T * 3 * H * 4.0

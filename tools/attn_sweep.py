@@ -3,7 +3,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from piano_a2s_amd import hip
 B = int(sys.argv[1]); T, H = 1201, 256
 L = hip.lib(); dev = torch.device("cuda:0")
-keys = torch.randn(B, T, H, device=dev) * 0.5; enc = torch.randn(B, T, 2 * H, device=dev)
+keys = torch.exp(2 * torch.randn(B, T, H, device=dev) * 0.5); enc = torch.randn(B, T, 2 * H, device=dev)
 q = torch.randn(B, H, device=dev) * 0.5; v = torch.randn(H, device=dev) * 0.3
 ctx = torch.empty(B, 2 * H, device=dev); attw = torch.empty(B, T, device=dev); ws = hip.attn_workspace(B, T, H, dev)
 dctx = torch.randn(B, 2 * H, device=dev); dq = torch.empty(B, H, device=dev); ds = torch.empty(B, T, device=dev)
