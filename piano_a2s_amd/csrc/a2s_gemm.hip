@@ -242,19 +242,32 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
     if (M <= 0 || N <= 0 || batch <= 0) return A2S_OK;
     A2S_REQUIRE(K >= 0 && A && B && C, "gemm: null operand or negative K");
     A2S_REQUIRE(splitk >= 0, "gemm: splitk must be >= 0 (0 = choose automatically when a workspace is given)");
+    // Mid-size row counts (the per-step products of a fused-bars decoder call: M = bars x batch rows, N <= 1792, K <= 1792):
+    // tools/gemm_sweep.py on MI355X -- 64x32 tiles beat 64x64 up to M = 1024 (more workgroups for the same work), and K is split
+    // 4 ways only while the tile count stays under one workgroup per CU.
+    const bool mid = M > 64 && M <= 2048 && batch == 1 && N <= 2048;
+    int mid_tile = 0;
+    if (mid) mid_tile = M <= 1024 ? 2 : 3;                 // 2: 64x32, 3: 64x64
     if (splitk == 0) {
         // Skinny per-step products (M = batch rows, K up to 1792): a handful of output tiles would leave most of the 256 CUs
         // idle and serialise 50+ K-tiles behind one barrier each; spread K over workgroups instead (deterministic reduce).
         splitk = 1;
-        const long bm = M <= 16 ? 16 : (M <= 32 ? 32 : 64), bn = M <= 64 ? (M <= 16 ? 64 : (M <= 32 ? 64 : 32)) : 64;
-        const long tiles = (long)a2s_cdiv(M, bm) * a2s_cdiv(N, bn) * batch;
-        if (ws && tiles < 192 && K >= 256) {
-            long s = (256 + tiles - 1) / tiles;
-            if (s > K / 64) s = K / 64;
-            if (s > 16) s = 16;
-            while (s > 1 && a2s_gemm_workspace_bytes_impl(M, N, batch, (int)s) > ws_bytes) --s;
-            if (s > 1) splitk = (int)s;
+        if (mid) {
+            const long tiles = (long)a2s_cdiv(M, 64) * a2s_cdiv(N, mid_tile == 2 ? 32 : 64);
+            if (ws && tiles < 256 && K >= 512 && a2s_gemm_workspace_bytes_impl(M, N, batch, 4) <= ws_bytes) splitk = 4;
+        } else {
+            const long bm = M <= 16 ? 16 : (M <= 32 ? 32 : 64), bn = M <= 64 ? (M <= 16 ? 64 : (M <= 32 ? 64 : 32)) : 64;
+            const long tiles = (long)a2s_cdiv(M, bm) * a2s_cdiv(N, bn) * batch;
+            if (ws && tiles < 192 && K >= 256) {
+                long s = (256 + tiles - 1) / tiles;
+                if (s > K / 64) s = K / 64;
+                if (s > 16) s = 16;
+                while (s > 1 && a2s_gemm_workspace_bytes_impl(M, N, batch, (int)s) > ws_bytes) --s;
+                if (s > 1) splitk = (int)s;
+            }
         }
+    } else {
+        mid_tile = 0;                                       // explicit split count: the caller's (wgrad-type) shape rules apply
     }
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
@@ -272,7 +285,9 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
     g.vecA = (akc ? (sAk == 1 && aligned(A, sAm, bsA)) : (sAm == 1 && aligned(A, sAk, bsA))) ? 1 : 0;
     g.vecB = (bkc ? (sBk == 1 && aligned(B, sBn, bsB)) : (sBn == 1 && aligned(B, sBk, bsB))) ? 1 : 0;
 
-    if (g_force_tile && M > 64) {
+    if (!g_force_tile && mid_tile == 2 && g.splitk >= 1 && M * (long)N < (1L << 22)) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);
+    else if (!g_force_tile && mid_tile == 3 && M * (long)N < (1L << 22)) launch_cfg<64, 64, 2, 2>(g, akc, bkc, st);
+    else if (g_force_tile && M > 64) {
         switch (g_force_tile) {
             case 1: launch_cfg<32, 64, 2, 2>(g, akc, bkc, st); break;
             case 2: launch_cfg<64, 32, 4, 1>(g, akc, bkc, st); break;
