@@ -148,9 +148,12 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     return dh[0]
 
 
-def backward(eng, S, grad_outputs):
+def backward(eng, S, grad_outputs, grad_ready=None):
     """Gradients of sum_i <out_i, grad_outputs_i> wrt every parameter.  Returns dict name -> tensor (views of ONE flat buffer,
-    also returned as `flat` under key None) in state_dict parameter order."""
+    also returned as `flat` under key None) in state_dict parameter order.
+    grad_ready(flat, start, end): optional callback, called when flat[start:end] is final (everything that writes it has been
+    enqueued on the current stream) -- first the encoder + decoder slice, then the ConvStack slice; train.GradientExchange starts
+    the data-parallel all-reduce of a slice there, under the rest of the backward pass."""
     from .spec import is_buffer
     sv = eng.saved
     assert sv["training"], "backward needs a forward run with training=True (batch statistics / saved activations)"
@@ -285,7 +288,12 @@ def backward(eng, S, grad_outputs):
         hip.gemm(dKp, 1, H, enc2d, H2, 1, G[Wn], 4 * H, H, H2, B * T, beta=1.0, splitk=sk, c_off=H2)
         hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2)
     d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T)
+    n_conv = next(off for k, off in zip(names, offs) if not k.startswith("convstack."))      # state_dict order: convstack first
+    if grad_ready is not None:
+        grad_ready(flat, n_conv, total)
     _convstack_bwd(eng, S, G, sv["conv"], d_conv, B, T, F)
+    if grad_ready is not None:
+        grad_ready(flat, 0, n_conv)
     G[None] = flat
     eng._keep_alive = keep_alive
     return G

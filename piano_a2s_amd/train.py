@@ -33,6 +33,30 @@ def average_gradients(flat_g, world):
     return flat_g
 
 
+class GradientExchange:
+    """The same exchange, overlapped with the backward pass: engine_bwd.backward announces contiguous slices of the flat gradient
+    buffer as soon as they are final (decoder + encoder parameters first -- 89 % of the bytes -- while the ConvStack backward, 40 %
+    of the step, is still to run; then the ConvStack slice), each slice is all-reduced asynchronously on the collective's own stream,
+    and finish() waits for all of them and divides by the world size.  One all-reduce per slice, bit-identical to average_gradients."""
+
+    def __init__(self, world):
+        self.world = world
+        self.active = world > 1 or (dist.is_available() and dist.is_initialized() and world == 1 and _FORCE_COLLECTIVES)
+        self.pending = []
+
+    def slice_ready(self, flat_g, start, end):
+        if self.active and end > start:
+            self.pending.append(dist.all_reduce(flat_g[start:end], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self, flat_g):
+        for work in self.pending:
+            work.wait()
+        self.pending = []
+        if self.active and self.world > 1:
+            flat_g.div_(self.world)
+        return flat_g
+
+
 def broadcast_parameters(flat_p, src=0):
     """Make every replica start from rank `src`'s parameters (what DDP's constructor does)."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES):
@@ -129,9 +153,9 @@ class TrainStep:
             outs = (outs[0], outs[1], outs[2].transpose(0, 1), outs[3].transpose(0, 1))
         else:
             losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
-        G = engine_bwd.backward(eng, S, gouts)
-        flat_g = G[None]
-        average_gradients(flat_g, self.world)
+        exchange = GradientExchange(self.world)
+        G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready)
+        flat_g = exchange.finish(G[None])
         torch.sum(losses[:, 0], dim=0, keepdim=True, out=self.total)          # total loss stays on the device
         self.opt.step(flat_g, self.total, zero_grad=False)
         eng.saved = None

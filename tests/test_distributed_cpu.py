@@ -53,7 +53,14 @@ def _worker(rank, world, port, outdir):
     train.broadcast_parameters(flat_p, src=0)
     g_local = _rank_gradient(rank, 11)
     g = train.average_gradients(g_local.clone(), world)
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=flat_p.numpy(), g_local=g_local.numpy(), g=g.numpy())
+    # the overlapped form the fused step uses: slices announced as the backward pass finishes them (later parameters first)
+    ex = train.GradientExchange(world)
+    g2 = g_local.clone()
+    cut = g2.numel() // 3
+    ex.slice_ready(g2, cut, g2.numel())
+    ex.slice_ready(g2, 0, cut)
+    g2 = ex.finish(g2)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=flat_p.numpy(), g_local=g_local.numpy(), g=g.numpy(), g2=g2.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,6 +76,7 @@ def test_two_rank_gradient_exchange(tmp_path):
     ref_p = torch.cat([v.reshape(-1) for v in P0.values()]).numpy()
     assert np.array_equal(r[0]["params"], ref_p) and np.array_equal(r[1]["params"], ref_p), "broadcast from rank 0"
     assert np.array_equal(r[0]["g"], r[1]["g"]), "both ranks must hold the identical reduced gradient"
+    assert np.array_equal(r[0]["g2"], r[0]["g"]) and np.array_equal(r[1]["g2"], r[0]["g"]), "slice-wise overlapped exchange == one all-reduce"
     mean = (r[0]["g_local"].astype(np.float64) + r[1]["g_local"].astype(np.float64)) / 2
     assert np.abs(r[0]["g"] - mean).max() <= 1e-6 * max(1.0, np.abs(mean).max())
     assert np.abs(r[0]["g_local"] - r[1]["g_local"]).max() > 0, "ranks must have seen different minibatches"
