@@ -457,7 +457,9 @@ class Engine:
         # per-staff scratch (split-T attention partials, split-K slabs): the two staves run concurrently on two streams
         attn_ws = [hip.attn_workspace(B, T, H, dev, groups=max_rows // B) for _ in range(2)]
         gemm_ws = [hip.gemm_workspace(max_rows, dev) for _ in range(2)]
-        concurrent = gt_cpu is not None and getattr(self, "concurrent_staves", True)    # greedy decode polls the device: sequential
+        # the two staves of a segment run on two streams, each issued by its own host thread -- also in greedy decoding, where each
+        # thread polls the done counter of its own stream (the hipGraph variant captures on one created stream and stays sequential)
+        concurrent = getattr(self, "concurrent_staves", True) and not (gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH))
         streams = side_streams(dev) if concurrent else None
 
         def bar_step(bar, token, hidden):
@@ -580,6 +582,9 @@ class Engine:
             for (name, _), (ids, lengths, sv) in zip(calls, join()):     # the next token / next bar may read what the staves produced
                 sv["groups"] = nb
                 staff[name] = (ids, lengths, sv)
+                if concurrent and gt_cpu is None:
+                    for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference (upper, then lower)
+                        rng.random()
             seg_saved.append(dict(bars=seg, staff=staff))
             for bar in seg:
                 bar_saved[bar]["staff"] = staff            # (shared by the bars of a fused segment)
