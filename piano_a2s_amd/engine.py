@@ -94,11 +94,14 @@ def fork_on_streams(device, streams, fns):
             _ISSUE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="a2s-issue")
         futures = [_ISSUE_POOL.submit(task, st, fn) for st, fn in zip(streams, fns)]
 
-    def join():
+    def join(wait=True):
+        """wait=False: the caller's stream is NOT made to wait; returns (results, [events to wait for later])."""
         res = results if futures is None else [f.result() for f in futures]
-        for _, done in res:
-            if done is not None:
-                torch.cuda.current_stream().wait_event(done)
+        events = [done for _, done in res if done is not None]
+        if not wait:
+            return [r for r, _ in res], events
+        for done in events:
+            torch.cuda.current_stream().wait_event(done)
         return [r for r, _ in res]
     return join
 

@@ -202,11 +202,16 @@ def backward(eng, S, grad_outputs, grad_ready=None):
             else:
                 dpr, pr = dout[:, bar0], out_t[:, bar0]
             calls.append((eng, S, G, seg["staff"][name][2], sv["keys"][prefix], enc, dpr, pr, dK[prefix], dEnc_staff[si], B, T))
-        if concurrent:      # one host thread per staff (engine.fork_on_streams)
-            dh0s = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])()
+        if concurrent:      # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
+            seg_dh0[si_seg] = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
         else:
-            dh0s = [_note_decoder_bwd(*args) for args in calls]
-        seg_dh0[si_seg] = dh0s
+            seg_dh0[si_seg] = ([_note_decoder_bwd(*args) for args in calls], [])
+
+    # The note decoders' backward passes only need the loss gradients: all segments are enqueued up front (last segment first, as the
+    # bar chain below consumes them), so the two staff streams run through every segment back to back instead of draining at each
+    # segment boundary while the bar-level chain catches up.
+    for si_seg in reversed(range(len(sv["segments"]))):
+        segment_decoders_bwd(si_seg)
 
     d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
     d_token_next = None         # gradient wrt the (pre-dropout) token that bar k produced for bar k+1
@@ -238,9 +243,10 @@ def backward(eng, S, grad_outputs, grad_ready=None):
         # ---- (3) note decoders: both start from bar_summary
         d_hnew = torch.zeros((B, H2), dtype=torch.float32, device=dev)
         si_seg, j = b["seg"]
-        if si_seg not in seg_dh0:
-            segment_decoders_bwd(si_seg)
-        for dh0 in seg_dh0[si_seg]:
+        dh0s, events = seg_dh0[si_seg]
+        for ev in events:
+            torch.cuda.current_stream().wait_event(ev)
+        for dh0 in dh0s:
             d_hnew.add_(dh0[j * B:(j + 1) * B])
         d_hnew.add_(d_headin[:, :H2])
         if d_hid_carry is not None:
