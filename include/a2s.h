@@ -38,6 +38,13 @@ int a2s_version(void);
 int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
                  int batch, long bsA, long bsB, long bsC, int splitk, float* workspace, size_t workspace_bytes);
+/* The same with BatchNorm + ReLU of an operand applied while it is staged: element -> max(0, e*scale[c] + shift[c]), c = (index along
+ * the operand's unit-stride dimension) / period; NULL scale = operand taken as is.  The 19200->256 Linear (models.py:537-539) reads the
+ * last convolution's pre-BN output this way (forward: A; weight gradient: B), so the activated tensor is never materialised. */
+int a2s_gemm_f32_affine(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk, const float* B, long sBk,
+                        long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,
+                        int splitk, float* workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_period,
+                        const float* b_scale, const float* b_shift, int b_period);
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch);
 /* tuning aid (tools/gemm_sweep.py): force the tile configuration for M > 64 (1: 32x64, 2: 64x32, 3: 64x64, 4: 128x128; 0: heuristic) */

@@ -9,6 +9,8 @@ thread_local char a2s_err_msg[512] = {0};
 int a2s_gemm_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long,
                   const float*, int, int, long, long, long, int, float*, size_t);
 size_t a2s_gemm_workspace_bytes_impl(int, int, int, int);
+int a2s_gemm_affine_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long, const float*,
+                         int, int, long, long, long, int, float*, size_t, const float*, const float*, int, const float*, const float*, int);
 int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*);
 size_t a2s_conv3x3_workspace_floats_impl(int);
 int a2s_conv3x3_stat_blocks_impl(int, int, int, int);
@@ -76,6 +78,13 @@ int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A,
                  int splitk, float* workspace, size_t workspace_bytes) {
     return a2s_gemm_impl(ST, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk,
                          workspace, workspace_bytes);
+}
+int a2s_gemm_f32_affine(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk, const float* B, long sBk,
+                        long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,
+                        int splitk, float* workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_period,
+                        const float* b_scale, const float* b_shift, int b_period) {
+    return a2s_gemm_affine_impl(ST, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk,
+                                workspace, workspace_bytes, a_scale, a_shift, a_period, b_scale, b_shift, b_period);
 }
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk) { return a2s_gemm_workspace_bytes_impl(M, N, batch, splitk); }
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch) { return a2s_gemm_pick_splitk_impl(M, N, K, batch); }

@@ -24,6 +24,11 @@ struct GemmArgs {
     int splitk; int kchunk; // kchunk: K range per split (multiple of 32)
     float* partial;         // [batch*splitk][M][N] when splitk > 1
     int vecA, vecB;         // 16-byte loads allowed along the operand's unit-stride dimension
+    // optional BatchNorm+ReLU of an operand applied while it is staged: element -> max(0, e * scale[c] + shift[c]) with
+    // c = (index along the operand's unit-stride dimension) / period.  Lets the 19200->256 Linear read the last convolution's raw
+    // output (forward: A, k-contiguous; weight gradient: B, n-contiguous) -- the activated copy is never written.
+    const float* a_scale; const float* a_shift; int a_period;
+    const float* b_scale; const float* b_shift; int b_period;
 };
 
 #define GEMM_BK 32
@@ -39,7 +44,8 @@ template <int ROWS, bool KC> struct LdsTile {
 // One operand tile: ROWS (m or n) x 32 (k).  elem(r,k) = P[r*sR + k*sK].
 template <int ROWS, bool KC, int NLD>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, long sR, long sK, int r0, int k0,
-                                          int rmax, int kmax, bool vec, f32x4 (&reg)[NLD]) {
+                                          int rmax, int kmax, bool vec, f32x4 (&reg)[NLD], float (&aff)[NLD][2],
+                                          const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr, int period = 1) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -47,6 +53,11 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, long sR, 
         int r, k;
         if (KC) { r = slot >> 3; k = (slot & 7) * 4; }                 // 8 float4 per row of 32 k
         else    { constexpr int PER = ROWS / 4; k = slot / PER; r = (slot % PER) * 4; }
+        if (scale) {      // channel constants of this float4 (aligned quads share a channel when period % 4 == 0): fetched with the operand,
+            const int u0 = KC ? k0 + k : r0 + r;                      // so that they too are in flight during the multiply
+            const int c = min((int)(((float)u0 + 0.5f) * (1.f / (float)period)), ((KC ? kmax : rmax) - 1) / period);
+            aff[i][0] = scale[max(c, 0)]; aff[i][1] = shift[max(c, 0)];
+        }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const bool in_tile = KC ? (r < ROWS) : (k < GEMM_BK);
         if (in_tile) {
@@ -75,8 +86,12 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, long sR, 
     }
 }
 
+// registers -> LDS.  The optional operand BatchNorm+ReLU is applied HERE, not at load time: the global loads of the next tile stay in
+// flight during the multiply of the current one, and the transform only touches them once they have landed.
 template <int ROWS, bool KC, int NLD>
-__device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 (&reg)[NLD]) {
+__device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 (&reg)[NLD], const float (&aff)[NLD][2], int r0 = 0, int k0 = 0,
+                                           int rmax = 0, int kmax = 0, const float* __restrict__ scale = nullptr,
+                                           const float* __restrict__ shift = nullptr, int period = 1) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -85,7 +100,24 @@ __device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 
         if (KC) { r = slot >> 3; k = (slot & 7) * 4; }
         else    { constexpr int PER = ROWS / 4; k = slot / PER; r = (slot % PER) * 4; }
         const bool in_tile = KC ? (r < ROWS) : (k < GEMM_BK);
-        if (in_tile) *reinterpret_cast<f32x4*>(lds + LdsTile<ROWS, KC>::at(r, k)) = reg[i];
+        f32x4 v = reg[i];
+        if (scale && in_tile) {      // operand affine + ReLU; elements outside the matrix stay exactly 0
+            const int gr = r0 + r, gk = k0 + k;
+            const int u0 = KC ? gk : gr;                            // index along the unit-stride dimension of the first of the 4
+            const bool row_ok = KC ? (gr < rmax) : (gk < kmax);
+            const int umax = KC ? kmax : rmax;
+            const float inv = 1.f / (float)period;                  // exact channel for indices < 2^22: (u + 0.5) / period truncated
+            if ((period & 3) == 0 && (u0 & 3) == 0) {               // the 4 elements share one channel
+                const float sc = aff[i][0], sh = aff[i][1];     // prefetched by tile_load
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (row_ok && u0 + j < umax) v[j] = fmaxf(fmaf(v[j], sc, sh), 0.f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (row_ok && u0 + j < umax) { const int c = (int)(((float)(u0 + j) + 0.5f) * inv); v[j] = fmaxf(fmaf(v[j], scale[c], shift[c]), 0.f); }
+            }
+        }
+        if (in_tile) *reinterpret_cast<f32x4*>(lds + LdsTile<ROWS, KC>::at(r, k)) = v;
     }
 }
 
@@ -114,21 +146,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[NLA], rb[NLB];
+    float fa[NLA][2], fb[NLB][2];          // per-float4 operand BatchNorm constants (only touched when an operand affine is given)
     const int ntiles = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
     if (ntiles > 0) {
-        tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, g.vecA, ra);
-        tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, g.vecB, rb);
+        tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
+        tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
     }
     for (int t = 0; t < ntiles; ++t) {
         float* la = lds + (t & 1) * (LA::SIZE + LB::SIZE);
         float* lb = la + LA::SIZE;
-        tile_store<BM, A_KC, NLA>(la, ra);
-        tile_store<BN, B_KC, NLB>(lb, rb);
+        tile_store<BM, A_KC, NLA>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period);
+        tile_store<BN, B_KC, NLB>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period);
         __syncthreads();
         if (t + 1 < ntiles) {   // prefetch next tile while this one is multiplied
             const int k0 = kbeg + (t + 1) * GEMM_BK;
-            tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra);
-            tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb);
+            tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
+            tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
         }
 #pragma unroll
         for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
@@ -236,9 +269,10 @@ int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
 static int g_force_tile = 0;
 void a2s_gemm_debug_tile_impl(int cfg) { g_force_tile = cfg; }
 
-int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
                   const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
-                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes) {
+                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes,
+                  const float* a_scale, const float* a_shift, int a_period, const float* b_scale, const float* b_shift, int b_period) {
     if (M <= 0 || N <= 0 || batch <= 0) return A2S_OK;
     A2S_REQUIRE(K >= 0 && A && B && C, "gemm: null operand or negative K");
     A2S_REQUIRE(splitk >= 0, "gemm: splitk must be >= 0 (0 = choose automatically when a workspace is given)");
@@ -274,6 +308,12 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
     g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.act = act;
     g.batch = batch; g.bsA = bsA; g.bsB = bsB; g.bsC = bsC;
     g.splitk = splitk; g.partial = ws;
+    A2S_REQUIRE((a_scale == nullptr) == (a_shift == nullptr) && (b_scale == nullptr) == (b_shift == nullptr), "gemm: operand scale/shift must come together");
+    A2S_REQUIRE((!a_scale || a_period > 0) && (!b_scale || b_period > 0), "gemm: operand affine needs a positive period");
+    A2S_REQUIRE(!a_scale || sAk == 1 || sAm == 1, "gemm: operand affine needs a unit-stride dimension on A");
+    A2S_REQUIRE(!b_scale || sBk == 1 || sBn == 1, "gemm: operand affine needs a unit-stride dimension on B");
+    g.a_scale = a_scale; g.a_shift = a_shift; g.a_period = a_period > 0 ? a_period : 1;
+    g.b_scale = b_scale; g.b_shift = b_shift; g.b_period = b_period > 0 ? b_period : 1;
     g.kchunk = a2s_cdiv(a2s_cdiv(K, splitk), GEMM_BK) * GEMM_BK;
     if (g.kchunk == 0) g.kchunk = GEMM_BK;
     if (splitk > 1)
@@ -307,4 +347,11 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
         A2S_CHECK_LAUNCH("gemm_splitk_reduce");
     }
     return A2S_OK;
+}
+
+int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
+                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes) {
+    return a2s_gemm_affine_impl(st, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk, ws, ws_bytes,
+                                nullptr, nullptr, 0, nullptr, nullptr, 0);
 }

@@ -171,11 +171,18 @@ class Engine:
             saved["y"].append(y)
             saved["bn"].append((mean, invstd, scale, shift))
             x = y
-        a4 = self._empty(B * T, 40 * F, dev=dev)
-        hip.check(L.a2s_bn_relu_apply(hip.stream(), hip._p(x), hip._p(a4), hip._p(scale), hip._p(shift), C.c_long(a4.numel()), 40, F),
-                  "a2s_bn_relu_apply")
+        # the (B*T, 40*F) operand of the 19200->256 Linear is relu(bn4(y4)): formed while the GEMM stages its A tiles (column k belongs
+        # to channel k // F), never written to memory (A2S_MATERIALIZE_A4=1: the separate bn_relu_apply pass, for A/B measurements)
+        y4 = x.view(B * T, 40 * F)
         Cf = self.cfg["conv_feature_size"]
-        z = hip.linear(a4, S["convstack.out.weight"])
+        if _os.environ.get("A2S_MATERIALIZE_A4") == "1":
+            a4 = self._empty(B * T, 40 * F, dev=dev)
+            hip.check(L.a2s_bn_relu_apply(hip.stream(), hip._p(x), hip._p(a4), hip._p(scale), hip._p(shift), C.c_long(a4.numel()), 40, F),
+                      "a2s_bn_relu_apply")
+            z = hip.linear(a4, S["convstack.out.weight"])
+        else:
+            a4 = None
+            z = hip.linear(y4, S["convstack.out.weight"], x_affine=(scale, shift, F))
         rows = B * T
         rpb = 64
         nblk = (rows + rpb - 1) // rpb

@@ -36,12 +36,14 @@ def _colsum(x, ld, out, rows, ncol, x_off=0, out_off=0, beta=1.0):
                                     hip.f32(1.0), hip.f32(beta), hip._p(ws), C.c_size_t(ws.numel() if ws is not None else 0)), "a2s_col_sum")
 
 
-def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0):
-    """y = x W^T + b  (x (M,K) contiguous, W (N,K)):  dW += dy^T x ; db += colsum(dy) ; dx (+)= dy W."""
+def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0, x_affine=None):
+    """y = x W^T + b  (x (M,K) contiguous, W (N,K)):  dW += dy^T x ; db += colsum(dy) ; dx (+)= dy W.
+    x_affine = (scale, shift, period): the layer's input was max(0, x*scale[k // period] + shift[k // period]) formed on the fly
+    (hip.linear) -- the weight gradient re-forms it the same way while staging x."""
     M, K = x.shape
     N = W.shape[0]
     sk = hip.lib().a2s_gemm_pick_splitk(N, K, M, 1)
-    hip.gemm(dy, 1, N, x, K, 1, G[wname], K, N, K, M, beta=1.0, splitk=sk)
+    hip.gemm(dy, 1, N, x, K, 1, G[wname], K, N, K, M, beta=1.0, splitk=sk, b_affine=x_affine)
     if bname is not None:
         _colsum(dy, N, G[bname], M, N)
     if dx is not None:
@@ -395,8 +397,13 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
     dz = bn_bwd(g, cs["z"], cs["out_bn"], "convstack.out_bn", cs["drop"], rows, Cf, 1)
     # Linear 19200 -> Cf, no bias:  dW += dz^T a4 ; da4 = dz W
     a4 = cs["a4"]
-    da = torch.empty_like(a4)
-    _linear_bwd(a4, S["convstack.out.weight"], dz, G, "convstack.out.weight", None, dx=da)
+    if a4 is None:                         # the Linear read relu(bn4(y4)) on the fly: so does its weight gradient
+        y4 = cs["y"][3].view(rows, 40 * F)
+        da = torch.empty_like(y4)
+        _linear_bwd(y4, S["convstack.out.weight"], dz, G, "convstack.out.weight", None, dx=da, x_affine=(cs["bn"][3][2], cs["bn"][3][3], F))
+    else:
+        da = torch.empty_like(a4)
+        _linear_bwd(a4, S["convstack.out.weight"], dz, G, "convstack.out.weight", None, dx=da)
     chans = [(1, 20), (20, 20), (20, 40), (40, 40)]
     g = da.view(B, T, 40, F)
     for i in (4, 3, 2, 1):

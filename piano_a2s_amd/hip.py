@@ -99,8 +99,9 @@ def f32(x):
 
 
 def gemm(A, sAm, sAk, B, sBk, sBn, Cout, ldc, M, N, K, alpha=1.0, beta=0.0, bias=None, act=0,
-         batch=1, bsA=0, bsB=0, bsC=0, splitk=1, a_off=0, b_off=0, c_off=0):
-    """C[m,n] = act(alpha*sum_k A(m,k)B(k,n) + beta*C + bias[n]); *_off are element offsets into the tensors."""
+         batch=1, bsA=0, bsB=0, bsC=0, splitk=1, a_off=0, b_off=0, c_off=0, a_affine=None, b_affine=None):
+    """C[m,n] = act(alpha*sum_k A(m,k)B(k,n) + beta*C + bias[n]); *_off are element offsets into the tensors.
+    a_affine / b_affine = (scale, shift, period): BatchNorm+ReLU of that operand applied while it is staged (a2s_gemm_f32_affine)."""
     L = lib()
     ws, ws_bytes = None, 0
     if splitk > 1:
@@ -109,17 +110,25 @@ def gemm(A, sAm, sAk, B, sBk, sBn, Cout, ldc, M, N, K, alpha=1.0, beta=0.0, bias
     pa = C.c_void_p(A.data_ptr() + 4 * a_off)
     pb = C.c_void_p(B.data_ptr() + 4 * b_off)
     pc = C.c_void_p(Cout.data_ptr() + 4 * c_off)
-    check(L.a2s_gemm_f32(stream(), M, N, K, f32(alpha), pa, C.c_long(sAm), C.c_long(sAk), pb, C.c_long(sBk), C.c_long(sBn),
-                         f32(beta), pc, C.c_long(ldc), _p(bias), act, batch, C.c_long(bsA), C.c_long(bsB), C.c_long(bsC),
-                         splitk, _p(ws), C.c_size_t(ws_bytes)), "a2s_gemm_f32")
+    if a_affine is None and b_affine is None:
+        check(L.a2s_gemm_f32(stream(), M, N, K, f32(alpha), pa, C.c_long(sAm), C.c_long(sAk), pb, C.c_long(sBk), C.c_long(sBn),
+                             f32(beta), pc, C.c_long(ldc), _p(bias), act, batch, C.c_long(bsA), C.c_long(bsB), C.c_long(bsC),
+                             splitk, _p(ws), C.c_size_t(ws_bytes)), "a2s_gemm_f32")
+        return
+    asc, ash, ap = a_affine if a_affine is not None else (None, None, 0)
+    bsc, bsh, bp = b_affine if b_affine is not None else (None, None, 0)
+    check(L.a2s_gemm_f32_affine(stream(), M, N, K, f32(alpha), pa, C.c_long(sAm), C.c_long(sAk), pb, C.c_long(sBk), C.c_long(sBn),
+                                f32(beta), pc, C.c_long(ldc), _p(bias), act, batch, C.c_long(bsA), C.c_long(bsB), C.c_long(bsC),
+                                splitk, _p(ws), C.c_size_t(ws_bytes), _p(asc), _p(ash), ap, _p(bsc), _p(bsh), bp), "a2s_gemm_f32_affine")
 
 
-def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0):
-    """y = act(x @ weight.T + bias) for row-major contiguous x (M,K) and weight (N,K)."""
+def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0, x_affine=None):
+    """y = act(x @ weight.T + bias) for row-major contiguous x (M,K) and weight (N,K); x_affine = (scale, shift, period): the input
+    is max(0, x*scale[k // period] + shift[k // period]) formed on the fly."""
     M, K = x2d.shape
     N = weight.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
     gemm(x2d, x2d.stride(0), x2d.stride(1), weight, weight.stride(1), weight.stride(0), out, out.stride(0), M, N, K,
-         bias=bias, act=act, beta=beta)
+         bias=bias, act=act, beta=beta, a_affine=x_affine)
     return out

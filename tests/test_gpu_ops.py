@@ -252,3 +252,31 @@ def test_staff_embedding_ragged_lengths(dev):
     e = max(_rel(out, ref), _rel(out32, ref))
     _report("staff_emb ragged", e)
     assert e < 1e-5, e
+
+
+def test_gemm_with_operand_batchnorm_relu(dev):
+    """a2s_gemm_f32_affine: BatchNorm+ReLU of an operand formed while it is staged -- the forward Linear form (A k-contiguous,
+    channel = k // period) and the weight-gradient form (B n-contiguous, channel = n // period), ragged sizes (zero padding must stay 0)."""
+    from piano_a2s_amd import hip
+    g = torch.Generator().manual_seed(5)
+    M, N, period, chans = 203, 37, 12, 7
+    K = period * chans
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.2
+    scale, shift = torch.rand(chans, generator=g) + 0.5, torch.randn(chans, generator=g) * 0.3
+    act = torch.relu(x * scale.repeat_interleave(period) + shift.repeat_interleave(period))
+    xd, Wd, sc, sh = x.to(dev), W.to(dev), scale.to(dev), shift.to(dev)
+    y = hip.linear(xd, Wd, x_affine=(sc, sh, period))
+    e1 = _rel(y, act @ W.t())
+    dy = torch.randn(M, N, generator=g)
+    dW = torch.zeros(N, K, device=dev)
+    dyd = dy.to(dev)
+    hip.gemm(dyd, 1, N, xd, K, 1, dW, K, N, K, M, beta=1.0, b_affine=(sc, sh, period))            # dW = dy^T act(x)
+    e2 = _rel(dW, dy.t() @ act)
+    dW2 = torch.zeros(N, K, device=dev)
+    hip.gemm(dyd, 1, N, xd, K, 1, dW2, K, N, K, M, beta=1.0, splitk=3, b_affine=(sc, sh, period))
+    e3 = _rel(dW2, dy.t() @ act)
+    torch.cuda.synchronize()
+    _report("gemm operand affine forward", e1)
+    _report("gemm operand affine wgrad", max(e2, e3))
+    assert max(e1, e2, e3) < 2e-5, (e1, e2, e3)
