@@ -327,7 +327,8 @@ def test_staff_embedding_backward(dev):
     assert max(errs.values()) < 2e-5, errs
 
 
-@pytest.mark.parametrize("H,T,clips,groups,split", [(256, 1201, 3, 2, True), (256, 333, 70, 3, True), (256, 77, 5, 5, True), (32, 41, 3, 3, False)])
+@pytest.mark.parametrize("H,T,clips,groups,split", [(256, 1201, 3, 2, True), (256, 333, 70, 3, True), (256, 77, 5, 5, True), (256, 61, 5, 5, True), (256, 61, 5, 4, True),
+                                                    (256, 61, 5, 3, True), (256, 61, 5, 2, True), (32, 41, 3, 3, False)])
 def test_fused_rows_attention_forward_backward(dev, H, T, clips, groups, split):
     """The attention step over `groups` bars of the same clips (row = group * clips + clip) with finished rows skipped: forward
     context / weights, dq, and the deferred dK / dEnc over S steps against torch autograd on the unfinished (row, step) pairs.
