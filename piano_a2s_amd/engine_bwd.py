@@ -307,6 +307,16 @@ def backward(eng, S, grad_outputs, grad_ready=None):
     return G
 
 
+_WG_STREAMS = {}
+
+
+def _weight_grad_stream(dev):
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _WG_STREAMS:
+        _WG_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _WG_STREAMS[key]
+
+
 def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
     L = hip.lib()
     H = eng.cfg["hidden_size"]
@@ -345,16 +355,29 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
             return (dgi, dghs, dgh_first, dhbuf, dgh_tmp)
 
         res = fork_on_streams(dev, streams, [lambda d=d, sfx=sfx: direction(d, sfx) for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse"))])()
-        for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):      # deferred weight / input gradients (main stream, ordered)
+        # input gradient (what the next recurrence / the ConvStack needs) on the current stream ...
+        for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
+            dgi2 = res[d][0].view(B * T, 3 * H)
+            Wih = S[f"encoder.gru.weight_ih_{sfx}"]
+            hip.gemm(dgi2, 3 * H, 1, Wih, I, 1, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0)
+        # ... the weight gradients (MFMA-bound, nobody waits for them) on a third stream, under the next layer's latency-bound recurrence
+        wg = _weight_grad_stream(dev)
+        ev = torch.cuda.Event()
+        ev.record()
+        wg.wait_event(ev)
+        for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
             dgi, dghs, dgh_first = res[d][:3]
-            dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)
-            _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}", dx=dX,
-                        dx_beta=0.0 if d == 0 else 1.0)
-            sk = L.a2s_gemm_pick_splitk(3 * H, H, B * T, 1)
-            hip.gemm(dghs2, 1, 3 * H, out, 2 * H, 1, G[f"encoder.gru.weight_hh_{sfx}"], H, 3 * H, H, B * T, beta=1.0, splitk=sk, b_off=d * H)
-            _colsum(dghs2, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B * T, 3 * H)
-            _colsum(dgh_first, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B, 3 * H)
+            for t in (dgi, dghs, dgh_first):
+                t.record_stream(wg)
+            with torch.cuda.stream(wg):
+                dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)
+                _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}")
+                sk = L.a2s_gemm_pick_splitk(3 * H, H, B * T, 1)
+                hip.gemm(dghs2, 1, 3 * H, out, 2 * H, 1, G[f"encoder.gru.weight_hh_{sfx}"], H, 3 * H, H, B * T, beta=1.0, splitk=sk, b_off=d * H)
+                _colsum(dghs2, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B * T, 3 * H)
+                _colsum(dgh_first, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B, 3 * H)
         dout = dX.view(B, T, I)
+    torch.cuda.current_stream().wait_stream(_weight_grad_stream(dev))     # the encoder gradients are complete past this point
     return dout                                              # (B, T, conv_feature_size)
 
 
