@@ -337,6 +337,9 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
 //   dgh_first (B,3H)   <- dgh of the first processed step (h_prev = 0): only contributes to db_hh
 bool a2s_gru_step_fused_enabled(void);
 int a2s_skinny_gemm_acc_impl(hipStream_t st, const float* A, long lda, const float* Bt, long ldb, float* Cm, long ldc, int R, int N, int K);
+int a2s_gru_bptt_step_impl(hipStream_t st, const float* dgh, const float* w_hh_t, const float* dhz_in, const float* dout, long ld_dout,
+                           const float* save, const float* hprev, long ld_hprev, float* dgi, long ld_dgi, float* dgh_out, float* dgh2,
+                           long ld_dgh2, float* dhz_out, int R, int H);
 
 // out[c][r] = in[r][c]  (rows x cols -> cols x rows); small parameter matrices only
 __global__ void transpose_f32(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
@@ -362,6 +365,35 @@ int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, lon
     if (fused) {
         hipLaunchKernelGGL(transpose_f32, dim3(a2s_cdiv(3 * H * H, 256)), dim3(256), 0, st, w_hh, ws, 3 * H, H);
         A2S_CHECK_LAUNCH("transpose_f32");
+    }
+    if (fused && ws_bytes >= sizeof(float) * (3 * (size_t)H * H + 3 * (size_t)B * H) && (3 * H * H) % 4 == 0) {
+        // ONE launch per step: the carry product of step s with the gate backward of step s-1 on its accumulators
+        // (gru_bptt_step_fused); the two dgh scratch buffers alternate (this launch reads one as its A operand and writes the other)
+        float* tmp[2] = {dgh_tmp, ws + 3 * (size_t)H * H};
+        auto tix = [&](int s) { return reverse ? T - 1 - s : s; };
+        int cur = 0, p = 0;
+        {   // last processed step first: plain gate backward
+            const int s = T - 1, t = tix(s), tp = reverse ? t + 1 : t - 1;
+            float* dgh = (s == 0) ? dgh_first : tmp[p];
+            int rc = a2s_gru_gates_bwd_impl(st, dhbuf, H, dout + (long)t * do_tstride, do_bstride, gates + (long)t * B * 4 * H,
+                                            s == 0 ? nullptr : out + (long)tp * out_tstride, out_bstride,
+                                            dgi_all + (long)t * 3 * H, (long)T * 3 * H, dgh, 3 * H,
+                                            s == 0 ? nullptr : dgh_shift + (long)tp * 3 * H, (long)T * 3 * H, dhbuf + (long)B * H, H, B, H);
+            if (rc) return rc;
+            cur = 1;
+        }
+        for (int s = T - 1; s >= 1; --s) {
+            const int sp = s - 1, t = tix(sp), tp = reverse ? t + 1 : t - 1;      // the epilogue handles step s-1
+            float* dgh_out = (sp == 0) ? dgh_first : tmp[p ^ 1];
+            int rc = a2s_gru_bptt_step_impl(st, tmp[p], ws, dhbuf + (long)cur * B * H, dout + (long)t * do_tstride, do_bstride,
+                                            gates + (long)t * B * 4 * H, sp == 0 ? nullptr : out + (long)tp * out_tstride, out_bstride,
+                                            dgi_all + (long)t * 3 * H, (long)T * 3 * H, dgh_out,
+                                            sp == 0 ? nullptr : dgh_shift + (long)tp * 3 * H, (long)T * 3 * H,
+                                            dhbuf + (long)(cur ^ 1) * B * H, B, H);
+            if (rc) return rc;
+            cur ^= 1; p ^= 1;
+        }
+        return A2S_OK;
     }
     int cur = 0;
     for (int s = T - 1; s >= 0; --s) {                 // s = processing index of the forward pass

@@ -170,6 +170,72 @@ __global__ __launch_bounds__(256) void skinny_gemm_acc(const float* __restrict__
     }
 }
 
+// One launch per BPTT step of an encoder direction: the carry  dh_{s-1} = dhz_s + dgh_s W_hh  (tile: 16 rows x 16 hidden units, the
+// skinny product above) and, on the accumulators, the gate backward of step s-1 for exactly those (row, unit) pairs
+// (gru_gates_bwd): dgi_{s-1}, dgh_{s-1} (next launch's A operand, written to the OTHER scratch buffer), its shifted copy for the
+// deferred dW_hh, and dhz_{s-1} = (dh_{s-1} + dout_{s-1}) z_{s-1}.  The epilogue operands are fetched before the product.
+struct GruBpttStep {
+    const float* dgh; const float* w_hh_t;              // (R, 3H) of step s; (H, 3H)
+    const float* dhz_in;                                // (R, H): (dh_s + dout_s) z_s
+    const float* dout; long ld_dout;                    // step s-1 slice of the layer-output gradient
+    const float* save;                                  // (R, 4H) [r|z|n|gh_n] of step s-1
+    const float* hprev; long ld_hprev;                  // h_{s-2} (null: zeros)
+    float* dgi; long ld_dgi; float* dgh_out; float* dgh2; long ld_dgh2;   // dgh2 may be null
+    float* dhz_out;                                     // (R, H)
+    int R, H;
+};
+__global__ __launch_bounds__(256) void gru_bptt_step_fused(GruBpttStep a) {
+    __shared__ f32x4 part[3 * 64];
+    const int H = a.H, R = a.R;
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int j = j0 + li;
+    float carry[4], dov[4], rg[4], zg[4], ng[4], ghn[4], hp[4];
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(row0 + lk * 4 + r, R - 1);
+            carry[r] = a.dhz_in[(long)row * H + j];
+            dov[r] = a.dout[(long)row * a.ld_dout + j];
+            const float* sv = a.save + (long)row * 4 * H;
+            rg[r] = sv[j]; zg[r] = sv[H + j]; ng[r] = sv[2 * H + j]; ghn[r] = sv[3 * H + j];
+            hp[r] = a.hprev ? a.hprev[(long)row * a.ld_hprev + j] : 0.f;
+        }
+    }
+    const float* arow = a.dgh + (long)min(row0 + li, R - 1) * 3 * H;
+    const float* brow[1] = {a.w_hh_t + (long)(j0 + li) * 3 * H};
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    mfma_rows<1, 12>(arow, brow, 3 * H / 16, wave, lk, acc);
+    if (wave > 0) part[(wave - 1) * 64 + lane] = acc[0];
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + lk * 4 + r;
+        if (row >= R) continue;
+        const float dh = carry[r] + acc[0][r] + part[lane][r] + part[64 + lane][r] + part[128 + lane][r] + dov[r];
+        const float dn = dh * (1.f - zg[r]) * (1.f - ng[r] * ng[r]);
+        const float dz = dh * (hp[r] - ng[r]) * zg[r] * (1.f - zg[r]);
+        const float dr = dn * ghn[r] * rg[r] * (1.f - rg[r]);
+        float* gi = a.dgi + (long)row * a.ld_dgi;
+        gi[j] = dr; gi[H + j] = dz; gi[2 * H + j] = dn;
+        float* gh = a.dgh_out + (long)row * 3 * H;
+        gh[j] = dr; gh[H + j] = dz; gh[2 * H + j] = dn * rg[r];
+        if (a.dgh2) { float* g2 = a.dgh2 + (long)row * a.ld_dgh2; g2[j] = dr; g2[H + j] = dz; g2[2 * H + j] = dn * rg[r]; }
+        a.dhz_out[(long)row * H + j] = dh * zg[r];
+    }
+}
+
+int a2s_gru_bptt_step_impl(hipStream_t st, const float* dgh, const float* w_hh_t, const float* dhz_in, const float* dout, long ld_dout,
+                           const float* save, const float* hprev, long ld_hprev, float* dgi, long ld_dgi, float* dgh_out, float* dgh2,
+                           long ld_dgh2, float* dhz_out, int R, int H) {
+    GruBpttStep a{dgh, w_hh_t, dhz_in, dout, ld_dout, save, hprev, ld_hprev, dgi, ld_dgi, dgh_out, dgh2, ld_dgh2, dhz_out, R, H};
+    hipLaunchKernelGGL(gru_bptt_step_fused, dim3(H / 16, a2s_cdiv(R, 16)), dim3(256), 0, st, a);
+    A2S_CHECK_LAUNCH("gru_bptt_step_fused");
+    return A2S_OK;
+}
+
 int a2s_skinny_gemm_acc_impl(hipStream_t st, const float* A, long lda, const float* Bt, long ldb, float* Cm, long ldc, int R, int N, int K) {
     A2S_REQUIRE(N % 16 == 0 && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A | (uintptr_t)Bt) % 16 == 0,
                 "skinny_gemm_acc: N %% 16, K %% 16 and 16-byte aligned K-contiguous operands required");
