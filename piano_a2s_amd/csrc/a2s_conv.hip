@@ -251,47 +251,74 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a, const float* __r
     }
 }
 
-// First layer: Cin = 1.  One thread per (b,t,f) position computes all Cout (<= 20) channels.
+// First layer: Cin = 1.  A streaming kernel (53 GFLOP at B = 256 against 12 GB written): a thread owns 4 consecutive f positions of a
+// row (16-byte stores of every output channel), walks the rows grid-stride, and keeps its per-channel sum / sum of squares in
+// registers -- the batch-statistics partials are reduced ONCE per workgroup at the end (the first version reduced 40 values across the
+// wave for every position and wrote 92 MB of partials).  C1_BLOCKS workgroups = that many partial rows.
+#define C1_BLOCKS 2048
 __global__ __launch_bounds__(256) void conv3x3_c1(ConvArgs a) {
     __shared__ float lw[20 * 9];
     __shared__ float red[4][20][2];
     for (int e = threadIdx.x; e < a.Cout * 9; e += 256) lw[e] = a.w[e];
     __syncthreads();
-    const long pos = (long)blockIdx.x * 256 + threadIdx.x;
-    const long npos = (long)a.B * a.T * a.F;
-    const bool ok = pos < npos;
-    const int f = ok ? (int)(pos % a.F) : 0;
-    const int t = ok ? (int)((pos / a.F) % a.T) : 0;
-    const int b = ok ? (int)(pos / ((long)a.F * a.T)) : 0;
-    float v[9];
-#pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-        for (int df = 0; df < 3; ++df) {
-            const int tt = t + dt - 1, ff = f + df - 1;
-            float x = 0.f;
-            if (ok && tt >= 0 && tt < a.T && ff >= 0 && ff < a.F) x = a.x[((long)b * a.T + tt) * a.F + ff];
-            v[dt * 3 + df] = x;
-        }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int co = 0; co < a.Cout; ++co) {
-        float s = 0.f;
+    const int qpr = (a.F + 3) / 4;                               // quads per row
+    const long nquads = (long)a.B * a.T * qpr;
+    const bool vec = (a.F % 4 == 0) && (((uintptr_t)a.y & 15) == 0);
+    float s1[20], s2[20];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s = fmaf(v[k], lw[co * 9 + k], s);
-        if (ok) a.y[(((long)b * a.T + t) * a.Cout + co) * a.F + f] = s;
-        if (a.stat_partial) {
-            const float sv = ok ? s : 0.f;
-            const float ws = wave_sum(sv), ws2 = wave_sum(sv * sv);
-            if (lane == 0) { red[wave][co][0] = ws; red[wave][co][1] = ws2; }
+    for (int co = 0; co < 20; ++co) { s1[co] = 0.f; s2[co] = 0.f; }
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+        const int f0 = (int)(q % qpr) * 4;
+        const long row = q / qpr;                                // b * T + t
+        const int t = (int)(row % a.T);
+        float v[3][6];                                           // input window: rows t-1..t+1, columns f0-1..f0+4
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int tt = t + dt - 1;
+            const float* xr = a.x + (row + dt - 1) * a.F;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int ff = f0 + c - 1;
+                v[dt][c] = (tt >= 0 && tt < a.T && ff >= 0 && ff < a.F) ? xr[ff] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 20; ++co) {
+            if (co >= a.Cout) break;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df) {
+                    const float w = lw[co * 9 + dt * 3 + df];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) o[p] = fmaf(v[dt][p + df], w, o[p]);
+                }
+            float* dst = a.y + (row * a.Cout + co) * a.F + f0;
+            if (vec) {
+                *reinterpret_cast<f32x4*>(dst) = o;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { s1[co] += o[p]; s2[co] = fmaf(o[p], o[p], s2[co]); }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) if (f0 + p < a.F) { dst[p] = o[p]; s1[co] += o[p]; s2[co] = fmaf(o[p], o[p], s2[co]); }
+            }
         }
     }
     if (a.stat_partial) {
+#pragma unroll
+        for (int co = 0; co < 20; ++co) {
+            if (co >= a.Cout) break;
+            const float w1 = wave_sum(s1[co]), w2 = wave_sum(s2[co]);
+            if (lane == 0) { red[wave][co][0] = w1; red[wave][co][1] = w2; }
+        }
         __syncthreads();
         if (threadIdx.x < a.Cout) {
-            float s = 0.f, s2 = 0.f;
-            for (int w = 0; w < 4; ++w) { s += red[w][threadIdx.x][0]; s2 += red[w][threadIdx.x][1]; }
+            float s = 0.f, q2 = 0.f;
+            for (int w = 0; w < 4; ++w) { s += red[w][threadIdx.x][0]; q2 += red[w][threadIdx.x][1]; }
             a.stat_partial[((long)blockIdx.x * a.Cout + threadIdx.x) * 2 + 0] = s;
-            a.stat_partial[((long)blockIdx.x * a.Cout + threadIdx.x) * 2 + 1] = s2;
+            a.stat_partial[((long)blockIdx.x * a.Cout + threadIdx.x) * 2 + 1] = q2;
         }
     }
 }
@@ -386,6 +413,8 @@ __global__ void bn1d_relu_dropout(const float* __restrict__ x, float* __restrict
 // ------------------------------------------------------------------------------------------- launchers
 size_t a2s_conv3x3_workspace_floats_impl(int Cin) { return Cin == 1 ? 0 : (size_t)(Cin / CV_CK) * C2_WCHUNK; }
 
+int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin);
+
 int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, const float* in_scale,
                      const float* in_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* ws) {
     A2S_REQUIRE(x && w && y, "conv3x3: null tensor");
@@ -393,7 +422,7 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
     ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip};
     if (Cin == 1) {
         A2S_REQUIRE(Cout <= 20 && !flip && !in_scale, "conv3x3: Cin=1 path supports Cout<=20, no flip, no input affine");
-        hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_cdiv((long)B * T * F, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_conv3x3_stat_blocks_impl(B, T, F, 1)), dim3(256), 0, st, a);
     } else {
         A2S_REQUIRE(Cin % 4 == 0 && Cin % CV_CK == 0, "conv3x3: Cin must be a multiple of %d", CV_CK);
         A2S_REQUIRE(ws, "conv3x3: needs a workspace of a2s_conv3x3_workspace_floats(Cin) floats for the packed weights");
@@ -410,7 +439,11 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
 }
 
 int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin) {
-    return Cin == 1 ? a2s_cdiv((long)B * T * F, 256) : B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
+    if (Cin == 1) {       // the streaming first-layer kernel: at most C1_BLOCKS grid-stride workgroups
+        const long want = a2s_cdiv((long)B * T * ((F + 3) / 4), 256);
+        return (int)(want < C1_BLOCKS ? want : C1_BLOCKS);
+    }
+    return B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
 }
 
 int a2s_bn_finalize_impl(hipStream_t st, const float* partial, int nblocks, int C, double count, const float* gamma,

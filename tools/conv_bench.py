@@ -25,7 +25,7 @@ def main():
     T, F = 1201, 480
     dev = torch.device("cuda:0")
     L = hip.lib()
-    for ci, co, flip, what in ((20, 20, 0, "conv2 fwd"), (20, 40, 0, "conv3 fwd"), (40, 40, 0, "conv4 fwd"), (40, 40, 1, "conv4 dgrad"), (40, 20, 1, "conv3 dgrad")):
+    for ci, co, flip, what in ((1, 20, 0, "conv1 fwd"), (20, 20, 0, "conv2 fwd"), (20, 40, 0, "conv3 fwd"), (40, 40, 0, "conv4 fwd"), (40, 40, 1, "conv4 dgrad"), (40, 20, 1, "conv3 dgrad")):
         x = torch.randn(B, T, ci, F, device=dev)
         y = torch.empty(B, T, co, F, device=dev)
         w = torch.randn((ci, co, 3, 3) if flip else (co, ci, 3, 3), device=dev) * 0.05
@@ -33,6 +33,8 @@ def main():
         nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
         partial = torch.empty(nblk, co, 2, device=dev)
         cws = hip.conv_workspace(ci, dev)
+        if ci == 1:
+            scale = shift = None
         ms = timed(lambda: hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(w), hip._p(y), hip._p(None if flip else scale), hip._p(None if flip else shift),
                                                    hip._p(None if flip else partial), B, T, F, ci, co, flip, hip._p(cws)), "conv"))
         fl = 2.0 * 9 * ci * co * B * T * F
