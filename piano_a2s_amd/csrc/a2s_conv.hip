@@ -814,11 +814,24 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c1(const float* __restrict_
         const float* drow = dy + row * (long)Cout * F;
         if (bn.y) {                         // fused BatchNorm backward of the dy operand (see BnBwdFuse)
             const float* yrow = bn.y + row * (long)Cout * F;
-            for (int e = tid; e < Cout * F; e += 256) {
-                const int c = e / F;
-                const float v = bn_bwd_value(drow[e], yrow[e], bn.mean[c], bn.invstd[c], bn.scale[c], bn.shift[c], bn.c12[2 * c], bn.c12[2 * c + 1]);
-                ldy[e] = v;
-                if (bn.dy_out) bn.dy_out[row * (long)Cout * F + e] = v;
+            if (vec_ok && (((uintptr_t)bn.y & 15) == 0)) {
+                for (int e = tid; e < Cout * F / 4; e += 256) {
+                    const int c = (e * 4) / F;
+                    const f32x4 g4 = reinterpret_cast<const f32x4*>(drow)[e], y4 = reinterpret_cast<const f32x4*>(yrow)[e];
+                    const float mean = bn.mean[c], invstd = bn.invstd[c], sc = bn.scale[c], sh = bn.shift[c], c1 = bn.c12[2 * c], c2 = bn.c12[2 * c + 1];
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = bn_bwd_value(g4[q], y4[q], mean, invstd, sc, sh, c1, c2);
+                    reinterpret_cast<f32x4*>(ldy)[e] = v;
+                    if (bn.dy_out) reinterpret_cast<f32x4*>(bn.dy_out + row * (long)Cout * F)[e] = v;
+                }
+            } else {
+                for (int e = tid; e < Cout * F; e += 256) {
+                    const int c = e / F;
+                    const float v = bn_bwd_value(drow[e], yrow[e], bn.mean[c], bn.invstd[c], bn.scale[c], bn.shift[c], bn.c12[2 * c], bn.c12[2 * c + 1]);
+                    ldy[e] = v;
+                    if (bn.dy_out) bn.dy_out[row * (long)Cout * F + e] = v;
+                }
             }
         } else if (vec_ok) {
             for (int e = tid; e < Cout * F / 4; e += 256) reinterpret_cast<f32x4*>(ldy)[e] = reinterpret_cast<const f32x4*>(drow)[e];

@@ -385,6 +385,7 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
 # bn_bwd_apply pass.  Built and parity-tested, but OFF: the extra operand pushes conv3x3_wgrad<40> from 202 to 281 registers
 # (occupancy 2 -> 1) and the ConvStack backward got 19 % slower (409 -> 487 ms at B=256) instead of 14 % faster.
 _FUSE_BN_APPLY = os.environ.get("A2S_FUSE_BN_APPLY", "0") == "1"
+_FUSE_BN_APPLY_L1 = os.environ.get("A2S_FUSE_BN_APPLY_L1", "1") != "0"
 
 
 def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
@@ -436,7 +437,10 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         in_bn = cs["bn"][i - 2] if i > 1 else None
         nb = L.a2s_conv3x3_wgrad_workspace_bytes(ci, co)
         ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
-        if eng.sync_bn or not _FUSE_BN_APPLY:
+        # the first layer has no data-gradient consumer: its BatchNorm input gradient is only read by the (streaming, HBM-bound)
+        # weight-gradient kernel, which forms it on the fly -- one pass over (g, y) instead of apply (read 2, write 1) + read 1
+        fuse_here = _FUSE_BN_APPLY or (i == 1 and _FUSE_BN_APPLY_L1)
+        if eng.sync_bn or not fuse_here:
             dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F)
             hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
                                           hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
