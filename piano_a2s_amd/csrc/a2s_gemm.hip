@@ -258,16 +258,6 @@ int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
         }
         return best;
     }
-    // few output tiles, huge K (the decoder's deferred weight gradients: (1536 x 528) with K = steps x rows ~ 1e5): split so that
-    // 128x128 tiles fill the 512 workgroup slots -- the 128x128 configuration reaches ~1.7x the MFMA rate of the 64x64 one
-    if (K >= 8192) {
-        const long t128 = (long)a2s_cdiv(M, 128) * a2s_cdiv(N, 128) * batch;
-        long s = 512 / t128;
-        const long maxs = K / 1024;
-        if (s > maxs) s = maxs;
-        if (s > 64) s = 64;
-        return s < 1 ? 1 : (int)s;
-    }
     long s = 512 / tiles;
     const long maxs = K / 512;
     if (s > maxs) s = maxs;
