@@ -792,12 +792,18 @@ __global__ void wgrad_reduce(const float* __restrict__ partial, float* __restric
 // the (b,t) rows; a row's dy block (Cout x F) and the 3 x (F+2) input window go through LDS; thread = (co, slice of F) keeps its 9
 // tap sums in registers; one slab [Cout][9] per workgroup, reduced in fixed order by wgrad_reduce_c1.
 #define C1W_PARTS 12
+#define C1W_XIT 10                          // float4 loads per thread and row in the fused path (20 x 480 / 4 / 256 = 9.4)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_c1(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
                                                         int B, int T, int F, int Cout, BnBwdFuse bn) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* ldy = sm;                            // Cout * F
     float* lx = sm + Cout * F;                  // 3 * (F + 2)
+    __shared__ float lconst[20 * 6];            // per channel: mean, invstd, scale, shift, c1, c2 (fused BatchNorm backward)
     const int tid = threadIdx.x;
+    if (bn.y && tid < Cout) {
+        float* k = lconst + tid * 6;
+        k[0] = bn.mean[tid]; k[1] = bn.invstd[tid]; k[2] = bn.scale[tid]; k[3] = bn.shift[tid]; k[4] = bn.c12[2 * tid]; k[5] = bn.c12[2 * tid + 1];
+    }
     const int co = tid / C1W_PARTS, part = tid % C1W_PARTS;
     const int fper = (F + C1W_PARTS - 1) / C1W_PARTS;
     const int fa = part * fper, fb = min(F, fa + fper);
@@ -812,26 +818,35 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c1(const float* __restrict_
         const long b = row / T;
         __syncthreads();
         const float* drow = dy + row * (long)Cout * F;
-        if (bn.y) {                         // fused BatchNorm backward of the dy operand (see BnBwdFuse)
+        if (bn.y && vec_ok && (((uintptr_t)bn.y & 15) == 0) && Cout * F <= 4 * 256 * C1W_XIT) {
+            // fused BatchNorm backward of the dy operand (see BnBwdFuse): all loads of the row first (one round trip), constants from LDS
             const float* yrow = bn.y + row * (long)Cout * F;
-            if (vec_ok && (((uintptr_t)bn.y & 15) == 0)) {
-                for (int e = tid; e < Cout * F / 4; e += 256) {
+            f32x4 g4[C1W_XIT], y4[C1W_XIT];
+#pragma unroll
+            for (int it = 0; it < C1W_XIT; ++it) {
+                const int e = tid + 256 * it;
+                if (e < Cout * F / 4) { g4[it] = reinterpret_cast<const f32x4*>(drow)[e]; y4[it] = reinterpret_cast<const f32x4*>(yrow)[e]; }
+            }
+#pragma unroll
+            for (int it = 0; it < C1W_XIT; ++it) {
+                const int e = tid + 256 * it;
+                if (e < Cout * F / 4) {
                     const int c = (e * 4) / F;
-                    const f32x4 g4 = reinterpret_cast<const f32x4*>(drow)[e], y4 = reinterpret_cast<const f32x4*>(yrow)[e];
-                    const float mean = bn.mean[c], invstd = bn.invstd[c], sc = bn.scale[c], sh = bn.shift[c], c1 = bn.c12[2 * c], c2 = bn.c12[2 * c + 1];
+                    const float* k = lconst + c * 6;
                     f32x4 v;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = bn_bwd_value(g4[q], y4[q], mean, invstd, sc, sh, c1, c2);
+                    for (int q = 0; q < 4; ++q) v[q] = bn_bwd_value(g4[it][q], y4[it][q], k[0], k[1], k[2], k[3], k[4], k[5]);
                     reinterpret_cast<f32x4*>(ldy)[e] = v;
                     if (bn.dy_out) reinterpret_cast<f32x4*>(bn.dy_out + row * (long)Cout * F)[e] = v;
                 }
-            } else {
-                for (int e = tid; e < Cout * F; e += 256) {
-                    const int c = e / F;
-                    const float v = bn_bwd_value(drow[e], yrow[e], bn.mean[c], bn.invstd[c], bn.scale[c], bn.shift[c], bn.c12[2 * c], bn.c12[2 * c + 1]);
-                    ldy[e] = v;
-                    if (bn.dy_out) bn.dy_out[row * (long)Cout * F + e] = v;
-                }
+            }
+        } else if (bn.y) {
+            const float* yrow = bn.y + row * (long)Cout * F;
+            for (int e = tid; e < Cout * F; e += 256) {
+                const int c = e / F;
+                const float v = bn_bwd_value(drow[e], yrow[e], bn.mean[c], bn.invstd[c], bn.scale[c], bn.shift[c], bn.c12[2 * c], bn.c12[2 * c + 1]);
+                ldy[e] = v;
+                if (bn.dy_out) bn.dy_out[row * (long)Cout * F + e] = v;
             }
         } else if (vec_ok) {
             for (int e = tid; e < Cout * F / 4; e += 256) reinterpret_cast<f32x4*>(ldy)[e] = reinterpret_cast<const f32x4*>(drow)[e];
@@ -846,12 +861,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c1(const float* __restrict_
         __syncthreads();
         if (worker) {
             const float* d = ldy + co * F;
+            float w[3][3];                                  // input window, slid along f: 3 new values per position instead of 9
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) { w[dt][1] = lx[dt * (F + 2) + fa]; w[dt][2] = lx[dt * (F + 2) + fa + 1]; }
             for (int f = fa; f < fb; ++f) {
                 const float g = d[f];
 #pragma unroll
-                for (int dt = 0; dt < 3; ++dt)
+                for (int dt = 0; dt < 3; ++dt) {
+                    w[dt][0] = w[dt][1]; w[dt][1] = w[dt][2]; w[dt][2] = lx[dt * (F + 2) + f + 2];
 #pragma unroll
-                    for (int df = 0; df < 3; ++df) acc[dt * 3 + df] = fmaf(g, lx[dt * (F + 2) + f + df], acc[dt * 3 + df]);
+                    for (int df = 0; df < 3; ++df) acc[dt * 3 + df] = fmaf(g, w[dt][df], acc[dt * 3 + df]);
+                }
             }
         }
     }
