@@ -561,6 +561,46 @@ __global__ void bn_bwd_apply(const float* __restrict__ g, const float* __restric
     }
 }
 
+// The same for the (rows, C, F) activation layout with F % 4 == 0: one workgroup per (b,t) row, 16-byte accesses, the channel of a
+// quad computed once (the generic kernel above spends two integer divisions per element and moves 4 bytes per access).
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ c12,
+                                                           float* __restrict__ dx, int C, int F) {
+    __shared__ float k[64 * 6];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        k[c * 6 + 0] = mean[c]; k[c * 6 + 1] = invstd[c]; k[c * 6 + 2] = scale[c]; k[c * 6 + 3] = shift[c];
+        k[c * 6 + 4] = c12[2 * c]; k[c * 6 + 5] = c12[2 * c + 1];
+    }
+    __syncthreads();
+    const int qpp = F / 4, nq = C * qpp;                       // quads per plane, per row
+    const long base = (long)blockIdx.x * C * F;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g + base);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dx + base);
+    for (int q0 = threadIdx.x; q0 < nq; q0 += 4 * 256) {        // 4 quads in flight per thread
+        f32x4 gv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * 256;
+            if (q < nq) { gv[u] = g4[q]; xv[u] = x4[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u * 256;
+            if (q >= nq) continue;
+            const float* kc = k + (q / qpp) * 6;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gm = (xv[u][e] * kc[2] + kc[3] > 0.f) ? gv[u][e] : 0.f;
+                o[e] = kc[2] * (gm - kc[4] - (xv[u][e] - kc[0]) * kc[1] * kc[5]);
+            }
+            d4[q] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- conv weight gradient
 // Optional fused BatchNorm backward of the layer's OUTPUT side: instead of a ready dy the kernel gets g (gradient wrt the activation
 // relu(bn(y))) and y (the layer's pre-BN output) and forms  dy = scale_c * (g' - c1_c - (y - mean_c) * invstd_c * c2_c),
@@ -954,6 +994,11 @@ int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float*
     A2S_CHECK_LAUNCH("bn_bwd_finalize");
     if (!dx) return A2S_OK;            // statistics only: the input gradient is formed by the consumer (a2s_conv3x3_wgrad_bn)
     const long n = rows * C * F;
+    if (F > 1 && F % 4 == 0 && C <= 64 && !mask && ((((uintptr_t)g | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)) {
+        hipLaunchKernelGGL(bn_bwd_apply_planes, dim3((unsigned)rows), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, dx, C, F);
+        A2S_CHECK_LAUNCH("bn_bwd_apply_planes");
+        return A2S_OK;
+    }
     hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, mask,
                        inv_keep, dx, n, C, F);
     A2S_CHECK_LAUNCH("bn_bwd_apply");
