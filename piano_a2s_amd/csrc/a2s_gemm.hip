@@ -174,38 +174,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);     // transposed tile: see the epilogue
         }
         // the other LDS buffer is written next iteration; its readers finished before the barrier above
     }
 
-    // epilogue: lane holds rows (lane>>4)*4 + r, column lane&15 of every 16x16 tile
+    // epilogue.  The MFMAs were issued with the operands swapped (B fragment first), so every accumulator holds the TRANSPOSED 16x16 tile:
+    // lane = (m = lane & 15, n-quad = lane >> 4) owns C[m][4q .. 4q+3] -- four CONSECUTIVE columns of one output row, i.e. one 16-byte
+    // store per tile and lane instead of four scattered 4-byte stores (the 19200-wide data-gradient GEMM writes 23.6 GB this way).
     const bool partial = g.splitk > 1;
     float* C = partial ? g.partial + (long)blockIdx.z * g.M * g.N : g.C + (long)zb * g.bsC;
     const long ldc = partial ? g.N : g.ldc;
+    const bool vec_c = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm + i * 16 + lr;
+        if (m >= g.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn + j * 16 + lr;
+            const int n = n0 + wn + j * 16 + lk * 4;
             if (n >= g.N) continue;
-            const float bv = (!partial && g.bias) ? g.bias[n] : 0.f;
+            f32x4 v = acc[i][j];
+            float* dst = C + (long)m * ldc + n;
+            const bool full = vec_c && n + 3 < g.N;
+            if (!partial) {
+                f32x4 old = {0.f, 0.f, 0.f, 0.f};
+                if (g.beta != 0.f) {
+                    if (full) old = *reinterpret_cast<const f32x4*>(dst);
+                    else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + i * 16 + lk * 4 + r;
-                if (m >= g.M) continue;
-                float v = acc[i][j][r];
-                if (!partial) {
-                    v = g.alpha * v + bv;
-                    if (g.beta != 0.f) v += g.beta * C[(long)m * ldc + n];
-                    if (g.act == 1) v = fmaxf(v, 0.f);
-                    else if (g.act == 2) v = fast_tanh(v);
-    else if (g.act == 3) v = exp2x_clamped(v);
-                    else if (g.act == 3) v = exp2x_clamped(v);
+                        for (int r = 0; r < 4; ++r) if (n + r < g.N) old[r] = dst[r];
+                    }
                 }
-                C[(long)m * ldc + n] = v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = g.alpha * v[r] + ((g.bias && n + r < g.N) ? g.bias[n + r] : 0.f);
+                    if (g.beta != 0.f) x += g.beta * old[r];
+                    if (g.act == 1) x = fmaxf(x, 0.f);
+                    else if (g.act == 2) x = fast_tanh(x);
+                    else if (g.act == 3) x = exp2x_clamped(x);
+                    v[r] = x;
+                }
+            }
+            if (full) *reinterpret_cast<f32x4*>(dst) = v;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < g.N) dst[r] = v[r];
             }
         }
+    }
 }
 
 // Fixed-order reduction of the split-K partial slabs (deterministic), with the epilogue applied once.
