@@ -623,7 +623,7 @@ __device__ __forceinline__ float bn_bwd_value(float g, float yv, float mean, flo
 // (4 consecutive f per MFMA).  gridDim.x persistent workgroups walk the (b, 4-row strip, 32-column) tiles; each writes
 // ONE partial slab [Cout][180]; wgrad_reduce sums the slabs in fixed order (deterministic).
 template <int COUT, bool BN>
-__global__ __launch_bounds__(256) void conv3x3_wgrad(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void conv3x3_wgrad(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                      float* __restrict__ partial, int B, int T, int F, int Cin, BnBwdFuse bn) {
     constexpr int MT = (COUT + 15) / 16;
@@ -938,7 +938,7 @@ __global__ void wgrad_reduce_c1(const float* __restrict__ partial, float* __rest
 
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
-    return (size_t)chunks * WGRAD_SLABS * Cout * CV_CK * 9 * sizeof(float);
+    return (size_t)chunks * 1024 * Cout * CV_CK * 9 * sizeof(float);
 }
 
 int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
@@ -960,8 +960,9 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
         }
     }
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
-    // persistent workgroups: one full round of the occupancy the kernel reaches (Cout 20: 3 per CU, Cout 40: 2 per CU by registers)
-    const int slabs = Cout == 20 ? WGRAD_SLABS : 512;
+    // persistent workgroups: one full round of the occupancy the kernel reaches (__launch_bounds__(256, 3): 3 per CU for Cout 40,
+    // 4 per CU for Cout 20 -- without the bound the compiler spent 200 registers and dropped Cout 40 to 2 per CU)
+    const int slabs = Cout == 20 ? 1024 : WGRAD_SLABS;
     dim3 grid(slabs, chunks);
     if (Cout == 20 && !bn_y) hipLaunchKernelGGL((conv3x3_wgrad<20, false>), grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, bn);
     else if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad<20, true>), grid, dim3(256), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, bn);
