@@ -65,7 +65,7 @@ __global__ void conv_pack_weights(const float* __restrict__ w, float* __restrict
 //   * with one input chunk (Cin = 20) the packed weights are staged once per workgroup; with two, consecutive tiles visit the chunks
 //     in serpentine order (0,1 | 1,0 | 0,1 ...) so the weight slice changes every other stage only;
 //   * batch-statistics partials are accumulated over the workgroup's tiles and written once.
-#define C3_TPW 16
+#define C3_TPW 8
 #define C3_WIT ((C2_WCHUNK / 4 + 255) / 256)                                  // float4 weight loads per thread and stage (9)
 #define C3_XIT ((CV_CK * (CV_TR + 2) * (C2_FT / 4) + 255) / 256)              // float4 input loads per thread and stage (8)
 
