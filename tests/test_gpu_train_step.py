@@ -141,8 +141,9 @@ def test_sync_bn_single_rank_equals_local_bn(case, dev):
 
 
 def test_full_width_step_with_flat_parameters(dev):
-    """The fused training step on the 256-wide model whose parameters are views of ONE flat buffer (arbitrary 4-byte offsets): exercises
-    the 16-byte-load kernels' alignment handling on the real parameter layout (separately allocated test tensors are always aligned)."""
+    """The fused training step on the 256-wide model whose parameters are views of ONE flat buffer (spec.flat_layout puts every tensor
+    on a 16-byte boundary; the odd-sized ones -- 173-row vocabulary matrices, biases -- are what used to land on 4-byte offsets): the
+    16-byte-load kernels run on the real parameter layout (separately allocated test tensors are always aligned)."""
     import models
     from piano_a2s_amd import spec, synthetic, train
     cfg = spec.default_cfg(max_length=(12, 8), max_bars=2)
