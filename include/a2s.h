@@ -59,6 +59,15 @@ int a2s_debug_set(const char* key, int value);
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
                 float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace);
 int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin);
+/* Data gradient of a convolution (flip form: g = dy (*) w') whose output is the gradient wrt relu(bn(yl)) of the layer below, with that
+ * layer's BatchNorm-backward statistics (sum g', sum g' xhat; g' = g where bn(yl) > 0) accumulated in the epilogue into stat_partial
+ * [a2s_conv3x3_stat_blocks(B,T,F,Cin)][Cout][2] -- pass it to a2s_bn_bwd_from_partial instead of running the statistics pass of
+ * a2s_bn_bwd.  Cin / Cout are those of THIS launch (Cin = channels of dy, Cout = channels of g and yl). */
+int a2s_conv3x3_dgrad_bnstats(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
+                              const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
+                              float* workspace);
+int a2s_bn_bwd_from_partial(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                            float* dgamma, float* dbeta, float* dx /* may be NULL */, const float* partial, int nblocks, float* c12, long rows, int C, int F);
 size_t a2s_conv3x3_workspace_floats(int Cin);   /* scratch for the packed weight image (0 for Cin = 1) */
 /* BatchNorm2d/1d statistics -> affine (models.py:499-505): reduces the partials in fixed order (double),
  * updates running stats (momentum, unbiased var) and num_batches_tracked when training, emits mean/invstd

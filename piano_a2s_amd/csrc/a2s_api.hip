@@ -11,7 +11,8 @@ int a2s_gemm_impl(hipStream_t, int, int, int, float, const float*, long, long, c
 size_t a2s_gemm_workspace_bytes_impl(int, int, int, int);
 int a2s_gemm_affine_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long, const float*,
                          int, int, long, long, long, int, float*, size_t, const float*, const float*, int, const float*, const float*, int);
-int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*);
+int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*,
+                     const float*, const float*, const float*, const float*, const float*);
 size_t a2s_conv3x3_workspace_floats_impl(int);
 int a2s_conv3x3_stat_blocks_impl(int, int, int, int);
 int a2s_bn_finalize_impl(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*,
@@ -52,6 +53,9 @@ int a2s_staff_emb_bwd_impl(hipStream_t, const float*, const float* const*, float
 int a2s_bn_bwd_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
                     float*, float*, float*, float*, float*, long, int, int);
 size_t a2s_bn_bwd_partial_floats_impl(long, int, int);
+int a2s_bn_bwd_from_partial_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
+                                 const float*, int, float*, long, int, int);
+
 int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int,
                            const float*, const float*, const float*, const float*, const float*, const float*, float*);
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int, int);
@@ -99,7 +103,17 @@ int a2s_debug_set(const char* key, int value) {
 
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
                 float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace) {
-    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, workspace);
+    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, workspace, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+int a2s_conv3x3_dgrad_bnstats(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
+                              const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
+                              float* workspace) {
+    if (!yl) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_dgrad_bnstats: yl is required"); return A2S_ERR_ARG; }
+    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift);
+}
+int a2s_bn_bwd_from_partial(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                            float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12, long rows, int C, int F) {
+    return a2s_bn_bwd_from_partial_impl(ST, g, x, mean, invstd, scale, shift, dgamma, dbeta, dx, partial, nblocks, c12, rows, C, F);
 }
 size_t a2s_conv3x3_workspace_floats(int Cin) { return a2s_conv3x3_workspace_floats_impl(Cin); }
 int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin) { return a2s_conv3x3_stat_blocks_impl(B, T, F, Cin); }

@@ -32,6 +32,10 @@ struct ConvArgs {
     float* stat_partial; // [nblocks][Cout][2] sum, sumsq over the block's valid positions (null -> skip)
     int B, T, F, Cin, Cout;
     int flip;            // 1: use w as a transposed/flipped kernel (dgrad): w'[ci][co][2-dt][2-df]
+    // data-gradient launches only (template BNRED): the output g is the gradient wrt relu(bn(yl)) of the layer below; its BatchNorm
+    // backward statistics  sum g', sum g' xhat  (g' = g where bn(yl) > 0) are accumulated in the epilogue and written to stat_partial
+    // in the layout bn_bwd_finalize reads -- the separate statistics pass over (g, yl) disappears
+    const float* yl; const float* yl_mean; const float* yl_invstd; const float* yl_scale; const float* yl_shift;
 };
 
 // ---- v2 geometry (round 1, after profiling: the first version spent more time staging than multiplying -- scalar loads with
@@ -69,8 +73,8 @@ __global__ void conv_pack_weights(const float* __restrict__ w, float* __restrict
 #define C3_WIT ((C2_WCHUNK / 4 + 255) / 256)                                  // float4 weight loads per thread and stage (9)
 #define C3_XIT ((CV_CK * (CV_TR + 2) * (C2_FT / 4) + 255) / 256)              // float4 input loads per thread and stage (8)
 
-template <int COUT>
-__global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a, const float* __restrict__ wpack) {
+template <int COUT, bool BNRED>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma(ConvArgs a, const float* __restrict__ wpack) {
     constexpr int NT = (COUT + 15) / 16;               // n-tiles: 2 (Cout 20) or 3 (Cout 40)
     __shared__ __attribute__((aligned(16))) float lin[CV_CK * C2_PLANE];       // 34560 B
     __shared__ __attribute__((aligned(16))) float lw[C2_WCHUNK];               // 34560 B
@@ -213,19 +217,38 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs a, const float* __r
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int co = j * 16 + li;
+            float bm = 0.f, bi = 0.f, bsc = 0.f, bsh = 0.f;
+            f32x4 yv[4];
+            if (BNRED && row_ok && co < COUT) {          // layer-below BatchNorm constants of this lane's channel + its yl values
+                bm = a.yl_mean[co]; bi = a.yl_invstd[co]; bsc = a.yl_scale[co]; bsh = a.yl_shift[co];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = f0 + i * 16 + lk * 4;
+                    const float* src = a.yl + (((long)b * a.T + t) * COUT + co) * a.F + f;
+                    if (f + 3 < a.F && (a.F % 4 == 0)) yv[i] = *reinterpret_cast<const f32x4*>(src);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) yv[i][r] = (f + r < a.F) ? src[r] : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int f = f0 + i * 16 + lk * 4;
                 if (row_ok && co < COUT) {
                     float* dst = a.y + (((long)b * a.T + t) * COUT + co) * a.F + f;
-                    if (f + 3 < a.F && (a.F % 4 == 0)) {
-                        *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+                    const bool full = f + 3 < a.F && (a.F % 4 == 0);
+                    if (full) *reinterpret_cast<f32x4*>(dst) = acc[i][j];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { st_s[j] += acc[i][j][r]; st_s2[j] += acc[i][j][r] * acc[i][j][r]; }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (f + r < a.F) { dst[r] = acc[i][j][r]; st_s[j] += acc[i][j][r]; st_s2[j] += acc[i][j][r] * acc[i][j][r]; }
+                    for (int r = 0; r < 4; ++r) {
+                        if (!full && f + r >= a.F) continue;
+                        const float v = acc[i][j][r];
+                        if (!full) dst[r] = v;
+                        if (BNRED) {
+                            const float xv = yv[i][r];
+                            const float gm = (xv * bsc + bsh > 0.f) ? v : 0.f;
+                            st_s[j] += gm; st_s2[j] += gm * (xv - bm) * bi;
+                        } else { st_s[j] += v; st_s2[j] += v * v; }
                     }
                 }
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -416,10 +439,12 @@ size_t a2s_conv3x3_workspace_floats_impl(int Cin) { return Cin == 1 ? 0 : (size_
 int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin);
 
 int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, const float* in_scale,
-                     const float* in_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* ws) {
+                     const float* in_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* ws,
+                     const float* yl, const float* yl_mean, const float* yl_invstd, const float* yl_scale, const float* yl_shift) {
     A2S_REQUIRE(x && w && y, "conv3x3: null tensor");
     A2S_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
-    ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip};
+    A2S_REQUIRE(!yl || (yl_mean && yl_invstd && yl_scale && yl_shift && stat_partial && Cin != 1), "conv3x3: the fused BatchNorm-backward statistics need all of their tensors");
+    ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, yl, yl_mean, yl_invstd, yl_scale, yl_shift};
     if (Cin == 1) {
         A2S_REQUIRE(Cout <= 20 && !flip && !in_scale, "conv3x3: Cin=1 path supports Cout<=20, no flip, no input affine");
         hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_conv3x3_stat_blocks_impl(B, T, F, 1)), dim3(256), 0, st, a);
@@ -431,8 +456,10 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
         hipLaunchKernelGGL(conv_pack_weights, dim3(a2s_cdiv(chunks * C2_WCHUNK, 256)), dim3(256), 0, st, w, ws, Cin, Cout, flip, chunks);
         A2S_CHECK_LAUNCH("conv_pack_weights");
         const int nblk = B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
-        if (Cout == 20) hipLaunchKernelGGL(conv3x3_mfma<20>, dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
-        else hipLaunchKernelGGL(conv3x3_mfma<40>, dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
+        if (Cout == 20 && !yl) hipLaunchKernelGGL((conv3x3_mfma<20, false>), dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
+        else if (Cout == 20) hipLaunchKernelGGL((conv3x3_mfma<20, true>), dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
+        else if (!yl) hipLaunchKernelGGL((conv3x3_mfma<40, false>), dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
+        else hipLaunchKernelGGL((conv3x3_mfma<40, true>), dim3(nblk), dim3(256), 0, st, a, (const float*)ws);
     }
     A2S_CHECK_LAUNCH("conv3x3");
     return A2S_OK;
@@ -1002,6 +1029,27 @@ int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float*
     }
     hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, mask,
                        inv_keep, dx, n, C, F);
+    A2S_CHECK_LAUNCH("bn_bwd_apply");
+    return A2S_OK;
+}
+
+// BatchNorm backward whose statistics partials were produced elsewhere (the data-gradient convolution's epilogue,
+// a2s_conv3x3_dgrad_bnstats): finalize (dgamma, dbeta, c12) + apply.  (rows, C, F) layout only.
+int a2s_bn_bwd_from_partial_impl(hipStream_t st, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+                                 const float* shift, float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12,
+                                 long rows, int C, int F) {
+    A2S_REQUIRE(g && x && mean && invstd && scale && shift && dgamma && dbeta && partial && c12 && nblocks > 0, "bn_bwd_from_partial: null tensor");
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, st, partial, nblocks, C, (double)rows * F, dgamma, dbeta, c12);
+    A2S_CHECK_LAUNCH("bn_bwd_finalize");
+    if (!dx) return A2S_OK;
+    const long n = rows * C * F;
+    if (F > 1 && F % 4 == 0 && C <= 64 && ((((uintptr_t)g | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)) {
+        hipLaunchKernelGGL(bn_bwd_apply_planes, dim3((unsigned)rows), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, dx, C, F);
+        A2S_CHECK_LAUNCH("bn_bwd_apply_planes");
+        return A2S_OK;
+    }
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12,
+                       (const uint8_t*)nullptr, 1.f, dx, n, C, F);
     A2S_CHECK_LAUNCH("bn_bwd_apply");
     return A2S_OK;
 }

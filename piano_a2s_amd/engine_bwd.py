@@ -386,6 +386,7 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
 # (occupancy 2 -> 1) and the ConvStack backward got 19 % slower (409 -> 487 ms at B=256) instead of 14 % faster.
 _FUSE_BN_APPLY = os.environ.get("A2S_FUSE_BN_APPLY", "0") == "1"
 _FUSE_BN_APPLY_L1 = os.environ.get("A2S_FUSE_BN_APPLY_L1", "1") != "0"
+_DGRAD_BNSTATS = os.environ.get("A2S_DGRAD_BNSTATS", "1") != "0"      # BatchNorm-backward statistics in the data-gradient conv's epilogue
 
 
 def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
@@ -394,10 +395,17 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
     Cf = eng.cfg["conv_feature_size"]
     rows = B * T
 
-    def bn_bwd(g, x, bn, name, mask, n_rows, C_, F_, stats_only=False):
+    def bn_bwd(g, x, bn, name, mask, n_rows, C_, F_, stats_only=False, partial=None):
         """stats_only: dgamma / dbeta and the two per-channel means (returned) only -- the input gradient is then formed inside the
-        weight-gradient kernel (a2s_conv3x3_wgrad_bn)."""
+        weight-gradient kernel (a2s_conv3x3_wgrad_bn).  partial = (tensor, nblocks): the statistics partials were already produced by
+        the data-gradient convolution that wrote g (a2s_conv3x3_dgrad_bnstats): no statistics pass."""
         mean, invstd, scale, shift = bn
+        if partial is not None and not eng.sync_bn:
+            c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+            hip.check(L.a2s_bn_bwd_from_partial(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift),
+                                                hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), NULL if stats_only else hip._p(g),
+                                                hip._p(partial[0]), partial[1], hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd_from_partial")
+            return c12 if stats_only else g
         part = torch.empty(L.a2s_bn_bwd_partial_floats(C.c_long(n_rows), C_, F_), dtype=torch.float32, device=dev)
         c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
         if eng.sync_bn:                                       # statistics of the global minibatch (see Engine.__init__)
@@ -430,6 +438,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         _linear_bwd(a4, S["convstack.out.weight"], dz, G, "convstack.out.weight", None, dx=da)
     chans = [(1, 20), (20, 20), (20, 40), (40, 40)]
     g = da.view(B, T, 40, F)
+    g_partial = None                     # BatchNorm-backward statistics partials of g, when the kernel that produced g also reduced them
     for i in (4, 3, 2, 1):
         ci, co = chans[i - 1]
         y = cs["y"][i - 1]                                    # pre-BN conv output of this layer
@@ -441,14 +450,14 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         # weight-gradient kernel, which forms it on the fly -- one pass over (g, y) instead of apply (read 2, write 1) + read 1
         fuse_here = _FUSE_BN_APPLY or (i == 1 and _FUSE_BN_APPLY_L1)
         if eng.sync_bn or not fuse_here:
-            dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F)
+            dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F, partial=g_partial)
             hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
                                           hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
         else:
             # BatchNorm backward: statistics pass only; dy = scale (g' - c1 - xhat c2) is formed by the weight-gradient kernel while
             # it stages its dy operand (MFMA-bound, HBM to spare) and written out for the data-gradient convolution below
             bn_i = cs["bn"][i - 1]
-            c12 = bn_bwd(g, y, bn_i, f"convstack.bn{i}", None, rows, co, F, stats_only=True)
+            c12 = bn_bwd(g, y, bn_i, f"convstack.bn{i}", None, rows, co, F, stats_only=True, partial=g_partial)
             dy = torch.empty_like(g) if i > 1 else None
             hip.check(L.a2s_conv3x3_wgrad_bn(hip.stream(), hip._p(g), hip._p(y), hip._p(bn_i[0]), hip._p(bn_i[1]), hip._p(bn_i[2]), hip._p(bn_i[3]),
                                              hip._p(c12), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
@@ -456,6 +465,17 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         if i > 1:
             gprev = torch.empty((B, T, ci, F), dtype=torch.float32, device=dev)
             cws = hip.conv_workspace(co, dev)
-            hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), NULL, NULL, NULL, B, T, F, co, ci, 1,
-                                    hip._p(cws)), "a2s_conv3x3 dgrad")
+            if _DGRAD_BNSTATS and not eng.sync_bn:
+                # the data-gradient convolution also accumulates the BatchNorm-backward statistics of the layer below in its epilogue
+                bn_l = cs["bn"][i - 2]
+                nblk = L.a2s_conv3x3_stat_blocks(B, T, F, co)
+                part = torch.empty((nblk, ci, 2), dtype=torch.float32, device=dev)
+                hip.check(L.a2s_conv3x3_dgrad_bnstats(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), hip._p(cs["y"][i - 2]),
+                                                      hip._p(bn_l[0]), hip._p(bn_l[1]), hip._p(bn_l[2]), hip._p(bn_l[3]), hip._p(part), B, T, F, co, ci,
+                                                      hip._p(cws)), "a2s_conv3x3_dgrad_bnstats")
+                g_partial = (part, nblk)
+            else:
+                hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), NULL, NULL, NULL, B, T, F, co, ci, 1,
+                                        hip._p(cws)), "a2s_conv3x3 dgrad")
+                g_partial = None
             g = gprev
