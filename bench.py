@@ -76,7 +76,7 @@ def conv_roofline(B, T, F, iters=6):
     avg_s = e0.elapsed_time(e1) / iters / 1e3
     flops = 2.0 * 9 * ci * co * B * T * F
     achieved = flops / avg_s / 1e12
-    return {"bound": "mfma", "kernel": "conv3x3_mfma<40> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
+    return {"bound": "mfma", "kernel": "conv3x3_mfma<40, false> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
             "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFS, 4), "traffic": None,
             "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}
 
