@@ -45,6 +45,12 @@ int a2s_gemm_f32_affine(void* stream, int M, int N, int K, float alpha, const fl
                         long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,
                         int splitk, float* workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_period,
                         const float* b_scale, const float* b_shift, int b_period);
+/* C = A B whose output (M rows x N = channels * period columns, same layout as y) is the gradient wrt relu(bn(y)) of a ConvStack layer (the
+ * data gradient of the 19200->256 Linear): its BatchNorm-backward statistics (sum g', sum g' xhat per channel) are accumulated in the
+ * epilogue into partial[a2s_gemm_bnstats_blocks(M, period)][N / period][2] -- the layout a2s_bn_bwd_from_partial reads. */
+int a2s_gemm_f32_bnstats(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
+                         const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial);
+int a2s_gemm_bnstats_blocks(int M, int period);
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch);
 /* tuning aid (tools/gemm_sweep.py): force the tile configuration for M > 64 (1: 32x64, 2: 64x32, 3: 64x64, 4: 128x128; 0: heuristic) */

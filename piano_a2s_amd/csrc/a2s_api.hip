@@ -10,7 +10,9 @@ int a2s_gemm_impl(hipStream_t, int, int, int, float, const float*, long, long, c
                   const float*, int, int, long, long, long, int, float*, size_t);
 size_t a2s_gemm_workspace_bytes_impl(int, int, int, int);
 int a2s_gemm_affine_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long, const float*,
-                         int, int, long, long, long, int, float*, size_t, const float*, const float*, int, const float*, const float*, int);
+                         int, int, long, long, long, int, float*, size_t, const float*, const float*, int, const float*, const float*, int,
+                         const float*, const float*, const float*, const float*, const float*, float*, int);
+int a2s_gemm_bnstats_slots(int);
 int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*,
                      const float*, const float*, const float*, const float*, const float*);
 size_t a2s_conv3x3_workspace_floats_impl(int);
@@ -88,8 +90,15 @@ int a2s_gemm_f32_affine(void* stream, int M, int N, int K, float alpha, const fl
                         int splitk, float* workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_period,
                         const float* b_scale, const float* b_shift, int b_period) {
     return a2s_gemm_affine_impl(ST, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk,
-                                workspace, workspace_bytes, a_scale, a_shift, a_period, b_scale, b_shift, b_period);
+                                workspace, workspace_bytes, a_scale, a_shift, a_period, b_scale, b_shift, b_period,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
 }
+int a2s_gemm_f32_bnstats(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
+                         const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial) {
+    return a2s_gemm_affine_impl(ST, M, N, K, 1.f, A, sAm, sAk, B, sBk, sBn, 0.f, C, ldc, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0,
+                                nullptr, nullptr, 0, nullptr, nullptr, 0, y, mean, invstd, scale, shift, partial, period);
+}
+int a2s_gemm_bnstats_blocks(int M, int period) { return a2s_cdiv(M, 128) * a2s_gemm_bnstats_slots(period); }
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk) { return a2s_gemm_workspace_bytes_impl(M, N, batch, splitk); }
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch) { return a2s_gemm_pick_splitk_impl(M, N, K, batch); }
 void a2s_gemm_debug_tile(int cfg) { a2s_gemm_debug_tile_impl(cfg); }

@@ -29,6 +29,11 @@ struct GemmArgs {
     // output (forward: A, k-contiguous; weight gradient: B, n-contiguous) -- the activated copy is never written.
     const float* a_scale; const float* a_shift; int a_period;
     const float* b_scale; const float* b_shift; int b_period;
+    // optional epilogue: the output C (M rows x N = channels * period columns) is the gradient wrt relu(bn(Y)) of a ConvStack layer; its
+    // BatchNorm-backward statistics (sum g', sum g' xhat per channel; g' = g where bn(y) > 0) are accumulated here, one partial row per
+    // (row tile, column-tile slot of the channel) in the [blocks][channels][2] layout bn_bwd_finalize reads.  128x128 tiles only.
+    const float* ep_y; const float* ep_mean; const float* ep_invstd; const float* ep_scale; const float* ep_shift;
+    float* ep_partial; int ep_period, ep_channels, ep_slots;
 };
 
 #define GEMM_BK 32
@@ -186,6 +191,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     float* C = partial ? g.partial + (long)blockIdx.z * g.M * g.N : g.C + (long)zb * g.bsC;
     const long ldc = partial ? g.N : g.ldc;
     const bool vec_c = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0);
+    const int ep_c0 = g.ep_y ? n0 / g.ep_period : 0;             // first channel this column tile touches (it touches at most two)
+    float ep_s[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm + i * 16 + lr;
@@ -220,6 +227,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n + r < g.N) dst[r] = v[r];
+            }
+            if (g.ep_y && full) {      // (host guarantees N % 4 == 0, period % 4 == 0: a quad never straddles a channel)
+                const int c = n / g.ep_period;
+                const f32x4 yq = *reinterpret_cast<const f32x4*>(g.ep_y + (long)m * ldc + n);
+                const float mean = g.ep_mean[c], invstd = g.ep_invstd[c], sc = g.ep_scale[c], sh = g.ep_shift[c];
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gm = (yq[r] * sc + sh > 0.f) ? v[r] : 0.f;
+                    a1 += gm; a2 += gm * (yq[r] - mean) * invstd;
+                }
+                if (c == ep_c0) { ep_s[0][0] += a1; ep_s[0][1] += a2; } else { ep_s[1][0] += a1; ep_s[1][1] += a2; }
+            }
+        }
+    }
+    if (g.ep_y) {                      // workgroup totals of the (at most) two channels -> their (row tile, slot) partial rows
+        float* red = lds;              // the operand tiles are dead by now
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float w = wave_sum(ep_s[sl][k]);
+                if (lane == 0) red[wave * 4 + sl * 2 + k] = w;
+            }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int sl = threadIdx.x >> 1, k = threadIdx.x & 1;
+            const int c = ep_c0 + sl;
+            if (c < g.ep_channels && (long)c * g.ep_period < (long)n0 + BN) {
+                const float tot = red[0 * 4 + threadIdx.x] + red[1 * 4 + threadIdx.x] + red[2 * 4 + threadIdx.x] + red[3 * 4 + threadIdx.x];
+                const int slot = blockIdx.x - (int)(((long)c * g.ep_period) / BN);        // which of the channel's column tiles this is
+                g.ep_partial[(((long)blockIdx.y * g.ep_slots + slot) * g.ep_channels + c) * 2 + k] = tot;
             }
         }
     }
@@ -282,6 +322,9 @@ int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
     return s < 1 ? 1 : (int)s;
 }
 
+// column tiles (of 128) one channel of `period` columns can touch: the partial rows per row tile of the BatchNorm-statistics epilogue
+int a2s_gemm_bnstats_slots(int period) { return period > 0 ? (period + 127) / 128 + 1 : 0; }
+
 // tuning aid (tools/gemm_sweep.py): force a tile configuration for M > 64; 0 = the heuristic below
 static int g_force_tile = 0;
 void a2s_gemm_debug_tile_impl(int cfg) { g_force_tile = cfg; }
@@ -289,7 +332,9 @@ void a2s_gemm_debug_tile_impl(int cfg) { g_force_tile = cfg; }
 int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
                   const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
                   int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes,
-                  const float* a_scale, const float* a_shift, int a_period, const float* b_scale, const float* b_shift, int b_period) {
+                  const float* a_scale, const float* a_shift, int a_period, const float* b_scale, const float* b_shift, int b_period,
+                  const float* ep_y, const float* ep_mean, const float* ep_invstd, const float* ep_scale, const float* ep_shift,
+                  float* ep_partial, int ep_period) {
     if (M <= 0 || N <= 0 || batch <= 0) return A2S_OK;
     A2S_REQUIRE(K >= 0 && A && B && C, "gemm: null operand or negative K");
     A2S_REQUIRE(splitk >= 0, "gemm: splitk must be >= 0 (0 = choose automatically when a workspace is given)");
@@ -331,6 +376,16 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
     A2S_REQUIRE(!b_scale || sBk == 1 || sBn == 1, "gemm: operand affine needs a unit-stride dimension on B");
     g.a_scale = a_scale; g.a_shift = a_shift; g.a_period = a_period > 0 ? a_period : 1;
     g.b_scale = b_scale; g.b_shift = b_shift; g.b_period = b_period > 0 ? b_period : 1;
+    g.ep_y = ep_y; g.ep_mean = ep_mean; g.ep_invstd = ep_invstd; g.ep_scale = ep_scale; g.ep_shift = ep_shift; g.ep_partial = ep_partial;
+    g.ep_period = ep_period > 0 ? ep_period : 1; g.ep_channels = ep_y ? N / g.ep_period : 0; g.ep_slots = ep_y ? a2s_gemm_bnstats_slots(ep_period) : 0;
+    if (ep_y) {
+        A2S_REQUIRE(ep_mean && ep_invstd && ep_scale && ep_shift && ep_partial && ep_period >= 128 && ep_period % 4 == 0 && N % ep_period == 0,
+                    "gemm: the BatchNorm-statistics epilogue needs its tensors, period >= 128, period %% 4 == 0, N a multiple of the period");
+        A2S_REQUIRE(splitk == 1 && batch == 1 && M > 64 && ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && ((uintptr_t)ep_y % 16 == 0) && beta == 0.f,
+                    "gemm: the BatchNorm-statistics epilogue needs one split, one batch, M > 64, beta 0 and 16-byte aligned rows");
+        hipError_t e = hipMemsetAsync(ep_partial, 0, sizeof(float) * 2 * (size_t)a2s_cdiv(M, 128) * g.ep_slots * g.ep_channels, st);
+        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gemm bn-stats memset: %s", hipGetErrorString(e));
+    }
     g.kchunk = a2s_cdiv(a2s_cdiv(K, splitk), GEMM_BK) * GEMM_BK;
     if (g.kchunk == 0) g.kchunk = GEMM_BK;
     if (splitk > 1)
@@ -342,7 +397,8 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
     g.vecA = (akc ? (sAk == 1 && aligned(A, sAm, bsA)) : (sAm == 1 && aligned(A, sAk, bsA))) ? 1 : 0;
     g.vecB = (bkc ? (sBk == 1 && aligned(B, sBn, bsB)) : (sBn == 1 && aligned(B, sBk, bsB))) ? 1 : 0;
 
-    if (!g_force_tile && mid_tile == 2 && g.splitk >= 1 && M * (long)N < (1L << 22)) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);
+    if (ep_y) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);
+    else if (!g_force_tile && mid_tile == 2 && g.splitk >= 1 && M * (long)N < (1L << 22)) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);
     else if (!g_force_tile && mid_tile == 3 && M * (long)N < (1L << 22)) launch_cfg<64, 64, 2, 2>(g, akc, bkc, st);
     else if (g_force_tile && M > 64) {
         switch (g_force_tile) {
@@ -370,5 +426,5 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
                   const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
                   int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes) {
     return a2s_gemm_affine_impl(st, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk, ws, ws_bytes,
-                                nullptr, nullptr, 0, nullptr, nullptr, 0);
+                                nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
 }

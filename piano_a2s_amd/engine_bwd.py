@@ -429,16 +429,28 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
     dz = bn_bwd(g, cs["z"], cs["out_bn"], "convstack.out_bn", cs["drop"], rows, Cf, 1)
     # Linear 19200 -> Cf, no bias:  dW += dz^T a4 ; da4 = dz W
     a4 = cs["a4"]
+    g_partial = None                     # BatchNorm-backward statistics partials of g, when the kernel that produced g also reduced them
+    Wout = S["convstack.out.weight"]
     if a4 is None:                         # the Linear read relu(bn4(y4)) on the fly: so does its weight gradient
         y4 = cs["y"][3].view(rows, 40 * F)
         da = torch.empty_like(y4)
-        _linear_bwd(y4, S["convstack.out.weight"], dz, G, "convstack.out.weight", None, dx=da, x_affine=(cs["bn"][3][2], cs["bn"][3][3], F))
+        bn4 = cs["bn"][3]
+        _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F))
+        if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0:
+            # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
+            nblk = L.a2s_gemm_bnstats_blocks(rows, F)
+            part = torch.empty((nblk, 40, 2), dtype=torch.float32, device=dev)
+            hip.check(L.a2s_gemm_f32_bnstats(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(Wout), C.c_long(40 * F), C.c_long(1),
+                                             hip._p(da), C.c_long(40 * F), hip._p(y4), hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F,
+                                             hip._p(part)), "a2s_gemm_f32_bnstats")
+            g_partial = (part, nblk)
+        else:
+            hip.gemm(dz, Cf, 1, Wout, 40 * F, 1, da, 40 * F, rows, 40 * F, Cf)
     else:
         da = torch.empty_like(a4)
-        _linear_bwd(a4, S["convstack.out.weight"], dz, G, "convstack.out.weight", None, dx=da)
+        _linear_bwd(a4, Wout, dz, G, "convstack.out.weight", None, dx=da)
     chans = [(1, 20), (20, 20), (20, 40), (40, 40)]
     g = da.view(B, T, 40, F)
-    g_partial = None                     # BatchNorm-backward statistics partials of g, when the kernel that produced g also reduced them
     for i in (4, 3, 2, 1):
         ci, co = chans[i - 1]
         y = cs["y"][i - 1]                                    # pre-BN conv output of this layer

@@ -280,3 +280,41 @@ def test_gemm_with_operand_batchnorm_relu(dev):
     _report("gemm operand affine forward", e1)
     _report("gemm operand affine wgrad", max(e2, e3))
     assert max(e1, e2, e3) < 2e-5, (e1, e2, e3)
+
+
+@pytest.mark.parametrize("M,period,chans,K", [(203, 128, 3, 40), (300, 480, 2, 64), (130, 132, 5, 16)])
+def test_gemm_with_batchnorm_backward_statistics_epilogue(dev, M, period, chans, K):
+    """a2s_gemm_f32_bnstats: C = A B plus, in the epilogue, the per-channel sums  sum g', sum g' xhat  of the output read as the gradient
+    wrt relu(bn(y)) (channel = column // period; channels straddle the 128-column tiles), in the partial layout bn_bwd_finalize reads."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g0 = torch.Generator().manual_seed(M + period)
+    N = period * chans
+    A = torch.randn(M, K, generator=g0)
+    Bm = torch.randn(K, N, generator=g0) * 0.2
+    y = torch.randn(M, N, generator=g0)
+    mean, invstd = torch.randn(chans, generator=g0) * 0.1, torch.rand(chans, generator=g0) + 0.5
+    scale, shift = torch.rand(chans, generator=g0) + 0.5, torch.randn(chans, generator=g0) * 0.3
+    Cref = A @ Bm
+    ch = torch.arange(N) // period
+    mask = (y * scale[ch] + shift[ch]) > 0
+    gm = torch.where(mask, Cref, torch.zeros(()))
+    xhat = (y - mean[ch]) * invstd[ch]
+    s1 = torch.stack([gm[:, ch == c].sum() for c in range(chans)])
+    s2 = torch.stack([(gm * xhat)[:, ch == c].sum() for c in range(chans)])
+    Ad, Bd, yd = A.to(dev), Bm.to(dev), y.to(dev)
+    md, isd, scd, shd = mean.to(dev), invstd.to(dev), scale.to(dev), shift.to(dev)      # named: raw pointers keep nothing alive
+    Cd = torch.empty(M, N, device=dev)
+    nblk = L.a2s_gemm_bnstats_blocks(M, period)
+    part = torch.full((nblk, chans, 2), 7.0, device=dev)
+    hip.check(L.a2s_gemm_f32_bnstats(hip.stream(), M, N, K, hip._p(Ad), C.c_long(K), C.c_long(1), hip._p(Bd), C.c_long(N), C.c_long(1), hip._p(Cd), C.c_long(N),
+                                     hip._p(yd), hip._p(md), hip._p(isd), hip._p(scd), hip._p(shd), period,
+                                     hip._p(part)), "gemm bnstats")
+    torch.cuda.synchronize()
+    tot = part.double().sum(0).cpu()
+    e_c = _rel(Cd, Cref)
+    e1 = float((tot[:, 0] - s1.double()).abs().max() / s1.abs().max())
+    e2 = float((tot[:, 1] - s2.double()).abs().max() / s2.abs().max())
+    _report(f"gemm bn-stats epilogue M{M} period{period} C", e_c)
+    _report(f"gemm bn-stats epilogue M{M} period{period} sums", max(e1, e2))
+    assert e_c < 2e-5 and e1 < 2e-5 and e2 < 2e-5, (e_c, e1, e2)
