@@ -81,8 +81,11 @@ def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_a
     _colsum(dvp, H, G[prefix + ".v.weight"], nblk, H)
 
 
-def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T):
-    """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (rows, 2H); rows = groups * n_clips."""
+def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T, deferred=None):
+    """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (rows, 2H); rows = groups * n_clips.
+    deferred: optional HIP stream for everything that does not gate the recurrence (weight gradients, the deferred key / encoder-
+    output gradients, embedding scatter): a staff's stream executes in order, so leaving them on it would put ~20 % of MFMA-bound GEMM
+    time in series with the HBM-bound attention steps of the next segment; returns (dh0, event after the deferred work or None)."""
     L = hip.lib()
     groups = sv.get("groups", 1)
     B = groups * n_clips
@@ -98,7 +101,8 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     # (b) output projection, all steps at once: do_all = dlog W_out ; dW_out += dlog^T o ; db_out += colsum
     o2d, dlog2d = sv["o"].view(R, 2 * H2), dlog.view(R, V)
     do_all = torch.empty((n, B, 2 * H2), dtype=torch.float32, device=dev)
-    _linear_bwd(o2d, S[prefix + ".out.weight"], dlog2d, G, prefix + ".out.weight", prefix + ".out.bias", dx=do_all.view(R, 2 * H2))
+    Wo = S[prefix + ".out.weight"]
+    hip.gemm(dlog2d, V, 1, Wo, 2 * H2, 1, do_all.view(R, 2 * H2), 2 * H2, R, 2 * H2, V)          # do_all = dlog W_out  (gates the recurrence)
     # (c) reverse recurrence
     dgi_all = torch.empty((n, B, 3 * H2), dtype=torch.float32, device=dev)
     dgh_all = torch.empty((n, B, 3 * H2), dtype=torch.float32, device=dev)
@@ -120,34 +124,49 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     a.n_clips = sv["active"]["n_clips"] if sv.get("active") else 0
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
-    # (d) deferred weight gradients over all steps
-    x2d, h2d = sv["x"][:n].view(R, ldx), sv["h"][:n].view(R, H2)
-    _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_all.view(R, 3 * H2), G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0")
-    _linear_bwd(h2d, S[prefix + ".gru.weight_hh_l0"], dgh_all.view(R, 3 * H2), G, prefix + ".gru.weight_hh_l0", prefix + ".gru.bias_hh_l0")
-    # attention query half: dW[:, :2H] += dq^T h ; db += colsum(dq)
-    Gw = G[prefix + ".attn.attn.weight"]
-    sk = L.a2s_gemm_pick_splitk(H, H2, R, 1)
-    hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk)
-    _colsum(dq_all, H, G[prefix + ".attn.attn.bias"], R, H)
-    _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, n_clips, T, H, n, sv.get("active"), groups)
-    # embedding rows of the tokens consumed at each step: <sos> at step 0, then gt or argmax of the previous step
-    tok = torch.full((n, B), SOS, dtype=torch.int32, device=dev)
-    if n > 1:
-        prev = sv["ids"][:, :n - 1].t()
-        if sv["gt_bar"] is not None:
-            bits = sv.get("flags_dev")                                                                            # bit g: group g teacher-forced
-            if bits is None:
-                bits = torch.tensor(sv["flags"][:n - 1], dtype=torch.int32, device=dev)
-            bits = bits[:n - 1].unsqueeze(1)
-            grp = (torch.arange(B, dtype=torch.int32, device=dev) // n_clips).unsqueeze(0)
-            flags = ((bits >> grp) & 1).bool()
-            prev = torch.where(flags, sv["gt_bar"][:, :n - 1].t().to(torch.int32), prev)
-        tok[1:] = prev
-    drop = sv["drop"]
-    hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[prefix + ".embedding.weight"]), NULL, hip._p(tok), C.c_long(1), 0, hip._p(dx),
-                                      C.c_long(ldx), 0, R, E, hip._p(drop), hip.f32(1.0 / (1.0 - sv["drop_p"]) if drop is not None else 1.0)),
-              "a2s_embed_scatter_add")
-    return dh[0]
+    # (d) everything nobody in the recurrence waits for
+    def deferred_work():
+        _linear_bwd(o2d, Wo, dlog2d, G, prefix + ".out.weight", prefix + ".out.bias")               # dW_out += dlog^T o ; db_out += colsum
+        x2d, h2d = sv["x"][:n].view(R, ldx), sv["h"][:n].view(R, H2)
+        _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_all.view(R, 3 * H2), G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0")
+        _linear_bwd(h2d, S[prefix + ".gru.weight_hh_l0"], dgh_all.view(R, 3 * H2), G, prefix + ".gru.weight_hh_l0", prefix + ".gru.bias_hh_l0")
+        # attention query half: dW[:, :2H] += dq^T h ; db += colsum(dq)
+        Gw = G[prefix + ".attn.attn.weight"]
+        sk = L.a2s_gemm_pick_splitk(H, H2, R, 1)
+        hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk)
+        _colsum(dq_all, H, G[prefix + ".attn.attn.bias"], R, H)
+        _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, n_clips, T, H, n, sv.get("active"), groups)
+        # embedding rows of the tokens consumed at each step: <sos> at step 0, then gt or argmax of the previous step
+        tok = torch.full((n, B), SOS, dtype=torch.int32, device=dev)
+        if n > 1:
+            prev = sv["ids"][:, :n - 1].t()
+            if sv["gt_bar"] is not None:
+                bits = sv.get("flags_dev")                                                                            # bit g: group g teacher-forced
+                if bits is None:
+                    bits = torch.tensor(sv["flags"][:n - 1], dtype=torch.int32, device=dev)
+                bits = bits[:n - 1].unsqueeze(1)
+                grp = (torch.arange(B, dtype=torch.int32, device=dev) // n_clips).unsqueeze(0)
+                flags = ((bits >> grp) & 1).bool()
+                prev = torch.where(flags, sv["gt_bar"][:, :n - 1].t().to(torch.int32), prev)
+            tok[1:] = prev
+        drop = sv["drop"]
+        hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[prefix + ".embedding.weight"]), NULL, hip._p(tok), C.c_long(1), 0, hip._p(dx),
+                                          C.c_long(ldx), 0, R, E, hip._p(drop), hip.f32(1.0 / (1.0 - sv["drop_p"]) if drop is not None else 1.0)),
+                  "a2s_embed_scatter_add")
+
+    if deferred is None:
+        deferred_work()
+        return dh[0], None
+    ev = torch.cuda.Event()
+    ev.record()
+    deferred.wait_event(ev)
+    for t in (dlog, do_all, dgi_all, dgh_all, dq_all, ds_all, dctx_all, dx):
+        t.record_stream(deferred)                       # keep the allocator from handing them back to the staff stream too early
+    with torch.cuda.stream(deferred):
+        deferred_work()
+        done = torch.cuda.Event()
+        done.record()
+    return dh[0], done
 
 
 def backward(eng, S, grad_outputs, grad_ready=None):
@@ -190,6 +209,10 @@ def backward(eng, S, grad_outputs, grad_ready=None):
     dEnc_staff = [torch.zeros_like(dEnc), torch.zeros_like(dEnc)] if concurrent else [dEnc, dEnc]
 
     bar_major = bool(sv.get("bar_major"))
+    # weight gradients etc. of each staff: off its recurrence stream (A2S_DEFER_STREAM=0: in line, for A/B measurements)
+    use_deferred = concurrent and os.environ.get("A2S_DEFER_STREAM", "1") != "0"
+    deferred_streams = _deferred_streams(dev) if use_deferred else None
+    deferred_done = []
     seg_dh0 = {}                # segment index -> [dh0 of the upper call, dh0 of the lower call], rows = (bar in segment, clip)
 
     def segment_decoders_bwd(si_seg):
@@ -203,11 +226,14 @@ def backward(eng, S, grad_outputs, grad_ready=None):
                 dpr, pr = dout[bar0:bar0 + nb].view(nb * B, maxs, -1), out_t[bar0:bar0 + nb].view(nb * B, maxs, -1)
             else:
                 dpr, pr = dout[:, bar0], out_t[:, bar0]
-            calls.append((eng, S, G, seg["staff"][name][2], sv["keys"][prefix], enc, dpr, pr, dK[prefix], dEnc_staff[si], B, T))
+            calls.append((eng, S, G, seg["staff"][name][2], sv["keys"][prefix], enc, dpr, pr, dK[prefix], dEnc_staff[si], B, T,
+                          deferred_streams[si] if use_deferred else None))
         if concurrent:      # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
-            seg_dh0[si_seg] = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
+            res, events = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
+            seg_dh0[si_seg] = ([r[0] for r in res], events)
+            deferred_done.extend(r[1] for r in res if r[1] is not None)
         else:
-            seg_dh0[si_seg] = ([_note_decoder_bwd(*args) for args in calls], [])
+            seg_dh0[si_seg] = ([_note_decoder_bwd(*args)[0] for args in calls], [])
 
     # The note decoders' backward passes only need the loss gradients: all segments are enqueued up front (last segment first, as the
     # bar chain below consumes them), so the two staff streams run through every segment back to back instead of draining at each
@@ -286,6 +312,8 @@ def backward(eng, S, grad_outputs, grad_ready=None):
     for table, cid, col, width in (("decoder.time_sig_emb.weight", cfg["num_time_sig"], 4 * Sz, te), ("decoder.key_emb.weight", cfg["num_keys"], 4 * Sz + te, ke)):
         hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[table]), NULL, NULL, C.c_long(0), cid, hip._p(d_token_next), C.c_long(tokw), col, B, width,
                                           NULL, hip.f32(1.0)), "scatter sos ts/key")
+    for ev in deferred_done:                      # the staves' weight / key / encoder-output gradients are complete past this point
+        torch.cuda.current_stream().wait_event(ev)
     if concurrent:
         dEnc.add_(dEnc_staff[0]).add_(dEnc_staff[1])
     # ---- attention keys: K = enc W_e^T  ->  dW_e += dK^T enc ; dEnc += dK W_e
@@ -308,6 +336,15 @@ def backward(eng, S, grad_outputs, grad_ready=None):
 
 
 _WG_STREAMS = {}
+_DEFERRED_STREAMS = {}
+
+
+def _deferred_streams(dev):
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _DEFERRED_STREAMS:
+        _DEFERRED_STREAMS[key] = (torch.cuda.Stream(device=key), torch.cuda.Stream(device=key))
+    return _DEFERRED_STREAMS[key]
+
 
 
 def _weight_grad_stream(dev):
