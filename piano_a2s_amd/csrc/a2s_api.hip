@@ -16,6 +16,7 @@ int a2s_gemm_bnstats_slots(int);
 int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*,
                      const float*, const float*, const float*, const float*, const float*);
 size_t a2s_conv3x3_workspace_floats_impl(int);
+void a2s_conv_bf16x3_set(int);
 int a2s_conv3x3_stat_blocks_impl(int, int, int, int);
 int a2s_bn_finalize_impl(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*,
                          float*, float*, float*, float*, float, float, int);
@@ -106,6 +107,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!key) return A2S_ERR_ARG;
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
+    if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
     return A2S_ERR_ARG;
 }

@@ -274,6 +274,318 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(ConvArgs a, const float* 
     }
 }
 
+// ---- v4: the same fp32 convolution on the bf16 matrix pipes (16x the fp32-input MFMA rate).  Every fp32 operand is split
+// EXACTLY into three bf16 terms x = x0 + x1 + x2 (8 significand bits each, by truncation; the residuals are exact in fp32), and a
+// product is formed from the six term products of order >= 2^-16:  a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0), each exact in the
+// fp32 accumulator (8 x 8 bits); the dropped terms are <= 3 * 2^-24 |a||b| -- the size of one fp32 rounding.  Same tile / pipeline
+// as v3; what changes:
+//   * K = (tap, 8-channel group): v_mfma_f32_16x16x32_bf16 takes 8 consecutive k per lane = the 8 channels of a group at one tap,
+//     the four 16-lane groups of a k-step take four consecutive (tap, group) pairs of the chunk (pair p = tap * ncg + group);
+//   * input chunk = 2 channel groups (16 channels; the last chunk of Cin = 20 / 40 has one), staged position-major:
+//     lin[term][row 6][position 66][16 ch] bf16, so a lane's A fragment is ONE ds_read_b128 (32-byte position stride: conflict-free
+//     within the hardware's 16-lane read groups);  a thread stages (row, position, group) items: 8 scalar loads (coalesced along
+//     f, halo columns included -- no separate halo path), BatchNorm+ReLU, split, three 16-byte LDS stores;
+//   * weights are pre-split and pre-packed per chunk as [term][pair slot 20][n COUT][8 ch] bf16 (conv_pack_weights_bf16x3).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define C4_POS 66
+#define C4_PSTR 32                              // bytes per position (2 groups x 8 bf16)
+#define C4_ROWB (C4_POS * C4_PSTR)              // 2112
+#define C4_INPL ((CV_TR + 2) * C4_ROWB)         // bytes per term plane of the input tile (12672)
+#define C4_SLOTS 20                             // pair slots per chunk (5 k-steps x 4)
+#define C4_XIT 4                                // staging items per thread and stage (792 items / 256)
+#define C4_ITEMS ((CV_TR + 2) * C4_POS)         // items per channel group (396)
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// Two fp32 values -> their three bf16 terms, packed (x0's term in the low half): v_cvt_pk_bf16_f32 rounds to nearest even, the
+// residuals are exact in fp32 and the third term is exact, so t0 + t1 + t2 == x and the dropped products have no sign bias.
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    f32x2 v = {x0, x1};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v[0] -= __uint_as_float(p0 << 16); v[1] -= __uint_as_float(p0 & 0xffff0000u);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v[0] -= __uint_as_float(p1 << 16); v[1] -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+__host__ __device__ inline int c4_chunks(int Cin) { return ((Cin + 7) / 8 + 1) / 2; }
+// Weight slots of a term plane: the even slots first, the odd ones from a 256-byte aligned base -- the two slots a hardware
+// ds_read_b128 lane group touches (pairs p, p+1) then start on the same bank and their 8 + 8 lanes interleave without conflicts.
+__host__ __device__ constexpr int c4_odd_base(int Cout) { return (C4_SLOTS / 2 * Cout * 16 + 255) / 256 * 256; }
+__host__ __device__ constexpr int c4_wpl(int Cout) { return c4_odd_base(Cout) + C4_SLOTS / 2 * Cout * 16; }
+__host__ __device__ inline size_t c4_chunk_bytes(int Cout) { return ((size_t)3 * c4_wpl(Cout) + 4095) / 4096 * 4096; }   // whole LDS-DMA rounds
+
+__global__ void conv_pack_weights_bf16x3(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int flip) {
+    const int ncgs = (Cin + 7) / 8, nchunks = (ncgs + 1) / 2;
+    const int per_term = C4_SLOTS * Cout * 8;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nchunks * per_term) return;
+    const int chunk = e / per_term, rem = e % per_term;
+    const int k8 = rem % 8, n = (rem / 8) % Cout, p = rem / (8 * Cout);
+    const int ncg = min(2, ncgs - 2 * chunk);
+    float v = 0.f;
+    if (p < 9 * ncg) {
+        const int tap = p / ncg, ci = (chunk * 2 + p % ncg) * 8 + k8;
+        if (ci < Cin) v = flip ? w[((long)ci * Cout + n) * 9 + (8 - tap)] : w[((long)n * Cin + ci) * 9 + tap];
+    }
+    unsigned t0, t1, t2;
+    split3_pair(v, 0.f, t0, t1, t2);
+    const int wpl = c4_wpl(Cout) / 2;                 // in bf16 elements
+    unsigned short* dst = wp + (long)chunk * (c4_chunk_bytes(Cout) / 2) + (p & 1) * (c4_odd_base(Cout) / 2) + ((p >> 1) * Cout + n) * 8 + k8;
+    dst[0] = (unsigned short)t0; dst[wpl] = (unsigned short)t1; dst[2 * wpl] = (unsigned short)t2;      // pads are zeroed by the launcher
+}
+
+#ifndef C4_MH
+#define C4_MH 2          // m-tiles per pass of a k-step (2: half the A-fragment registers, B fragments read twice)
+#endif
+template <int KS, int NT, int COUT>
+__device__ __forceinline__ void c4_multiply(const unsigned char* __restrict__ lin, const unsigned char* __restrict__ lw,
+                                            const int (&aoff)[KS], int boff, f32x4 (&acc)[4][NT]) {
+    constexpr int WPL = c4_wpl(COUT);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int h = 0; h < 4 / C4_MH; ++h) {
+            bf16x8 av[3][C4_MH];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int i = 0; i < C4_MH; ++i) av[sp][i] = *reinterpret_cast<const bf16x8*>(lin + sp * C4_INPL + aoff[s] + (C4_MH * h + i) * 16 * C4_PSTR);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 bv[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) bv[sp] = *reinterpret_cast<const bf16x8*>(lw + sp * WPL + boff + s * 2 * COUT * 16 + j * 256);
+                // smallest terms first
+#define C4_PRODUCT(SA, SB)                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < C4_MH; ++i)                                                            \
+                    acc[C4_MH * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[SA][i], bv[SB], acc[C4_MH * h + i][j], 0, 0, 0);
+                C4_PRODUCT(2, 0) C4_PRODUCT(1, 1) C4_PRODUCT(0, 2) C4_PRODUCT(1, 0) C4_PRODUCT(0, 1) C4_PRODUCT(0, 0)
+#undef C4_PRODUCT
+            }
+        }
+    }
+}
+
+#ifndef C4_PREFETCH
+#define C4_PREFETCH 0
+#endif
+template <int COUT, bool BNRED>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsigned char* __restrict__ wpack) {
+    constexpr int NT = (COUT + 15) / 16;
+    constexpr int WPL = c4_wpl(COUT);                    // bytes per term plane of a packed weight chunk
+    constexpr int WCH = (3 * WPL + 4095) / 4096 * 4096;  // chunk stride of the packed image: whole 4 x 1 KB LDS-DMA rounds
+    __shared__ __attribute__((aligned(16))) unsigned char lin[3 * C4_INPL];          // 38016 B
+    __shared__ __attribute__((aligned(16))) unsigned char lw[WCH];                   // 40960 B (COUT 40); the zero tail covers the n-tile overrun of the last slot
+    __shared__ float red[4][NT * 16][2];
+    __shared__ __attribute__((aligned(16))) float lsc[48], lsh[48];                   // producer's BatchNorm scale / shift (0 beyond Cin)
+
+    const int tilesF = (a.F + C2_FT - 1) / C2_FT;
+    const int tilesT = (a.T + CV_TR - 1) / CV_TR;
+    const int groupsT = (tilesT + C3_TPW - 1) / C3_TPW;
+    int bid = blockIdx.x;
+    const int ft = bid % tilesF; bid /= tilesF;
+    const int tg = bid % groupsT; const int b = bid / groupsT;
+    const int f0 = ft * C2_FT;
+    const int tile0 = tg * C3_TPW, ntile = min(C3_TPW, tilesT - tile0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ncgs = (a.Cin + 7) / 8, nchunks = (ncgs + 1) / 2;
+    const int nstage = ntile * nchunks;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float st_s[NT], st_s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { st_s[j] = 0.f; st_s2[j] = 0.f; }
+    if (tid < 48) {
+        lsc[tid] = (a.in_scale && tid < a.Cin) ? a.in_scale[tid] : 0.f;
+        lsh[tid] = (a.in_scale && tid < a.Cin) ? a.in_shift[tid] : 0.f;
+    }
+
+    // per-lane fragment offsets: pair p = 4 s + lk of the chunk (clamped: the padded slots carry zero weights)
+    int aoff2[5], aoff1[3];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int p = min(4 * s + lk, 17), tap = p >> 1;
+        aoff2[s] = ((wave + tap / 3) * C4_POS + tap % 3 + li) * C4_PSTR + (p & 1) * 16;
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int tap = min(4 * s + lk, 8);
+        aoff1[s] = ((wave + tap / 3) * C4_POS + tap % 3 + li) * C4_PSTR;
+    }
+    const int boff = (lk & 1) * c4_odd_base(COUT) + ((lk >> 1) * COUT + li) * 16;
+
+    auto stage_tile = [&](int q) { return q / nchunks; };
+    auto stage_chunk = [&](int q) { const int i = q / nchunks, c = q % nchunks; return (i & 1) ? nchunks - 1 - c : c; };
+
+    float xreg[C4_XIT][8];
+    // packed weight chunk -> LDS by LDS-DMA (global_load_lds_dwordx4: a wave copies 1 KB, lane-linear, no registers, no ds_write):
+    // issued right after the barrier that retires the previous stage, in flight under the commit's BatchNorm / split arithmetic
+    auto load_weights = [&](int ch) {
+        const unsigned char* wsrc = wpack + (long)ch * WCH;
+#pragma unroll
+        for (int it = 0; it < WCH / 4096; ++it) {
+            const int off = (it * 4 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + off + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(lw + off), 16, 0, 0);
+        }
+    };
+    // Staging items of this thread, decoded ONCE: (row, position, group) packed in one register + the element offset relative to
+    // the stage's (t0, first channel, f0) corner.  Inside the stage loop only "laundered" copies are used, so that nothing derived
+    // from them is hoisted (the compiler otherwise keeps ~100 loop-invariant addresses in registers and spills around the multiply).
+    int it_desc[C4_XIT], it_goff[C4_XIT];
+#pragma unroll
+    for (int it = 0; it < C4_XIT; ++it) {
+        const int e = tid + 256 * it;
+        const int cgl = e / C4_ITEMS, rp = e % C4_ITEMS;
+        const int r = rp / C4_POS, pos = rp % C4_POS;
+        it_desc[it] = r | (pos << 4) | (cgl << 12);
+        it_goff[it] = ((r - 1) * a.Cin + cgl * 8) * a.F + pos - 1;
+    }
+    const int clip_elems = a.T * a.Cin * a.F;
+    const float* __restrict__ xclip = a.x + (long)b * clip_elems;
+    auto issue = [&](int q) {
+        const int ch = stage_chunk(q), t0 = (tile0 + stage_tile(q)) * CV_TR;
+        const int ncg = min(2, ncgs - 2 * ch);
+        const int corner = (t0 * a.Cin + ch * 16) * a.F + f0;
+#pragma unroll
+        for (int it = 0; it < C4_XIT; ++it) {
+            if (256 * it >= ncg * C4_ITEMS) break;                 // uniform: the one-group chunk has 396 items
+            int g = it_goff[it];
+            asm volatile("" : "+v"(g));
+            g += corner;
+            // unconditional loads from a clamped element index (a branch per load would serialise the round trips); masked at commit
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xreg[it][k] = xclip[min(max(g + k * a.F, 0), clip_elems - 1)];
+        }
+    };
+    auto commit = [&](int q) {     // registers -> LDS; BN+ReLU of the producer folded in; zero = padding (of the ACTIVATED tensor)
+        const int ch = stage_chunk(q), t0 = (tile0 + stage_tile(q)) * CV_TR;
+        const int ncg = min(2, ncgs - 2 * ch);
+#pragma unroll
+        for (int it = 0; it < C4_XIT; ++it) {
+            if (256 * it >= ncg * C4_ITEMS) break;
+            int d = it_desc[it];
+            asm volatile("" : "+v"(d));
+            const int r = d & 15, pos = (d >> 4) & 255, cgl = d >> 12, rp = r * C4_POS + pos;
+            if (cgl >= ncg) continue;
+            const int t = t0 + r - 1, f = f0 + pos - 1, c0 = (ch * 2 + cgl) * 8;
+            const bool ok = t >= 0 && t < a.T && f >= 0 && f < a.F;
+            float v[8];
+            if (a.in_scale) {                                     // lsc / lsh are zero beyond Cin: padded channels come out as 0
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(lsc + c0), sc1 = *reinterpret_cast<const f32x4*>(lsc + c0 + 4);
+                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(lsh + c0), sh1 = *reinterpret_cast<const f32x4*>(lsh + c0 + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = ok ? fmaxf(xreg[it][k] * sc0[k] + sh0[k], 0.f) : 0.f;
+                    v[4 + k] = ok ? fmaxf(xreg[it][4 + k] * sc1[k] + sh1[k], 0.f) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (ok && c0 + k < a.Cin) ? xreg[it][k] : 0.f;
+            }
+            uint4 o[3];
+            split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
+            split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+            split3_pair(v[4], v[5], o[0].z, o[1].z, o[2].z);
+            split3_pair(v[6], v[7], o[0].w, o[1].w, o[2].w);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint4*>(lin + sp * C4_INPL + rp * C4_PSTR + cgl * 16) = o[sp];
+        }
+    };
+
+    int resident = -1;
+#if C4_PREFETCH
+    issue(0);
+#endif
+    for (int q = 0; q < nstage; ++q) {
+        __syncthreads();                      // previous stage fully consumed (and this stage's input loads have landed)
+        if (stage_chunk(q) != resident) load_weights(stage_chunk(q));
+#if !C4_PREFETCH
+        issue(q);                             // no register prefetch: the CU's other workgroup multiplies during this round trip
+#endif
+        commit(q);
+        resident = stage_chunk(q);
+        __syncthreads();
+#if C4_PREFETCH
+        if (q + 1 < nstage) issue(q + 1);      // in flight during the multiply below
+#endif
+#ifndef C4_NOMUL
+        if (ncgs - 2 * resident >= 2) c4_multiply<5, NT, COUT>(lin, lw, aoff2, boff, acc);
+        else c4_multiply<3, NT, COUT>(lin, lw, aoff1, boff, acc);
+#endif
+        if ((q + 1) % nchunks != 0) continue;
+        // ---- tile epilogue.  C/D map: lane holds column n = li (channel), rows lk*4+r (f positions) of each m-tile.
+        const int t = (tile0 + stage_tile(q)) * CV_TR + wave;
+        const bool row_ok = t < a.T;
+        int li_ = li, lk_ = lk;
+        asm volatile("" : "+v"(li_), "+v"(lk_));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = j * 16 + li_;
+            float bm = 0.f, bi = 0.f, bsc = 0.f, bsh = 0.f;
+            f32x4 yv[4];
+            if (BNRED && row_ok && co < COUT) {
+                bm = a.yl_mean[co]; bi = a.yl_invstd[co]; bsc = a.yl_scale[co]; bsh = a.yl_shift[co];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = f0 + i * 16 + lk_ * 4;
+                    const float* src = a.yl + (((long)b * a.T + t) * COUT + co) * a.F + f;
+                    if (f + 3 < a.F && (a.F % 4 == 0)) yv[i] = *reinterpret_cast<const f32x4*>(src);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) yv[i][r] = (f + r < a.F) ? src[r] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = f0 + i * 16 + lk_ * 4;
+                if (row_ok && co < COUT) {
+                    float* dst = a.y + (((long)b * a.T + t) * COUT + co) * a.F + f;
+                    const bool full = f + 3 < a.F && (a.F % 4 == 0);
+                    if (full) *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (!full && f + r >= a.F) continue;
+                        const float v = acc[i][j][r];
+                        if (!full) dst[r] = v;
+                        if (BNRED) {
+                            const float xv = yv[i][r];
+                            const float gm = (xv * bsc + bsh > 0.f) ? v : 0.f;
+                            st_s[j] += gm; st_s2[j] += gm * (xv - bm) * bi;
+                        } else { st_s[j] += v; st_s2[j] += v * v; }
+                    }
+                }
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);        // one n-tile at a time: hoisting every yl load spills the prefetched input
+        }
+    }
+    if (a.stat_partial) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = st_s[j], s2 = st_s2[j];
+            s += __shfl_xor(s, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lk == 0) { red[wave][j * 16 + li][0] = s; red[wave][j * 16 + li][1] = s2; }
+        }
+        __syncthreads();
+        if (tid < COUT) {
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[w][tid][0]; s2 += red[w][tid][1]; }
+            a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 0] = s;
+            a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 1] = s2;
+        }
+    }
+}
+
 // First layer: Cin = 1.  A streaming kernel (53 GFLOP at B = 256 against 12 GB written): a thread owns 4 consecutive f positions of a
 // row (16-byte stores of every output channel), walks the rows grid-stride, and keeps its per-channel sum / sum of squares in
 // registers -- the batch-statistics partials are reduced ONCE per workgroup at the end (the first version reduced 40 values across the
@@ -434,7 +746,15 @@ __global__ void bn1d_relu_dropout(const float* __restrict__ x, float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------- launchers
-size_t a2s_conv3x3_workspace_floats_impl(int Cin) { return Cin == 1 ? 0 : (size_t)(Cin / CV_CK) * C2_WCHUNK; }
+static int g_conv_bf16x3 = 0;         // 1: convolutions on the bf16 matrix pipes with 3-term split operands (conv3x3_bf16x3)
+void a2s_conv_bf16x3_set(int on) { g_conv_bf16x3 = on; }
+int a2s_conv_bf16x3_enabled(void) { return g_conv_bf16x3; }
+
+size_t a2s_conv3x3_workspace_floats_impl(int Cin) {
+    if (Cin == 1) return 0;
+    const size_t f32_image = (size_t)(Cin / CV_CK) * C2_WCHUNK, split_image = (size_t)c4_chunks(Cin) * c4_chunk_bytes(40) / 4;
+    return f32_image > split_image ? f32_image : split_image;
+}
 
 int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin);
 
@@ -452,6 +772,21 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
         A2S_REQUIRE(Cin % 4 == 0 && Cin % CV_CK == 0, "conv3x3: Cin must be a multiple of %d", CV_CK);
         A2S_REQUIRE(ws, "conv3x3: needs a workspace of a2s_conv3x3_workspace_floats(Cin) floats for the packed weights");
         A2S_REQUIRE(Cout == 20 || Cout == 40, "conv3x3: Cout must be 20 or 40 (got %d)", Cout);
+        const int nblk4 = B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
+        if (g_conv_bf16x3) {
+            const int n = c4_chunks(Cin) * C4_SLOTS * Cout * 8;
+            const hipError_t me = hipMemsetAsync(ws, 0, c4_chunks(Cin) * c4_chunk_bytes(Cout), st);
+            A2S_REQUIRE(me == hipSuccess, "conv3x3: hipMemsetAsync(packed weights): %s", hipGetErrorString(me));
+            hipLaunchKernelGGL(conv_pack_weights_bf16x3, dim3(a2s_cdiv(n, 256)), dim3(256), 0, st, w, (unsigned short*)ws, Cin, Cout, flip);
+            A2S_CHECK_LAUNCH("conv_pack_weights_bf16x3");
+            const unsigned char* wp = (const unsigned char*)ws;
+            if (Cout == 20 && !yl) hipLaunchKernelGGL((conv3x3_bf16x3<20, false>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            else if (Cout == 20) hipLaunchKernelGGL((conv3x3_bf16x3<20, true>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            else if (!yl) hipLaunchKernelGGL((conv3x3_bf16x3<40, false>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            else hipLaunchKernelGGL((conv3x3_bf16x3<40, true>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            A2S_CHECK_LAUNCH("conv3x3_bf16x3");
+            return A2S_OK;
+        }
         const int chunks = Cin / CV_CK;
         hipLaunchKernelGGL(conv_pack_weights, dim3(a2s_cdiv(chunks * C2_WCHUNK, 256)), dim3(256), 0, st, w, ws, Cin, Cout, flip, chunks);
         A2S_CHECK_LAUNCH("conv_pack_weights");
