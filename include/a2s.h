@@ -55,7 +55,10 @@ size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch);
 /* tuning aid (tools/gemm_sweep.py): force the tile configuration for M > 64 (1: 32x64, 2: 64x32, 3: 64x64, 4: 128x128; 0: heuristic) */
 void a2s_gemm_debug_tile(int cfg);
-/* measurement switches for A/B runs (tools/ab_step.py): "gru_fused" 0/1 (one-launch recurrent step), "gemm_tile" as above */
+/* measurement switches for A/B runs (tools/ab_step.py): "gru_fused" 0/1 (one-launch recurrent step), "gemm_tile" as above,
+ * "conv_bf16x3" bit mask -- which 3x3 convolutions run on the bf16 matrix pipes with every fp32 operand split exactly into three bf16
+ * terms (six products, fp32-level accuracy; csrc/a2s_conv.hip conv3x3_bf16x3): bit 0 forward launches, bit 1 data-gradient launches
+ * (default 2; 0 = the fp32-input MFMA kernel everywhere) */
 int a2s_debug_set(const char* key, int value);
 
 /* ---- ConvStack (models.py:475-502,:523-534).  Activations are (B, T, C, F); see csrc/a2s_conv.hip.

@@ -335,6 +335,9 @@ __global__ void conv_pack_weights_bf16x3(const float* __restrict__ w, unsigned s
     dst[0] = (unsigned short)t0; dst[wpl] = (unsigned short)t1; dst[2 * wpl] = (unsigned short)t2;      // pads are zeroed by the launcher
 }
 
+#ifndef C4_FRESH
+#define C4_FRESH 0        // 1: sum each k-step's six products in a fresh accumulator (3x smaller element error, 15 % slower)
+#endif
 #ifndef C4_MH
 #define C4_MH 2          // m-tiles per pass of a k-step (2: half the A-fragment registers, B fragments read twice)
 #endif
@@ -350,18 +353,42 @@ __device__ __forceinline__ void c4_multiply(const unsigned char* __restrict__ li
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
+#ifdef C4_NOLDS
+                for (int i = 0; i < C4_MH; ++i) av[sp][i] = *reinterpret_cast<const bf16x8*>(lin + sp * C4_INPL + aoff[0] + i * 16 * C4_PSTR);
+#else
                 for (int i = 0; i < C4_MH; ++i) av[sp][i] = *reinterpret_cast<const bf16x8*>(lin + sp * C4_INPL + aoff[s] + (C4_MH * h + i) * 16 * C4_PSTR);
+#endif
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 bf16x8 bv[3];
 #pragma unroll
+#ifdef C4_NOLDS
+                for (int sp = 0; sp < 3; ++sp) bv[sp] = *reinterpret_cast<const bf16x8*>(lw + sp * WPL + boff);
+#else
                 for (int sp = 0; sp < 3; ++sp) bv[sp] = *reinterpret_cast<const bf16x8*>(lw + sp * WPL + boff + s * 2 * COUT * 16 + j * 256);
+#endif
+#if C4_FRESH
+                // The six term products of this k-step (32 k values) are summed in a FRESH accumulator, smallest terms first, and added
+                // to the running one once: the large accumulator is rounded once per 32 k (the fp32-input MFMA path rounds it 8 times),
+                // and the 2^-8 / 2^-16 terms are never rounded against it.
+                f32x4 t[C4_MH];
+#pragma unroll
+                for (int i = 0; i < C4_MH; ++i) t[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2][i], bv[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#define C4_PRODUCT(SA, SB)                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < C4_MH; ++i)                                                            \
+                    t[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[SA][i], bv[SB], t[i], 0, 0, 0);
+                C4_PRODUCT(1, 1) C4_PRODUCT(0, 2) C4_PRODUCT(1, 0) C4_PRODUCT(0, 1) C4_PRODUCT(0, 0)
+#undef C4_PRODUCT
+#pragma unroll
+                for (int i = 0; i < C4_MH; ++i) acc[C4_MH * h + i][j] += t[i];
+#else
                 // smallest terms first
 #define C4_PRODUCT(SA, SB)                                                                                                   \
                 _Pragma("unroll") for (int i = 0; i < C4_MH; ++i)                                                            \
                     acc[C4_MH * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[SA][i], bv[SB], acc[C4_MH * h + i][j], 0, 0, 0);
                 C4_PRODUCT(2, 0) C4_PRODUCT(1, 1) C4_PRODUCT(0, 2) C4_PRODUCT(1, 0) C4_PRODUCT(0, 1) C4_PRODUCT(0, 0)
 #undef C4_PRODUCT
+#endif
             }
         }
     }
@@ -506,10 +533,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsig
     for (int q = 0; q < nstage; ++q) {
         __syncthreads();                      // previous stage fully consumed (and this stage's input loads have landed)
         if (stage_chunk(q) != resident) load_weights(stage_chunk(q));
+#ifdef C4_NOSTAGE
+        if (q == 0) {
+#endif
 #if !C4_PREFETCH
         issue(q);                             // no register prefetch: the CU's other workgroup multiplies during this round trip
 #endif
         commit(q);
+#ifdef C4_NOSTAGE
+        }
+#endif
         resident = stage_chunk(q);
         __syncthreads();
 #if C4_PREFETCH
@@ -520,6 +553,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsig
         else c4_multiply<3, NT, COUT>(lin, lw, aoff1, boff, acc);
 #endif
         if ((q + 1) % nchunks != 0) continue;
+#ifdef C4_NOEPI
+        if (a.B > 0) continue;
+#endif
         // ---- tile epilogue.  C/D map: lane holds column n = li (channel), rows lk*4+r (f positions) of each m-tile.
         const int t = (tile0 + stage_tile(q)) * CV_TR + wave;
         const bool row_ok = t < a.T;
@@ -746,7 +782,7 @@ __global__ void bn1d_relu_dropout(const float* __restrict__ x, float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------- launchers
-static int g_conv_bf16x3 = 0;         // 1: convolutions on the bf16 matrix pipes with 3-term split operands (conv3x3_bf16x3)
+static int g_conv_bf16x3 = 2;         // convolutions on the bf16 matrix pipes with 3-term split operands (conv3x3_bf16x3): bit 0 forward, bit 1 data-gradient launches
 void a2s_conv_bf16x3_set(int on) { g_conv_bf16x3 = on; }
 int a2s_conv_bf16x3_enabled(void) { return g_conv_bf16x3; }
 
@@ -773,7 +809,7 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
         A2S_REQUIRE(ws, "conv3x3: needs a workspace of a2s_conv3x3_workspace_floats(Cin) floats for the packed weights");
         A2S_REQUIRE(Cout == 20 || Cout == 40, "conv3x3: Cout must be 20 or 40 (got %d)", Cout);
         const int nblk4 = B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
-        if (g_conv_bf16x3) {
+        if (g_conv_bf16x3 & (flip ? 2 : 1)) {
             const int n = c4_chunks(Cin) * C4_SLOTS * Cout * 8;
             const hipError_t me = hipMemsetAsync(ws, 0, c4_chunks(Cin) * c4_chunk_bytes(Cout), st);
             A2S_REQUIRE(me == hipSuccess, "conv3x3: hipMemsetAsync(packed weights): %s", hipGetErrorString(me));

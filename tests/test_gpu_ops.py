@@ -135,6 +135,64 @@ def test_conv3x3_flip_is_data_gradient(dev):
     assert err < 5e-6, err
 
 
+@pytest.mark.parametrize("Cin,Cout,flip", [(20, 20, 0), (20, 40, 0), (40, 40, 0), (40, 40, 1), (40, 20, 1), (20, 20, 1)])
+@pytest.mark.parametrize("B,T,F", [(2, 9, 24), (1, 41, 480), (1, 6, 100)])
+def test_conv3x3_split_operand_kernel(dev, Cin, Cout, flip, B, T, F):
+    """conv3x3_bf16x3 (fp32 operands as three bf16 terms on the bf16 matrix pipes) against float64: forward launches with the
+    producer's BatchNorm+ReLU and the batch statistics, data-gradient launches with the BatchNorm-backward statistics epilogue.
+    The error is measured against sum |a||b| (what an fp32 dot product is allowed to lose) and must stay at the fp32 level."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(Cin * 100 + Cout + T + flip)
+    x = torch.randn(B, T, Cin, F, generator=g) * torch.exp(torch.randn(B, T, Cin, F, generator=g))      # wide dynamic range
+    w = torch.randn((Cin, Cout, 3, 3) if flip else (Cout, Cin, 3, 3), generator=g) * 0.2
+    scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    xd64 = x.double().permute(0, 2, 1, 3)
+    if not flip:
+        xd64 = torch.relu(xd64 * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    w64 = w.double().transpose(0, 1).flip(2, 3) if flip else w.double()
+    ref = torch.nn.functional.conv2d(xd64, w64, padding=1).permute(0, 2, 1, 3).contiguous()
+    mag = torch.nn.functional.conv2d(xd64.abs(), w64.abs(), padding=1).permute(0, 2, 1, 3) + 1e-30
+    y = torch.full((B, T, Cout, F), float("nan"), device=dev)
+    nblk = L.a2s_conv3x3_stat_blocks(B, T, F, Cin)
+    part = torch.zeros(nblk, Cout, 2, device=dev)
+    xd, wd, scd, shd = x.to(dev), w.to(dev), scale.to(dev), shift.to(dev)
+    cws = hip.conv_workspace(Cin, dev)
+    yl = torch.randn(B, T, Cout, F, generator=g)
+    mean, invstd = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    bsc, bsh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    yld, md, isd, bscd, bshd = yl.to(dev), mean.to(dev), invstd.to(dev), bsc.to(dev), bsh.to(dev)
+    hip.check(L.a2s_debug_set(b"conv_bf16x3", 3), "debug_set")
+    try:
+        if flip:
+            hip.check(L.a2s_conv3x3_dgrad_bnstats(hip.stream(), hip._p(xd), hip._p(wd), hip._p(y), hip._p(yld), hip._p(md), hip._p(isd), hip._p(bscd),
+                                                  hip._p(bshd), hip._p(part), B, T, F, Cin, Cout, hip._p(cws)), "dgrad_bnstats")
+        else:
+            hip.check(L.a2s_conv3x3(hip.stream(), hip._p(xd), hip._p(wd), hip._p(y), hip._p(scd), hip._p(shd), hip._p(part), B, T, F, Cin, Cout, 0,
+                                    hip._p(cws)), "conv")
+        torch.cuda.synchronize()
+    finally:
+        hip.check(L.a2s_debug_set(b"conv_bf16x3", 2), "debug_set")
+    assert not torch.isnan(y).any()
+    err = float(((y.cpu().double() - ref).abs() / mag).max())
+    _report(f"conv3x3 split {Cin}->{Cout} flip{flip} B{B} T{T} F{F} (vs sum|a||b|)", err)
+    assert err < 2e-6, err                                            # measured 4e-7 ... 8e-7, the fp32-input MFMA kernel 4e-7 ... 9e-7
+    assert _rel(y, ref.float()) < 5e-6
+    sums = part.cpu().double().sum(0)
+    if flip:
+        on = (yl.double() * bsc.double().view(1, 1, -1, 1) + bsh.double().view(1, 1, -1, 1)) > 0
+        gm = torch.where(on, ref, torch.zeros_like(ref))
+        xhat = (yl.double() - mean.double().view(1, 1, -1, 1)) * invstd.double().view(1, 1, -1, 1)
+        ref_s, ref_s2 = gm.sum(dim=(0, 1, 3)), (gm * xhat).sum(dim=(0, 1, 3))
+        scale_s = float(torch.where(on, mag, torch.zeros_like(mag)).sum(dim=(0, 1, 3)).max())
+        assert float((sums[:, 0] - ref_s).abs().max()) < 1e-5 * scale_s
+        assert float((sums[:, 1] - ref_s2).abs().max()) < 1e-5 * scale_s * float(xhat.abs().max())
+    else:
+        ref_s, ref_s2 = ref.sum(dim=(0, 1, 3)), (ref ** 2).sum(dim=(0, 1, 3))
+        assert float((sums[:, 0] - ref_s).abs().max()) < 1e-3 * float(ref_s.abs().max().clamp_min(1.0))
+        assert float((sums[:, 1] - ref_s2).abs().max()) < 1e-4 * float(ref_s2.abs().max())
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_finalize_matches_oracle_batch_norm(dev, training):
     from oracle import model_ref

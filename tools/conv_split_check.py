@@ -58,14 +58,14 @@ def main():
             ref = reference(x, w, scale, shift, flip)
             mag = reference(x.abs() if flip else x, w.abs(), scale, shift, flip).abs() + 1e-30     # sum |a||b|: the error scale
             out = {}
-            for mode in (0, 1):
+            for mode in (0, 3):
                 L.a2s_debug_set(b"conv_bf16x3", mode)
                 y, part = run(L, x, w, scale, shift, flip, co, stats=not flip)
                 err = ((y.double() - ref).abs() / mag).max().item()
                 s = part.double().sum(0)
                 serr = (s[:, 0] - ref.sum((0, 1, 3))).abs().max().item() if not flip else 0.0
                 out[mode] = (err, serr, torch.isnan(y).any().item())
-            print(f"B{b} T{T} F{F} {ci:2d}->{co:2d} flip{flip}: fp32 mfma err/|a||b| {out[0][0]:.2e} (sum {out[0][1]:.1e})   split {out[1][0]:.2e} (sum {out[1][1]:.1e}) nan={out[1][2]}")
+            print(f"B{b} T{T} F{F} {ci:2d}->{co:2d} flip{flip}: fp32 mfma err/|a||b| {out[0][0]:.2e} (sum {out[0][1]:.1e})   split {out[3][0]:.2e} (sum {out[3][1]:.1e}) nan={out[3][2]}")
     T, F = 1201, 480
     for ci, co, flip, what in ((20, 20, 0, "conv2 fwd"), (20, 40, 0, "conv3 fwd"), (40, 40, 0, "conv4 fwd"), (40, 40, 1, "conv4 dgrad"), (40, 20, 1, "conv3 dgrad")):
         x = torch.randn(B, T, ci, F, device=dev)
@@ -76,7 +76,7 @@ def main():
         partial = torch.empty(nblk, co, 2, device=dev)
         cws = hip.conv_workspace(ci, dev)
         line = f"{what:12s} {ci:2d}->{co:2d}"
-        for mode in (0, 1):
+        for mode in (0, 3):
             L.a2s_debug_set(b"conv_bf16x3", mode)
             ms = timed(lambda: hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(w), hip._p(y), hip._p(None if flip else scale), hip._p(None if flip else shift),
                                                        hip._p(None if flip else partial), B, T, F, ci, co, flip, hip._p(cws)), "conv"))
@@ -84,7 +84,7 @@ def main():
             line += f"   {'split' if mode else 'fp32 '} {ms:8.2f} ms {fl / ms / 1e9:6.1f} TFLOP/s"
         print(line)
         del x, y
-    L.a2s_debug_set(b"conv_bf16x3", 0)
+    L.a2s_debug_set(b"conv_bf16x3", 2)
 
 
 if __name__ == "__main__":

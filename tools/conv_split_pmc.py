@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from piano_a2s_amd import hip  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-mode = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 T, F = 1201, 480
 dev = torch.device("cuda:0")
 L = hip.lib()
