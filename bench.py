@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFS = 2500.0    # dense bf16 MFMA peak (same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense")
 MFMA_F32_PEAK_TFS = 157.3      # dense fp32-input MFMA peak (same guide: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD)
 TF_RATIO = 0.7                 # hparams/pretrain.yaml teacher_forcing_ratio at epoch 0
 
@@ -76,6 +77,15 @@ def conv_roofline(B, T, F, iters=6):
     avg_s = e0.elapsed_time(e1) / iters / 1e3
     flops = 2.0 * 9 * ci * co * B * T * F
     achieved = flops / avg_s / 1e12
+    if L.a2s_debug_get(b"conv_bf16x3") & 1:
+        # forward convolutions run on the bf16 matrix pipes: every fp32 product is six bf16 term products, so the roof of the
+        # fp32-equivalent rate is the dense bf16 peak / 6 (the achieved figure stays the ALGORITHMIC fp32 flops of the launch)
+        peak = MFMA_BF16_PEAK_TFS / 6
+        return {"bound": "mfma", "kernel": "conv3x3_bf16x3<40, false> (conv4 forward launch, incl. its weight split/packing pre-kernel)",
+                "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 term products per fp32 product (3-term exact operand split)",
+                "frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFS, 4),
+                "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}
     return {"bound": "mfma", "kernel": "conv3x3_mfma<40, false> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
             "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFS, 4), "traffic": None,
             "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}

@@ -17,6 +17,7 @@ int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const floa
                      const float*, const float*, const float*, const float*, const float*);
 size_t a2s_conv3x3_workspace_floats_impl(int);
 void a2s_conv_bf16x3_set(int);
+int a2s_conv_bf16x3_enabled(void);
 int a2s_conv3x3_stat_blocks_impl(int, int, int, int);
 int a2s_bn_finalize_impl(hipStream_t, const float*, int, int, double, const float*, const float*, float*, float*, long long*,
                          float*, float*, float*, float*, float, float, int);
@@ -36,6 +37,7 @@ int a2s_staff_emb_fwd_impl(hipStream_t, const float*, const float* const*, const
 int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch);
 void a2s_gemm_debug_tile_impl(int);
 void a2s_gru_step_fused_set(int);
+bool a2s_gru_step_fused_enabled(void);
 int a2s_note_decoder_fwd_impl(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
 
 int a2s_log_softmax_bwd_rows_impl(hipStream_t, const float*, const float*, long, int, float*, int, int, int, int);
@@ -110,6 +112,12 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
     return A2S_ERR_ARG;
+}
+
+int a2s_debug_get(const char* key) {
+    if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
+    if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
+    return -1;
 }
 
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,

@@ -12,10 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(330)
 def test_two_ranks_equal_one_process_on_the_whole_minibatch():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_check.py")], capture_output=True, text=True, timeout=540, cwd=ROOT)
+    torch.cuda.empty_cache()          # the ranks are separate processes on the same GPU: hand the parent's cached blocks back first
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_check.py")], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ranks identical: max |p0 - p1| = 0.000e+00" in r.stdout, r.stdout[-1000:]

@@ -162,6 +162,7 @@ def test_conv3x3_split_operand_kernel(dev, Cin, Cout, flip, B, T, F):
     mean, invstd = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
     bsc, bsh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
     yld, md, isd, bscd, bshd = yl.to(dev), mean.to(dev), invstd.to(dev), bsc.to(dev), bsh.to(dev)
+    previous = L.a2s_debug_get(b"conv_bf16x3")
     hip.check(L.a2s_debug_set(b"conv_bf16x3", 3), "debug_set")
     try:
         if flip:
@@ -172,7 +173,7 @@ def test_conv3x3_split_operand_kernel(dev, Cin, Cout, flip, B, T, F):
                                     hip._p(cws)), "conv")
         torch.cuda.synchronize()
     finally:
-        hip.check(L.a2s_debug_set(b"conv_bf16x3", 2), "debug_set")
+        hip.check(L.a2s_debug_set(b"conv_bf16x3", previous), "debug_set")
     assert not torch.isnan(y).any()
     err = float(((y.cpu().double() - ref).abs() / mag).max())
     _report(f"conv3x3 split {Cin}->{Cout} flip{flip} B{B} T{T} F{F} (vs sum|a||b|)", err)

@@ -1,0 +1,8 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 300 python tools/conv_split_check.py 64 2>&1 | grep -v amdgpu.ids > gpurun_out/conv_split_check.txt
+timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- python bench.py --steps 3 --warmup 1 > gpurun_out/bench_kt.log 2>&1
+python tools/kernel_stats.py gpurun_out/kt > gpurun_out/kernel_stats.txt 2>&1
+rm -rf gpurun_out/kt
+for c in "MfmaUtil SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"; do timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_split -- python tools/conv_split_pmc.py 32 3 > gpurun_out/pmc_split.log 2>&1; done
+python tools/pmc_summary.py gpurun_out/pmc_split > gpurun_out/pmc_split_summary.txt; rm -rf gpurun_out/pmc_split

@@ -57,15 +57,17 @@ def main():
             shift = None if flip else torch.randn(ci, device=dev) * 0.1
             ref = reference(x, w, scale, shift, flip)
             mag = reference(x.abs() if flip else x, w.abs(), scale, shift, flip).abs() + 1e-30     # sum |a||b|: the error scale
-            out = {}
+            out, bias = {}, {}
             for mode in (0, 3):
                 L.a2s_debug_set(b"conv_bf16x3", mode)
                 y, part = run(L, x, w, scale, shift, flip, co, stats=not flip)
                 err = ((y.double() - ref).abs() / mag).max().item()
+                bias[mode] = ((y.double() - ref) / mag).mean().item(), ((y.double() - ref) / mag).std().item()
                 s = part.double().sum(0)
                 serr = (s[:, 0] - ref.sum((0, 1, 3))).abs().max().item() if not flip else 0.0
                 out[mode] = (err, serr, torch.isnan(y).any().item())
-            print(f"B{b} T{T} F{F} {ci:2d}->{co:2d} flip{flip}: fp32 mfma err/|a||b| {out[0][0]:.2e} (sum {out[0][1]:.1e})   split {out[3][0]:.2e} (sum {out[3][1]:.1e}) nan={out[3][2]}")
+            print(f"B{b} T{T} F{F} {ci:2d}->{co:2d} flip{flip}: fp32 mfma err/|a||b| {out[0][0]:.2e} (sum {out[0][1]:.1e})   split {out[3][0]:.2e} (sum {out[3][1]:.1e}) nan={out[3][2]}"
+                  f"   signed mean/std of err/|a||b|: fp32 {bias[0][0]:+.2e}/{bias[0][1]:.2e}  split {bias[3][0]:+.2e}/{bias[3][1]:.2e}")
     T, F = 1201, 480
     for ci, co, flip, what in ((20, 20, 0, "conv2 fwd"), (20, 40, 0, "conv3 fwd"), (40, 40, 0, "conv4 fwd"), (40, 40, 1, "conv4 dgrad"), (40, 20, 1, "conv3 dgrad")):
         x = torch.randn(B, T, ci, F, device=dev)
@@ -84,7 +86,7 @@ def main():
             line += f"   {'split' if mode else 'fp32 '} {ms:8.2f} ms {fl / ms / 1e9:6.1f} TFLOP/s"
         print(line)
         del x, y
-    L.a2s_debug_set(b"conv_bf16x3", 2)
+    L.a2s_debug_set(b"conv_bf16x3", 3)
 
 
 if __name__ == "__main__":
