@@ -346,12 +346,13 @@ __global__ void conv_pack_weights_bf16x3(const float* __restrict__ w, unsigned s
 #endif
 template <int KS, int NT, int COUT>
 __device__ __forceinline__ void c4_multiply(const unsigned char* __restrict__ lin, const unsigned char* __restrict__ lw,
-                                            const int (&aoff)[KS], int boff, f32x4 (&acc)[4][NT]) {
+                                            const int (&aoff)[KS], int boff, f32x4 (&acc)[4][NT], int nh) {
     constexpr int WPL = c4_wpl(COUT);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int h = 0; h < 4 / C4_MH; ++h) {
+            if (h >= nh) break;                     // uniform: the right half of the last column tile of F = 480 lies outside the row
             bf16x8 av[3][C4_MH];
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp)
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsig
 
     int resident = -1;
     bool acc_neg = false;
+    const int nh = (f0 + C4_MH * 16 >= a.F) ? 1 : 4 / C4_MH;      // m-tile passes that hold any valid column (F = 480: 7.5 tiles of 64)
     auto flip_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -543,8 +545,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsig
         // stages therefore accumulate the NEGATED sum (input negated while staging, accumulators flipped): the truncation then pushes
         // the value the other way, and a tile's stages / neighbouring tiles cancel.
         if (!C4_FRESH && acc_neg != bool(q & 1)) { flip_acc(); acc_neg = !acc_neg; }
-        if (ncgs - 2 * resident >= 2) c4_multiply<5, NT, COUT>(lin, lw, aoff2, boff, acc);
-        else c4_multiply<3, NT, COUT>(lin, lw, aoff1, boff, acc);
+        if (ncgs - 2 * resident >= 2) c4_multiply<5, NT, COUT>(lin, lw, aoff2, boff, acc, nh);
+        else c4_multiply<3, NT, COUT>(lin, lw, aoff1, boff, acc, nh);
         if ((q + 1) % nchunks != 0) continue;
         if (acc_neg) { flip_acc(); acc_neg = false; }
         // ---- tile epilogue.  C/D map: lane holds column n = li (channel), rows lk*4+r (f positions) of each m-tile.
