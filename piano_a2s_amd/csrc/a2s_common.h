@@ -135,4 +135,20 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
     x = fminf(fmaxf(x, -30.f), 30.f);
     return __builtin_amdgcn_rcpf(1.f + __expf(-x));
 }
+// ---- fp32 operands on the bf16 matrix pipes (conv3x3_bf16x3, gemm split path)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// Two fp32 values -> their three bf16 terms, packed (x0's term in the low half): v_cvt_pk_bf16_f32 rounds to nearest even, the
+// residuals are exact in fp32 and the third term is exact, so t0 + t1 + t2 == x and the dropped products have no sign bias.
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    f32x2 v = {x0, x1};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v[0] -= __uint_as_float(p0 << 16); v[1] -= __uint_as_float(p0 & 0xffff0000u);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v[0] -= __uint_as_float(p1 << 16); v[1] -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+
 #endif

@@ -286,7 +286,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(ConvArgs a, const float* 
 //     within the hardware's 16-lane read groups);  a thread stages (row, position, group) items: 8 scalar loads (coalesced along
 //     f, halo columns included -- no separate halo path), BatchNorm+ReLU, split, three 16-byte LDS stores;
 //   * weights are pre-split and pre-packed per chunk as [term][pair slot 20][n COUT][8 ch] bf16 (conv_pack_weights_bf16x3).
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define C4_POS 66
 #define C4_PSTR 32                              // bytes per position (2 groups x 8 bf16)
 #define C4_ROWB (C4_POS * C4_PSTR)              // 2112
@@ -294,19 +293,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define C4_SLOTS 20                             // pair slots per chunk (5 k-steps x 4)
 #define C4_XIT 4                                // staging items per thread and stage (792 items / 256)
 #define C4_ITEMS ((CV_TR + 2) * C4_POS)         // items per channel group (396)
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-// Two fp32 values -> their three bf16 terms, packed (x0's term in the low half): v_cvt_pk_bf16_f32 rounds to nearest even, the
-// residuals are exact in fp32 and the third term is exact, so t0 + t1 + t2 == x and the dropped products have no sign bias.
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
-    f32x2 v = {x0, x1};
-    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    v[0] -= __uint_as_float(p0 << 16); v[1] -= __uint_as_float(p0 & 0xffff0000u);
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-    v[0] -= __uint_as_float(p1 << 16); v[1] -= __uint_as_float(p1 & 0xffff0000u);
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
 
 __host__ __device__ inline int c4_chunks(int Cin) { return ((Cin + 7) / 8 + 1) / 2; }
 // Weight slots of a term plane: the even slots first, the odd ones from a 256-byte aligned base -- the two slots a hardware

@@ -126,7 +126,46 @@ __device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+// Split path (both operands k-contiguous): registers -> LDS as three bf16 term planes [term][ROWS][32 k (+8 pad)], 80-byte rows so
+// that a lane's fragment (8 consecutive k of one row) is one ds_read_b128.  Same optional operand BatchNorm+ReLU as tile_store.
+#define GEMM_SPLIT_RS 80
+template <int ROWS, int NLD>
+__device__ __forceinline__ void tile_store_split(unsigned char* __restrict__ lds, const f32x4 (&reg)[NLD], const float (&aff)[NLD][2], int r0, int k0,
+                                                 int rmax, int kmax, const float* __restrict__ scale, const float* __restrict__ shift, int period,
+                                                 bool negate) {
+    const int tid = threadIdx.x;
+    const unsigned sgn = negate ? 0x80000000u : 0u;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int slot = tid + i * 256;
+        const int r = slot >> 3, k = (slot & 7) * 4;
+        if (r >= ROWS) continue;
+        f32x4 v = reg[i];
+        if (scale) {
+            const int gr = r0 + r, gk = k0 + k;
+            const bool row_ok = gr < rmax;
+            if ((period & 3) == 0 && (gk & 3) == 0) {
+                const float sc = aff[i][0], sh = aff[i][1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (row_ok && gk + j < kmax) v[j] = fmaxf(fmaf(v[j], sc, sh), 0.f);
+            } else {
+                const float inv = 1.f / (float)period;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (row_ok && gk + j < kmax) { const int c = (int)(((float)(gk + j) + 0.5f) * inv); v[j] = fmaxf(fmaf(v[j], scale[c], shift[c]), 0.f); }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__float_as_uint(v[j]) ^ sgn);
+        uint2 o[3];
+        split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
+        split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint2*>(lds + (sp * ROWS + r) * GEMM_SPLIT_RS + k * 2) = o[sp];
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
     constexpr int NLA = (BM * 8 + 255) / 256, NLB = (BN * 8 + 255) / 256;
@@ -157,32 +196,81 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
         tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
     }
-    for (int t = 0; t < ntiles; ++t) {
-        float* la = lds + (t & 1) * (LA::SIZE + LB::SIZE);
-        float* lb = la + LA::SIZE;
-        tile_store<BM, A_KC, NLA>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period);
-        tile_store<BN, B_KC, NLB>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period);
-        __syncthreads();
-        if (t + 1 < ntiles) {   // prefetch next tile while this one is multiplied
-            const int k0 = kbeg + (t + 1) * GEMM_BK;
-            tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
-            tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
-        }
-#pragma unroll
-        for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = la[LA::at(wm + i * 16 + lr, ks * 4 + lk)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = lb[LB::at(wn + j * 16 + lr, ks * 4 + lk)];
+    if constexpr (SPLIT) {
+        // fp32 operands as three exact bf16 terms on the bf16 matrix pipes (six term products per k-step of 32, see conv3x3_bf16x3 in
+        // a2s_conv.hip); single LDS buffer (2 x 30 KB), the next tile's global loads stay in flight during the multiply.  The pipe truncates
+        // its internal sum toward -infinity: every other block of 8 k-tiles accumulates the negated sum (A negated while staging).
+        static_assert(A_KC && B_KC && 3 * (BM + BN) * GEMM_SPLIT_RS <= (int)sizeof(lds), "split path: k-contiguous operands only");
+        unsigned char* la = reinterpret_cast<unsigned char*>(lds);
+        unsigned char* lb = la + 3 * BM * GEMM_SPLIT_RS;
+        bool neg = false;
+        auto flip = [&]() {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);     // transposed tile: see the epilogue
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = -acc[i][j][r];
+        };
+        for (int t = 0; t < ntiles; ++t) {
+            const bool want = (t >> 3) & 1;
+            __syncthreads();                  // the previous tile's fragments are consumed
+            tile_store_split<BM, NLA>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want);
+            tile_store_split<BN, NLB>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false);
+            __syncthreads();
+            if (t + 1 < ntiles) {
+                const int k0 = kbeg + (t + 1) * GEMM_BK;
+                tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
+                tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
+            }
+            if (want != neg) { flip(); neg = want; }
+            bf16x8 af[3][TM];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[sp][i] = *reinterpret_cast<const bf16x8*>(la + (sp * BM + wm + i * 16 + lr) * GEMM_SPLIT_RS + lk * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bf16x8 bf[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) bf[sp] = *reinterpret_cast<const bf16x8*>(lb + (sp * BN + wn + j * 16 + lr) * GEMM_SPLIT_RS + lk * 16);
+#define GEMM_PRODUCT(SA, SB)                                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[SB], af[SA][i], acc[i][j], 0, 0, 0);
+                GEMM_PRODUCT(2, 0) GEMM_PRODUCT(1, 1) GEMM_PRODUCT(0, 2) GEMM_PRODUCT(1, 0) GEMM_PRODUCT(0, 1) GEMM_PRODUCT(0, 0)
+#undef GEMM_PRODUCT
+            }
         }
-        // the other LDS buffer is written next iteration; its readers finished before the barrier above
-    }
+        if (neg) flip();
+    } else {
+    for (int t = 0; t < ntiles; ++t) {
+            float* la = lds + (t & 1) * (LA::SIZE + LB::SIZE);
+            float* lb = la + LA::SIZE;
+            tile_store<BM, A_KC, NLA>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period);
+            tile_store<BN, B_KC, NLB>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period);
+            __syncthreads();
+            if (t + 1 < ntiles) {   // prefetch next tile while this one is multiplied
+                const int k0 = kbeg + (t + 1) * GEMM_BK;
+                tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
+                tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
+            }
+    #pragma unroll
+            for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
+                float a[TM], b[TN];
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = la[LA::at(wm + i * 16 + lr, ks * 4 + lk)];
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = lb[LB::at(wn + j * 16 + lr, ks * 4 + lk)];
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);     // transposed tile: see the epilogue
+            }
+            // the other LDS buffer is written next iteration; its readers finished before the barrier above
+        }
+    
+}
 
     // epilogue.  The MFMAs were issued with the operands swapped (B fragment first), so every accumulator holds the TRANSPOSED 16x16 tile:
     // lane = (m = lane & 15, n-quad = lane >> 4) owns C[m][4q .. 4q+3] -- four CONSECUTIVE columns of one output row, i.e. one 16-byte
@@ -284,9 +372,20 @@ __global__ void gemm_splitk_reduce(GemmArgs g) {
     *c = v;
 }
 
+// 1: 128x128 launches with two k-contiguous operands run on the bf16 matrix pipes with 3-term split operands (a2s_debug_set "gemm_bf16x3")
+static int g_gemm_split = 1;
+void a2s_gemm_split_set(int on) { g_gemm_split = on; }
+int a2s_gemm_split_enabled(void) { return g_gemm_split; }
+
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
     dim3 grid(a2s_cdiv(g.N, BN), a2s_cdiv(g.M, BM), g.batch * g.splitk);
+    if constexpr (BM == 128 && BN == 128) {
+        if (akc && bkc && g_gemm_split && g.K >= 256) {
+            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, true>), grid, dim3(256), 0, st, g);
+            return;
+        }
+    }
     if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, g);
     else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, g);
     else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, g);

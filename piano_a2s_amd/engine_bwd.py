@@ -477,7 +477,13 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             nblk = L.a2s_gemm_bnstats_blocks(rows, F)
             part = torch.empty((nblk, 40, 2), dtype=torch.float32, device=dev)
-            hip.check(L.a2s_gemm_f32_bnstats(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(Wout), C.c_long(40 * F), C.c_long(1),
+            if L.a2s_debug_get(b"gemm_bf16x3") > 0:
+                # a k-contiguous copy of the weight (19.7 MB) puts this product on the split-operand path of the GEMM (both operands k-contiguous)
+                Wt = Wout.t().contiguous()
+                wb, s_bk, s_bn = Wt, 1, Cf
+            else:
+                wb, s_bk, s_bn = Wout, 40 * F, 1
+            hip.check(L.a2s_gemm_f32_bnstats(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(wb), C.c_long(s_bk), C.c_long(s_bn),
                                              hip._p(da), C.c_long(40 * F), hip._p(y4), hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F,
                                              hip._p(part)), "a2s_gemm_f32_bnstats")
             g_partial = (part, nblk)

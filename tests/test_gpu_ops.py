@@ -194,6 +194,40 @@ def test_conv3x3_split_operand_kernel(dev, Cin, Cout, flip, B, T, F):
         assert float((sums[:, 1] - ref_s2).abs().max()) < 1e-4 * float(ref_s2.abs().max())
 
 
+@pytest.mark.parametrize("K,affine", [(1000, False), (960, True), (19200, True)])
+def test_gemm_split_operand_path(dev, K, affine):
+    """The 128x128 GEMM tile with two k-contiguous operands on the bf16 matrix pipes (fp32 operands as three exact bf16 terms; opt-in
+    switch "gemm_bf16x3") against float64, with and without the operand BatchNorm+ReLU; M is large enough for the 128x128 configuration."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(K)
+    M, N = 12800 + 37, 256
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    period = 480 if K == 19200 else 40
+    aff = ((torch.rand(K // period, generator=g) + 0.5).to(dev), (torch.randn(K // period, generator=g) * 0.3).to(dev), period) if affine else None
+    xd = x.double()
+    if affine:
+        xd = torch.relu(xd * aff[0].double().repeat_interleave(period) + aff[1].double().repeat_interleave(period))
+    ref = xd @ w.double().t() + b.double()
+    mag = xd.abs() @ w.double().abs().t() + b.double().abs() + 1e-30
+    previous = L.a2s_debug_get(b"gemm_bf16x3")
+    errs = {}
+    try:
+        for mode in (0, 1):
+            hip.check(L.a2s_debug_set(b"gemm_bf16x3", mode), "debug_set")
+            y = hip.linear(x, w, b, x_affine=aff)
+            torch.cuda.synchronize()
+            errs[mode] = float(((y.double() - ref).abs() / mag).max())
+    finally:
+        hip.check(L.a2s_debug_set(b"gemm_bf16x3", previous), "debug_set")
+    _report(f"gemm split K{K} affine{int(affine)} (vs sum|a||b|): fp32-input", errs[0])
+    _report(f"gemm split K{K} affine{int(affine)} (vs sum|a||b|): split", errs[1])
+    assert errs[1] < 2e-6, errs
+    assert errs[1] < 3 * errs[0] + 1e-7, errs          # at the fp32-input kernel's level
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_finalize_matches_oracle_batch_norm(dev, training):
     from oracle import model_ref
