@@ -396,7 +396,10 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
         for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
             dgi2 = res[d][0].view(B * T, 3 * H)
             Wih = S[f"encoder.gru.weight_ih_{sfx}"]
-            hip.gemm(dgi2, 3 * H, 1, Wih, I, 1, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0)
+            if L.a2s_debug_get(b"gemm_bf16x3") > 0:      # k-contiguous weight copy (<= 1.5 MB): both operands on the GEMM's split-operand path
+                hip.gemm(dgi2, 3 * H, 1, Wih.t().contiguous(), 1, 3 * H, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0)
+            else:
+                hip.gemm(dgi2, 3 * H, 1, Wih, I, 1, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0)
         # ... the weight gradients (MFMA-bound, nobody waits for them) on a third stream, under the next layer's latency-bound recurrence
         wg = _weight_grad_stream(dev)
         ev = torch.cuda.Event()
