@@ -228,6 +228,48 @@ def test_gemm_split_operand_path(dev, K, affine):
     assert errs[1] < 3 * errs[0] + 1e-7, errs          # at the fp32-input kernel's level
 
 
+@pytest.mark.parametrize("form", ["data_gradient", "weight_gradient"])
+def test_gemm_split_operand_path_row_contiguous_operands(dev, form):
+    """Split-operand GEMM tiles with operands whose ROW dimension is the contiguous one (transposed staging): the data-gradient form
+    (B = W[k][n]) and the weight-gradient form (both operands row-contiguous, K = the long row count, split-K, BatchNorm+ReLU on B)."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(len(form))
+    if form == "data_gradient":
+        M, K, N = 12800 + 37, 1000, 256
+        a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(dev)
+        w = (torch.randn(K, N, generator=g) * 0.05).to(dev)
+        ref = a.double() @ w.double()
+        mag = a.double().abs() @ w.double().abs() + 1e-30
+        run = lambda out: hip.gemm(a, K, 1, w, N, 1, out, N, M, N, K)
+        shape = (M, N)
+    else:
+        R, Mo, No, period = 30000 + 3, 256, 512, 64
+        dz = torch.randn(R, Mo, generator=g).to(dev)
+        x = (torch.randn(R, No, generator=g) * torch.exp(torch.randn(R, 1, generator=g))).to(dev)
+        aff = ((torch.rand(No // period, generator=g) + 0.5).to(dev), (torch.randn(No // period, generator=g) * 0.3).to(dev), period)
+        xa = torch.relu(x.double() * aff[0].double().repeat_interleave(period) + aff[1].double().repeat_interleave(period))
+        ref = dz.double().t() @ xa
+        mag = dz.double().abs().t() @ xa.abs() + 1e-30
+        run = lambda out: hip.gemm(dz, 1, Mo, x, No, 1, out, No, Mo, No, R, splitk=24, b_affine=aff)
+        shape = (Mo, No)
+    previous = L.a2s_debug_get(b"gemm_bf16x3")
+    errs = {}
+    try:
+        for mode in (0, 1):
+            hip.check(L.a2s_debug_set(b"gemm_bf16x3", mode), "debug_set")
+            out = torch.full(shape, float("nan"), device=dev)
+            run(out)
+            torch.cuda.synchronize()
+            errs[mode] = float(((out.double() - ref).abs() / mag).max())
+    finally:
+        hip.check(L.a2s_debug_set(b"gemm_bf16x3", previous), "debug_set")
+    _report(f"gemm split {form} (vs sum|a||b|): fp32-input", errs[0])
+    _report(f"gemm split {form} (vs sum|a||b|): split", errs[1])
+    assert errs[1] < 2e-6, errs
+    assert errs[1] < 3 * errs[0] + 1e-7, errs
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_finalize_matches_oracle_batch_norm(dev, training):
     from oracle import model_ref
