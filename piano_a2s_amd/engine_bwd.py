@@ -476,7 +476,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         da = torch.empty_like(y4)
         bn4 = cs["bn"][3]
         _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F))
-        if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0:
+        if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             nblk = L.a2s_gemm_bnstats_blocks(rows, F)
             part = torch.empty((nblk, 40, 2), dtype=torch.float32, device=dev)

@@ -197,3 +197,30 @@ def test_skipping_rows_and_fusing_bars_do_not_change_the_step(dev, tf_ratio, see
             assert torch.allclose(out0[keep], out1[keep], rtol=0, atol=2e-6)
         assert torch.allclose(o0[0], o1[0], atol=2e-6) and torch.allclose(o0[1], o1[1], atol=2e-6)
         assert not torch.equal(o0[2], o1[2])
+
+
+@pytest.mark.parametrize("B,T,maxlen,bars,tf", [(1, 37, (9, 5), 2, 0.7), (5, 64, (3, 2), 4, 0.0), (7, 203, (21, 33), 3, 0.5)])
+def test_odd_shapes_through_the_fused_step_and_the_greedy_decoder(dev, B, T, maxlen, bars, tf):
+    """Full-width model on shapes that are not multiples of any tile size (tools/robustness_sweep.py has the longer list): a single clip of
+    37 frames (fewer rows than one GEMM tile -- the BatchNorm-statistics epilogue of the Linear's data gradient must step aside), bars of 2-3
+    tokens, no teacher forcing.  Finite losses, an applied update, finite greedy outputs."""
+    import random
+
+    import models
+    from piano_a2s_amd import spec, synthetic, train
+    cfg = spec.default_cfg(max_length=maxlen, max_bars=bars)
+    torch.manual_seed(B)
+    m = models.ScoreTranscription(**cfg).to(dev)
+    m.train()
+    step = train.TrainStep(m)
+    batch = synthetic.make_batch(B, cfg, 3 + B, frames=T, upper_range=(1, maxlen[0]), lower_range=(1, maxlen[1]), full_tail=0.15)
+    batch = [t.to(dev) if torch.is_tensor(t) else t for t in batch]
+    for k in range(2):
+        losses = step(batch, tf, rng=random.Random(k))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(losses).all()) and float(step.opt.ctl[2]) == 1.0
+    m.eval()
+    with torch.no_grad():
+        outs = m(spectrogram=batch[0], inference=True, device=dev)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
