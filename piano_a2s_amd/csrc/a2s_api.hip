@@ -18,6 +18,8 @@ int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const floa
 size_t a2s_conv3x3_workspace_floats_impl(int);
 void a2s_conv_bf16x3_set(int);
 void a2s_gemm_split_set(int);
+void a2s_wgrad_split_set(int);
+int a2s_wgrad_split_enabled(void);
 int a2s_gemm_split_enabled(void);
 int a2s_conv_bf16x3_enabled(void);
 int a2s_conv3x3_stat_blocks_impl(int, int, int, int);
@@ -113,6 +115,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_bf16x3")) { a2s_gemm_split_set(value); return A2S_OK; }
+    if (!strcmp(key, "wgrad_bf16x3")) { a2s_wgrad_split_set(value); return A2S_OK; }
     snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
     return A2S_ERR_ARG;
 }
@@ -120,6 +123,7 @@ int a2s_debug_set(const char* key, int value) {
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();
+    if (key && !strcmp(key, "wgrad_bf16x3")) return a2s_wgrad_split_enabled();
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
     return -1;
 }

@@ -1313,6 +1313,218 @@ __global__ void wgrad_reduce_c1(const float* __restrict__ partial, float* __rest
     dW[idx] += s;
 }
 
+// ---- weight gradient on the bf16 matrix pipes with 3-term split operands (see conv3x3_bf16x3).  K = positions: a fragment is 8
+// consecutive f positions of ONE channel row, so dy (M = co) and the input (N = ci) both stay position-contiguous in LDS; an N-tile is
+// 16 input channels at ONE tap, which makes the +-1 column shift of the tap uniform per MFMA: the lane reads the aligned 8 positions plus
+// the dword before and after -- df = 1 is the aligned window, df = 0 / 2 are four v_alignbit_b32 each.  One 512-thread workgroup per CU
+// walks (clip, 2-row strip, 64-column) tiles; the 9 x ceil(Cin/16) (tap, channel-tile) column tiles are dealt round robin to the 8 waves
+// (<= 4 each, 12 accumulator tiles); every other tile accumulates the negated sum (dy negated while staging) against the pipe's
+// truncation bias.  One partial slab [Cout][Cin][9] per workgroup, summed in fixed order by wgrad_reduce_c1.
+#define W4_XROW 160                       // bytes per staged input row: 80 bf16, interior at element 8 (halo columns at 7 and 72)
+#define W4_XCI (4 * W4_XROW + 16)         // 656: channel stride (pad -> conflict-free fragment reads across the 16 channels of a tile)
+#define W4_DYCO (2 * 128 + 16)            // 272: output-channel stride of the dy image [co][2 rows][64]
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int COUT>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                               float* __restrict__ partial, int B, int T, int F, int Cin) {
+    constexpr int MT = (COUT + 15) / 16;
+    constexpr int XPL = 48 * W4_XCI;          // bytes per term plane of the input image (48 channel planes; beyond Cin they stay zero)
+    constexpr int DPL = MT * 16 * W4_DYCO;
+    __shared__ __attribute__((aligned(16))) unsigned char lx[3 * XPL];
+    __shared__ __attribute__((aligned(16))) unsigned char ldy[3 * DPL];
+    __shared__ __attribute__((aligned(16))) float lsc[48], lsh[48];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nc16 = (Cin + 15) / 16, npair = 9 * nc16;
+    for (int e = tid; e < 3 * XPL / 16; e += 512) reinterpret_cast<uint4*>(lx)[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int e = tid; e < 3 * DPL / 16; e += 512) reinterpret_cast<uint4*>(ldy)[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 48) {
+        lsc[tid] = (in_scale && tid < Cin) ? in_scale[tid] : 0.f;
+        lsh[tid] = (in_scale && tid < Cin) ? in_shift[tid] : 0.f;
+    }
+    f32x4 acc[4][MT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tilesF = (F + 63) / 64, tilesT = (T + 1) / 2;
+    const long ntiles = (long)B * tilesT * tilesF;
+    const bool vec_ok = (F % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+    bool acc_neg = false;
+    int round = 0;
+    // register prefetch: the global loads of the NEXT tile are issued before the multiply of the current one and committed after it
+    constexpr int DIT = (COUT * 32 + 511) / 512, XIT = 5;           // 16-byte loads per thread: dy (3 / 2), input (<= 40 ch x 4 rows x 16)
+    f32x4 dreg[DIT], xreg[XIT];
+    float hreg = 0.f;
+    auto issue = [&](long tile) {
+        long bid = tile;
+        const int ft = (int)(bid % tilesF); bid /= tilesF;
+        const int tt = (int)(bid % tilesT); const int b = (int)(bid / tilesT);
+        const int t0 = tt * 2, f0 = ft * 64;
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + 512 * it;
+            const int co = e >> 5, r = (e >> 4) & 1, fq = e & 15;
+            const int t = t0 + r, f = f0 + 4 * fq;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < COUT * 32 && t < T && f < F) {
+                const float* src = dy + (((long)b * T + t) * COUT + co) * F + f;
+                if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+                }
+            }
+            dreg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tid + 512 * it;
+            const int ci = e >> 6, row = (e >> 4) & 3, fq = e & 15;
+            const int t = t0 + row - 1, f = f0 + 4 * fq;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < Cin * 64 && t >= 0 && t < T && f < F) {
+                const float* src = x + (((long)b * T + t) * Cin + ci) * F + f;
+                if (vec_ok && f + 3 < F) v = *reinterpret_cast<const f32x4*>(src);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (f + q < F) v[q] = src[q];
+                }
+            }
+            xreg[it] = v;
+        }
+        hreg = 0.f;
+        if (tid < Cin * 8) {                 // halo columns f0 - 1 and f0 + 64
+            const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
+            const int t = t0 + row - 1, f = side ? f0 + 64 : f0 - 1;
+            if (t >= 0 && t < T && f >= 0 && f < F) hreg = x[(((long)b * T + t) * Cin + ci) * F + f];
+        }
+    };
+    auto commit = [&](long tile, unsigned sgn) {
+        long bid = tile;
+        const int ft = (int)(bid % tilesF); bid /= tilesF;
+        const int tt = (int)(bid % tilesT);
+        const int t0 = tt * 2, f0 = ft * 64;
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int e = tid + 512 * it;
+            if (e >= COUT * 32) continue;
+            const int co = e >> 5, r = (e >> 4) & 1, fq = e & 15;
+            f32x4 v = dreg[it];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(__float_as_uint(v[q]) ^ sgn);
+            uint2 o[3];
+            split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
+            split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint2*>(ldy + sp * DPL + co * W4_DYCO + r * 128 + fq * 8) = o[sp];
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tid + 512 * it;
+            if (e >= Cin * 64) continue;
+            const int ci = e >> 6, row = (e >> 4) & 3, fq = e & 15;
+            const int t = t0 + row - 1, f = f0 + 4 * fq;
+            f32x4 v = xreg[it];
+            if (in_scale && t >= 0 && t < T && f < F) {
+                const float sc = lsc[ci], sh = lsh[ci];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (f + q < F) ? fmaxf(v[q] * sc + sh, 0.f) : 0.f;
+            }
+            uint2 o[3];
+            split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
+            split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint2*>(lx + sp * XPL + ci * W4_XCI + row * W4_XROW + (8 + 4 * fq) * 2) = o[sp];
+        }
+        if (tid < Cin * 8) {
+            const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
+            const int t = t0 + row - 1, f = side ? f0 + 64 : f0 - 1;
+            float v = hreg;
+            if (in_scale && t >= 0 && t < T && f >= 0 && f < F) v = fmaxf(v * lsc[ci] + lsh[ci], 0.f);
+            unsigned p0, p1, p2;
+            split3_pair(v, 0.f, p0, p1, p2);
+            unsigned char* dst = lx + ci * W4_XCI + row * W4_XROW + (side ? 72 : 7) * 2;
+            *reinterpret_cast<unsigned short*>(dst) = (unsigned short)p0;
+            *reinterpret_cast<unsigned short*>(dst + XPL) = (unsigned short)p1;
+            *reinterpret_cast<unsigned short*>(dst + 2 * XPL) = (unsigned short)p2;
+        }
+    };
+    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++round) {
+        const bool neg = round & 1;
+        __syncthreads();                     // previous tile consumed (first round: the zero fill is complete)
+        commit(tile, neg ? 0x80000000u : 0u);
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);      // in flight during the multiply below
+        if (neg != acc_neg) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][i][r] = -acc[j][i][r];
+            acc_neg = neg;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = s >> 1, fl = (s & 1) * 32 + lk * 8;
+            bf16x8 a[3][MT];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[sp][i] = *reinterpret_cast<const bf16x8*>(ldy + sp * DPL + (i * 16 + li) * W4_DYCO + r * 128 + fl * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = wave + 8 * j;
+                if (p >= npair) continue;                       // uniform per wave
+                const int tap = p / nc16, c16 = p % nc16, dt = tap / 3, df = tap % 3;
+                const unsigned char* base = lx + (c16 * 16 + li) * W4_XCI + (r + dt) * W4_XROW + (fl + 8) * 2;
+                bf16x8 bfrag[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(base + sp * XPL);
+                    const unsigned dm1 = *reinterpret_cast<const unsigned*>(base + sp * XPL - 4);
+                    const unsigned d4 = *reinterpret_cast<const unsigned*>(base + sp * XPL + 16);
+                    u32x4 w = d;                                 // df == 1: the aligned window
+                    if (df == 0) {
+                        w[0] = __builtin_amdgcn_alignbit(d[0], dm1, 16); w[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+                        w[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16); w[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+                    } else if (df == 2) {
+                        w[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16); w[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+                        w[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16); w[3] = __builtin_amdgcn_alignbit(d4, d[3], 16);
+                    }
+                    bfrag[sp] = __builtin_bit_cast(bf16x8, w);
+                }
+#define W4_PRODUCT(SA, SB)                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                               \
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[SA][i], bfrag[SB], acc[j][i], 0, 0, 0);
+                W4_PRODUCT(2, 0) W4_PRODUCT(1, 1) W4_PRODUCT(0, 2) W4_PRODUCT(1, 0) W4_PRODUCT(0, 1) W4_PRODUCT(0, 0)
+#undef W4_PRODUCT
+            }
+        }
+    }
+    // slab [Cout][Cin][9]; C/D map: lane holds column n = li (input channel of the tile), rows 4 lk + r (output channel)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave + 8 * j;
+        if (p >= npair) continue;
+        const int tap = p / nc16, c16 = p % nc16, ci = c16 * 16 + li;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = i * 16 + lk * 4 + r;
+                if (co < COUT && ci < Cin) partial[(((long)blockIdx.x * COUT + co) * Cin + ci) * 9 + tap] = acc_neg ? -acc[j][i][r] : acc[j][i][r];
+            }
+    }
+}
+
+static int g_wgrad_split = 0;          // conv3x3_wgrad_bf16x3 for the plain (no fused BatchNorm backward) weight-gradient launches
+void a2s_wgrad_split_set(int on) { g_wgrad_split = on; }
+int a2s_wgrad_split_enabled(void) { return g_wgrad_split; }
+
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
     return (size_t)chunks * 1024 * Cout * CV_CK * 9 * sizeof(float);
@@ -1335,6 +1547,16 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
             A2S_CHECK_LAUNCH("wgrad_reduce_c1");
             return A2S_OK;
         }
+    }
+    if (g_wgrad_split && !bn_y && Cin > 1 && Cin <= 40 && (Cout == 20 || Cout == 40)) {
+        const int nslabs = 256;               // one 512-thread workgroup per CU
+        A2S_REQUIRE(ws_bytes >= (size_t)nslabs * Cout * Cin * 9 * sizeof(float), "conv3x3_wgrad: workspace too small for the split-operand kernel");
+        if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_bf16x3<20>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
+        else hipLaunchKernelGGL((conv3x3_wgrad_bf16x3<40>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
+        A2S_CHECK_LAUNCH("conv3x3_wgrad_bf16x3");
+        hipLaunchKernelGGL(wgrad_reduce_c1, dim3(a2s_cdiv(Cout * Cin * 9, 256)), dim3(256), 0, st, ws, dW, nslabs, Cout * Cin * 9);
+        A2S_CHECK_LAUNCH("wgrad_reduce_c1");
+        return A2S_OK;
     }
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
     // persistent workgroups: one full round of the occupancy the kernel reaches (__launch_bounds__(256, 3): 3 per CU for Cout 40,

@@ -202,12 +202,14 @@ def test_bn_relu_dropout_backward(dev, layout):
     assert max(errs.values()) < 2e-5, errs
 
 
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("Cin,Cout", [(1, 20), (20, 20), (20, 40), (40, 40)])
-def test_conv_weight_gradient(dev, Cin, Cout):
+def test_conv_weight_gradient(dev, Cin, Cout, split):
+    """split = 1: the split-operand kernel conv3x3_wgrad_bf16x3 (opt-in switch "wgrad_bf16x3"; Cin = 1 keeps its streaming kernel)."""
     from piano_a2s_amd import hip
     L = hip.lib()
     g = torch.Generator().manual_seed(Cin + Cout)
-    B, T, F = 2, 11, 56
+    B, T, F = (2, 11, 56) if not split else (3, 13, 100)
     x = torch.randn(B, T, Cin, F, generator=g)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2).requires_grad_(True)
     scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
@@ -222,11 +224,16 @@ def test_conv_weight_gradient(dev, Cin, Cout):
     dW = torch.zeros(Cout, Cin, 3, 3, device=dev)
     nb = L.a2s_conv3x3_wgrad_workspace_bytes(Cin, Cout)
     ws = torch.empty(nb // 4, device=dev)
-    hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dyd), hip._p(xd), hip._p(scd) if use_affine else NULL, hip._p(shd) if use_affine else NULL,
-                                  hip._p(dW), hip._p(ws), C.c_size_t(nb), B, T, F, Cin, Cout), "wgrad")
-    torch.cuda.synchronize()
+    previous = L.a2s_debug_get(b"wgrad_bf16x3")
+    hip.check(L.a2s_debug_set(b"wgrad_bf16x3", split), "debug_set")
+    try:
+        hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dyd), hip._p(xd), hip._p(scd) if use_affine else NULL, hip._p(shd) if use_affine else NULL,
+                                      hip._p(dW), hip._p(ws), C.c_size_t(nb), B, T, F, Cin, Cout), "wgrad")
+        torch.cuda.synchronize()
+    finally:
+        hip.check(L.a2s_debug_set(b"wgrad_bf16x3", previous), "debug_set")
     e = _rel(dW, w.grad)
-    _report(f"conv wgrad {Cin}->{Cout}", e)
+    _report(f"conv wgrad {Cin}->{Cout} split{split}", e)
     assert e < 2e-5, e
 
 
