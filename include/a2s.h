@@ -59,8 +59,8 @@ void a2s_gemm_debug_tile(int cfg);
  * "conv_bf16x3" bit mask -- which 3x3 convolutions run on the bf16 matrix pipes with every fp32 operand split exactly into three bf16
  * terms (six products, fp32-level accuracy; csrc/a2s_conv.hip conv3x3_bf16x3): bit 0 forward launches, bit 1 data-gradient launches
  * (default 3; 0 = the fp32-input MFMA kernel everywhere); "gemm_bf16x3" 0/1 -- the same split for 128x128 GEMM tiles whose two
- * operands are k- or row-contiguous (default 1); "wgrad_bf16x3" 0/1 -- the split-operand weight-gradient convolution (default 0: parity-tested,
- * not yet faster than conv3x3_wgrad) */
+ * operands are k- or row-contiguous (default 1); "wgrad_bf16x3" 0/1/2 -- the split-operand weight-gradient convolution: 1 (default) where it is
+ * faster than conv3x3_wgrad (40 -> 40 channels), 2 every eligible launch */
 int a2s_debug_set(const char* key, int value);
 int a2s_debug_get(const char* key);   /* current value of "conv_bf16x3" / "gemm_bf16x3" / "wgrad_bf16x3" / "gru_fused"; -1 for an unknown key */
 

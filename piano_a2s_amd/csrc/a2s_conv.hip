@@ -1351,6 +1351,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
     const int tilesF = (F + 63) / 64, tilesT = (T + 1) / 2;
     const long ntiles = (long)B * tilesT * tilesF;
     const bool vec_ok = (F % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+    int pj_off[4], pj_df[4];                  // this wave's (tap, channel-tile) column tiles: LDS offset of the lane's channel row, column shift
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = min(wave + 8 * j, npair - 1), tap = p / nc16, c16 = p % nc16;
+        pj_off[j] = (c16 * 16 + li) * W4_XCI + (tap / 3) * W4_XROW;
+        pj_df[j] = tap % 3;
+    }
     bool acc_neg = false;
     int round = 0;
     // register prefetch: the global loads of the NEXT tile are issued before the multiply of the current one and committed after it
@@ -1467,39 +1474,50 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
                     for (int r = 0; r < 4; ++r) acc[j][i][r] = -acc[j][i][r];
             acc_neg = neg;
         }
+        // A lane group owns 16 consecutive positions of a row: two k-steps (positions 16 lk + 8 h + [0, 8), h = 0 / 1 -- any k order is
+        // fine as long as dy and the input agree) share ONE set of loads, so the two conflict-prone 4-byte neighbour reads are paid
+        // once per 16 positions.
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int r = s >> 1, fl = (s & 1) * 32 + lk * 8;
-            bf16x8 a[3][MT];
+        for (int r = 0; r < 2; ++r) {
+            bf16x8 a[2][3][MT];
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[sp][i] = *reinterpret_cast<const bf16x8*>(ldy + sp * DPL + (i * 16 + li) * W4_DYCO + r * 128 + fl * 2);
+                for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        a[h][sp][i] = *reinterpret_cast<const bf16x8*>(ldy + sp * DPL + (i * 16 + li) * W4_DYCO + r * 128 + (lk * 16 + h * 8) * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int p = wave + 8 * j;
-                if (p >= npair) continue;                       // uniform per wave
-                const int tap = p / nc16, c16 = p % nc16, dt = tap / 3, df = tap % 3;
-                const unsigned char* base = lx + (c16 * 16 + li) * W4_XCI + (r + dt) * W4_XROW + (fl + 8) * 2;
-                bf16x8 bfrag[3];
+                if (wave + 8 * j >= npair) continue;            // uniform per wave
+                const int df = pj_df[j];
+                const unsigned char* base = lx + pj_off[j] + r * W4_XROW + (lk * 16 + 8) * 2;
+                bf16x8 bfrag[2][3];
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp) {
-                    const u32x4 d = *reinterpret_cast<const u32x4*>(base + sp * XPL);
-                    const unsigned dm1 = *reinterpret_cast<const unsigned*>(base + sp * XPL - 4);
-                    const unsigned d4 = *reinterpret_cast<const unsigned*>(base + sp * XPL + 16);
-                    u32x4 w = d;                                 // df == 1: the aligned window
+                    const u32x4 d0 = *reinterpret_cast<const u32x4*>(base + sp * XPL);
+                    const u32x4 d1 = *reinterpret_cast<const u32x4*>(base + sp * XPL + 16);
+                    u32x4 w0 = d0, w1 = d1;                      // df == 1: the aligned windows
                     if (df == 0) {
-                        w[0] = __builtin_amdgcn_alignbit(d[0], dm1, 16); w[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
-                        w[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16); w[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+                        const unsigned dm1 = *reinterpret_cast<const unsigned*>(base + sp * XPL - 4);
+                        w0[0] = __builtin_amdgcn_alignbit(d0[0], dm1, 16); w0[1] = __builtin_amdgcn_alignbit(d0[1], d0[0], 16);
+                        w0[2] = __builtin_amdgcn_alignbit(d0[2], d0[1], 16); w0[3] = __builtin_amdgcn_alignbit(d0[3], d0[2], 16);
+                        w1[0] = __builtin_amdgcn_alignbit(d1[0], d0[3], 16); w1[1] = __builtin_amdgcn_alignbit(d1[1], d1[0], 16);
+                        w1[2] = __builtin_amdgcn_alignbit(d1[2], d1[1], 16); w1[3] = __builtin_amdgcn_alignbit(d1[3], d1[2], 16);
                     } else if (df == 2) {
-                        w[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16); w[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
-                        w[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16); w[3] = __builtin_amdgcn_alignbit(d4, d[3], 16);
+                        const unsigned d8 = *reinterpret_cast<const unsigned*>(base + sp * XPL + 32);
+                        w0[0] = __builtin_amdgcn_alignbit(d0[1], d0[0], 16); w0[1] = __builtin_amdgcn_alignbit(d0[2], d0[1], 16);
+                        w0[2] = __builtin_amdgcn_alignbit(d0[3], d0[2], 16); w0[3] = __builtin_amdgcn_alignbit(d1[0], d0[3], 16);
+                        w1[0] = __builtin_amdgcn_alignbit(d1[1], d1[0], 16); w1[1] = __builtin_amdgcn_alignbit(d1[2], d1[1], 16);
+                        w1[2] = __builtin_amdgcn_alignbit(d1[3], d1[2], 16); w1[3] = __builtin_amdgcn_alignbit(d8, d1[3], 16);
                     }
-                    bfrag[sp] = __builtin_bit_cast(bf16x8, w);
+                    bfrag[0][sp] = __builtin_bit_cast(bf16x8, w0);
+                    bfrag[1][sp] = __builtin_bit_cast(bf16x8, w1);
                 }
 #define W4_PRODUCT(SA, SB)                                                                                                   \
-                _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                               \
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[SA][i], bfrag[SB], acc[j][i], 0, 0, 0);
+                _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                \
+                    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h][SA][i], bfrag[h][SB], acc[j][i], 0, 0, 0);
                 W4_PRODUCT(2, 0) W4_PRODUCT(1, 1) W4_PRODUCT(0, 2) W4_PRODUCT(1, 0) W4_PRODUCT(0, 1) W4_PRODUCT(0, 0)
 #undef W4_PRODUCT
             }
@@ -1521,7 +1539,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
     }
 }
 
-static int g_wgrad_split = 0;          // conv3x3_wgrad_bf16x3 for the plain (no fused BatchNorm backward) weight-gradient launches
+static int g_wgrad_split = 1;          // conv3x3_wgrad_bf16x3 for the plain weight-gradient launches: 1 = where it is faster (40 -> 40 channels), 2 = every eligible launch
 void a2s_wgrad_split_set(int on) { g_wgrad_split = on; }
 int a2s_wgrad_split_enabled(void) { return g_wgrad_split; }
 
@@ -1548,7 +1566,7 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
             return A2S_OK;
         }
     }
-    if (g_wgrad_split && !bn_y && Cin > 1 && Cin <= 40 && (Cout == 20 || Cout == 40)) {
+    if (g_wgrad_split && !bn_y && Cin > 1 && Cin <= 40 && (Cout == 20 || Cout == 40) && (g_wgrad_split > 1 || (Cin == 40 && Cout == 40))) {
         const int nslabs = 256;               // one 512-thread workgroup per CU
         A2S_REQUIRE(ws_bytes >= (size_t)nslabs * Cout * Cin * 9 * sizeof(float), "conv3x3_wgrad: workspace too small for the split-operand kernel");
         if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_bf16x3<20>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);

@@ -205,7 +205,8 @@ def test_bn_relu_dropout_backward(dev, layout):
 @pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("Cin,Cout", [(1, 20), (20, 20), (20, 40), (40, 40)])
 def test_conv_weight_gradient(dev, Cin, Cout, split):
-    """split = 1: the split-operand kernel conv3x3_wgrad_bf16x3 (opt-in switch "wgrad_bf16x3"; Cin = 1 keeps its streaming kernel)."""
+    """split = 1: the split-operand kernel conv3x3_wgrad_bf16x3 for every eligible launch (switch "wgrad_bf16x3" = 2; the default 1 uses it
+    for 40 -> 40 channels only; Cin = 1 keeps its streaming kernel)."""
     from piano_a2s_amd import hip
     L = hip.lib()
     g = torch.Generator().manual_seed(Cin + Cout)
@@ -225,7 +226,7 @@ def test_conv_weight_gradient(dev, Cin, Cout, split):
     nb = L.a2s_conv3x3_wgrad_workspace_bytes(Cin, Cout)
     ws = torch.empty(nb // 4, device=dev)
     previous = L.a2s_debug_get(b"wgrad_bf16x3")
-    hip.check(L.a2s_debug_set(b"wgrad_bf16x3", split), "debug_set")
+    hip.check(L.a2s_debug_set(b"wgrad_bf16x3", 2 * split), "debug_set")
     try:
         hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dyd), hip._p(xd), hip._p(scd) if use_affine else NULL, hip._p(shd) if use_affine else NULL,
                                       hip._p(dW), hip._p(ws), C.c_size_t(nb), B, T, F, Cin, Cout), "wgrad")
