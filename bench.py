@@ -243,10 +243,10 @@ def main():
                           "full_length_tail": args.full_tail, "parallelism": f"dp{world}", "batchnorm": "per-rank statistics",
                           "decoder": "rows whose remaining targets are all <pad> skipped; teacher-forced bars decoded in one call "
                                      "(loss, gradients and update identical to the per-bar loop)",
-                          "arithmetic": "fp32 data and fp32 accumulation everywhere; the 3x3 convolutions (forward / data gradient) and the "
+                          "arithmetic": "fp32 data and fp32 accumulation everywhere; the 3x3 convolutions (forward / data gradient, conv4 weight gradient) and the "
                                         "128x128 GEMM tiles multiply on the bf16 matrix pipes with every fp32 operand carried as three exact "
                                         "bf16 terms (six term products per fp32 product; element error vs float64 equal to the fp32-input "
-                                        "MFMA kernels', DESIGN.md section 3); A2S_CONV_BF16X3=0 A2S_GEMM_BF16X3=0 select the fp32-input kernels",
+                                        "MFMA kernels', DESIGN.md section 3); A2S_CONV_BF16X3=0 A2S_GEMM_BF16X3=0 A2S_WGRAD_BF16X3=0 select the fp32-input kernels",
                           "final_loss": round(loss, 4), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}}
         step.last_outputs = None
         torch.cuda.empty_cache()
