@@ -28,6 +28,27 @@ def pad_measure(tokens, max_length):
     return torch.from_numpy(synthetic.pad_measure(tokens, max_length))
 
 
+def read_clip(folder, spectrogram_name, target_name, hparams, ts_index):
+    """One clip of the rendered-corpus / ASAP file layout -> the first seven elements of the reference's item tuple
+    (reference syn.py:93-111 == asap.py:299-312): ``<folder>/spectrogram/<spectrogram_name>.npy`` (frames, bins) zero-padded /
+    cut to max_frame_num -> (1, T, bins) f32; ``<folder>/target/<target_name>.pkl`` = one [key, time_sig, LOWER ids, UPPER ids]
+    per bar -> key + 6, time-signature class index, rows padded with pad_measure, lengths clipped to max_length."""
+    spec = torch.from_numpy(np.asarray(load(os.path.join(folder, "spectrogram", spectrogram_name + ".npy")))).float()
+    T = hparams["max_frame_num"]
+    padded = torch.zeros((T, spec.shape[-1]))
+    n = min(spec.shape[0], T)
+    padded[:n] = spec[:n]
+    score = load(os.path.join(folder, "target", target_name + ".pkl"))
+    U, L = hparams["max_length"]
+    key = torch.tensor([int(bar[0]) for bar in score]) + 6
+    ts = torch.tensor([ts_index[bar[1]] for bar in score])
+    upper = torch.stack([pad_measure(bar[3], U) for bar in score])
+    lower = torch.stack([pad_measure(bar[2], L) for bar in score])
+    up_len = torch.tensor([min(len(bar[3]), U) for bar in score])
+    lo_len = torch.tensor([min(len(bar[2]), L) for bar in score])
+    return padded.unsqueeze(0), ts, key, upper, up_len, lower, lo_len
+
+
 class _ClipFolder(Dataset):
     def __init__(self, hparams, split, device="cpu", version=(0,)):
         self.hp, self.split, self.device, self.version = hparams, split, device, list(version)
@@ -38,21 +59,9 @@ class _ClipFolder(Dataset):
             self.songs[v] = sorted(f[:-4] for f in os.listdir(folder))
 
     def _item(self, v, name):
+        """name = ``<chunk>~<soundfont>``: every soundfont rendering of a chunk shares the chunk's target (syn.py:97)."""
         base = os.path.join(self.hp["feature_folder"], self.split, str(v))
-        spec = torch.from_numpy(np.asarray(load(os.path.join(base, "spectrogram", name + ".npy")))).float()
-        T = self.hp["max_frame_num"]
-        padded = torch.zeros((T, spec.shape[-1]))
-        n = min(spec.shape[0], T)
-        padded[:n] = spec[:n]
-        score = load(os.path.join(base, "target", name.split("~")[0] + ".pkl"))
-        U, L = self.hp["max_length"]
-        key = torch.tensor([bar[0] for bar in score]) + 6
-        ts = torch.tensor([self.ts_index[bar[1]] for bar in score])
-        upper = torch.stack([pad_measure(bar[3], U) for bar in score])
-        lower = torch.stack([pad_measure(bar[2], L) for bar in score])
-        up_len = torch.tensor([min(len(bar[3]), U) for bar in score])
-        lo_len = torch.tensor([min(len(bar[2]), L) for bar in score])
-        return padded.unsqueeze(0), ts, key, upper, up_len, lower, lo_len, name, v
+        return read_clip(base, name, name.split("~")[0], self.hp, self.ts_index) + (name, v)
 
 
 class TrainDataset(_ClipFolder):

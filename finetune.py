@@ -40,8 +40,9 @@ def main(argv):
     with open(hparams_file) as fin:
         hparams = load_hyperpyyaml(fin, overrides)
     sb.create_experiment_directory(experiment_directory=hparams["output_folder"], hyperparams_to_save=hparams_file, overrides=overrides)
-    if sb.utils.distributed.if_main_process():
-        seed_from_pretraining(hparams["pretrained_output_folder"], hparams["output_folder"])
+    # rank 0 copies, every rank waits: the others must not look for checkpoints in a half-copied save/ (the reference runs the cp
+    # synchronously on every rank, finetune.py:251-258); Brain.on_fit_start then broadcasts rank 0's recovered parameters
+    sb.utils.distributed.run_on_main(seed_from_pretraining, args=[hparams["pretrained_output_folder"], hparams["output_folder"]])
 
     n_syn = int(hparams.get("synthetic_clips", 0) or 0)
     if n_syn:

@@ -256,7 +256,7 @@ int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const flo
  * dlogp (zero-filled by the caller, or NULL) receives d(gscale*loss)/dlogp.  partial: 2*nblocks doubles. */
 int a2s_nll_loss(void* stream, const float* logp, const long long* target, long rows, int V, long long ignore_index,
                  float* loss_out, float* dlogp, float gscale, double* partial, int nblocks);
-/* clip_grad_norm_(max_norm) + Adadelta over one flat buffer; skipped when *loss is not finite (NULL: always apply).
+/* clip_grad_norm_(max_norm) + Adadelta over one flat buffer; skipped when *loss (NULL: not looked at) or the gradient norm is not finite.
  * ctl[0..2] = {total norm, clip coefficient, applied flag}; partial: nblocks doubles; zero_grad clears the gradients. */
 int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_avg, float* acc_delta, long n, const float* loss,
                       float max_norm, float lr, float rho, float eps, float* ctl, double* partial, int nblocks, int zero_grad);

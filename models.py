@@ -134,7 +134,10 @@ class ScoreTranscription(nn.Module):
             P[f"convstack.bn{i}.weight"].fill_(1.0)
         _xavier_uniform(P["convstack.out.weight"])
         P["convstack.out_bn.weight"].fill_(1.0)
-        _gru_init(P, "encoder.gru", ("l0", "l0_reverse", "l1", "l1_reverse"))
+        # init_gru walks `weight_ih_l{i}` / `weight_hh_l{i}` for i < num_layers only (models.py:574-585): the REVERSE direction of the
+        # bidirectional encoder GRU is never touched by it and keeps torch.nn.GRU's default U(+-1/sqrt(hidden)), biases included
+        _gru_init(P, "encoder.gru", ("l0", "l1"))
+        _default_gru_init(P, "encoder.gru", ("l0_reverse", "l1_reverse"))
         _xavier_uniform(P["encoder.fc.weight"])
         for n in ("decoder.note_emb.weight", "decoder.time_sig_emb.weight", "decoder.key_emb.weight",
                   "decoder.upper_decoder.embedding.weight", "decoder.lower_decoder.embedding.weight"):
@@ -177,6 +180,15 @@ class ScoreTranscription(nn.Module):
                 p.data = flat[off:off + p.numel()].view(p.shape)
         self._flat = flat
         return flat
+
+    def flat_layout(self):
+        """[(offset in floats, shape)] of every parameter inside the flat buffer, in `self.parameters()` order (the index space of a
+        torch optimizer's state_dict built from `modules.parameters()`)."""
+        from piano_a2s_amd.spec import flat_layout
+        params = self._param_dict()
+        assert list(params) == list(self._names), "parameter registration order differs from the state_dict order"
+        offs, _ = flat_layout([params[n].numel() for n in self._names])
+        return [(off, tuple(params[n].shape)) for n, off in zip(self._names, offs)]
 
     # ------------------------------------------------------------------ forward (reference models.py:26-51)
     def forward(self,

@@ -1,30 +1,59 @@
 """Build liba2s_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so sits next to its sources so it
-travels with the repository snapshot to the GPU box."""
+travels with the repository snapshot to the GPU box.  Every .hip file is compiled to an object of its own (in parallel, only when it or
+a header changed), then linked."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liba2s_hip.so")
-SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip", "a2s_vqt.hip"]
+OBJ = os.path.join(CSRC, "_obj")
+SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip", "a2s_vqt.hip", "a2s_step.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _headers():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "a2s.h"))
+    return deps
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "a2s.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    return _stale(LIB, srcs + _headers())
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + SOURCES + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, cwd=CSRC, check=True)
+    os.makedirs(OBJ, exist_ok=True)
+    headers = _headers()
+    jobs, objs = [], []
+    for f in SOURCES:
+        src = os.path.join(CSRC, f)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJ, f[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([hipcc] + FLAGS + ["-c", f, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, cwd=CSRC, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as pool:
+        list(pool.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB
 
 

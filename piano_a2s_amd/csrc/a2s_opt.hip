@@ -76,8 +76,10 @@ __global__ void clip_finalize(const double* __restrict__ partial, int nblocks, c
     const float total = (float)sqrt(s);
     float coef = max_norm / (total + 1e-6f);          // torch.nn.utils.clip_grad_norm_
     if (coef > 1.f) coef = 1.f;
-    const bool finite_loss = loss ? isfinite(*loss) : true;     // check_gradients: non-finite loss -> skip the step
-    ctl[0] = total; ctl[1] = coef; ctl[2] = finite_loss ? 1.f : 0.f;
+    // check_gradients: non-finite loss -> skip the step.  A non-finite gradient norm skips it too (the reference would apply
+    // coef = NaN and destroy the parameters; under data parallelism one rank's NaN gradients reach every rank through the all-reduce)
+    const bool finite_loss = loss ? isfinite(*loss) : true;
+    ctl[0] = total; ctl[1] = coef; ctl[2] = (finite_loss && isfinite(total)) ? 1.f : 0.f;
 }
 
 // torch.optim.Adadelta (weight_decay = 0) on the clipped gradient; also clears the gradient (zero_grad)

@@ -8,6 +8,7 @@ per forward into a plan when ground truth is given, and on the device (with spar
 """
 import ctypes as C
 import random as _py_random
+import threading
 
 import torch
 
@@ -42,14 +43,90 @@ _GREEDY_GRAPH = _os.environ.get("A2S_GREEDY_GRAPH") == "1"
 _SIDE_STREAMS = {}
 
 
-def side_streams(device):
-    """Two extra HIP streams per device: the upper- and lower-staff note decoders of a bar are independent given the bar summary
-    (reference models.py:261-275 runs them one after the other), so their step loops are enqueued on separate streams and overlap
-    -- one staff's latency-bound kernels (skinny GEMMs, gates, epilogues) run under the other's bandwidth-bound attention."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def _dev_index(device):
+    return torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+
+
+def side_streams(device, group=0):
+    """Two extra HIP streams per device (and clip group): the upper- and lower-staff note decoders of a bar are independent given the
+    bar summary (reference models.py:261-275 runs them one after the other), so their step loops are enqueued on separate streams and
+    overlap -- one staff's latency-bound kernels (skinny GEMMs, gates, epilogues) run under the other's bandwidth-bound attention."""
+    key = (_dev_index(device), group)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=key), torch.cuda.Stream(device=key))
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=key[0]), torch.cuda.Stream(device=key[0]))
     return _SIDE_STREAMS[key]
+
+
+_GROUP_STREAMS = {}
+_GROUP_POOL = None
+
+
+def group_stream(device, group):
+    """The ONE stream everything of clip group `group` > 0 runs on (group 0: the caller's current stream + side_streams).
+
+    Stream budget.  The HIP runtime multiplexes every stream of a process onto GPU_MAX_HW_QUEUES = 4 hardware queues (a new stream
+    joins the least-shared queue) and two streams on one queue execute in order.  Measured on MI355X with the long-clip group on
+    streams of its own: 308 clips/s with 4 queues, 245 with 6, 224 with 16 (more hardware queues than 4 are time-sliced), and 241 with
+    high-priority streams (a second pool of queues: same oversubscription).  So the step uses exactly FOUR streams: the default one,
+    the two side streams (staves of group 0; encoder directions) and this one -- the long-clip group's latency chain gets a hardware
+    queue to itself instead of waiting in line behind the bulk group's bandwidth-bound kernels.  The encoder's weight-gradient
+    GEMMs reuse it (engine_bwd._weight_grad_stream): the decoder is done by then."""
+    key = (_dev_index(device), 1)
+    if key not in _GROUP_STREAMS:
+        _GROUP_STREAMS[key] = torch.cuda.Stream(device=key[0])
+    return _GROUP_STREAMS[key]
+
+
+def group_views(t, clip_groups, gidx):
+    """Bar-major staff tensor (bars, B, len, V) as ONE flat buffer in which every clip group owns a contiguous bar-major block:
+    returns group gidx's block as (bars, clips of the group, len, V).  With a single group that is `t` itself."""
+    bars, B = t.shape[0], t.shape[1]
+    b0, b1 = clip_groups[gidx]
+    per_clip = t[0, 0].numel()
+    return t.view(-1)[bars * per_clip * b0: bars * per_clip * b1].view((bars, b1 - b0) + tuple(t.shape[2:]))
+
+
+def gather_group_views(t, clip_groups):
+    """Inverse view of group_views: the flat-by-group buffer back as an ordinary (bars, B, len, V) tensor (a copy when there are groups)."""
+    if len(clip_groups) == 1:
+        return t
+    return torch.cat([group_views(t, clip_groups, g) for g in range(len(clip_groups))], dim=1)
+
+
+def run_clip_groups(device, fns):
+    """fns[g]() = the decoder work of clip group g.  Group 0 runs on the calling thread and its current stream; every other group on
+    a host thread of its own with group_stream(device, g) current (forked from the caller's stream, joined to it before returning) --
+    its step loops are issued by that thread's own two issue threads (fork_on_streams).  Returns [fns[g]() results]."""
+    global _GROUP_POOL
+    if len(fns) == 1:
+        return [fns[0]()]
+    fork = torch.cuda.Event()
+    fork.record()
+    dev_index = _dev_index(device)
+
+    def task(g, fn):
+        torch.cuda.set_device(dev_index)
+        st = group_stream(device, g)
+        st.wait_event(fork)
+        with torch.cuda.stream(st):
+            r = fn()
+            done = torch.cuda.Event()
+            done.record()
+        return r, done
+
+    if _os.environ.get("A2S_ISSUE_THREADS", "1") == "0":
+        rest = [task(g, fn) for g, fn in enumerate(fns[1:], start=1)]
+        first = fns[0]()
+    else:
+        if _GROUP_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _GROUP_POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="a2s-group")
+        futures = [_GROUP_POOL.submit(task, g, fn) for g, fn in enumerate(fns[1:], start=1)]
+        first = fns[0]()
+        rest = [f.result() for f in futures]
+    for _, done in rest:
+        torch.cuda.current_stream().wait_event(done)
+    return [first] + [r for r, _ in rest]
 
 
 def encoder_streams(device):
@@ -72,7 +149,7 @@ def fork_on_streams(device, streams, fns):
     global _ISSUE_POOL
     fork = torch.cuda.Event()
     fork.record()
-    dev_index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    dev_index = _dev_index(device)
 
     def task(st, fn):
         torch.cuda.set_device(dev_index)
@@ -91,7 +168,7 @@ def fork_on_streams(device, streams, fns):
     else:
         if _ISSUE_POOL is None:
             from concurrent.futures import ThreadPoolExecutor
-            _ISSUE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="a2s-issue")
+            _ISSUE_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="a2s-issue")      # 2 staves x up to 2 clip groups
         futures = [_ISSUE_POOL.submit(task, st, fn) for st, fn in zip(streams, fns)]
 
     def join(wait=True):
@@ -340,8 +417,9 @@ class Engine:
 
     # ------------------------------------------------------------------ full forward
     def forward(self, S, spectrogram, inference=True, ground_truth=None, teacher_forcing_ratio=0.0, training=False,
-                rng=_py_random, dropout=True):
-        """S: dict name -> device tensor (parameters and BN buffers, reference state_dict names)."""
+                rng=_py_random, dropout=True, gt_host=None):
+        """S: dict name -> device tensor (parameters and BN buffers, reference state_dict names).
+        gt_host: optional host copies (upper, lower, upper_len, lower_len) of the ground truth, when the caller already has them."""
         if inference:
             assert teacher_forcing_ratio == 0 and ground_truth is None     # models.py:202-204
         if not spectrogram.is_cuda:
@@ -359,7 +437,8 @@ class Engine:
         gt_cpu = None
         if ground_truth is not None:
             ts_gt, key_gt, up_gt, up_len_gt, lo_gt, lo_len_gt = [g.contiguous() for g in ground_truth]
-            gt_cpu = (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())      # ONE host sync per forward, before anything is enqueued
+            # ONE host sync per forward, before anything is enqueued
+            gt_cpu = tuple(gt_host) if gt_host is not None else (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())
 
         # ConvStack + encoder are enqueued first: the host-side planning of the decoder below runs while they execute.  Its small
         # host->device uploads go through pinned memory without synchronising (a pageable upload would drain the stream each time).
@@ -369,15 +448,14 @@ class Engine:
         enc2d = enc.view(B * T, 2 * H)
         keys = {p: self._keys(S, p + ".attn", enc2d, H) for p in ("decoder", "decoder.upper_decoder", "decoder.lower_decoder")}
         pinned = []                                      # keeps the staging buffers alive until the step is over
+        pin_lock = threading.Lock()
 
         def upload(t):
             p = t.contiguous().pin_memory()
-            pinned.append(p)
+            with pin_lock:
+                pinned.append(p)
             return p.to(dev, non_blocking=True)
 
-        sos_ids = torch.full((B, 2), SOS, dtype=torch.long, device=dev)
-        sos_ids[:, 1] = EOS
-        two = torch.full((B,), 2, dtype=torch.long, device=dev)
         maxlen = (U, Lo)
         # ---- host plan.  With ground truth the number of executed steps of every (bar, staff) is known up front, so every coin of
         # the reference's protocol (one per executed note step, upper then lower, then one per bar: models.py:404,289) is drawn here,
@@ -398,7 +476,12 @@ class Engine:
         #    bar token (its staff embedding reads ids[:length] only): its attention, the HBM-bound part of a step, is skipped;
         #  fuse_bars -- when bar k's coin says "teacher-force", bar k+1's input token comes from the ground truth, so the note
         #    decoders of bar k+1 do not depend on those of bar k: consecutive such bars are decoded in ONE call over bars x B rows
-        #    (fewer, fatter launches; the rows of a clip share its keys / encoder outputs, streamed once for all of them).
+        #    (fewer, fatter launches; the rows of a clip share its keys / encoder outputs, streamed once for all of them);
+        #  clip_groups -- everything behind the encoder is independent per CLIP (the reference couples the clips of a minibatch only
+        #    through the loop lengths and the shared coin flips, both already in the plan): the minibatch is cut into contiguous clip
+        #    ranges, e.g. [clips with ordinary bars | clips holding a full-length bar], each range decodes with ITS OWN step counts on
+        #    its own streams / host threads, concurrently -- the few-row, latency-bound tail of the long clips (398 dependent steps per
+        #    segment) runs under the bandwidth-bound attention of the many ordinary ones instead of after it.
         skip = plan is not None and training and getattr(self, "skip_finished_rows", False)
         fuse = skip and getattr(self, "fuse_bars", False)
         segments = [[0]]
@@ -413,199 +496,258 @@ class Engine:
             for g in gt_cpu[:2]:
                 idx = torch.arange(1, g.shape[-1] + 1, dtype=torch.int32)
                 until_all.append(((g != PAD).to(torch.int32) * idx).amax(dim=-1).to(torch.int32).t().contiguous())   # (bars, B): last real target + 1
-
-        def active_rows(gi_idx, seg, n):
-            """Row / clip bookkeeping of one decoder call over the bars `seg` (n steps launched)."""
-            until = torch.stack([until_all[gi_idx][bar].clamp(max=plan[bar][gi_idx][0]) for bar in seg])        # the bar's loop ends at its own step count
-            clip_until = until.amax(dim=0)
-            order = torch.argsort(clip_until, descending=True, stable=True).to(torch.int32)                     # clips that finish last come first
-            rank = torch.empty_like(order)
-            rank[order.long()] = torch.arange(B, dtype=torch.int32)
-            cnt = torch.bincount(clip_until.long(), minlength=n + 1)
-            n_act = B - torch.cumsum(cnt, 0)[:n]                                                                # clips with until > t
-            return dict(until=upload(until.reshape(-1)), order=upload(order), rank=upload(rank),
-                        n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=B)
-
-        # Every host-side decision of the decoder and every small upload happens HERE, while the GPU is busy with the ConvStack and
-        # the encoder enqueued above -- not once per (segment, staff) in the middle of the decoder.
-        seg_plan = []
-        for seg in segments:
-            sp = {}
-            for gi_idx in (0, 1):
-                if plan is None:
-                    sp[gi_idx] = (maxlen[gi_idx], None, None, None)
-                    continue
-                steps = max(plan[bar][gi_idx][0] for bar in seg)
-                flags = [sum(int(t < plan[bar][gi_idx][0] and plan[bar][gi_idx][1][t]) << j for j, bar in enumerate(seg)) for t in range(steps)]
-                # the backward pass needs the flags on the device (which token each step consumed)
-                flags_dev = upload(torch.tensor(flags[:steps - 1], dtype=torch.int32)) if training and steps > 1 else None
-                sp[gi_idx] = (steps, flags, active_rows(gi_idx, seg, steps) if skip else None, flags_dev)
-            seg_plan.append(sp)
+        clip_groups = getattr(self, "clip_groups", None) if fuse else None
+        if not clip_groups or len(clip_groups) < 2:
+            clip_groups = [(0, B)]
+        assert clip_groups[0][0] == 0 and clip_groups[-1][1] == B and all(a[1] == b[0] for a, b in zip(clip_groups[:-1], clip_groups[1:]))
 
         bar_major = fuse
         self.bar_major = bar_major
         ts_out = torch.zeros((B, bars, cfg["num_time_sig"]), device=dev)
         key_out = torch.zeros((B, bars, cfg["num_keys"]), device=dev)
-        # fused bars: staff outputs bar-major (bars, B, len, V) so that the rows of consecutive bars are uniformly strided
+        # fused bars: staff outputs bar-major (bars, clips, len, V) so that the rows of consecutive bars are uniformly strided; with
+        # clip groups every group owns a contiguous bar-major block of ONE flat buffer (group_views) -- the loss is a mean over
+        # rows, whatever their order (train.TrainStep lays the targets out the same way)
         up_out = torch.zeros((bars, B, U, V) if bar_major else (B, bars, U, V), device=dev)
         lo_out = torch.zeros((bars, B, Lo, V) if bar_major else (B, bars, Lo, V), device=dev)
-        gt_bm = (up_gt.transpose(0, 1).contiguous(), lo_gt.transpose(0, 1).contiguous()) if bar_major else None
+        self.clip_groups_used = list(clip_groups)
 
         tokw = 4 * Sz + te + ke
-        token = self._empty(B, tokw, dev=dev)
-        sos_rec = [] if training else None
-        self._staff_token(S, sos_ids, two, 1, token, 0, 2, 2, True, sos_rec)
-        token[:, 2 * Sz:4 * Sz].copy_(token[:, :2 * Sz])
-        hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S["decoder.time_sig_emb.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0),
-                                   cfg["num_time_sig"], hip._p(token), C.c_long(tokw), 4 * Sz, B, te, C.c_void_p(0), hip.f32(1.0)), "embed ts")
-        hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S["decoder.key_emb.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0),
-                                   cfg["num_keys"], hip._p(token), C.c_long(tokw), 4 * Sz + te, B, ke, C.c_void_p(0), hip.f32(1.0)), "embed key")
-
         ldxb = tokw + 2 * H
-        bar_saved, seg_saved = [], []
-        max_rows = B * max(len(sg) for sg in segments)
-        # per-staff scratch (split-T attention partials, split-K slabs): the two staves run concurrently on two streams
-        attn_ws = [hip.attn_workspace(B, T, H, dev, groups=max_rows // B) for _ in range(2)]
-        gemm_ws = [hip.gemm_workspace(max_rows, dev) for _ in range(2)]
+        greedy_graph = gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH)
         # the two staves of a segment run on two streams, each issued by its own host thread -- also in greedy decoding, where each
         # thread polls the done counter of its own stream (the hipGraph variant captures on one created stream and stays sequential)
-        concurrent = getattr(self, "concurrent_staves", True) and not (gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH))
-        streams = side_streams(dev) if concurrent else None
+        concurrent = getattr(self, "concurrent_staves", True) and not greedy_graph
+        enc_hidden = hidden
 
-        def bar_step(bar, token, hidden):
-            """Bar-level attention + GRU step (models.py:241-247) and the two heads (models.py:281-286)."""
-            xbar = self._empty(B, ldxb, dev=dev)
-            headin = self._empty(B, 4 * H, dev=dev)
-            if drop_on:
-                keep = (torch.rand((B, tokw), device=dev) >= 0.1).to(token.dtype)
-                xbar[:, :tokw].copy_(token * keep / 0.9)
+        def decode_group(gidx, b0, b1, gen):
+            """The decoder (reference HierarchicalDecoder.decode_bars, models.py:191-316) over the clips [b0, b1).  Runs on the calling
+            thread's current stream plus that group's two staff streams; `gen`: the torch generator its dropout masks come from."""
+            Bg = b1 - b0
+            hidden = enc_hidden[b0:b1]
+            enc_g = enc[b0:b1]
+            keys_g = {p: k.view(B, T, H)[b0:b1] for p, k in keys.items()}
+            if ground_truth is not None:
+                ts_g, key_g, up_g, upl_g, lo_g, lol_g = ts_gt[b0:b1], key_gt[b0:b1], up_gt[b0:b1], up_len_gt[b0:b1], lo_gt[b0:b1], lo_len_gt[b0:b1]
+                gt_cpu_g = tuple(t[b0:b1] for t in gt_cpu)
+            ts_out_g, key_out_g = ts_out[b0:b1], key_out[b0:b1]
+            if bar_major:
+                up_out_g, lo_out_g = group_views(up_out, clip_groups, gidx), group_views(lo_out, clip_groups, gidx)
+                gt_bm = (up_g.transpose(0, 1).contiguous(), lo_g.transpose(0, 1).contiguous())
             else:
-                keep = None
-                xbar[:, :tokw].copy_(token)
-            qb = self._empty(B, H, dev=dev)
-            Wa = S["decoder.attn.attn.weight"]
-            hip.gemm(hidden, 2 * H, 1, Wa, 1, 4 * H, qb, H, B, H, 2 * H, bias=S["decoder.attn.attn.bias"])
-            attw = self._empty(B, T, dev=dev) if training else None
-            hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys["decoder"]), hip._p(enc), hip._p(qb), C.c_long(H),
-                                          hip._p(S["decoder.attn.v.weight"]), C.c_void_p(xbar.data_ptr() + 4 * tokw), C.c_long(ldxb),
-                                          C.c_void_p(headin.data_ptr() + 4 * 2 * H), C.c_long(4 * H), hip._p(attw), B, T, H,
-                                          C.c_void_p(0), 0, C.c_void_p(0)), "a2s_attn_step_fwd")   # 5 calls per forward: one-WG-per-clip kernel
-            # (the bar-level GRU input row [token(141) | ctx] has an odd stride, which the 16-byte-load split kernels reject)
-            gi = hip.linear(xbar, S["decoder.gru.weight_ih_l0"], S["decoder.gru.bias_ih_l0"])
-            gh = hip.linear(hidden, S["decoder.gru.weight_hh_l0"], S["decoder.gru.bias_hh_l0"])
-            hnew = self._empty(B, 2 * H, dev=dev)
-            gates = self._empty(B, 8 * H, dev=dev) if training else None
-            hip.check(L.a2s_gru_gates_fwd(hip.stream(), hip._p(gi), C.c_long(6 * H), hip._p(gh), C.c_long(6 * H), hip._p(hidden),
-                                          C.c_long(2 * H), hip._p(hnew), C.c_long(2 * H), hip._p(headin), C.c_long(4 * H),
-                                          hip._p(gates), B, 2 * H), "a2s_gru_gates_fwd")
-            return dict(xbar=xbar, headin=headin, qb=qb, attw=attw, gates=gates, hprev=hidden, hnew=hnew, keep=keep)
+                up_out_g, lo_out_g = up_out[b0:b1], lo_out[b0:b1]
+                gt_bm = None
+            # the long-clip groups run both staves one after the other on their single stream (group_stream: the stream budget)
+            concurrent_g = concurrent and gidx == 0
+            streams = side_streams(dev, 0) if concurrent_g else None
 
-        def bar_heads(bar, headin):
-            heads = {}
-            for hname, out_t, nc in (("time_sig_out", ts_out, cfg["num_time_sig"]), ("key_out", key_out, cfg["num_keys"])):
-                t1 = hip.linear(headin, S[f"decoder.{hname}.0.weight"], S[f"decoder.{hname}.0.bias"], act=1)
-                t2 = hip.linear(t1, S[f"decoder.{hname}.2.weight"], S[f"decoder.{hname}.2.bias"], act=1)
-                lg = hip.linear(t2, S[f"decoder.{hname}.4.weight"], S[f"decoder.{hname}.4.bias"])
-                am = torch.empty(B, dtype=torch.int32, device=dev)
-                hip.check(L.a2s_log_softmax_rows(hip.stream(), hip._p(lg), C.c_long(nc), C.c_void_p(out_t.data_ptr() + 4 * bar * nc),
-                                                 C.c_long(bars * nc), hip._p(am), B, nc), "a2s_log_softmax_rows")
-                heads[hname] = (t1, t2, lg, am)
-            return heads
+            def rand(shape):
+                return torch.rand(shape, device=dev, generator=gen)
 
-        def next_token(bar, teacher_force, staff, heads):
-            """Token bar `bar` hands to the next one (models.py:289-311); staff: {name: (ids, lengths)} of this bar's rows (not needed
-            when teacher-forced)."""
-            token = self._empty(B, tokw, dev=dev)
-            tok_rec = [] if training else None
-            if teacher_force and not inference:
-                if int(gt_cpu[2][:, bar].min()) <= 0 or int(gt_cpu[3][:, bar].min()) <= 0:
-                    raise RuntimeError("Length of all samples has to be greater than 0")     # pack_padded_sequence
-                self._staff_token(S, up_gt[:, bar], up_len_gt[:, bar], bars, token, 0, U, bars * U, True, tok_rec)
-                self._staff_token(S, lo_gt[:, bar], lo_len_gt[:, bar], bars, token, 2 * Sz, Lo, bars * Lo, True, tok_rec)
-                ts_ids, key_ids, i64, stride = ts_gt[:, bar], key_gt[:, bar], True, bars
-            else:
-                self._staff_token(S, staff["up"][0], staff["up"][1], 1, token, 0, U, U, False, tok_rec)
-                self._staff_token(S, staff["lo"][0], staff["lo"][1], 1, token, 2 * Sz, Lo, Lo, False, tok_rec)
-                ts_ids, key_ids, i64, stride = heads["time_sig_out"][3], heads["key_out"][3], False, 1
-            for table, ids_, col, width in ((S["decoder.time_sig_emb.weight"], ts_ids, 4 * Sz, te), (S["decoder.key_emb.weight"], key_ids, 4 * Sz + te, ke)):
-                hip.check(L.a2s_embed_rows(hip.stream(), hip._p(table), hip._p(ids_) if i64 else C.c_void_p(0),
-                                           C.c_void_p(0) if i64 else hip._p(ids_), C.c_long(stride), 0, hip._p(token), C.c_long(tokw), col, B,
-                                           width, C.c_void_p(0), hip.f32(1.0)), "embed next token")
-            return token, tok_rec, (ts_ids, key_ids, i64, stride)
+            # steps of this group's calls: the loop of a (bar, staff) ends when every row OF THE GROUP has shown <eos> (a group with no
+            # full-length row does not run to the cap because another group has one); the coins are the plan's (global step index)
+            gsteps = None
+            if plan is not None:
+                gsteps = [{gi_idx: min(plan[bar][gi_idx][0], plan_note_steps(gt_cpu_g[gi_idx][:, bar, :], maxlen[gi_idx])[0]) for gi_idx in (0, 1)}
+                          for bar in range(bars)]
 
-        for seg_i, seg in enumerate(segments):
-            nb = len(seg)
-            # (1) bar-level chain of the segment: inside a segment every next token comes from the ground truth
-            for j, bar in enumerate(seg):
-                rec = bar_step(bar, token, hidden)
-                rec["seg"] = (len(seg_saved), j)
-                bar_saved.append(rec)
-                hidden = rec["hnew"]
-                if j + 1 < nb:
-                    token, rec["tok_rec"], rec["next_ids"] = next_token(bar, True, None, None)
-                    rec["teacher_force"] = True
-            h0 = bar_saved[seg[0]]["hnew"] if nb == 1 else torch.cat([bar_saved[bar]["hnew"] for bar in seg], dim=0)
-            R = nb * B
-            # (2) note decoders of the segment (models.py:261-275)
-            staff = {}
-            calls = []
-            for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out, 0), ("lo", "decoder.lower_decoder", Lo, lo_out, 1)):
-                steps, flags, active, flags_dev = seg_plan[seg_i][gi_idx]
-                if plan is not None:
-                    if bar_major:
-                        gt_bar = gt_bm[gi_idx][seg[0]:seg[0] + nb].view(R, maxs)
-                        probs = out_t[seg[0]:seg[0] + nb].view(R, maxs, V)
-                    else:
-                        gt_bar = (up_gt if gi_idx == 0 else lo_gt)[:, seg[0], :]
-                        probs = out_t[:, seg[0]]
+            def active_rows(gi_idx, seg, n):
+                """Row / clip bookkeeping of one decoder call over the bars `seg` (n steps launched)."""
+                until = torch.stack([until_all[gi_idx][bar][b0:b1].clamp(max=gsteps[bar][gi_idx]) for bar in seg])   # the bar's loop ends at its own step count
+                clip_until = until.amax(dim=0)
+                order = torch.argsort(clip_until, descending=True, stable=True).to(torch.int32)                     # clips that finish last come first
+                rank = torch.empty_like(order)
+                rank[order.long()] = torch.arange(Bg, dtype=torch.int32)
+                cnt = torch.bincount(clip_until.long(), minlength=n + 1)
+                n_act = Bg - torch.cumsum(cnt, 0)[:n]                                                               # clips with until > t
+                return dict(until=upload(until.reshape(-1)), order=upload(order), rank=upload(rank),
+                            n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=Bg)
+
+            # Every host-side decision of the decoder and every small upload happens HERE, while the GPU is busy with the ConvStack and
+            # the encoder enqueued above -- not once per (segment, staff) in the middle of the decoder.
+            seg_plan = []
+            for seg in segments:
+                sp = {}
+                for gi_idx in (0, 1):
+                    if plan is None:
+                        sp[gi_idx] = (maxlen[gi_idx], None, None, None)
+                        continue
+                    steps = max(gsteps[bar][gi_idx] for bar in seg)
+                    flags = [sum(int(t < gsteps[bar][gi_idx] and plan[bar][gi_idx][1][t]) << j for j, bar in enumerate(seg)) for t in range(steps)]
+                    # the backward pass needs the flags on the device (which token each step consumed)
+                    flags_dev = upload(torch.tensor(flags[:steps - 1], dtype=torch.int32)) if training and steps > 1 else None
+                    sp[gi_idx] = (steps, flags, active_rows(gi_idx, seg, steps) if skip else None, flags_dev)
+                seg_plan.append(sp)
+
+            sos_ids = torch.full((Bg, 2), SOS, dtype=torch.long, device=dev)
+            sos_ids[:, 1] = EOS
+            two = torch.full((Bg,), 2, dtype=torch.long, device=dev)
+            token = self._empty(Bg, tokw, dev=dev)
+            sos_rec = [] if training else None
+            self._staff_token(S, sos_ids, two, 1, token, 0, 2, 2, True, sos_rec)
+            token[:, 2 * Sz:4 * Sz].copy_(token[:, :2 * Sz])
+            hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S["decoder.time_sig_emb.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0),
+                                       cfg["num_time_sig"], hip._p(token), C.c_long(tokw), 4 * Sz, Bg, te, C.c_void_p(0), hip.f32(1.0)), "embed ts")
+            hip.check(L.a2s_embed_rows(hip.stream(), hip._p(S["decoder.key_emb.weight"]), C.c_void_p(0), C.c_void_p(0), C.c_long(0),
+                                       cfg["num_keys"], hip._p(token), C.c_long(tokw), 4 * Sz + te, Bg, ke, C.c_void_p(0), hip.f32(1.0)), "embed key")
+
+            bar_saved, seg_saved = [], []
+            max_rows = Bg * max(len(sg) for sg in segments)
+            # per-staff scratch (split-T attention partials, split-K slabs): the two staves run concurrently on two streams
+            attn_ws = [hip.attn_workspace(Bg, T, H, dev, groups=max_rows // Bg) for _ in range(2)]
+            gemm_ws = [hip.gemm_workspace(max_rows, dev) for _ in range(2)]
+
+            def bar_step(bar, token, hidden):
+                """Bar-level attention + GRU step (models.py:241-247) and the two heads (models.py:281-286)."""
+                xbar = self._empty(Bg, ldxb, dev=dev)
+                headin = self._empty(Bg, 4 * H, dev=dev)
+                if drop_on:
+                    keep = (rand((Bg, tokw)) >= 0.1).to(token.dtype)
+                    xbar[:, :tokw].copy_(token * keep / 0.9)
                 else:
-                    gt_bar, probs = None, out_t[:, seg[0]]
-                # the dropout masks are drawn here, on the caller's thread and stream: one deterministic draw order per seed
-                drop = (torch.rand((steps + 1, R, E), device=dev) >= 0.1).to(torch.uint8) if drop_on else None
-                calls.append((name, (S, prefix, keys[prefix], enc, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
-                                     attn_ws[gi_idx], gemm_ws[gi_idx], active, drop, flags_dev)))
-            if concurrent:
-                join = fork_on_streams(dev, streams, [lambda args=args: self._decode_staff(*args) for _, args in calls])
-            elif gt_cpu is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH):
-                # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
-                st = side_streams(dev)[0]
-                res = []
-                for _, args in calls:
-                    st.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(st):
-                        res.append(self._decode_staff(*args))
-                    torch.cuda.current_stream().wait_stream(st)
-                    for _ in range(res[-1][2]["steps"]):       # the reference draws once per executed step, also in inference
-                        rng.random()
-                join = lambda res=res: res
-            else:
-                res = []
-                for _, args in calls:
-                    res.append(self._decode_staff(*args))
-                    if gt_cpu is None:
-                        for _ in range(res[-1][2]["steps"]):
+                    keep = None
+                    xbar[:, :tokw].copy_(token)
+                qb = self._empty(Bg, H, dev=dev)
+                Wa = S["decoder.attn.attn.weight"]
+                hip.gemm(hidden, 2 * H, 1, Wa, 1, 4 * H, qb, H, Bg, H, 2 * H, bias=S["decoder.attn.attn.bias"])
+                attw = self._empty(Bg, T, dev=dev) if training else None
+                hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys_g["decoder"]), hip._p(enc_g), hip._p(qb), C.c_long(H),
+                                              hip._p(S["decoder.attn.v.weight"]), C.c_void_p(xbar.data_ptr() + 4 * tokw), C.c_long(ldxb),
+                                              C.c_void_p(headin.data_ptr() + 4 * 2 * H), C.c_long(4 * H), hip._p(attw), Bg, T, H,
+                                              C.c_void_p(0), 0, C.c_void_p(0)), "a2s_attn_step_fwd")   # 5 calls per forward: one-WG-per-clip kernel
+                # (the bar-level GRU input row [token(141) | ctx] has an odd stride, which the 16-byte-load split kernels reject)
+                gi = hip.linear(xbar, S["decoder.gru.weight_ih_l0"], S["decoder.gru.bias_ih_l0"])
+                gh = hip.linear(hidden, S["decoder.gru.weight_hh_l0"], S["decoder.gru.bias_hh_l0"])
+                hnew = self._empty(Bg, 2 * H, dev=dev)
+                gates = self._empty(Bg, 8 * H, dev=dev) if training else None
+                hip.check(L.a2s_gru_gates_fwd(hip.stream(), hip._p(gi), C.c_long(6 * H), hip._p(gh), C.c_long(6 * H), hip._p(hidden),
+                                              C.c_long(2 * H), hip._p(hnew), C.c_long(2 * H), hip._p(headin), C.c_long(4 * H),
+                                              hip._p(gates), Bg, 2 * H), "a2s_gru_gates_fwd")
+                return dict(xbar=xbar, headin=headin, qb=qb, attw=attw, gates=gates, hprev=hidden, hnew=hnew, keep=keep)
+
+            def bar_heads(bar, headin):
+                heads = {}
+                for hname, out_t, nc in (("time_sig_out", ts_out_g, cfg["num_time_sig"]), ("key_out", key_out_g, cfg["num_keys"])):
+                    t1 = hip.linear(headin, S[f"decoder.{hname}.0.weight"], S[f"decoder.{hname}.0.bias"], act=1)
+                    t2 = hip.linear(t1, S[f"decoder.{hname}.2.weight"], S[f"decoder.{hname}.2.bias"], act=1)
+                    lg = hip.linear(t2, S[f"decoder.{hname}.4.weight"], S[f"decoder.{hname}.4.bias"])
+                    am = torch.empty(Bg, dtype=torch.int32, device=dev)
+                    hip.check(L.a2s_log_softmax_rows(hip.stream(), hip._p(lg), C.c_long(nc), C.c_void_p(out_t.data_ptr() + 4 * bar * nc),
+                                                     C.c_long(bars * nc), hip._p(am), Bg, nc), "a2s_log_softmax_rows")
+                    heads[hname] = (t1, t2, lg, am)
+                return heads
+
+            def next_token(bar, teacher_force, staff, heads):
+                """Token bar `bar` hands to the next one (models.py:289-311); staff: {name: (ids, lengths)} of this bar's rows (not needed
+                when teacher-forced)."""
+                token = self._empty(Bg, tokw, dev=dev)
+                tok_rec = [] if training else None
+                if teacher_force and not inference:
+                    if int(gt_cpu_g[2][:, bar].min()) <= 0 or int(gt_cpu_g[3][:, bar].min()) <= 0:
+                        raise RuntimeError("Length of all samples has to be greater than 0")     # pack_padded_sequence
+                    self._staff_token(S, up_g[:, bar], upl_g[:, bar], bars, token, 0, U, bars * U, True, tok_rec)
+                    self._staff_token(S, lo_g[:, bar], lol_g[:, bar], bars, token, 2 * Sz, Lo, bars * Lo, True, tok_rec)
+                    ts_ids, key_ids, i64, stride = ts_g[:, bar], key_g[:, bar], True, bars
+                else:
+                    self._staff_token(S, staff["up"][0], staff["up"][1], 1, token, 0, U, U, False, tok_rec)
+                    self._staff_token(S, staff["lo"][0], staff["lo"][1], 1, token, 2 * Sz, Lo, Lo, False, tok_rec)
+                    ts_ids, key_ids, i64, stride = heads["time_sig_out"][3], heads["key_out"][3], False, 1
+                for table, ids_, col, width in ((S["decoder.time_sig_emb.weight"], ts_ids, 4 * Sz, te), (S["decoder.key_emb.weight"], key_ids, 4 * Sz + te, ke)):
+                    hip.check(L.a2s_embed_rows(hip.stream(), hip._p(table), hip._p(ids_) if i64 else C.c_void_p(0),
+                                               C.c_void_p(0) if i64 else hip._p(ids_), C.c_long(stride), 0, hip._p(token), C.c_long(tokw), col, Bg,
+                                               width, C.c_void_p(0), hip.f32(1.0)), "embed next token")
+                return token, tok_rec, (ts_ids, key_ids, i64, stride)
+
+            for seg_i, seg in enumerate(segments):
+                nb = len(seg)
+                # (1) bar-level chain of the segment: inside a segment every next token comes from the ground truth
+                for j, bar in enumerate(seg):
+                    rec = bar_step(bar, token, hidden)
+                    rec["seg"] = (len(seg_saved), j)
+                    bar_saved.append(rec)
+                    hidden = rec["hnew"]
+                    if j + 1 < nb:
+                        token, rec["tok_rec"], rec["next_ids"] = next_token(bar, True, None, None)
+                        rec["teacher_force"] = True
+                h0 = bar_saved[seg[0]]["hnew"] if nb == 1 else torch.cat([bar_saved[bar]["hnew"] for bar in seg], dim=0)
+                R = nb * Bg
+                # (2) note decoders of the segment (models.py:261-275)
+                staff = {}
+                calls = []
+                for name, prefix, maxs, out_t, gi_idx in (("up", "decoder.upper_decoder", U, up_out_g, 0), ("lo", "decoder.lower_decoder", Lo, lo_out_g, 1)):
+                    steps, flags, active, flags_dev = seg_plan[seg_i][gi_idx]
+                    if plan is not None:
+                        if bar_major:
+                            gt_bar = gt_bm[gi_idx][seg[0]:seg[0] + nb].view(R, maxs)
+                            probs = out_t[seg[0]:seg[0] + nb].view(R, maxs, V)
+                        else:
+                            gt_bar = (up_g if gi_idx == 0 else lo_g)[:, seg[0], :]
+                            probs = out_t[:, seg[0]]
+                    else:
+                        gt_bar, probs = None, out_t[:, seg[0]]
+                    # the dropout masks are drawn here, on the caller's thread and stream: one deterministic draw order per seed
+                    drop = (rand((steps + 1, R, E)) >= 0.1).to(torch.uint8) if drop_on else None
+                    calls.append((name, (S, prefix, keys_g[prefix], enc_g, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
+                                         attn_ws[gi_idx], gemm_ws[gi_idx], active, drop, flags_dev)))
+                if concurrent_g:
+                    join = fork_on_streams(dev, streams, [lambda args=args: self._decode_staff(*args) for _, args in calls])
+                elif greedy_graph:
+                    # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
+                    st = side_streams(dev)[0]
+                    res = []
+                    for _, args in calls:
+                        st.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(st):
+                            res.append(self._decode_staff(*args))
+                        torch.cuda.current_stream().wait_stream(st)
+                        for _ in range(res[-1][2]["steps"]):       # the reference draws once per executed step, also in inference
                             rng.random()
-                join = lambda res=res: res
-            # (3) heads do not depend on the note decoders: they overlap with them on the main stream
-            for bar in seg:
-                bar_saved[bar]["heads"] = bar_heads(bar, bar_saved[bar]["headin"])
-            for (name, _), (ids, lengths, sv) in zip(calls, join()):     # the next token / next bar may read what the staves produced
-                sv["groups"] = nb
-                staff[name] = (ids, lengths, sv)
-                if concurrent and gt_cpu is None:
-                    for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference (upper, then lower)
-                        rng.random()
-            seg_saved.append(dict(bars=seg, staff=staff))
-            for bar in seg:
-                bar_saved[bar]["staff"] = staff            # (shared by the bars of a fused segment)
-            # (4) token for the bar after the segment: one draw per bar, after both staves (drawn in the plan with ground truth)
-            last = seg[-1]
-            teacher_force = plan[last]["tf"] if plan is not None else (rng.random() < teacher_forcing_ratio)
-            rec = bar_saved[last]
-            last_rows = {name: (staff[name][0][(nb - 1) * B:], staff[name][1][(nb - 1) * B:]) for name in staff}
-            token, rec["tok_rec"], rec["next_ids"] = next_token(last, teacher_force, last_rows, rec["heads"])
-            rec["teacher_force"] = teacher_force
-        self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, bars=bar_saved, segments=seg_saved, enc_out=enc, sos_rec=sos_rec,
+                    join = lambda res=res: res
+                else:
+                    res = []
+                    for _, args in calls:
+                        res.append(self._decode_staff(*args))
+                        if gt_cpu is None:
+                            for _ in range(res[-1][2]["steps"]):
+                                rng.random()
+                    join = lambda res=res: res
+                # (3) heads do not depend on the note decoders: they overlap with them on the main stream
+                for bar in seg:
+                    bar_saved[bar]["heads"] = bar_heads(bar, bar_saved[bar]["headin"])
+                for (name, _), (ids, lengths, sv) in zip(calls, join()):     # the next token / next bar may read what the staves produced
+                    sv["groups"] = nb
+                    staff[name] = (ids, lengths, sv)
+                    if concurrent_g and gt_cpu is None:
+                        for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference (upper, then lower)
+                            rng.random()
+                seg_saved.append(dict(bars=seg, staff=staff))
+                for bar in seg:
+                    bar_saved[bar]["staff"] = staff            # (shared by the bars of a fused segment)
+                # (4) token for the bar after the segment: one draw per bar, after both staves (drawn in the plan with ground truth)
+                last = seg[-1]
+                teacher_force = plan[last]["tf"] if plan is not None else (rng.random() < teacher_forcing_ratio)
+                rec = bar_saved[last]
+                last_rows = {name: (staff[name][0][(nb - 1) * Bg:], staff[name][1][(nb - 1) * Bg:]) for name in staff}
+                token, rec["tok_rec"], rec["next_ids"] = next_token(last, teacher_force, last_rows, rec["heads"])
+                rec["teacher_force"] = teacher_force
+            return dict(range=(b0, b1), bars=bar_saved, segments=seg_saved, sos_rec=sos_rec, keys=keys_g, enc=enc_g,
+                        outs=(ts_out_g, key_out_g, up_out_g, lo_out_g), gt=(ground_truth is not None and (up_g, lo_g)) or None)
+
+        if len(clip_groups) == 1:
+            group_saved = [decode_group(0, 0, B, None)]
+        else:
+            # group 0 on the caller's thread and stream; every other group on a host thread and stream set of its own, forked from and
+            # joined to the caller's stream.  Dropout masks: one generator per group, seeded from torch's (seeded) CPU generator, so
+            # that a seed still fixes the run whatever the interleaving of the threads.
+            gens = []
+            for _ in clip_groups:
+                g_ = torch.Generator(device=dev)
+                g_.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+                gens.append(g_)
+            group_saved = run_clip_groups(dev, [lambda gi=gi, r=r: decode_group(gi, r[0], r[1], gens[gi]) for gi, r in enumerate(clip_groups)])
+        self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, groups=group_saved, enc_out=enc,
+                          bars=group_saved[0]["bars"], segments=group_saved[0]["segments"], sos_rec=group_saved[0]["sos_rec"],
                           training=training, concurrent=concurrent, outs=(ts_out, key_out, up_out, lo_out), bar_major=bar_major,
-                          gt=(ground_truth is not None and (up_gt, lo_gt)) or None, shape=(B, T, F), drop_on=drop_on, pinned=pinned)
+                          clip_groups=list(clip_groups), gt=(ground_truth is not None and (up_gt, lo_gt)) or None, shape=(B, T, F),
+                          drop_on=drop_on, pinned=pinned)
         return ts_out, key_out, up_out, lo_out

@@ -203,117 +203,157 @@ def backward(eng, S, grad_outputs, grad_ready=None):
     keep_alive = [ptrs_host]
     # the two note decoders of a bar back-propagate concurrently on two side streams (see engine.side_streams); each accumulates its
     # encoder-output gradient in its own buffer (summed once at the end), everything else they write is per-staff already
-    from .engine import fork_on_streams, side_streams
+    from .engine import fork_on_streams, group_views, run_clip_groups, side_streams
     concurrent = bool(sv.get("concurrent"))
-    streams = side_streams(dev) if concurrent else None
     dEnc_staff = [torch.zeros_like(dEnc), torch.zeros_like(dEnc)] if concurrent else [dEnc, dEnc]
-
     bar_major = bool(sv.get("bar_major"))
-    # weight gradients etc. of each staff: off its recurrence stream (A2S_DEFER_STREAM=0: in line, for A/B measurements)
-    use_deferred = concurrent and os.environ.get("A2S_DEFER_STREAM", "1") != "0"
-    deferred_streams = _deferred_streams(dev) if use_deferred else None
-    deferred_done = []
-    seg_dh0 = {}                # segment index -> [dh0 of the upper call, dh0 of the lower call], rows = (bar in segment, clip)
+    # weight gradients etc. of each staff off its recurrence stream: measured +0.7 % in round 1, but two more streams than the four
+    # hardware queues the runtime has (engine.group_stream) -- off by default since the clip groups need a queue (A2S_DEFER_STREAM=1)
+    use_deferred = concurrent and os.environ.get("A2S_DEFER_STREAM", "0") == "1"
+    clip_groups = sv.get("clip_groups") or [(0, B)]
+    d_hidden = torch.empty((B, H2), dtype=torch.float32, device=dev)       # gradient wrt the encoder's bridge output (initial bar-level hidden)
+    # Clip groups (engine.Engine.forward): each group's decoder backward runs concurrently on its own streams / host threads.  What the
+    # groups write per CLIP (dEnc, dK, d_hidden) they write to disjoint slices; what they ACCUMULATE over clips (every weight gradient)
+    # goes to a flat gradient buffer of the group's own (16.4 M floats), added to `flat` once after the join -- no two streams ever
+    # accumulate into the same memory.
+    group_flat = [flat] + [torch.zeros_like(flat) for _ in clip_groups[1:]]
+    group_ptrs = [G["__staff_emb_ptrs__"]]
+    for gf in group_flat[1:]:
+        delta = gf.data_ptr() - flat.data_ptr()
+        ph = (ptrs_host + delta).pin_memory()
+        keep_alive.append(ph)
+        group_ptrs.append(ph.to(dev, non_blocking=True))
 
-    def segment_decoders_bwd(si_seg):
-        """Both note decoders of a segment (bars decoded in one call each): they only need the loss gradients."""
-        seg = sv["segments"][si_seg]
-        bar0, nb = seg["bars"][0], len(seg["bars"])
-        calls = []
-        for si, (name, prefix, dout, out_t) in enumerate((("up", "decoder.upper_decoder", dup, up_out), ("lo", "decoder.lower_decoder", dlo, lo_out))):
-            if bar_major:
-                maxs = out_t.shape[2]
-                dpr, pr = dout[bar0:bar0 + nb].view(nb * B, maxs, -1), out_t[bar0:bar0 + nb].view(nb * B, maxs, -1)
-            else:
-                dpr, pr = dout[:, bar0], out_t[:, bar0]
-            calls.append((eng, S, G, seg["staff"][name][2], sv["keys"][prefix], enc, dpr, pr, dK[prefix], dEnc_staff[si], B, T,
-                          deferred_streams[si] if use_deferred else None))
-        if concurrent:      # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
-            res, events = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
-            seg_dh0[si_seg] = ([r[0] for r in res], events)
-            deferred_done.extend(r[1] for r in res if r[1] is not None)
+    def decoder_group_bwd(gidx):
+        gs = sv["groups"][gidx]
+        b0, b1 = gs["range"]
+        Bg = b1 - b0
+        Gg = G if gidx == 0 else {k: group_flat[gidx][off:off + S[k].numel()].view(S[k].shape) for k, off in zip(names, offs)}
+        Gg["__staff_emb_ptrs__"] = group_ptrs[gidx]
+        enc_g, keys_g = gs["enc"], gs["keys"]
+        dEnc_g = dEnc[b0:b1]
+        dK_g = {p: t[b0:b1] for p, t in dK.items()}
+        dEnc_staff_g = [t[b0:b1] for t in dEnc_staff]
+        ts_out_g, key_out_g, up_out_g, lo_out_g = gs["outs"]
+        dts_g, dkey_g = dts[b0:b1], dkey[b0:b1]
+        if bar_major:
+            dup_g, dlo_g = group_views(dup, clip_groups, gidx), group_views(dlo, clip_groups, gidx)
         else:
-            seg_dh0[si_seg] = ([_note_decoder_bwd(*args)[0] for args in calls], [])
+            dup_g, dlo_g = dup[b0:b1], dlo[b0:b1]
+        concurrent_g = concurrent and gidx == 0           # the long-clip groups: everything in order on their one stream
+        streams = side_streams(dev, 0) if concurrent_g else None
+        use_deferred_g = use_deferred and gidx == 0
+        deferred_streams = _deferred_streams(dev, gidx) if use_deferred_g else None
+        deferred_done = []
+        seg_dh0 = {}                # segment index -> [dh0 of the upper call, dh0 of the lower call], rows = (bar in segment, clip)
 
-    # The note decoders' backward passes only need the loss gradients: all segments are enqueued up front (last segment first, as the
-    # bar chain below consumes them), so the two staff streams run through every segment back to back instead of draining at each
-    # segment boundary while the bar-level chain catches up.
-    for si_seg in reversed(range(len(sv["segments"]))):
-        segment_decoders_bwd(si_seg)
+        def segment_decoders_bwd(si_seg):
+            """Both note decoders of a segment (bars decoded in one call each): they only need the loss gradients."""
+            seg = gs["segments"][si_seg]
+            bar0, nb = seg["bars"][0], len(seg["bars"])
+            calls = []
+            for si, (name, prefix, dout, out_t) in enumerate((("up", "decoder.upper_decoder", dup_g, up_out_g), ("lo", "decoder.lower_decoder", dlo_g, lo_out_g))):
+                if bar_major:
+                    maxs = out_t.shape[2]
+                    dpr, pr = dout[bar0:bar0 + nb].view(nb * Bg, maxs, -1), out_t[bar0:bar0 + nb].view(nb * Bg, maxs, -1)
+                else:
+                    dpr, pr = dout[:, bar0], out_t[:, bar0]
+                calls.append((eng, S, Gg, seg["staff"][name][2], keys_g[prefix], enc_g, dpr, pr, dK_g[prefix], dEnc_staff_g[si], Bg, T,
+                              deferred_streams[si] if use_deferred_g else None))
+            if concurrent_g:    # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
+                res, events = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
+                seg_dh0[si_seg] = ([r[0] for r in res], events)
+                deferred_done.extend(r[1] for r in res if r[1] is not None)
+            else:
+                seg_dh0[si_seg] = ([_note_decoder_bwd(*args)[0] for args in calls], [])
 
-    d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
-    d_token_next = None         # gradient wrt the (pre-dropout) token that bar k produced for bar k+1
-    for bar in reversed(range(bars)):
-        b = sv["bars"][bar]
-        # ---- (1) the token this bar produced for the next one
-        if d_token_next is not None:
-            for rec in b["tok_rec"]:
-                keep_alive.append(_staff_token_bwd(eng, S, G, rec, d_token_next))
-            ts_ids, key_ids, i64, stride = b["next_ids"]
-            for table, ids_, col, width in (("decoder.time_sig_emb.weight", ts_ids, 4 * Sz, te), ("decoder.key_emb.weight", key_ids, 4 * Sz + te, ke)):
-                hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[table]), hip._p(ids_) if i64 else NULL, NULL if i64 else hip._p(ids_),
-                                                  C.c_long(stride), 0, hip._p(d_token_next), C.c_long(tokw), col, B, width, NULL, hip.f32(1.0)), "scatter ts/key")
-        # ---- (2) heads: log_softmax + 3-layer MLP on headin = [bar_summary | ctx]
-        d_headin = torch.zeros((B, 4 * H), dtype=torch.float32, device=dev)
-        for hname, dout, out_t, nc in (("time_sig_out", dts, ts_out, cfg["num_time_sig"]), ("key_out", dkey, key_out, cfg["num_keys"])):
-            t1, t2, lg, _ = b["heads"][hname]
-            dlg = torch.empty((B, nc), dtype=torch.float32, device=dev)
-            hip.check(L.a2s_log_softmax_bwd_rows(hip.stream(), _ptr(dout, bar * nc), _ptr(out_t, bar * nc), C.c_long(bars * nc), 1, hip._p(dlg),
-                                                 B, nc, B, 0), "lsm bwd head")
-            p = f"decoder.{hname}"
-            dt2 = torch.empty_like(t2)
-            _linear_bwd(t2, S[p + ".4.weight"], dlg, G, p + ".4.weight", p + ".4.bias", dx=dt2)
-            hip.check(L.a2s_ew_act_bwd(hip.stream(), hip._p(dt2), hip._p(t2), hip._p(dt2), C.c_long(dt2.numel()), 1), "relu bwd")
-            dt1 = torch.empty_like(t1)
-            _linear_bwd(t1, S[p + ".2.weight"], dt2, G, p + ".2.weight", p + ".2.bias", dx=dt1)
-            hip.check(L.a2s_ew_act_bwd(hip.stream(), hip._p(dt1), hip._p(t1), hip._p(dt1), C.c_long(dt1.numel()), 1), "relu bwd")
-            _linear_bwd(b["headin"], S[p + ".0.weight"], dt1, G, p + ".0.weight", p + ".0.bias", dx=d_headin, dx_beta=1.0)
-        # ---- (3) note decoders: both start from bar_summary
-        d_hnew = torch.zeros((B, H2), dtype=torch.float32, device=dev)
-        si_seg, j = b["seg"]
-        dh0s, events = seg_dh0[si_seg]
-        for ev in events:
+        # The note decoders' backward passes only need the loss gradients: all segments are enqueued up front (last segment first, as the
+        # bar chain below consumes them), so the two staff streams run through every segment back to back instead of draining at each
+        # segment boundary while the bar-level chain catches up.
+        for si_seg in reversed(range(len(gs["segments"]))):
+            segment_decoders_bwd(si_seg)
+
+        d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
+        d_token_next = None         # gradient wrt the (pre-dropout) token that bar k produced for bar k+1
+        for bar in reversed(range(bars)):
+            b = gs["bars"][bar]
+            # ---- (1) the token this bar produced for the next one
+            if d_token_next is not None:
+                for rec in b["tok_rec"]:
+                    _staff_token_bwd(eng, S, Gg, rec, d_token_next)
+                ts_ids, key_ids, i64, stride = b["next_ids"]
+                for table, ids_, col, width in (("decoder.time_sig_emb.weight", ts_ids, 4 * Sz, te), ("decoder.key_emb.weight", key_ids, 4 * Sz + te, ke)):
+                    hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(Gg[table]), hip._p(ids_) if i64 else NULL, NULL if i64 else hip._p(ids_),
+                                                      C.c_long(stride), 0, hip._p(d_token_next), C.c_long(tokw), col, Bg, width, NULL, hip.f32(1.0)), "scatter ts/key")
+            # ---- (2) heads: log_softmax + 3-layer MLP on headin = [bar_summary | ctx]
+            d_headin = torch.zeros((Bg, 4 * H), dtype=torch.float32, device=dev)
+            for hname, dout, out_t, nc in (("time_sig_out", dts_g, ts_out_g, cfg["num_time_sig"]), ("key_out", dkey_g, key_out_g, cfg["num_keys"])):
+                t1, t2, lg, _ = b["heads"][hname]
+                dlg = torch.empty((Bg, nc), dtype=torch.float32, device=dev)
+                hip.check(L.a2s_log_softmax_bwd_rows(hip.stream(), _ptr(dout, bar * nc), _ptr(out_t, bar * nc), C.c_long(bars * nc), 1, hip._p(dlg),
+                                                     Bg, nc, Bg, 0), "lsm bwd head")
+                p = f"decoder.{hname}"
+                dt2 = torch.empty_like(t2)
+                _linear_bwd(t2, S[p + ".4.weight"], dlg, Gg, p + ".4.weight", p + ".4.bias", dx=dt2)
+                hip.check(L.a2s_ew_act_bwd(hip.stream(), hip._p(dt2), hip._p(t2), hip._p(dt2), C.c_long(dt2.numel()), 1), "relu bwd")
+                dt1 = torch.empty_like(t1)
+                _linear_bwd(t1, S[p + ".2.weight"], dt2, Gg, p + ".2.weight", p + ".2.bias", dx=dt1)
+                hip.check(L.a2s_ew_act_bwd(hip.stream(), hip._p(dt1), hip._p(t1), hip._p(dt1), C.c_long(dt1.numel()), 1), "relu bwd")
+                _linear_bwd(b["headin"], S[p + ".0.weight"], dt1, Gg, p + ".0.weight", p + ".0.bias", dx=d_headin, dx_beta=1.0)
+            # ---- (3) note decoders: both start from bar_summary
+            d_hnew = torch.zeros((Bg, H2), dtype=torch.float32, device=dev)
+            si_seg, j = b["seg"]
+            dh0s, events = seg_dh0[si_seg]
+            for ev in events:
+                torch.cuda.current_stream().wait_event(ev)
+            for dh0 in dh0s:
+                d_hnew.add_(dh0[j * Bg:(j + 1) * Bg])
+            d_hnew.add_(d_headin[:, :H2])
+            if d_hid_carry is not None:
+                d_hnew.add_(d_hid_carry)
+            # ---- (4) bar-level GRU step + attention
+            ldxb = tokw + H2
+            dgi, dgh = torch.empty((Bg, 3 * H2), device=dev), torch.empty((Bg, 3 * H2), device=dev)
+            dhp = torch.empty((Bg, H2), device=dev)
+            hip.check(L.a2s_gru_gates_bwd(hip.stream(), hip._p(d_hnew), C.c_long(H2), NULL, C.c_long(0), hip._p(b["gates"]), hip._p(b["hprev"]), C.c_long(H2),
+                                          hip._p(dgi), C.c_long(3 * H2), hip._p(dgh), C.c_long(3 * H2), NULL, C.c_long(0), hip._p(dhp), C.c_long(H2), Bg, H2),
+                      "gates bwd bar")
+            d_xbar = torch.empty((Bg, ldxb), device=dev)
+            _linear_bwd(b["xbar"], S["decoder.gru.weight_ih_l0"], dgi, Gg, "decoder.gru.weight_ih_l0", "decoder.gru.bias_ih_l0", dx=d_xbar)
+            _linear_bwd(b["hprev"], S["decoder.gru.weight_hh_l0"], dgh, Gg, "decoder.gru.weight_hh_l0", "decoder.gru.bias_hh_l0", dx=dhp, dx_beta=1.0)
+            dq, ds = torch.empty((Bg, H), device=dev), torch.empty((1, Bg, T), device=dev)
+            dctx = torch.empty((1, Bg, H2), device=dev)
+            hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(keys_g["decoder"]), hip._p(enc_g), hip._p(b["qb"]), C.c_long(H), hip._p(S["decoder.attn.v.weight"]),
+                                          hip._p(b["attw"]), _ptr(b["xbar"], tokw), C.c_long(ldxb), _ptr(d_xbar, tokw), C.c_long(ldxb), _ptr(d_headin, H2),
+                                          C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), Bg, T, H, NULL), "attn bwd bar")
+            Wa = S["decoder.attn.attn.weight"]
+            hip.gemm(dq, H, 1, Wa, 4 * H, 1, dhp, H2, Bg, H2, H, beta=1.0)                              # d hprev += dq W_h
+            hip.gemm(dq, 1, H, b["hprev"], H2, 1, Gg["decoder.attn.attn.weight"], 4 * H, H, H2, Bg, beta=1.0)   # dW_h += dq^T hprev
+            _colsum(dq, H, Gg["decoder.attn.attn.bias"], Bg, H)
+            _attn_deferred(eng, S, Gg, "decoder.attn", keys_g["decoder"], enc_g, b["qb"].view(1, Bg, H), ds, b["attw"].view(1, Bg, T), dctx,
+                           dK_g["decoder"], dEnc_g, Bg, T, H, 1)
+            d_hid_carry = dhp
+            d_token = d_xbar[:, :tokw].contiguous()
+            if b["keep"] is not None:
+                d_token = d_token * b["keep"] / 0.9
+            d_token_next = d_token
+        # ---- initial token: <sos>/<eos> staff token (used for both staves) + time-signature / key <sos> rows
+        d_sos = d_token_next.clone()
+        d_sos[:, :2 * Sz] += d_sos[:, 2 * Sz:4 * Sz]
+        _staff_token_bwd(eng, S, Gg, gs["sos_rec"][0], d_sos)
+        for table, cid, col, width in (("decoder.time_sig_emb.weight", cfg["num_time_sig"], 4 * Sz, te), ("decoder.key_emb.weight", cfg["num_keys"], 4 * Sz + te, ke)):
+            hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(Gg[table]), NULL, NULL, C.c_long(0), cid, hip._p(d_token_next), C.c_long(tokw), col, Bg, width,
+                                              NULL, hip.f32(1.0)), "scatter sos ts/key")
+        d_hidden[b0:b1].copy_(d_hid_carry)
+        for ev in deferred_done:                      # the staves' weight / key / encoder-output gradients are complete past this point
             torch.cuda.current_stream().wait_event(ev)
-        for dh0 in dh0s:
-            d_hnew.add_(dh0[j * B:(j + 1) * B])
-        d_hnew.add_(d_headin[:, :H2])
-        if d_hid_carry is not None:
-            d_hnew.add_(d_hid_carry)
-        # ---- (4) bar-level GRU step + attention
-        ldxb = tokw + H2
-        dgi, dgh = torch.empty((B, 3 * H2), device=dev), torch.empty((B, 3 * H2), device=dev)
-        dhp = torch.empty((B, H2), device=dev)
-        hip.check(L.a2s_gru_gates_bwd(hip.stream(), hip._p(d_hnew), C.c_long(H2), NULL, C.c_long(0), hip._p(b["gates"]), hip._p(b["hprev"]), C.c_long(H2),
-                                      hip._p(dgi), C.c_long(3 * H2), hip._p(dgh), C.c_long(3 * H2), NULL, C.c_long(0), hip._p(dhp), C.c_long(H2), B, H2),
-                  "gates bwd bar")
-        d_xbar = torch.empty((B, ldxb), device=dev)
-        _linear_bwd(b["xbar"], S["decoder.gru.weight_ih_l0"], dgi, G, "decoder.gru.weight_ih_l0", "decoder.gru.bias_ih_l0", dx=d_xbar)
-        _linear_bwd(b["hprev"], S["decoder.gru.weight_hh_l0"], dgh, G, "decoder.gru.weight_hh_l0", "decoder.gru.bias_hh_l0", dx=dhp, dx_beta=1.0)
-        dq, ds = torch.empty((B, H), device=dev), torch.empty((1, B, T), device=dev)
-        dctx = torch.empty((1, B, H2), device=dev)
-        hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(sv["keys"]["decoder"]), hip._p(enc), hip._p(b["qb"]), C.c_long(H), hip._p(S["decoder.attn.v.weight"]),
-                                      hip._p(b["attw"]), _ptr(b["xbar"], tokw), C.c_long(ldxb), _ptr(d_xbar, tokw), C.c_long(ldxb), _ptr(d_headin, H2),
-                                      C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), B, T, H, NULL), "attn bwd bar")
-        Wa = S["decoder.attn.attn.weight"]
-        hip.gemm(dq, H, 1, Wa, 4 * H, 1, dhp, H2, B, H2, H, beta=1.0)                              # d hprev += dq W_h
-        hip.gemm(dq, 1, H, b["hprev"], H2, 1, G["decoder.attn.attn.weight"], 4 * H, H, H2, B, beta=1.0)   # dW_h += dq^T hprev
-        _colsum(dq, H, G["decoder.attn.attn.bias"], B, H)
-        _attn_deferred(eng, S, G, "decoder.attn", sv["keys"]["decoder"], enc, b["qb"].view(1, B, H), ds, b["attw"].view(1, B, T), dctx,
-                       dK["decoder"], dEnc, B, T, H, 1)
-        d_hid_carry = dhp
-        d_token = d_xbar[:, :tokw].contiguous()
-        if b["keep"] is not None:
-            d_token = d_token * b["keep"] / 0.9
-        d_token_next = d_token
-    # ---- initial token: <sos>/<eos> staff token (used for both staves) + time-signature / key <sos> rows
-    d_sos = d_token_next.clone()
-    d_sos[:, :2 * Sz] += d_sos[:, 2 * Sz:4 * Sz]
-    keep_alive.append(_staff_token_bwd(eng, S, G, sv["sos_rec"][0], d_sos))
-    for table, cid, col, width in (("decoder.time_sig_emb.weight", cfg["num_time_sig"], 4 * Sz, te), ("decoder.key_emb.weight", cfg["num_keys"], 4 * Sz + te, ke)):
-        hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[table]), NULL, NULL, C.c_long(0), cid, hip._p(d_token_next), C.c_long(tokw), col, B, width,
-                                          NULL, hip.f32(1.0)), "scatter sos ts/key")
-    for ev in deferred_done:                      # the staves' weight / key / encoder-output gradients are complete past this point
-        torch.cuda.current_stream().wait_event(ev)
+        return None
+
+    run_clip_groups(dev, [lambda gi=gi: decoder_group_bwd(gi) for gi in range(len(clip_groups))])
+    G["__staff_emb_ptrs__"] = group_ptrs[0]
+    for gf in group_flat[1:]:
+        flat.add_(gf)
+    d_hid_carry = d_hidden
     if concurrent:
         dEnc.add_(dEnc_staff[0]).add_(dEnc_staff[1])
     # ---- attention keys: K = enc W_e^T  ->  dW_e += dK^T enc ; dEnc += dK W_e
@@ -339,19 +379,18 @@ _WG_STREAMS = {}
 _DEFERRED_STREAMS = {}
 
 
-def _deferred_streams(dev):
-    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+def _deferred_streams(dev, group=0):
+    idx = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    key = (idx, group)
     if key not in _DEFERRED_STREAMS:
-        _DEFERRED_STREAMS[key] = (torch.cuda.Stream(device=key), torch.cuda.Stream(device=key))
+        _DEFERRED_STREAMS[key] = (torch.cuda.Stream(device=idx), torch.cuda.Stream(device=idx))
     return _DEFERRED_STREAMS[key]
 
 
 
 def _weight_grad_stream(dev):
-    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
-    if key not in _WG_STREAMS:
-        _WG_STREAMS[key] = torch.cuda.Stream(device=key)
-    return _WG_STREAMS[key]
+    from .engine import group_stream
+    return group_stream(dev, 1)             # the fourth stream of the budget: idle while the encoder back-propagates
 
 
 def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):

@@ -103,15 +103,33 @@ class ASR(sb.Brain):
                 self._fused = train.TrainStep(model, lr=g["lr"], rho=g["rho"], eps=g["eps"], max_grad_norm=self.max_grad_norm)
         return self._fused
 
+    def init_optimizers(self):
+        """As sb.Brain.init_optimizers (the optimizer becomes the checkpointer's `optimizer` recoverable) -- but when the fused HIP step
+        is the one that trains, ITS Adadelta accumulators are the optimizer state: FusedAdadelta is registered instead of the idle
+        torch object (same optimizer.ckpt format), before on_fit_start recovers, so a resumed run continues with the saved
+        square_avg / acc_delta instead of silently restarting them from zero."""
+        super().init_optimizers()
+        fused = self._fused_step()
+        if fused and self.checkpointer is not None:
+            self.checkpointer.add_recoverable("optimizer", fused.opt)
+
     def fit_batch(self, batch):
         fused = self._fused_step()
         if not fused:
             return super().fit_batch(batch)
         fused.opt.lr = self.optimizer.param_groups[0]["lr"]          # NewBob annealing acts on the torch optimizer object
-        losses = fused(_features(batch, self.device), self.teacher_forcing_ratio)
-        terms = losses[:, 0].tolist()                                 # one small D2H per step (the reference does four)
+        fused(_features(batch, self.device), self.teacher_forcing_ratio)
+        *terms, applied = fused.report()                              # one small D2H per step (the reference does four)
         self._record_losses(*[torch.tensor(t) for t in terms])
-        return torch.tensor(sum(terms))
+        loss = torch.tensor(sum(terms))
+        if not applied:
+            # the device skipped the update (non-finite loss on some rank or non-finite gradient norm): SpeechBrain's check_gradients
+            # counts these and gives up after `nonfinite_patience` of them (reference pretrain.py:126)
+            self.nonfinite_count += 1
+            if self.nonfinite_count > self.nonfinite_patience:
+                raise ValueError("Loss is not finite and patience is exhausted. To debug, wrap `fit()` with autograd's "
+                                 "`detect_anomaly()`.")
+        return loss
 
     def evaluate_batch(self, batch, stage):
         with torch.no_grad():

@@ -111,6 +111,21 @@ class EpochCounter:
             return self.current
         raise StopIteration
 
+    # SpeechBrain's EpochCounter checkpoints itself as a PLAIN-TEXT integer (its @mark_as_saver / @mark_as_loader hooks), not as a
+    # pickled dict: `_save` / `_recover` below are the hooks Checkpointer looks for, so that a save/ directory written by SpeechBrain
+    # (the reference's pretrain run, the README's published checkpoints) recovers here and vice versa.
+    def _save(self, path):
+        with open(path, "w") as f:
+            f.write(str(self.current))
+
+    def _recover(self, path, end_of_epoch=True, device=None):
+        try:
+            with open(path) as f:
+                value = int(f.read().strip())
+        except (UnicodeDecodeError, ValueError):          # a counter.ckpt written by round 1 of this repository: torch.save({"current": n})
+            value = int(torch.load(path, map_location="cpu")["current"])
+        self.current = value if end_of_epoch else value - 1
+
     def state_dict(self):
         return {"current": self.current}
 
@@ -217,15 +232,19 @@ class Checkpointer:
     def save_checkpoint(self, meta=None, name=None):
         meta = dict(meta or {})
         meta.setdefault("unixtime", time.time())
+        meta.setdefault("end-of-epoch", True)
         stamp = datetime.datetime.fromtimestamp(meta["unixtime"]).strftime("%Y-%m-%d+%H-%M-%S") + "+00"
         path = os.path.join(self.checkpoints_dir, name or f"CKPT+{stamp}")
         if if_main_process():
             os.makedirs(path, exist_ok=True)
             for n, obj in self.recoverables.items():
-                sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
-                torch.save(sd, os.path.join(path, f"{n}.ckpt"))
+                target = os.path.join(path, f"{n}.ckpt")
+                if hasattr(obj, "_save"):                 # the object's own saver hook (SpeechBrain: @mark_as_saver)
+                    obj._save(target)
+                else:
+                    torch.save(obj.state_dict() if hasattr(obj, "state_dict") else obj, target)
             with open(os.path.join(path, "CKPT.yaml"), "w") as f:
-                yaml.safe_dump({k: (float(v) if hasattr(v, "__float__") else v) for k, v in meta.items()}, f)
+                yaml.safe_dump({k: (float(v) if hasattr(v, "__float__") and not isinstance(v, bool) else v) for k, v in meta.items()}, f)
         return path
 
     def save_and_keep_only(self, meta=None, min_keys=(), max_keys=(), num_to_keep=1, **_):
@@ -265,7 +284,11 @@ class Checkpointer:
         path, meta = found
         for n, obj in self.recoverables.items():
             f = os.path.join(path, f"{n}.ckpt")
-            if os.path.exists(f) and hasattr(obj, "load_state_dict"):
+            if not os.path.exists(f):
+                continue
+            if hasattr(obj, "_recover"):                  # the object's own loader hook (SpeechBrain: @mark_as_loader)
+                obj._recover(f, end_of_epoch=bool(meta.get("end-of-epoch", True)), device=device)
+            elif hasattr(obj, "load_state_dict"):
                 obj.load_state_dict(torch.load(f, map_location=device or "cpu"))
         return path, meta
 
@@ -278,6 +301,10 @@ class Brain:
     def __init__(self, modules=None, opt_class=None, hparams=None, run_opts=None, checkpointer=None):
         run_opts = dict(run_opts or {})
         self.device = run_opts.get("device", "cuda" if torch.cuda.is_available() else "cpu")
+        if str(self.device).startswith("cuda") and torch.cuda.is_available():
+            # liba2s_hip.so launches on torch's CURRENT stream of the CURRENT device: make the run's device current (SpeechBrain's
+            # Brain.__init__ does the same), or `--device cuda:1` would launch on a device-0 stream with device-1 pointers
+            torch.cuda.set_device(torch.device(self.device))
         self.max_grad_norm = float(run_opts.get("max_grad_norm", 5.0))
         self.nonfinite_patience = int(run_opts.get("nonfinite_patience", 3))
         self.debug, self.debug_batches, self.debug_epochs = bool(run_opts.get("debug")), int(run_opts.get("debug_batches", 2)), int(run_opts.get("debug_epochs", 2))
@@ -308,6 +335,15 @@ class Brain:
         self.init_optimizers()
         if self.checkpointer is not None:
             self.checkpointer.recover_if_possible(device=self.device)
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """What DDP's constructor does for the reference (SpeechBrain wraps modules in DDP in on_fit_start): every replica starts
+        from rank 0's parameters and buffers, whatever each rank's own initialisation or checkpoint recovery produced."""
+        if self.world > 1:
+            with torch.no_grad():
+                for t in list(self.modules.parameters()) + list(self.modules.buffers()):
+                    dist.broadcast(t.data, src=0)
 
     def init_optimizers(self):
         if self.opt_class is not None and self.optimizer is None:
@@ -352,6 +388,10 @@ class Brain:
         if stage == Stage.TRAIN and self.world > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=loader_kwargs.pop("shuffle", False))
             loader_kwargs["shuffle"] = False
+        if str(self.device).startswith("cuda"):
+            # batches are collated into PINNED host buffers, so the trainer's one `.to(device, non_blocking=True)` per batch tensor is a
+            # single asynchronous DMA (the reference moves every ITEM to the device inside Dataset.__getitem__, syn.py:113)
+            loader_kwargs.setdefault("pin_memory", True)
         return torch.utils.data.DataLoader(dataset, sampler=sampler, **loader_kwargs)
 
     def fit(self, epoch_counter, train_set, valid_set=None, train_loader_kwargs=None, valid_loader_kwargs=None, progressbar=None):

@@ -87,11 +87,18 @@ class Objective:
 
 
 class FusedAdadelta:
-    """clip_grad_norm_(max_grad_norm) + torch.optim.Adadelta(lr, rho, eps) over the model's flat parameter buffer."""
+    """clip_grad_norm_(max_grad_norm) + torch.optim.Adadelta(lr, rho, eps) over the model's flat parameter buffer.
 
-    def __init__(self, flat_params, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0):
+    `layout` = [(offset, shape), ...] of the parameters inside the flat buffer, in `module.parameters()` order: with it,
+    state_dict() / load_state_dict() speak torch.optim.Adadelta's own format ({"state": {i: {"step", "square_avg", "acc_delta"}},
+    "param_groups": [...]}), so the `optimizer.ckpt` SpeechBrain's Brain writes for the reference recipe (init_optimizers registers
+    the optimizer as a recoverable) and the one written here are interchangeable."""
+
+    def __init__(self, flat_params, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, layout=None):
         self.p = flat_params
         self.lr, self.rho, self.eps, self.max_grad_norm = lr, rho, eps, max_grad_norm
+        self.layout = layout
+        self.steps = 0
         dev = flat_params.device
         self.square_avg = torch.zeros_like(flat_params)
         self.acc_delta = torch.zeros_like(flat_params)
@@ -100,35 +107,127 @@ class FusedAdadelta:
         self.partial = torch.empty(self.nblocks, dtype=torch.float64, device=dev)
 
     def step(self, flat_grads, loss_scalar=None, zero_grad=True):
+        """The update is skipped ON THE DEVICE (ctl[2] = 0) when *loss_scalar or the gradient norm is not finite."""
         hip.check(hip.lib().a2s_clip_adadelta(hip.stream(), hip._p(self.p), hip._p(flat_grads), hip._p(self.square_avg), hip._p(self.acc_delta),
                                               C.c_long(self.p.numel()), hip._p(loss_scalar), hip.f32(self.max_grad_norm), hip.f32(self.lr), hip.f32(self.rho),
                                               hip.f32(self.eps), hip._p(self.ctl), hip._p(self.partial), self.nblocks, 1 if zero_grad else 0), "a2s_clip_adadelta")
+        self.steps += 1
+
+    @property
+    def param_groups(self):          # so that sb.nnet.schedulers.update_learning_rate(optimizer, lr) works on this object too
+        return [self]
+
+    def __getitem__(self, key):      # param-group view of the hyper-parameters
+        return {"lr": self.lr, "rho": self.rho, "eps": self.eps}[key]
+
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
 
     def state_dict(self):
-        return {"square_avg": self.square_avg, "acc_delta": self.acc_delta, "lr": self.lr, "rho": self.rho, "eps": self.eps}
+        if self.layout is None:
+            return {"square_avg": self.square_avg.cpu(), "acc_delta": self.acc_delta.cpu(), "lr": self.lr, "rho": self.rho, "eps": self.eps}
+        state = {}
+        for i, (off, shape) in enumerate(self.layout):
+            n = 1
+            for d in shape:
+                n *= d
+            state[i] = {"step": torch.tensor(float(self.steps)), "square_avg": self.square_avg[off:off + n].view(shape).clone(),
+                        "acc_delta": self.acc_delta[off:off + n].view(shape).clone()}
+        group = {"lr": self.lr, "rho": self.rho, "eps": self.eps, "weight_decay": 0, "foreach": None, "capturable": False, "maximize": False,
+                 "differentiable": False, "params": list(range(len(self.layout)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.square_avg.copy_(sd["square_avg"])
-        self.acc_delta.copy_(sd["acc_delta"])
-        self.lr = sd.get("lr", self.lr)
+        if "state" in sd:                                   # torch.optim.Adadelta format (ours, or SpeechBrain's optimizer.ckpt)
+            if sd["state"] and self.layout is None:
+                raise ValueError("FusedAdadelta: a per-parameter optimizer state needs the parameter layout")
+            for i, st in sd["state"].items():
+                off, shape = self.layout[int(i)]
+                n = st["square_avg"].numel()
+                if tuple(st["square_avg"].shape) != tuple(shape):
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['square_avg'].shape)} != parameter shape {tuple(shape)}")
+                self.square_avg[off:off + n].copy_(st["square_avg"].reshape(-1))
+                self.acc_delta[off:off + n].copy_(st["acc_delta"].reshape(-1))
+                self.steps = int(float(st.get("step", self.steps)))
+            g = sd["param_groups"][0]
+            self.lr, self.rho, self.eps = g.get("lr", self.lr), g.get("rho", self.rho), g.get("eps", self.eps)
+        else:                                               # flat format of round 1
+            self.square_avg.copy_(sd["square_avg"])
+            self.acc_delta.copy_(sd["acc_delta"])
+            self.lr = sd.get("lr", self.lr)
+
+
+def plan_clip_groups(until_up, until_lo, max_tail_frac=0.5, min_gain=0.08, step_cost=150.0, jump=1.3, max_candidates=8):
+    """Cut a minibatch into [ordinary clips | long clips] for Engine.forward's clip groups.
+
+    until_up / until_lo: (B, bars) int arrays, decode steps each (clip, bar) row needs (last real target + 1).  Cost model of a group
+    of clips, in units of one clip's attention pass (~0.7 us on MI355X): a decode step costs max(step_cost, rows still active) --
+    bandwidth-bound while many rows are active, a latency floor (~100 us of dependent small kernels) once only a few long rows
+    remain -- summed over the steps of the longer staff of every bar.  Two groups run CONCURRENTLY but share the HBM, so a cut costs
+    max(cost of either group, attention work of both).  Candidate cuts: the places where the clips' longest rows, sorted, jump by
+    `jump`x.  The best cut is taken if it beats the uncut minibatch by min_gain.  Returns (order, n_main): `order` = clip permutation
+    (ordinary clips first, original order kept inside each group), n_main = size of the first group (== B: do not split)."""
+    import numpy as np
+    up, lo = np.asarray(until_up, dtype=np.int64), np.asarray(until_lo, dtype=np.int64)
+    B = up.shape[0]
+    ident = np.arange(B)
+    if B < 4:
+        return ident, B
+
+    def cost(sel):
+        total, work = 0.0, 0.0
+        for bar in range(up.shape[1]):
+            u, l = up[sel, bar], lo[sel, bar]
+            n = int(max(u.max(), l.max()))
+            act = np.zeros(n, dtype=np.float64)
+            for v in (u, l):
+                act += len(v) - np.cumsum(np.bincount(v, minlength=n + 1))[:n]         # rows with until > t
+            total += np.maximum(act, step_cost).sum()
+            work += act.sum()
+        return total, work
+
+    longest = np.maximum(up.max(1), lo.max(1))
+    by_len = np.argsort(-longest, kind="stable")                 # longest clips first
+    srt = longest[by_len].astype(np.float64)
+    kmax = max(1, int(B * max_tail_frac))
+    ratio = srt[:kmax] / np.maximum(srt[1:kmax + 1], 1.0)        # jump between the k-th longest clip and the next
+    cands = [int(k) + 1 for k in np.argsort(-ratio, kind="stable")[:max_candidates] if ratio[k] >= jump]
+    if not cands:
+        return ident, B
+    whole, _ = cost(ident)
+    best_k, best = None, (1.0 - min_gain) * whole
+    for k in cands:
+        ct, wt = cost(by_len[:k])
+        cm, wm = cost(by_len[k:])
+        c = max(ct, cm, wt + wm)
+        if c < best:
+            best_k, best = k, c
+    if best_k is None:
+        return ident, B
+    return np.concatenate([np.sort(by_len[best_k:]), np.sort(by_len[:best_k])]), B - best_k
 
 
 class TrainStep:
     """model: models.ScoreTranscription on a GPU.  One call = one optimizer step on one minibatch."""
 
     def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True, sync_bn=None, skip_finished_rows=None,
-                 fuse_bars=None):
+                 fuse_bars=None, clip_groups=None):
         """skip_finished_rows (default on; A2S_SKIP_FINISHED=0 turns it off): the note decoders skip the attention of rows whose
         remaining targets are all <pad>.  fuse_bars (default on with the former; A2S_FUSE_BARS=0 turns it off): consecutive bars
         whose bar-level input is teacher-forced are decoded in one call (Engine.forward).  Loss, gradients and the update are
         unchanged (skipped rows are ignore_index positions and nothing else reads them); only `last_outputs` positions whose target
-        is <pad> differ from the reference's values."""
+        is <pad> differ from the reference's values.  clip_groups (default on with fuse_bars; A2S_CLIP_GROUPS=0 turns it off): the
+        clips holding exceptionally long bars decode as a group of their own, concurrently with the ordinary ones (plan_clip_groups;
+        Engine.forward) -- the minibatch is permuted for that, which no loss term, gradient or statistic depends on."""
         self.model = model
         self.sync_bn = (_os.environ.get("A2S_SYNC_BN") == "1") if sync_bn is None else bool(sync_bn)
         self.skip_finished_rows = (_os.environ.get("A2S_SKIP_FINISHED", "1") != "0") if skip_finished_rows is None else bool(skip_finished_rows)
         self.fuse_bars = (_os.environ.get("A2S_FUSE_BARS", "1") != "0") if fuse_bars is None else bool(fuse_bars)
+        # True / False, or an explicit list of contiguous clip ranges [(0, n), (n, B)] (tests: no planner, no permutation)
+        self.clip_groups = (_os.environ.get("A2S_CLIP_GROUPS", "1") != "0") if clip_groups is None else clip_groups
+        self._last = None
         self.flat = model.flatten_()
-        self.opt = FusedAdadelta(self.flat, lr, rho, eps, max_grad_norm)
+        self.opt = FusedAdadelta(self.flat, lr, rho, eps, max_grad_norm, layout=model.flat_layout())
         self.objective = Objective(self.flat.device)
         self.total = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
         self.dropout = dropout
@@ -145,19 +244,69 @@ class TrainStep:
         eng = engine.Engine(self.model.cfg, sync_bn=self.sync_bn)
         eng.skip_finished_rows = self.skip_finished_rows
         eng.fuse_bars = self.skip_finished_rows and self.fuse_bars
+        gt_host, perm = None, None
+        if eng.fuse_bars and isinstance(self.clip_groups, (list, tuple)):
+            eng.clip_groups = [tuple(r) for r in self.clip_groups]
+        elif eng.fuse_bars and self.clip_groups:
+            gt_host = [up_t.cpu(), lo_t.cpu(), up_len.cpu(), lo_len.cpu()]       # the one host sync of the step (Engine.forward reuses it)
+            idx_u = torch.arange(1, up_t.shape[-1] + 1)
+            idx_l = torch.arange(1, lo_t.shape[-1] + 1)
+            order, n_main = plan_clip_groups(((gt_host[0] != PAD).long() * idx_u).amax(-1).numpy(), ((gt_host[1] != PAD).long() * idx_l).amax(-1).numpy())
+            B = up_t.shape[0]
+            if n_main < B:
+                perm = torch.from_numpy(order)
+                gt_host = [t[perm] for t in gt_host]
+                pd = perm.to(spectrogram.device, non_blocking=True)
+                spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len)]
+                eng.clip_groups = [(0, n_main), (n_main, B)]
         S = self.state()
         outs = eng.forward(S, spectrogram, inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len],
-                           teacher_forcing_ratio=teacher_forcing_ratio, training=True, rng=rng, dropout=self.dropout)
-        if eng.bar_major:            # fused bars: the staff outputs come bar-major (bars, B, len, V); the loss is a mean over rows
-            losses, gouts = self.objective(outs, (ts_t, key_t, up_t.transpose(0, 1), lo_t.transpose(0, 1)))
-            outs = (outs[0], outs[1], outs[2].transpose(0, 1), outs[3].transpose(0, 1))
+                           teacher_forcing_ratio=teacher_forcing_ratio, training=True, rng=rng, dropout=self.dropout, gt_host=gt_host)
+        groups = eng.clip_groups_used
+        if eng.bar_major:
+            # fused bars: the staff outputs come bar-major, one contiguous (bars, clips, len, V) block per clip group; the loss is a mean
+            # over rows, so the targets are simply laid out the same way
+            lay = lambda t: torch.cat([t[b0:b1].transpose(0, 1).reshape(-1) for b0, b1 in groups])
+            losses, gouts = self.objective(outs, (ts_t, key_t, lay(up_t), lay(lo_t)))
         else:
             losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
         exchange = GradientExchange(self.world)
         G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready)
         flat_g = exchange.finish(G[None])
         torch.sum(losses[:, 0], dim=0, keepdim=True, out=self.total)          # total loss stays on the device
-        self.opt.step(flat_g, self.total, zero_grad=False)
+        gate = self.total
+        if exchange.active:
+            # every replica must take the SAME skip / apply decision (reference check_gradients looks at the local loss only, which
+            # under data parallelism lets one rank skip while the others apply): the gate is the sum of all ranks' losses -- finite
+            # iff every rank's is; non-finite gradients reach every rank through the all-reduce and gate via the norm
+            gate = self.total.clone()
+            dist.all_reduce(gate, op=dist.ReduceOp.SUM)
+        self.opt.step(flat_g, gate, zero_grad=False)
         eng.saved = None
-        self.last_outputs = outs
+        self._last = (outs, eng.bar_major, groups, perm)
         return losses
+
+    @property
+    def last_outputs(self):
+        """The four log-probability tensors of the last step in the reference's layout and the caller's clip order."""
+        if self._last is None:
+            return None
+        outs, bar_major, groups, perm = self._last
+        outs = list(outs)
+        if bar_major:
+            outs[2], outs[3] = (engine.gather_group_views(o, groups).transpose(0, 1) for o in outs[2:])
+        if perm is not None:
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel())
+            inv = inv.to(outs[0].device)
+            outs = [o.index_select(0, inv) for o in outs]
+        return tuple(outs)
+
+    @last_outputs.setter
+    def last_outputs(self, value):
+        self._last = None if value is None else (value, False, [(0, value[0].shape[0])], None)
+
+    def report(self):
+        """Host copy of the last step's [time-sig, key, upper, lower loss, applied flag] -- ONE small device-to-host read (the
+        reference recipe does four .cpu() reads per step, pretrain.py:90-93)."""
+        return torch.cat([self.objective.losses[:, 0], self.opt.ctl[2:3]]).tolist()

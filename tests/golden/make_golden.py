@@ -7,7 +7,7 @@ procedural weights (piano_a2s_amd.spec.procedural_state) and synthetic batches
 (piano_a2s_amd.synthetic.make_batch), and stores inputs' checksums + the reference's outputs.
 Nothing of the reference's text is stored: fixtures are numbers.
 
-Usage:  python tests/golden/make_golden.py [g1] [g2] [tok] [step]
+Usage:  python tests/golden/make_golden.py [g1] [g2] [g2tf] [tok]
 The fixtures are committed; this script documents how they were made and can regenerate them.
 """
 import hashlib
@@ -239,6 +239,66 @@ def make_g2(ref_models, seed=2032, eb=None):
     print("g2 written")
 
 
+def make_g2_tf(ref_models, seed=2032, eb=2.5, tf=0.7, rseeds=(3, 5, 9, 12)):
+    """Full-size model, train mode (batch-statistics BatchNorm, dropout neutralised), SEEDED teacher forcing tf = 0.7 -- the epoch-0
+    ratio of hparams/pretrain.yaml and the second case of BASELINE.md section 3's parity gate.  Same weights and batch as g2.  With
+    0 < tf < 1 the steps whose coin says "no" feed the model's OWN argmax back, so a near-tie in any such decision would let two correct
+    fp32 implementations diverge; the Python-random seed is picked among `rseeds` as the one whose decisions have the largest minimum
+    top-2 margin, the margin is stored, and the parity test asserts that precondition (as g2 does for greedy decoding)."""
+    cfg = spec.default_cfg()
+    st = spec.procedural_state(cfg, seed, eos_bias=eb, lively="token")
+    batch = synthetic.make_batch(2, cfg, 77, **FULL_BATCH)
+    no_dropout()
+    best = None
+    for rseed in rseeds:
+        m = ref_models.ScoreTranscription(**cfg)
+        m.load_state_dict(st)
+        m.train()
+        random.seed(rseed)
+        state0 = random.getstate()
+        outs = m(spectrogram=batch[0], inference=False, ground_truth=gt_of(batch), teacher_forcing_ratio=tf, device="cpu")
+        state1 = random.getstate()
+        random.setstate(state0)
+        draws = 0
+        while random.getstate() != state1 and draws < 100000:
+            random.random()
+            draws += 1
+        margins = []
+        for o in outs[2:]:
+            decoded = o.detach().abs().sum(-1) > 0
+            top2 = o.detach().topk(2, dim=-1).values
+            margins.append(float((top2[..., 0] - top2[..., 1])[decoded].min()))
+        for o in outs[:2]:
+            top2 = o.detach().topk(2, dim=-1).values
+            margins.append(float((top2[..., 0] - top2[..., 1]).min()))
+        print("g2_tf: python-random seed", rseed, "draws", draws, "min margins (up, lo, ts, key)", margins, flush=True)
+        if best is None or min(margins) > min(best[3]):
+            best = (rseed, draws, outs, margins, m)
+    rseed, draws, outs, margins, m = best
+    losses = ref_losses(outs, batch)
+    losses[0].backward()
+    g = np.random.default_rng(1)
+    out = {"losses": np.array([float(l) for l in losses], dtype=np.float64), "ts": outs[0].detach().numpy(), "key": outs[1].detach().numpy(),
+           "up_rows": (outs[2].detach().abs().sum(-1) > 0).sum(-1).numpy().astype(np.int16),
+           "lo_rows": (outs[3].detach().abs().sum(-1) > 0).sum(-1).numpy().astype(np.int16),
+           "up_ids": outs[2].detach().argmax(-1).numpy().astype(np.int16), "lo_ids": outs[3].detach().argmax(-1).numpy().astype(np.int16)}
+    for nm, o in (("up", outs[2]), ("lo", outs[3])):
+        idx = g.integers(0, o.numel(), size=2000)
+        out[f"{nm}_sample_idx"], out[f"{nm}_sample"] = idx, o.detach().flatten()[idx].numpy()
+    names, norms = [], []
+    for k, p in m.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+    out["gradnorms"] = np.array(norms)
+    meta = {"weights_seed": seed, "eos_bias": eb, "lively": "token", "batch_seed": 77, "tf": tf, "random_seed": rseed, "draws": draws,
+            "min_margin": dict(zip(("up", "lo", "ts", "key"), margins)), "grad_names": names, "state_sha256": digest(st.values()),
+            "batch_sha256": digest([batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]])}
+    np.savez_compressed(os.path.join(HERE, "g2_full_tf07.npz"), **out)
+    with open(os.path.join(HERE, "g2_full_tf07.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("g2_tf written: seed", rseed, "losses", out["losses"].tolist())
+
+
 def make_tok(RefLabels):
     lab = RefLabels(extended=True)
     cases = ["4c", "4c\t8e 8g\n4r", "[2.CC#_ 4ee-;]\t.\n16ffff", "8.r\t4c 4e 4g", "16.BBB#]\t[8cccc-",
@@ -273,3 +333,5 @@ if __name__ == "__main__":
         make_g1(ref_models)
     if "g2" in what:
         make_g2(ref_models)
+    if "g2tf" in what:
+        make_g2_tf(ref_models)

@@ -120,3 +120,53 @@ def test_full_size_gradient_norms(golden_dir, dev):
         if e_norm > (5e-4 if k.startswith("convstack.") else 2e-4) or e_samp > 3e-3:
             failures.append((k, e_norm, e_samp))
     assert not failures, f"{len(failures)} gradients off: {failures[:8]}"
+
+
+def test_full_size_seeded_teacher_forcing(golden_dir, dev):
+    """BASELINE.md section 3 parity gate, second case: the FULL model in train mode with SEEDED teacher forcing tf = 0.7 (hparams/pretrain.yaml's
+    epoch-0 ratio) against the reference's fixture (tests/golden/make_golden.py g2tf): Python-random draw count, executed steps per (clip, bar),
+    every fed-back token id, the four loss terms + total within 1e-4 rel (north-star bar), gradient norms."""
+    import random
+    from piano_a2s_amd import engine, engine_bwd, spec, synthetic
+    data = np.load(os.path.join(golden_dir, "g2_full_tf07.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g2_full_tf07.json")))
+    g2 = json.load(open(os.path.join(golden_dir, "g2_full.json")))
+    assert min(meta["min_margin"].values()) >= 1e-3, "fixture precondition: no near-tie among the fed-back argmax decisions"
+    cfg = spec.default_cfg()
+    st = spec.procedural_state(cfg, meta["weights_seed"], eos_bias=meta["eos_bias"], lively=meta["lively"])
+    kw = dict(g2["batch_kwargs"])
+    kw["upper_range"], kw["lower_range"] = tuple(kw["upper_range"]), tuple(kw["lower_range"])
+    batch = synthetic.make_batch(2, cfg, meta["batch_seed"], **kw)
+    S = {k: v.to(dev) for k, v in st.items()}
+    gt = [b.to(dev) for b in batch[1:7]]
+    rng = random.Random(meta["random_seed"])
+    draws = {"n": 0}
+
+    class Counting:
+        def random(self):
+            draws["n"] += 1
+            return rng.random()
+    eng = engine.Engine(cfg)
+    outs = eng.forward(S, batch[0].to(dev), inference=False, ground_truth=gt, teacher_forcing_ratio=meta["tf"], training=True, dropout=False, rng=Counting())
+    torch.cuda.synchronize()
+    assert draws["n"] == meta["draws"], "the forward must consume the reference's number of Python-random draws"
+    up, lo = outs[2].cpu(), outs[3].cpu()
+    assert np.array_equal((up.abs().sum(-1) > 0).sum(-1).numpy(), data["up_rows"]) and np.array_equal((lo.abs().sum(-1) > 0).sum(-1).numpy(), data["lo_rows"])
+    assert np.array_equal(up.argmax(-1).numpy(), data["up_ids"]) and np.array_equal(lo.argmax(-1).numpy(), data["lo_ids"]), "token ids (incl. every fed-back argmax)"
+    for nm, o in (("up", up), ("lo", lo)):
+        err = np.abs(o.flatten()[torch.from_numpy(data[f"{nm}_sample_idx"])].numpy() - data[f"{nm}_sample"]).max()
+        assert err <= 1e-4, f"{nm} log-probabilities differ by {err:.3e}"
+    assert np.abs(outs[0].cpu().numpy() - data["ts"]).max() <= 1e-4 and np.abs(outs[1].cpu().numpy() - data["key"]).max() <= 1e-4
+    losses, gouts = _loss_grads(outs, batch, dev)
+    for i, (l, r) in enumerate(zip(losses, data["losses"])):
+        _log(f"full tf0.7 loss term {i}: {l} vs {r} rel {abs(l - r) / abs(r):.3e}")
+        assert abs(l - r) <= 1e-4 * abs(r), f"loss term {i}: {l} vs reference {r}"
+    G = engine_bwd.backward(eng, S, gouts)
+    torch.cuda.synchronize()
+    failures = []
+    for k, rn in zip(meta["grad_names"], data["gradnorms"]):
+        e = abs(float(G[k].double().norm()) - rn) / max(rn, 1e-12)
+        _log(f"full tf0.7 {k}: norm {e:.3e}")
+        if e > (5e-4 if k.startswith("convstack.") else 2e-4):       # same bars as test_full_size_gradient_norms (see the note there)
+            failures.append((k, e))
+    assert not failures, f"{len(failures)} gradient norms off: {failures[:8]}"

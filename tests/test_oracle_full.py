@@ -93,3 +93,39 @@ def test_full_train_loss_and_grad_norms(g2):
         assert np.abs(got - rs).max() <= 1e-3 * max(np.abs(rs).max(), rn / np.sqrt(P[name].numel())) + 1e-9, f"grad samples {name}"
     for k, b in B.items():
         assert np.abs(b.numpy() - data[f"train_tf1.buf.{k}"]).max() <= 1e-5 * max(1.0, np.abs(data[f"train_tf1.buf.{k}"]).max())
+
+
+# ---------------------------------------------------------------------------------------------- seeded teacher forcing, full size
+@pytest.fixture(scope="module")
+def g2tf(golden_dir, g2):
+    _, _, cfg, st, batch = g2
+    data = np.load(os.path.join(golden_dir, "g2_full_tf07.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g2_full_tf07.json")))
+    assert _digest(st.values()) == meta["state_sha256"] and _digest(batch[:7]) == meta["batch_sha256"]
+    return data, meta, cfg, st, batch
+
+
+def test_full_size_seeded_teacher_forcing(g2tf):
+    """BASELINE.md section 3 parity gate, second case: full model, train mode, seeded tf = 0.7 (fixture made by the reference with
+    random.seed(meta['random_seed'])): draw count, executed steps, fed-back token ids and the four loss terms."""
+    import random
+    data, meta, cfg, st, batch = g2tf
+    for k, v in meta["min_margin"].items():
+        assert v >= MARGIN_FLOOR, f"fixture has a near-tie in '{k}' ({v:.2e})"
+    P, B = spec.split_state(st)
+    rng = random.Random(meta["random_seed"])
+    counter = {"n": 0}
+
+    class Counting:
+        def random(self):
+            counter["n"] += 1
+            return rng.random()
+    with torch.no_grad():
+        outs = model_ref.forward(P, B, cfg, batch[0], inference=False, ground_truth=[batch[i] for i in range(1, 7)], teacher_forcing_ratio=meta["tf"],
+                                 training=True, rng=Counting(), dropout=False)
+    assert counter["n"] == meta["draws"]
+    assert np.array_equal((outs[2].abs().sum(-1) > 0).sum(-1).numpy(), data["up_rows"]) and np.array_equal((outs[3].abs().sum(-1) > 0).sum(-1).numpy(), data["lo_rows"])
+    assert np.array_equal(outs[2].argmax(-1).numpy(), data["up_ids"]) and np.array_equal(outs[3].argmax(-1).numpy(), data["lo_ids"])
+    losses = recipe_ref.objectives(outs, (batch[1], batch[2], batch[3], batch[5]))
+    for i, (l, r) in enumerate(zip(losses, data["losses"])):
+        assert abs(float(l) - r) <= 1e-5 * abs(r), f"loss term {i}: {float(l)} vs {r}"

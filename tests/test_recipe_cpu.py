@@ -126,3 +126,93 @@ def test_pretrain_then_finetune_plumbing(tmp_path):
     assert fbrain.teacher_forcing_ratio == 0.0 and "teacher_forcing_ratio" not in fbrain.train_stats
     metas = [yaml.safe_load(open(os.path.join(fout, "save", d, "CKPT.yaml"))) for d in os.listdir(os.path.join(fout, "save"))]
     assert len(metas) == 1 and metas[0]["WER"] < 100                                           # the seeded WER=100 checkpoint was replaced
+
+
+def test_speechbrain_format_checkpoint_directory_recovers(tmp_path):
+    """A save/ directory as SpeechBrain 0.5.15 writes it for the reference recipe (pretrain.yaml:110-116): torch-pickled state dicts
+    for modules / scheduler, but the EPOCH COUNTER as a plain-text integer (its own saver hook), CKPT.yaml with `end-of-epoch`."""
+    d = tmp_path / "save" / "CKPT+2024-10-08+12-00-00+00"
+    d.mkdir(parents=True)
+    lin = torch.nn.ModuleList([torch.nn.Linear(2, 2)])
+    torch.save({"0.weight": torch.full((2, 2), 3.0), "0.bias": torch.zeros(2)}, d / "model.ckpt")
+    torch.save({"hyperparam_value": 0.64, "metric_values": [0.9, 0.8], "current_patient": 0}, d / "scheduler.ckpt")
+    (d / "counter.ckpt").write_text("7")
+    (d / "CKPT.yaml").write_text("WER: 0.8\nend-of-epoch: true\nloss: 1.5\nunixtime: 1728388800.0\n")
+    counter, sched = sb_compat.EpochCounter(30), sb_compat.NewBobScheduler(1.0, annealing_factor=0.8)
+    ck = sb_compat.Checkpointer(str(tmp_path / "save"), {"model": lin, "scheduler": sched, "counter": counter})
+    path, meta = ck.recover_if_possible()
+    assert meta["WER"] == 0.8 and counter.current == 7 and sched.hyperparam_value == 0.64 and float(lin[0].weight[0, 0]) == 3.0
+    assert next(counter) == 8                                          # training resumes with epoch 8
+    # and what is written here is readable by SpeechBrain: text counter, pickled dicts
+    ck.save_checkpoint(meta={"WER": 0.5, "unixtime": 1728388900.0}, name="CKPT+x")
+    assert (tmp_path / "save" / "CKPT+x" / "counter.ckpt").read_text() == "8"
+    assert yaml.safe_load((tmp_path / "save" / "CKPT+x" / "CKPT.yaml").read_text())["end-of-epoch"] is True
+    assert set(torch.load(tmp_path / "save" / "CKPT+x" / "scheduler.ckpt")) == {"hyperparam_value", "metric_values", "current_patient"}
+    # a mid-epoch checkpoint re-runs the interrupted epoch (SpeechBrain: current = saved - 1)
+    (d / "CKPT.yaml").write_text("WER: 0.1\nend-of-epoch: false\nunixtime: 1728389900.0\n")
+    c2 = sb_compat.EpochCounter(30)
+    sb_compat.Checkpointer(str(tmp_path / "save"), {"counter": c2}).recover_if_possible(min_key="WER")
+    assert c2.current == 6
+    # round-1 checkpoints of this repository pickled the counter: still readable
+    torch.save({"current": 4}, d / "counter.ckpt")
+    sb_compat.Checkpointer(str(tmp_path / "save"), {"counter": c2}).recover_if_possible(min_key="WER")
+    assert c2.current == 3
+
+
+def test_fused_adadelta_state_is_torch_adadelta_state():
+    """optimizer.ckpt interchange: FusedAdadelta.state_dict() loads into torch.optim.Adadelta and the other way round (the
+    reference's Brain checkpoints `optimizer` = torch.optim.Adadelta.state_dict())."""
+    from piano_a2s_amd.spec import flat_layout
+    from piano_a2s_amd.train import FusedAdadelta
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 3))]
+    ref = torch.optim.Adadelta(params, lr=0.8, rho=0.95, eps=1e-8)
+    for _ in range(2):
+        for p in params:
+            p.grad = torch.randn_like(p)
+        ref.step()
+    offs, total = flat_layout([p.numel() for p in params])
+    layout = [(o, tuple(p.shape)) for o, p in zip(offs, params)]
+    fused = FusedAdadelta(torch.zeros(total), lr=1.0, layout=layout)
+    fused.load_state_dict(ref.state_dict())
+    assert fused.lr == 0.8 and fused.steps == 2
+    for (o, shape), p in zip(layout, params):
+        n = p.numel()
+        assert torch.equal(fused.square_avg[o:o + n].view(shape), ref.state[p]["square_avg"])
+        assert torch.equal(fused.acc_delta[o:o + n].view(shape), ref.state[p]["acc_delta"])
+    assert float(fused.square_avg.sum()) == pytest.approx(float(sum(ref.state[p]["square_avg"].sum() for p in params)))    # padding stays zero
+    fresh = torch.optim.Adadelta(params, lr=1.0)
+    fresh.load_state_dict(fused.state_dict())
+    for p in params:
+        assert torch.equal(fresh.state[p]["square_avg"], ref.state[p]["square_avg"]) and torch.equal(fresh.state[p]["acc_delta"], ref.state[p]["acc_delta"])
+    assert fresh.param_groups[0]["lr"] == 0.8
+    import io
+    buf = io.BytesIO()
+    torch.save(fused.state_dict(), buf)                               # what Checkpointer does
+    buf.seek(0)
+    again = FusedAdadelta(torch.zeros(total), layout=layout)
+    again.load_state_dict(torch.load(buf))
+    assert torch.equal(again.square_avg, fused.square_avg) and torch.equal(again.acc_delta, fused.acc_delta)
+
+
+def test_clip_group_planner():
+    """train.plan_clip_groups: no cut for a homogeneous minibatch; the clips holding full-length bars become the second group when
+    there are a few of them; the permutation keeps the original order inside each group."""
+    import numpy as np
+    from piano_a2s_amd import spec, synthetic
+    from piano_a2s_amd.train import plan_clip_groups
+    cfg = spec.default_cfg()
+
+    def untils(tail, seed):
+        b = synthetic.make_batch(256, cfg, seed, frames=4, full_tail=tail)
+        iu, il = torch.arange(1, 399), torch.arange(1, 190)
+        return ((b[3] != 147).long() * iu).amax(-1).numpy(), ((b[5] != 147).long() * il).amax(-1).numpy()
+
+    up, lo = untils(0.0, 3)
+    order, n_main = plan_clip_groups(up, lo)
+    assert n_main == 256 and order.tolist() == list(range(256))
+    up, lo = untils(0.01, 3)
+    order, n_main = plan_clip_groups(up, lo)
+    assert 0 < 256 - n_main <= 128 and sorted(order.tolist()) == list(range(256))
+    assert order[:n_main].tolist() == sorted(order[:n_main].tolist()) and order[n_main:].tolist() == sorted(order[n_main:].tolist())
+    assert up[order[:n_main]].max() <= 121 and all(up[c].max() == 398 for c in order[n_main:])

@@ -14,6 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--full-tail", type=float, default=0.01)
     a = ap.parse_args()
     import models
     from piano_a2s_amd import engine, engine_bwd, spec, synthetic, train
@@ -23,7 +24,7 @@ def main():
     m = models.ScoreTranscription(**cfg).to(dev)
     m.train()
     step = train.TrainStep(m)
-    b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=0.0)
+    b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=a.full_tail)
     b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
     marks = []
 
@@ -50,12 +51,16 @@ def main():
     wrap(engine_bwd, "backward", "backward tail")
     wrap(train.Objective, "__call__", "loss")
     totals = {}
+    import time
+    walls = []
     for k in range(a.steps + 1):
         marks.clear()
         mark("start")
+        t0 = time.time()
         step(b, 0.7, rng=random.Random(100 + k))
         mark("optimizer")
         torch.cuda.synchronize()
+        walls.append((time.time() - t0) * 1e3)
         if k == 0:
             continue
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
@@ -64,6 +69,7 @@ def main():
     tot = sum(totals.values())
     for n, t in totals.items():
         print(f"{t / a.steps:9.1f} ms  {100 * t / tot:5.1f} %  {n}")
+    print("wall ms per step (host clock, first = warm-up):", " ".join(f"{w:.0f}" for w in walls), " groups:", step._last[2])
     print(f"{tot / a.steps:9.1f} ms  total  -> {a.batch / (tot / a.steps) * 1e3:.1f} clips/s")
 
 
