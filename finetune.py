@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-from piano_a2s_amd.recipe import ASR, sb
+from piano_a2s_amd.recipe import ASR, sb, write_run_summary
 from utilities import load, save
 
 try:
@@ -63,6 +63,7 @@ def main(argv):
     brain.fit(brain.hparams.epoch_counter, train_set, valid_set,
               train_loader_kwargs=hparams["train_dataloader_opts"], valid_loader_kwargs=hparams["valid_dataloader_opts"])
     brain.evaluate(test_set, test_loader_kwargs=hparams["test_dataloader_opts"], min_key="WER")
+    write_run_summary(brain, hparams)
     return brain
 
 

@@ -192,3 +192,18 @@ class ASR(sb.Brain):
         composer = load(info_path).get("composer") if os.path.exists(info_path) else None
         return {"style": "classical" if chunk[:1].islower() else "pop", "soundfont": soundfont, "composer": composer,
                 "target_path": os.path.join(ff, split, version, "target", f"{chunk}.pkl")}
+
+
+def write_run_summary(brain, hparams):
+    """<output_folder>/run_summary.json (rank 0): how the run executed -- which training step, how many ranks over which backend, how many
+    optimizer steps and gradient all-reduces.  Not part of the reference's artefacts; it is what lets a launch under torchrun be
+    checked end to end (tests/test_gpu_recipe.py)."""
+    import torch.distributed as dist
+    if not sb.utils.distributed.if_main_process():
+        return
+    fused = getattr(brain, "_fused", None)
+    inited = dist.is_available() and dist.is_initialized()
+    save({"fused_hip_step": bool(fused), "world_size": dist.get_world_size() if inited else 1, "backend": dist.get_backend() if inited else None,
+          "optimizer_steps": int(getattr(brain, "step", 0)), "gradient_allreduces": int(fused.collectives) if fused else 0,
+          "nonfinite_steps": int(getattr(brain, "nonfinite_count", 0)), "device": str(brain.device)},
+         os.path.join(hparams["output_folder"], "run_summary.json"))

@@ -75,7 +75,7 @@ def parse_arguments(arg_list):
 def ddp_init_group(run_opts):
     """One process per GPU: initialise the process group whenever the torchrun environment is present (the README launches
     with torchrun but without --distributed_launch)."""
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and not dist.is_initialized():      # torchrun's environment, any world size
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = run_opts.get("distributed_backend", "nccl")
         if not str(run_opts.get("device", "cpu")).startswith("cuda"):
@@ -385,7 +385,7 @@ class Brain:
         if isinstance(dataset, torch.utils.data.DataLoader):
             return dataset
         sampler = None
-        if stage == Stage.TRAIN and self.world > 1:
+        if stage == Stage.TRAIN and dist.is_available() and dist.is_initialized():
             sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=loader_kwargs.pop("shuffle", False))
             loader_kwargs["shuffle"] = False
         if str(self.device).startswith("cuda"):

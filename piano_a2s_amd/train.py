@@ -20,13 +20,12 @@ from .spec import PAD, VOCAB_SIZE
 
 
 import os as _os
-_FORCE_COLLECTIVES = _os.environ.get("A2S_FORCE_DIST") == "1"      # debug: run the collectives even with a single rank
 
 
 def average_gradients(flat_g, world):
     """Data-parallel gradient exchange: SUM all-reduce of the flat gradient buffer, then / world (DDP semantics: every rank
     contributes the gradient of ITS minibatch mean).  Backend-agnostic: RCCL (nccl) on GPUs, gloo in the CPU tests."""
-    if world > 1 or (dist.is_available() and dist.is_initialized() and world == 1 and _FORCE_COLLECTIVES):
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
         if world > 1:
             flat_g.div_(world)
@@ -41,12 +40,16 @@ class GradientExchange:
 
     def __init__(self, world):
         self.world = world
-        self.active = world > 1 or (dist.is_available() and dist.is_initialized() and world == 1 and _FORCE_COLLECTIVES)
+        # active whenever a process group exists -- also with a single rank (torchrun --nproc-per-node 1): the collectives then run
+        # through RCCL exactly as with N ranks, which is what lets a 1-GPU box exercise the data-parallel path end to end
+        self.active = dist.is_available() and dist.is_initialized()
         self.pending = []
+        self.issued = 0
 
     def slice_ready(self, flat_g, start, end):
         if self.active and end > start:
             self.pending.append(dist.all_reduce(flat_g[start:end], op=dist.ReduceOp.SUM, async_op=True))
+            self.issued += 1
 
     def finish(self, flat_g):
         for work in self.pending:
@@ -59,7 +62,7 @@ class GradientExchange:
 
 def broadcast_parameters(flat_p, src=0):
     """Make every replica start from rank `src`'s parameters (what DDP's constructor does)."""
-    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES):
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(flat_p, src=src)
     return flat_p
 
@@ -232,6 +235,10 @@ class TrainStep:
         self.total = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
         self.dropout = dropout
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.collectives = 0               # gradient all-reduces issued so far (0 without a process group)
+        self.decode_steps = 0              # note-decoder steps the last call executed (the straggler term of data parallelism)
+        self.time_exchange = False         # bench: measure how long the step's stream waits for the gradient all-reduce
+        self.exchange_wait_ms = []
 
     def state(self):
         S = dict(self.model.named_parameters())
@@ -272,7 +279,16 @@ class TrainStep:
             losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
         exchange = GradientExchange(self.world)
         G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready)
-        flat_g = exchange.finish(G[None])
+        self.decode_steps = sum(seg["staff"][k][2]["steps"] for g in eng.saved["groups"] for seg in g["segments"] for k in ("up", "lo"))
+        if self.time_exchange and exchange.active:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            flat_g = exchange.finish(G[None])
+            e1.record()
+            self._exchange_events = getattr(self, "_exchange_events", []) + [(e0, e1)]
+        else:
+            flat_g = exchange.finish(G[None])
+        self.collectives += exchange.issued
         torch.sum(losses[:, 0], dim=0, keepdim=True, out=self.total)          # total loss stays on the device
         gate = self.total
         if exchange.active:

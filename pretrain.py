@@ -6,7 +6,7 @@ Same command line, yaml keys and recipe hooks as the reference's pretrain.py (:2
 piano_a2s_amd/recipe.py.  ``--synthetic_clips=N`` trains on N seeded synthetic clips instead of a rendered corpus."""
 import sys
 
-from piano_a2s_amd.recipe import ASR, sb
+from piano_a2s_amd.recipe import ASR, sb, write_run_summary
 
 try:
     from hyperpyyaml import load_hyperpyyaml
@@ -45,6 +45,7 @@ def main(argv):
     brain.fit(brain.hparams.epoch_counter, train_set, valid_set,
               train_loader_kwargs=hparams["train_dataloader_opts"], valid_loader_kwargs=hparams["valid_dataloader_opts"])
     brain.evaluate(test_set, test_loader_kwargs=hparams["test_dataloader_opts"], min_key="WER")
+    write_run_summary(brain, hparams)
     return brain
 
 
