@@ -157,8 +157,11 @@ typedef struct a2s_note_dec_args {
     int n_clips;                      /* 0 = R (one group) */
     int R, T, H, E, V, steps, poll, eos_id;
     int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
+    float* step_ws; size_t step_ws_floats;   /* a2s_note_step_workspace_floats(H, E) floats or NULL: scratch of the fused few-row step kernels
+                                                (csrc/a2s_step.hip: 4 launches per step instead of 9-13; used when R <= A2S_DEC_FUSED_MAX_ROWS) */
 } a2s_note_dec_args;
 int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done);
+size_t a2s_note_step_workspace_floats(int H, int E);
 
 /* ---- packed staff-embedding bi-GRU final states (get_staff_token_from_{gt,probs}, models.py:164-189).
  * gru_w: 8 device pointers {w_ih,w_hh,b_ih,b_hh} forward then reverse. */
@@ -213,6 +216,7 @@ typedef struct a2s_note_dec_bwd_args {
     const int* n_active;                 /* HOST */
     int n_clips;
     int R, T, H, E, steps;
+    float* step_ws; size_t step_ws_floats;   /* as in the forward call (holds the transposed weight copies of the fused backward step) */
 } a2s_note_dec_bwd_args;
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);
 
@@ -256,6 +260,10 @@ int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const flo
  * dlogp (zero-filled by the caller, or NULL) receives d(gscale*loss)/dlogp.  partial: 2*nblocks doubles. */
 int a2s_nll_loss(void* stream, const float* logp, const long long* target, long rows, int V, long long ignore_index,
                  float* loss_out, float* dlogp, float gscale, double* partial, int nblocks);
+/* the gradient alone for `rows` rows, with loss_out[1] = 1/count given by the caller (the count of targets != ignore_index over the WHOLE
+ * minibatch is known from the targets): dlogp (zero-filled) receives d(gscale*loss)/dlogp of these rows. */
+int a2s_nll_grad(void* stream, float* dlogp, const long long* target, const float* loss_out, float gscale, long rows, int V,
+                 long long ignore_index);
 /* clip_grad_norm_(max_norm) + Adadelta over one flat buffer; skipped when *loss (NULL: not looked at) or the gradient norm is not finite.
  * ctl[0..2] = {total norm, clip coefficient, applied flag}; partial: nblocks doubles; zero_grad clears the gradients. */
 int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_avg, float* acc_delta, long n, const float* loss,

@@ -41,6 +41,13 @@ int a2s_staff_emb_fwd_impl(hipStream_t, const float*, const float* const*, const
 int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch);
 void a2s_gemm_debug_tile_impl(int);
 void a2s_gru_step_fused_set(int);
+int a2s_nll_grad_impl(hipStream_t st, float* dlogp, const long long* target, const float* loss_out, float gscale, long rows, int V, long long ignore_index);
+void a2s_dec_fused_set(int v);
+void a2s_dec_fused_max_rows_set(int v);
+int a2s_dec_fused_enabled(void);
+int a2s_dec_fused_max_rows(void);
+size_t a2s_note_step_workspace_floats_impl(int H, int E);
+
 bool a2s_gru_step_fused_enabled(void);
 int a2s_note_decoder_fwd_impl(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
 
@@ -109,8 +116,11 @@ int a2s_gemm_bnstats_blocks(int M, int period) { return a2s_cdiv(M, 128) * a2s_g
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk) { return a2s_gemm_workspace_bytes_impl(M, N, batch, splitk); }
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch) { return a2s_gemm_pick_splitk_impl(M, N, K, batch); }
 void a2s_gemm_debug_tile(int cfg) { a2s_gemm_debug_tile_impl(cfg); }
+size_t a2s_note_step_workspace_floats(int H, int E) { return a2s_note_step_workspace_floats_impl(H, E); }
 int a2s_debug_set(const char* key, int value) {
     if (!key) return A2S_ERR_ARG;
+    if (!strcmp(key, "dec_fused")) { a2s_dec_fused_set(value); return A2S_OK; }
+    if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
@@ -125,6 +135,8 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();
     if (key && !strcmp(key, "wgrad_bf16x3")) return a2s_wgrad_split_enabled();
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
+    if (key && !strcmp(key, "dec_fused")) return a2s_dec_fused_enabled();
+    if (key && !strcmp(key, "dec_fused_max_rows")) return a2s_dec_fused_max_rows();
     return -1;
 }
 
@@ -270,6 +282,9 @@ int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const flo
 }
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) { return a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout); }
 
+int a2s_nll_grad(void* stream, float* dlogp, const long long* target, const float* loss_out, float gscale, long rows, int V, long long ignore_index) {
+    return a2s_nll_grad_impl(ST, dlogp, target, loss_out, gscale, rows, V, ignore_index);
+}
 int a2s_nll_loss(void* stream, const float* logp, const long long* target, long rows, int V, long long ignore_index, float* loss_out,
                  float* dlogp, float gscale, double* partial, int nblocks) {
     return a2s_nll_loss_impl(ST, logp, target, rows, V, ignore_index, loss_out, dlogp, gscale, partial, nblocks);

@@ -56,6 +56,16 @@ int a2s_nll_loss_impl(hipStream_t st, const float* logp, const long long* target
     return A2S_OK;
 }
 
+// gradient only, 1/count supplied by the caller (loss_out[1]): lets a part of the rows back-propagate before the rest of the minibatch
+// has even been decoded -- the denominator of the mean is a function of the targets alone
+int a2s_nll_grad_impl(hipStream_t st, float* dlogp, const long long* target, const float* loss_out, float gscale, long rows, int V, long long ignore_index) {
+    A2S_REQUIRE(dlogp && target && loss_out, "nll_grad: null tensor");
+    if (rows <= 0) return A2S_OK;
+    hipLaunchKernelGGL(nll_grad, dim3(a2s_cdiv(rows, 256)), dim3(256), 0, st, dlogp, target, loss_out, gscale, rows, V, ignore_index);
+    A2S_CHECK_LAUNCH("nll_grad");
+    return A2S_OK;
+}
+
 // ------------------------------------------------------------------------------------------- clip + Adadelta
 __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g, long n, double* __restrict__ partial) {
     __shared__ double rs[256];

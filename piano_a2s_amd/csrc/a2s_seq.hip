@@ -493,10 +493,35 @@ int a2s_embed_rows_impl(hipStream_t st, const float* table, const long long* ids
 // no-op once n_done == R, and the host polls n_done every `poll` steps to stop launching.
 typedef a2s_note_dec_args NoteDecArgs;   // one definition only: the public C struct (include/a2s.h)
 
+bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats);
+int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last);
+static bool note_step_fusable(const NoteDecArgs& a) {
+    const void* ptrs[] = {a.x, a.h, a.o, a.q, a.w_ih, a.w_hh, a.out_w, a.attn_w};
+    return a2s_dec_step_fusable(a.R, a.H, a.E, a.V, ptrs, 8, a.step_ws, a.step_ws_floats);
+}
+// q of slot `sv` from the state in slot `si` (the fused path computes every later query in the previous step's last launch)
+static int enqueue_query(hipStream_t st, const NoteDecArgs& a, int si, int sv) {
+    const int H2 = 2 * a.H;
+    return a2s_gemm_impl(st, a.R, a.H, H2, 1.f, a.h + (long)si * a.R * H2, H2, 1, a.attn_w, 1, 2 * H2, 0.f, a.q + (long)sv * a.R * a.H, a.H, a.attn_b, 0, 1, 0,
+                         0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+}
+
 // one decode step: state read from slot `si`, written to slot `so` (slot = step index, or step parity in graph mode);
-// per-step saved tensors (q, o, gates, attention weights) go to index `sv`
-static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int so, int sv, int t, const int* t_base, int tf) {
+// per-step saved tensors (q, o, gates, attention weights) go to index `sv`.  fused: the few-row path of a2s_step.hip -- the query
+// of slot sv must already be there (enqueue_query / the previous step), this step leaves the next one's in slot sv_next (!last).
+static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int so, int sv, int t, const int* t_base, int tf,
+                             bool fused = false, int sv_next = 0, bool last = false) {
     const int H2 = 2 * a.H, ldx = a.E + H2;
+    if (fused) {
+        float* xs = a.x + (long)si * a.R * ldx;
+        float* os = a.o + (long)sv * a.R * 2 * H2;
+        a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : a.R, a.n_active ? a.n_active[t] : 0, t};
+        int rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, a.q + (long)sv * a.R * a.H, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
+                                        a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws,
+                                        a.n_active ? &rows_v : nullptr);
+        if (rc) return rc;
+        return a2s_note_step_fused_fwd(st, a, si, so, sv, sv_next, t, t_base, tf, last);
+    }
     const float* hp = a.h + (long)si * a.R * H2;
     float* hq = a.h + (long)so * a.R * H2;
     float* xs = a.x + (long)si * a.R * ldx;
@@ -551,10 +576,12 @@ static int note_decoder_greedy_graph(hipStream_t st, const NoteDecArgs& a, int* 
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "greedy graph memset: %s", hipGetErrorString(e));
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    const bool fused = note_step_fusable(a);
+    int rc = fused ? enqueue_query(st, a, 0, 0) : A2S_OK;     // the very first query; every later one is left behind by the previous step
+    if (rc) return rc;
     e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
-    int rc = A2S_OK;
-    for (int j = 0; j < chunk && rc == A2S_OK; ++j) rc = enqueue_note_step(st, a, j & 1, (j + 1) & 1, 0, j, a.t_base, 0);
+    for (int j = 0; j < chunk && rc == A2S_OK; ++j) rc = enqueue_note_step(st, a, j & 1, (j + 1) & 1, 0, j, a.t_base, 0, fused, 0, false);
     if (rc == A2S_OK) hipLaunchKernelGGL(advance_counter, dim3(1), dim3(64), 0, st, a.t_base, chunk);
     e = hipStreamEndCapture(st, &graph);
     if (rc != A2S_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -582,8 +609,10 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
     // stream capture is not allowed on the legacy default stream: callers that want the graph path run on a created stream
     if (!a.gt && a.use_graph && a.t_base && !a.gates && !a.attw && !a.drop && st != nullptr) return note_decoder_greedy_graph(st, a, steps_done);
     int s = 0;
+    const bool fused = note_step_fusable(a);
+    if (fused && a.steps > 0) { int rc = enqueue_query(st, a, 0, 0); if (rc) return rc; }
     for (; s < a.steps; ++s) {
-        int rc = enqueue_note_step(st, a, s, s + 1, s, s, nullptr, a.tf_flags ? a.tf_flags[s] : 0);
+        int rc = enqueue_note_step(st, a, s, s + 1, s, s, nullptr, a.tf_flags ? a.tf_flags[s] : 0, fused, s + 1, s + 1 == a.steps);
         if (rc) return rc;
         if (!a.gt && a.poll > 0 && ((s + 1) % a.poll == 0) && s + 1 < a.steps) {
             int done = 0;   // greedy only: one small D2H + sync per `poll` steps

@@ -1,0 +1,469 @@
+// Fused per-step kernels of the note decoder for FEW rows (reference NoteDecoder.decode_notes step, models.py:388-419, and its reverse).
+//
+// A decode step is a chain of dependent products on a handful of rows: as library-style launches (4 GEMMs + their split-K reduces +
+// gates + epilogue) it is 9-13 kernels of ~10 us each whatever the row count -- which is what bounds (i) the long-clip group of the
+// fused training step (engine.Engine.forward, clip groups: ~400 dependent steps per segment on 20-40 rows), (ii) small-batch greedy
+// decoding.  Here a step is FOUR launches forward (attention split, attention combine, `dec_gru_step`, `dec_out_step`) and FIVE
+// backward (gate backward, `dec_bwd_products`, attention split, attention combine, `dec_bwd_query`):
+//
+//   dec_gru_step   gi = x W_ih^T and gh = h W_hh^T for a 16-row x 16-unit tile (x 3 gates) on the fp32 matrix cores, gate math on
+//                  the accumulators -> h' (state slot, [h' | ctx] output row, saved gates).  Replaces 2 GEMMs + 2 reduces + gates.
+//   dec_out_step   logits = [h' | ctx] W_out^T + b for 16 rows x all 173 symbols in ONE workgroup, log-softmax, argmax (lowest index on
+//                  ties, torch's CPU rule), teacher-forced / fed-back token choice, its embedding (+ dropout) into the next input row,
+//                  <eos> bookkeeping -- and, in other workgroups of the same launch, the NEXT step's attention query
+//                  q = h' W_h^T + b.  Replaces 2 GEMMs + 2 reduces + the epilogue kernel.
+//   dec_bwd_products   dx = dgi W_ih and dh_prev += dgh W_hh (both on transposed weight copies made once per call).
+//   dec_bwd_query      dh_prev += dq W_h after the attention backward.
+//
+// All operands are K-contiguous rows fetched straight from L2 with 16-byte loads (no LDS staging, as gru_step_fwd_fused); the 8 waves
+// of a workgroup take the 16-wide k-steps round robin and their partial tiles meet in a fixed-order tree through LDS (deterministic).
+// Used when the call has at most A2S_DEC_FUSED_MAX_ROWS rows (default 192): with many rows every workgroup re-reads the weights from
+// L2 and the tiled GEMMs win again (they only run under the other staff's attention there anyway).
+#include "a2s_common.h"
+#include "../../include/a2s.h"
+
+int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
+                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes);
+int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                           float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H, const int* n_done, int n_rows,
+                           float* ws, const a2s_attn_rows* rows);
+int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                           const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
+                           float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws, const a2s_attn_rows* rows);
+int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const float* dh_b, long ldb, const float* save,
+                           const float* hprev, long ldhp, float* dgi, long ldgi, float* dgh, long ldgh, float* dgh2, long ldgh2,
+                           float* dhprev, long lddp, int R, int H);
+
+#define NW 8                      // waves per workgroup
+
+// acc[g] += A-row-fragments x B-row-fragments over this wave's share of the k-steps (k-step u covers k in [16u, 16u+16); this lane
+// reads 4 floats at 16u + 4*lk of its A row and of its NT B rows)
+template <int NT, int CH>
+__device__ __forceinline__ void mfma_rows8(const float* __restrict__ arow, const float* const (&brow)[NT], int ksteps, int wave, int lk,
+                                           f32x4 (&acc)[NT]) {
+    for (int u0 = wave; u0 < ksteps; u0 += NW * CH) {
+        f32x4 a[CH], b[NT][CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int u = u0 + NW * c;
+            const bool ok = u < ksteps;
+            a[c] = ok ? *reinterpret_cast<const f32x4*>(arow + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NT; ++g)
+                b[g][c] = ok ? *reinterpret_cast<const f32x4*>(brow[g] + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (u0 + NW * c >= ksteps) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < NT; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[g][c][j], acc[g], 0, 0, 0);
+        }
+    }
+}
+
+// Sum of the 8 waves' partial tiles in wave 0, fixed order: (w, w+4) -> (w, w+2) -> (0, 1).  part: 4 * NT * 64 f32x4 of LDS.
+template <int NT>
+__device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NT], f32x4* part, int wave, int lane) {
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int g = 0; g < NT; ++g) part[((wave - half) * NT + g) * 64 + lane] = acc[g];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int g = 0; g < NT; ++g) {
+                const f32x4 o = part[(wave * NT + g) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][r] += o[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------- forward: GRU cell
+struct DecGruArgs {
+    const float* x; long ldx; int kx;                   // (R, ldx) rows [token | ctx]; kx = E + 2H
+    const float* h;                                     // (R, H2) previous state
+    const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
+    float* hout; float* o; long ldo; float* save;       // h' -> hout (R, H2) and o[:, :H2]; save (R, 4 H2) [r|z|n|gh_n] or null
+    const int* n_done; int* skip;                       // greedy: the step is a no-op once *n_done >= R; *skip tells the step's later kernels
+    int R, H2;
+};
+
+__global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
+    __shared__ f32x4 part[4 * 4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.n_done) {
+        const bool done = *a.n_done >= a.R;               // nobody writes n_done while this kernel runs (the epilogue of the previous step is over)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.skip = done ? 1 : 0;
+        if (done) return;
+    }
+    const int H2 = a.H2, R = a.R;
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int j = j0 + li;
+    float hp[4], br = 0.f, bz = 0.f, bin = 0.f, bhn = 0.f;
+    if (wave == 0) {                                      // epilogue operands: in flight while the products run
+        br = a.b_ih[j] + a.b_hh[j]; bz = a.b_ih[H2 + j] + a.b_hh[H2 + j]; bin = a.b_ih[2 * H2 + j]; bhn = a.b_hh[2 * H2 + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hp[r] = a.h[(long)min(row0 + lk * 4 + r, R - 1) * H2 + j];
+    }
+    const int arow_i = min(row0 + li, R - 1);
+    const float* bi[3];
+    const float* bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { bi[g] = a.w_ih + ((long)g * H2 + j0 + li) * a.kx; bh[g] = a.w_hh + ((long)g * H2 + j0 + li) * H2; }
+    f32x4 t[3], u[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) t[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows8<3, 4>(a.x + (long)arow_i * a.ldx, bi, a.kx / 16, wave, lk, t);          // gi: r, z, n
+    u[0] = t[0]; u[1] = t[1]; u[2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows8<3, 4>(a.h + (long)arow_i * H2, bh, H2 / 16, wave, lk, u);               // + gh on r, z; gh_n apart
+    f32x4 acc[4] = {u[0], u[1], t[2], u[2]};
+    reduce_waves<4>(acc, part, wave, lane);
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + lk * 4 + r;
+        if (row >= R) continue;
+        const float ghn = acc[3][r] + bhn;
+        const float rg = fast_sigmoid(acc[0][r] + br);
+        const float zg = fast_sigmoid(acc[1][r] + bz);
+        const float ng = fast_tanh(acc[2][r] + bin + rg * ghn);
+        const float hn = (1.f - zg) * ng + zg * hp[r];
+        a.hout[(long)row * H2 + j] = hn;
+        a.o[(long)row * a.ldo + j] = hn;
+        if (a.save) {
+            float* sv = a.save + (long)row * 4 * H2;
+            sv[j] = rg; sv[H2 + j] = zg; sv[2 * H2 + j] = ng; sv[3 * H2 + j] = ghn;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- forward: output projection + epilogue + next query
+// One launch, three kinds of workgroups (blockIdx.y), all 16 rows x 32 columns x full K on 8 waves:
+//   [0, NVW)        logits tile = [h' | ctx] W_out^T + b  -> a.logits; the workgroup that finishes LAST for its 16 rows (ticket counter
+//                   per row block, release/acquire through L2) runs the step epilogue for them: log-softmax, argmax, token choice,
+//                   embedding, <eos> bookkeeping -- one wave per row, as note_step_finalize;
+//   [NVW, NVW+NQW)  the NEXT step's attention query  q = h' W_h^T + b.
+// (A single workgroup per 16 rows doing all 173 columns took 40 us at 1-4 workgroups per launch: one CU pulling the 708 KB of W_out
+// alone; spread over 6 + 8 workgroups per row block the launch takes ~10.)
+#define NTV 11                    // 16-column tiles of the vocabulary: 161..176 symbols (LabelsMultiple(extended=True): 173)
+#define NVW 6                     // vocabulary workgroups per row block (2 tiles each; the last one has one)
+struct DecOutArgs {
+    const float* o; long ldo; int ko;                   // (R, 2 H2) rows [h' | ctx]; ko = 2 H2
+    const float* out_w; const float* out_b;             // (V, ko), (V)
+    float* logits; long ldl;                            // (R, ldl) scratch, ldl >= 16 * NTV
+    int* tickets;                                       // one counter per row block, zero between launches
+    float* probs; long probs_bstride;                   // log-probabilities: row b, step t at probs + b*probs_bstride + t*V
+    const long long* gt; long gt_bstride;
+    const float* emb; float* xnext; long ldx;           // token embedding of the next step -> xnext[:, :E]
+    const uint8_t* drop; float inv_keep;
+    int* argmax_out; long am_bstride;
+    int* eos_seen; long long* lengths; int* n_done; int* steps_exec;
+    const int* t_base; const int* row_until; const int* skip;
+    // next step's attention query
+    const float* hnew; const float* attn_w; long ld_aw; const float* attn_b; float* q_next; int H;
+    int n_clips, R, V, E, t, teacher_force, eos_id, max_t, H2;
+};
+
+// the step epilogue for one row, executed by one wave (reference models.py:401-419); lg: the row's logits, read past the L1 (they
+// were written by other workgroups of this launch)
+__device__ __forceinline__ void dec_row_epilogue(const DecOutArgs& a, int row, int t, int lane) {
+    const volatile float* lg = a.logits + (long)row * a.ldl;
+    const bool finished = a.row_until && t >= a.row_until[row];    // its bar's loop has ended in the reference or only <pad> targets remain
+    float v[3];
+    float m = -INFINITY; int mi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int j = lane + 64 * k;
+        v[k] = j < a.V ? lg[j] : -INFINITY;
+        if (v[k] > m) { m = v[k]; mi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    if (!finished) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (lane + 64 * k < a.V) s += expf(v[k] - m);
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        float* pr = a.probs + (long)row * a.probs_bstride + (long)t * a.V;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (lane + 64 * k < a.V) pr[lane + 64 * k] = v[k] - lse;
+    }
+    const long long gtok = a.gt ? a.gt[(long)row * a.gt_bstride + t] : -1;
+    const int tf = (a.teacher_force >> (a.n_clips > 0 ? row / a.n_clips : 0)) & 1;
+    const int next_id = (a.gt && tf) ? (int)gtok : mi;
+    for (int j = lane; j < a.E; j += 64) {
+        float e = a.emb[(long)next_id * a.E + j];
+        if (a.drop) e = a.drop[(long)row * a.E + j] ? e * a.inv_keep : 0.f;
+        a.xnext[(long)row * a.ldx + j] = e;
+    }
+    if (lane == 0 && !finished) {
+        if (row == 0 && a.steps_exec) *a.steps_exec = t + 1;      // steps run in order on one stream
+        if (a.argmax_out) a.argmax_out[(long)row * a.am_bstride + t] = mi;
+        const bool hit = a.gt ? (gtok == a.eos_id) : (mi == a.eos_id);
+        if (hit) {
+            if (!a.eos_seen[row]) { a.eos_seen[row] = 1; atomicAdd(a.n_done, 1); }
+            a.lengths[row] = t + 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
+    __shared__ f32x4 part[4 * 2 * 64];
+    __shared__ int last_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.skip && *a.skip) return;
+    const int t = a.t + (a.t_base ? *a.t_base : 0);
+    if (t >= a.max_t) return;                                   // a replayed chunk may overshoot the step budget
+    const int R = a.R, row0 = blockIdx.x * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool vocab = (int)blockIdx.y < NVW;
+    if (!vocab && !a.q_next) return;
+    const int n0 = (vocab ? blockIdx.y : blockIdx.y - NVW) * 32;
+    const int ncols = vocab ? a.V : a.H;
+    const float* Bm = vocab ? a.out_w : a.attn_w;
+    const long ldb = vocab ? (long)a.ko : a.ld_aw;
+    const int K = vocab ? a.ko : a.H2;
+    const float* brow[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) brow[g] = Bm + (long)min(n0 + g * 16 + li, ncols - 1) * ldb;
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const float* arow = (vocab ? a.o + (long)min(row0 + li, R - 1) * a.ldo : a.hnew + (long)min(row0 + li, R - 1) * a.H2);
+    mfma_rows8<2, 4>(arow, brow, K / 16, wave, lk, acc);
+    reduce_waves<2>(acc, part, wave, lane);
+    if (wave == 0) {
+        const float* bias = vocab ? a.out_b : a.attn_b;
+        float* out = vocab ? a.logits : a.q_next;
+        const long ldo = vocab ? a.ldl : (long)a.H;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int col = n0 + g * 16 + li;
+            if (col >= ncols) continue;
+            const float b = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + lk * 4 + r;
+                if (row < R) out[(long)row * ldo + col] = acc[g][r] + b;
+            }
+        }
+    }
+    if (!vocab) return;
+    // ---- last vocabulary workgroup of this row block: the epilogue
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();                                           // this workgroup's logits tile is visible device-wide before its ticket
+        const int ticket = atomicAdd(a.tickets + blockIdx.x, 1);
+        last_flag = (ticket == NVW - 1);
+        if (last_flag) a.tickets[blockIdx.x] = 0;                  // ready for the next launch
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    for (int rr = wave; rr < 16; rr += NW) {
+        const int row = row0 + rr;
+        if (row < R) dec_row_epilogue(a, row, t, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward products
+// role A (blockIdx.x < nxa): dx[:, n] = dgi . W_ih[:, n]   for 32 columns n of the kx input columns  (B rows = W_ih^T rows)
+// role B (the rest):         dh[:, n] += dgh . W_hh[:, n]  for 32 of the H2 state columns          (B rows = W_hh^T rows)
+struct DecBwdProdArgs {
+    const float* dgi; const float* dgh;                 // (R, 3 H2) each
+    const float* wih_t; const float* whh_t;             // (kx, 3 H2), (H2, 3 H2)
+    float* dx; long ldx; float* dh;                     // (R, ldx) overwritten; (R, H2) accumulated
+    int nxa, kx, R, H2;
+};
+
+__global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
+    __shared__ f32x4 part[4 * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = a.R, K = 3 * a.H2, row0 = blockIdx.y * 16;
+    const bool role_a = (int)blockIdx.x < a.nxa;
+    const int n0 = (role_a ? blockIdx.x : blockIdx.x - a.nxa) * 32;
+    const int ncols = role_a ? a.kx : a.H2;
+    const float* A = role_a ? a.dgi : a.dgh;
+    const float* Bt = role_a ? a.wih_t : a.whh_t;
+    const float* brow[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) brow[g] = Bt + (long)min(n0 + g * 16 + li, ncols - 1) * K;
+    float c0[2][4];
+    if (wave == 0 && !role_a) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)min(row0 + lk * 4 + r, R - 1) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    mfma_rows8<2, 4>(A + (long)min(row0 + li, R - 1) * K, brow, K / 16, wave, lk, acc);
+    reduce_waves<2>(acc, part, wave, lane);
+    if (wave > 0) return;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int col = n0 + g * 16 + li;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + lk * 4 + r;
+            if (row >= R) continue;
+            if (role_a) a.dx[(long)row * a.ldx + col] = acc[g][r];
+            else a.dh[(long)row * a.H2 + col] = c0[g][r] + acc[g][r];
+        }
+    }
+}
+
+// dh[:, n] += dq . W_h[:, n]  (B rows = W_h^T rows, (H2, H)); 32 columns per workgroup
+__global__ __launch_bounds__(64 * NW) void dec_bwd_query(const float* __restrict__ dq, const float* __restrict__ wh_t, float* __restrict__ dh,
+                                                         int R, int H, int H2) {
+    __shared__ f32x4 part[4 * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int row0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
+    const float* brow[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) brow[g] = wh_t + (long)min(n0 + g * 16 + li, H2 - 1) * H;
+    float c0[2][4];
+    if (wave == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c0[g][r] = dh[(long)min(row0 + lk * 4 + r, R - 1) * H2 + min(n0 + g * 16 + li, H2 - 1)];
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    mfma_rows8<2, 2>(dq + (long)min(row0 + li, R - 1) * H, brow, H / 16, wave, lk, acc);
+    reduce_waves<2>(acc, part, wave, lane);
+    if (wave > 0) return;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int col = n0 + g * 16 + li;
+        if (col >= H2) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + lk * 4 + r;
+            if (row < R) dh[(long)row * H2 + col] = c0[g][r] + acc[g][r];
+        }
+    }
+}
+
+// out[c][r] = in[r * ld + c] for r < rows, c < cols
+__global__ void transpose_ld(const float* __restrict__ in, long ld, float* __restrict__ out, int rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int c = (int)(i / rows), r = (int)(i % rows);
+    out[i] = in[(long)r * ld + c];
+}
+
+// ------------------------------------------------------------------------------------------- switches / eligibility
+static int g_dec_fused = -1, g_dec_fused_max_rows = -1;
+void a2s_dec_fused_set(int v) { g_dec_fused = v ? 1 : 0; }
+void a2s_dec_fused_max_rows_set(int v) { g_dec_fused_max_rows = v; }
+int a2s_dec_fused_enabled(void) {
+    if (g_dec_fused < 0) { const char* e = getenv("A2S_DEC_FUSED"); g_dec_fused = (e && e[0] == '0') ? 0 : 1; }
+    return g_dec_fused;
+}
+int a2s_dec_fused_max_rows(void) {
+    if (g_dec_fused_max_rows < 0) { const char* e = getenv("A2S_DEC_FUSED_MAX_ROWS"); g_dec_fused_max_rows = e ? atoi(e) : 192; }
+    return g_dec_fused_max_rows;
+}
+// scratch layout (floats): [16: flags | FUSED_MAX_RB: tickets | max_rows x 176: logits] then [W_ih^T | W_hh^T | W_h^T] for the backward
+#define FUSED_MAX_ROWS_CAP 1024
+#define FUSED_HEAD (16 + FUSED_MAX_ROWS_CAP / 16 + (long)FUSED_MAX_ROWS_CAP * 16 * NTV)
+size_t a2s_note_step_workspace_floats_impl(int H, int E) {
+    const long H2 = 2L * H, kx = E + H2;
+    return (size_t)(FUSED_HEAD + kx * 3 * H2 + H2 * 3 * H2 + H2 * H);
+}
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats) {
+    if (!a2s_dec_fused_enabled() || R > a2s_dec_fused_max_rows() || R > FUSED_MAX_ROWS_CAP || !ws || ws_floats < a2s_note_step_workspace_floats_impl(H, E)) return false;
+    if (H % 16 || E % 16 || (V + 15) / 16 != NTV || !aligned16(ws)) return false;
+    for (int i = 0; i < nptrs; ++i) if (!aligned16(ptrs[i])) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------- forward step (after the attention)
+int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    int* flags = reinterpret_cast<int*>(a.step_ws);
+    const bool greedy = a.gt == nullptr;
+    DecGruArgs g;
+    g.x = a.x + (long)si * R * ldx; g.ldx = ldx; g.kx = ldx;
+    g.h = a.h + (long)si * R * H2;
+    g.w_ih = a.w_ih; g.w_hh = a.w_hh; g.b_ih = a.b_ih; g.b_hh = a.b_hh;
+    g.hout = a.h + (long)so * R * H2; g.o = a.o + (long)sv * R * 2 * H2; g.ldo = 2 * H2;
+    g.save = a.gates ? a.gates + (long)sv * R * 4 * H2 : nullptr;
+    g.n_done = greedy ? a.n_done : nullptr; g.skip = flags;
+    g.R = R; g.H2 = H2;
+    hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(R, 16)), dim3(64 * NW), 0, st, g);
+    A2S_CHECK_LAUNCH("dec_gru_step");
+    DecOutArgs f;
+    f.o = g.o; f.ldo = 2 * H2; f.ko = 2 * H2; f.out_w = a.out_w; f.out_b = a.out_b;
+    f.tickets = flags + 16; f.logits = a.step_ws + 16 + FUSED_MAX_ROWS_CAP / 16; f.ldl = 16 * NTV;
+    f.probs = a.probs; f.probs_bstride = a.probs_bstride; f.gt = a.gt; f.gt_bstride = a.gt_bstride;
+    f.emb = a.emb; f.xnext = a.x + (long)so * R * ldx; f.ldx = ldx;
+    f.drop = a.drop ? a.drop + (long)so * R * a.E : nullptr; f.inv_keep = a.inv_keep;
+    f.argmax_out = a.argmax_out; f.am_bstride = a.am_bstride;
+    f.eos_seen = a.eos_seen; f.lengths = a.lengths; f.n_done = a.n_done; f.steps_exec = a.steps_exec;
+    f.t_base = t_base; f.row_until = a.n_active ? a.row_until : nullptr; f.skip = greedy ? flags : nullptr;
+    f.hnew = g.hout; f.attn_w = a.attn_w; f.ld_aw = 2 * H2; f.attn_b = a.attn_b;
+    f.q_next = last ? nullptr : a.q + (long)sv_next * R * a.H; f.H = a.H;
+    f.n_clips = a.n_clips > 0 ? a.n_clips : R; f.R = R; f.V = a.V; f.E = a.E; f.t = t; f.teacher_force = tf; f.eos_id = a.eos_id;
+    f.max_t = a.steps; f.H2 = H2;
+    hipLaunchKernelGGL(dec_out_step, dim3(a2s_cdiv(R, 16), NVW + a2s_cdiv(a.H, 32)), dim3(64 * NW), 0, st, f);
+    A2S_CHECK_LAUNCH("dec_out_step");
+    return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- backward: once per call, then per step
+int a2s_note_step_fused_bwd_prepare(hipStream_t st, const a2s_note_dec_bwd_args& a) {
+    const int H2 = 2 * a.H, kx = a.E + H2;
+    float* wih_t = a.step_ws + FUSED_HEAD;
+    float* whh_t = wih_t + (long)kx * 3 * H2;
+    float* wh_t = whh_t + (long)H2 * 3 * H2;
+    hipLaunchKernelGGL(transpose_ld, dim3(a2s_cdiv((long)3 * H2 * kx, 256)), dim3(256), 0, st, a.w_ih, (long)kx, wih_t, 3 * H2, kx);
+    hipLaunchKernelGGL(transpose_ld, dim3(a2s_cdiv((long)3 * H2 * H2, 256)), dim3(256), 0, st, a.w_hh, (long)H2, whh_t, 3 * H2, H2);
+    hipLaunchKernelGGL(transpose_ld, dim3(a2s_cdiv((long)a.H * H2, 256)), dim3(256), 0, st, a.attn_w, (long)2 * H2, wh_t, a.H, H2);
+    A2S_CHECK_LAUNCH("transpose_ld");
+    return A2S_OK;
+}
+
+int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const float* dh_in, float* dh_out, const a2s_attn_rows* rows) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    const float* dos = a.do_all + (long)s * R * 2 * H2;
+    float* dgi = a.dgi_all + (long)s * R * 3 * H2;
+    float* dgh = a.dgh_all + (long)s * R * 3 * H2;
+    float* dxs = a.dx + (long)s * R * ldx;
+    float* wih_t = a.step_ws + FUSED_HEAD;
+    float* whh_t = wih_t + (long)ldx * 3 * H2;
+    float* wh_t = whh_t + (long)H2 * 3 * H2;
+    // GRU cell: dh = carry + dh_from_out;  hprev = h[s]; dh_out = dh * z
+    int rc = a2s_gru_gates_bwd_impl(st, dh_in, H2, dos, 2 * H2, a.gates + (long)s * R * 4 * H2, a.h + (long)s * R * H2, H2,
+                                    dgi, 3 * H2, dgh, 3 * H2, nullptr, 0, dh_out, H2, R, H2);
+    if (rc) return rc;
+    DecBwdProdArgs p;
+    p.dgi = dgi; p.dgh = dgh; p.wih_t = wih_t; p.whh_t = whh_t; p.dx = dxs; p.ldx = ldx; p.dh = dh_out;
+    p.nxa = a2s_cdiv(ldx, 32); p.kx = ldx; p.R = R; p.H2 = H2;
+    hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(R, 16)), dim3(64 * NW), 0, st, p);
+    A2S_CHECK_LAUNCH("dec_bwd_products");
+    // attention: dctx = dx[:, E:] + do[:, 2H:]
+    rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
+                                a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
+                                a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
+                                a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dec_bwd_query, dim3(a2s_cdiv(H2, 32), a2s_cdiv(R, 16)), dim3(64 * NW), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, R, a.H, H2);
+    A2S_CHECK_LAUNCH("dec_bwd_query");
+    return A2S_OK;
+}

@@ -36,7 +36,7 @@ __global__ void vqt_logmag(const float* __restrict__ C, const float* __restrict_
         const float mag = sqrtf(re * re + im * im);
         float db = 20.f * log10f(fmaxf(1e-5f, mag)) - 20.f * log10f(fmaxf(1e-5f, mx));
         db = fmaxf(db, -top_db);
-        out[i] = db * (1.f / 80.f) + 1.f;
+        out[i] = (db + 80.f) / 80.f;          // exactly 0 at the floor and exactly 1 at the clip maximum (db/80 + 1 rounds to -1.5e-8 at -80 dB)
     }
 }
 

@@ -394,6 +394,8 @@ class Engine:
                         ("row_until", active and active["until"])):
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.gemm_ws_bytes = gemm_ws.numel() * 4 if gemm_ws is not None else 0
+        step_ws = hip.step_workspace(H, E, dev)
+        a.step_ws, a.step_ws_floats = step_ws.data_ptr(), step_ws.numel()
         a.n_active = C.cast(active["n_active"], C.c_void_p).value if active else None
         a.n_clips = active["n_clips"] if active else 0
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
@@ -412,7 +414,8 @@ class Engine:
         # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
         executed = n if gt_bar is not None else int(steps_exec.item())
         saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
-                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active, flags_dev=flags_dev)
+                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active, flags_dev=flags_dev,
+                     step_ws=step_ws)
         return ids, lengths, saved
 
     # ------------------------------------------------------------------ full forward
@@ -730,8 +733,14 @@ class Engine:
                 last_rows = {name: (staff[name][0][(nb - 1) * Bg:], staff[name][1][(nb - 1) * Bg:]) for name in staff}
                 token, rec["tok_rec"], rec["next_ids"] = next_token(last, teacher_force, last_rows, rec["heads"])
                 rec["teacher_force"] = teacher_force
-            return dict(range=(b0, b1), bars=bar_saved, segments=seg_saved, sos_rec=sos_rec, keys=keys_g, enc=enc_g,
-                        outs=(ts_out_g, key_out_g, up_out_g, lo_out_g), gt=(ground_truth is not None and (up_g, lo_g)) or None)
+            gs = dict(range=(b0, b1), bars=bar_saved, segments=seg_saved, sos_rec=sos_rec, keys=keys_g, enc=enc_g,
+                      outs=(ts_out_g, key_out_g, up_out_g, lo_out_g), gt=(ground_truth is not None and (up_g, lo_g)) or None)
+            hook = getattr(self, "group_hook", None)
+            if hook is not None:
+                # train.TrainStep: the group's loss gradients and decoder backward follow its forward at once, on the group's own
+                # thread and streams (the denominators of the NLL means are known from the targets, so no group waits for another)
+                hook(gidx, gs)
+            return gs
 
         if len(clip_groups) == 1:
             group_saved = [decode_group(0, 0, B, None)]

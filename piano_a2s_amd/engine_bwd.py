@@ -120,6 +120,8 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
                     ("row_until", sv.get("active") and sv["active"]["until"])):
         setattr(a, name, t.data_ptr() if t is not None else None)
     a.gemm_ws_bytes = sv["gemm_ws"].numel() * 4 if sv["gemm_ws"] is not None else 0
+    if sv.get("step_ws") is not None:
+        a.step_ws, a.step_ws_floats = sv["step_ws"].data_ptr(), sv["step_ws"].numel()
     a.n_active = C.cast(sv["active"]["n_active"], C.c_void_p).value if sv.get("active") else None
     a.n_clips = sv["active"]["n_clips"] if sv.get("active") else 0
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
@@ -169,63 +171,65 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     return dh[0], done
 
 
-def backward(eng, S, grad_outputs, grad_ready=None):
-    """Gradients of sum_i <out_i, grad_outputs_i> wrt every parameter.  Returns dict name -> tensor (views of ONE flat buffer,
-    also returned as `flat` under key None) in state_dict parameter order.
-    grad_ready(flat, start, end): optional callback, called when flat[start:end] is final (everything that writes it has been
-    enqueued on the current stream) -- first the encoder + decoder slice, then the ConvStack slice; train.GradientExchange starts
-    the data-parallel all-reduce of a slice there, under the rest of the backward pass."""
-    from .spec import is_buffer
-    sv = eng.saved
-    assert sv["training"], "backward needs a forward run with training=True (batch statistics / saved activations)"
-    L = hip.lib()
-    cfg = eng.cfg
-    H, Sz = cfg["hidden_size"], cfg["staff_emb_size"]
-    te, ke, bars = cfg["time_sig_emb_size"], cfg["key_emb_size"], cfg["max_bars"]
-    tokw = 4 * Sz + te + ke
-    B, T, F = sv["shape"]
-    H2 = 2 * H
-    enc = sv["enc_out"]
-    dev = enc.device
-    names = [k for k in S if not is_buffer(k)]
-    from .spec import flat_layout
-    offs, total = flat_layout([S[k].numel() for k in names])          # same layout as models.ScoreTranscription.flatten_()
-    flat = torch.zeros(total, dtype=torch.float32, device=dev)
-    G = {k: flat[off:off + S[k].numel()].view(S[k].shape) for k, off in zip(names, offs)}
-    # device table of the staff-embedding gradient pointers: uploaded once, before the first kernel of the backward pass
-    ptrs_host = torch.tensor([G[f"decoder.staff_emb.{w}_{sfx}"].data_ptr() for sfx in ("l0", "l0_reverse")
-                              for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")], dtype=torch.int64).pin_memory()
-    G["__staff_emb_ptrs__"] = ptrs_host.to(dev, non_blocking=True)          # pinned: no stream synchronisation (the host keeps running ahead)
-    dts, dkey, dup, dlo = [g.contiguous() for g in grad_outputs]
-    ts_out, key_out, up_out, lo_out = sv["outs"]
-    dEnc = torch.zeros((B, T, H2), dtype=torch.float32, device=dev)
-    dK = {p: torch.zeros((B, T, H), dtype=torch.float32, device=dev) for p in sv["keys"]}
-    keep_alive = [ptrs_host]
-    # the two note decoders of a bar back-propagate concurrently on two side streams (see engine.side_streams); each accumulates its
-    # encoder-output gradient in its own buffer (summed once at the end), everything else they write is per-staff already
-    from .engine import fork_on_streams, group_views, run_clip_groups, side_streams
-    concurrent = bool(sv.get("concurrent"))
-    dEnc_staff = [torch.zeros_like(dEnc), torch.zeros_like(dEnc)] if concurrent else [dEnc, dEnc]
-    bar_major = bool(sv.get("bar_major"))
-    # weight gradients etc. of each staff off its recurrence stream: measured +0.7 % in round 1, but two more streams than the four
-    # hardware queues the runtime has (engine.group_stream) -- off by default since the clip groups need a queue (A2S_DEFER_STREAM=1)
-    use_deferred = concurrent and os.environ.get("A2S_DEFER_STREAM", "0") == "1"
-    clip_groups = sv.get("clip_groups") or [(0, B)]
-    d_hidden = torch.empty((B, H2), dtype=torch.float32, device=dev)       # gradient wrt the encoder's bridge output (initial bar-level hidden)
-    # Clip groups (engine.Engine.forward): each group's decoder backward runs concurrently on its own streams / host threads.  What the
-    # groups write per CLIP (dEnc, dK, d_hidden) they write to disjoint slices; what they ACCUMULATE over clips (every weight gradient)
-    # goes to a flat gradient buffer of the group's own (16.4 M floats), added to `flat` once after the join -- no two streams ever
-    # accumulate into the same memory.
-    group_flat = [flat] + [torch.zeros_like(flat) for _ in clip_groups[1:]]
-    group_ptrs = [G["__staff_emb_ptrs__"]]
-    for gf in group_flat[1:]:
-        delta = gf.data_ptr() - flat.data_ptr()
-        ph = (ptrs_host + delta).pin_memory()
-        keep_alive.append(ph)
-        group_ptrs.append(ph.to(dev, non_blocking=True))
+class Backward:
+    """The backward pass in three phases, so that the decoder part of each clip group can be started by whoever has that group's loss
+    gradients first (train.TrainStep chains it right behind the group's forward, on the group's own streams):
+        ctx = Backward(eng, S, (B, T, F), device, clip_groups, concurrent, bar_major)     allocations, before any group starts
+        ctx.decoder_group(gidx, gs, dts_g, dkey_g, dup_g, dlo_g)                        one group: note decoders, bar chain, heads
+        G = ctx.finish(grad_ready)                                                      keys, encoder, ConvStack
+    What the groups write per CLIP (dEnc, dK, d_hidden) they write to disjoint slices; what they ACCUMULATE over clips (every weight
+    gradient) goes to a flat gradient buffer of the group's own (16.4 M floats), added to `flat` once after the join -- no two streams
+    ever accumulate into the same memory."""
 
-    def decoder_group_bwd(gidx):
-        gs = sv["groups"][gidx]
+    def __init__(self, eng, S, shape, dev, clip_groups, concurrent, bar_major):
+        from .spec import flat_layout, is_buffer
+        self.eng, self.S, self.dev = eng, S, dev
+        self.B, self.T, self.F = shape
+        B, T = self.B, self.T
+        H = eng.cfg["hidden_size"]
+        H2 = 2 * H
+        self.names = [k for k in S if not is_buffer(k)]
+        self.offs, self.total = flat_layout([S[k].numel() for k in self.names])          # same layout as models.ScoreTranscription.flatten_()
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.G = {k: self.flat[off:off + S[k].numel()].view(S[k].shape) for k, off in zip(self.names, self.offs)}
+        # device table of the staff-embedding gradient pointers: uploaded once, before the first kernel of the backward pass
+        ptrs_host = torch.tensor([self.G[f"decoder.staff_emb.{w}_{sfx}"].data_ptr() for sfx in ("l0", "l0_reverse")
+                                  for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")], dtype=torch.int64).pin_memory()
+        self.G["__staff_emb_ptrs__"] = ptrs_host.to(dev, non_blocking=True)          # pinned: no stream synchronisation (the host keeps running ahead)
+        self.keep_alive = [ptrs_host]
+        self.dEnc = torch.zeros((B, T, H2), dtype=torch.float32, device=dev)
+        self.dK = {p: torch.zeros((B, T, H), dtype=torch.float32, device=dev) for p in ("decoder", "decoder.upper_decoder", "decoder.lower_decoder")}
+        # the two note decoders of a bar back-propagate concurrently on two side streams (see engine.side_streams); each accumulates its
+        # encoder-output gradient in its own buffer (summed once at the end), everything else they write is per-staff already
+        self.concurrent = bool(concurrent)
+        self.dEnc_staff = [torch.zeros_like(self.dEnc), torch.zeros_like(self.dEnc)] if self.concurrent else [self.dEnc, self.dEnc]
+        self.bar_major = bool(bar_major)
+        # weight gradients etc. of each staff off its recurrence stream: measured +0.7 % in round 1, but two more streams than the four
+        # hardware queues the runtime has (engine.group_stream) -- off by default since the clip groups need a queue (A2S_DEFER_STREAM=1)
+        self.use_deferred = self.concurrent and os.environ.get("A2S_DEFER_STREAM", "0") == "1"
+        self.clip_groups = list(clip_groups) if clip_groups else [(0, B)]
+        self.d_hidden = torch.empty((B, H2), dtype=torch.float32, device=dev)       # gradient wrt the encoder's bridge output (initial bar-level hidden)
+        self.group_flat = [self.flat] + [torch.zeros_like(self.flat) for _ in self.clip_groups[1:]]
+        self.group_ptrs = [self.G["__staff_emb_ptrs__"]]
+        for gf in self.group_flat[1:]:
+            ph = (ptrs_host + (gf.data_ptr() - self.flat.data_ptr())).pin_memory()
+            self.keep_alive.append(ph)
+            self.group_ptrs.append(ph.to(dev, non_blocking=True))
+
+    def decoder_group(self, gidx, gs, dts_g, dkey_g, dup_g, dlo_g):
+        """Decoder backward of clip group gidx (gs: what Engine.forward saved for it) on the calling thread's current stream (+ the two
+        side streams for group 0).  d*_g: gradients wrt the group's four output views (gs["outs"])."""
+        from .engine import fork_on_streams, side_streams
+        eng, S, G, dev, T = self.eng, self.S, self.G, self.dev, self.T
+        names, offs, group_flat, group_ptrs = self.names, self.offs, self.group_flat, self.group_ptrs
+        dEnc, dK, dEnc_staff, d_hidden = self.dEnc, self.dK, self.dEnc_staff, self.d_hidden
+        concurrent, bar_major, use_deferred = self.concurrent, self.bar_major, self.use_deferred
+        L = hip.lib()
+        cfg = eng.cfg
+        H, Sz = cfg["hidden_size"], cfg["staff_emb_size"]
+        te, ke, bars = cfg["time_sig_emb_size"], cfg["key_emb_size"], cfg["max_bars"]
+        tokw = 4 * Sz + te + ke
+        H2 = 2 * H
         b0, b1 = gs["range"]
         Bg = b1 - b0
         Gg = G if gidx == 0 else {k: group_flat[gidx][off:off + S[k].numel()].view(S[k].shape) for k, off in zip(names, offs)}
@@ -235,11 +239,6 @@ def backward(eng, S, grad_outputs, grad_ready=None):
         dK_g = {p: t[b0:b1] for p, t in dK.items()}
         dEnc_staff_g = [t[b0:b1] for t in dEnc_staff]
         ts_out_g, key_out_g, up_out_g, lo_out_g = gs["outs"]
-        dts_g, dkey_g = dts[b0:b1], dkey[b0:b1]
-        if bar_major:
-            dup_g, dlo_g = group_views(dup, clip_groups, gidx), group_views(dlo, clip_groups, gidx)
-        else:
-            dup_g, dlo_g = dup[b0:b1], dlo[b0:b1]
         concurrent_g = concurrent and gidx == 0           # the long-clip groups: everything in order on their one stream
         streams = side_streams(dev, 0) if concurrent_g else None
         use_deferred_g = use_deferred and gidx == 0
@@ -349,30 +348,69 @@ def backward(eng, S, grad_outputs, grad_ready=None):
             torch.cuda.current_stream().wait_event(ev)
         return None
 
-    run_clip_groups(dev, [lambda gi=gi: decoder_group_bwd(gi) for gi in range(len(clip_groups))])
-    G["__staff_emb_ptrs__"] = group_ptrs[0]
-    for gf in group_flat[1:]:
-        flat.add_(gf)
-    d_hid_carry = d_hidden
-    if concurrent:
-        dEnc.add_(dEnc_staff[0]).add_(dEnc_staff[1])
-    # ---- attention keys: K = enc W_e^T  ->  dW_e += dK^T enc ; dEnc += dK W_e
-    enc2d = enc.view(B * T, H2)
-    for p, dKp in dK.items():
-        Wn = p + ".attn.attn.weight"
-        sk = L.a2s_gemm_pick_splitk(H, H2, B * T, 1)
-        hip.gemm(dKp, 1, H, enc2d, H2, 1, G[Wn], 4 * H, H, H2, B * T, beta=1.0, splitk=sk, c_off=H2)
-        hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2)
-    d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T)
-    n_conv = next(off for k, off in zip(names, offs) if not k.startswith("convstack."))      # state_dict order: convstack first
-    if grad_ready is not None:
-        grad_ready(flat, n_conv, total)
-    _convstack_bwd(eng, S, G, sv["conv"], d_conv, B, T, F)
-    if grad_ready is not None:
-        grad_ready(flat, 0, n_conv)
-    G[None] = flat
-    eng._keep_alive = keep_alive
-    return G
+
+    def finish(self, grad_ready=None):
+        eng, S, G, dev = self.eng, self.S, self.G, self.dev
+        B, T, F = self.B, self.T, self.F
+        names, offs, total, flat = self.names, self.offs, self.total, self.flat
+        dEnc, dK = self.dEnc, self.dK
+        sv = eng.saved
+        assert sv["training"], "backward needs a forward run with training=True (batch statistics / saved activations)"
+        L = hip.lib()
+        H = eng.cfg["hidden_size"]
+        H2 = 2 * H
+        enc = sv["enc_out"]
+        G["__staff_emb_ptrs__"] = self.group_ptrs[0]
+        for gf in self.group_flat[1:]:
+            flat.add_(gf)
+        d_hid_carry = self.d_hidden
+        if self.concurrent:
+            dEnc.add_(self.dEnc_staff[0]).add_(self.dEnc_staff[1])
+        # ---- attention keys: K = enc W_e^T  ->  dW_e += dK^T enc ; dEnc += dK W_e
+        enc2d = enc.view(B * T, H2)
+        for p, dKp in dK.items():
+            Wn = p + ".attn.attn.weight"
+            sk = L.a2s_gemm_pick_splitk(H, H2, B * T, 1)
+            hip.gemm(dKp, 1, H, enc2d, H2, 1, G[Wn], 4 * H, H, H2, B * T, beta=1.0, splitk=sk, c_off=H2)
+            hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2)
+        d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T)
+        n_conv = next(off for k, off in zip(names, offs) if not k.startswith("convstack."))      # state_dict order: convstack first
+        if grad_ready is not None:
+            grad_ready(flat, n_conv, total)
+        _convstack_bwd(eng, S, G, sv["conv"], d_conv, B, T, F)
+        if grad_ready is not None:
+            grad_ready(flat, 0, n_conv)
+        G[None] = flat
+        eng._keep_alive = self.keep_alive
+        return G
+
+
+
+
+def backward(eng, S, grad_outputs, grad_ready=None):
+    """Gradients of sum_i <out_i, grad_outputs_i> wrt every parameter.  Returns dict name -> tensor (views of ONE flat buffer,
+    also returned as `flat` under key None) in state_dict parameter order.
+    grad_ready(flat, start, end): optional callback, called when flat[start:end] is final (everything that writes it has been
+    enqueued on the current stream) -- first the encoder + decoder slice, then the ConvStack slice; train.GradientExchange starts
+    the data-parallel all-reduce of a slice there, under the rest of the backward pass."""
+    from .engine import group_views, run_clip_groups
+    sv = eng.saved
+    assert sv["training"], "backward needs a forward run with training=True (batch statistics / saved activations)"
+    dev = sv["enc_out"].device
+    clip_groups = sv.get("clip_groups") or [(0, sv["shape"][0])]
+    ctx = Backward(eng, S, sv["shape"], dev, clip_groups, sv.get("concurrent"), sv.get("bar_major"))
+    dts, dkey, dup, dlo = [g.contiguous() for g in grad_outputs]
+
+    def group(gidx):
+        b0, b1 = clip_groups[gidx]
+        if ctx.bar_major:
+            dup_g, dlo_g = group_views(dup, clip_groups, gidx), group_views(dlo, clip_groups, gidx)
+        else:
+            dup_g, dlo_g = dup[b0:b1], dlo[b0:b1]
+        ctx.decoder_group(gidx, sv["groups"][gidx], dts[b0:b1], dkey[b0:b1], dup_g, dlo_g)
+
+    run_clip_groups(dev, [lambda gi=gi: group(gi) for gi in range(len(clip_groups))])
+    return ctx.finish(grad_ready)
 
 
 _WG_STREAMS = {}

@@ -30,7 +30,8 @@ class NoteDecArgs(C.Structure):
         ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("t_base", C.c_void_p), ("clip_order", C.c_void_p), ("clip_rank", C.c_void_p),
         ("row_until", C.c_void_p), ("n_active", C.c_void_p), ("n_clips", C.c_int),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
-        ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int), ("use_graph", C.c_int)]
+        ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int), ("use_graph", C.c_int),
+        ("step_ws", C.c_void_p), ("step_ws_floats", C.c_size_t)]
 
 
 class NoteDecBwdArgs(C.Structure):
@@ -40,7 +41,8 @@ class NoteDecBwdArgs(C.Structure):
         "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh", "attn_ws", "gemm_ws")] + [
         ("gemm_ws_bytes", C.c_size_t), ("clip_order", C.c_void_p), ("clip_rank", C.c_void_p), ("row_until", C.c_void_p),
         ("n_active", C.c_void_p), ("n_clips", C.c_int),
-        ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int)]
+        ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int),
+        ("step_ws", C.c_void_p), ("step_ws_floats", C.c_size_t)]
 
 
 def lib():
@@ -51,10 +53,11 @@ def lib():
                            "There is no CPU fallback for the transcription hot path.")
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
-        for fn in ("a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
+        for fn in ("a2s_note_step_workspace_floats", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
                    "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
-        for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3")):
+        for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"),
+                         ("A2S_DEC_FUSED", b"dec_fused"), ("A2S_DEC_FUSED_MAX_ROWS", b"dec_fused_max_rows")):
             if os.environ.get(env):
                 _lib.a2s_debug_set(key, int(os.environ[env]))
     return _lib
@@ -86,6 +89,12 @@ def conv_workspace(cin, device):
 def gemm_workspace(rows, device):
     """Split-K scratch for the per-step skinny GEMMs of the decoder loops (16 slabs of rows x 2048 floats)."""
     return torch.empty(16 * max(rows, 1) * 2048, dtype=torch.float32, device=device)
+
+
+def step_workspace(H, E, device):
+    """Scratch of the fused few-row decoder step kernels (csrc/a2s_step.hip): flags, ticket counters (must start at zero), logits,
+    transposed weight copies."""
+    return torch.zeros(lib().a2s_note_step_workspace_floats(H, E), dtype=torch.float32, device=device)
 
 
 def stream():

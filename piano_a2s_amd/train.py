@@ -228,6 +228,9 @@ class TrainStep:
         self.fuse_bars = (_os.environ.get("A2S_FUSE_BARS", "1") != "0") if fuse_bars is None else bool(fuse_bars)
         # True / False, or an explicit list of contiguous clip ranges [(0, n), (n, B)] (tests: no planner, no permutation)
         self.clip_groups = (_os.environ.get("A2S_CLIP_GROUPS", "1") != "0") if clip_groups is None else clip_groups
+        # each clip group's decoder backward follows its forward at once (see __call__); A2S_PIPELINE_GROUPS=0: forward of every group,
+        # then the objective, then backward of every group
+        self.pipeline_groups = _os.environ.get("A2S_PIPELINE_GROUPS", "1") != "0"
         self._last = None
         self.flat = model.flatten_()
         self.opt = FusedAdadelta(self.flat, lr, rho, eps, max_grad_norm, layout=model.flat_layout())
@@ -267,18 +270,57 @@ class TrainStep:
                 spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len)]
                 eng.clip_groups = [(0, n_main), (n_main, B)]
         S = self.state()
-        outs = eng.forward(S, spectrogram, inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len],
-                           teacher_forcing_ratio=teacher_forcing_ratio, training=True, rng=rng, dropout=self.dropout, gt_host=gt_host)
-        groups = eng.clip_groups_used
-        if eng.bar_major:
-            # fused bars: the staff outputs come bar-major, one contiguous (bars, clips, len, V) block per clip group; the loss is a mean
-            # over rows, so the targets are simply laid out the same way
-            lay = lambda t: torch.cat([t[b0:b1].transpose(0, 1).reshape(-1) for b0, b1 in groups])
-            losses, gouts = self.objective(outs, (ts_t, key_t, lay(up_t), lay(lo_t)))
-        else:
-            losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
         exchange = GradientExchange(self.world)
-        G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready)
+        fwd = dict(inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len], teacher_forcing_ratio=teacher_forcing_ratio, training=True,
+                   rng=rng, dropout=self.dropout, gt_host=gt_host)
+        if eng.fuse_bars and self.pipeline_groups:
+            # Pipelined clip groups.  The gradient of the 4-term objective wrt a row's log-probabilities is -1/count at its target --
+            # and the counts (denominators of the NLL means) are functions of the TARGETS alone.  So a clip group does not have to
+            # wait for the others' forward passes before it back-propagates: its loss gradients and decoder backward are chained
+            # right behind its decoder forward, on its own thread and streams (Engine.group_hook).  With [ordinary | long] clip groups
+            # the long clips' ~400-step latency chains (forward AND backward) then run under the ordinary clips' forward + backward
+            # instead of under their forward only.  The loss VALUES are reduced after the join.
+            B, bars = ts_t.shape
+            groups = getattr(eng, "clip_groups", None) or [(0, B)]
+            cfg, dev = self.model.cfg, spectrogram.device
+            U, Lo = cfg["max_length"]
+            lay = lambda t: torch.cat([t[b0:b1].transpose(0, 1).reshape(-1) for b0, b1 in groups])
+            up_lay, lo_lay = lay(up_t), lay(lo_t)
+            inv = torch.zeros((4, 2), dtype=torch.float32, device=dev)
+            inv[0:2, 1] = 1.0 / (B * bars)
+            inv[2, 1] = 1.0 / (up_t != PAD).sum()
+            inv[3, 1] = 1.0 / (lo_t != PAD).sum()
+            gouts = [torch.zeros((B, bars, cfg["num_time_sig"]), device=dev), torch.zeros((B, bars, cfg["num_keys"]), device=dev),
+                     torch.zeros((bars, B, U, VOCAB_SIZE), device=dev), torch.zeros((bars, B, Lo, VOCAB_SIZE), device=dev)]
+            ctx = engine_bwd.Backward(eng, S, (B, spectrogram.shape[2], spectrogram.shape[3]), dev, groups, True, True)
+            L = hip.lib()
+
+            def grads_and_backward(gidx, gs):
+                b0, b1 = gs["range"]
+                n = b1 - b0
+                d = [gouts[0][b0:b1], gouts[1][b0:b1], engine.group_views(gouts[2], groups, gidx), engine.group_views(gouts[3], groups, gidx)]
+                tg = [ts_t[b0:b1], key_t[b0:b1], up_lay[bars * U * b0: bars * U * b1], lo_lay[bars * Lo * b0: bars * Lo * b1]]
+                for i, (V_, ign) in enumerate(((cfg["num_time_sig"], -1), (cfg["num_keys"], -1), (VOCAB_SIZE, PAD), (VOCAB_SIZE, PAD))):
+                    hip.check(L.a2s_nll_grad(hip.stream(), hip._p(d[i]), hip._p(tg[i]), C.c_void_p(inv.data_ptr() + 8 * i), hip.f32(1.0),
+                                             C.c_long(d[i].numel() // V_), V_, C.c_longlong(ign)), "a2s_nll_grad")
+                ctx.decoder_group(gidx, gs, *d)
+
+            eng.group_hook = grads_and_backward
+            outs = eng.forward(S, spectrogram, **fwd)
+            groups = eng.clip_groups_used
+            losses, _ = self.objective(outs, (ts_t, key_t, up_lay, lo_lay), want_grad=False)
+            G = ctx.finish(grad_ready=exchange.slice_ready)
+        else:
+            outs = eng.forward(S, spectrogram, **fwd)
+            groups = eng.clip_groups_used
+            if eng.bar_major:
+                # fused bars: the staff outputs come bar-major, one contiguous (bars, clips, len, V) block per clip group; the loss is a
+                # mean over rows, so the targets are simply laid out the same way
+                lay = lambda t: torch.cat([t[b0:b1].transpose(0, 1).reshape(-1) for b0, b1 in groups])
+                losses, gouts = self.objective(outs, (ts_t, key_t, lay(up_t), lay(lo_t)))
+            else:
+                losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
+            G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready)
         self.decode_steps = sum(seg["staff"][k][2]["steps"] for g in eng.saved["groups"] for seg in g["segments"] for k in ("up", "lo"))
         if self.time_exchange and exchange.active:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

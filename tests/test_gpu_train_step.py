@@ -237,3 +237,46 @@ def test_odd_shapes_through_the_fused_step_and_the_greedy_decoder(dev, B, T, max
         outs = m(spectrogram=batch[0], inference=True, device=dev)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(o).all()) for o in outs)
+
+
+def test_fused_few_row_decoder_step_matches_the_library_path(dev):
+    """csrc/a2s_step.hip (4 launches per decode step forward, 5 backward, used for calls of few rows) against the GEMM-by-GEMM step
+    (a2s_debug_set('dec_fused', 0)): the same training step -- losses, gradient norm, updated parameters, log-probabilities -- and
+    the same greedy decode (identical token ids), on the full-width model with ragged rows, mixed teacher forcing and dropout off."""
+    import random
+    import models
+    from piano_a2s_amd import hip, spec, synthetic, train
+    L = hip.lib()
+    cfg = spec.default_cfg(max_length=(14, 9), max_bars=3)
+    st = spec.procedural_state(cfg, 5, eos_bias=1.0, lively="token")
+    batch = synthetic.make_batch(5, cfg, 21, frames=61, upper_range=(1, 14), lower_range=(1, 9), full_tail=0.2, spectrogram="ridges")
+    dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
+    assert L.a2s_debug_get(b"dec_fused") == 1 and L.a2s_debug_get(b"dec_fused_max_rows") >= 15
+    res = {}
+    try:
+        for fused in (0, 1):
+            L.a2s_debug_set(b"dec_fused", fused)
+            m = models.ScoreTranscription(**cfg)
+            m.load_state_dict(st)
+            m = m.to(dev)
+            m.eval()
+            with torch.no_grad():
+                greedy = [o.cpu() for o in m(spectrogram=dbatch[0], inference=True, device=dev)]
+            m.train()
+            step = train.TrainStep(m, dropout=False)
+            losses = step(dbatch, teacher_forcing_ratio=0.6, rng=random.Random(4))
+            torch.cuda.synchronize()
+            res[fused] = (losses[:, 0].cpu().clone(), step.opt.ctl.cpu().clone(), step.flat.cpu().clone(), [o.cpu() for o in step.last_outputs], greedy)
+    finally:
+        L.a2s_debug_set(b"dec_fused", 1)
+    (l0, c0, p0, o0, g0), (l1, c1, p1, o1, g1) = res[0], res[1]
+    assert torch.isfinite(l0).all() and float(c0[2]) == 1.0 and float(c1[2]) == 1.0
+    assert torch.allclose(l0, l1, rtol=5e-6, atol=0), (l0, l1)
+    assert abs(float(c0[0]) - float(c1[0])) <= 2e-5 * float(c0[0])
+    assert float((p0 - p1).abs().max()) <= 5e-6 * float(p0.abs().max())
+    for a, b, gt in ((o0[2], o1[2], batch[3]), (o0[3], o1[3], batch[5])):
+        keep = gt != 147
+        assert float((a[keep] - b[keep]).abs().max()) <= 2e-5
+    for a, b in zip(g0, g1):
+        assert torch.equal(a.argmax(-1), b.argmax(-1)) and float((a - b).abs().max()) <= 2e-5
+    assert torch.equal((g0[2].abs().sum(-1) > 0), (g1[2].abs().sum(-1) > 0)), "executed greedy steps differ"
