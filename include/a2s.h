@@ -80,6 +80,16 @@ int a2s_conv3x3_dgrad_bnstats(void* stream, const float* dy, const float* w, flo
                               float* workspace);
 int a2s_bn_bwd_from_partial(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
                             float* dgamma, float* dbeta, float* dx /* may be NULL */, const float* partial, int nblocks, float* c12, long rows, int C, int F);
+/* The same two calls for the TWO-TERM fp16 convolution path (csrc/a2s_conv.hip conv3x3_split<.., 2>: every fp32 operand as two fp16
+ * terms, three products instead of the six of the three-term bf16 split).  fp16 has no exponent range to spare for gradients, so the
+ * kernel that WRITES a gradient tensor also reduces max |dx| into a device scalar (dx_absmax, 1 float) and the data-gradient convolution
+ * that READS it scales its operand by the exact power of two that brings that maximum to 2^12 (dy_absmax; NULL = three-term path). */
+int a2s_conv3x3_dgrad_bnstats_scaled(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
+                                     const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
+                                     float* workspace, const float* dy_absmax);
+int a2s_bn_bwd_from_partial_amax(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                 float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12, long rows, int C, int F,
+                                 float* dx_absmax);
 size_t a2s_conv3x3_workspace_floats(int Cin);   /* scratch for the packed weight image (0 for Cin = 1) */
 /* BatchNorm2d/1d statistics -> affine (models.py:499-505): reduces the partials in fixed order (double),
  * updates running stats (momentum, unbiased var) and num_batches_tracked when training, emits mean/invstd
@@ -236,6 +246,9 @@ int a2s_staff_emb_bwd(void* stream, const float* note_emb, const float* const* g
 int a2s_bn_bwd(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
                const float* shift, const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx,
                float* partial, float* c12, long rows, int C, int F);
+int a2s_bn_bwd_amax(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
+                    const float* shift, const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx,
+                    float* partial, float* c12, long rows, int C, int F, float* dx_absmax);
 size_t a2s_bn_bwd_partial_floats(long rows, int C, int F);
 /* the same in two halves for synchronised BatchNorm: (1) this rank's per-channel {sum g', sum g' xhat} -> sums[2C];
  * [host: all-reduce];  (2) dgamma/dbeta += LOCAL sums, dx from the GLOBAL sums / global element count. */

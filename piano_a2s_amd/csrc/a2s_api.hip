@@ -14,7 +14,9 @@ int a2s_gemm_affine_impl(hipStream_t, int, int, int, float, const float*, long, 
                          const float*, const float*, const float*, const float*, const float*, float*, int);
 int a2s_gemm_bnstats_slots(int);
 int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*,
-                     const float*, const float*, const float*, const float*, const float*);
+                     const float*, const float*, const float*, const float*, const float*, const float*);
+void a2s_conv_f16x2_set(int);
+int a2s_conv_f16x2_enabled(void);
 size_t a2s_conv3x3_workspace_floats_impl(int);
 void a2s_conv_bf16x3_set(int);
 void a2s_gemm_split_set(int);
@@ -67,10 +69,10 @@ int a2s_staff_emb_bwd_impl(hipStream_t, const float*, const float* const*, float
                            const long long*, long, const float*, long, int, const float*, int, int, int, int);
 
 int a2s_bn_bwd_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
-                    float*, float*, float*, float*, float*, long, int, int);
+                    float*, float*, float*, float*, float*, long, int, int, float*);
 size_t a2s_bn_bwd_partial_floats_impl(long, int, int);
 int a2s_bn_bwd_from_partial_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
-                                 const float*, int, float*, long, int, int);
+                                 const float*, int, float*, long, int, int, float*);
 
 int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int,
                            const float*, const float*, const float*, const float*, const float*, const float*, float*);
@@ -124,6 +126,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
+    if (!strcmp(key, "conv_f16x2")) { a2s_conv_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_bf16x3")) { a2s_gemm_split_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_bf16x3")) { a2s_wgrad_split_set(value); return A2S_OK; }
     snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
@@ -132,6 +135,7 @@ int a2s_debug_set(const char* key, int value) {
 
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
+    if (key && !strcmp(key, "conv_f16x2")) return a2s_conv_f16x2_enabled();
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();
     if (key && !strcmp(key, "wgrad_bf16x3")) return a2s_wgrad_split_enabled();
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
@@ -142,17 +146,28 @@ int a2s_debug_get(const char* key) {
 
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
                 float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace) {
-    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, workspace, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, workspace, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 int a2s_conv3x3_dgrad_bnstats(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
                               const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
                               float* workspace) {
     if (!yl) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_dgrad_bnstats: yl is required"); return A2S_ERR_ARG; }
-    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift);
+    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, nullptr);
+}
+int a2s_conv3x3_dgrad_bnstats_scaled(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
+                                     const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
+                                     float* workspace, const float* dy_absmax) {
+    if (!yl) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_dgrad_bnstats_scaled: yl is required"); return A2S_ERR_ARG; }
+    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, dy_absmax);
 }
 int a2s_bn_bwd_from_partial(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
                             float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12, long rows, int C, int F) {
-    return a2s_bn_bwd_from_partial_impl(ST, g, x, mean, invstd, scale, shift, dgamma, dbeta, dx, partial, nblocks, c12, rows, C, F);
+    return a2s_bn_bwd_from_partial_impl(ST, g, x, mean, invstd, scale, shift, dgamma, dbeta, dx, partial, nblocks, c12, rows, C, F, nullptr);
+}
+int a2s_bn_bwd_from_partial_amax(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                 float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12, long rows, int C, int F,
+                                 float* dx_absmax) {
+    return a2s_bn_bwd_from_partial_impl(ST, g, x, mean, invstd, scale, shift, dgamma, dbeta, dx, partial, nblocks, c12, rows, C, F, dx_absmax);
 }
 size_t a2s_conv3x3_workspace_floats(int Cin) { return a2s_conv3x3_workspace_floats_impl(Cin); }
 int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin) { return a2s_conv3x3_stat_blocks_impl(B, T, F, Cin); }
@@ -266,7 +281,12 @@ int a2s_staff_emb_bwd(void* stream, const float* note_emb, const float* const* g
 
 int a2s_bn_bwd(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
                const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx, float* partial, float* c12, long rows, int C, int F) {
-    return a2s_bn_bwd_impl(ST, g, x, mean, invstd, scale, shift, keep_mask, inv_keep, dgamma, dbeta, dx, partial, c12, rows, C, F);
+    return a2s_bn_bwd_impl(ST, g, x, mean, invstd, scale, shift, keep_mask, inv_keep, dgamma, dbeta, dx, partial, c12, rows, C, F, nullptr);
+}
+int a2s_bn_bwd_amax(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
+                    const uint8_t* keep_mask, float inv_keep, float* dgamma, float* dbeta, float* dx, float* partial, float* c12, long rows, int C, int F,
+                    float* dx_absmax) {
+    return a2s_bn_bwd_impl(ST, g, x, mean, invstd, scale, shift, keep_mask, inv_keep, dgamma, dbeta, dx, partial, c12, rows, C, F, dx_absmax);
 }
 size_t a2s_bn_bwd_partial_floats(long rows, int C, int F) { return a2s_bn_bwd_partial_floats_impl(rows, C, F); }
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,

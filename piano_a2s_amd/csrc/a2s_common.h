@@ -150,5 +150,25 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p0, un
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
+// ---- fp32 operands on the fp16 matrix pipes, TWO terms (conv3x3_split<.., 2>): x = t0 + t1 with fp16 t0 = rn(x), t1 = rn(x - t0); the
+// residual x - t0 is exact in fp32, so |x - t0 - t1| <= 2^-23 |x| as long as t1 is a NORMAL fp16 number (|x| >= 2^-3 after the caller's
+// power-of-two scaling; below that the absolute error is the fp16 subnormal quantum 2^-25).  Three term products (t0 t0', t0 t1', t1 t0')
+// instead of the six of the bf16 three-term split: each is exact in the fp32 accumulator (11 x 11 bits), the dropped t1 t1' <= 2^-22 |x x'|.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ void split2_pair_f16(float x0, float x1, unsigned& p0, unsigned& p1) {
+    f32x2 v = {x0, x1};
+    const f16x2 t0 = __builtin_convertvector(v, f16x2);              // v_cvt_f16_f32: round to nearest even
+    p0 = __builtin_bit_cast(unsigned, t0);
+    const f32x2 b = __builtin_convertvector(t0, f32x2);
+    v[0] -= b[0]; v[1] -= b[1];
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// power-of-two scale that brings a tensor whose largest magnitude is `amax` to [2^target, 2^(target+1)): exact to apply and to undo
+__device__ __forceinline__ int pow2_scale_exp(float amax, int target) {
+    if (!(amax > 0.f) || !isfinite(amax)) return 0;
+    const int k = target - ilogbf(amax);
+    return min(max(k, -96), 96);
+}
 
 #endif

@@ -36,6 +36,8 @@ struct ConvArgs {
     // backward statistics  sum g', sum g' xhat  (g' = g where bn(yl) > 0) are accumulated in the epilogue and written to stat_partial
     // in the layout bn_bwd_finalize reads -- the separate statistics pass over (g, yl) disappears
     const float* yl; const float* yl_mean; const float* yl_invstd; const float* yl_scale; const float* yl_shift;
+    // two-term fp16 split (conv3x3_split<.., 2>) only: device scalars holding max|x| (null: the operand is used unscaled) and max|w|
+    const float* x_absmax; const float* w_absmax;
 };
 
 // ---- v2 geometry (round 1, after profiling: the first version spent more time staging than multiplying -- scalar loads with
@@ -299,12 +301,24 @@ __host__ __device__ inline int c4_chunks(int Cin) { return ((Cin + 7) / 8 + 1) /
 // ds_read_b128 lane group touches (pairs p, p+1) then start on the same bank and their 8 + 8 lanes interleave without conflicts.
 __host__ __device__ constexpr int c4_odd_base(int Cout) { return (C4_SLOTS / 2 * Cout * 16 + 255) / 256 * 256; }
 __host__ __device__ constexpr int c4_wpl(int Cout) { return c4_odd_base(Cout) + C4_SLOTS / 2 * Cout * 16; }
-__host__ __device__ inline size_t c4_chunk_bytes(int Cout) { return ((size_t)3 * c4_wpl(Cout) + 4095) / 4096 * 4096; }   // whole LDS-DMA rounds
+__host__ __device__ inline size_t c4_chunk_bytes(int Cout, int terms = 3) { return ((size_t)terms * c4_wpl(Cout) + 4095) / 4096 * 4096; }   // whole LDS-DMA rounds
 
 #ifndef C4_FRESH
 #define C4_FRESH 0        // 1: sum each k-step's six products in a fresh accumulator (3x smaller element error, 15 % slower)
 #endif
-__global__ void conv_pack_weights_bf16x3(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int flip) {
+// max |w| of a small tensor by ONE workgroup (the fp16 two-term path scales the weights by a power of two: their second term would
+// otherwise sit in fp16's subnormal range)
+__global__ __launch_bounds__(256) void absmax_small(const float* __restrict__ w, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    m = block_max(m, red);
+    if (threadIdx.x == 0) *out = m;
+}
+
+template <int TERMS>
+__global__ void conv_pack_weights_split(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int flip,
+                                        const float* __restrict__ w_absmax) {
     const int ncgs = (Cin + 7) / 8, nchunks = (ncgs + 1) / 2;
     const int per_term = C4_SLOTS * Cout * 8;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,16 +334,52 @@ __global__ void conv_pack_weights_bf16x3(const float* __restrict__ w, unsigned s
 #if C4_FRESH
     if ((p >> 2) & 1) v = -v;                         // odd k-steps accumulate the negated sum (c4_multiply subtracts it)
 #endif
-    unsigned t0, t1, t2;
-    split3_pair(v, 0.f, t0, t1, t2);
-    const int wpl = c4_wpl(Cout) / 2;                 // in bf16 elements
-    unsigned short* dst = wp + (long)chunk * (c4_chunk_bytes(Cout) / 2) + (p & 1) * (c4_odd_base(Cout) / 2) + ((p >> 1) * Cout + n) * 8 + k8;
-    dst[0] = (unsigned short)t0; dst[wpl] = (unsigned short)t1; dst[2 * wpl] = (unsigned short)t2;      // pads are zeroed by the launcher
+    const int wpl = c4_wpl(Cout) / 2;                 // in 16-bit elements
+    unsigned short* dst = wp + (long)chunk * (c4_chunk_bytes(Cout, TERMS) / 2) + (p & 1) * (c4_odd_base(Cout) / 2) + ((p >> 1) * Cout + n) * 8 + k8;
+    if (TERMS == 3) {
+        unsigned t0, t1, t2;
+        split3_pair(v, 0.f, t0, t1, t2);
+        dst[0] = (unsigned short)t0; dst[wpl] = (unsigned short)t1; dst[2 * wpl] = (unsigned short)t2;      // pads are zeroed by the launcher
+    } else {
+        unsigned t0, t1;
+        split2_pair_f16(ldexpf(v, pow2_scale_exp(*w_absmax, 13)), 0.f, t0, t1);
+        dst[0] = (unsigned short)t0; dst[wpl] = (unsigned short)t1;
+    }
 }
 
 #ifndef C4_MH
 #define C4_MH 2          // m-tiles per pass of a k-step (2: half the A-fragment registers, B fragments read twice)
 #endif
+// two-term fp16 variant of c4_multiply: three products per k-step, smallest first
+template <int KS, int NT, int COUT>
+__device__ __forceinline__ void c4_multiply_f16x2(const unsigned char* __restrict__ lin, const unsigned char* __restrict__ lw,
+                                                  const int (&aoff)[KS], int boff, f32x4 (&acc)[4][NT], int nh) {
+    constexpr int WPL = c4_wpl(COUT);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int h = 0; h < 4 / C4_MH; ++h) {
+            if (h >= nh) break;
+            f16x8 av[2][C4_MH];
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int i = 0; i < C4_MH; ++i) av[sp][i] = *reinterpret_cast<const f16x8*>(lin + sp * C4_INPL + aoff[s] + (C4_MH * h + i) * 16 * C4_PSTR);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f16x8 bv[2];
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) bv[sp] = *reinterpret_cast<const f16x8*>(lw + sp * WPL + boff + s * 2 * COUT * 16 + j * 256);
+#define C4_PRODUCT(SA, SB)                                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < C4_MH; ++i)                                                            \
+                    acc[C4_MH * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[SA][i], bv[SB], acc[C4_MH * h + i][j], 0, 0, 0);
+                C4_PRODUCT(1, 0) C4_PRODUCT(0, 1) C4_PRODUCT(0, 0)
+#undef C4_PRODUCT
+            }
+        }
+    }
+}
+
 template <int KS, int NT, int COUT>
 __device__ __forceinline__ void c4_multiply(const unsigned char* __restrict__ lin, const unsigned char* __restrict__ lw,
                                             const int (&aoff)[KS], int boff, f32x4 (&acc)[4][NT], int nh) {
@@ -376,12 +426,17 @@ __device__ __forceinline__ void c4_multiply(const unsigned char* __restrict__ li
     }
 }
 
-template <int COUT, bool BNRED>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsigned char* __restrict__ wpack) {
+// TERMS = 3: every fp32 operand as three bf16 terms, six products (conv3x3_bf16x3 of round 1).  TERMS = 2: two fp16 terms, THREE
+// products -- half the matrix-pipe work and two thirds of the LDS traffic for the same fp32-level result (a2s_common.h:
+// split2_pair_f16); fp16's narrow exponent range is handled by exact power-of-two scales: the weights by 2^(13 - exponent of max|w|)
+// (pack kernel), a gradient operand by 2^(12 - exponent of max|x|) (x_absmax, written by the kernel that produced it), activations
+// unscaled; the accumulators are multiplied by the inverse power of two in the epilogue.
+template <int COUT, bool BNRED, int TERMS>
+__global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsigned char* __restrict__ wpack) {
     constexpr int NT = (COUT + 15) / 16;
     constexpr int WPL = c4_wpl(COUT);                    // bytes per term plane of a packed weight chunk
-    constexpr int WCH = (3 * WPL + 4095) / 4096 * 4096;  // chunk stride of the packed image: whole 4 x 1 KB LDS-DMA rounds
-    __shared__ __attribute__((aligned(16))) unsigned char lin[3 * C4_INPL];          // 38016 B
+    constexpr int WCH = (TERMS * WPL + 4095) / 4096 * 4096;  // chunk stride of the packed image: whole 4 x 1 KB LDS-DMA rounds
+    __shared__ __attribute__((aligned(16))) unsigned char lin[TERMS * C4_INPL];      // 38016 B (3 terms)
     __shared__ __attribute__((aligned(16))) unsigned char lw[WCH];                   // 40960 B (COUT 40); the zero tail covers the n-tile overrun of the last slot
     __shared__ float red[4][NT * 16][2];
     __shared__ __attribute__((aligned(16))) float lsc[48], lsh[48];                   // producer's BatchNorm scale / shift (0 beyond Cin)
@@ -410,6 +465,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsig
     if (tid < 48) {
         lsc[tid] = (a.in_scale && tid < a.Cin) ? a.in_scale[tid] : 0.f;
         lsh[tid] = (a.in_scale && tid < a.Cin) ? a.in_shift[tid] : 0.f;
+    }
+    float xscale = 1.f, unscale = 1.f;                   // TERMS == 2: exact power-of-two operand scale and its inverse (times the weights')
+    if (TERMS == 2) {
+        const int kx = a.x_absmax ? pow2_scale_exp(*a.x_absmax, 12) : 0;
+        const int kw = pow2_scale_exp(*a.w_absmax, 13);
+        xscale = ldexpf(1.f, kx);
+        unscale = ldexpf(1.f, -(kx + kw));
     }
 
     // per-lane fragment offsets: pair p = 4 s + lk of the chunk (clamped: the padded slots carry zero weights)
@@ -498,13 +560,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsig
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(__float_as_uint(v[k]) ^ sgn);      // odd stages multiply -x (see the stage loop)
-            uint4 o[3];
-            split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
-            split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
-            split3_pair(v[4], v[5], o[0].z, o[1].z, o[2].z);
-            split3_pair(v[6], v[7], o[0].w, o[1].w, o[2].w);
+            uint4 o[TERMS];
+            if (TERMS == 3) {
+                split3_pair(v[0], v[1], o[0].x, o[1].x, o[TERMS - 1].x);
+                split3_pair(v[2], v[3], o[0].y, o[1].y, o[TERMS - 1].y);
+                split3_pair(v[4], v[5], o[0].z, o[1].z, o[TERMS - 1].z);
+                split3_pair(v[6], v[7], o[0].w, o[1].w, o[TERMS - 1].w);
+            } else {
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint4*>(lin + sp * C4_INPL + rp * C4_PSTR + cgl * 16) = o[sp];
+                for (int k = 0; k < 8; ++k) v[k] = fminf(fmaxf(v[k] * xscale, -65000.f), 65000.f);     // (the clamp only bites on absurd activations)
+                split2_pair_f16(v[0], v[1], o[0].x, o[1].x);
+                split2_pair_f16(v[2], v[3], o[0].y, o[1].y);
+                split2_pair_f16(v[4], v[5], o[0].z, o[1].z);
+                split2_pair_f16(v[6], v[7], o[0].w, o[1].w);
+            }
+#pragma unroll
+            for (int sp = 0; sp < TERMS; ++sp) *reinterpret_cast<uint4*>(lin + sp * C4_INPL + rp * C4_PSTR + cgl * 16) = o[sp];
         }
     };
 
@@ -531,10 +602,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3(ConvArgs a, const unsig
         // stages therefore accumulate the NEGATED sum (input negated while staging, accumulators flipped): the truncation then pushes
         // the value the other way, and a tile's stages / neighbouring tiles cancel.
         if (!C4_FRESH && acc_neg != bool(q & 1)) { flip_acc(); acc_neg = !acc_neg; }
-        if (ncgs - 2 * resident >= 2) c4_multiply<5, NT, COUT>(lin, lw, aoff2, boff, acc, nh);
-        else c4_multiply<3, NT, COUT>(lin, lw, aoff1, boff, acc, nh);
+        if (TERMS == 3) {
+            if (ncgs - 2 * resident >= 2) c4_multiply<5, NT, COUT>(lin, lw, aoff2, boff, acc, nh);
+            else c4_multiply<3, NT, COUT>(lin, lw, aoff1, boff, acc, nh);
+        } else {
+            if (ncgs - 2 * resident >= 2) c4_multiply_f16x2<5, NT, COUT>(lin, lw, aoff2, boff, acc, nh);
+            else c4_multiply_f16x2<3, NT, COUT>(lin, lw, aoff1, boff, acc, nh);
+        }
         if ((q + 1) % nchunks != 0) continue;
         if (acc_neg) { flip_acc(); acc_neg = false; }
+        if (TERMS == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] *= unscale;
+        }
         // ---- tile epilogue.  C/D map: lane holds column n = li (channel), rows lk*4+r (f positions) of each m-tile.
         const int t = (tile0 + stage_tile(q)) * CV_TR + wave;
         const bool row_ok = t < a.T;
@@ -761,25 +845,34 @@ __global__ void bn1d_relu_dropout(const float* __restrict__ x, float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------- launchers
-static int g_conv_bf16x3 = 3;         // convolutions on the bf16 matrix pipes with 3-term split operands (conv3x3_bf16x3): bit 0 forward, bit 1 data-gradient launches
+static int g_conv_bf16x3 = 3;         // convolutions on the bf16 matrix pipes with 3-term split operands (conv3x3_split<.., 3>): bit 0 forward, bit 1 data-gradient launches
 void a2s_conv_bf16x3_set(int on) { g_conv_bf16x3 = on; }
 int a2s_conv_bf16x3_enabled(void) { return g_conv_bf16x3; }
+// ... and of those, which use the TWO-term fp16 split instead (conv3x3_split<.., 2>: three products instead of six); a data-gradient
+// launch additionally needs the max |dy| scalar of its operand (a2s_conv3x3_dgrad_bnstats_scaled) and stays on three terms without it
+static int g_conv_f16x2 = -1;
+void a2s_conv_f16x2_set(int on) { g_conv_f16x2 = on; }
+int a2s_conv_f16x2_enabled(void) {
+    if (g_conv_f16x2 < 0) { const char* e = getenv("A2S_CONV_F16X2"); g_conv_f16x2 = e ? atoi(e) : 3; }
+    return g_conv_f16x2;
+}
 
 size_t a2s_conv3x3_workspace_floats_impl(int Cin) {
     if (Cin == 1) return 0;
     const size_t f32_image = (size_t)(Cin / CV_CK) * C2_WCHUNK, split_image = (size_t)c4_chunks(Cin) * c4_chunk_bytes(40) / 4;
-    return f32_image > split_image ? f32_image : split_image;
+    return (f32_image > split_image ? f32_image : split_image) + 4;          // + the max |w| scalar of the two-term path
 }
 
 int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin);
 
 int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, const float* in_scale,
                      const float* in_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* ws,
-                     const float* yl, const float* yl_mean, const float* yl_invstd, const float* yl_scale, const float* yl_shift) {
+                     const float* yl, const float* yl_mean, const float* yl_invstd, const float* yl_scale, const float* yl_shift,
+                     const float* x_absmax) {
     A2S_REQUIRE(x && w && y, "conv3x3: null tensor");
     A2S_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     A2S_REQUIRE(!yl || (yl_mean && yl_invstd && yl_scale && yl_shift && stat_partial && Cin != 1), "conv3x3: the fused BatchNorm-backward statistics need all of their tensors");
-    ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, yl, yl_mean, yl_invstd, yl_scale, yl_shift};
+    ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, yl, yl_mean, yl_invstd, yl_scale, yl_shift, x_absmax, nullptr};
     if (Cin == 1) {
         A2S_REQUIRE(Cout <= 20 && !flip && !in_scale, "conv3x3: Cin=1 path supports Cout<=20, no flip, no input affine");
         hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_conv3x3_stat_blocks_impl(B, T, F, 1)), dim3(256), 0, st, a);
@@ -789,17 +882,34 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
         A2S_REQUIRE(Cout == 20 || Cout == 40, "conv3x3: Cout must be 20 or 40 (got %d)", Cout);
         const int nblk4 = B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
         if (g_conv_bf16x3 & (flip ? 2 : 1)) {
+            // two fp16 terms when enabled -- a gradient operand (flip) only with its max |x| scalar: fp16 has no exponent range to spare
+            const bool two = (a2s_conv_f16x2_enabled() & (flip ? 2 : 1)) && (!flip || x_absmax);
+            const int terms = two ? 2 : 3;
             const int n = c4_chunks(Cin) * C4_SLOTS * Cout * 8;
-            const hipError_t me = hipMemsetAsync(ws, 0, c4_chunks(Cin) * c4_chunk_bytes(Cout), st);
+            const size_t image = c4_chunks(Cin) * c4_chunk_bytes(Cout, terms);
+            const hipError_t me = hipMemsetAsync(ws, 0, image, st);
             A2S_REQUIRE(me == hipSuccess, "conv3x3: hipMemsetAsync(packed weights): %s", hipGetErrorString(me));
-            hipLaunchKernelGGL(conv_pack_weights_bf16x3, dim3(a2s_cdiv(n, 256)), dim3(256), 0, st, w, (unsigned short*)ws, Cin, Cout, flip);
-            A2S_CHECK_LAUNCH("conv_pack_weights_bf16x3");
+            float* wmax = ws + a2s_conv3x3_workspace_floats_impl(Cin) - 4;
             const unsigned char* wp = (const unsigned char*)ws;
-            if (Cout == 20 && !yl) hipLaunchKernelGGL((conv3x3_bf16x3<20, false>), dim3(nblk4), dim3(256), 0, st, a, wp);
-            else if (Cout == 20) hipLaunchKernelGGL((conv3x3_bf16x3<20, true>), dim3(nblk4), dim3(256), 0, st, a, wp);
-            else if (!yl) hipLaunchKernelGGL((conv3x3_bf16x3<40, false>), dim3(nblk4), dim3(256), 0, st, a, wp);
-            else hipLaunchKernelGGL((conv3x3_bf16x3<40, true>), dim3(nblk4), dim3(256), 0, st, a, wp);
-            A2S_CHECK_LAUNCH("conv3x3_bf16x3");
+            if (two) {
+                hipLaunchKernelGGL(absmax_small, dim3(1), dim3(256), 0, st, w, Cout * Cin * 9, wmax);
+                hipLaunchKernelGGL(conv_pack_weights_split<2>, dim3(a2s_cdiv(n, 256)), dim3(256), 0, st, w, (unsigned short*)ws, Cin, Cout, flip, (const float*)wmax);
+                A2S_CHECK_LAUNCH("conv_pack_weights_split<2>");
+                a.w_absmax = wmax;
+                if (Cout == 20 && !yl) hipLaunchKernelGGL((conv3x3_split<20, false, 2>), dim3(nblk4), dim3(256), 0, st, a, wp);
+                else if (Cout == 20) hipLaunchKernelGGL((conv3x3_split<20, true, 2>), dim3(nblk4), dim3(256), 0, st, a, wp);
+                else if (!yl) hipLaunchKernelGGL((conv3x3_split<40, false, 2>), dim3(nblk4), dim3(256), 0, st, a, wp);
+                else hipLaunchKernelGGL((conv3x3_split<40, true, 2>), dim3(nblk4), dim3(256), 0, st, a, wp);
+                A2S_CHECK_LAUNCH("conv3x3_split<2>");
+                return A2S_OK;
+            }
+            hipLaunchKernelGGL(conv_pack_weights_split<3>, dim3(a2s_cdiv(n, 256)), dim3(256), 0, st, w, (unsigned short*)ws, Cin, Cout, flip, (const float*)nullptr);
+            A2S_CHECK_LAUNCH("conv_pack_weights_split<3>");
+            if (Cout == 20 && !yl) hipLaunchKernelGGL((conv3x3_split<20, false, 3>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            else if (Cout == 20) hipLaunchKernelGGL((conv3x3_split<20, true, 3>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            else if (!yl) hipLaunchKernelGGL((conv3x3_split<40, false, 3>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            else hipLaunchKernelGGL((conv3x3_split<40, true, 3>), dim3(nblk4), dim3(256), 0, st, a, wp);
+            A2S_CHECK_LAUNCH("conv3x3_split<3>");
             return A2S_OK;
         }
         const int chunks = Cin / CV_CK;
@@ -927,14 +1037,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__
 __global__ void bn_bwd_apply(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean,
                              const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
                              const float* __restrict__ c12, const uint8_t* __restrict__ mask, float inv_keep,
-                             float* __restrict__ dx, long n, int C, int F) {
+                             float* __restrict__ dx, long n, int C, int F, float* __restrict__ absmax) {
     const long stride = (long)gridDim.x * blockDim.x;
+    float am = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int c = (int)((i / F) % C);
         const float xv = x[i];
         float gv = (xv * scale[c] + shift[c] > 0.f) ? g[i] : 0.f;
         if (mask) gv = mask[i] ? gv * inv_keep : 0.f;
-        dx[i] = scale[c] * (gv - c12[2 * c] - (xv - mean[c]) * invstd[c] * c12[2 * c + 1]);
+        const float o = scale[c] * (gv - c12[2 * c] - (xv - mean[c]) * invstd[c] * c12[2 * c + 1]);
+        dx[i] = o;
+        am = fmaxf(am, fabsf(o));
+    }
+    if (absmax) {           // max |dx| for the consumer's power-of-two operand scale (non-negative floats order like their bit patterns)
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(am));
     }
 }
 
@@ -943,8 +1060,9 @@ __global__ void bn_bwd_apply(const float* __restrict__ g, const float* __restric
 __global__ __launch_bounds__(256) void bn_bwd_apply_planes(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ c12,
-                                                           float* __restrict__ dx, int C, int F) {
+                                                           float* __restrict__ dx, int C, int F, float* __restrict__ absmax) {
     __shared__ float k[64 * 6];
+    float am = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) {
         k[c * 6 + 0] = mean[c]; k[c * 6 + 1] = invstd[c]; k[c * 6 + 2] = scale[c]; k[c * 6 + 3] = shift[c];
         k[c * 6 + 4] = c12[2 * c]; k[c * 6 + 5] = c12[2 * c + 1];
@@ -972,9 +1090,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(const float* __restri
             for (int e = 0; e < 4; ++e) {
                 const float gm = (xv[u][e] * kc[2] + kc[3] > 0.f) ? gv[u][e] : 0.f;
                 o[e] = kc[2] * (gm - kc[4] - (xv[u][e] - kc[0]) * kc[1] * kc[5]);
+                am = fmaxf(am, fabsf(o[e]));
             }
             d4[q] = o;
         }
+    }
+    if (absmax) {
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(am));
     }
 }
 
@@ -1595,8 +1718,12 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
 
 int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
                     const float* shift, const uint8_t* mask, float inv_keep, float* dgamma, float* dbeta, float* dx, float* partial,
-                    float* c12, long rows, int C, int F) {
+                    float* c12, long rows, int C, int F, float* dx_absmax) {
     A2S_REQUIRE(g && x && mean && invstd && scale && shift && dgamma && dbeta && partial && c12, "bn_bwd: null tensor");
+    if (dx_absmax && dx) {
+        const hipError_t me = hipMemsetAsync(dx_absmax, 0, sizeof(float), st);
+        A2S_REQUIRE(me == hipSuccess, "bn_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
+    }
     int nblocks;
     if (F > 1) {
         A2S_REQUIRE(!mask, "bn_bwd: dropout mask only supported on the (rows, C) layout");
@@ -1613,12 +1740,12 @@ int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float*
     if (!dx) return A2S_OK;            // statistics only: the input gradient is formed by the consumer (a2s_conv3x3_wgrad_bn)
     const long n = rows * C * F;
     if (F > 1 && F % 4 == 0 && C <= 64 && !mask && ((((uintptr_t)g | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)) {
-        hipLaunchKernelGGL(bn_bwd_apply_planes, dim3((unsigned)rows), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, dx, C, F);
+        hipLaunchKernelGGL(bn_bwd_apply_planes, dim3((unsigned)rows), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, dx, C, F, dx_absmax);
         A2S_CHECK_LAUNCH("bn_bwd_apply_planes");
         return A2S_OK;
     }
     hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, mask,
-                       inv_keep, dx, n, C, F);
+                       inv_keep, dx, n, C, F, dx_absmax);
     A2S_CHECK_LAUNCH("bn_bwd_apply");
     return A2S_OK;
 }
@@ -1627,19 +1754,23 @@ int a2s_bn_bwd_impl(hipStream_t st, const float* g, const float* x, const float*
 // a2s_conv3x3_dgrad_bnstats): finalize (dgamma, dbeta, c12) + apply.  (rows, C, F) layout only.
 int a2s_bn_bwd_from_partial_impl(hipStream_t st, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
                                  const float* shift, float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12,
-                                 long rows, int C, int F) {
+                                 long rows, int C, int F, float* dx_absmax) {
     A2S_REQUIRE(g && x && mean && invstd && scale && shift && dgamma && dbeta && partial && c12 && nblocks > 0, "bn_bwd_from_partial: null tensor");
+    if (dx_absmax && dx) {
+        const hipError_t me = hipMemsetAsync(dx_absmax, 0, sizeof(float), st);
+        A2S_REQUIRE(me == hipSuccess, "bn_bwd_from_partial: hipMemsetAsync: %s", hipGetErrorString(me));
+    }
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, st, partial, nblocks, C, (double)rows * F, dgamma, dbeta, c12);
     A2S_CHECK_LAUNCH("bn_bwd_finalize");
     if (!dx) return A2S_OK;
     const long n = rows * C * F;
     if (F > 1 && F % 4 == 0 && C <= 64 && ((((uintptr_t)g | (uintptr_t)x | (uintptr_t)dx) & 15) == 0)) {
-        hipLaunchKernelGGL(bn_bwd_apply_planes, dim3((unsigned)rows), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, dx, C, F);
+        hipLaunchKernelGGL(bn_bwd_apply_planes, dim3((unsigned)rows), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, dx, C, F, dx_absmax);
         A2S_CHECK_LAUNCH("bn_bwd_apply_planes");
         return A2S_OK;
     }
     hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12,
-                       (const uint8_t*)nullptr, 1.f, dx, n, C, F);
+                       (const uint8_t*)nullptr, 1.f, dx, n, C, F, dx_absmax);
     A2S_CHECK_LAUNCH("bn_bwd_apply");
     return A2S_OK;
 }
@@ -1699,7 +1830,7 @@ int a2s_bn_bwd_apply_impl(hipStream_t st, const float* g, const float* x, const 
     A2S_CHECK_LAUNCH("bn_bwd_c12_from_sums");
     const long n = rows * C * F;
     hipLaunchKernelGGL(bn_bwd_apply, dim3(min((long)4096, (n + 255) / 256)), dim3(256), 0, st, g, x, mean, invstd, scale, shift, c12, mask,
-                       inv_keep, dx, n, C, F);
+                       inv_keep, dx, n, C, F, (float*)nullptr);
     A2S_CHECK_LAUNCH("bn_bwd_apply");
     return A2S_OK;
 }

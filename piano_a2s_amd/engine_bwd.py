@@ -512,16 +512,17 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
     Cf = eng.cfg["conv_feature_size"]
     rows = B * T
 
-    def bn_bwd(g, x, bn, name, mask, n_rows, C_, F_, stats_only=False, partial=None):
+    def bn_bwd(g, x, bn, name, mask, n_rows, C_, F_, stats_only=False, partial=None, amax=None):
         """stats_only: dgamma / dbeta and the two per-channel means (returned) only -- the input gradient is then formed inside the
         weight-gradient kernel (a2s_conv3x3_wgrad_bn).  partial = (tensor, nblocks): the statistics partials were already produced by
         the data-gradient convolution that wrote g (a2s_conv3x3_dgrad_bnstats): no statistics pass."""
         mean, invstd, scale, shift = bn
         if partial is not None and not eng.sync_bn:
             c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
-            hip.check(L.a2s_bn_bwd_from_partial(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift),
-                                                hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), NULL if stats_only else hip._p(g),
-                                                hip._p(partial[0]), partial[1], hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd_from_partial")
+            hip.check(L.a2s_bn_bwd_from_partial_amax(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift),
+                                                     hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), NULL if stats_only else hip._p(g),
+                                                     hip._p(partial[0]), partial[1], hip._p(c12), C.c_long(n_rows), C_, F_, hip._p(amax)),
+                      "a2s_bn_bwd_from_partial")
             return c12 if stats_only else g
         part = torch.empty(L.a2s_bn_bwd_partial_floats(C.c_long(n_rows), C_, F_), dtype=torch.float32, device=dev)
         c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
@@ -536,9 +537,9 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                                          hip.f32(1.0 / 0.8), hip._p(local), hip._p(glob), C.c_double(eng.bn_counts[name]), hip._p(G[name + ".weight"]),
                                          hip._p(G[name + ".bias"]), hip._p(g), hip._p(c12), C.c_long(n_rows), C_, F_), "a2s_bn_bwd_apply")
             return g
-        hip.check(L.a2s_bn_bwd(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(mask), hip.f32(1.0 / 0.8),
-                               hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), NULL if stats_only else hip._p(g), hip._p(part), hip._p(c12),
-                               C.c_long(n_rows), C_, F_), "a2s_bn_bwd")
+        hip.check(L.a2s_bn_bwd_amax(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), hip._p(mask), hip.f32(1.0 / 0.8),
+                                    hip._p(G[name + ".weight"]), hip._p(G[name + ".bias"]), NULL if stats_only else hip._p(g), hip._p(part), hip._p(c12),
+                                    C.c_long(n_rows), C_, F_, hip._p(amax)), "a2s_bn_bwd")
         return c12 if stats_only else g                       # in place: g now holds dx
 
     # dropout + ReLU + BatchNorm1d over the (B*T, Cf) Linear output
@@ -584,8 +585,11 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         # the first layer has no data-gradient consumer: its BatchNorm input gradient is only read by the (streaming, HBM-bound)
         # weight-gradient kernel, which forms it on the fly -- one pass over (g, y) instead of apply (read 2, write 1) + read 1
         fuse_here = _FUSE_BN_APPLY or (i == 1 and _FUSE_BN_APPLY_L1)
+        # max |dy| of this layer's output gradient, reduced by the kernel that writes dy: the two-term fp16 data-gradient convolution
+        # below scales its operand by the matching power of two (gradients would otherwise sit in fp16's subnormal range)
+        dy_amax = torch.zeros(1, dtype=torch.float32, device=dev) if (i > 1 and not eng.sync_bn) else None
         if eng.sync_bn or not fuse_here:
-            dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F, partial=g_partial)
+            dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F, partial=g_partial, amax=dy_amax)
             hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
                                           hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
         else:
@@ -605,9 +609,10 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                 bn_l = cs["bn"][i - 2]
                 nblk = L.a2s_conv3x3_stat_blocks(B, T, F, co)
                 part = torch.empty((nblk, ci, 2), dtype=torch.float32, device=dev)
-                hip.check(L.a2s_conv3x3_dgrad_bnstats(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), hip._p(cs["y"][i - 2]),
-                                                      hip._p(bn_l[0]), hip._p(bn_l[1]), hip._p(bn_l[2]), hip._p(bn_l[3]), hip._p(part), B, T, F, co, ci,
-                                                      hip._p(cws)), "a2s_conv3x3_dgrad_bnstats")
+                hip.check(L.a2s_conv3x3_dgrad_bnstats_scaled(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev),
+                                                             hip._p(cs["y"][i - 2]), hip._p(bn_l[0]), hip._p(bn_l[1]), hip._p(bn_l[2]), hip._p(bn_l[3]),
+                                                             hip._p(part), B, T, F, co, ci, hip._p(cws),
+                                                             hip._p(dy_amax) if not fuse_here else NULL), "a2s_conv3x3_dgrad_bnstats")
                 g_partial = (part, nblk)
             else:
                 hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), NULL, NULL, NULL, B, T, F, co, ci, 1,
