@@ -260,6 +260,9 @@ int a2s_bn_bwd_apply(void* stream, const float* g, const float* x, const float* 
 /* conv weight gradient dW += dy (*) relu(x*in_scale+in_shift)  (deterministic two-stage reduction) */
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
                       float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);
+/* ... with max |dy| (device scalar written by a2s_bn_bwd*_amax) for the two-term fp16 path of the split-operand kernel (NULL: as above) */
+int a2s_conv3x3_wgrad_scaled(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
+                             float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax);
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
 /* The same with the BatchNorm backward of the layer's output folded into the staging of the dy operand: g = gradient wrt
  * relu(bn(y)), y = the layer's pre-BN output, c12 from a2s_bn_bwd(..., dx = NULL); dy = scale*(g' - c1 - xhat*c2) is formed on the fly

@@ -75,7 +75,9 @@ int a2s_bn_bwd_from_partial_impl(hipStream_t, const float*, const float*, const 
                                  const float*, int, float*, long, int, int, float*);
 
 int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int,
-                           const float*, const float*, const float*, const float*, const float*, const float*, float*);
+                           const float*, const float*, const float*, const float*, const float*, const float*, float*, const float*);
+void a2s_wgrad_f16x2_set(int);
+int a2s_wgrad_f16x2_enabled(void);
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int, int);
 
 int a2s_nll_loss_impl(hipStream_t, const float*, const long long*, long, int, long long, float*, float*, float, double*, int);
@@ -127,6 +129,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_f16x2")) { a2s_conv_f16x2_set(value); return A2S_OK; }
+    if (!strcmp(key, "wgrad_f16x2")) { a2s_wgrad_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_bf16x3")) { a2s_gemm_split_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_bf16x3")) { a2s_wgrad_split_set(value); return A2S_OK; }
     snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
@@ -136,6 +139,7 @@ int a2s_debug_set(const char* key, int value) {
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_f16x2")) return a2s_conv_f16x2_enabled();
+    if (key && !strcmp(key, "wgrad_f16x2")) return a2s_wgrad_f16x2_enabled();
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();
     if (key && !strcmp(key, "wgrad_bf16x3")) return a2s_wgrad_split_enabled();
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
@@ -292,13 +296,18 @@ size_t a2s_bn_bwd_partial_floats(long rows, int C, int F) { return a2s_bn_bwd_pa
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
                       size_t workspace_bytes, int B, int T, int F, int Cin, int Cout) {
     return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, nullptr, nullptr);
+                                  nullptr, nullptr, nullptr, nullptr);
+}
+int a2s_conv3x3_wgrad_scaled(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
+                             size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax) {
+    return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, dy_absmax);
 }
 int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
                          const float* c12, float* dy_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
                          size_t workspace_bytes, int B, int T, int F, int Cin, int Cout) {
     if (!y) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_wgrad_bn: y is required"); return A2S_ERR_ARG; }
-    return a2s_conv3x3_wgrad_impl(ST, g, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, y, mean, invstd, scale, shift, c12, dy_out);
+    return a2s_conv3x3_wgrad_impl(ST, g, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, y, mean, invstd, scale, shift, c12, dy_out, nullptr);
 }
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) { return a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout); }
 

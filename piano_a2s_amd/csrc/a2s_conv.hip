@@ -1447,21 +1447,29 @@ __global__ void wgrad_reduce_c1(const float* __restrict__ partial, float* __rest
 #define W4_XCI (4 * W4_XROW + 16)         // 656: channel stride (pad -> conflict-free fragment reads across the 16 channels of a tile)
 #define W4_DYCO (2 * 128 + 16)            // 272: output-channel stride of the dy image [co][2 rows][64]
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int COUT>
-__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __restrict__ dy, const float* __restrict__ x,
-                                                               const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                                               float* __restrict__ partial, int B, int T, int F, int Cin) {
+// TERMS = 3: bf16 three-term split (six products); TERMS = 2: fp16 two-term split (three products), dy scaled by the power of two that
+// brings max |dy| (dy_absmax, device scalar; null = unscaled) to 2^12, the slab unscaled on the way out -- see conv3x3_split.
+template <int COUT, int TERMS>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                              float* __restrict__ partial, int B, int T, int F, int Cin,
+                                                              const float* __restrict__ dy_absmax) {
     constexpr int MT = (COUT + 15) / 16;
     constexpr int XPL = 48 * W4_XCI;          // bytes per term plane of the input image (48 channel planes; beyond Cin they stay zero)
     constexpr int DPL = MT * 16 * W4_DYCO;
-    __shared__ __attribute__((aligned(16))) unsigned char lx[3 * XPL];
-    __shared__ __attribute__((aligned(16))) unsigned char ldy[3 * DPL];
+    __shared__ __attribute__((aligned(16))) unsigned char lx[TERMS * XPL];
+    __shared__ __attribute__((aligned(16))) unsigned char ldy[TERMS * DPL];
     __shared__ __attribute__((aligned(16))) float lsc[48], lsh[48];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int nc16 = (Cin + 15) / 16, npair = 9 * nc16;
-    for (int e = tid; e < 3 * XPL / 16; e += 512) reinterpret_cast<uint4*>(lx)[e] = make_uint4(0u, 0u, 0u, 0u);
-    for (int e = tid; e < 3 * DPL / 16; e += 512) reinterpret_cast<uint4*>(ldy)[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int e = tid; e < TERMS * XPL / 16; e += 512) reinterpret_cast<uint4*>(lx)[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int e = tid; e < TERMS * DPL / 16; e += 512) reinterpret_cast<uint4*>(ldy)[e] = make_uint4(0u, 0u, 0u, 0u);
+    float dscale = 1.f, unscale = 1.f;
+    if (TERMS == 2 && dy_absmax) {
+        const int kd = pow2_scale_exp(*dy_absmax, 12);
+        dscale = ldexpf(1.f, kd); unscale = ldexpf(1.f, -kd);
+    }
     if (tid < 48) {
         lsc[tid] = (in_scale && tid < Cin) ? in_scale[tid] : 0.f;
         lsh[tid] = (in_scale && tid < Cin) ? in_shift[tid] : 0.f;
@@ -1544,11 +1552,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
             f32x4 v = dreg[it];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(__float_as_uint(v[q]) ^ sgn);
-            uint2 o[3];
-            split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
-            split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+            uint2 o[TERMS];
+            if (TERMS == 3) {
+                split3_pair(v[0], v[1], o[0].x, o[1].x, o[TERMS - 1].x);
+                split3_pair(v[2], v[3], o[0].y, o[1].y, o[TERMS - 1].y);
+            } else {
+                split2_pair_f16(v[0] * dscale, v[1] * dscale, o[0].x, o[1].x);
+                split2_pair_f16(v[2] * dscale, v[3] * dscale, o[0].y, o[1].y);
+            }
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint2*>(ldy + sp * DPL + co * W4_DYCO + r * 128 + fq * 8) = o[sp];
+            for (int sp = 0; sp < TERMS; ++sp) *reinterpret_cast<uint2*>(ldy + sp * DPL + co * W4_DYCO + r * 128 + fq * 8) = o[sp];
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -1562,23 +1575,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = (f + q < F) ? fmaxf(v[q] * sc + sh, 0.f) : 0.f;
             }
-            uint2 o[3];
-            split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
-            split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+            uint2 o[TERMS];
+            if (TERMS == 3) {
+                split3_pair(v[0], v[1], o[0].x, o[1].x, o[TERMS - 1].x);
+                split3_pair(v[2], v[3], o[0].y, o[1].y, o[TERMS - 1].y);
+            } else {
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint2*>(lx + sp * XPL + ci * W4_XCI + row * W4_XROW + (8 + 4 * fq) * 2) = o[sp];
+                for (int q = 0; q < 4; ++q) v[q] = fminf(fmaxf(v[q], -65000.f), 65000.f);
+                split2_pair_f16(v[0], v[1], o[0].x, o[1].x);
+                split2_pair_f16(v[2], v[3], o[0].y, o[1].y);
+            }
+#pragma unroll
+            for (int sp = 0; sp < TERMS; ++sp) *reinterpret_cast<uint2*>(lx + sp * XPL + ci * W4_XCI + row * W4_XROW + (8 + 4 * fq) * 2) = o[sp];
         }
         if (tid < Cin * 8) {
             const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
             const int t = t0 + row - 1, f = side ? f0 + 64 : f0 - 1;
             float v = hreg;
             if (in_scale && t >= 0 && t < T && f >= 0 && f < F) v = fmaxf(v * lsc[ci] + lsh[ci], 0.f);
-            unsigned p0, p1, p2;
-            split3_pair(v, 0.f, p0, p1, p2);
+            unsigned p0, p1, p2 = 0;
+            if (TERMS == 3) split3_pair(v, 0.f, p0, p1, p2);
+            else split2_pair_f16(fminf(fmaxf(v, -65000.f), 65000.f), 0.f, p0, p1);
             unsigned char* dst = lx + ci * W4_XCI + row * W4_XROW + (side ? 72 : 7) * 2;
             *reinterpret_cast<unsigned short*>(dst) = (unsigned short)p0;
             *reinterpret_cast<unsigned short*>(dst + XPL) = (unsigned short)p1;
-            *reinterpret_cast<unsigned short*>(dst + 2 * XPL) = (unsigned short)p2;
+            if (TERMS == 3) *reinterpret_cast<unsigned short*>(dst + (TERMS - 1) * XPL) = (unsigned short)p2;
         }
     };
     if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -1602,22 +1623,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
         // once per 16 positions.
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            bf16x8 a[2][3][MT];
+            u32x4 a[2][TERMS][MT];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
+                for (int sp = 0; sp < TERMS; ++sp)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
-                        a[h][sp][i] = *reinterpret_cast<const bf16x8*>(ldy + sp * DPL + (i * 16 + li) * W4_DYCO + r * 128 + (lk * 16 + h * 8) * 2);
+                        a[h][sp][i] = *reinterpret_cast<const u32x4*>(ldy + sp * DPL + (i * 16 + li) * W4_DYCO + r * 128 + (lk * 16 + h * 8) * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (wave + 8 * j >= npair) continue;            // uniform per wave
                 const int df = pj_df[j];
                 const unsigned char* base = lx + pj_off[j] + r * W4_XROW + (lk * 16 + 8) * 2;
-                bf16x8 bfrag[2][3];
+                u32x4 bfrag[2][TERMS];
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) {
+                for (int sp = 0; sp < TERMS; ++sp) {
                     const u32x4 d0 = *reinterpret_cast<const u32x4*>(base + sp * XPL);
                     const u32x4 d1 = *reinterpret_cast<const u32x4*>(base + sp * XPL + 16);
                     u32x4 w0 = d0, w1 = d1;                      // df == 1: the aligned windows
@@ -1634,14 +1655,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
                         w1[0] = __builtin_amdgcn_alignbit(d1[1], d1[0], 16); w1[1] = __builtin_amdgcn_alignbit(d1[2], d1[1], 16);
                         w1[2] = __builtin_amdgcn_alignbit(d1[3], d1[2], 16); w1[3] = __builtin_amdgcn_alignbit(d8, d1[3], 16);
                     }
-                    bfrag[0][sp] = __builtin_bit_cast(bf16x8, w0);
-                    bfrag[1][sp] = __builtin_bit_cast(bf16x8, w1);
+                    bfrag[0][sp] = w0;
+                    bfrag[1][sp] = w1;
                 }
 #define W4_PRODUCT(SA, SB)                                                                                                   \
                 _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                \
                     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h][SA][i], bfrag[h][SB], acc[j][i], 0, 0, 0);
-                W4_PRODUCT(2, 0) W4_PRODUCT(1, 1) W4_PRODUCT(0, 2) W4_PRODUCT(1, 0) W4_PRODUCT(0, 1) W4_PRODUCT(0, 0)
+                        acc[j][i] = (TERMS == 3) ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[h][SA][i]), __builtin_bit_cast(bf16x8, bfrag[h][SB]), acc[j][i], 0, 0, 0) \
+                                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[h][SA][i]), __builtin_bit_cast(f16x8, bfrag[h][SB]), acc[j][i], 0, 0, 0);
+                if (TERMS == 3) { W4_PRODUCT(TERMS - 1, 0) W4_PRODUCT(1, 1) W4_PRODUCT(0, TERMS - 1) }
+                W4_PRODUCT(1, 0) W4_PRODUCT(0, 1) W4_PRODUCT(0, 0)
 #undef W4_PRODUCT
             }
         }
@@ -1657,14 +1680,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3(const float* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = i * 16 + lk * 4 + r;
-                if (co < COUT && ci < Cin) partial[(((long)blockIdx.x * COUT + co) * Cin + ci) * 9 + tap] = acc_neg ? -acc[j][i][r] : acc[j][i][r];
+                if (co < COUT && ci < Cin) partial[(((long)blockIdx.x * COUT + co) * Cin + ci) * 9 + tap] = (acc_neg ? -acc[j][i][r] : acc[j][i][r]) * unscale;
             }
     }
 }
 
-static int g_wgrad_split = 1;          // conv3x3_wgrad_bf16x3 for the plain weight-gradient launches: 1 = where it is faster (40 -> 40 channels), 2 = every eligible launch
+static int g_wgrad_split = 1;          // conv3x3_wgrad_split for the plain weight-gradient launches: 1 = where it is faster, 2 = every eligible launch
 void a2s_wgrad_split_set(int on) { g_wgrad_split = on; }
 int a2s_wgrad_split_enabled(void) { return g_wgrad_split; }
+static int g_wgrad_f16x2 = -1;         // ... with two fp16 terms (needs the max |dy| scalar) instead of three bf16 terms
+void a2s_wgrad_f16x2_set(int on) { g_wgrad_f16x2 = on; }
+int a2s_wgrad_f16x2_enabled(void) {
+    if (g_wgrad_f16x2 < 0) { const char* e = getenv("A2S_WGRAD_F16X2"); g_wgrad_f16x2 = e ? atoi(e) : 1; }
+    return g_wgrad_f16x2;
+}
 
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
@@ -1673,7 +1702,8 @@ size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
 
 int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
                            float* ws, size_t ws_bytes, int B, int T, int F, int Cin, int Cout, const float* bn_y, const float* bn_mean,
-                           const float* bn_invstd, const float* bn_scale, const float* bn_shift, const float* bn_c12, float* dy_out) {
+                           const float* bn_invstd, const float* bn_scale, const float* bn_shift, const float* bn_c12, float* dy_out,
+                           const float* dy_absmax) {
     A2S_REQUIRE(dy && x && dW && ws, "conv3x3_wgrad: null tensor");
     A2S_REQUIRE(!bn_y || (bn_mean && bn_invstd && bn_scale && bn_shift && bn_c12), "conv3x3_wgrad: the fused BatchNorm backward needs all of its tensors");
     A2S_REQUIRE(!dy_out || bn_y, "conv3x3_wgrad: dy_out is only written by the fused BatchNorm backward");
@@ -1689,12 +1719,19 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
             return A2S_OK;
         }
     }
-    if (g_wgrad_split && !bn_y && Cin > 1 && Cin <= 40 && (Cout == 20 || Cout == 40) && (g_wgrad_split > 1 || (Cin == 40 && Cout == 40))) {
+    const bool two = a2s_wgrad_f16x2_enabled() && dy_absmax;          // two fp16 terms: with the operand's max |dy| only
+    // measured at B = 64 (tools/conv_f16x2_check.py; fp32-input kernel / three bf16 terms / two fp16 terms): 40 -> 40: 12.3 / 9.9 / 7.1 ms,
+    // 20 -> 40: 6.3 / 7.4 / 5.3 ms, 20 -> 20: 4.6 / 6.2 / 4.6 ms -- the three-term kernel only pays off at 40 -> 40 channels, the two-term
+    // one for 40 output channels (wgrad_bf16x3 = 2 / wgrad_f16x2 = 2: every eligible launch regardless)
+    const bool split_here = g_wgrad_split > 1 || (Cin == 40 && Cout == 40) || (two && (Cout == 40 || a2s_wgrad_f16x2_enabled() > 1));
+    if (g_wgrad_split && !bn_y && Cin > 1 && Cin <= 40 && (Cout == 20 || Cout == 40) && split_here) {
         const int nslabs = 256;               // one 512-thread workgroup per CU
         A2S_REQUIRE(ws_bytes >= (size_t)nslabs * Cout * Cin * 9 * sizeof(float), "conv3x3_wgrad: workspace too small for the split-operand kernel");
-        if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_bf16x3<20>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
-        else hipLaunchKernelGGL((conv3x3_wgrad_bf16x3<40>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin);
-        A2S_CHECK_LAUNCH("conv3x3_wgrad_bf16x3");
+        if (two && Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_split<20, 2>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, dy_absmax);
+        else if (two) hipLaunchKernelGGL((conv3x3_wgrad_split<40, 2>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, dy_absmax);
+        else if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_split<20, 3>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, (const float*)nullptr);
+        else hipLaunchKernelGGL((conv3x3_wgrad_split<40, 3>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, (const float*)nullptr);
+        A2S_CHECK_LAUNCH("conv3x3_wgrad_split");
         hipLaunchKernelGGL(wgrad_reduce_c1, dim3(a2s_cdiv(Cout * Cin * 9, 256)), dim3(256), 0, st, ws, dW, nslabs, Cout * Cin * 9);
         A2S_CHECK_LAUNCH("wgrad_reduce_c1");
         return A2S_OK;

@@ -61,6 +61,19 @@ _GROUP_STREAMS = {}
 _GROUP_POOL = None
 
 
+def staff_streams(device, group):
+    """(upper, lower) streams of a clip group's note decoders, inside the four-stream budget (group_stream): group 0 = the caller's
+    current (default) stream + side stream 1, the long-clip group = its own stream (current in its thread) + side stream 0.  The
+    upper staff's step loop is issued by a worker thread INTO the stream the group's bar-level chain and heads also use -- the loop
+    is the long pole (398 vs 189 steps), the bar-level kernels interleave with it -- so each group's lower staff gets a hardware queue
+    of its own and the long-clip group's two staves run side by side instead of one after the other (1292 -> 876 dependent steps)."""
+    cur = torch.cuda.current_stream()
+    side = side_streams(device, 0)
+    if _os.environ.get("A2S_STAFF_ON_OWN_STREAM", "1") == "0":          # A/B: round-2's first layout (group 0 on the two side streams,
+        return side if group == 0 else (cur, cur)                       # the long-clip group's staves one after the other on its stream)
+    return (cur, side[1]) if group == 0 else (cur, side[0])
+
+
 def group_stream(device, group):
     """The ONE stream everything of clip group `group` > 0 runs on (group 0: the caller's current stream + side_streams).
 
@@ -150,11 +163,13 @@ def fork_on_streams(device, streams, fns):
     fork = torch.cuda.Event()
     fork.record()
     dev_index = _dev_index(device)
+    caller_stream = torch.cuda.current_stream()
 
     def task(st, fn):
         torch.cuda.set_device(dev_index)
-        if st == torch.cuda.current_stream():
-            return fn(), None
+        if st == caller_stream:                # the caller's own stream (stream order does the fork / join): just issue from this thread
+            with torch.cuda.stream(st):
+                return fn(), None
         st.wait_event(fork)                    # everything the loop reads was enqueued before the fork
         with torch.cuda.stream(st):
             r = fn()
@@ -540,9 +555,8 @@ class Engine:
             else:
                 up_out_g, lo_out_g = up_out[b0:b1], lo_out[b0:b1]
                 gt_bm = None
-            # the long-clip groups run both staves one after the other on their single stream (group_stream: the stream budget)
-            concurrent_g = concurrent and gidx == 0
-            streams = side_streams(dev, 0) if concurrent_g else None
+            concurrent_g = concurrent and gidx <= 1           # (a third group would have no stream left: everything in order on its own)
+            streams = staff_streams(dev, gidx) if concurrent_g else None
 
             def rand(shape):
                 return torch.rand(shape, device=dev, generator=gen)

@@ -9,6 +9,7 @@ does not depend on the recurrence is deferred and batched over all steps of a (b
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -28,7 +29,9 @@ _COLSUM_WS = {}
 def _colsum(x, ld, out, rows, ncol, x_off=0, out_off=0, beta=1.0):
     ws = None
     if rows >= 2048:                                  # two-stage reduction scratch, one buffer per (device, stream), reused
-        key = (x.device, torch.cuda.current_stream().cuda_stream)
+        # (per host thread as well: two threads may issue into ONE stream -- engine.staff_streams -- and a reduction's two launches must
+        # not be interleaved with another reduction that uses the same scratch)
+        key = (x.device, torch.cuda.current_stream().cuda_stream, threading.get_ident())
         ws = _COLSUM_WS.get(key)
         if ws is None or ws.numel() < 1024 * ncol:
             ws = _COLSUM_WS[key] = torch.empty(1024 * max(ncol, 2048), dtype=torch.float32, device=x.device)
@@ -219,7 +222,7 @@ class Backward:
     def decoder_group(self, gidx, gs, dts_g, dkey_g, dup_g, dlo_g):
         """Decoder backward of clip group gidx (gs: what Engine.forward saved for it) on the calling thread's current stream (+ the two
         side streams for group 0).  d*_g: gradients wrt the group's four output views (gs["outs"])."""
-        from .engine import fork_on_streams, side_streams
+        from .engine import fork_on_streams, staff_streams
         eng, S, G, dev, T = self.eng, self.S, self.G, self.dev, self.T
         names, offs, group_flat, group_ptrs = self.names, self.offs, self.group_flat, self.group_ptrs
         dEnc, dK, dEnc_staff, d_hidden = self.dEnc, self.dK, self.dEnc_staff, self.d_hidden
@@ -239,8 +242,8 @@ class Backward:
         dK_g = {p: t[b0:b1] for p, t in dK.items()}
         dEnc_staff_g = [t[b0:b1] for t in dEnc_staff]
         ts_out_g, key_out_g, up_out_g, lo_out_g = gs["outs"]
-        concurrent_g = concurrent and gidx == 0           # the long-clip groups: everything in order on their one stream
-        streams = side_streams(dev, 0) if concurrent_g else None
+        concurrent_g = concurrent and gidx <= 1           # as in Engine.forward (engine.staff_streams)
+        streams = staff_streams(dev, gidx) if concurrent_g else None
         use_deferred_g = use_deferred and gidx == 0
         deferred_streams = _deferred_streams(dev, gidx) if use_deferred_g else None
         deferred_done = []
@@ -590,8 +593,9 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         dy_amax = torch.zeros(1, dtype=torch.float32, device=dev) if (i > 1 and not eng.sync_bn) else None
         if eng.sync_bn or not fuse_here:
             dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F, partial=g_partial, amax=dy_amax)
-            hip.check(L.a2s_conv3x3_wgrad(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
-                                          hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co), "a2s_conv3x3_wgrad")
+            hip.check(L.a2s_conv3x3_wgrad_scaled(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
+                                                 hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co, hip._p(dy_amax)),
+                      "a2s_conv3x3_wgrad")
         else:
             # BatchNorm backward: statistics pass only; dy = scale (g' - c1 - xhat c2) is formed by the weight-gradient kernel while
             # it stages its dy operand (MFMA-bound, HBM to spare) and written out for the data-gradient convolution below

@@ -56,7 +56,7 @@ def lib():
         for fn in ("a2s_note_step_workspace_floats", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
                    "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
-        for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"), ("A2S_CONV_F16X2", b"conv_f16x2"),
+        for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"), ("A2S_CONV_F16X2", b"conv_f16x2"), ("A2S_WGRAD_F16X2", b"wgrad_f16x2"),
                          ("A2S_DEC_FUSED", b"dec_fused"), ("A2S_DEC_FUSED_MAX_ROWS", b"dec_fused_max_rows")):
             if os.environ.get(env):
                 _lib.a2s_debug_set(key, int(os.environ[env]))

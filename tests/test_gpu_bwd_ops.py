@@ -451,3 +451,36 @@ def test_weight_gradient_with_fused_batchnorm_backward(dev, Cin, Cout, F):
     for k, e in errs.items():
         _report(f"wgrad+bn fused Cin{Cin} Cout{Cout} F{F} {k}", e)
     assert max(errs.values()) < 2e-5, errs
+
+
+@pytest.mark.parametrize("ci,co,gmag", [(20, 40, 3e-5), (40, 40, 1e-8), (20, 20, 2.0)])
+def test_conv_weight_gradient_two_term_fp16(dev, ci, co, gmag):
+    """a2s_conv3x3_wgrad_scaled (conv3x3_wgrad_split<.., 2>: dy and the activated input as two fp16 terms each, three MFMA products, dy
+    scaled by the power of two derived from the max |dy| scalar) against float64, at gradient magnitudes from 1e-8 to O(1); error relative
+    to sum |dy||x| at the fp32-input kernel's level."""
+    import ctypes as C
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    torch.manual_seed(3)
+    b, T, F = 2, 23, 132
+    x = torch.randn(b, T, ci, F)
+    dy = gmag * torch.randn(b, T, co, F) * torch.exp(torch.randn(b, T, co, F))
+    scale, shift = torch.rand(ci) + 0.5, torch.randn(ci) * 0.1
+    act = torch.relu(x.double() * scale.double()[None, None, :, None] + shift.double()[None, None, :, None]).permute(0, 2, 1, 3)
+    g = dy.double().permute(0, 2, 1, 3)
+    ref = torch.nn.grad.conv2d_weight(act, (co, ci, 3, 3), g, padding=1)
+    mag = torch.nn.grad.conv2d_weight(act.abs(), (co, ci, 3, 3), g.abs(), padding=1)
+    xd, dyd, scd, shd = x.to(dev), dy.to(dev), scale.to(dev), shift.to(dev)
+    amax = dyd.abs().max().reshape(1)
+    nb = L.a2s_conv3x3_wgrad_workspace_bytes(ci, co)
+    ws = torch.empty(nb // 4, device=dev)
+    try:
+        L.a2s_debug_set(b"wgrad_f16x2", 2)                     # every eligible launch on the two-term kernel
+        dW = torch.zeros(co, ci, 3, 3, device=dev)
+        hip.check(L.a2s_conv3x3_wgrad_scaled(hip.stream(), hip._p(dyd), hip._p(xd), hip._p(scd), hip._p(shd), hip._p(dW), hip._p(ws), C.c_size_t(nb),
+                                             b, T, F, ci, co, hip._p(amax)), "wgrad")
+        torch.cuda.synchronize()
+    finally:
+        L.a2s_debug_set(b"wgrad_f16x2", 1)
+    err = ((dW.cpu().double() - ref).abs() / mag).max().item()
+    assert err < 2e-7, err

@@ -41,7 +41,7 @@ def main():
         target = _Env()
     else:
         target = step
-    b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=0.0)
+    b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=float(os.environ.get("A2S_AB_TAIL", "0.01")))
     b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
     for v in (False, True):
         setattr(target, a.attr, v)
@@ -57,6 +57,9 @@ def main():
             torch.cuda.synchronize()
             tot[v].append(time.time() - t0)
     ms = torch.cuda.memory_stats()
+    import statistics
+    d = [x - y for x, y in zip(tot[False], tot[True])]
+    print(f"paired difference False - True: mean {statistics.mean(d) * 1e3:+.1f} ms, stdev {statistics.pstdev(d) * 1e3:.1f} ms over {len(d)} pairs")
     print("order False/True per pair (ms):", " ".join(f"{x * 1e3:.0f}/{y * 1e3:.0f}" for x, y in zip(tot[False], tot[True])))
     print(f"alloc retries {ms['num_alloc_retries']}, reserved {ms['reserved_bytes.all.peak'] / 2**30:.1f} GiB, allocated peak "
           f"{ms['allocated_bytes.all.peak'] / 2**30:.1f} GiB, hipMalloc calls {ms['segment.all.allocated']}")

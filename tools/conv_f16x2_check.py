@@ -103,3 +103,59 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def wgrad_check(B):
+    """Weight gradient: fp32-input MFMA kernel / three-term bf16 / two-term fp16 against float64, then durations at the training shapes."""
+    dev = torch.device("cuda:0")
+    L = hip.lib()
+    torch.manual_seed(1)
+
+    def run(dy, x, scale, shift, ci, co, amax):
+        b, T, _, F = x.shape
+        dW = torch.zeros(co, ci, 3, 3, device=dev)
+        nb = L.a2s_conv3x3_wgrad_workspace_bytes(ci, co)
+        ws = torch.empty(nb // 4, device=dev)
+        hip.check(L.a2s_conv3x3_wgrad_scaled(hip.stream(), hip._p(dy), hip._p(x), hip._p(scale), hip._p(shift), hip._p(dW), hip._p(ws), C.c_size_t(nb),
+                                             b, T, F, ci, co, hip._p(amax)), "wgrad")
+        return dW
+
+    modes = (("fp32", 0, 0), ("bf16x3", 2, 0), ("f16x2", 2, 2))
+    for (b, T, F, ci, co, gmag) in ((2, 37, 100, 20, 20, 1e-6), (2, 64, 480, 20, 40, 3e-4), (2, 64, 480, 40, 40, 1e-8)):
+        x = torch.randn(b, T, ci, F, device=dev)
+        dy = gmag * torch.randn(b, T, co, F, device=dev) * torch.exp(torch.randn(b, T, co, F, device=dev))
+        scale, shift = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+        act = torch.relu(x.double() * scale.double()[None, None, :, None] + shift.double()[None, None, :, None]).permute(0, 2, 1, 3).cpu()
+        g = dy.double().permute(0, 2, 1, 3).cpu()
+        ref = torch.nn.grad.conv2d_weight(act, (co, ci, 3, 3), g, padding=1)
+        mag = torch.nn.grad.conv2d_weight(act.abs(), (co, ci, 3, 3), g.abs(), padding=1) + 1e-300
+        amax = dy.abs().max().reshape(1).float()
+        line = f"wgrad B{b} T{T} F{F} {ci:2d}->{co:2d} |dy|~{gmag:.0e}:"
+        for name, sp, f16 in modes:
+            L.a2s_debug_set(b"wgrad_bf16x3", sp)
+            L.a2s_debug_set(b"wgrad_f16x2", f16)
+            dW = run(dy, x, scale, shift, ci, co, amax)
+            torch.cuda.synchronize()
+            rel = (dW.double().cpu() - ref) / mag
+            line += f"  {name} max {rel.abs().max().item():.2e} mean {rel.mean().item():+.1e}{' NaN!' if torch.isnan(dW).any() else ''}"
+        print(line, flush=True)
+    T, F = 1201, 480
+    for ci, co, what in ((20, 20, "conv2 wgrad"), (20, 40, "conv3 wgrad"), (40, 40, "conv4 wgrad")):
+        x = torch.randn(B, T, ci, F, device=dev)
+        dy = 1e-5 * torch.randn(B, T, co, F, device=dev)
+        scale, shift = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+        amax = dy.abs().max().reshape(1).float()
+        flops = 2.0 * 9 * ci * co * B * T * F
+        line = f"{what:12s} {ci:2d}->{co:2d}"
+        for name, sp, f16 in modes:
+            L.a2s_debug_set(b"wgrad_bf16x3", sp)
+            L.a2s_debug_set(b"wgrad_f16x2", f16)
+            ms = timed(lambda: run(dy, x, scale, shift, ci, co, amax))
+            line += f"   {name} {ms:7.2f} ms {flops / ms / 1e9:6.1f} TFLOP/s"
+        print(line, flush=True)
+    L.a2s_debug_set(b"wgrad_bf16x3", 1)
+    L.a2s_debug_set(b"wgrad_f16x2", 1)
+
+
+if __name__ == "__main__" and os.environ.get("A2S_CHECK_WGRAD", "1") == "1":
+    wgrad_check(int(sys.argv[1]) if len(sys.argv) > 1 else 64)

@@ -1,0 +1,47 @@
+"""From a rocprofv3 --kernel-trace csv: how the long-clip group's per-step chain (dec_gru_step / dec_out_step / dec_bwd_* launches,
+which only that group issues) sits in time relative to the bulk group's kernels on the other queues.
+usage: python tools/trace_overlap.py <dir-with-*_kernel_trace.csv>"""
+import csv, glob, os, sys
+import numpy as np
+
+f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "")
+t0 = min(int(r["Start_Timestamp"]) for r in rows)
+K = [(name(r), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"), r.get("Stream_Id", "?")) for r in rows]
+K.sort(key=lambda k: k[1])
+queues = {}
+for k in K:
+    queues.setdefault(k[3], []).append(k)
+print("queues:", {q: len(v) for q, v in queues.items()})
+chain = [k for k in K if k[0].startswith(("dec_gru_step", "dec_out_step", "dec_bwd_products", "dec_bwd_query"))]
+if not chain:
+    sys.exit("no fused-step kernels in the trace")
+q1 = max(set(k[3] for k in chain), key=lambda q: sum(1 for k in chain if k[3] == q))
+print("long-clip group's queue:", q1, " kernels on it:", len(queues[q1]))
+g1 = queues[q1]
+# per-step period of the chain: time between consecutive dec_gru_step launches
+gs = [k for k in g1 if k[0].startswith("dec_gru_step")]
+per = np.diff([k[1] for k in gs])
+per = per[per < 1000]
+print(f"forward step period on that queue: median {np.median(per):.1f} us, p10 {np.quantile(per, .1):.1f}, p90 {np.quantile(per, .9):.1f}  ({len(per)} steps)")
+bs = [k for k in g1 if k[0].startswith("dec_bwd_products")]
+per = np.diff([k[1] for k in bs])
+per = per[per < 1000]
+if len(per):
+    print(f"backward step period: median {np.median(per):.1f} us, p10 {np.quantile(per, .1):.1f}, p90 {np.quantile(per, .9):.1f}  ({len(per)} steps)")
+# kernel durations on that queue, and the gaps between them
+byname = {}
+for a, b in zip(g1[:-1], g1[1:]):
+    byname.setdefault(a[0], []).append((a[2] - a[1], b[1] - a[2]))
+print("kernel                          n     dur_us(median)   gap_after_us(median)")
+for n, v in sorted(byname.items(), key=lambda kv: -len(kv[1]))[:14]:
+    d = np.array(v)
+    print(f"{n[:30]:30s} {len(v):6d} {np.median(d[:, 0]):10.1f} {np.median(d[:, 1]):14.1f}")
+# how busy are the other queues while the chain runs?
+lo, hi = g1[0][1], g1[-1][2]
+for q, v in queues.items():
+    if q == q1:
+        continue
+    busy = sum(min(k[2], hi) - max(k[1], lo) for k in v if k[2] > lo and k[1] < hi)
+    print(f"queue {q}: busy {100 * busy / (hi - lo):.0f} % of the chain's span ({(hi - lo) / 1e3:.0f} ms)")
