@@ -83,12 +83,16 @@ def conv_roofline(B, T, F, iters=6):
     flops = 2.0 * 9 * ci * co * B * T * F
     achieved = flops / avg_s / 1e12
     if L.a2s_debug_get(b"conv_bf16x3") & 1:
-        # forward convolutions run on the bf16 matrix pipes: every fp32 product is six bf16 term products, so the roof of the
-        # fp32-equivalent rate is the dense bf16 peak / 6 (the achieved figure stays the ALGORITHMIC fp32 flops of the launch)
-        peak = MFMA_BF16_PEAK_TFS / 6
-        return {"bound": "mfma", "kernel": "conv3x3_bf16x3<40, false> (conv4 forward launch, incl. its weight split/packing pre-kernel)",
+        # forward convolutions run on the 16-bit matrix pipes with exactly split fp32 operands: two fp16 terms / three term products per
+        # fp32 product (default) or three bf16 terms / six products -- the roof of the fp32-equivalent rate is the dense 16-bit MFMA peak
+        # divided by the products per fp32 product (the achieved figure stays the ALGORITHMIC fp32 flops of the launch)
+        two = bool(L.a2s_debug_get(b"conv_f16x2") & 1)
+        products = 3 if two else 6
+        peak = MFMA_BF16_PEAK_TFS / products
+        return {"bound": "mfma", "kernel": f"conv3x3_split<40, false, {2 if two else 3}> (conv4 forward launch, incl. its weight split/packing pre-kernels)",
                 "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense bf16 MFMA / 6 term products per fp32 product (3-term exact operand split)",
+                "peak_note": f"fp32-equivalent: 2.5 PFLOP/s dense {'fp16' if two else 'bf16'} MFMA / {products} term products per fp32 product "
+                             f"({'two-term fp16' if two else 'three-term bf16'} exact operand split)",
                 "frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFS, 4),
                 "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}
     return {"bound": "mfma", "kernel": "conv3x3_mfma<40, false> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
@@ -140,7 +144,7 @@ def attention_roofline(step, batch_dev, B, T, H, iters=50):
 # threads, in a child process under a hard timeout.  The oracle's per-step ops are small, so a host with hundreds of hardware threads
 # can be SLOWER with all of them (round 1: 256 threads did not finish one step in 15 min); the attempts below fall back -- all threads
 # -> 16 threads -> 16 threads on one clip -- and the line says which one ran and which ones timed out.
-CPU_BASELINE_ATTEMPTS = ((4, 0, 110), (4, 16, 150), (1, 16, 60))        # (clips, threads (0 = os.cpu_count()), timeout s)
+CPU_BASELINE_ATTEMPTS = ((4, 0, 75), (4, 16, 150), (1, 16, 60))        # (clips, threads (0 = os.cpu_count()), timeout s)
 
 
 def _cpu_model():
@@ -342,10 +346,12 @@ def main():
                                      "holding full-length bars decoded as a concurrent clip group (loss, gradients and update identical "
                                      "to the per-bar loop over the whole minibatch)",
                           "clip_groups": groups, "decode_steps_per_step": round(sum(decode_steps) / max(len(decode_steps), 1), 1),
-                          "arithmetic": "fp32 data and fp32 accumulation everywhere; the 3x3 convolutions (forward / data gradient, conv4 weight gradient) and the "
-                                        "128x128 GEMM tiles multiply on the bf16 matrix pipes with every fp32 operand carried as three exact "
-                                        "bf16 terms (six term products per fp32 product; element error vs float64 equal to the fp32-input "
-                                        "MFMA kernels', DESIGN.md section 3); A2S_CONV_BF16X3=0 A2S_GEMM_BF16X3=0 A2S_WGRAD_BF16X3=0 select the fp32-input kernels",
+                          "arithmetic": "fp32 data and fp32 accumulation everywhere; the 3x3 convolutions (forward, data gradient, conv3/conv4 weight "
+                                        "gradient) multiply on the fp16 matrix pipes with every fp32 operand carried as TWO exact fp16 terms under "
+                                        "power-of-two scales (three term products per fp32 product), the 128x128 GEMM tiles on the bf16 pipes with "
+                                        "three bf16 terms (six products); element error vs float64 equal to the fp32-input MFMA kernels' "
+                                        "(DESIGN.md section 3); A2S_CONV_F16X2=0 A2S_WGRAD_F16X2=0 select the three-term kernels, "
+                                        "A2S_CONV_BF16X3=0 A2S_GEMM_BF16X3=0 A2S_WGRAD_BF16X3=0 the fp32-input ones",
                           "final_loss": round(loss, 4), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}}
         if secondary is not None:
             out["tail_off"] = secondary

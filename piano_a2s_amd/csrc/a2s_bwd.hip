@@ -135,8 +135,10 @@ int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, 
     const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
     if (H == 256) hipLaunchKernelGGL(attn_step_bwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
+    else if (H == 128) hipLaunchKernelGGL(attn_step_bwd<128>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
+    else if (H == 64) hipLaunchKernelGGL(attn_step_bwd<64>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
     else if (H == 32) hipLaunchKernelGGL(attn_step_bwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
-    else A2S_FAIL(A2S_ERR_ARG, "attn_step_bwd: hidden_size must be 256 or 32 (got %d)", H);
+    else A2S_FAIL(A2S_ERR_ARG, "attn_step_bwd: hidden_size must be 32, 64, 128 or 256 (got %d)", H);
     A2S_CHECK_LAUNCH("attn_step_bwd");
     return A2S_OK;
 }
@@ -193,8 +195,10 @@ int a2s_attn_dk_accum_impl(hipStream_t st, const float* Kmat, const float* q_all
     const int nblk = B * a2s_cdiv(T, 16);
     if (groups < 1) groups = 1;
     if (H == 256) hipLaunchKernelGGL(attn_dk_accum<256>, dim3(nblk), dim3(256), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
+    else if (H == 128) hipLaunchKernelGGL(attn_dk_accum<128>, dim3(nblk), dim3(128), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
+    else if (H == 64) hipLaunchKernelGGL(attn_dk_accum<64>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
     else if (H == 32) hipLaunchKernelGGL(attn_dk_accum<32>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
-    else A2S_FAIL(A2S_ERR_ARG, "attn_dk_accum: hidden_size must be 256 or 32 (got %d)", H);
+    else A2S_FAIL(A2S_ERR_ARG, "attn_dk_accum: hidden_size must be 32, 64, 128 or 256 (got %d)", H);
     A2S_CHECK_LAUNCH("attn_dk_accum");
     return A2S_OK;
 }

@@ -363,8 +363,10 @@ int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, 
     const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 16) * sizeof(float);
     if (H == 256) hipLaunchKernelGGL(attn_step_fwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
+    else if (H == 128) hipLaunchKernelGGL(attn_step_fwd<128>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
+    else if (H == 64) hipLaunchKernelGGL(attn_step_fwd<64>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
     else if (H == 32) hipLaunchKernelGGL(attn_step_fwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
-    else A2S_FAIL(A2S_ERR_ARG, "attn_step_fwd: hidden_size must be 256 or 32 (got %d)", H);
+    else A2S_FAIL(A2S_ERR_ARG, "attn_step_fwd: hidden_size must be 32, 64, 128 or 256 (got %d)", H);
     A2S_CHECK_LAUNCH("attn_step_fwd");
     return A2S_OK;
 }

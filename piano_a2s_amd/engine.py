@@ -213,15 +213,16 @@ class Engine:
         self.sync_bn = bool(sync_bn) and _dist_world() >= 1
 
     def _global_stats(self, partial, nblocks, C_, count):
-        """(nblocks, C, 2) per-block partial sums of this rank -> (1, C, 2) sums of ALL ranks, global element count."""
+        """(nblocks, C, 2) per-block partial sums of this rank -> (1, C, 2) sums of ALL ranks, global element count.
+        The count is world x the local count, on the host: every rank of a data-parallel step holds the same number of clips and frames
+        (DistributedSampler pads the index list; the batches of one step have one shape), so no device-to-host read stalls the forward
+        pass five times per step (round 1 all-reduced the count and fetched it with .item())."""
         import torch.distributed as dist
         sums = torch.empty(2 * C_, dtype=torch.float32, device=partial.device)
         hip.check(hip.lib().a2s_col_sum(hip.stream(), hip._p(partial), C.c_long(2 * C_), hip._p(sums), C.c_long(nblocks), 2 * C_,
                                         hip.f32(1.0), hip.f32(0.0), C.c_void_p(0), C.c_size_t(0)), "a2s_col_sum (bn stats)")
-        cnt = torch.tensor([count], dtype=torch.float64, device=partial.device)
         dist.all_reduce(sums)
-        dist.all_reduce(cnt)
-        return sums, float(cnt.item())
+        return sums, float(count) * dist.get_world_size()
 
     # ------------------------------------------------------------------ helpers
     @staticmethod

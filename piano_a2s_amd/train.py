@@ -42,7 +42,7 @@ class GradientExchange:
         self.world = world
         # active whenever a process group exists -- also with a single rank (torchrun --nproc-per-node 1): the collectives then run
         # through RCCL exactly as with N ranks, which is what lets a 1-GPU box exercise the data-parallel path end to end
-        self.active = dist.is_available() and dist.is_initialized()
+        self.active = dist.is_available() and dist.is_initialized() and _os.environ.get("A2S_NO_EXCHANGE") != "1"      # (debug: A/B without the collectives)
         self.pending = []
         self.issued = 0
 

@@ -170,3 +170,38 @@ def test_full_size_seeded_teacher_forcing(golden_dir, dev):
         if e > (5e-4 if k.startswith("convstack.") else 2e-4):       # same bars as test_full_size_gradient_norms (see the note there)
             failures.append((k, e))
     assert not failures, f"{len(failures)} gradient norms off: {failures[:8]}"
+
+
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_other_hidden_sizes_forward_and_gradients(dev, hidden):
+    """hidden_size 64 / 128 (the reference constructor takes any width; the HIP attention kernels are instantiated for 32, 64, 128, 256):
+    forward log-probabilities, loss and all 83 gradients against the oracle on CPU, train mode, teacher forcing 0.6 (seeded)."""
+    import random
+    from oracle import model_ref, recipe_ref
+    from piano_a2s_amd import engine, engine_bwd, spec, synthetic
+    cfg = spec.default_cfg(freq_bins=24, conv_feature_size=48, hidden_size=hidden, max_length=(12, 8))
+    st = spec.procedural_state(cfg, 31, eos_bias=2.0, lively=True)
+    batch = synthetic.make_batch(3, cfg, 6, frames=37, upper_range=(3, 10), lower_range=(2, 7), full_tail=0.1)
+    P, Bf = spec.split_state(st)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = model_ref.forward(P, {k: v.clone() for k, v in Bf.items()}, cfg, batch[0], inference=False, ground_truth=[batch[i] for i in range(1, 7)],
+                            teacher_forcing_ratio=0.6, training=True, rng=random.Random(5), dropout=False)
+    rl = recipe_ref.objectives(ref, (batch[1], batch[2], batch[3], batch[5]))
+    rl[0].backward()
+    S = {k: v.to(dev) for k, v in st.items()}
+    eng = engine.Engine(cfg)
+    outs = eng.forward(S, batch[0].to(dev), inference=False, ground_truth=[b.to(dev) for b in batch[1:7]], teacher_forcing_ratio=0.6, training=True,
+                       dropout=False, rng=random.Random(5))
+    for name, o, r in zip(("ts", "key", "up", "lo"), outs, ref):
+        assert float((o.cpu() - r.detach()).abs().max()) <= 1e-4, name
+    losses, gouts = _loss_grads(outs, batch, dev)
+    assert abs(losses[0] - float(rl[0])) <= 1e-4 * abs(float(rl[0]))
+    G = engine_bwd.backward(eng, S, gouts)
+    torch.cuda.synchronize()
+    bad = []
+    for k, p in P.items():
+        rg = p.grad.double()
+        err = float((G[k].cpu().double() - rg).abs().max()) / max(float(rg.abs().max()), 1e-12)
+        if err > 2e-4:
+            bad.append((k, err))
+    assert not bad, bad[:6]
