@@ -470,12 +470,37 @@ __global__ __launch_bounds__(128) void staff_emb_bwd(const float* __restrict__ n
     for (int i = tid; i < S; i += nt) dh[i] = dout[(long)b * lddo + col0 + dir * S + i];
     int len = (int)lengths[(long)b * len_stride];
     len = max(0, min(len, maxlen));
+    // Latency: the recurrence is up to 398 dependent steps of a tiny cell, so anything that waits on global memory inside the loop is
+    // paid 398 times (round 1: token id -> embedding row -> h_prev, three dependent round trips per step, ~10 us per step, 4 ms per
+    // full-length row).  The row's token ids go to LDS once; the embedding row and h_prev of step s-1 are fetched into registers
+    // while step s computes; the index arithmetic of the gradient accumulations uses shifts when E and S are powers of two.
+    int* lid = reinterpret_cast<int*>(dh + S);          // maxlen ints behind the float scratch (the launcher sizes the LDS for it)
+    for (int i = tid; i < len; i += nt) {
+        const int t = dir ? len - 1 - i : i;
+        lid[i] = ids64 ? (int)ids64[(long)b * id_bstride + t] : ids32[(long)b * id_bstride + t];
+    }
+    const bool pre = E <= nt && S <= nt;                // one element per thread: register prefetch
+    const bool pow2 = (E & (E - 1)) == 0 && (S & (S - 1)) == 0;
+    const int esh = 31 - __clz(E), ssh = 31 - __clz(S);
     __syncthreads();
+    float xe_n = 0.f, hp_n = 0.f;
+    if (pre && len > 0) {
+        if (tid < E) xe_n = note_emb[(long)lid[len - 1] * E + tid];
+        if (tid < S && len > 1) hp_n = hsave[(((long)b * 2 + dir) * maxlen + len - 2) * S + tid];
+    }
     for (int s = len - 1; s >= 0; --s) {
-        const int t = dir ? len - 1 - s : s;
-        const long id = ids64 ? ids64[(long)b * id_bstride + t] : ids32[(long)b * id_bstride + t];
-        for (int i = tid; i < E; i += nt) xe[i] = note_emb[id * E + i];
-        for (int i = tid; i < S; i += nt) hp[i] = s > 0 ? hsave[(((long)b * 2 + dir) * maxlen + s - 1) * S + i] : 0.f;
+        const long id = lid[s];
+        if (pre) {
+            if (tid < E) xe[tid] = xe_n;
+            if (tid < S) hp[tid] = hp_n;
+            if (s > 0) {                                 // next step's operands: in flight during this step's arithmetic
+                if (tid < E) xe_n = note_emb[(long)lid[s - 1] * E + tid];
+                if (tid < S) hp_n = s > 1 ? hsave[(((long)b * 2 + dir) * maxlen + s - 2) * S + tid] : 0.f;
+            }
+        } else {
+            for (int i = tid; i < E; i += nt) xe[i] = note_emb[id * E + i];
+            for (int i = tid; i < S; i += nt) hp[i] = s > 0 ? hsave[(((long)b * 2 + dir) * maxlen + s - 1) * S + i] : 0.f;
+        }
         __syncthreads();
         for (int r = tid; r < 6 * S; r += nt) {          // recompute the pre-activations of this step
             float acc;
@@ -498,18 +523,33 @@ __global__ __launch_bounds__(128) void staff_emb_bwd(const float* __restrict__ n
             dh[tid] = d * zg;                              // direct path; recurrent path added below
         }
         __syncthreads();
-        for (int i = tid; i < 3 * S * E; i += nt) gWi[i] = fmaf(dgi[i / E], xe[i % E], gWi[i]);
-        for (int i = tid; i < 3 * S * S; i += nt) gWh[i] = fmaf(dgh[i / S], hp[i % S], gWh[i]);
-        for (int i = tid; i < 3 * S; i += nt) { gbi[i] += dgi[i]; gbh[i] += dgh[i]; }
-        for (int k = tid; k < E; k += nt) {                // dx -> embedding row of this token
-            float acc = 0.f;
-            for (int r = 0; r < 3 * S; ++r) acc = fmaf(dgi[r], Wi[r * E + k], acc);
-            atomicAdd(note_emb_grad + id * E + k, acc);
+        if (pow2) {
+            for (int i = tid; i < 3 * S * E; i += nt) gWi[i] = fmaf(dgi[i >> esh], xe[i & (E - 1)], gWi[i]);
+            for (int i = tid; i < 3 * S * S; i += nt) gWh[i] = fmaf(dgh[i >> ssh], hp[i & (S - 1)], gWh[i]);
+        } else {
+            for (int i = tid; i < 3 * S * E; i += nt) gWi[i] = fmaf(dgi[i / E], xe[i % E], gWi[i]);
+            for (int i = tid; i < 3 * S * S; i += nt) gWh[i] = fmaf(dgh[i / S], hp[i % S], gWh[i]);
         }
-        float add = 0.f;
-        if (tid < S) for (int r = 0; r < 3 * S; ++r) add = fmaf(dgh[r], Wh[r * S + tid], add);
+        for (int i = tid; i < 3 * S; i += nt) { gbi[i] += dgi[i]; gbh[i] += dgh[i]; }
+        // dx -> embedding row of this token, and the recurrent part of dh: two transposed matvecs of 3S terms each, dealt to ALL threads
+        // (thread -> (output k, quarter of the 3S rows), partial sums meet in LDS) instead of E + S threads running 96-term chains
+        float part = 0.f;
+        const int nout = E + S;
+        const int parts = max(1, min(nt / nout, (6 * S) / nout));      // 128 / 48 = 2 row partitions (and the partials must fit the 6S scratch)
+        if (tid < nout * parts) {
+            const int k = tid % nout, pr = tid / nout;
+            const int r0 = (3 * S * pr) / parts, r1 = (3 * S * (pr + 1)) / parts;
+            if (k < E) { for (int r = r0; r < r1; ++r) part = fmaf(dgi[r], Wi[r * E + k], part); }
+            else { const int kk = k - E; for (int r = r0; r < r1; ++r) part = fmaf(dgh[r], Wh[r * S + kk], part); }
+            g[tid] = part;                                 // g (6S floats >= nt) is free again after the gate math
+        }
         __syncthreads();
-        if (tid < S) dh[tid] += add;
+        if (tid < nout) {
+            float tot = 0.f;
+            for (int pr = 0; pr < parts; ++pr) tot += g[pr * nout + tid];
+            if (tid < E) atomicAdd(note_emb_grad + id * E + tid, tot);
+            else dh[tid - E] += tot;
+        }
         __syncthreads();
     }
     float* gwi = grads[dir * 4 + 0]; float* gwh = grads[dir * 4 + 1]; float* gb1 = grads[dir * 4 + 2]; float* gb2 = grads[dir * 4 + 3];
@@ -523,7 +563,8 @@ int a2s_staff_emb_bwd_impl(hipStream_t st, const float* note_emb, const float* c
                            const float* dout, long lddo, int col0, const float* hsave, int R, int maxlen, int E, int S) {
     A2S_REQUIRE((ids64 != nullptr) != (ids32 != nullptr), "staff_emb_bwd: exactly one of ids64/ids32");
     A2S_REQUIRE(hsave && grads_dev && note_emb_grad && dout, "staff_emb_bwd: null tensor");
-    const size_t shm = sizeof(float) * (2 * (3 * S * E + 3 * S * S) + 4 * 3 * S + E + S + 6 * S + 6 * S + S);
+    A2S_REQUIRE(E <= 5 * S && E + S <= 128, "staff_emb_bwd: note_emb_size <= 5 * staff_emb_size and note_emb_size + staff_emb_size <= 128 expected");
+    const size_t shm = sizeof(float) * (2 * (3 * S * E + 3 * S * S) + 4 * 3 * S + E + S + 6 * S + 6 * S + S) + sizeof(int) * (size_t)maxlen;
     hipLaunchKernelGGL(staff_emb_bwd, dim3(R, 2), dim3(128), shm, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
                        grads_dev, note_emb_grad, ids64, ids32, id_bstride, lengths, len_stride, dout, lddo, col0, hsave, maxlen, E, S);
     A2S_CHECK_LAUNCH("staff_emb_bwd");

@@ -37,17 +37,24 @@ static inline int a2s_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Split of the T frames of a clip over G workgroups for the attention kernels (forward and backward must agree):
-// aim at ~768 workgroups (3 per CU) but never more than 16 chunks; chunk is a multiple of 4 frames.
+// aim at ~768 workgroups (3 per CU) but never more than A2S_ATTN_MAX_SPLIT chunks (default 16; 64 measured slower overall: with only a handful of clips still
+// decoding -- the long-clip group -- a chunk of 76 frames is 5 + 10 dependent load rounds in one workgroup, ~15-35 us per launch; 20
+// frames are 2 + 3); chunk is a multiple of 4 frames.
 #include <stdlib.h>
 static inline int a2s_attn_target_wgs(void) {
     static int v = 0;
     if (!v) { const char* e = getenv("A2S_ATTN_WGS"); v = e ? atoi(e) : 768; if (v < 1) v = 768; }
     return v;
 }
+static inline int a2s_attn_max_split(void) {
+    static int v = 0;
+    if (!v) { const char* e = getenv("A2S_ATTN_MAX_SPLIT"); v = e ? atoi(e) : 16; if (v < 1) v = 16; }
+    return v;
+}
 static inline void a2s_attn_split_geometry(int B, int T, int* G, int* chunk) {
     const int target = a2s_attn_target_wgs();
     int g = (target + B - 1) / B;
-    if (g > 16) g = 16;
+    if (g > a2s_attn_max_split()) g = a2s_attn_max_split();
     if (g < 1) g = 1;
     int c = (T + g - 1) / g;
     c = (c + 3) & ~3;

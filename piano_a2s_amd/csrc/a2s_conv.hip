@@ -517,6 +517,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
     }
     const int clip_elems = a.T * a.Cin * a.F;
     const float* __restrict__ xclip = a.x + (long)b * clip_elems;
+    // raw buffer over this clip's input: a load whose byte offset falls outside [0, 4 clip_elems) returns 0 -- rows above / below the
+    // clip, columns left of f = 0 on the first row -- so the addresses need no clamping (the clamped-index version spent ~6 VALU
+    // instructions per scalar load, a third of the staging arithmetic); everything outside the tile's valid region is masked at commit
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xclip), 0, clip_elems * 4, 0x00020000);
     auto issue = [&](int q) {
         const int ch = stage_chunk(q), t0 = (tile0 + stage_tile(q)) * CV_TR;
         const int ncg = min(2, ncgs - 2 * ch);
@@ -526,10 +530,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
             if (256 * it >= ncg * C4_ITEMS) break;                 // uniform: the one-group chunk has 396 items
             int g = it_goff[it];
             asm volatile("" : "+v"(g));
-            g += corner;
-            // unconditional loads from a clamped element index (a branch per load would serialise the round trips); masked at commit
+            g = (g + corner) * 4;
+            const int plane = a.F * 4;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xreg[it][k] = xclip[min(max(g + k * a.F, 0), clip_elems - 1)];
+            for (int k = 0; k < 8; ++k) xreg[it][k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, g + k * plane, 0, 0));
         }
     };
     auto commit = [&](int q) {     // registers -> LDS; BN+ReLU of the producer folded in; zero = padding (of the ACTIVATED tensor)
@@ -558,17 +562,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = (ok && c0 + k < a.Cin) ? xreg[it][k] : 0.f;
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(__float_as_uint(v[k]) ^ sgn);      // odd stages multiply -x (see the stage loop)
             uint4 o[TERMS];
             if (TERMS == 3) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(__float_as_uint(v[k]) ^ sgn);      // odd stages multiply -x (see the stage loop)
                 split3_pair(v[0], v[1], o[0].x, o[1].x, o[TERMS - 1].x);
                 split3_pair(v[2], v[3], o[0].y, o[1].y, o[TERMS - 1].y);
                 split3_pair(v[4], v[5], o[0].z, o[1].z, o[TERMS - 1].z);
                 split3_pair(v[6], v[7], o[0].w, o[1].w, o[TERMS - 1].w);
             } else {
+                // the odd stages' sign rides on the power-of-two scale; activations (unscaled) are clamped to fp16's range in one
+                // v_med3 (it only bites on absurd values), a gradient operand is already inside it by construction of its scale
+                const float xs = sgn ? -xscale : xscale;
+                if (a.in_scale) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fminf(fmaxf(v[k] * xscale, -65000.f), 65000.f);     // (the clamp only bites on absurd activations)
+                    for (int k = 0; k < 8; ++k) v[k] = __builtin_amdgcn_fmed3f(v[k] * xs, -65000.f, 65000.f);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] *= xs;
+                }
                 split2_pair_f16(v[0], v[1], o[0].x, o[1].x);
                 split2_pair_f16(v[2], v[3], o[0].y, o[1].y);
                 split2_pair_f16(v[4], v[5], o[0].z, o[1].z);
@@ -590,13 +602,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = -acc[i][j][r];
     };
+#ifndef C4_PREFETCH
+#define C4_PREFETCH 1     // issue the next stage's input loads before this stage's multiply (with three products per k-step the multiply no
+#endif                    // longer covers the other workgroup's load round trip; round 1, six products: no gain)
+    if (C4_PREFETCH && nstage > 0) issue(0);
     for (int q = 0; q < nstage; ++q) {
         __syncthreads();                      // previous stage fully consumed
         if (stage_chunk(q) != resident) load_weights(stage_chunk(q));
-        issue(q);                             // no register prefetch (measured: no gain): the CU's other workgroup multiplies during this round trip
+        if (!C4_PREFETCH) issue(q);
         commit(q);
         resident = stage_chunk(q);
         __syncthreads();
+        if (C4_PREFETCH && q + 1 < nstage) issue(q + 1);
         // The bf16 matrix pipe truncates its internal sum toward -infinity (measured: mean error -3e-9 sum|a||b|, always negative, against
         // a random part of 5e-8) -- nothing for one output, but the BatchNorm sums over 10^6 positions see 70x their random error.  Odd
         // stages therefore accumulate the NEGATED sum (input negated while staging, accumulators flipped): the truncation then pushes
