@@ -296,11 +296,15 @@ def main():
         if use_dist:
             dist.barrier()
         step._exchange_events = []
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step GPU time (diagnostic only: no extra sync)
         t0 = time.time()
+        marks[0].record()
         for i in range(steps):
             step(batches[i % len(batches)], TF_RATIO)
             decode_steps.append(step.decode_steps)
+            marks[i + 1].record()
         torch.cuda.synchronize()
+        timed.step_ms = [round(a.elapsed_time(b), 1) for a, b in zip(marks[:-1], marks[1:])]
         if use_dist:
             dist.barrier()
         elapsed = time.time() - t0
@@ -312,6 +316,7 @@ def main():
 
     batches = make_batches(args.full_tail)
     elapsed, decode_steps = timed(batches, args.warmup, args.steps)
+    main_step_ms = list(timed.step_ms)
     loss = float(step.total)
     groups = step._last[2] if step._last else None
     # data-parallel straggler terms: decode steps each rank executed per optimizer step, and how long each rank's stream
@@ -346,6 +351,10 @@ def main():
                                      "holding full-length bars decoded as a concurrent clip group (loss, gradients and update identical "
                                      "to the per-bar loop over the whole minibatch)",
                           "clip_groups": groups, "decode_steps_per_step": round(sum(decode_steps) / max(len(decode_steps), 1), 1),
+                          "step_ms": main_step_ms,
+                          "allocator": {"hipMalloc_calls": torch.cuda.memory_stats().get("segment.all.allocated", 0),
+                                        "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0),
+                                        "reserved_peak_GiB": round(torch.cuda.memory_stats().get("reserved_bytes.all.peak", 0) / 2 ** 30, 1)},
                           "arithmetic": "fp32 data and fp32 accumulation everywhere; the 3x3 convolutions (forward, data gradient, conv3/conv4 weight "
                                         "gradient) multiply on the fp16 matrix pipes with every fp32 operand carried as TWO exact fp16 terms under "
                                         "power-of-two scales (three term products per fp32 product), the 128x128 GEMM tiles on the bf16 pipes with "
