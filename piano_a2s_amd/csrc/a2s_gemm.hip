@@ -485,6 +485,17 @@ int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
         }
         return best;
     }
+    // Mid-size outputs with a huge K (the decoder's deferred weight gradients: 1536 x 528 / 1536 x 512 / 173 x 1024 outputs, K = steps x
+    // rows = tens of thousands): with the split below they would run as ~430 workgroups of 64x64 fp32-input tiles (~55 TFLOP/s, 59 ms
+    // per step in profiles/r02_kernel_stats.txt).  Split K far enough that the 128x128 tiles -- the split-operand path, ~2x the rate --
+    // give one workgroup per CU instead.
+    const long t128 = (long)a2s_cdiv(M, 128) * a2s_cdiv(N, 128) * batch;
+    if (K >= 8192 && t128 >= 12) {
+        long s = a2s_cdiv(256, t128);
+        if (s > K / 2048) s = K / 2048;
+        if (s > 16) s = 16;
+        if (s >= 1 && t128 * s >= 192) return (int)s;
+    }
     long s = 512 / tiles;
     const long maxs = K / 512;
     if (s > maxs) s = maxs;
