@@ -50,6 +50,20 @@ int a2s_gemm_f32_affine(void* stream, int M, int N, int K, float alpha, const fl
  * epilogue into partial[a2s_gemm_bnstats_blocks(M, period)][N / period][2] -- the layout a2s_bn_bwd_from_partial reads. */
 int a2s_gemm_f32_bnstats(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
                          const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial);
+/* The two entries above on the two-term fp16 split (three matrix-core products instead of the six of the three-term bf16 split, same
+ * fp32-level accuracy; 128x128 tiles with k- or row-contiguous operands, otherwise the call runs as the unscaled entry): a_absmax /
+ * b_absmax are device scalars holding max |A| / max |B| (a2s_absmax, or the BatchNorm backward's a2s_bn_bwd_amax), from which the kernel
+ * derives exact power-of-two operand scales; NULL = that operand is O(1) (post-BatchNorm activations) and is used as is.  Switch:
+ * a2s_debug_set("gemm_f16x2", 0/1), environment A2S_GEMM_F16X2 (default 1). */
+int a2s_gemm_f32_affine_scaled(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk, const float* B, long sBk,
+                               long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,
+                               int splitk, float* workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_period,
+                               const float* b_scale, const float* b_shift, int b_period, const float* a_absmax, const float* b_absmax);
+int a2s_gemm_f32_bnstats_scaled(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
+                                const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
+                                const float* a_absmax, const float* b_absmax);
+/* out[0] = max |x[i]| over n floats (device scalar) */
+int a2s_absmax(void* stream, const float* x, long n, float* out);
 int a2s_gemm_bnstats_blocks(int M, int period);
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 int a2s_gemm_pick_splitk(int M, int N, int K, int batch);

@@ -11,7 +11,10 @@ int a2s_gemm_impl(hipStream_t, int, int, int, float, const float*, long, long, c
 size_t a2s_gemm_workspace_bytes_impl(int, int, int, int);
 int a2s_gemm_affine_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long, const float*,
                          int, int, long, long, long, int, float*, size_t, const float*, const float*, int, const float*, const float*, int,
-                         const float*, const float*, const float*, const float*, const float*, float*, int);
+                         const float*, const float*, const float*, const float*, const float*, float*, int, int, const float*, const float*);
+int a2s_absmax_impl(hipStream_t, const float*, long, float*);
+void a2s_gemm_f16x2_set(int);
+int a2s_gemm_f16x2_enabled(void);
 int a2s_gemm_bnstats_slots(int);
 int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*,
                      const float*, const float*, const float*, const float*, const float*, const float*);
@@ -109,12 +112,27 @@ int a2s_gemm_f32_affine(void* stream, int M, int N, int K, float alpha, const fl
                         const float* b_scale, const float* b_shift, int b_period) {
     return a2s_gemm_affine_impl(ST, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk,
                                 workspace, workspace_bytes, a_scale, a_shift, a_period, b_scale, b_shift, b_period,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr);
 }
+int a2s_gemm_f32_affine_scaled(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk, const float* B, long sBk,
+                               long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,
+                               int splitk, float* workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_period,
+                               const float* b_scale, const float* b_shift, int b_period, const float* a_absmax, const float* b_absmax) {
+    return a2s_gemm_affine_impl(ST, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk,
+                                workspace, workspace_bytes, a_scale, a_shift, a_period, b_scale, b_shift, b_period,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, a_absmax, b_absmax);
+}
+int a2s_gemm_f32_bnstats_scaled(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
+                                const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
+                                const float* a_absmax, const float* b_absmax) {
+    return a2s_gemm_affine_impl(ST, M, N, K, 1.f, A, sAm, sAk, B, sBk, sBn, 0.f, C, ldc, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0,
+                                nullptr, nullptr, 0, nullptr, nullptr, 0, y, mean, invstd, scale, shift, partial, period, 1, a_absmax, b_absmax);
+}
+int a2s_absmax(void* stream, const float* x, long n, float* out) { return a2s_absmax_impl(ST, x, n, out); }
 int a2s_gemm_f32_bnstats(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
                          const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial) {
     return a2s_gemm_affine_impl(ST, M, N, K, 1.f, A, sAm, sAk, B, sBk, sBn, 0.f, C, ldc, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0,
-                                nullptr, nullptr, 0, nullptr, nullptr, 0, y, mean, invstd, scale, shift, partial, period);
+                                nullptr, nullptr, 0, nullptr, nullptr, 0, y, mean, invstd, scale, shift, partial, period, 0, nullptr, nullptr);
 }
 int a2s_gemm_bnstats_blocks(int M, int period) { return a2s_cdiv(M, 128) * a2s_gemm_bnstats_slots(period); }
 size_t a2s_gemm_workspace_bytes(int M, int N, int batch, int splitk) { return a2s_gemm_workspace_bytes_impl(M, N, batch, splitk); }
@@ -131,6 +149,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "conv_f16x2")) { a2s_conv_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_f16x2")) { a2s_wgrad_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_bf16x3")) { a2s_gemm_split_set(value); return A2S_OK; }
+    if (!strcmp(key, "gemm_f16x2")) { a2s_gemm_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_bf16x3")) { a2s_wgrad_split_set(value); return A2S_OK; }
     snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
     return A2S_ERR_ARG;
@@ -141,6 +160,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "conv_f16x2")) return a2s_conv_f16x2_enabled();
     if (key && !strcmp(key, "wgrad_f16x2")) return a2s_wgrad_f16x2_enabled();
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();
+    if (key && !strcmp(key, "gemm_f16x2")) return a2s_gemm_f16x2_enabled();
     if (key && !strcmp(key, "wgrad_bf16x3")) return a2s_wgrad_split_enabled();
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
     if (key && !strcmp(key, "dec_fused")) return a2s_dec_fused_enabled();

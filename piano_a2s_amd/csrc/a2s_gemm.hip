@@ -34,6 +34,9 @@ struct GemmArgs {
     // (row tile, column-tile slot of the channel) in the [blocks][channels][2] layout bn_bwd_finalize reads.  128x128 tiles only.
     const float* ep_y; const float* ep_mean; const float* ep_invstd; const float* ep_scale; const float* ep_shift;
     float* ep_partial; int ep_period, ep_channels, ep_slots;
+    // two-term fp16 split path (128x128 tiles): device scalars max|A| / max|B| for the power-of-two operand scales (null = the operand is
+    // used unscaled: O(1) activations)
+    int two_term; const float* a_absmax; const float* b_absmax;
 };
 
 #define GEMM_BK 32
@@ -129,10 +132,10 @@ __device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 
 // Split path (both operands k-contiguous): registers -> LDS as three bf16 term planes [term][ROWS][32 k (+8 pad)], 80-byte rows so
 // that a lane's fragment (8 consecutive k of one row) is one ds_read_b128.  Same optional operand BatchNorm+ReLU as tile_store.
 #define GEMM_SPLIT_RS 80
-template <int ROWS, int NLD>
+template <int ROWS, int NLD, int TERMS = 3>
 __device__ __forceinline__ void tile_store_split(unsigned char* __restrict__ lds, const f32x4 (&reg)[NLD], const float (&aff)[NLD][2], int r0, int k0,
                                                  int rmax, int kmax, const float* __restrict__ scale, const float* __restrict__ shift, int period,
-                                                 bool negate) {
+                                                 bool negate, float pscale = 1.f) {
     const int tid = threadIdx.x;
     const unsigned sgn = negate ? 0x80000000u : 0u;
 #pragma unroll
@@ -155,13 +158,21 @@ __device__ __forceinline__ void tile_store_split(unsigned char* __restrict__ lds
                     if (row_ok && gk + j < kmax) { const int c = (int)(((float)(gk + j) + 0.5f) * inv); v[j] = fmaxf(fmaf(v[j], scale[c], shift[c]), 0.f); }
             }
         }
+        uint2 o[TERMS];
+        if (TERMS == 3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__float_as_uint(v[j]) ^ sgn);
-        uint2 o[3];
-        split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
-        split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+            for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__float_as_uint(v[j]) ^ sgn);
+            split3_pair(v[0], v[1], o[0].x, o[1].x, o[TERMS - 1].x);
+            split3_pair(v[2], v[3], o[0].y, o[1].y, o[TERMS - 1].y);
+        } else {
+            const float ps = negate ? -pscale : pscale;           // exact power-of-two operand scale (sign: the negated k-tile blocks)
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint2*>(lds + (sp * ROWS + r) * GEMM_SPLIT_RS + k * 2) = o[sp];
+            for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * ps, -65000.f, 65000.f);
+            split2_pair_f16(v[0], v[1], o[0].x, o[1].x);
+            split2_pair_f16(v[2], v[3], o[0].y, o[1].y);
+        }
+#pragma unroll
+        for (int sp = 0; sp < TERMS; ++sp) *reinterpret_cast<uint2*>(lds + (sp * ROWS + r) * GEMM_SPLIT_RS + k * 2) = o[sp];
     }
 }
 
@@ -195,10 +206,10 @@ __device__ __forceinline__ void tile_load_T(const float* __restrict__ P, long sK
     }
 }
 
-template <int ROWS>
+template <int ROWS, int TERMS = 3>
 __device__ __forceinline__ void tile_store_split_T(unsigned char* __restrict__ lds, const f32x4 (&reg)[4], const float (&aff)[2], int r0, int k0,
                                                    int rmax, int kmax, const float* __restrict__ scale, const float* __restrict__ shift, int period,
-                                                   bool negate) {
+                                                   bool negate, float pscale = 1.f) {
     const int rq = threadIdx.x >> 3, kc = threadIdx.x & 7;
     const unsigned sgn = negate ? 0x80000000u : 0u;
     const int gr = r0 + rq * 4;
@@ -213,17 +224,27 @@ __device__ __forceinline__ void tile_store_split_T(unsigned char* __restrict__ l
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (gr + j < rmax && k0 + kc * 4 + i < kmax) v[i] = fmaxf(fmaf(v[i], sc, sh), 0.f);
         }
+        uint2 o[TERMS];
+        if (TERMS == 3) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(__float_as_uint(v[i]) ^ sgn);
-        uint2 o[3];
-        split3_pair(v[0], v[1], o[0].x, o[1].x, o[2].x);
-        split3_pair(v[2], v[3], o[0].y, o[1].y, o[2].y);
+            for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(__float_as_uint(v[i]) ^ sgn);
+            split3_pair(v[0], v[1], o[0].x, o[1].x, o[TERMS - 1].x);
+            split3_pair(v[2], v[3], o[0].y, o[1].y, o[TERMS - 1].y);
+        } else {
+            const float ps = negate ? -pscale : pscale;
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<uint2*>(lds + (sp * ROWS + rq * 4 + j) * GEMM_SPLIT_RS + kc * 8) = o[sp];
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i] * ps, -65000.f, 65000.f);
+            split2_pair_f16(v[0], v[1], o[0].x, o[1].x);
+            split2_pair_f16(v[2], v[3], o[0].y, o[1].y);
+        }
+#pragma unroll
+        for (int sp = 0; sp < TERMS; ++sp) *reinterpret_cast<uint2*>(lds + (sp * ROWS + rq * 4 + j) * GEMM_SPLIT_RS + kc * 8) = o[sp];
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, bool SPLIT = false>
+// SPLIT: 0 = fp32-input MFMA; 3 = three bf16 terms, six products; 2 = two fp16 terms, three products (operands scaled by exact powers of two
+// from their max-magnitude scalars, the accumulators unscaled before the epilogue -- see conv3x3_split in a2s_conv.hip)
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int SPLIT = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
     constexpr int NLA = (BM * 8 + 255) / 256, NLB = (BN * 8 + 255) / 256;
@@ -254,15 +275,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
         tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
     }
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT != 0) {
         // fp32 operands as three exact bf16 terms on the bf16 matrix pipes (six term products per k-step of 32, see conv3x3_bf16x3 in
         // a2s_conv.hip); single LDS buffer (2 x 30 KB), the next tile's global loads stay in flight during the multiply.  The pipe truncates
         // its internal sum toward -infinity: every other block of 8 k-tiles accumulates the negated sum (A negated while staging).
-        static_assert(3 * (BM + BN) * GEMM_SPLIT_RS <= (int)sizeof(lds), "split path: the term planes must fit the fp32 path's LDS");
+        static_assert(SPLIT * (BM + BN) * GEMM_SPLIT_RS <= (int)sizeof(lds), "split path: the term planes must fit the fp32 path's LDS");
         static_assert((A_KC || BM == 128) && (B_KC || BN == 128), "split path: row-contiguous operands need 128-row tiles");
         unsigned char* la = reinterpret_cast<unsigned char*>(lds);
-        unsigned char* lb = la + 3 * BM * GEMM_SPLIT_RS;
+        unsigned char* lb = la + SPLIT * BM * GEMM_SPLIT_RS;
         bool neg = false;
+        float psa = 1.f, psb = 1.f, unscale = 1.f;
+        if (SPLIT == 2) {
+            const int ka = g.a_absmax ? pow2_scale_exp(*g.a_absmax, 12) : 0, kb = g.b_absmax ? pow2_scale_exp(*g.b_absmax, 12) : 0;
+            psa = ldexpf(1.f, ka); psb = ldexpf(1.f, kb); unscale = ldexpf(1.f, -(ka + kb));
+        }
         auto flip = [&]() {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -283,31 +309,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         for (int t = 0; t < ntiles; ++t) {
             const bool want = (t >> 3) & 1;
             __syncthreads();                  // the previous tile's fragments are consumed
-            if constexpr (A_KC) tile_store_split<BM, NLA>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want);
-            else tile_store_split_T<BM>(la, ta, tfa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want);
-            if constexpr (B_KC) tile_store_split<BN, NLB>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false);
-            else tile_store_split_T<BN>(lb, tb, tfb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false);
+            if constexpr (A_KC) tile_store_split<BM, NLA, SPLIT>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want, psa);
+            else tile_store_split_T<BM, SPLIT>(la, ta, tfa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want, psa);
+            if constexpr (B_KC) tile_store_split<BN, NLB, SPLIT>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false, psb);
+            else tile_store_split_T<BN, SPLIT>(lb, tb, tfb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false, psb);
             __syncthreads();
             if (t + 1 < ntiles) load_tile(kbeg + (t + 1) * GEMM_BK);
             if (want != neg) { flip(); neg = want; }
-            bf16x8 af[3][TM];
+            typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+            gu32x4 af[SPLIT][TM];
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
+            for (int sp = 0; sp < SPLIT; ++sp)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[sp][i] = *reinterpret_cast<const bf16x8*>(la + (sp * BM + wm + i * 16 + lr) * GEMM_SPLIT_RS + lk * 16);
+                for (int i = 0; i < TM; ++i) af[sp][i] = *reinterpret_cast<const gu32x4*>(la + (sp * BM + wm + i * 16 + lr) * GEMM_SPLIT_RS + lk * 16);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bf16x8 bf[3];
+                gu32x4 bf[SPLIT];
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) bf[sp] = *reinterpret_cast<const bf16x8*>(lb + (sp * BN + wn + j * 16 + lr) * GEMM_SPLIT_RS + lk * 16);
+                for (int sp = 0; sp < SPLIT; ++sp) bf[sp] = *reinterpret_cast<const gu32x4*>(lb + (sp * BN + wn + j * 16 + lr) * GEMM_SPLIT_RS + lk * 16);
 #define GEMM_PRODUCT(SA, SB)                                                                                                    \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[SB], af[SA][i], acc[i][j], 0, 0, 0);
-                GEMM_PRODUCT(2, 0) GEMM_PRODUCT(1, 1) GEMM_PRODUCT(0, 2) GEMM_PRODUCT(1, 0) GEMM_PRODUCT(0, 1) GEMM_PRODUCT(0, 0)
+                    acc[i][j] = (SPLIT == 3) ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[SB]), __builtin_bit_cast(bf16x8, af[SA][i]), acc[i][j], 0, 0, 0) \
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[SB]), __builtin_bit_cast(f16x8, af[SA][i]), acc[i][j], 0, 0, 0);
+                if (SPLIT == 3) { GEMM_PRODUCT(SPLIT - 1, 0) GEMM_PRODUCT(1, 1) GEMM_PRODUCT(0, SPLIT - 1) }
+                GEMM_PRODUCT(1, 0) GEMM_PRODUCT(0, 1) GEMM_PRODUCT(0, 0)
 #undef GEMM_PRODUCT
             }
         }
         if (neg) flip();
+        if (SPLIT == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] *= unscale;
+        }
     } else {
     for (int t = 0; t < ntiles; ++t) {
             float* la = lds + (t & 1) * (LA::SIZE + LB::SIZE);
@@ -442,6 +479,31 @@ __global__ void gemm_splitk_reduce(GemmArgs g) {
 static int g_gemm_split = 1;
 void a2s_gemm_split_set(int on) { g_gemm_split = on; }
 int a2s_gemm_split_enabled(void) { return g_gemm_split; }
+// ... two fp16 terms instead of three bf16 terms where the caller vouches for the operands' ranges (a2s_gemm_f32_desc: two_term)
+static int g_gemm_f16x2 = -1;
+void a2s_gemm_f16x2_set(int on) { g_gemm_f16x2 = on; }
+int a2s_gemm_f16x2_enabled(void) {
+    if (g_gemm_f16x2 < 0) { const char* e = getenv("A2S_GEMM_F16X2"); g_gemm_f16x2 = e ? atoi(e) : 1; }
+    return g_gemm_f16x2;
+}
+
+// max |x| of a tensor into a device scalar (atomicMax on the float bits; *out must be zero before): the power-of-two operand scales of
+// the two-term fp16 kernels
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+int a2s_absmax_impl(hipStream_t st, const float* x, long n, float* out) {
+    A2S_REQUIRE(x && out && n >= 0, "absmax: null tensor");
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "absmax memset: %s", hipGetErrorString(e));
+    if (n == 0) return A2S_OK;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, st, x, n, out);
+    A2S_CHECK_LAUNCH("absmax_kernel");
+    return A2S_OK;
+}
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
@@ -450,10 +512,17 @@ static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
         // row-contiguous operands need unit row stride and 16-byte loads for the transposed staging (else the fp32-input path)
         const bool a_ok = akc || (g.sAm == 1 && g.vecA), b_ok = bkc || (g.sBn == 1 && g.vecB);
         if (g_gemm_split && g.K >= 256 && a_ok && b_ok) {
-            if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, true>), grid, dim3(256), 0, st, g);
-            else if (akc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, true>), grid, dim3(256), 0, st, g);
-            else if (bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, true>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(256), 0, st, g);
+            if (g.two_term && a2s_gemm_f16x2_enabled()) {
+                if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, 2>), grid, dim3(256), 0, st, g);
+                else if (akc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, 2>), grid, dim3(256), 0, st, g);
+                else if (bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, 2>), grid, dim3(256), 0, st, g);
+                else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, 2>), grid, dim3(256), 0, st, g);
+                return;
+            }
+            if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, 3>), grid, dim3(256), 0, st, g);
+            else if (akc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, 3>), grid, dim3(256), 0, st, g);
+            else if (bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, 3>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, 3>), grid, dim3(256), 0, st, g);
             return;
         }
     }
@@ -515,7 +584,7 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
                   int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes,
                   const float* a_scale, const float* a_shift, int a_period, const float* b_scale, const float* b_shift, int b_period,
                   const float* ep_y, const float* ep_mean, const float* ep_invstd, const float* ep_scale, const float* ep_shift,
-                  float* ep_partial, int ep_period) {
+                  float* ep_partial, int ep_period, int two_term, const float* a_absmax, const float* b_absmax) {
     if (M <= 0 || N <= 0 || batch <= 0) return A2S_OK;
     A2S_REQUIRE(K >= 0 && A && B && C, "gemm: null operand or negative K");
     A2S_REQUIRE(splitk >= 0, "gemm: splitk must be >= 0 (0 = choose automatically when a workspace is given)");
@@ -551,6 +620,7 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
     g.sAm = sAm; g.sAk = sAk; g.sBk = sBk; g.sBn = sBn; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.act = act;
     g.batch = batch; g.bsA = bsA; g.bsB = bsB; g.bsC = bsC;
     g.splitk = splitk; g.partial = ws;
+    g.two_term = two_term; g.a_absmax = a_absmax; g.b_absmax = b_absmax;
     A2S_REQUIRE((a_scale == nullptr) == (a_shift == nullptr) && (b_scale == nullptr) == (b_shift == nullptr), "gemm: operand scale/shift must come together");
     A2S_REQUIRE((!a_scale || a_period > 0) && (!b_scale || b_period > 0), "gemm: operand affine needs a positive period");
     A2S_REQUIRE(!a_scale || sAk == 1 || sAm == 1, "gemm: operand affine needs a unit-stride dimension on A");
@@ -607,5 +677,5 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
                   const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
                   int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes) {
     return a2s_gemm_affine_impl(st, M, N, K, alpha, A, sAm, sAk, B, sBk, sBn, beta, C, ldc, bias, act, batch, bsA, bsB, bsC, splitk, ws, ws_bytes,
-                                nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+                                nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr);
 }

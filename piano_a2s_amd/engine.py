@@ -275,7 +275,9 @@ class Engine:
             z = hip.linear(a4, S["convstack.out.weight"])
         else:
             a4 = None
-            z = hip.linear(y4, S["convstack.out.weight"], x_affine=(scale, shift, F))
+            # two-term fp16 split: the activations are O(1) and used as they are, the weights get a power-of-two scale from max|W|
+            saved["w_out_amax"] = hip.absmax(S["convstack.out.weight"])
+            z = hip.linear(y4, S["convstack.out.weight"], x_affine=(scale, shift, F), two_term=(None, saved["w_out_amax"]))
         rows = B * T
         rpb = 64
         nblk = (rows + rpb - 1) // rpb

@@ -39,14 +39,15 @@ def _colsum(x, ld, out, rows, ncol, x_off=0, out_off=0, beta=1.0):
                                     hip.f32(1.0), hip.f32(beta), hip._p(ws), C.c_size_t(ws.numel() if ws is not None else 0)), "a2s_col_sum")
 
 
-def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0, x_affine=None):
+def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0, x_affine=None, dy_amax=None):
     """y = x W^T + b  (x (M,K) contiguous, W (N,K)):  dW += dy^T x ; db += colsum(dy) ; dx (+)= dy W.
     x_affine = (scale, shift, period): the layer's input was max(0, x*scale[k // period] + shift[k // period]) formed on the fly
-    (hip.linear) -- the weight gradient re-forms it the same way while staging x."""
+    (hip.linear) -- the weight gradient re-forms it the same way while staging x.  dy_amax: device scalar max|dy| -- the weight
+    gradient may then run on the two-term fp16 split (x is O(1): post-BatchNorm activations)."""
     M, K = x.shape
     N = W.shape[0]
     sk = hip.lib().a2s_gemm_pick_splitk(N, K, M, 1)
-    hip.gemm(dy, 1, N, x, K, 1, G[wname], K, N, K, M, beta=1.0, splitk=sk, b_affine=x_affine)
+    hip.gemm(dy, 1, N, x, K, 1, G[wname], K, N, K, M, beta=1.0, splitk=sk, b_affine=x_affine, two_term=(dy_amax, None) if dy_amax is not None else None)
     if bname is not None:
         _colsum(dy, N, G[bname], M, N)
     if dx is not None:
@@ -547,7 +548,11 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
 
     # dropout + ReLU + BatchNorm1d over the (B*T, Cf) Linear output
     g = d_out.reshape(rows, Cf).contiguous()
-    dz = bn_bwd(g, cs["z"], cs["out_bn"], "convstack.out_bn", cs["drop"], rows, Cf, 1)
+    dz_amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    dz = bn_bwd(g, cs["z"], cs["out_bn"], "convstack.out_bn", cs["drop"], rows, Cf, 1, amax=dz_amax)
+    if eng.sync_bn:
+        hip.absmax(dz, dz_amax)
+    w_amax = cs.get("w_out_amax")
     # Linear 19200 -> Cf, no bias:  dW += dz^T a4 ; da4 = dz W
     a4 = cs["a4"]
     g_partial = None                     # BatchNorm-backward statistics partials of g, when the kernel that produced g also reduced them
@@ -556,7 +561,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         y4 = cs["y"][3].view(rows, 40 * F)
         da = torch.empty_like(y4)
         bn4 = cs["bn"][3]
-        _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F))
+        _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax)
         if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             nblk = L.a2s_gemm_bnstats_blocks(rows, F)
@@ -567,9 +572,11 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                 wb, s_bk, s_bn = Wt, 1, Cf
             else:
                 wb, s_bk, s_bn = Wout, 40 * F, 1
-            hip.check(L.a2s_gemm_f32_bnstats(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(wb), C.c_long(s_bk), C.c_long(s_bn),
-                                             hip._p(da), C.c_long(40 * F), hip._p(y4), hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F,
-                                             hip._p(part)), "a2s_gemm_f32_bnstats")
+            if w_amax is None:
+                w_amax = hip.absmax(Wout)
+            hip.check(L.a2s_gemm_f32_bnstats_scaled(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(wb), C.c_long(s_bk), C.c_long(s_bn),
+                                                    hip._p(da), C.c_long(40 * F), hip._p(y4), hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F,
+                                                    hip._p(part), hip._p(dz_amax), hip._p(w_amax)), "a2s_gemm_f32_bnstats_scaled")
             g_partial = (part, nblk)
         else:
             hip.gemm(dz, Cf, 1, Wout, 40 * F, 1, da, 40 * F, rows, 40 * F, Cf)

@@ -111,9 +111,11 @@ def f32(x):
 
 
 def gemm(A, sAm, sAk, B, sBk, sBn, Cout, ldc, M, N, K, alpha=1.0, beta=0.0, bias=None, act=0,
-         batch=1, bsA=0, bsB=0, bsC=0, splitk=1, a_off=0, b_off=0, c_off=0, a_affine=None, b_affine=None):
+         batch=1, bsA=0, bsB=0, bsC=0, splitk=1, a_off=0, b_off=0, c_off=0, a_affine=None, b_affine=None, two_term=None):
     """C[m,n] = act(alpha*sum_k A(m,k)B(k,n) + beta*C + bias[n]); *_off are element offsets into the tensors.
-    a_affine / b_affine = (scale, shift, period): BatchNorm+ReLU of that operand applied while it is staged (a2s_gemm_f32_affine)."""
+    a_affine / b_affine = (scale, shift, period): BatchNorm+ReLU of that operand applied while it is staged (a2s_gemm_f32_affine).
+    two_term = (a_absmax, b_absmax): device scalars max|A| / max|B| (None: the operand is O(1)) -- the product may run on the two-term
+    fp16 split (a2s_gemm_f32_affine_scaled)."""
     L = lib()
     ws, ws_bytes = None, 0
     if splitk > 1:
@@ -122,19 +124,33 @@ def gemm(A, sAm, sAk, B, sBk, sBn, Cout, ldc, M, N, K, alpha=1.0, beta=0.0, bias
     pa = C.c_void_p(A.data_ptr() + 4 * a_off)
     pb = C.c_void_p(B.data_ptr() + 4 * b_off)
     pc = C.c_void_p(Cout.data_ptr() + 4 * c_off)
-    if a_affine is None and b_affine is None:
+    if a_affine is None and b_affine is None and two_term is None:
         check(L.a2s_gemm_f32(stream(), M, N, K, f32(alpha), pa, C.c_long(sAm), C.c_long(sAk), pb, C.c_long(sBk), C.c_long(sBn),
                              f32(beta), pc, C.c_long(ldc), _p(bias), act, batch, C.c_long(bsA), C.c_long(bsB), C.c_long(bsC),
                              splitk, _p(ws), C.c_size_t(ws_bytes)), "a2s_gemm_f32")
         return
     asc, ash, ap = a_affine if a_affine is not None else (None, None, 0)
     bsc, bsh, bp = b_affine if b_affine is not None else (None, None, 0)
+    if two_term is not None:
+        check(L.a2s_gemm_f32_affine_scaled(stream(), M, N, K, f32(alpha), pa, C.c_long(sAm), C.c_long(sAk), pb, C.c_long(sBk), C.c_long(sBn),
+                                           f32(beta), pc, C.c_long(ldc), _p(bias), act, batch, C.c_long(bsA), C.c_long(bsB), C.c_long(bsC),
+                                           splitk, _p(ws), C.c_size_t(ws_bytes), _p(asc), _p(ash), ap, _p(bsc), _p(bsh), bp,
+                                           _p(two_term[0]), _p(two_term[1])), "a2s_gemm_f32_affine_scaled")
+        return
     check(L.a2s_gemm_f32_affine(stream(), M, N, K, f32(alpha), pa, C.c_long(sAm), C.c_long(sAk), pb, C.c_long(sBk), C.c_long(sBn),
                                 f32(beta), pc, C.c_long(ldc), _p(bias), act, batch, C.c_long(bsA), C.c_long(bsB), C.c_long(bsC),
                                 splitk, _p(ws), C.c_size_t(ws_bytes), _p(asc), _p(ash), ap, _p(bsc), _p(bsh), bp), "a2s_gemm_f32_affine")
 
 
-def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0, x_affine=None):
+def absmax(x, out=None):
+    """max |x| of a contiguous float32 tensor as a device scalar (operand scale of the two-term fp16 kernels)."""
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib().a2s_absmax(stream(), _p(x), C.c_long(x.numel()), _p(out)), "a2s_absmax")
+    return out
+
+
+def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0, x_affine=None, two_term=None):
     """y = act(x @ weight.T + bias) for row-major contiguous x (M,K) and weight (N,K); x_affine = (scale, shift, period): the input
     is max(0, x*scale[k // period] + shift[k // period]) formed on the fly."""
     M, K = x2d.shape
@@ -142,5 +158,5 @@ def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0, x_affine=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
     gemm(x2d, x2d.stride(0), x2d.stride(1), weight, weight.stride(1), weight.stride(0), out, out.stride(0), M, N, K,
-         bias=bias, act=act, beta=beta, a_affine=x_affine)
+         bias=bias, act=act, beta=beta, a_affine=x_affine, two_term=two_term)
     return out

@@ -270,6 +270,61 @@ def test_gemm_split_operand_path_row_contiguous_operands(dev, form):
     assert errs[1] < 3 * errs[0] + 1e-7, errs
 
 
+@pytest.mark.parametrize("form", ["forward", "data_gradient", "weight_gradient"])
+def test_gemm_two_term_fp16_path(dev, form):
+    """The 128x128 GEMM tiles on the two-term fp16 split (three matrix-core products; power-of-two operand scales from max|operand|
+    device scalars) against float64 and against the three-term bf16 split, in the three forms of the 19200 -> 256 Linear: forward
+    (O(1) activations unscaled + BatchNorm/ReLU while staging, small weights scaled), data gradient (tiny gradients x small weights,
+    both scaled), weight gradient (transposed staging, split-K, tiny gradients scaled x affine activations unscaled)."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(7 + len(form))
+    if form == "forward":
+        M, K, N, period = 12800 + 37, 1920, 256, 48
+        x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.007).to(dev)
+        aff = ((torch.rand(K // period, generator=g) + 0.5).to(dev), (torch.randn(K // period, generator=g) * 0.3).to(dev), period)
+        xa = torch.relu(x.double() * aff[0].double().repeat_interleave(period) + aff[1].double().repeat_interleave(period))
+        ref, mag = xa @ w.double().t(), xa.abs() @ w.double().abs().t() + 1e-300
+        wmax = hip.absmax(w)
+        assert float(wmax) == float(w.abs().max())
+        run = lambda out, tt: hip.linear(x, w, out=out, x_affine=aff, two_term=(None, wmax) if tt else None)
+        shape = (M, N)
+    elif form == "data_gradient":
+        M, K, N = 12800 + 37, 256, 1920
+        dz = (torch.randn(M, K, generator=g) * 3e-7 * torch.exp(2 * torch.randn(M, 1, generator=g))).to(dev)
+        wt = (torch.randn(N, K, generator=g) * 0.007).to(dev)                 # k-contiguous copy of the weight, as engine_bwd passes it
+        ref, mag = dz.double() @ wt.double().t(), dz.double().abs() @ wt.double().abs().t() + 1e-300
+        amax, wmax = hip.absmax(dz), hip.absmax(wt)
+        # rows 2^-20 and more below the tensor's maximum meet the ABSOLUTE floor of the two-term split: the second term of an element
+        # below 2^-3 (after scaling the maximum to 2^12) is an fp16 subnormal, quantum 2^-24, i.e. an error of at most 2^-37 max|dz| per
+        # element whatever its size -- negligible in every sum the gradient enters, but not relative to such a row alone
+        mag = mag + (2.0 ** -36 / 2e-6) * (float(amax) * wt.double().abs().sum(dim=1)[None, :] + float(wmax) * dz.double().abs().sum(dim=1)[:, None])
+        run = lambda out, tt: hip.gemm(dz, K, 1, wt, 1, K, out, N, M, N, K, two_term=(amax, wmax) if tt else None)
+        shape = (M, N)
+    else:
+        R, Mo, No, period = 30000 + 3, 256, 512, 64
+        dz = (torch.randn(R, Mo, generator=g) * 3e-7 * torch.exp(2 * torch.randn(R, 1, generator=g))).to(dev)
+        x = (torch.randn(R, No, generator=g) * torch.exp(torch.randn(R, 1, generator=g))).to(dev)
+        aff = ((torch.rand(No // period, generator=g) + 0.5).to(dev), (torch.randn(No // period, generator=g) * 0.3).to(dev), period)
+        xa = torch.relu(x.double() * aff[0].double().repeat_interleave(period) + aff[1].double().repeat_interleave(period))
+        ref, mag = dz.double().t() @ xa, dz.double().abs().t() @ xa.abs() + 1e-300
+        amax = hip.absmax(dz)
+        run = lambda out, tt: hip.gemm(dz, 1, Mo, x, No, 1, out, No, Mo, No, R, splitk=24, b_affine=aff, two_term=(amax, None) if tt else None)
+        shape = (Mo, No)
+    assert L.a2s_debug_get(b"gemm_f16x2") == 1 and L.a2s_debug_get(b"gemm_bf16x3") == 1
+    errs = {}
+    for tt in (False, True):
+        out = torch.full(shape, float("nan"), device=dev)
+        run(out, tt)
+        torch.cuda.synchronize()
+        errs[tt] = float(((out.double() - ref).abs() / mag).max())
+    _report(f"gemm two-term {form} (vs sum|a||b|): three bf16 terms", errs[False])
+    _report(f"gemm two-term {form} (vs sum|a||b|): two fp16 terms", errs[True])
+    assert errs[True] < 2e-6, errs
+    assert errs[True] < 3 * errs[False] + 1e-7, errs
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_finalize_matches_oracle_batch_norm(dev, training):
     from oracle import model_ref
