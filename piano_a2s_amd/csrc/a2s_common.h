@@ -171,6 +171,17 @@ __device__ __forceinline__ void split2_pair_f16(float x0, float x1, unsigned& p0
     v[0] -= b[0]; v[1] -= b[1];
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
+// Fold a workgroup's running max |x| (am >= 0, per thread) into a device scalar: one candidate per workgroup, and the atomic only when
+// it would raise the value (non-negative floats order like their bit patterns).  Half a million unconditional same-address atomics -- one
+// per wave of bn_bwd_apply_planes -- serialise at ~30 ns each: 5 ms on a 10 ms kernel.  `red` = 16 floats of LDS, blockDim.x a multiple of 64.
+__device__ __forceinline__ void block_absmax_to(float* __restrict__ out, float am, float* red) {
+    am = block_max(am, red);
+    if (threadIdx.x == 0) {
+        const unsigned bits = __float_as_uint(am);
+        if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned*>(out), bits);
+    }
+}
 // power-of-two scale that brings a tensor whose largest magnitude is `amax` to [2^target, 2^(target+1)): exact to apply and to undo
 __device__ __forceinline__ int pow2_scale_exp(float amax, int target) {
     if (!(amax > 0.f) || !isfinite(amax)) return 0;

@@ -1066,9 +1066,9 @@ __global__ void bn_bwd_apply(const float* __restrict__ g, const float* __restric
         dx[i] = o;
         am = fmaxf(am, fabsf(o));
     }
-    if (absmax) {           // max |dx| for the consumer's power-of-two operand scale (non-negative floats order like their bit patterns)
-        am = wave_max(am);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(am));
+    if (absmax) {           // max |dx| for the consumer's power-of-two operand scale
+        __shared__ float red[16];
+        block_absmax_to(absmax, am, red);
     }
 }
 
@@ -1113,8 +1113,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(const float* __restri
         }
     }
     if (absmax) {
-        am = wave_max(am);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(am));
+        __shared__ float red[16];
+        block_absmax_to(absmax, am, red);
     }
 }
 

@@ -492,8 +492,8 @@ int a2s_gemm_f16x2_enabled(void) {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    __shared__ float red[16];
+    block_absmax_to(out, m, red);
 }
 int a2s_absmax_impl(hipStream_t st, const float* x, long n, float* out) {
     A2S_REQUIRE(x && out && n >= 0, "absmax: null tensor");
