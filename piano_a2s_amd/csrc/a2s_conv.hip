@@ -350,32 +350,75 @@ __global__ void conv_pack_weights_split(const float* __restrict__ w, unsigned sh
 #ifndef C4_MH
 #define C4_MH 2          // m-tiles per pass of a k-step (2: half the A-fragment registers, B fragments read twice)
 #endif
-// two-term fp16 variant of c4_multiply: three products per k-step, smallest first
-template <int KS, int NT, int COUT>
-__device__ __forceinline__ void c4_multiply_f16x2(const unsigned char* __restrict__ lin, const unsigned char* __restrict__ lw,
-                                                  const int (&aoff)[KS], int boff, f32x4 (&acc)[4][NT], int nh) {
+// two-term fp16 variant of c4_multiply: three products per k-step, smallest first.
+//   * product-major order: each product runs over ALL MT x NT accumulators before the next product touches them again (an MFMA that
+//     accumulates into the register its predecessor-but-one wrote would stall on the 8-pass latency of v_mfma_f32_16x16x32);
+//   * the fragment reads are software-pipelined: the 2 (MT + NT) ds_read_b128 of k-step s+1 are issued BETWEEN the MFMAs of k-step s
+//     (sched_group_barrier: one read, then three MFMAs, ...), into a second register set.  hipcc's own schedule issued every read right
+//     before its first use (s_waitcnt lgkmcnt straight after the read, three to five times per k-step): with two waves per SIMD the
+//     ~130-cycle LDS latency was exposed each time -- the multiply phase alone ran at 35 % matrix-pipe utilisation.
+// MT = m-tiles computed (2: the last column tile of F = 480 holds 32 valid columns).
+#ifndef C2_PIPE
+#define C2_PIPE 1
+#endif
+template <int MT, int NT>
+struct C2Frag { f16x8 a[2][MT], b[2][NT]; };
+template <int MT, int NT, int COUT>
+__device__ __forceinline__ void c2_load(C2Frag<MT, NT>& f, const unsigned char* __restrict__ lin, const unsigned char* __restrict__ lw, int aoff, int boff, int s) {
     constexpr int WPL = c4_wpl(COUT);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+    for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int h = 0; h < 4 / C4_MH; ++h) {
-            if (h >= nh) break;
-            f16x8 av[2][C4_MH];
+        for (int i = 0; i < MT; ++i) f.a[sp][i] = *reinterpret_cast<const f16x8*>(lin + sp * C4_INPL + aoff + i * 16 * C4_PSTR);
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp)
+    for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-                for (int i = 0; i < C4_MH; ++i) av[sp][i] = *reinterpret_cast<const f16x8*>(lin + sp * C4_INPL + aoff[s] + (C4_MH * h + i) * 16 * C4_PSTR);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                f16x8 bv[2];
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) bv[sp] = *reinterpret_cast<const f16x8*>(lw + sp * WPL + boff + s * 2 * COUT * 16 + j * 256);
+        for (int j = 0; j < NT; ++j) f.b[sp][j] = *reinterpret_cast<const f16x8*>(lw + sp * WPL + boff + s * 2 * COUT * 16 + j * 256);
+}
+template <int MT, int NT, bool PIN>
+__device__ __forceinline__ void c2_products(const C2Frag<MT, NT>& f, f32x4 (&acc)[4][NT]) {
 #define C4_PRODUCT(SA, SB)                                                                                                   \
-                _Pragma("unroll") for (int i = 0; i < C4_MH; ++i)                                                            \
-                    acc[C4_MH * h + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[SA][i], bv[SB], acc[C4_MH * h + i][j], 0, 0, 0);
-                C4_PRODUCT(1, 0) C4_PRODUCT(0, 1) C4_PRODUCT(0, 0)
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[SA][i], f.b[SB][j], acc[i][j], 0, 0, 0);
+    // PIN (the last k-step, nothing to interleave): keep the three products apart -- left alone, hipcc groups the three MFMAs of each
+    // accumulator back to back (a dependent chain: three times the 8-pass latency per accumulator)
+    C4_PRODUCT(1, 0)
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
+    C4_PRODUCT(0, 1)
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
+    C4_PRODUCT(0, 0)
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
 #undef C4_PRODUCT
+}
+template <int KS, int MT, int NT, int COUT>
+__device__ __forceinline__ void c4_multiply_f16x2(const unsigned char* __restrict__ lin, const unsigned char* __restrict__ lw,
+                                                  const int (&aoff)[KS], int boff, f32x4 (&acc)[4][NT]) {
+    constexpr int NREAD = 2 * (MT + NT), NMFMA = 3 * MT * NT, PER = NMFMA / NREAD;        // MFMAs between two reads
+#if !C2_PIPE
+    // one register set (3 workgroups per CU: 168 registers): the other two waves of the SIMD cover the read latency
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        C2Frag<MT, NT> g;
+        c2_load<MT, NT, COUT>(g, lin, lw, aoff[s], boff, s);
+        c2_products<MT, NT, true>(g, acc);
+    }
+    return;
+#endif
+    C2Frag<MT, NT> f[2];
+    c2_load<MT, NT, COUT>(f[0], lin, lw, aoff[0], boff, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) c2_load<MT, NT, COUT>(f[(s + 1) & 1], lin, lw, aoff[s + 1], boff, s + 1);
+        if (s + 1 < KS) c2_products<MT, NT, false>(f[s & 1], acc);
+        else { __builtin_amdgcn_sched_barrier(0); c2_products<MT, NT, true>(f[s & 1], acc); }
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int r = 0; r < NREAD; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // one DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                // PER MFMAs
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - PER * NREAD, 0);
         }
     }
 }
@@ -431,20 +474,53 @@ __device__ __forceinline__ void c4_multiply(const unsigned char* __restrict__ li
 // split2_pair_f16); fp16's narrow exponent range is handled by exact power-of-two scales: the weights by 2^(13 - exponent of max|w|)
 // (pack kernel), a gradient operand by 2^(12 - exponent of max|x|) (x_absmax, written by the kernel that produced it), activations
 // unscaled; the accumulators are multiplied by the inverse power of two in the epilogue.
+#ifdef C4_TRACE
+// timing instrumentation (tools/conv_trace.py): shader-clock stamps of wave 0 of a few mid-grid workgroups, 8 stamps per stage
+#define C4_TRACE_WGS 8
+#define C4_TRACE_STAGES 24
+__device__ unsigned long long c4_trace[C4_TRACE_WGS * C4_TRACE_STAGES * 8];
+extern "C" int a2s_conv_trace_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(c4_trace), sizeof(c4_trace));
+}
+#define C4_STAMP(k)                                                                                                           \
+    do {                                                                                                                      \
+        if (trace_wg >= 0 && q < C4_TRACE_STAGES && tid == 0) c4_trace[(trace_wg * C4_TRACE_STAGES + q) * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define C4_STAMP(k) do {} while (0)
+#endif
+#ifndef C4_XCD_SWIZZLE
+#define C4_XCD_SWIZZLE 1
+#endif
+#ifndef C4_WGS
+#define C4_WGS 2          // workgroups per CU the two-term kernel is compiled for (3: 168 registers, 52.9 KB of LDS)
+#endif
 template <int COUT, bool BNRED, int TERMS>
-__global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsigned char* __restrict__ wpack) {
+__global__ __launch_bounds__(256, (TERMS == 2 ? C4_WGS : 2)) void conv3x3_split(ConvArgs a, const unsigned char* __restrict__ wpack) {
     constexpr int NT = (COUT + 15) / 16;
     constexpr int WPL = c4_wpl(COUT);                    // bytes per term plane of a packed weight chunk
     constexpr int WCH = (TERMS * WPL + 4095) / 4096 * 4096;  // chunk stride of the packed image: whole 4 x 1 KB LDS-DMA rounds
+    // LDS copy of a chunk: whole 1 KB DMA pieces.  The B fragments of the last n-tile read up to 7 rows past a slot (channels 40..47): past the
+    // last slot that is beyond this array -- whatever lies there only reaches accumulator columns >= COUT, which are never stored.
+    constexpr int WLDS = (TERMS * WPL + 1023) / 1024 * 1024;
     __shared__ __attribute__((aligned(16))) unsigned char lin[TERMS * C4_INPL];      // 38016 B (3 terms)
-    __shared__ __attribute__((aligned(16))) unsigned char lw[WCH];                   // 40960 B (COUT 40); the zero tail covers the n-tile overrun of the last slot
+    __shared__ __attribute__((aligned(16))) unsigned char lw[WLDS];
     __shared__ float red[4][NT * 16][2];
     __shared__ __attribute__((aligned(16))) float lsc[48], lsh[48];                   // producer's BatchNorm scale / shift (0 beyond Cin)
 
     const int tilesF = (a.F + C2_FT - 1) / C2_FT;
     const int tilesT = (a.T + CV_TR - 1) / CV_TR;
     const int groupsT = (tilesT + C3_TPW - 1) / C3_TPW;
+    // XCD-aware order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (id % 8), each with its own L2.  Logical
+    // tile L = (id % 8) * (n / 8) + id / 8 gives every XCD a contiguous run of tiles, so the F-tiles of a row group -- which share halo
+    // columns and together read each 1920-byte activation row in full -- are resident on ONE XCD at the same time.
     int bid = blockIdx.x;
+#if C4_XCD_SWIZZLE
+    {
+        const int per = (int)gridDim.x / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+#endif
     const int ft = bid % tilesF; bid /= tilesF;
     const int tg = bid % groupsT; const int b = bid / groupsT;
     const int f0 = ft * C2_FT;
@@ -497,10 +573,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
     auto load_weights = [&](int ch) {
         const unsigned char* wsrc = wpack + (long)ch * WCH;
 #pragma unroll
-        for (int it = 0; it < WCH / 4096; ++it) {
+        for (int it = 0; it < (WLDS / 1024 + 3) / 4; ++it) {
             const int off = (it * 4 + wave) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + off + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(lw + off), 16, 0, 0);
+            if (off < WLDS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + off + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(lw + off), 16, 0, 0);
         }
     };
     // Staging items of this thread, decoded ONCE: (row, position, group) packed in one register + the element offset relative to
@@ -594,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
     int resident = -1;
     bool acc_neg = false;
     const int nh = (f0 + C4_MH * 16 >= a.F) ? 1 : 4 / C4_MH;      // m-tile passes that hold any valid column (F = 480: 7.5 tiles of 64)
+    const bool half_tile = f0 + 32 >= a.F;                        // two-term kernel: two m-tiles instead of four
     auto flip_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -605,15 +683,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
 #ifndef C4_PREFETCH
 #define C4_PREFETCH 1     // issue the next stage's input loads before this stage's multiply (with three products per k-step the multiply no
 #endif                    // longer covers the other workgroup's load round trip; round 1, six products: no gain)
+#ifdef C4_TRACE
+    const int trace_first = (int)gridDim.x / 2;
+    const int trace_wg = ((int)blockIdx.x >= trace_first && (int)blockIdx.x < trace_first + C4_TRACE_WGS) ? (int)blockIdx.x - trace_first : -1;
+#endif
     if (C4_PREFETCH && nstage > 0) issue(0);
     for (int q = 0; q < nstage; ++q) {
+        C4_STAMP(0);
         __syncthreads();                      // previous stage fully consumed
+        C4_STAMP(1);
         if (stage_chunk(q) != resident) load_weights(stage_chunk(q));
         if (!C4_PREFETCH) issue(q);
         commit(q);
         resident = stage_chunk(q);
+        C4_STAMP(2);
         __syncthreads();
+        C4_STAMP(3);
         if (C4_PREFETCH && q + 1 < nstage) issue(q + 1);
+        C4_STAMP(4);
         // The bf16 matrix pipe truncates its internal sum toward -infinity (measured: mean error -3e-9 sum|a||b|, always negative, against
         // a random part of 5e-8) -- nothing for one output, but the BatchNorm sums over 10^6 positions see 70x their random error.  Odd
         // stages therefore accumulate the NEGATED sum (input negated while staging, accumulators flipped): the truncation then pushes
@@ -623,9 +710,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
             if (ncgs - 2 * resident >= 2) c4_multiply<5, NT, COUT>(lin, lw, aoff2, boff, acc, nh);
             else c4_multiply<3, NT, COUT>(lin, lw, aoff1, boff, acc, nh);
         } else {
-            if (ncgs - 2 * resident >= 2) c4_multiply_f16x2<5, NT, COUT>(lin, lw, aoff2, boff, acc, nh);
-            else c4_multiply_f16x2<3, NT, COUT>(lin, lw, aoff1, boff, acc, nh);
+            if (half_tile) {
+                if (ncgs - 2 * resident >= 2) c4_multiply_f16x2<5, 2, NT, COUT>(lin, lw, aoff2, boff, acc);
+                else c4_multiply_f16x2<3, 2, NT, COUT>(lin, lw, aoff1, boff, acc);
+            } else {
+                if (ncgs - 2 * resident >= 2) c4_multiply_f16x2<5, 4, NT, COUT>(lin, lw, aoff2, boff, acc);
+                else c4_multiply_f16x2<3, 4, NT, COUT>(lin, lw, aoff1, boff, acc);
+            }
         }
+        C4_STAMP(5);
         if ((q + 1) % nchunks != 0) continue;
         if (acc_neg) { flip_acc(); acc_neg = false; }
         if (TERMS == 2) {
@@ -682,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split(ConvArgs a, const unsign
             }
             __builtin_amdgcn_sched_barrier(0);        // one n-tile at a time: hoisting every yl load spills the prefetched input
         }
+        C4_STAMP(6);
     }
     if (a.stat_partial) {
 #pragma unroll
@@ -1182,7 +1276,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad(const float* __restrict_
         ldy[(r * MT * 16 + COUT) * DRS + rem] = 0.f;
     }
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // XCD-aware walk (see conv3x3_wgrad_split): each XCD's workgroups (id % 8) share a contiguous eighth of the tile space
+    long t_begin = blockIdx.x, t_end = ntiles, t_step = gridDim.x;
+    if (gridDim.x % 8 == 0) {
+        const long chunk = (ntiles + 7) / 8;
+        t_begin = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+        t_end = min(ntiles, (long)(blockIdx.x % 8 + 1) * chunk);
+        t_step = gridDim.x / 8;
+    }
+    for (long tile = t_begin; tile < t_end; tile += t_step) {
         long bid = tile;
         const int ft = (int)(bid % tilesF); bid /= tilesF;
         const int tt = (int)(bid % tilesT); const int b = (int)(bid / tilesT);
@@ -1619,13 +1721,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __res
             if (TERMS == 3) *reinterpret_cast<unsigned short*>(dst + (TERMS - 1) * XPL) = (unsigned short)p2;
         }
     };
-    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++round) {
+    // XCD-aware walk: workgroup ids are dealt round-robin to the 8 XCDs (id % 8); every XCD walks its own contiguous eighth of the tile
+    // space, its workgroups side by side on consecutive tiles -- the 8 column tiles of a row strip (the whole 1920-byte rows) and the
+    // strips above / below (shared halo rows) then meet in ONE L2 instead of eight.
+    long t_begin = blockIdx.x, t_end = ntiles, t_step = gridDim.x;
+    if (gridDim.x % 8 == 0) {
+        const long chunk = (ntiles + 7) / 8;
+        t_begin = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+        t_end = min(ntiles, (long)(blockIdx.x % 8 + 1) * chunk);
+        t_step = gridDim.x / 8;
+    }
+    if (t_begin < t_end) issue(t_begin);
+    for (long tile = t_begin; tile < t_end; tile += t_step, ++round) {
         const bool neg = round & 1;
         __syncthreads();                     // previous tile consumed (first round: the zero fill is complete)
         commit(tile, neg ? 0x80000000u : 0u);
         __syncthreads();
-        if (tile + gridDim.x < ntiles) issue(tile + gridDim.x);      // in flight during the multiply below
+        if (tile + t_step < t_end) issue(tile + t_step);      // in flight during the multiply below
         if (neg != acc_neg) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
