@@ -89,12 +89,26 @@ def conv_roofline(B, T, F, iters=6):
         two = bool(L.a2s_debug_get(b"conv_f16x2") & 1)
         products = 3 if two else 6
         peak = MFMA_BF16_PEAK_TFS / products
-        return {"bound": "mfma", "kernel": f"conv3x3_split<40, false, {2 if two else 3}> (conv4 forward launch, incl. its weight split/packing pre-kernels)",
-                "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+        mfma = {"achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "peak_note": f"fp32-equivalent: 2.5 PFLOP/s dense {'fp16' if two else 'bf16'} MFMA / {products} term products per fp32 product "
                              f"({'two-term fp16' if two else 'three-term bf16'} exact operand split)",
-                "frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFS, 4),
-                "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}
+                "frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFS, 4), "algorithmic_flops_per_launch": int(flops)}
+        # The same launch against the HBM roof: algorithmic bytes = the input and the output tensor once each.  With three term products the
+        # kernel's arithmetic intensity (2*9*Cin*Cout / (4*(Cin+Cout)) = 90 flop/B) lies just below the ridge of the two roofs (833 TFLOP/s /
+        # 8 TB/s = 104 flop/B): it is the memory side that binds, and `bound` names whichever roof the launch is closer to.  `traffic`: the
+        # PMC measurement committed in profiles/r02_conv_analysis.txt (FETCH_SIZE x2 + WRITE_SIZE at B = 32: 1.289 x the algorithmic bytes
+        # -- the 6/4 x 66/64 tile halo is re-fetched), scaled to this launch's batch.
+        nbytes = 4.0 * B * T * F * (ci + co)
+        gbs = nbytes / avg_s / 1e9
+        hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+               "algorithmic_bytes_per_launch": int(nbytes)}
+        traffic = int(1.289 * nbytes) if two else None
+        first, other, bound = (hbm, mfma, "hbm") if hbm["frac"] >= mfma["frac"] else (mfma, hbm, "mfma")
+        out = {"bound": bound, "kernel": f"conv3x3_split<40, false, {2 if two else 3}> (conv4 forward launch, incl. its weight split/packing pre-kernels)"}
+        out.update(first)
+        out.update({"traffic": traffic, "traffic_source": "rocprofv3 PMC at B=32 scaled by batch (profiles/r02_conv_analysis.txt)" if traffic else None,
+                    "avg_launch_us": round(avg_s * 1e6, 1), ("mfma_view" if bound == "hbm" else "hbm_view"): other})
+        return out
     return {"bound": "mfma", "kernel": "conv3x3_mfma<40, false> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
             "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFS, 4), "traffic": None,
             "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}

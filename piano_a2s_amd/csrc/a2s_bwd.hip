@@ -840,7 +840,13 @@ __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restri
     }
     const float* pb = dq_partial + ((long)slot * groups + grp) * G * 256;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += pb[(long)g * 256 + j];
+    for (int g0 = 0; g0 < G; g0 += 8) {               // 8 independent loads per round trip
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = (g0 + u < G) ? pb[(long)(g0 + u) * 256 + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += p[u];
+    }
     dq[(long)b * lddq + j] = s;
 }
 

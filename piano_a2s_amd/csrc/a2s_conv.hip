@@ -1614,13 +1614,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __res
     constexpr int DIT = (COUT * 32 + 511) / 512, XIT = 5;           // 16-byte loads per thread: dy (3 / 2), input (<= 40 ch x 4 rows x 16)
     f32x4 dreg[DIT], xreg[XIT];
     float hreg = 0.f;
-    auto issue = [&](long tile) {
+    // one slice = one 16-byte load per thread (slices 0 .. DIT-1: dy, then XIT of the input; the halo columns ride on the last)
+    auto issue_slice = [&](long tile, int slice) {
         long bid = tile;
         const int ft = (int)(bid % tilesF); bid /= tilesF;
         const int tt = (int)(bid % tilesT); const int b = (int)(bid / tilesT);
         const int t0 = tt * 2, f0 = ft * 64;
 #pragma unroll
         for (int it = 0; it < DIT; ++it) {
+            if (it != slice) continue;
             const int e = tid + 512 * it;
             const int co = e >> 5, r = (e >> 4) & 1, fq = e & 15;
             const int t = t0 + r, f = f0 + 4 * fq;
@@ -1637,6 +1639,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __res
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
+            if (DIT + it != slice) continue;
             const int e = tid + 512 * it;
             const int ci = e >> 6, row = (e >> 4) & 3, fq = e & 15;
             const int t = t0 + row - 1, f = f0 + 4 * fq;
@@ -1651,6 +1654,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __res
             }
             xreg[it] = v;
         }
+        if (slice != DIT + XIT - 1) return;
         hreg = 0.f;
         if (tid < Cin * 8) {                 // halo columns f0 - 1 and f0 + 64
             const int ci = tid >> 3, row = (tid >> 1) & 3, side = tid & 1;
@@ -1731,13 +1735,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __res
         t_end = min(ntiles, (long)(blockIdx.x % 8 + 1) * chunk);
         t_step = gridDim.x / 8;
     }
+#ifdef C4_TRACE
+    const int trace_wg = (blockIdx.x >= 64 && blockIdx.x < 64 + C4_TRACE_WGS) ? (int)blockIdx.x - 64 : -1;
+#define W4_STAMP(k) do { if (trace_wg >= 0 && round >= 100 && round < 100 + C4_TRACE_STAGES && tid == 0) c4_trace[(trace_wg * C4_TRACE_STAGES + round - 100) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W4_STAMP(k) do {} while (0)
+#endif
+    auto issue = [&](long tile) {
+#pragma unroll
+        for (int sl = 0; sl < DIT + XIT; ++sl) issue_slice(tile, sl);
+    };
     if (t_begin < t_end) issue(t_begin);
     for (long tile = t_begin; tile < t_end; tile += t_step, ++round) {
         const bool neg = round & 1;
+        W4_STAMP(0);
         __syncthreads();                     // previous tile consumed (first round: the zero fill is complete)
+        W4_STAMP(1);
         commit(tile, neg ? 0x80000000u : 0u);
+        W4_STAMP(2);
         __syncthreads();
-        if (tile + t_step < t_end) issue(tile + t_step);      // in flight during the multiply below
+        W4_STAMP(3);
+        // in flight during the multiply below.  (Issuing them slice by slice BETWEEN the MFMAs of the multiply instead of as one burst was
+        // measured: the burst's 2.3 k clocks of back-pressure disappear, but the multiply grows from 8.1 k to 12.8 k clocks per tile -- a
+        // wave stalled on a full memory queue issues no MFMAs either.)
+        if (tile + t_step < t_end) issue(tile + t_step);
+        W4_STAMP(4);
         if (neg != acc_neg) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -1797,6 +1819,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __res
 #undef W4_PRODUCT
             }
         }
+        W4_STAMP(5);
     }
     // slab [Cout][Cin][9]; C/D map: lane holds column n = li (input channel of the tile), rows 4 lk + r (output channel)
 #pragma unroll

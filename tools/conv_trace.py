@@ -26,7 +26,17 @@ def main():
     nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
     partial = torch.empty(nblk, co, 2, device=dev)
     cws = hip.conv_workspace(ci, dev)
-    for _ in range(2):
+    wgrad = os.environ.get("A2S_TRACE_WGRAD") == "1"
+    if wgrad:                                            # weight-gradient kernel instead (stamps of rounds 100..123 of 8 workgroups)
+        dy = torch.randn(B, T, co, F, device=dev) * 1e-4
+        dW = torch.zeros(co, ci, 3, 3, device=dev)
+        nbytes = L.a2s_conv3x3_wgrad_workspace_bytes(ci, co)
+        ws = torch.empty(nbytes // 4, device=dev)
+        amax = hip.absmax(dy)
+        for _ in range(2):
+            hip.check(L.a2s_conv3x3_wgrad_scaled(hip.stream(), hip._p(dy), hip._p(x), hip._p(scale), hip._p(shift), hip._p(dW), hip._p(ws),
+                                                 C.c_size_t(nbytes), B, T, F, ci, co, hip._p(amax)), "wgrad")
+    for _ in range(0 if wgrad else 2):
         hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(w), hip._p(y), hip._p(scale), hip._p(shift), hip._p(partial), B, T, F, ci, co, 0, hip._p(cws)), "conv")
     torch.cuda.synchronize()
     buf = np.zeros(8 * 24 * 8, dtype=np.uint64)
@@ -34,6 +44,8 @@ def main():
     assert rc == 0, rc
     t = buf.reshape(8, 24, 8).astype(np.int64)
     names = ["barrier1 wait", "commit (+weight DMA issue)", "barrier2 wait", "issue next loads", "multiply (issue)", "epilogue"]
+    if wgrad:
+        names[1], names[5] = "commit", "(unused)"
     tot = np.zeros(6)
     for wg in range(8):
         for q in range(24):
