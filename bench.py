@@ -40,8 +40,8 @@ TF_RATIO = 0.7                 # hparams/pretrain.yaml teacher_forcing_ratio at 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("A2S_BENCH_BATCH", "256")), help="clips per GPU per step")
     ap.add_argument("--full-tail", type=float, default=0.01, help="probability of a full-length (no <eos>) row per (clip,bar,staff); SURVEY 8d: 1 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")

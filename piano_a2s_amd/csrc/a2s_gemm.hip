@@ -242,6 +242,14 @@ __device__ __forceinline__ void tile_store_split_T(unsigned char* __restrict__ l
     }
 }
 
+#ifdef GEMM_TRACE
+// timing instrumentation (tools/linear_bench.py --trace): shader-clock stamps of thread 0 of 8 mid-grid workgroups, k-tiles 100..123
+__device__ unsigned long long gemm_trace[8 * 24 * 8];
+extern "C" int a2s_gemm_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm_trace), sizeof(gemm_trace)); }
+#define G_STAMP(k) do { if (trace_wg >= 0 && t >= 100 && t < 124 && threadIdx.x == 0) gemm_trace[(trace_wg * 24 + t - 100) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G_STAMP(k) do {} while (0)
+#endif
 // SPLIT: 0 = fp32-input MFMA; 3 = three bf16 terms, six products; 2 = two fp16 terms, three products (operands scaled by exact powers of two
 // from their max-magnitude scalars, the accumulators unscaled before the epilogue -- see conv3x3_split in a2s_conv.hip)
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int SPLIT = 0>
@@ -250,12 +258,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int NLA = (BM * 8 + 255) / 256, NLB = (BN * 8 + 255) / 256;
     using LA = LdsTile<BM, A_KC>;
     using LB = LdsTile<BN, B_KC>;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (LA::SIZE + LB::SIZE)];
+    // the split paths stage ONE tile as term planes (2 terms, 128x128: 40 KB -- three workgroups per CU where the registers allow);
+    // the fp32 path double-buffers fp32 tiles
+    constexpr int LDS_FLOATS = SPLIT != 0 ? SPLIT * (BM + BN) * GEMM_SPLIT_RS / 4 : 2 * (LA::SIZE + LB::SIZE);
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
     const float* A = g.A + (long)zb * g.bsA;
     const float* B = g.B + (long)zb * g.bsB;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: the hardware deals consecutive workgroup ids (x fastest) round-robin to the 8 XCDs, each with its own L2.
+    // Logical tile L = (id % 8) * (n / 8) + id / 8 gives every XCD a contiguous run of tiles: the column tiles of one row block (which
+    // read the same A rows) and neighbouring row blocks (the same B k-slices at the same time) then share ONE L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int n = gridDim.x * gridDim.y, id = by * gridDim.x + bx, per = n / 8;
+        if (n >= 64 && id < per * 8) {
+            const int l = (id % 8) * per + id / 8;
+            bx = l % gridDim.x; by = l / gridDim.x;
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = zs * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -306,15 +328,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             else tile_load_T<BN>(B, g.sBk, n0, k0, g.N, kend, g.vecB, tb, tfb, g.b_scale, g.b_shift, g.b_period);
         };
         if (ntiles > 0 && !(A_KC && B_KC)) load_tile(kbeg);      // (the k-contiguous prologue loads above are dead code for a transposed operand)
+#ifdef GEMM_TRACE
+        const int trace_id = (int)(blockIdx.y * gridDim.x + blockIdx.x), trace_first = (int)(gridDim.x * gridDim.y) / 2;
+        const int trace_wg = (trace_id >= trace_first && trace_id < trace_first + 8) ? trace_id - trace_first : -1;
+#endif
         for (int t = 0; t < ntiles; ++t) {
             const bool want = (t >> 3) & 1;
+            G_STAMP(0);
             __syncthreads();                  // the previous tile's fragments are consumed
+            G_STAMP(1);
             if constexpr (A_KC) tile_store_split<BM, NLA, SPLIT>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want, psa);
             else tile_store_split_T<BM, SPLIT>(la, ta, tfa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want, psa);
             if constexpr (B_KC) tile_store_split<BN, NLB, SPLIT>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false, psb);
             else tile_store_split_T<BN, SPLIT>(lb, tb, tfb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false, psb);
+            G_STAMP(2);
             __syncthreads();
+            G_STAMP(3);
             if (t + 1 < ntiles) load_tile(kbeg + (t + 1) * GEMM_BK);
+            G_STAMP(4);
             if (want != neg) { flip(); neg = want; }
             typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
             gu32x4 af[SPLIT][TM];
@@ -335,6 +366,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 GEMM_PRODUCT(1, 0) GEMM_PRODUCT(0, 1) GEMM_PRODUCT(0, 0)
 #undef GEMM_PRODUCT
             }
+            G_STAMP(5);
         }
         if (neg) flip();
         if (SPLIT == 2) {
@@ -449,8 +481,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int c = ep_c0 + sl;
             if (c < g.ep_channels && (long)c * g.ep_period < (long)n0 + BN) {
                 const float tot = red[0 * 4 + threadIdx.x] + red[1 * 4 + threadIdx.x] + red[2 * 4 + threadIdx.x] + red[3 * 4 + threadIdx.x];
-                const int slot = blockIdx.x - (int)(((long)c * g.ep_period) / BN);        // which of the channel's column tiles this is
-                g.ep_partial[(((long)blockIdx.y * g.ep_slots + slot) * g.ep_channels + c) * 2 + k] = tot;
+                const int slot = bx - (int)(((long)c * g.ep_period) / BN);        // which of the channel's column tiles this is
+                g.ep_partial[(((long)by * g.ep_slots + slot) * g.ep_channels + c) * 2 + k] = tot;
             }
         }
     }

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2; mkdir -p $O
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_kt.log 2>&1
+python tools/kernel_stats.py $O/kt 60 > $O/kernel_stats.txt 2>&1
+python tools/trace_overlap.py $O/kt > $O/trace_overlap.txt 2>&1
+rm -rf $O/kt
