@@ -50,14 +50,14 @@ template <int ROWS, bool KC> struct LdsTile {
 };
 
 // One operand tile: ROWS (m or n) x 32 (k).  elem(r,k) = P[r*sR + k*sK].
-template <int ROWS, bool KC, int NLD>
+template <int ROWS, bool KC, int NLD, int NTH = 256>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, long sR, long sK, int r0, int k0,
                                           int rmax, int kmax, bool vec, f32x4 (&reg)[NLD], float (&aff)[NLD][2],
                                           const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr, int period = 1) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int slot = tid + i * 256;
+        const int slot = tid + i * NTH;
         int r, k;
         if (KC) { r = slot >> 3; k = (slot & 7) * 4; }                 // 8 float4 per row of 32 k
         else    { constexpr int PER = ROWS / 4; k = slot / PER; r = (slot % PER) * 4; }
@@ -132,7 +132,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 
 // Split path (both operands k-contiguous): registers -> LDS as three bf16 term planes [term][ROWS][32 k (+8 pad)], 80-byte rows so
 // that a lane's fragment (8 consecutive k of one row) is one ds_read_b128.  Same optional operand BatchNorm+ReLU as tile_store.
 #define GEMM_SPLIT_RS 80
-template <int ROWS, int NLD, int TERMS = 3>
+template <int ROWS, int NLD, int TERMS = 3, int NTH = 256>
 __device__ __forceinline__ void tile_store_split(unsigned char* __restrict__ lds, const f32x4 (&reg)[NLD], const float (&aff)[NLD][2], int r0, int k0,
                                                  int rmax, int kmax, const float* __restrict__ scale, const float* __restrict__ shift, int period,
                                                  bool negate, float pscale = 1.f) {
@@ -140,7 +140,7 @@ __device__ __forceinline__ void tile_store_split(unsigned char* __restrict__ lds
     const unsigned sgn = negate ? 0x80000000u : 0u;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int slot = tid + i * 256;
+        const int slot = tid + i * NTH;
         const int r = slot >> 3, k = (slot & 7) * 4;
         if (r >= ROWS) continue;
         f32x4 v = reg[i];
@@ -183,7 +183,7 @@ __device__ __forceinline__ void tile_store_split(unsigned char* __restrict__ lds
 template <int ROWS>
 __device__ __forceinline__ void tile_load_T(const float* __restrict__ P, long sK, int r0, int k0, int rmax, int kmax, bool vec, f32x4 (&reg)[4],
                                             float (&aff)[2], const float* __restrict__ scale, const float* __restrict__ shift, int period) {
-    static_assert(ROWS == 128, "transposed split staging is written for 128-row tiles");
+    // ROWS = threads / 2 (128-row tiles with 256 threads, 256-row tiles with 512): enforced by the kernel
     const int rq = threadIdx.x >> 3, kc = threadIdx.x & 7;
     const int gr = r0 + rq * 4;
     if (scale) {
@@ -253,9 +253,11 @@ extern "C" int a2s_gemm_trace_read(unsigned long long* out) { return (int)hipMem
 // SPLIT: 0 = fp32-input MFMA; 3 = three bf16 terms, six products; 2 = two fp16 terms, three products (operands scaled by exact powers of two
 // from their max-magnitude scalars, the accumulators unscaled before the epilogue -- see conv3x3_split in a2s_conv.hip)
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int SPLIT = 0>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int NTH = WM * WN * 64;                   // 256 threads; 512 for the 256x256 two-term tile
     constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
-    constexpr int NLA = (BM * 8 + 255) / 256, NLB = (BN * 8 + 255) / 256;
+    constexpr int NLA = (BM * 8 + NTH - 1) / NTH, NLB = (BN * 8 + NTH - 1) / NTH;
+    static_assert(NTH == 256 || SPLIT == 2, "only the two-term split kernel is written for 8 waves");
     using LA = LdsTile<BM, A_KC>;
     using LB = LdsTile<BN, B_KC>;
     // the split paths stage ONE tile as term planes (2 terms, 128x128: 40 KB -- three workgroups per CU where the registers allow);
@@ -294,15 +296,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     float fa[NLA][2], fb[NLB][2];          // per-float4 operand BatchNorm constants (only touched when an operand affine is given)
     const int ntiles = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
     if (ntiles > 0) {
-        tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
-        tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
+        tile_load<BM, A_KC, NLA, NTH>(A, g.sAm, g.sAk, m0, kbeg, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
+        tile_load<BN, B_KC, NLB, NTH>(B, g.sBn, g.sBk, n0, kbeg, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
     }
     if constexpr (SPLIT != 0) {
         // fp32 operands as three exact bf16 terms on the bf16 matrix pipes (six term products per k-step of 32, see conv3x3_bf16x3 in
         // a2s_conv.hip); single LDS buffer (2 x 30 KB), the next tile's global loads stay in flight during the multiply.  The pipe truncates
         // its internal sum toward -infinity: every other block of 8 k-tiles accumulates the negated sum (A negated while staging).
         static_assert(SPLIT * (BM + BN) * GEMM_SPLIT_RS <= (int)sizeof(lds), "split path: the term planes must fit the fp32 path's LDS");
-        static_assert((A_KC || BM == 128) && (B_KC || BN == 128), "split path: row-contiguous operands need 128-row tiles");
+        static_assert((A_KC || BM == NTH / 2) && (B_KC || BN == NTH / 2), "split path: row-contiguous operands are staged 4 rows x 4 k per thread");
         unsigned char* la = reinterpret_cast<unsigned char*>(lds);
         unsigned char* lb = la + SPLIT * BM * GEMM_SPLIT_RS;
         bool neg = false;
@@ -322,9 +324,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         f32x4 ta[4], tb[4];                   // row-contiguous operands: 4 rows x 4 k per thread (tile_load_T)
         float tfa[2], tfb[2];
         auto load_tile = [&](int k0) {
-            if constexpr (A_KC) tile_load<BM, true, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
+            if constexpr (A_KC) tile_load<BM, true, NLA, NTH>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
             else tile_load_T<BM>(A, g.sAk, m0, k0, g.M, kend, g.vecA, ta, tfa, g.a_scale, g.a_shift, g.a_period);
-            if constexpr (B_KC) tile_load<BN, true, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
+            if constexpr (B_KC) tile_load<BN, true, NLB, NTH>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
             else tile_load_T<BN>(B, g.sBk, n0, k0, g.N, kend, g.vecB, tb, tfb, g.b_scale, g.b_shift, g.b_period);
         };
         if (ntiles > 0 && !(A_KC && B_KC)) load_tile(kbeg);      // (the k-contiguous prologue loads above are dead code for a transposed operand)
@@ -337,9 +339,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             G_STAMP(0);
             __syncthreads();                  // the previous tile's fragments are consumed
             G_STAMP(1);
-            if constexpr (A_KC) tile_store_split<BM, NLA, SPLIT>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want, psa);
+            if constexpr (A_KC) tile_store_split<BM, NLA, SPLIT, NTH>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want, psa);
             else tile_store_split_T<BM, SPLIT>(la, ta, tfa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period, want, psa);
-            if constexpr (B_KC) tile_store_split<BN, NLB, SPLIT>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false, psb);
+            if constexpr (B_KC) tile_store_split<BN, NLB, SPLIT, NTH>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false, psb);
             else tile_store_split_T<BN, SPLIT>(lb, tb, tfb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period, false, psb);
             G_STAMP(2);
             __syncthreads();
@@ -480,7 +482,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int sl = threadIdx.x >> 1, k = threadIdx.x & 1;
             const int c = ep_c0 + sl;
             if (c < g.ep_channels && (long)c * g.ep_period < (long)n0 + BN) {
-                const float tot = red[0 * 4 + threadIdx.x] + red[1 * 4 + threadIdx.x] + red[2 * 4 + threadIdx.x] + red[3 * 4 + threadIdx.x];
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM * WN; ++w) tot += red[w * 4 + threadIdx.x];
                 const int slot = bx - (int)(((long)c * g.ep_period) / BN);        // which of the channel's column tiles this is
                 g.ep_partial[(((long)by * g.ep_slots + slot) * g.ep_channels + c) * 2 + k] = tot;
             }
@@ -564,6 +568,26 @@ static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, g);
 }
 
+// 256x256 tiles, 8 waves, two-term fp16 split: the big two-term products (19200 -> 256 Linear forward and weight gradient).  The 128x128
+// kernel spends its k-tile period feeding operands into the CU (tools/linear_bench.py trace: 1.3 k clocks issuing the next tile's loads
+// + 2.8 k waiting for them against 1.2 k of multiply): the time goes with the bytes staged per MFMA, and a 256x256 tile stages half.
+static bool big_two_term_ok(const GemmArgs& g, bool akc, bool bkc) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("A2S_GEMM_BIG_TILE"); on = e ? atoi(e) : 1; }
+    const bool a_ok = akc || (g.sAm == 1 && g.vecA), b_ok = bkc || (g.sBn == 1 && g.vecB);
+    // (the BatchNorm-statistics epilogue keeps its partial layout: a 256-column tile touches at most two channels of period >= 256 and
+    // at most as many tiles per channel as the 128-column layout has slots; unused partial rows stay zero)
+    return on && g.two_term && a2s_gemm_f16x2_enabled() && g_gemm_split && (!g.ep_y || g.ep_period >= 256) && g.K >= 256 && a_ok && b_ok && g.M >= 256 && g.N >= 256 &&
+           (long)a2s_cdiv(g.M, 256) * a2s_cdiv(g.N, 256) * g.batch * g.splitk >= 192;
+}
+static void launch_big_two_term(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
+    dim3 grid(a2s_cdiv(g.N, 256), a2s_cdiv(g.M, 256), g.batch * g.splitk);
+    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 4, 2, true, true, 2>), grid, dim3(512), 0, st, g);
+    else if (akc) hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 4, 2, true, false, 2>), grid, dim3(512), 0, st, g);
+    else if (bkc) hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 4, 2, false, true, 2>), grid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<256, 256, 4, 2, false, false, 2>), grid, dim3(512), 0, st, g);
+}
+
 size_t a2s_gemm_workspace_bytes_impl(int M, int N, int batch, int splitk) {
     return splitk > 1 ? (size_t)batch * splitk * M * N * sizeof(float) : 0;
 }
@@ -578,10 +602,13 @@ int a2s_gemm_pick_splitk_impl(int M, int N, int K, int batch) {
         // Pick the split that fills whole rounds best.
         const long t128 = (long)a2s_cdiv(M, 128) * a2s_cdiv(N, 128) * batch;
         if (t128 >= 2048 || K < 32768) return 1;
+        // (judged for both tilings the launch may use: 128x128 at two workgroups per CU, 256x256 two-term at one)
+        const long t256 = (long)a2s_cdiv(M, 256) * a2s_cdiv(N, 256) * batch;
         int best = 1; double best_eff = 0.0;
-        for (int s = 1; s <= 8; ++s) {
-            const long wg = t128 * s;
-            const double eff = (double)wg / (double)(a2s_cdiv(wg, 512) * 512);
+        for (int s = 1; s <= 12; ++s) {
+            const long wg = t128 * s, wg2 = t256 * s;
+            double eff = (double)wg / (double)(a2s_cdiv(wg, 512) * 512);
+            if (M >= 256 && N >= 256) eff = fmin(eff, (double)wg2 / (double)(a2s_cdiv(wg2, 256) * 256));
             if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
         }
         return best;
@@ -680,7 +707,8 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
     g.vecA = (akc ? (sAk == 1 && aligned(A, sAm, bsA)) : (sAm == 1 && aligned(A, sAk, bsA))) ? 1 : 0;
     g.vecB = (bkc ? (sBk == 1 && aligned(B, sBn, bsB)) : (sBn == 1 && aligned(B, sBk, bsB))) ? 1 : 0;
 
-    if (ep_y) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);
+    if (!g_force_tile && big_two_term_ok(g, akc, bkc)) launch_big_two_term(g, akc, bkc, st);
+    else if (ep_y) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);
     else if (!g_force_tile && mid_tile == 2 && g.splitk >= 1 && M * (long)N < (1L << 22)) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);
     else if (!g_force_tile && mid_tile == 3 && M * (long)N < (1L << 22)) launch_cfg<64, 64, 2, 2>(g, akc, bkc, st);
     else if (g_force_tile && M > 64) {
