@@ -140,7 +140,10 @@ int a2s_attn_step_fwd_rows(void* stream, const float* keys, const float* enc, co
                            long ldctx, float* ctx2, long ldctx2, float* attw, int R, int T, int H, float* workspace, int n_clips,
                            const int* clip_order, const int* clip_rank, const int* row_until, int n_active, int step);
 /* workspace (a2s_attn_workspace_floats floats, shared by forward and backward) selects the split-T kernels: the frames of a
- * clip are spread over several workgroups and merged by a combine kernel; NULL (or hidden_size != 256) = one workgroup per clip. */
+ * clip are spread over several workgroups and merged by a combine kernel -- or, with a2s_debug_set("attn_fused_combine", 1), by the
+ * workgroup that finishes last for the clip (measured slower on MI355X, off by default); NULL (or hidden_size != 256) = one workgroup
+ * per clip.  The workspace must be ZERO-INITIALISED ONCE after allocation (its head holds the workgroups' arrival counters, which
+ * every launch leaves at zero) and must not be shared by launches that may run concurrently. */
 size_t a2s_attn_workspace_floats(int B, int T, int H);
 /* the same for a fused-bars decoder call (a2s_note_dec_args.n_clips): `groups` bars of n_clips clips in one call */
 size_t a2s_attn_workspace_floats_fused(int n_clips, int T, int H, int groups);

@@ -874,6 +874,7 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_bwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);
     A2S_REQUIRE(r.n_active >= 0 && r.n_active <= r.n_clips && (!r.clip_order || r.clip_rank), "attn_step_bwd_split: bad row compaction");
     int G = 1, chunk = T;
+    ws += A2S_ATTN_TICKETS;                 // the head of the workspace holds the arrival counters of the fused combines (a2s_seq.hip)
     if (r.n_active > 0) {
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G;

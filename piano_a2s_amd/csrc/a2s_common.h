@@ -76,6 +76,8 @@ struct a2s_attn_rows {
     int step;
 };
 #define A2S_ATTN_MAX_GROUPS 5
+// head of the attention workspace: arrival counters of the fused combine (forward: [0, 4096), backward: [4096, 8192)), in floats
+#define A2S_ATTN_TICKETS 8192
 
 // ----------------------------------------------------------------------------- device helpers
 #ifdef __HIPCC__

@@ -695,6 +695,67 @@ int a2s_staff_emb_fwd_impl(hipStream_t st, const float* note_emb, const float* c
     return A2S_OK;
 }
 
+// ---- combine of a row's G partials, shared by the stand-alone combine kernel and by the split kernels' fused tail (the workgroup that
+// finishes LAST for its clip -- ticket counter, release / acquire through L2 as in dec_out_step -- merges the partials itself: one launch
+// and one dependent-launch gap less per decode step; on the long-clip chain the combine was 7 us + ~4.5 us of gap in a 92 us step).
+// pb: the row's G partials [m, l, pad, pad, ctx(2H)]; one memory round trip for the statistics, one for the contexts.  wgt: 80 floats of LDS.
+struct AttnCombineOut { float* ctx; float* ctx2; float* attw; int T; };
+__device__ __forceinline__ void attn_combine_row(const volatile float* pb, int G, const AttnCombineOut& o, float* wgt) {
+    constexpr int H = 256, PS = 2 * H + 4;
+    const int tid = threadIdx.x;
+    __syncthreads();                                  // wgt free (previous row / the caller's scratch)
+    if (tid < 64) {                                   // G <= 64 (a2s_attn_max_split)
+        const bool have = tid < G;
+        const float mg = have ? pb[(long)tid * PS] : -INFINITY, lg = have ? pb[(long)tid * PS + 1] : 0.f;
+        const float m = wave_max(mg);
+        const float e = have ? __expf(mg - m) : 0.f;
+        const float l = wave_sum(lg * e);
+        wgt[tid] = e / l;
+        if (tid < 16) wgt[64 + tid] = 0.f;
+        if (tid == 0) { wgt[79] = m; wgt[78] = 1.f / l; }
+    }
+    __syncthreads();
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int g0 = 0; g0 < G; g0 += 8) {
+        float p0[8], p1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = g0 + u < G;
+            p0[u] = ok ? pb[(long)(g0 + u) * PS + 4 + tid] : 0.f;
+            p1[u] = ok ? pb[(long)(g0 + u) * PS + 4 + 256 + tid] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc0 = fmaf(p0[u], wgt[g0 + u], acc0); acc1 = fmaf(p1[u], wgt[g0 + u], acc1); }
+    }
+    o.ctx[tid] = acc0; o.ctx[256 + tid] = acc1;
+    if (o.ctx2) { o.ctx2[tid] = acc0; o.ctx2[256 + tid] = acc1; }
+    if (o.attw) {
+        const float m = wgt[79], inv = wgt[78];
+        volatile float* aw = o.attw;                  // raw scores written by the clip's other workgroups
+        for (int t = tid; t < o.T; t += 256) aw[t] = __expf(aw[t] - m) * inv;
+    }
+}
+__device__ __forceinline__ void attn_zero_row(const AttnCombineOut& o) {       // skipped row: a finite, well-defined context (zeros)
+    for (int d = threadIdx.x; d < 512; d += 256) { o.ctx[d] = 0.f; if (o.ctx2) o.ctx2[d] = 0.f; }
+    if (o.attw) for (int t = threadIdx.x; t < o.T; t += 256) o.attw[t] = 0.f;
+}
+// true in exactly one of the G workgroups of a slot: the last one to arrive, after everybody's partials are visible device-wide
+__device__ __forceinline__ bool attn_last_arrival(int* ticket, int G, int* flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(ticket, 1);
+        *flag = (t == G - 1);
+        if (t == G - 1) *ticket = 0;                  // ready for the next launch
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    if (last) __threadfence();
+    return last;
+}
+// what the fused tail needs besides the partials (tickets == nullptr: the stand-alone combine kernel follows)
+struct AttnFusedTail { int* tickets; float* ctx; long ldctx; float* ctx2; long ldctx2; int n_slots_active; int n_rows; };
+
 // =========================================================================================== split-T attention (H = 256)
 // The one-workgroup-per-clip kernel above is latency-bound (3.69 MB per workgroup, measured 15 GB/s per workgroup, 253 us per
 // launch whatever the batch).  Here the 1201 frames of a clip are split over G workgroups (flash-decoding style): each
@@ -705,12 +766,19 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
                                                          const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                          float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
                                                          const int* __restrict__ n_done, int n_rows_total,
-                                                         const int* __restrict__ row_order) {
+                                                         const int* __restrict__ row_order, AttnFusedTail ft) {
     if (n_done && *n_done >= n_rows_total) return;
     constexpr int H = 256;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int last_flag;
     float* pw = sm;                                   // chunk weights exp(s - m_g)
     float* red = sm + chunk;                          // 16 + 2 * 128 * 4 floats (reduction scratch)
+    if (ft.tickets && (int)blockIdx.x >= ft.n_slots_active * G) {        // fused tail: one extra workgroup per skipped row zero-fills it
+        const int zs = ft.n_slots_active + (int)blockIdx.x - ft.n_slots_active * G;
+        const int zb = row_order ? row_order[zs] : zs;
+        attn_zero_row(AttnCombineOut{ft.ctx + (long)zb * ft.ldctx, ft.ctx2 ? ft.ctx2 + (long)zb * ft.ldctx2 : nullptr, scores ? scores + (long)zb * T : nullptr, T});
+        return;
+    }
     const int slot = blockIdx.x / G, g = blockIdx.x % G;          // slot: position among the rows this launch covers
     const int b = row_order ? row_order[slot] : slot;
     const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
@@ -786,6 +854,10 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
         *reinterpret_cast<f32x4*>(pout + 4 + c4 * 4) = acc;
     }
     if (tid == 0) { pout[0] = m; pout[1] = l; }
+    if (!ft.tickets) return;
+    if (!attn_last_arrival(ft.tickets + slot, G, &last_flag)) return;
+    attn_combine_row(partial + (long)slot * G * (2 * H + 4), G,
+                     AttnCombineOut{ft.ctx + (long)b * ft.ldctx, ft.ctx2 ? ft.ctx2 + (long)b * ft.ldctx2 : nullptr, scores ? scores + (long)b * T : nullptr, T}, red);
 }
 
 // Fused bars: NQ rows (bars) of one clip per workgroup -- the clip's K and enc chunk is streamed ONCE and applied to every unfinished
@@ -796,11 +868,21 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
                                                             const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                             float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
                                                             const int* __restrict__ clip_order, const int* __restrict__ row_until,
-                                                            int step, int n_clips) {
+                                                            int step, int n_clips, AttnFusedTail ft) {
     constexpr int H = 256;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ int last_flag;
     float* pw = sm;                                   // NQ x chunk weights
     float* red = sm + NQ * chunk;                     // 16 + NQ * 128 * 4 floats
+    if (ft.tickets && (int)blockIdx.x >= ft.n_slots_active * G) {        // fused tail: one extra workgroup per clip without unfinished rows
+        const int zs = ft.n_slots_active + (int)blockIdx.x - ft.n_slots_active * G;
+        const int zb = clip_order ? clip_order[zs] : zs;
+        for (int j = 0; j < NQ; ++j) {
+            const long row = (long)j * n_clips + zb;
+            attn_zero_row(AttnCombineOut{ft.ctx + row * ft.ldctx, ft.ctx2 ? ft.ctx2 + row * ft.ldctx2 : nullptr, scores ? scores + row * T : nullptr, T});
+        }
+        return;
+    }
     const int slot = blockIdx.x / G, g = blockIdx.x % G;
     const int b = clip_order ? clip_order[slot] : slot;
     const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
@@ -913,6 +995,14 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
         }
         if (tid == 0) { pout[0] = mj[j]; pout[1] = lj[j]; }
     }
+    if (!ft.tickets) return;
+    if (!attn_last_arrival(ft.tickets + slot, G, &last_flag)) return;
+    for (int j = 0; j < NQ; ++j) {
+        const long row = (long)j * n_clips + b;
+        const AttnCombineOut o{ft.ctx + row * ft.ldctx, ft.ctx2 ? ft.ctx2 + row * ft.ldctx2 : nullptr, scores ? scores + row * T : nullptr, T};
+        if (on[j]) attn_combine_row(partial + (((long)slot * NQ + j) * G) * (2 * H + 4), G, o, red);
+        else attn_zero_row(o);
+    }
 }
 
 // merge the G partials of a row: ctx = sum_g ctx_g e^{m_g-m} / l ; optional normalisation of the saved weights.  One workgroup per
@@ -924,51 +1014,17 @@ __global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restri
                                                            int n_clips, int groups, int n_active, int step) {
     if (n_done && *n_done >= n_rows_total) return;
     constexpr int H = 256;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x;
     const int clip = b % n_clips, grp = b / n_clips;
     const int slot = clip_rank ? clip_rank[clip] : clip;
-    if (slot >= n_active || (row_until && step >= row_until[b])) {   // skipped row: a finite, well-defined context (zeros)
-        for (int d = tid; d < 2 * H; d += 256) { ctx[(long)b * ldctx + d] = 0.f; if (ctx2) ctx2[(long)b * ldctx2 + d] = 0.f; }
-        if (attw) for (int t = tid; t < T; t += 256) attw[(long)b * T + t] = 0.f;
+    if (slot >= n_active || (row_until && step >= row_until[b])) {   // skipped row
+        attn_zero_row(AttnCombineOut{ctx + (long)b * ldctx, ctx2 ? ctx2 + (long)b * ldctx2 : nullptr, attw ? attw + (long)b * T : nullptr, T});
         return;
     }
-    // One memory round trip for the G softmax statistics and one for the partial contexts (the first version walked the G partials in a
-    // serial loop per thread, three times: ~3 G dependent L2 latencies, 18 us per launch on the 40-row long-clip chain -- a fifth of its
-    // forward step period).
-    constexpr int PS = 2 * H + 4;
-    __shared__ float wgt[80];                         // e^{m_g - m} / l per partial; zero beyond G
-    const float* pb = partial + ((long)slot * groups + grp) * G * PS;
-    if (tid < 64) {                                   // G <= 64 (a2s_attn_max_split)
-        const bool have = tid < G;
-        const float mg = have ? pb[(long)tid * PS] : -INFINITY, lg = have ? pb[(long)tid * PS + 1] : 0.f;
-        const float m = wave_max(mg);
-        const float e = have ? __expf(mg - m) : 0.f;
-        const float l = wave_sum(lg * e);
-        wgt[tid] = e / l;
-        if (tid < 16) wgt[64 + tid] = 0.f;
-        if (tid == 0) { wgt[79] = m; wgt[78] = 1.f / l; }
-    }
-    __syncthreads();
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int g0 = 0; g0 < G; g0 += 8) {
-        float p0[8], p1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = g0 + u < G;
-            p0[u] = ok ? pb[(long)(g0 + u) * PS + 4 + tid] : 0.f;
-            p1[u] = ok ? pb[(long)(g0 + u) * PS + 4 + 256 + tid] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { acc0 = fmaf(p0[u], wgt[g0 + u], acc0); acc1 = fmaf(p1[u], wgt[g0 + u], acc1); }
-    }
-    ctx[(long)b * ldctx + tid] = acc0; ctx[(long)b * ldctx + 256 + tid] = acc1;
-    if (ctx2) { ctx2[(long)b * ldctx2 + tid] = acc0; ctx2[(long)b * ldctx2 + 256 + tid] = acc1; }
-    if (attw) {
-        const float m = wgt[79], inv = wgt[78];
-        for (int t = tid; t < T; t += 256) attw[(long)b * T + t] = __expf(attw[(long)b * T + t] - m) * inv;
-    }
+    __shared__ float wgt[80];
+    attn_combine_row(partial + ((long)slot * groups + grp) * G * (2 * H + 4), G,
+                     AttnCombineOut{ctx + (long)b * ldctx, ctx2 ? ctx2 + (long)b * ldctx2 : nullptr, attw ? attw + (long)b * T : nullptr, T}, wgt);
 }
-
 
 size_t a2s_attn_workspace_floats_impl(int B, int T, int H, int groups) {
     // a launch may cover any n <= B clips (finished rows skipped), each split G(n) ways: size for the largest n * G(n)
@@ -978,14 +1034,25 @@ size_t a2s_attn_workspace_floats_impl(int B, int T, int H, int groups) {
         a2s_attn_split_geometry(n, T, &G, &chunk);
         if ((size_t)n * G > rows) rows = (size_t)n * G;
     }
-    return rows * (groups > 0 ? groups : 1) * (2 * H + 4);
+    return A2S_ATTN_TICKETS + rows * (groups > 0 ? groups : 1) * (2 * H + 4);
 }
 
+// Fused combine (OFF by default; a2s_debug_set("attn_fused_combine", 1) / A2S_ATTN_FUSED_COMBINE=1): the split kernels' last-arriving
+// workgroup per clip merges the partials, no separate combine launch.  Parity-tested, and measured SLOWER in the training step (632 ->
+// 692 ms): every one of the ~770 workgroups of a launch pays a device-scope release (L2 write-back) before its ticket and the last one
+// an acquire (L2 invalidate) -- on an 8-XCD part that costs more than the 7 us launch it saves and evicts the other streams' lines.
+static int g_attn_fused_combine = -1;
+void a2s_attn_fused_combine_set(int v) { g_attn_fused_combine = v ? 1 : 0; }
+int a2s_attn_fused_combine_enabled(void) {
+    if (g_attn_fused_combine < 0) { const char* e = getenv("A2S_ATTN_FUSED_COMBINE"); g_attn_fused_combine = e ? (atoi(e) != 0) : 0; }
+    return g_attn_fused_combine;
+}
+static bool attn_fused_combine(void) { return a2s_attn_fused_combine_enabled() != 0; }
 template <int NQ>
 static void launch_fwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
-                          float* ws, float* attw, int T, int G, int chunk, const a2s_attn_rows& r) {
+                          float* ws, float* attw, int T, int G, int chunk, const a2s_attn_rows& r, const AttnFusedTail& ft) {
     hipLaunchKernelGGL(attn_fwd_split256_mq<NQ>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk,
-                       r.clip_order, r.row_until, r.step, r.n_clips);
+                       r.clip_order, r.row_until, r.step, r.n_clips, ft);
 }
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
@@ -1002,25 +1069,33 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     A2S_REQUIRE(groups == 1 || !n_done, "attn_step_fwd_split: fused bars are a training-only path");
     A2S_REQUIRE(a2s_attn_max_split() <= 64, "attn_step_fwd_split: A2S_ATTN_MAX_SPLIT must be <= 64");
     int G = 1, chunk = T;
-    if (r.n_active > 0) {
+    // workspace: [A2S_ATTN_TICKETS ints: arrival counters, zero between launches (the allocation must be zero-initialised once)] [partials]
+    int* tickets = reinterpret_cast<int*>(ws);
+    float* part = ws + A2S_ATTN_TICKETS;
+    const bool fused = attn_fused_combine() && r.n_clips <= A2S_ATTN_TICKETS / 2;
+    // fused tail: one extra workgroup per clip (row) WITHOUT unfinished rows zero-fills its outputs
+    const int n_zero = fused ? r.n_clips - r.n_active : 0;
+    const AttnFusedTail ft = {fused ? tickets : nullptr, ctx, ldctx, ctx2, ldctx2, r.n_active, B};
+    if (r.n_active > 0 || n_zero > 0) {
         // the grid covers the clips that still have unfinished rows, re-split so that it still fills the chip
-        a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
-        const int nwg = r.n_active * G;
+        if (r.n_active > 0) a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
+        const int nwg = r.n_active * G + n_zero;
         if (groups == 1) {
             const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
-            hipLaunchKernelGGL(attn_fwd_split256, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, n_done, n_rows_total, r.clip_order);
+            hipLaunchKernelGGL(attn_fwd_split256, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
         } else {
             const size_t shm = ((size_t)groups * chunk + 16 + (size_t)groups * 128 * 4) * sizeof(float);
             switch (groups) {
-                case 2: launch_fwd_mq<2>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
-                case 3: launch_fwd_mq<3>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
-                case 4: launch_fwd_mq<4>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
-                default: launch_fwd_mq<5>(st, nwg, shm, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r); break;
+                case 2: launch_fwd_mq<2>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
+                case 3: launch_fwd_mq<3>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
+                case 4: launch_fwd_mq<4>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
+                default: launch_fwd_mq<5>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
             }
         }
         A2S_CHECK_LAUNCH("attn_fwd_split256");
     }
-    hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, ws, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total,
+    if (fused) return A2S_OK;
+    hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, part, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total,
                        r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step);
     A2S_CHECK_LAUNCH("attn_fwd_combine256");
     return A2S_OK;

@@ -78,7 +78,8 @@ def attn_workspace(B, T, H, device, groups=1):
     """Scratch for the split-T attention kernels (None when the one-workgroup-per-clip kernels are used); groups: fused bars per call."""
     if H != 256:
         return None
-    return torch.empty(lib().a2s_attn_workspace_floats_fused(B, T, H, groups), dtype=torch.float32, device=device)
+    # zero-initialised: the head of the workspace holds the arrival counters of the fused combine (left at zero by every launch)
+    return torch.zeros(lib().a2s_attn_workspace_floats_fused(B, T, H, groups), dtype=torch.float32, device=device)
 
 
 def conv_workspace(cin, device):

@@ -337,10 +337,26 @@ def test_staff_embedding_backward(dev):
 
 @pytest.mark.parametrize("H,T,clips,groups,split", [(256, 1201, 3, 2, True), (256, 333, 70, 3, True), (256, 77, 5, 5, True), (256, 61, 5, 5, True), (256, 61, 5, 4, True),
                                                     (256, 61, 5, 3, True), (256, 61, 5, 2, True), (32, 41, 3, 3, False)])
-def test_fused_rows_attention_forward_backward(dev, H, T, clips, groups, split):
+@pytest.mark.parametrize("fused_combine", [0, 1])
+def test_fused_rows_attention_forward_backward(dev, H, T, clips, groups, split, fused_combine):
     """The attention step over `groups` bars of the same clips (row = group * clips + clip) with finished rows skipped: forward
     context / weights, dq, and the deferred dK / dEnc over S steps against torch autograd on the unfinished (row, step) pairs.
-    split=True: the multi-row split-T kernels (hidden 256); split=False: the one-workgroup-per-row kernels (no skipping)."""
+    split=True: the multi-row split-T kernels (hidden 256); split=False: the one-workgroup-per-row kernels (no skipping).
+    fused_combine=1: the forward partials merged by each clip's last-arriving workgroup (ticket counters in the workspace head,
+    switch "attn_fused_combine", off by default) instead of the combine launch."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    if fused_combine and not split:
+        pytest.skip("the fused combine belongs to the split-T kernels")
+    previous = L.a2s_debug_get(b"attn_fused_combine")
+    hip.check(L.a2s_debug_set(b"attn_fused_combine", fused_combine), "debug_set")
+    try:
+        _fused_rows_attention_case(dev, H, T, clips, groups, split, fused_combine)
+    finally:
+        hip.check(L.a2s_debug_set(b"attn_fused_combine", previous), "debug_set")
+
+
+def _fused_rows_attention_case(dev, H, T, clips, groups, split, fused_combine):
     from piano_a2s_amd import hip
     L = hip.lib()
     S, R = 4, groups * clips
@@ -403,7 +419,7 @@ def test_fused_rows_attention_forward_backward(dev, H, T, clips, groups, split):
     errs = {"ctx": _rel(ctx_all, torch.stack(ctxs)), "attw": _rel(attw, torch.stack(aws)),
             "dq": _rel(dq_all, torch.stack([q.grad for q in qs]) * live_dq), "dK": _rel(dK, K.grad), "dv": _rel(dv, v.grad), "dEnc": _rel(dEnc, enc.grad)}
     for k, e in errs.items():
-        _report(f"fused rows H{H} T{T} clips{clips} groups{groups} split={split} {k}", e)
+        _report(f"fused rows H{H} T{T} clips{clips} groups{groups} split={split} fused_combine={fused_combine} {k}", e)
     assert max(errs.values()) < 5e-5, errs
 
 

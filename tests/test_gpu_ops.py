@@ -378,16 +378,24 @@ def test_attention_step(dev, H, T, B, split):
     q = torch.empty(B, H, device=dev)
     hd, biasd, vd = hid[0].to(dev), bias.to(dev), v.to(dev)
     hip.gemm(hd, 2 * H, 1, Wd, 1, 4 * H, q, H, B, H, 2 * H, bias=biasd)
-    ctx = torch.empty(B, 2 * H, device=dev)
-    attw = torch.empty(B, T, device=dev)
     ws = hip.attn_workspace(B, T, H, dev) if split else None
-    hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys), hip._p(encd), hip._p(q), C.c_long(H), hip._p(vd), hip._p(ctx),
-                                  C.c_long(2 * H), C.c_void_p(0), C.c_long(0), hip._p(attw), B, T, H, C.c_void_p(0), 0, hip._p(ws)), "attn")
-    torch.cuda.synchronize()
-    e1, e2 = _rel(attw, a_ref), _rel(ctx, ctx_ref)
-    _report(f"attention H{H} T{T} B{B} split={split} weights", e1)
-    _report(f"attention H{H} T{T} B{B} split={split} context", e2)
-    assert e1 < 2e-5 and e2 < 2e-5, (e1, e2)
+    previous = L.a2s_debug_get(b"attn_fused_combine")
+    try:
+        for fused in ((0, 1) if split else (0,)):           # split-T kernels: separate combine launch / merged by the last-arriving workgroup
+            hip.check(L.a2s_debug_set(b"attn_fused_combine", fused), "debug_set")
+            for rep in range(2):                            # twice: the arrival counters must be back at zero after a launch
+                ctx = torch.full((B, 2 * H), 7.0, device=dev)
+                attw = torch.full((B, T), 7.0, device=dev)
+                hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys), hip._p(encd), hip._p(q), C.c_long(H), hip._p(vd), hip._p(ctx),
+                                              C.c_long(2 * H), C.c_void_p(0), C.c_long(0), hip._p(attw), B, T, H, C.c_void_p(0), 0, hip._p(ws)), "attn")
+                torch.cuda.synchronize()
+                e1, e2 = _rel(attw, a_ref), _rel(ctx, ctx_ref)
+                if rep == 0:
+                    _report(f"attention H{H} T{T} B{B} split={split} fused_combine={fused} weights", e1)
+                    _report(f"attention H{H} T{T} B{B} split={split} fused_combine={fused} context", e2)
+                assert e1 < 2e-5 and e2 < 2e-5, (fused, rep, e1, e2)
+    finally:
+        hip.check(L.a2s_debug_set(b"attn_fused_combine", previous), "debug_set")
 
 
 def test_gru_sequence_both_directions(dev):
