@@ -45,3 +45,18 @@ for q, v in queues.items():
         continue
     busy = sum(min(k[2], hi) - max(k[1], lo) for k in v if k[2] > lo and k[1] < hi)
     print(f"queue {q}: busy {100 * busy / (hi - lo):.0f} % of the chain's span ({(hi - lo) / 1e3:.0f} ms)")
+
+# ---- every queue: busy share of the traced span, idle time by gap size, top kernels by time
+span_lo, span_hi = K[0][1], max(k[2] for k in K)
+print(f"\ntraced span {(span_hi - span_lo) / 1e3:.0f} ms")
+for q, v in sorted(queues.items()):
+    v = sorted(v, key=lambda k: k[1])
+    busy = sum(k[2] - k[1] for k in v)
+    gaps = np.array([b[1] - a[2] for a, b in zip(v[:-1], v[1:])])
+    gaps = gaps[gaps > 0]
+    small, mid, big = gaps[gaps < 20].sum(), gaps[(gaps >= 20) & (gaps < 1000)].sum(), gaps[gaps >= 1000].sum()
+    print(f"queue {q}: {len(v)} kernels, busy {busy / 1e3:.0f} ms ({100 * busy / (span_hi - span_lo):.0f} %), idle in gaps < 20 us {small / 1e3:.0f} ms, 20 us - 1 ms {mid / 1e3:.0f} ms, > 1 ms {big / 1e3:.0f} ms")
+    tot = {}
+    for k in v:
+        tot[k[0]] = tot.get(k[0], 0.0) + k[2] - k[1]
+    print("    " + ", ".join(f"{n[:28]} {t / 1e3:.0f}" for n, t in sorted(tot.items(), key=lambda kv: -kv[1])[:8]))
