@@ -385,7 +385,9 @@ def main():
         torch.cuda.empty_cache()
         out["roofline"] = conv_roofline(B, 1201, cfg["freq_bins"])
         out["roofline_attention"] = attention_roofline(step, None, B, 1201, cfg["hidden_size"])
-        if not args.no_secondary:
+        if not args.no_secondary and not use_dist:
+            # (single-process runs only: with a process group every TrainStep call takes part in the gradient all-reduce, and rank 0 is
+            # alone here -- the N = 1 line of the same commit carries the check)
             out["loss_parity"] = loss_parity(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.full_tail)
