@@ -102,11 +102,12 @@ def conv_roofline(B, T, F, iters=6):
         gbs = nbytes / avg_s / 1e9
         hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                "algorithmic_bytes_per_launch": int(nbytes)}
-        traffic = int(1.289 * nbytes) if two else None
+        # (B = 256, profiles/r02_conv_traffic_b256.txt: FETCH_SIZE 18 180 796 KB x2 + WRITE_SIZE 23 085 836 KB = 60.87 GB; same ratio at B = 32)
+        traffic = (int((2 * 18180796.19 + 23085836.0) * 1024) if B == 256 else int(1.289 * nbytes)) if two else None
         first, other, bound = (hbm, mfma, "hbm") if hbm["frac"] >= mfma["frac"] else (mfma, hbm, "mfma")
         out = {"bound": bound, "kernel": f"conv3x3_split<40, false, {2 if two else 3}> (conv4 forward launch, incl. its weight split/packing pre-kernels)"}
         out.update(first)
-        out.update({"traffic": traffic, "traffic_source": "rocprofv3 PMC at B=32 scaled by batch (profiles/r02_conv_analysis.txt)" if traffic else None,
+        out.update({"traffic": traffic, "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, " + ("this launch at B=256: profiles/r02_conv_traffic_b256.txt" if B == 256 else "B=32 scaled by batch: profiles/r02_conv_traffic_b32.txt")) if traffic else None,
                     "avg_launch_us": round(avg_s * 1e6, 1), ("mfma_view" if bound == "hbm" else "hbm_view"): other})
         return out
     return {"bound": "mfma", "kernel": "conv3x3_mfma<40, false> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
