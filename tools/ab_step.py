@@ -32,7 +32,8 @@ def main():
 
         class _Knob:
             def __setattr__(self, name, v):
-                hip.check(hip.lib().a2s_debug_set(key, int(v) * (3 if key == b"conv_bf16x3" else 1)), "a2s_debug_set")
+                val = int(os.environ.get("A2S_AB_ON", "3" if key == b"conv_bf16x3" else "1")) if v else int(os.environ.get("A2S_AB_OFF", "0"))
+                hip.check(hip.lib().a2s_debug_set(key, val), "a2s_debug_set")
         target = _Knob()
     elif a.attr.startswith("env:"):
         class _Env:
