@@ -35,9 +35,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 MFMA_BF16_PEAK_TFS = 2500.0    # dense bf16 MFMA peak (same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense")
 MFMA_F32_PEAK_TFS = 157.3      # dense fp32-input MFMA peak (same guide: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD)
 TF_RATIO = 0.7                 # hparams/pretrain.yaml teacher_forcing_ratio at epoch 0
+# Teacher-forcing coin stream across data-parallel ranks: "shared" = every rank seeds Python's random alike (one coin per step for the
+# whole global batch, as the reference flips one coin for its whole minibatch), "rank_offset" = random.seed(1234 + rank) (rounds 1-2).
+# Decided from dp_straggler_simulation: shared coins remove the coin-driven spread between ranks.
+COIN_POLICY = os.environ.get("A2S_COIN_POLICY", "shared")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -49,7 +53,45 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no torchrun environment: print the launcher command as JSON and exit")
+    ap.add_argument("--master-port", type=int, default=int(os.environ.get("MASTER_PORT", "29533")))
+    ap.add_argument("--no-straggler-sim", action="store_true", help="skip the 1-GPU data-parallel straggler simulation (predicted_dp_efficiency)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the greedy-decode (config 5) block")
+    return ap.parse_args(argv)
+
+
+def launcher_command(args, argv):
+    """The command a bare `python bench.py --gpus N` (N > 1, no RANK in the environment) starts as a CHILD process: one rank per GPU
+    under torch.distributed.run, the reference's own launch shape (reference README.md:119-122, pretrain.py:257)."""
+    rest = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(args.master_port), os.path.abspath(__file__)] + rest
+
+
+def self_launch(args, argv):
+    """Start the ranks, relay their output (rank 0 prints the JSON line), exit non-zero if any rank fails.  Nothing in this process has
+    touched the GPU (no HIP call, no torch.cuda.is_available()): the ranks are children, never an exec of this process."""
+    import subprocess
+    cmd = launcher_command(args, argv)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd, "n_gpus": args.gpus}), flush=True)
+        return 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.master_port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        rc = 1
+    return rc
 
 
 def conv_roofline(B, T, F, iters=6):
@@ -260,11 +302,89 @@ def loss_parity(dev):
                       "TrainStep; total + 4 loss terms vs the reference's CPU values (tests/golden/g2_full.npz, g2_full_tf07.npz)"}
 
 
+def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=3):
+    """Data-parallel straggler term WITHOUT an 8-GPU box: every rank of an N-rank job meets the others at the gradient
+    all-reduce, so a job step lasts as long as its slowest rank's.  A rank's step time is a function of its minibatch (target lengths) and
+    of the teacher-forcing coins it draws (how bars fuse, reference models.py:289,404) -- not of the weights -- so the 8 ranks' step
+    sequences are run here one after another on this GPU and  predicted_dp_efficiency = mean(step time) / mean_k(max_rank step_k time).
+    Two coin policies: `rank_offset_coins` (random.seed(1234 + rank), round 2's default) and `shared_coins` (every rank seeds Python's
+    random alike, data still differs per rank: the N-rank job then flips ONE coin per step for the whole global batch, which is what the
+    reference does on one GPU with the N-fold batch).  Communication is not in this number (65.4 MB over xGMI, overlapped)."""
+    from piano_a2s_amd import synthetic
+
+    def run(rank, coin_seed):
+        rng = random.Random(coin_seed)
+        ms = []
+        for k in range(steps + 1):
+            b = synthetic.make_batch(B, cfg, 1234 + 1000 * rank + (k % 2), full_tail=full_tail)
+            b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step(b, TF_RATIO, rng=rng)
+            e1.record()
+            torch.cuda.synchronize()
+            if k:                                      # first step of a sequence: new shapes / plans, untimed
+                ms.append(e0.elapsed_time(e1))
+        return ms
+
+    def efficiency(table):
+        mean = sum(sum(r) for r in table) / (len(table) * steps)
+        worst = sum(max(r[k] for r in table) for k in range(steps)) / steps
+        return mean / worst
+
+    offset = [run(r, 1234 + r) for r in range(ranks)]
+    shared = [offset[0]] + [run(r, 1234) for r in range(1, ranks)]
+    out = {"ranks": ranks, "steps_per_rank": steps,
+           "rank_offset_coins": {"predicted_dp_efficiency": round(efficiency(offset), 4), "step_ms_by_rank": [[round(t, 1) for t in r] for r in offset]},
+           "shared_coins": {"predicted_dp_efficiency": round(efficiency(shared), 4), "step_ms_by_rank": [[round(t, 1) for t in r] for r in shared]},
+           "what": "8 ranks' step sequences run one after another on this GPU; efficiency = mean step time / mean over steps of the slowest "
+                   "rank's step time (straggler term only, no communication cost)"}
+    return out
+
+
+def inference_block(cfg, dev, batches=(256, 8)):
+    """BASELINE.json configs[4]: greedy decode, eval mode, procedural weights with an <eos> bias (decoding ends at data-dependent
+    steps), reference pretrain.py:131-136 / models.py:408.  clips/s and decoded tokens/s, kernel launches per executed decode step."""
+    from piano_a2s_amd import engine, hip, spec, synthetic
+    L = hip.lib()
+    S = {k: v.to(dev) for k, v in spec.procedural_state(cfg, 2032, eos_bias=2.5, lively="token").items()}
+    out = {"weights": "procedural (seed 2032, <eos> bias 2.5)", "mode": "eval, greedy, device-side <eos> bookkeeping polled every 16 steps"}
+    for B in batches:
+        x = synthetic.make_batch(B, cfg, 77, spectrogram="ridges", full_tail=0.0)[0].to(dev)
+        eng = engine.Engine(cfg)
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            n0 = L.a2s_launch_count() if hasattr(L, "a2s_launch_count") else None
+            t0 = time.time()
+            with torch.no_grad():
+                ts, key, up, lo = eng.forward(S, x, inference=True)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            n1 = L.a2s_launch_count() if hasattr(L, "a2s_launch_count") else None
+            best = dt if best is None else min(best, dt)
+        steps = sum(b["staff"][k][2]["steps"] for b in eng.saved["bars"] for k in ("up", "lo"))
+        launched = sum(b["staff"][k][2]["launched"] for b in eng.saved["bars"] for k in ("up", "lo"))
+        tokens = int((up.abs().sum(-1) > 0).sum() + (lo.abs().sum(-1) > 0).sum())
+        out[f"B{B}"] = {"seconds": round(best, 4), "clips_per_s": round(B / best, 2), "tokens_per_s": round(tokens / best),
+                         "executed_decode_steps": steps, "launched_decode_steps": launched,
+                         "kernel_launches_per_decode_step": (round((n1 - n0) / max(launched, 1), 2) if n0 is not None else None)}
+        del eng, x
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
     if args.cpu_baseline_child:                            # CPU-only helper process: never touches the GPU
         from piano_a2s_amd import spec
         print(json.dumps(_cpu_baseline_child(spec.default_cfg(), args.cpu_clips, 1234, args.cpu_threads or (os.cpu_count() or 1), args.full_tail)), flush=True)
+        return
+    if args.gpus > 1 and "RANK" not in os.environ:         # bare `python bench.py --gpus N`: start one rank per GPU as child processes
+        sys.exit(self_launch(args, argv))
+    if args.dry_launch:
+        print(json.dumps({"launch": None, "n_gpus": args.gpus}), flush=True)
         return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -282,7 +402,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(1234)
-    random.seed(1234 + rank)                               # python-random coin flips are per process
+    random.seed(1234 + (rank if COIN_POLICY == "rank_offset" else 0))      # teacher-forcing coins (COIN_POLICY above)
+    from piano_a2s_amd import build as a2s_build
+    build_info = dict(a2s_build.info(), lib=os.path.relpath(a2s_build.LIB, ROOT), stale_vs_sources=bool(a2s_build.needs_build()),
+                      note="last piano_a2s_amd.build.build() of the shipped .so; __graft_entry__.build() forces a from-scratch compile of all 8 .hip sources")
 
     import models
     from piano_a2s_amd import spec, synthetic, train
@@ -312,6 +435,7 @@ def main():
             dist.barrier()
         step._exchange_events = []
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step GPU time (diagnostic only: no extra sync)
+        timed.launches0 = a2s_hip.lib().a2s_launch_count()
         t0 = time.time()
         marks[0].record()
         for i in range(steps):
@@ -330,7 +454,9 @@ def main():
         return elapsed, decode_steps
 
     batches = make_batches(args.full_tail)
+    from piano_a2s_amd import hip as a2s_hip
     elapsed, decode_steps = timed(batches, args.warmup, args.steps)
+    launches_per_step = round((a2s_hip.lib().a2s_launch_count() - timed.launches0) / args.steps)
     main_step_ms = list(timed.step_ms)
     loss = float(step.total)
     groups = step._last[2] if step._last else None
@@ -362,6 +488,7 @@ def main():
                                       "random-init weights; tf_ratio 0.7; dropout on; fwd+loss+bwd+clip+Adadelta",
                           "per_gpu_batch": B, "global_batch": B * world, "upper_len": "U{20..120}", "lower_len": "U{10..80}",
                           "full_length_tail": args.full_tail, "parallelism": f"dp{world}", "batchnorm": "per-rank statistics",
+                          "coin_policy": COIN_POLICY, "kernel_launches_per_step": launches_per_step,
                           "decoder": "rows whose remaining targets are all <pad> skipped; teacher-forced bars decoded in one call; clips "
                                      "holding full-length bars decoded as a concurrent clip group (loss, gradients and update identical "
                                      "to the per-bar loop over the whole minibatch)",
@@ -390,6 +517,13 @@ def main():
             # (single-process runs only: with a process group every TrainStep call takes part in the gradient all-reduce, and rank 0 is
             # alone here -- the N = 1 line of the same commit carries the check)
             out["loss_parity"] = loss_parity(dev)
+        if world == 1 and not args.no_inference:
+            out["inference"] = inference_block(cfg, dev)
+            out["inference"]["attention_roofline_frac"] = out["roofline_attention"]["frac"]
+        if world == 1 and not args.no_straggler_sim:
+            out["dp_straggler_simulation"] = straggler_simulation(step, cfg, B, dev, args.full_tail)
+            out["predicted_dp_efficiency"] = out["dp_straggler_simulation"][COIN_POLICY + "_coins"]["predicted_dp_efficiency"]
+        out["build"] = build_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.full_tail)
         print(json.dumps(out), flush=True)

@@ -30,6 +30,9 @@ extern "C" {
 
 const char* a2s_last_error(void);
 int a2s_version(void);
+/* kernel launches issued by this process through the library so far (diagnostic: launches per optimizer / decode step in bench.py;
+ * the reference has no native layer, nothing replaced) */
+long long a2s_launch_count(void);
 
 /* ---- dense contraction: every nn.Linear / GRU projection of models.py (:68,:123-132,:359,:444-445,:504) and
  * their backward forms.  C[m,n] = act(alpha * sum_k A(m,k) B(k,n) + beta*C + bias[n]);

@@ -54,7 +54,21 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as pool:
         list(pool.map(run, jobs))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    import json
+    import time
+    with open(os.path.join(OBJ, "build_info.json"), "w") as f:
+        json.dump({"forced": bool(force), "sources_compiled": len(jobs), "sources_total": len(objs), "unix_time": int(time.time())}, f)
     return LIB
+
+
+def info():
+    """What the last build() of the shipped .so did (forced from-scratch compile or incremental)."""
+    import json
+    try:
+        with open(os.path.join(OBJ, "build_info.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {"forced": None}
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 #include "../../include/a2s.h"
 
 thread_local char a2s_err_msg[512] = {0};
+long long a2s_launch_counter = 0;
 
 // ---- launchers implemented in the kernel translation units
 int a2s_gemm_impl(hipStream_t, int, int, int, float, const float*, long, long, const float*, long, long, float, float*, long,
@@ -101,6 +102,7 @@ extern "C" {
 
 const char* a2s_last_error(void) { return a2s_err_msg; }
 int a2s_version(void) { return 1; }
+long long a2s_launch_count(void) { return __atomic_load_n(&a2s_launch_counter, __ATOMIC_RELAXED); }
 
 int a2s_gemm_f32(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk, const float* B, long sBk,
                  long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,

@@ -32,6 +32,16 @@ extern thread_local char a2s_err_msg[512];
         if (e_ != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// Every kernel launch of the library is counted (a relaxed host-side add): `a2s_launch_count()` lets the bench report launches per optimizer
+// step / per decode step without a profiler.
+extern long long a2s_launch_counter;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                              \
+    do {                                                                 \
+        __atomic_fetch_add(&a2s_launch_counter, 1LL, __ATOMIC_RELAXED);  \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);           \
+    } while (0)
+
 static inline int a2s_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -53,6 +53,7 @@ def lib():
                            "There is no CPU fallback for the transcription hot path.")
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
+        _lib.a2s_launch_count.restype = C.c_longlong
         for fn in ("a2s_note_step_workspace_floats", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
                    "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
