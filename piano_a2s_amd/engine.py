@@ -222,7 +222,34 @@ class Engine:
         hip.check(hip.lib().a2s_col_sum(hip.stream(), hip._p(partial), C.c_long(2 * C_), hip._p(sums), C.c_long(nblocks), 2 * C_,
                                         hip.f32(1.0), hip.f32(0.0), C.c_void_p(0), C.c_size_t(0)), "a2s_col_sum (bn stats)")
         dist.all_reduce(sums)
+        self._queue_count_check(count, partial.device)
         return sums, float(count) * dist.get_world_size()
+
+    def _queue_count_check(self, count, dev):
+        """world x local count is the global count only when every rank holds the same number of frames.  Every rank queues the SAME
+        tiny collective per statistics exchange (MAX of [count, -count]; no rank may skip it on a local condition, that would mismatch
+        the collectives) and nobody waits for it: `check_counts` reads the queued results later, at a point that synchronises anyway
+        (TrainStep.report, or the next forward)."""
+        import torch.distributed as dist
+        self.check_counts()
+        t = torch.tensor([float(count), -float(count)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        Engine._count_checks.append(t)
+
+    _count_checks = []                 # per process (a TrainStep builds a fresh Engine every step)
+
+    @staticmethod
+    def check_counts(all_pending=False):
+        """Raise if a queued frame-count exchange found ranks with different batch shapes (a user DataLoader's uneven last batch, a
+        custom sampler): the batch statistics of that step were wrong.  Reads results older than the current step only, unless asked."""
+        pend = Engine._count_checks
+        keep = 0 if all_pending else 5
+        while len(pend) > keep:
+            t = pend.pop(0)
+            hi, lo = float(t[0]), -float(t[1])
+            if hi != lo:
+                raise RuntimeError(f"synchronised BatchNorm: the ranks held different numbers of frames in one step ({lo:.0f} .. {hi:.0f}); "
+                                   "give every rank the same batch shape (DistributedSampler pads; drop or pad an uneven last batch)")
 
     # ------------------------------------------------------------------ helpers
     @staticmethod

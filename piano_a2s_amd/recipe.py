@@ -113,11 +113,21 @@ class ASR(sb.Brain):
         if fused and self.checkpointer is not None:
             self.checkpointer.add_recoverable("optimizer", fused.opt)
 
+    def on_fit_start(self):
+        """Recovery restores the learning rate with the optimizer state (optimizer.ckpt holds the NewBob-annealed lr, as in the
+        reference, whose torch optimizer IS the recoverable).  When the fused step trains, the recoverable is fused.opt: its recovered
+        lr is the truth, and the idle torch optimizer (which update_learning_rate also addresses) is brought in line with it -- without
+        this, the first epoch after a resume, or after finetune.py's copy of the pretraining save/, ran at the yaml's initial lr."""
+        super().on_fit_start()
+        fused = self._fused_step()
+        if fused and self.optimizer is not None:
+            for g in self.optimizer.param_groups:
+                g["lr"] = fused.opt.lr
+
     def fit_batch(self, batch):
         fused = self._fused_step()
         if not fused:
             return super().fit_batch(batch)
-        fused.opt.lr = self.optimizer.param_groups[0]["lr"]          # NewBob annealing acts on the torch optimizer object
         fused(_features(batch, self.device), self.teacher_forcing_ratio)
         *terms, applied = fused.report()                              # one small D2H per step (the reference does four)
         self._record_losses(*[torch.tensor(t) for t in terms])
@@ -172,6 +182,9 @@ class ASR(sb.Brain):
         stats.update(key_f1=key_f1, time_f1=time_f1, WER_upper=wer_up, WER_lower=wer_lo, WER=(wer_up + wer_lo) / 2)
         old_lr, new_lr = self.hparams.lr_annealing(stats["WER"])
         sb.nnet.schedulers.update_learning_rate(self.optimizer, new_lr)
+        fused = self._fused_step()
+        if fused:                                                      # the lr the fused step uses AND the one optimizer.ckpt saves below
+            sb.nnet.schedulers.update_learning_rate(fused.opt, new_lr)
         self.hparams.train_logger.log_stats(stats_meta={"epoch": epoch, "lr": old_lr}, train_stats=self.train_stats, valid_stats=stats)
         self.checkpointer.save_and_keep_only(meta={"loss": stats["loss"], "WER": stats["WER"]}, min_keys=["WER"])
         self.last_stats = stats

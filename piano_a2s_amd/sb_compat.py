@@ -72,6 +72,13 @@ def parse_arguments(arg_list):
     return known.param_file, run_opts, "\n".join(overrides)
 
 
+def _set_cuda_device(device):
+    """torch.cuda.set_device needs an index: a bare 'cuda' (single-process `--device cuda`, or a Brain built without run_opts) means the
+    current device."""
+    d = torch.device(device)
+    torch.cuda.set_device(d.index if d.index is not None else torch.cuda.current_device())
+
+
 def ddp_init_group(run_opts):
     """One process per GPU: initialise the process group whenever the torchrun environment is present (the README launches
     with torchrun but without --distributed_launch)."""
@@ -81,7 +88,7 @@ def ddp_init_group(run_opts):
         if not str(run_opts.get("device", "cpu")).startswith("cuda"):
             backend = "gloo"
         if str(run_opts.get("device", "")).startswith("cuda"):
-            torch.cuda.set_device(torch.device(run_opts["device"]))
+            _set_cuda_device(run_opts["device"])
         dist.init_process_group(backend=backend)
 
 
@@ -304,7 +311,7 @@ class Brain:
         if str(self.device).startswith("cuda") and torch.cuda.is_available():
             # liba2s_hip.so launches on torch's CURRENT stream of the CURRENT device: make the run's device current (SpeechBrain's
             # Brain.__init__ does the same), or `--device cuda:1` would launch on a device-0 stream with device-1 pointers
-            torch.cuda.set_device(torch.device(self.device))
+            _set_cuda_device(self.device)
         self.max_grad_norm = float(run_opts.get("max_grad_norm", 5.0))
         self.nonfinite_patience = int(run_opts.get("nonfinite_patience", 3))
         self.debug, self.debug_batches, self.debug_epochs = bool(run_opts.get("debug")), int(run_opts.get("debug_batches", 2)), int(run_opts.get("debug_epochs", 2))

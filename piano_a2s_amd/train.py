@@ -367,4 +367,6 @@ class TrainStep:
     def report(self):
         """Host copy of the last step's [time-sig, key, upper, lower loss, applied flag] -- ONE small device-to-host read (the
         reference recipe does four .cpu() reads per step, pretrain.py:90-93)."""
+        if self.sync_bn:
+            engine.Engine.check_counts(all_pending=True)
         return torch.cat([self.objective.losses[:, 0], self.opt.ctl[2:3]]).tolist()
