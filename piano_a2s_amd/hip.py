@@ -162,3 +162,49 @@ def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0, x_affine=None, two
     gemm(x2d, x2d.stride(0), x2d.stride(1), weight, weight.stride(1), weight.stride(0), out, out.stride(0), M, N, K,
          bias=bias, act=act, beta=beta, a_affine=x_affine, two_term=two_term)
     return out
+
+
+# ---- the ConvStack's launches as the engine issues them (one place: engine.py / engine_bwd.py and the robustness tests share these)
+def conv3x3_forward(x, w, y, scale, shift, partial, cws):
+    """y = conv3x3(relu(x * scale[c] + shift[c])) (scale None: x as it is), (B, T, C, F) tensors; batch-statistics partials in `partial`."""
+    B, T, Cin, F = x.shape
+    check(lib().a2s_conv3x3(stream(), _p(x), _p(w), _p(y), _p(scale), _p(shift), _p(partial), B, T, F, Cin, y.shape[2], 0, _p(cws)), "a2s_conv3x3")
+
+
+def conv3x3_dgrad_for_test(dy, w, yl):
+    """Data gradient of a (Cin -> Cout) layer as engine_bwd issues it: dy (B, T, Cout, F) -> dx (B, T, Cin, F), operand scaled by the
+    power of two derived from max|dy|, BatchNorm-backward statistics epilogue against `yl` (identity BatchNorm parameters here)."""
+    L = lib()
+    B, T, Cout, F = dy.shape
+    Cin = w.shape[1]
+    dev = dy.device
+    dx = torch.full((B, T, Cin, F), float("nan"), device=dev)
+    amax = absmax(dy)
+    part = torch.zeros(L.a2s_conv3x3_stat_blocks(B, T, F, Cout), Cin, 2, device=dev)
+    cws = conv_workspace(Cout, dev)
+    zeros, ones = torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
+    check(L.a2s_conv3x3_dgrad_bnstats_scaled(stream(), _p(dy), _p(w), _p(dx), _p(yl), _p(zeros), _p(ones), _p(ones), _p(zeros), _p(part),
+                                             B, T, F, Cout, Cin, _p(cws), _p(amax)), "a2s_conv3x3_dgrad_bnstats_scaled")
+    torch.cuda.synchronize()
+    return dx
+
+
+def conv3x3_wgrad_for_test(dy, x, scale, shift):
+    """Weight gradient as engine_bwd issues it: dW (Cout, Cin, 3, 3) from dy (B, T, Cout, F) and the layer input relu(x * scale + shift)."""
+    L = lib()
+    B, T, Cout, F = dy.shape
+    Cin = x.shape[2]
+    dev = dy.device
+    dW = torch.zeros(Cout, Cin, 3, 3, device=dev)
+    nb = L.a2s_conv3x3_wgrad_workspace_bytes(Cin, Cout)
+    ws = torch.empty(nb // 4, device=dev)
+    amax = absmax(dy)
+    check(L.a2s_conv3x3_wgrad_scaled(stream(), _p(dy), _p(x), _p(scale), _p(shift), _p(dW), _p(ws), C.c_size_t(nb), B, T, F, Cin, Cout, _p(amax)),
+          "a2s_conv3x3_wgrad_scaled")
+    torch.cuda.synchronize()
+    return dW
+
+
+def linear_forward_for_test(x, w, aff):
+    """The 19200 -> 256 Linear's forward as engine.convstack issues it (operand BatchNorm+ReLU while staging, two-term split)."""
+    return linear(x, w, x_affine=aff, two_term=(None, absmax(w)))
