@@ -87,6 +87,13 @@ int a2s_debug_get(const char* key);   /* current value of "conv_bf16x3" / "gemm_
  * flip=1 runs the data-gradient form with w read as w'[ci][co][2-dt][2-df]. */
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
                 float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace);
+/* The same forward convolution with operand RANGES (round 3; replaces nothing new in the reference: models.py:525-534 as a2s_conv3x3):
+ * in_absmax[Cin] = max |x| per input channel (as written into `out_absmax` by the launch that produced x; NULL: measured here by an
+ * extra pass), out_absmax[Cout] = max |y| per output channel, written by this launch (NULL: not wanted).  The row-streaming kernel
+ * (csrc/a2s_conv_rows.hip) derives exact power-of-two operand scales from them, so that its fp16 operand terms never overflow or lose
+ * precision whatever BatchNorm's scale is. */
+int a2s_conv3x3_ranged(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift, const float* in_absmax,
+                       float* stat_partial, float* out_absmax, int B, int T, int F, int Cin, int Cout, float* workspace);
 int a2s_conv3x3_stat_blocks(int B, int T, int F, int Cin);
 /* Data gradient of a convolution (flip form: g = dy (*) w') whose output is the gradient wrt relu(bn(yl)) of the layer below, with that
  * layer's BatchNorm-backward statistics (sum g', sum g' xhat; g' = g where bn(yl) > 0) accumulated in the epilogue into stat_partial

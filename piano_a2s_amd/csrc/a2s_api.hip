@@ -18,7 +18,9 @@ void a2s_gemm_f16x2_set(int);
 int a2s_gemm_f16x2_enabled(void);
 int a2s_gemm_bnstats_slots(int);
 int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*,
-                     const float*, const float*, const float*, const float*, const float*, const float*);
+                     const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*);
+void a2s_conv_rows_set(int);
+int a2s_conv_rows_enabled(void);
 void a2s_conv_f16x2_set(int);
 int a2s_conv_f16x2_enabled(void);
 size_t a2s_conv3x3_workspace_floats_impl(int);
@@ -151,6 +153,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
+    if (!strcmp(key, "conv_rows")) { a2s_conv_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_f16x2")) { a2s_conv_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_f16x2")) { a2s_wgrad_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_bf16x3")) { a2s_gemm_split_set(value); return A2S_OK; }
@@ -162,6 +165,7 @@ int a2s_debug_set(const char* key, int value) {
 
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
+    if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
     if (key && !strcmp(key, "conv_f16x2")) return a2s_conv_f16x2_enabled();
     if (key && !strcmp(key, "wgrad_f16x2")) return a2s_wgrad_f16x2_enabled();
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();
@@ -176,19 +180,25 @@ int a2s_debug_get(const char* key) {
 
 int a2s_conv3x3(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
                 float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* workspace) {
-    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, workspace, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, workspace, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr);
+}
+int a2s_conv3x3_ranged(void* stream, const float* x, const float* w, float* y, const float* in_scale, const float* in_shift, const float* in_absmax,
+                       float* stat_partial, float* out_absmax, int B, int T, int F, int Cin, int Cout, float* workspace) {
+    return a2s_conv3x3_impl(ST, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, 0, workspace, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            in_absmax, out_absmax);
 }
 int a2s_conv3x3_dgrad_bnstats(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
                               const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
                               float* workspace) {
     if (!yl) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_dgrad_bnstats: yl is required"); return A2S_ERR_ARG; }
-    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, nullptr);
+    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, nullptr, nullptr, nullptr);
 }
 int a2s_conv3x3_dgrad_bnstats_scaled(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
                                      const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
                                      float* workspace, const float* dy_absmax) {
     if (!yl) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_dgrad_bnstats_scaled: yl is required"); return A2S_ERR_ARG; }
-    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, dy_absmax);
+    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, dy_absmax, nullptr, nullptr);
 }
 int a2s_bn_bwd_from_partial(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
                             float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12, long rows, int C, int F) {

@@ -38,6 +38,7 @@ struct ConvArgs {
     const float* yl; const float* yl_mean; const float* yl_invstd; const float* yl_scale; const float* yl_shift;
     // two-term fp16 split (conv3x3_split<.., 2>) only: device scalars holding max|x| (null: the operand is used unscaled) and max|w|
     const float* x_absmax; const float* w_absmax;
+    float* out_absmax;   // [Cout] max |y| per output channel (atomic max of non-negative floats; zeroed by the launcher), or null
 };
 
 // ---- v2 geometry (round 1, after profiling: the first version spent more time staging than multiplying -- scalar loads with
@@ -810,9 +811,9 @@ __global__ __launch_bounds__(256) void conv3x3_c1(ConvArgs a) {
     const int qpr = (a.F + 3) / 4;                               // quads per row
     const long nquads = (long)a.B * a.T * qpr;
     const bool vec = (a.F % 4 == 0) && (((uintptr_t)a.y & 15) == 0);
-    float s1[20], s2[20];
+    float s1[20], s2[20], m1[20];
 #pragma unroll
-    for (int co = 0; co < 20; ++co) { s1[co] = 0.f; s2[co] = 0.f; }
+    for (int co = 0; co < 20; ++co) { s1[co] = 0.f; s2[co] = 0.f; m1[co] = 0.f; }
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
         const int f0 = (int)(q % qpr) * 4;
         const long row = q / qpr;                                // b * T + t
@@ -845,9 +846,22 @@ __global__ __launch_bounds__(256) void conv3x3_c1(ConvArgs a) {
                 *reinterpret_cast<f32x4*>(dst) = o;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { s1[co] += o[p]; s2[co] = fmaf(o[p], o[p], s2[co]); }
+                m1[co] = fmaxf(fmaxf(m1[co], fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             } else {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) if (f0 + p < a.F) { dst[p] = o[p]; s1[co] += o[p]; s2[co] = fmaf(o[p], o[p], s2[co]); }
+                for (int p = 0; p < 4; ++p) if (f0 + p < a.F) { dst[p] = o[p]; s1[co] += o[p]; s2[co] = fmaf(o[p], o[p], s2[co]); m1[co] = fmaxf(m1[co], fabsf(o[p])); }
+            }
+        }
+    }
+    if (a.out_absmax) {          // per-channel max |y|: the next layer derives its operand scale from it (a2s_conv_rows.hip)
+#pragma unroll
+        for (int co = 0; co < 20; ++co) {
+            if (co >= a.Cout) break;
+            const float m = wave_max(m1[co]);
+            if (lane == 0) {
+                const unsigned bits = __float_as_uint(m);
+                if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(a.out_absmax + co), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    atomicMax(reinterpret_cast<unsigned*>(a.out_absmax + co), bits);
             }
         }
     }
@@ -968,10 +982,20 @@ int a2s_conv_f16x2_enabled(void) {
     return g_conv_f16x2;
 }
 
+// the row-streaming kernel of a2s_conv_rows.hip (forward and data-gradient launches with F % 4 == 0, 20 / 40 channels)
+bool a2s_conv_rows_eligible(int F, int Cin);
+int a2s_conv_rows_blocks(int B, int T, int F);
+size_t a2s_conv_rows_workspace_floats(int Cin);
+int a2s_channel_absmax_impl(hipStream_t, const float*, long, int, int, float*);
+int a2s_conv3x3_rows_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int,
+                          float*, const float*, const float*, const float*, const float*, const float*, const float*);
+
 size_t a2s_conv3x3_workspace_floats_impl(int Cin) {
     if (Cin == 1) return 0;
     const size_t f32_image = (size_t)(Cin / CV_CK) * C2_WCHUNK, split_image = (size_t)c4_chunks(Cin) * c4_chunk_bytes(40) / 4;
-    return (f32_image > split_image ? f32_image : split_image) + 4;          // + the max |w| scalar of the two-term path
+    const size_t tiled = (f32_image > split_image ? f32_image : split_image) + 4;          // + the max |w| scalar of the two-term path
+    const size_t rows = a2s_conv_rows_workspace_floats(Cin);
+    return tiled > rows ? tiled : rows;
 }
 
 int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin);
@@ -979,11 +1003,25 @@ int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin);
 int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, const float* in_scale,
                      const float* in_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout, int flip, float* ws,
                      const float* yl, const float* yl_mean, const float* yl_invstd, const float* yl_scale, const float* yl_shift,
-                     const float* x_absmax) {
+                     const float* x_absmax, const float* in_absmax, float* out_absmax) {
     A2S_REQUIRE(x && w && y, "conv3x3: null tensor");
     A2S_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3: scale/shift must come together");
     A2S_REQUIRE(!yl || (yl_mean && yl_invstd && yl_scale && yl_shift && stat_partial && Cin != 1), "conv3x3: the fused BatchNorm-backward statistics need all of their tensors");
-    ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, yl, yl_mean, yl_invstd, yl_scale, yl_shift, x_absmax, nullptr};
+    ConvArgs a{x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, yl, yl_mean, yl_invstd, yl_scale, yl_shift, x_absmax, nullptr, out_absmax};
+    if (Cin != 1 && a2s_conv_rows_eligible(F, Cin) && (Cout == 20 || Cout == 40)) {
+        A2S_REQUIRE(ws, "conv3x3: needs a workspace of a2s_conv3x3_workspace_floats(Cin) floats for the packed weights");
+        return a2s_conv3x3_rows_impl(st, x, w, y, in_scale, in_shift, in_absmax, stat_partial, out_absmax, B, T, F, Cin, Cout, flip, ws,
+                                     yl, yl_mean, yl_invstd, yl_scale, yl_shift, x_absmax);
+    }
+    if (out_absmax && Cin == 1) {       // accumulated by atomic max in the first-layer kernel
+        const hipError_t me = hipMemsetAsync(out_absmax, 0, sizeof(float) * Cout, st);
+        A2S_REQUIRE(me == hipSuccess, "conv3x3: hipMemsetAsync(out_absmax): %s", hipGetErrorString(me));
+    }
+    if (out_absmax && Cin != 1) {       // the tiled kernels do not track it (A/B switch, odd shapes): one extra pass over y afterwards
+        const int rc = a2s_conv3x3_impl(st, x, w, y, in_scale, in_shift, stat_partial, B, T, F, Cin, Cout, flip, ws, yl, yl_mean, yl_invstd, yl_scale, yl_shift,
+                                        x_absmax, in_absmax, nullptr);
+        return rc != A2S_OK ? rc : a2s_channel_absmax_impl(st, y, (long)B * T, Cout, F, out_absmax);
+    }
     if (Cin == 1) {
         A2S_REQUIRE(Cout <= 20 && !flip && !in_scale, "conv3x3: Cin=1 path supports Cout<=20, no flip, no input affine");
         hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_conv3x3_stat_blocks_impl(B, T, F, 1)), dim3(256), 0, st, a);
@@ -1041,6 +1079,7 @@ int a2s_conv3x3_stat_blocks_impl(int B, int T, int F, int Cin) {
         const long want = a2s_cdiv((long)B * T * ((F + 3) / 4), 256);
         return (int)(want < C1_BLOCKS ? want : C1_BLOCKS);
     }
+    if (a2s_conv_rows_eligible(F, Cin)) return a2s_conv_rows_blocks(B, T, F);
     return B * a2s_cdiv(a2s_cdiv(T, CV_TR), C3_TPW) * a2s_cdiv(F, C2_FT);
 }
 

@@ -57,7 +57,7 @@ def lib():
         for fn in ("a2s_note_step_workspace_floats", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
                    "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
-        for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"), ("A2S_CONV_F16X2", b"conv_f16x2"), ("A2S_WGRAD_F16X2", b"wgrad_f16x2"),
+        for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_CONV_ROWS", b"conv_rows"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"), ("A2S_CONV_F16X2", b"conv_f16x2"), ("A2S_WGRAD_F16X2", b"wgrad_f16x2"),
                          ("A2S_DEC_FUSED", b"dec_fused"), ("A2S_DEC_FUSED_MAX_ROWS", b"dec_fused_max_rows")):
             if os.environ.get(env):
                 _lib.a2s_debug_set(key, int(os.environ[env]))
@@ -165,10 +165,12 @@ def linear(x2d, weight, bias=None, act=0, out=None, beta=0.0, x_affine=None, two
 
 
 # ---- the ConvStack's launches as the engine issues them (one place: engine.py / engine_bwd.py and the robustness tests share these)
-def conv3x3_forward(x, w, y, scale, shift, partial, cws):
-    """y = conv3x3(relu(x * scale[c] + shift[c])) (scale None: x as it is), (B, T, C, F) tensors; batch-statistics partials in `partial`."""
+def conv3x3_forward(x, w, y, scale, shift, partial, cws, in_absmax=None, out_absmax=None):
+    """y = conv3x3(relu(x * scale[c] + shift[c])) (scale None: x as it is), (B, T, C, F) tensors; batch-statistics partials in `partial`;
+    in_absmax / out_absmax: per-channel max |x| (from the launch that produced x) / max |y| (written here) -- a2s_conv3x3_ranged."""
     B, T, Cin, F = x.shape
-    check(lib().a2s_conv3x3(stream(), _p(x), _p(w), _p(y), _p(scale), _p(shift), _p(partial), B, T, F, Cin, y.shape[2], 0, _p(cws)), "a2s_conv3x3")
+    check(lib().a2s_conv3x3_ranged(stream(), _p(x), _p(w), _p(y), _p(scale), _p(shift), _p(in_absmax), _p(partial), _p(out_absmax),
+                                   B, T, F, Cin, y.shape[2], _p(cws)), "a2s_conv3x3_ranged")
 
 
 def conv3x3_dgrad_for_test(dy, w, yl):

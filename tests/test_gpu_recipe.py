@@ -215,21 +215,29 @@ def test_pretrain_under_torchrun_single_rank(tmp_path):
 
 
 def test_resume_keeps_the_annealed_learning_rate(tmp_path, monkeypatch):
-    """NewBob anneals the lr at the end of every epoch here (threshold forced); the annealed value must be what optimizer.ckpt saves and
-    what the fused step trains with after a resume (reference: the torch optimizer is the recoverable and carries its lr).  ADVICE r2:
-    the fused path used to restart every resumed run -- and every finetune seeded from a pretraining save/ -- at the yaml's lr = 1."""
+    """NewBob anneals the lr at the end of every evaluation here (threshold forced); the annealed value must be what optimizer.ckpt saves
+    and what the fused step trains with after a resume (reference: the torch optimizer is the recoverable and carries its lr).  ADVICE
+    r2: the fused path used to restart every resumed run -- and every finetune seeded from a pretraining save/ -- at the yaml's lr = 1.
+    The WER is forced to fall from evaluation to evaluation so that the checkpointer's keep-best rule keeps the LATEST checkpoint."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import pretrain
-    from piano_a2s_amd import sb_compat, train
+    from piano_a2s_amd import metrics, sb_compat, train
     if pretrain.sb is not sb_compat:
         pytest.skip("SpeechBrain installed: its own scheduler class is in use")
     orig_init = sb_compat.NewBobScheduler.__init__
 
     def always_anneal(self, *a, **k):
         orig_init(self, *a, **k)
-        self.improvement_threshold = 10.0                      # no epoch improves the WER tenfold: anneal after every epoch but the first
+        self.improvement_threshold = 10.0                      # no evaluation improves the WER tenfold: anneal after each but the first
     monkeypatch.setattr(sb_compat.NewBobScheduler, "__init__", always_anneal)
+    calls = [0]
+    orig_wer = metrics.corpus_wer
+
+    def falling_wer(*a, **k):
+        calls[0] += 1
+        return 1.0 / calls[0], orig_wer(*a, **k)[1]
+    monkeypatch.setattr(metrics, "corpus_wer", falling_wer)
     seen = []
     orig_call = train.TrainStep.__call__
 
@@ -239,11 +247,12 @@ def test_resume_keeps_the_annealed_learning_rate(tmp_path, monkeypatch):
     monkeypatch.setattr(train.TrainStep, "__call__", spy)
     args = [os.path.join(ROOT, "hparams", "pretrain.yaml"), "--device=cuda:0", f"--workspace={tmp_path}", "--soundfont_folder=/none",
             "--synthetic_clips=4", "--synthetic_frames=41", "--synthetic_lengths=[[3, 10], [2, 7]]", "--batch_size=2"] + SMALL
-    pretrain.main(args + ["--number_of_epochs=3"])            # epochs 1-3: lr 1, 1 (first metric: nothing to compare), 0.8
+    # evaluations: after epoch 1 (lr 1 -> 1: first metric), epoch 2 (1 -> .8), epoch 3 (.8 -> .64), the final TEST stage (.64 -> .512;
+    # the reference's on_stage_end anneals and checkpoints there too, pretrain.py:179-186)
+    pretrain.main(args + ["--number_of_epochs=3"])
     per_epoch = 2
-    assert seen[:per_epoch * 3] == [1.0] * (2 * per_epoch) + [0.8] * per_epoch, seen
-    n = len(seen)
+    assert seen == [1.0] * (2 * per_epoch) + [0.8] * per_epoch, seen
     brain = pretrain.main(args + ["--number_of_epochs=4"])    # a new run in the same workspace: recovers, trains epoch 4 only
-    resumed = seen[n:]
-    assert len(resumed) == per_epoch and all(abs(v - 0.64) < 1e-12 for v in resumed), f"lr after resume {resumed}, expected 0.8^2 (saved after epoch 3)"
-    assert abs(brain.optimizer.param_groups[0]["lr"] - 0.512) < 1e-12 and abs(brain._fused.opt.lr - 0.512) < 1e-12
+    resumed = seen[3 * per_epoch:]
+    assert len(resumed) == per_epoch and all(abs(v - 0.8 ** 3) < 1e-12 for v in resumed), f"lr after resume {resumed}, expected 0.8^3 (saved by the last evaluation)"
+    assert abs(brain.optimizer.param_groups[0]["lr"] - 0.8 ** 5) < 1e-12 and abs(brain._fused.opt.lr - 0.8 ** 5) < 1e-12
