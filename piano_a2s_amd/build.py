@@ -61,6 +61,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags, sources=None):
+    """A measurement build next to the product library: csrc/_obj/liba2s_hip_<name>.so with extra compiler flags (e.g. -DRW_TRACE); load it with
+    A2S_LIB=<path>.  Only `sources` (default: all) are recompiled with the flags, the rest reuse the product objects."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    build()
+    vdir = os.path.join(OBJ, name)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for f in SOURCES:
+        if sources is None or f in sources:
+            obj = os.path.join(vdir, f[:-4] + ".o")
+            subprocess.run([hipcc] + FLAGS + list(extra_flags) + ["-c", f, "-o", obj], cwd=CSRC, check=True)
+        else:
+            obj = os.path.join(OBJ, f[:-4] + ".o")
+        objs.append(obj)
+    out = os.path.join(OBJ, f"liba2s_hip_{name}.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out], check=True)
+    return out
+
+
 def info():
     """What the last build() of the shipped .so did (forced from-scratch compile or incremental)."""
     import json

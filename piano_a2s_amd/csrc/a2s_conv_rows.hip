@@ -38,6 +38,9 @@
 #define RW_P 120             // output columns per workgroup
 #define RW_SROW 288          // bytes per channel row of the fp16 image: 128 positions + 32 B (rows 8 banks apart)
 #define RW_SLOTS 5
+#ifndef RW_EB
+#define RW_EB 4              // row quads per epilogue batch (lane permutes in flight together)
+#endif
 #define RW_HDR 160           // header floats behind the packed weight image: asc[40], ash[40], unsc[40], xscale, ...
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -51,7 +54,7 @@ struct RwGeom {
     static constexpr int TS = CIN * RW_SROW;           // bytes per term plane of a slot
     static constexpr int SLOT = 2 * TS + (CIN % 8 ? 128 : 0);   // CIN = 20: consecutive rows' slots offset by 32 banks (block cb = 4 -> cb = 0 across dt)
     static constexpr int ITEMS = CIN * 32;             // 16-byte items per staged row
-    static constexpr int XIT = (ITEMS + 511) / 512;
+    static constexpr int XIT = (ITEMS + 255) / 256;   // per thread of the 4 waves (256 threads) that stage a row
 };
 
 struct RowsArgs {
@@ -153,6 +156,21 @@ int a2s_channel_absmax_impl(hipStream_t st, const float* x, long rows, int C, in
 }
 
 // ------------------------------------------------------------------------------------------- main kernel
+#ifdef RW_TRACE
+// timing instrumentation (tools/conv_rows_trace.py; never in the product build): shader-clock stamps of lane 0 of one even-row and one
+// odd-row wave of a few mid-grid workgroups, 8 stamps per iteration
+#define RW_TRACE_WGS 8
+#define RW_TRACE_ITERS 32
+__device__ unsigned long long rw_trace[RW_TRACE_WGS * 2 * RW_TRACE_ITERS * 8];
+extern "C" int a2s_rows_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rw_trace), sizeof(rw_trace)); }
+#define RW_STAMP(k)                                                                                                           \
+    do {                                                                                                                      \
+        if (trace_wg >= 0 && trace_it >= 0 && trace_it < RW_TRACE_ITERS && ng == 0 && lane == 0)                              \
+            rw_trace[((trace_wg * 2 + rp) * RW_TRACE_ITERS + trace_it) * 8 + (k)] = __builtin_readcyclecounter();             \
+    } while (0)
+#else
+#define RW_STAMP(k) do {} while (0)
+#endif
 __device__ __forceinline__ float rw_shr1(float x) {       // lane li of a 16-lane row receives lane li - 1's value
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
 }
@@ -166,16 +184,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
     constexpr int NJ = COUT / 20;             // n-tiles per wave
     constexpr int KS = G::KS, XIT = G::XIT;
     constexpr int MG = (NJ == 1) ? 4 : 2;     // m-tiles per fragment group
+    // Where the second fp16 term of the weights and (data gradient) the yl rows of the statistics epilogue live -- a register / LDS trade:
+    //   YLDS (data gradient with two n-tiles per wave): yl is fetched by LDS-DMA into a private slice while the wave multiplies (the 64
+    //        registers it would need in the epilogue do not exist) and both weight terms stay in registers;
+    //   otherwise the second weight term is re-read from LDS per k-step (32 registers saved) and yl, if needed, goes through registers.
+    constexpr bool YLDS = false;          // (measured: both forms fit the 256 registers of the 40 -> 40 data gradient only just; registers: 2 spills, LDS-DMA: 11)
+    constexpr bool B1L = !YLDS;
     __shared__ __attribute__((aligned(16))) unsigned char ring[RW_SLOTS * G::SLOT];
-    // data-gradient launches: the rows of yl (BatchNorm-backward statistics) a wave's epilogue needs, fetched by LDS-DMA while the wave
-    // multiplies -- [row parity][n-group][channel 5 NJ][32 x 4 positions]; private to the wave that fetched them
-    __shared__ __attribute__((aligned(16))) unsigned char ylbuf[BNRED ? 2 * COUT * 32 * 16 : 16];
+    // second fp16 term of the weights, in fragment order [n-tile][k-step][lane x 16 B] (the first term lives in registers; this one is
+    // needed by one product in three and re-read per row: 8 ds_read_b128 against 128 transposing reads of the activations)
+    __shared__ __attribute__((aligned(16))) unsigned char b1img[B1L ? (COUT / 5) * G::KS * 1024 : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char ylbuf[YLDS ? 8 * NJ * 5 * 32 * 16 : 16];      // [wave][channel 5 NJ][32 x 4 positions]
     __shared__ float red[8][NJ * 5][3];
     __shared__ float tab[(AFFINE ? 2 * CIN : 0) + (BNRED ? 4 * COUT : 0) + 4];      // [asc | ash] or [mean | invstd | scale | shift]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, g = lane >> 4;
-    const int rp = wave >> 2, ng = wave & 3;
+    const int rp = __builtin_amdgcn_readfirstlane(wave >> 2), ng = __builtin_amdgcn_readfirstlane(wave & 3);      // wave-uniform roles
 
     int bid = blockIdx.x;
     {   // XCD-aware order (workgroup ids go round-robin to the 8 XCDs): every XCD gets a contiguous run of logical tiles, so the
@@ -189,17 +214,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
     const int t_lo = strip * a.strip_len, t_hi = min(a.T, t_lo + a.strip_len);
 
     // ---- B fragments: resident in registers
-    s16x8 bw[NJ][KS][2];
+    const unsigned sgn = rp ? 0x80008000u : 0u;          // odd-row waves multiply by the negated weights
+    s16x8 bw[NJ][KS];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s) {
+            uint4 v = *reinterpret_cast<const uint4*>(a.wimg + ((size_t)((ng * NJ + j) * KS + s) * 2) * 1024 + lane * 16);
+            v.x ^= sgn; v.y ^= sgn; v.z ^= sgn; v.w ^= sgn;
+            bw[j][s] = __builtin_bit_cast(s16x8, v);
+        }
+    s16x8 bw1[B1L ? 1 : NJ][B1L ? 1 : KS];
+    if (B1L) {
+        for (int e = tid; e < (COUT / 5) * KS * 64; e += 512)
+            *reinterpret_cast<uint4*>(b1img + (size_t)e * 16) = *reinterpret_cast<const uint4*>(a.wimg + ((size_t)(e >> 6) * 2 + 1) * 1024 + (e & 63) * 16);
+    } else {
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                uint4 v = *reinterpret_cast<const uint4*>(a.wimg + ((size_t)((ng * NJ + j) * KS + s) * 2 + tm) * 1024 + lane * 16);
-                if (rp) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
-                bw[j][s][tm] = __builtin_bit_cast(s16x8, v);
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                uint4 v = *reinterpret_cast<const uint4*>(a.wimg + ((size_t)((ng * NJ + j) * KS + s) * 2 + 1) * 1024 + lane * 16);
+                v.x ^= sgn; v.y ^= sgn; v.z ^= sgn; v.w ^= sgn;
+                bw1[B1L ? 0 : j][B1L ? 0 : s] = __builtin_bit_cast(s16x8, v);
             }
+    }
     // ---- per-lane epilogue constants: column li = 3 c5 + df of n-tile j; lanes with df == 1 finish the output channel
     const bool useful = (q % 3 == 1) && q < 15;
     float unsc[NJ];
@@ -214,9 +252,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
         const float* src = tid < COUT ? a.yl_mean : tid < 2 * COUT ? a.yl_invstd : tid < 3 * COUT ? a.yl_scale : a.yl_shift;
         tab[tid] = src[tid % COUT];
     }
-    float st_s[NJ], st_s2[NJ], st_m[NJ];
+    __syncthreads();
+    f32x2 st_s[NJ], st_s2[NJ];            // two partial sums each (packed adds / FMAs)
+    float st_m[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) st_s[j] = st_s2[j] = st_m[j] = 0.f;
+    for (int j = 0; j < NJ; ++j) { st_s[j] = st_s2[j] = (f32x2){0.f, 0.f}; st_m[j] = 0.f; }
 
     // ---- A fragment addressing: running byte address (inside the ring) of this lane's 4-channel block for (s, r), for the wave's
     // first input row (dt = 0 of its output row); advanced by 2 slots per iteration modulo the ring
@@ -232,77 +272,79 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
     // ---- staging items of this thread: (channel, 4 positions)
     const int clip_rows = a.T;
     const float* __restrict__ xclip = a.x + (long)b * clip_rows * CIN * a.F;
-    // item `it` of a thread: e = tid + 512 it -> channel e >> 5, positions 4 (e & 31) ...; everything is re-derived from tid where it is
-    // used (a laundered copy, so that the compiler does not keep 4 loop-invariant registers per item alive across the multiply)
-    unsigned okmask = 0;
-#pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-        const int e = tid + 512 * it;
-        const int f = f_base - 4 + 4 * (e & 31);
-        if (e < G::ITEMS && f >= 0 && f < a.F) okmask |= 1u << it;
-    }
-    // always XIT loads per thread (the counted s_waitcnt of the data-gradient epilogue relies on it): rows / columns outside the clip
-    // read a clamped address and are zeroed when the row is converted
+    // A row is staged by the 4 waves that MULTIPLY in the phase it is converted in (256 threads, lt = their thread index): they issued its
+    // loads at the end of their preceding epilogue phase -- a full phase of latency cover -- and the waves that run an epilogue never have
+    // input-row loads in flight when they fetch yl (vector loads return in order).  Item `it` of a thread: e = lt + 256 it -> channel e >> 5,
+    // positions 4 (e & 31) ..: the column group is the same for all items; offsets are re-derived from a laundered lt where they are used
+    // (the compiler otherwise keeps several loop-invariant registers per item alive across the multiply, and spills).
+    const int lt = ng * 64 + lane;
+    const int fcol = f_base - 4 + 4 * (lt & 31);
+    const bool colok = fcol >= 0 && fcol < a.F;
+    // Input rows through a raw buffer over this clip.  The whole element offset sits in the VGPR offset: a row above / below the clip
+    // wraps out of the buffer's range and reads 0; columns outside the row are masked when the row is converted.
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xclip), 0, (unsigned)((long)a.T * CIN * a.F * 4), 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto issue = [&](int row, f32x4 (&xr)[XIT]) {
-        const long rbase = (long)min(max(row, 0), a.T - 1) * CIN * a.F;
+        const int rbase = row * CIN * a.F + f_base - 4;
+        int tl = lt;
+        asm volatile("" : "+v"(tl));
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            int e = tid + 512 * it;
-            asm volatile("" : "+v"(e));
-            const int goff = (e >> 5) * a.F + f_base - 4 + 4 * (e & 31);
-            xr[it] = *reinterpret_cast<const f32x4*>(xclip + rbase + ((okmask >> it & 1) ? goff : 0));
+            const int e = tl + 256 * it;
+            const int goff = (e >> 5) * a.F + 4 * (e & 31) + rbase;
+            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (colok && e < G::ITEMS) ? goff * 4 : -4, 0, 0));
         }
     };
-    auto commit = [&](int row, int slot, const f32x4 (&xr)[XIT]) {
-        const bool rowok = row >= 0 && row < a.T;
-        unsigned char* base = ring + slot * G::SLOT;
+    // one staged item: BatchNorm + ReLU of the producer (or the gradient's power-of-two scale), two fp16 terms, two 8-byte LDS stores
+    auto commit_item = [&](int it, bool ok, unsigned char* base, const f32x4& x) {
+        int tl = lt;
+        asm volatile("" : "+v"(tl));
+        const int e = tl + 256 * it;
+        if (e >= G::ITEMS) return;
+        const int ch = e >> 5, loff = ch * RW_SROW + (e & 31) * 8;
+        f32x4 v = x;
+        if (AFFINE) {
+            const float sc = tab[ch], sh = tab[CIN + ch];
 #pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            int e = tid + 512 * it;
-            asm volatile("" : "+v"(e));
-            if (e >= G::ITEMS) continue;
-            const int ch = e >> 5, loff = ch * RW_SROW + (e & 31) * 8;
-            f32x4 v = xr[it];
-            const bool ok = rowok && (okmask >> it & 1);
-            if (AFFINE) {
-                const float sc = tab[ch], sh = tab[CIN + ch];
+            for (int k = 0; k < 4; ++k) v[k] = ok ? fmaxf(fmaf(v[k], sc, sh), 0.f) : 0.f;
+        } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = ok ? fmaxf(fmaf(v[k], sc, sh), 0.f) : 0.f;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = ok ? v[k] * xscale : 0.f;
-            }
-            uint2 t0, t1;
-            split2_pair_f16(v[0], v[1], t0.x, t1.x);
-            split2_pair_f16(v[2], v[3], t0.y, t1.y);
-            *reinterpret_cast<uint2*>(base + loff) = t0;
-            *reinterpret_cast<uint2*>(base + G::TS + loff) = t1;
+            for (int k = 0; k < 4; ++k) v[k] = ok ? v[k] * xscale : 0.f;
         }
+        uint2 t0, t1;
+        split2_pair_f16(v[0], v[1], t0.x, t1.x);
+        split2_pair_f16(v[2], v[3], t0.y, t1.y);
+        *reinterpret_cast<uint2*>(base + loff) = t0;
+        *reinterpret_cast<uint2*>(base + G::TS + loff) = t1;
+    };
+    auto commit = [&](int row, int slot, const f32x4 (&xr)[XIT]) {
+        const bool ok = row >= 0 && row < a.T && colok;
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) commit_item(it, ok, ring + slot * G::SLOT, xr[it]);
     };
 
     f32x4 acc[8][NJ];
-    unsigned char* const ylw = ylbuf + (rp * 4 + ng) * (NJ * 5 * 32 * 16);          // this wave's private slice
-    // yl of output row t for this wave's channels: NJ * 5 channels x 32 items of 16 B = 2.5 (1.25) KB-instructions per lane
-    auto yl_fetch = [&](int t) {
-        if (!BNRED || t >= t_hi) return;
-        const float* __restrict__ ylrow = a.yl + (((long)b * a.T + t) * COUT + (ng * NJ) * 5) * a.F;
-#pragma unroll
-        for (int it = 0; it < (NJ * 5 * 32 + 63) / 64; ++it) {
-            const int e = it * 64 + lane, c = e >> 5, p4 = e & 31;
-            const int f = f_base - 4 + 4 * p4;
-            if (e < NJ * 5 * 32 && f >= 0 && f < a.F)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ylrow + (long)c * a.F + f),
-                                                 (__attribute__((address_space(3))) void*)(ylw + it * 1024), 16, 0, 0);
-        }
-    };
     // ---- multiply: output row of this wave from the three input rows at the running addresses
-    auto multiply = [&]() {
+    // ... and, between its k-steps, converts the input row `crow` this wave holds in xr into ring slot `cslot` (the VALU / LDS-store work
+    // rides in the shadow of the MFMAs: ~3 issue slots per 16-clock MFMA are free)
+    auto multiply = [&](bool converts, int crow, int cslot, const f32x4 (&xr)[XIT]) {
+        const bool cok = crow >= 0 && crow < a.T && colok;
+        unsigned char* const cbase = ring + cslot * G::SLOT;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            s16x8 b1[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (B1L) {
+                    uint4 v = *reinterpret_cast<const uint4*>(b1img + ((ng * NJ + j) * KS + s) * 1024 + lane * 16);
+                    v.x ^= sgn; v.y ^= sgn; v.z ^= sgn; v.w ^= sgn;
+                    b1[j] = __builtin_bit_cast(s16x8, v);
+                } else b1[j] = bw1[B1L ? 0 : j][B1L ? 0 : s];
+            }
 #pragma unroll
             for (int ig = 0; ig < 8 / MG; ++ig) {
                 s16x8 av[2][MG];
@@ -318,12 +360,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
 #define RW_PRODUCT(TA, TB)                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                           \
         _Pragma("unroll") for (int ii = 0; ii < MG; ++ii)                                                                    \
-            acc[ig * MG + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[TA][ii]), __builtin_bit_cast(f16x8, bw[j][s][TB]), acc[ig * MG + ii][j], 0, 0, 0);
-                RW_PRODUCT(1, 0)
-                RW_PRODUCT(0, 1)
-                RW_PRODUCT(0, 0)
+            acc[ig * MG + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[TA][ii]), __builtin_bit_cast(f16x8, TB), acc[ig * MG + ii][j], 0, 0, 0);
+                RW_PRODUCT(1, bw[j][s])
+                RW_PRODUCT(0, b1[j])
+                RW_PRODUCT(0, bw[j][s])
 #undef RW_PRODUCT
             }
+#pragma unroll
+            for (int it = 0; it < XIT; ++it)
+                if (converts && it * KS / XIT == s) commit_item(it, cok, cbase, xr[it]);
         }
     };
     auto advance = [&]() {      // two rows further down the ring
@@ -338,85 +383,181 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
     // ---- epilogue of output row t (the wave's own accumulators): df-combination, scale, store, statistics
     const int pv_addr = (((g + 3) & 3) * 16 + ((q + 15) & 15)) * 4;      // lane (li - 1, g - 1 mod 4)
     const int nx_addr = (((g + 1) & 3) * 16 + ((q + 1) & 15)) * 4;       // lane (li + 1, g + 1 mod 4)
+    // which of its 8 row quads (m-tile i, rows 16 i + 4 g ..) a lane stores: finishing lane, inside the 120 output columns, inside F
+    const bool full_tile = f_base + RW_P <= a.F;           // uniform
+    unsigned okbits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int p = 16 * i + 4 * g;
+        if (useful && p >= 4 && p < 4 + RW_P && f_base - 4 + p < a.F) okbits |= 1u << i;
+    }
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (long)b * a.T * COUT * a.F, 0, (unsigned)((long)a.T * COUT * a.F * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ylrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNRED ? a.yl + (long)b * a.T * COUT * a.F : a.x), 0,
+                                                                            BNRED ? (unsigned)((long)a.T * COUT * a.F * 4) : 0u, 0x00020000);
+    // data-gradient launches: yl at the positions this lane stores (same offsets as its stores), ALL quads of the wave's row, issued at the
+    // start of the epilogue phase BEFORE the phase's input-row loads (loads return in order: the epilogue must not queue behind those)
+    unsigned char* const ylw = ylbuf + (YLDS ? wave * (NJ * 5 * 32 * 16) : 0);          // this wave's private slice
+    // YLDS: yl of output row t for this wave's channels by LDS-DMA -- NJ * 5 channels x 32 items of 16 B, lane-linear in item order
+    auto yl_fetch = [&](int t) {
+        if (!YLDS || t >= t_hi) return;
+        const float* __restrict__ ylrow = a.yl + (((long)b * a.T + t) * COUT + (ng * NJ) * 5) * a.F;
+#pragma unroll
+        for (int it = 0; it < (NJ * 5 * 32 + 63) / 64; ++it) {
+            const int e = it * 64 + lane, c = e >> 5, p4 = e & 31;
+            const int f = f_base - 4 + 4 * p4;
+            if (e < NJ * 5 * 32 && f >= 0 && f < a.F)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ylrow + (long)c * a.F + f),
+                                                 (__attribute__((address_space(3))) void*)(ylw + it * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 ylv[(BNRED && !YLDS) ? NJ : 1][(BNRED && !YLDS) ? 8 : 1];
+    auto yl_issue = [&](int t) {
+        if (!BNRED) return;
+        if (YLDS) {      // fetched a phase ago by this very wave; nothing else of its vector memory traffic is outstanding by now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        const int yrow_off = t * COUT * a.F * 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int yvo = (((ng * NJ + j) * 5 + q / 3) * a.F + f_base - 4 + 4 * g) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                ylv[(BNRED && !YLDS) ? j : 0][(BNRED && !YLDS) ? i : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ylrsrc, yvo + 64 * i, yrow_off, 0));      // (lanes / quads that store nothing read a harmless in-range or range-checked address)
+        }
+    };
     auto epilogue = [&](int t) {
         if (t >= t_hi) return;
-        float* __restrict__ yrow = a.y + ((long)b * a.T + t) * COUT * a.F;
+        const int yrow_off = t * COUT * a.F * 4;                         // uniform: the s-offset of the stores
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int co = (ng * NJ + j) * 5 + q / 3;
+            const int yvo = (co * a.F + f_base - 4 + 4 * g) * 4;         // + 64 i: the instruction's immediate offset
             float bm = 0.f, bi = 0.f, bsc = 0.f, bsh = 0.f;
             if (BNRED && useful) { bm = tab[co]; bi = tab[COUT + co]; bsc = tab[2 * COUT + co]; bsh = tab[3 * COUT + co]; }
+            unsigned ob = okbits;                 // laundered: the per-quad store masks / scales are formed here, not kept in 16 registers
+            asm volatile("" : "+v"(ob));
+            // a workgroup whose 120 columns lie inside F (every one but the last column tile of a ragged F): only the first quad of row
+            // group 0 and the last of row group 3 fall outside the output columns
+            const float us_first = g > 0 ? unsc[j] : 0.f, us_last = g < 3 ? unsc[j] : 0.f;
+            // (1) the cross-group neighbours of all 8 quads first: 16 lane permutes in flight together (rows p - 1 / p + 1 of the
+            // neighbouring columns live in another 16-lane group, and in the neighbouring m-tile for g = 0 / 3)
+            // (in batches of RW_EB quads, fenced for the instruction scheduler: left alone it hoists every permute of both n-tiles and spills)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i0 = 0; i0 < 8; i0 += RW_EB) {
+            float X[RW_EB], Y[RW_EB];
+#pragma unroll
+            for (int ii = 0; ii < RW_EB; ++ii) {
+                const int i = i0 + ii;
+                const float m3 = (g == 3 && i > 0) ? acc[i > 0 ? i - 1 : 0][j][3] : acc[i][j][3];
+                const float m0 = (g == 0 && i < 7) ? acc[i < 7 ? i + 1 : 7][j][0] : acc[i][j][0];
+#ifdef RW_X_NOPERM
+                X[ii] = m3; Y[ii] = m0;
+#else
+                X[ii] = __int_as_float(__builtin_amdgcn_ds_bpermute(pv_addr, __float_as_int(m3)));
+                Y[ii] = __int_as_float(__builtin_amdgcn_ds_bpermute(nx_addr, __float_as_int(m0)));
+#endif
+            }
+            // (2) per quad, every lane (the DPP row shifts read all lanes): out = D0[p - 1] + D1[p] + D2[p + 1], scaled; lanes that do
+            // not finish a channel carry unsc = 0
+#pragma unroll
+            for (int ii = 0; ii < RW_EB; ++ii) {
+                const int i = i0 + ii;
                 const f32x4 v = acc[i][j];
-                // rows p - 1 / p + 1 of the neighbouring columns across the 4-row register groups (and across m-tiles for g = 0 / 3)
-                const float m3 = (g == 3 && i > 0) ? acc[i > 0 ? i - 1 : 0][j][3] : v[3];
-                const float m0 = (g == 0 && i < 7) ? acc[i < 7 ? i + 1 : 7][j][0] : v[0];
-                const float X = __int_as_float(__builtin_amdgcn_ds_bpermute(pv_addr, __float_as_int(m3)));
-                const float Y = __int_as_float(__builtin_amdgcn_ds_bpermute(nx_addr, __float_as_int(m0)));
+                // quads / lanes that store nothing come out as exact zeros: the statistics need no mask
+                const bool ok = full_tile ? (useful && (i == 0 ? g > 0 : i == 7 ? g < 3 : true)) : bool(ob >> i & 1);
+                const float us = full_tile ? (i == 0 ? us_first : i == 7 ? us_last : unsc[j]) : ((ob >> i & 1) ? unsc[j] : 0.f);
                 f32x4 o;
-                o[0] = (X + v[0]) + rw_shl1(v[1]);
-                o[1] = (rw_shr1(v[0]) + v[1]) + rw_shl1(v[2]);
-                o[2] = (rw_shr1(v[1]) + v[2]) + rw_shl1(v[3]);
-                o[3] = (rw_shr1(v[2]) + v[3]) + Y;
-                const int p = 16 * i + 4 * g, f = f_base - 4 + p;
-                if (useful && p >= 4 && p < 4 + RW_P && f < a.F) {
+                o[0] = ((X[ii] + v[0]) + rw_shl1(v[1])) * us;
+                o[1] = ((rw_shr1(v[0]) + v[1]) + rw_shl1(v[2])) * us;
+                o[2] = ((rw_shr1(v[1]) + v[2]) + rw_shl1(v[3])) * us;
+                o[3] = ((rw_shr1(v[2]) + v[3]) + Y[ii]) * us;
+#ifndef RW_X_NOSTORE
+                if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yvo + 64 * i, yrow_off, 0);
+#else
+                if (o[0] == 123.f && o[1] == 7.f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yvo + 64 * i, yrow_off, 0);
+#endif
+                if (BNRED) {
+                    const f32x4 xv = YLDS ? *reinterpret_cast<const f32x4*>(ylw + ((j * 5 + q / 3) * 32 + 4 * i + g) * 16) : ylv[(BNRED && !YLDS) ? j : 0][(BNRED && !YLDS) ? i : 0];
+                    f32x4 gm, xh;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] *= unsc[j];
-                    *reinterpret_cast<f32x4*>(yrow + (long)co * a.F + f) = o;
-                    if (BNRED) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(ylw + ((j * 5 + q / 3) * 32 + 4 * i + g) * 16);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float gm = (fmaf(xv[k], bsc, bsh) > 0.f) ? o[k] : 0.f;
-                            st_s[j] += gm; st_s2[j] = fmaf(gm * (xv[k] - bm), bi, st_s2[j]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { st_s[j] += o[k]; st_s2[j] = fmaf(o[k], o[k], st_s2[j]); }
-                        st_m[j] = fmaxf(fmaxf(st_m[j], fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                    for (int k = 0; k < 4; ++k) {
+                        gm[k] = (fmaf(xv[k], bsc, bsh) > 0.f) ? o[k] : 0.f;
+                        xh[k] = fmaf(xv[k], bi, -bm * bi);
                     }
+                    st_s[j] += (f32x2){gm[0], gm[1]}; st_s[j] += (f32x2){gm[2], gm[3]};
+                    st_s2[j] += (f32x2){gm[0], gm[1]} * (f32x2){xh[0], xh[1]}; st_s2[j] += (f32x2){gm[2], gm[3]} * (f32x2){xh[2], xh[3]};
+                } else {
+#ifndef RW_X_NOSTATS
+                    st_s[j] += (f32x2){o[0], o[1]}; st_s[j] += (f32x2){o[2], o[3]};
+                    st_s2[j] += (f32x2){o[0], o[1]} * (f32x2){o[0], o[1]}; st_s2[j] += (f32x2){o[2], o[3]} * (f32x2){o[2], o[3]};
+                    st_m[j] = fmaxf(fmaxf(st_m[j], fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+#endif
                 }
+                // pin the accumulation to this quad (left alone, the adds sink below all 16 quads and keep 64 output registers alive)
+                if (BNRED) asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]));
+                else asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]), "+v"(st_m[j]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
 
-    // ---- prologue: rows t_lo - 1 .. t_lo + 2 into slots 0 .. 3, row t_lo + 3 in flight
+    // ---- prologue: rows t_lo - 1 .. t_lo + 2 into slots 0 .. 3 (even-row waves: slots 0, 2; odd-row waves: 1, 3)
     f32x4 xa[XIT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        issue(t_lo - 1 + r, xa);
-        commit(t_lo - 1 + r, r, xa);
+    for (int r = 0; r < 2; ++r) {
+        issue(t_lo - 1 + 2 * r + rp, xa);
+        commit(t_lo - 1 + 2 * r + rp, 2 * r + rp, xa);
     }
+    issue(t_lo + 3 + rp, xa);                      // the row this wave converts during the first iteration
     __syncthreads();
 
-    // Per phase: [barrier] -> next input row's loads issued -> role (multiply | epilogue) -> that row converted into its slot -> [barrier].
-    // Even-row waves: multiply row t (+ fetch its yl), then its epilogue; odd-row waves: epilogue of row t - 1, then multiply row t + 1.
-    int slot_w = 4;
+    // Per iteration (two output rows, t by the even-row waves and t + 1 by the odd-row waves):
+    //   M: every wave multiplies its row (two waves per SIMD keep the matrix pipe fed and cover each other's LDS latency); the even-row
+    //      waves convert input row t + 3 into the one free ring slot between their k-steps;
+    //   E: the odd-row waves convert row t + 4 into the slot row t - 1 occupied (free once every wave has left M), every wave runs its
+    //      epilogue (df-combination, scale, store, statistics) and issues the loads of the row it converts in the next iteration.
+    // (Measured first, then dropped: even-row waves multiplying WHILE the odd-row waves run their epilogue and vice versa.  A wave issuing
+    // back-to-back MFMAs leaves its SIMD partner ~2 issue slots per MFMA: the epilogue took 6.5 k clocks beside a multiplying partner and
+    // 1.5 k alone, while a lone multiplying wave ran at 27 clocks per MFMA -- profiles/r03_conv_rows_ablation.txt.)
+    int slot_a = 4, slot_b = 0;
+#ifdef RW_TRACE
+    const int trace_first = (int)gridDim.x / 2;
+    const int trace_wg = ((int)blockIdx.x >= trace_first && (int)blockIdx.x < trace_first + RW_TRACE_WGS) ? (int)blockIdx.x - trace_first : -1;
+#endif
     for (int t = t_lo; t < t_hi; t += 2) {
-        issue(t + 3, xa);
-        if (rp == 0) { yl_fetch(t); multiply(); }
-        else if (t > t_lo) { if (BNRED) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XIT) : "memory"); epilogue(t - 1); }
-        commit(t + 3, slot_w, xa);
-        slot_w = slot_w == RW_SLOTS - 1 ? 0 : slot_w + 1;
+#ifdef RW_TRACE
+        const int trace_it = (t - t_lo) / 2 - 20;
+#endif
+        RW_STAMP(0);
+#ifndef RW_X_NOMUL
+        multiply(rp == 0, t + 3, slot_a, xa);
+#else
+        if (rp == 0) commit(t + 3, slot_a, xa);
+#endif
+        RW_STAMP(1);
         __syncthreads();
-        issue(t + 4, xa);
-        if (rp == 0) { if (BNRED) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XIT) : "memory"); epilogue(t); }
-        else { yl_fetch(t + 1); multiply(); }
-        commit(t + 4, slot_w, xa);
-        slot_w = slot_w == RW_SLOTS - 1 ? 0 : slot_w + 1;
+        RW_STAMP(2);
+        if (rp == 1) commit(t + 4, slot_b, xa);
+        RW_STAMP(3);
+#ifndef RW_X_NOEPI
+        if (t + rp < t_hi) { yl_issue(t + rp); epilogue(t + rp); }
+#endif
+        RW_STAMP(4);
+        issue(t + 5 + rp, xa);
+        slot_a = slot_a >= RW_SLOTS - 2 ? slot_a + 2 - RW_SLOTS : slot_a + 2;
+        slot_b = slot_b >= RW_SLOTS - 2 ? slot_b + 2 - RW_SLOTS : slot_b + 2;
         advance();
+        RW_STAMP(5);
         __syncthreads();
-    }
-    if (rp == 1 && t_hi > t_lo) {
-        if (BNRED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        epilogue(t_lo + ((t_hi - t_lo + 1) / 2) * 2 - 1);
+        RW_STAMP(6);
     }
 
     // ---- statistics: lanes of a column over the 4 row groups, then the two row-parity waves of the n-group
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        float s = st_s[j], s2 = st_s2[j], m = st_m[j];
+        float s = st_s[j][0] + st_s[j][1], s2 = st_s2[j][0] + st_s2[j][1], m = st_m[j];
         s += __shfl_xor(s, 16, 64); s2 += __shfl_xor(s2, 16, 64); m = fmaxf(m, __shfl_xor(m, 16, 64));
         s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64); m = fmaxf(m, __shfl_xor(m, 32, 64));
         if (g == 0 && useful) { red[wave][j * 5 + q / 3][0] = s; red[wave][j * 5 + q / 3][1] = s2; red[wave][j * 5 + q / 3][2] = m; }
