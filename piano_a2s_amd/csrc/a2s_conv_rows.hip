@@ -34,6 +34,7 @@
 //   An element x of an operand whose scaled magnitude is below 2^-3 has an absolute error of 2^-25 (second term subnormal): relative to
 //   the channel's (tensor's) largest magnitude that is 2^-39; everything above carries 22 significand bits.
 #include "a2s_common.h"
+#include <type_traits>
 
 #define RW_P 120             // output columns per workgroup
 #define RW_SROW 288          // bytes per channel row of the fp16 image: 128 positions + 32 B (rows 8 banks apart)
@@ -579,11 +580,404 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
     }
 }
 
+// =========================================================================================== rows16
+// Second generation of the row-streaming kernel (Cout = 40 launches): the n-tiles are [df][16 output channels] -- tile (cg, df) holds
+// D_df of the 16 channels of channel group cg, one channel per lane -- so the df-combination out[p][co] = D0[p-1] + D1[p] + D2[p+1] adds
+// three ACCUMULATOR REGISTERS OF THE SAME LANE (the row shift p +- 1 is a register rename inside a lane's 4 rows, one lane permute per
+// quad for the rows that cross a 16-lane group), every lane finishes an output channel, and a store writes 64 lanes x 16 B.  The first
+// generation (5 channels x 3 df per tile, above) spent 2.9 VALU instructions per MFMA on the combination with 5 of 16 lanes useful.
+//   * 40 channels = two groups of 16 (3 tiles each) + one of 8, laid out as 2 tiles ([df0 x 8 | df1 x 8], [df2 x 8 | idle]: D1 comes
+//     from lane + 8 by a DPP row rotate): 8 n-tiles, as many as the first generation needs;
+//   * 8 waves: waves 0-3 own (group 0 / 1, column half: 3 tiles x 4 m-tiles), waves 4-7 a column QUARTER of group 2 (2 tiles x 2 m-tiles):
+//     every SIMD carries 3 x 4 + 2 x 2 = 16 tile products per k-step and term product (192 MFMAs per row);
+//   * neighbouring column ranges of a group exchange the one accumulator row that crosses their boundary through a few floats of LDS;
+//   * one output row per iteration, ring of 4 slots, ONE barrier per row: all waves multiply (row t + 2 is converted into the free slot
+//     between the k-steps), barrier, epilogue + next row's loads;
+//   * both weight terms live in registers (96).
+// One block per n-tile: 0-5 = (group cg, df) of groups 0 / 1, 6 = [df0 | df1] and 7 = [df2 | idle] of group 2.
+// wimg[(tile * KS + s) * 2 + term][lane * 16 + (4 r + e) * 2]; header as rows_pack.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void rows16_pack(const float* __restrict__ w, int flip, const float* __restrict__ in_scale,
+                                                   const float* __restrict__ in_shift, const float* __restrict__ in_absmax,
+                                                   const float* __restrict__ x_absmax, unsigned char* __restrict__ wimg, float* __restrict__ hdr,
+                                                   float* __restrict__ out_absmax) {
+    static_assert(COUT == 40, "rows16: 40 output channels");
+    using G = RwGeom<CIN>;
+    __shared__ int kci[CIN];
+    __shared__ float red[16];
+    __shared__ int kw[16];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    // column li of this tile -> (output channel, df); co < 0: idle column
+    auto column = [&](int li, int& co, int& df) {
+        if (tile < 6) { co = (tile / 3) * 16 + li; df = tile % 3; }
+        else if (tile == 6) { co = 32 + (li & 7); df = li >> 3; }
+        else { co = li < 8 ? 32 + li : -1; df = 2; }
+    };
+    if (tid < CIN) {
+        int k = 0;
+        if (in_scale) k = pow2_scale_exp(fabsf(in_scale[tid]) * (in_absmax ? in_absmax[tid] : 1.f) + fabsf(in_shift[tid]), 14);
+        kci[tid] = k;
+        if (tile == 0) {
+            hdr[tid] = in_scale ? ldexpf(in_scale[tid], k) : 1.f;
+            hdr[40 + tid] = in_scale ? ldexpf(in_shift[tid], k) : 0.f;
+        }
+    }
+    if (tile == 0 && tid == 0) hdr[120] = ldexpf(1.f, (!in_scale && x_absmax) ? pow2_scale_exp(*x_absmax, 14) : 0);
+    if (tile == 0 && out_absmax && tid < COUT) out_absmax[tid] = 0.f;
+    __syncthreads();
+    auto weight = [&](int co, int ci, int tap) -> float {
+        const float wv = flip ? w[((long)ci * COUT + co) * 9 + (8 - tap)] : w[((long)co * CIN + ci) * 9 + tap];
+        return ldexpf(wv, -kci[ci]);
+    };
+    for (int c = 0; c < 16; ++c) {          // per-channel weight scale (over all taps: the same in every tile that holds the channel)
+        int co, df;
+        column(c, co, df);
+        float m = 0.f;
+        if (co >= 0)
+            for (int e = tid; e < CIN * 9; e += 256) m = fmaxf(m, fabsf(weight(co, e / 9, e % 9)));
+        m = block_max(m, red);
+        if (tid == 0) {
+            kw[c] = pow2_scale_exp(m, 13);
+            if (co >= 0 && df == 0) hdr[80 + co] = ldexpf(1.f, -kw[c]);
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < G::KS * 512; idx += 256) {
+        const int s = idx / 512, lane = (idx >> 3) & 63, e8 = idx & 7;
+        const int li = lane & 15, g = lane >> 4, r = e8 >> 2, e = e8 & 3;
+        const int kb = 8 * s + 4 * r + g;
+        int co, df;
+        column(li, co, df);
+        float v = 0.f;
+        if (co >= 0 && kb < 3 * G::NB) v = ldexpf(weight(co, 4 * (kb % G::NB) + e, (kb / G::NB) * 3 + df), kw[li]);
+        unsigned t0, t1;
+        split2_pair_f16(v, 0.f, t0, t1);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(wimg + ((size_t)(tile * G::KS + s) * 2) * 1024 + lane * 16 + e8 * 2);
+        dst[0] = (unsigned short)t0;
+        dst[512] = (unsigned short)t1;
+    }
+}
+
+__device__ __forceinline__ float rw_ror8(float x) {        // lane li of a 16-lane row receives lane (li + 8) % 16's value
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+}
+
+#define R16_SLOTS 4
+template <int CIN, int COUT, bool AFFINE, bool BNRED>
+__global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
+    static_assert(COUT == 40, "rows16: 40 output channels");
+    using G = RwGeom<CIN>;
+    constexpr int NTHR = 512, KS = G::KS;
+    constexpr int XIT = (G::ITEMS + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[R16_SLOTS * G::SLOT];
+    // accumulator rows that cross the boundary between neighbouring column ranges of a channel group, as TRUE values (sign undone):
+    // [iteration parity][boundary: 0 / 1 = halves of group 0 / 1, 2..4 = quarters of group 2][0: left range's last row of D0 | 1: right
+    // range's first row of D2][channel]
+    __shared__ float xch[2][5][2][16];
+    __shared__ float red[8][16][3];
+    __shared__ float tab[(AFFINE ? 2 * CIN : 0) + (BNRED ? 4 * COUT : 0) + 4];
+    // where the threads without an item in the last staging round put their (meaningless) 8 + 8 bytes: the conversion then has no
+    // branch, and the scheduler can weave it between the MFMAs
+    __shared__ __attribute__((aligned(16))) unsigned char dump[(G::ITEMS % NTHR) ? NTHR * 16 : 16];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 15, g = lane >> 4;
+    const bool wide = wave < 4;                           // waves 0-3: (group wave >> 1, half wave & 1); waves 4-7: quarter wave - 4 of group 2
+    const int m0 = wide ? 4 * (wave & 1) : 2 * (wave - 4); // first m-tile of the wave's column range
+    const int nm = wide ? 4 : 2;
+    const int tile0 = wide ? 3 * (wave >> 1) : 6;
+    const bool neg = wave & 1;                            // odd column ranges multiply by the negated weights (the matrix pipe's truncation
+    const float sg = neg ? -1.f : 1.f;                    // bias then cancels between neighbouring ranges in every per-channel sum)
+    const int bnd_l = wide ? (wave & 1 ? (wave >> 1) : -1) : (wave > 4 ? wave - 3 : -1);      // boundary index to the left / right (-1: tile edge)
+    const int bnd_r = wide ? (wave & 1 ? -1 : (wave >> 1)) : (wave < 7 ? wave - 2 : -1);
+
+    int bid = blockIdx.x;
+    {
+        const int per = (int)gridDim.x / 8;
+        if (bid < per * 8) bid = (bid % 8) * per + bid / 8;
+    }
+    const int ft = bid % a.tilesF; bid /= a.tilesF;
+    const int strip = bid % a.nstrips, b = bid / a.nstrips;
+    const int f_base = ft * RW_P;
+    const int t_lo = strip * a.strip_len, t_hi = min(a.T, t_lo + a.strip_len);
+
+    // ---- weights: both terms of the wave's tiles (3 or 2), all k-steps
+    const unsigned sgn = neg ? 0x80008000u : 0u;
+    s16x8 bw[3][KS][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                uint4 v = *reinterpret_cast<const uint4*>(a.wimg + ((size_t)((tile0 + ((wide || d < 2) ? d : 0)) * KS + s) * 2 + tm) * 1024 + lane * 16);
+                v.x ^= sgn; v.y ^= sgn; v.z ^= sgn; v.w ^= sgn;
+                bw[d][s][tm] = __builtin_bit_cast(s16x8, v);
+            }
+    const int co = wide ? (wave >> 1) * 16 + q : 32 + (q & 7);      // this lane's output channel
+    const bool useful = wide || q < 8;
+    const float xscale = a.hdr[120];
+    const float unsc = useful ? a.hdr[80 + co] / xscale * sg : 0.f;
+    if (AFFINE && tid < 2 * CIN) tab[tid] = a.hdr[tid < CIN ? tid : 40 + tid - CIN];
+    if (BNRED && tid < 4 * COUT) {
+        const float* src = tid < COUT ? a.yl_mean : tid < 2 * COUT ? a.yl_invstd : tid < 3 * COUT ? a.yl_scale : a.yl_shift;
+        tab[tid] = src[tid % COUT];
+    }
+    __syncthreads();
+    float bm = 0.f, bi = 0.f, bsc = 0.f, bsh = 0.f;
+    if (BNRED && useful) { bm = tab[co]; bi = tab[COUT + co]; bsc = tab[2 * COUT + co]; bsh = tab[3 * COUT + co]; }
+    f32x2 st_s = {0.f, 0.f}, st_s2 = {0.f, 0.f};
+    float st_m = 0.f;
+
+    // ---- A fragment addressing: running byte address of this lane's 4-channel block for (s, r), first input row of the output row
+    unsigned aaddr[KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int dt, cb;
+            rw_block<CIN>(8 * s + 4 * r + g, dt, cb);
+            aaddr[s][r] = (unsigned)(dt * G::SLOT + (4 * cb + q / 4) * RW_SROW + (q % 4) * 8 + m0 * 32);
+        }
+    // ---- staging: every thread, items e = tid + NTHR it (channel e >> 5, positions 4 (e & 31) ..)
+    const float* __restrict__ xclip = a.x + (long)b * a.T * CIN * a.F;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xclip), 0, (unsigned)((long)a.T * CIN * a.F * 4), 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int fcol = f_base - 4 + 4 * (tid & 31);
+    const bool colok = fcol >= 0 && fcol < a.F;          // (NTHR is a multiple of 32: the column group is the same for all items of a thread)
+    auto issue = [&](int row, f32x4 (&xr)[XIT]) {
+        const int rbase = row * CIN * a.F + f_base - 4;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tl + NTHR * it;
+            const int goff = (e >> 5) * a.F + 4 * (e & 31) + rbase;
+            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (colok && e < G::ITEMS) ? goff * 4 : -4, 0, 0));
+        }
+    };
+    auto commit_item = [&](int it, bool ok, unsigned char* base, const f32x4& x) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const int e = tl + NTHR * it;
+        const bool has = (it + 1) * NTHR <= G::ITEMS || e < G::ITEMS;
+        const int ch = has ? e >> 5 : 0;
+        unsigned char* const p0 = has ? base + ch * RW_SROW + (e & 31) * 8 : dump + tl * 16;
+        unsigned char* const p1 = has ? p0 + G::TS : p0 + 8;
+        f32x4 v = x;
+        if (AFFINE) {
+            const float sc = tab[ch], sh = tab[CIN + ch];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ok ? fmaxf(fmaf(v[k], sc, sh), 0.f) : 0.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ok ? v[k] * xscale : 0.f;
+        }
+        uint2 t0, t1;
+        split2_pair_f16(v[0], v[1], t0.x, t1.x);
+        split2_pair_f16(v[2], v[3], t0.y, t1.y);
+        *reinterpret_cast<uint2*>(p0) = t0;
+        *reinterpret_cast<uint2*>(p1) = t1;
+    };
+
+    f32x4 acc[4][3];                                     // [m-tile][tile of the wave]
+    // NM m-tiles x NT tiles; the conversion of input row crow (held in xr) rides between the k-steps
+    auto multiply = [&](auto NMc, auto NTc, int crow, int cslot, const f32x4 (&xr)[XIT]) {
+        constexpr int NM = decltype(NMc)::value, NT = decltype(NTc)::value;
+        const bool cok = crow >= 0 && crow < a.T && colok;
+        unsigned char* const cbase = ring + cslot * G::SLOT;
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int d = 0; d < NT; ++d) acc[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int ig = 0; ig < NM / 2; ++ig) {
+                s16x8 av[2][2];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int off = tm * G::TS + (ig * 2 + ii) * 32;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(RW_LDS(ring + aaddr[s][0] + off));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(RW_LDS(ring + aaddr[s][1] + off));
+                        av[tm][ii] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#define R16_PRODUCT(TA, TB)                                                                                                  \
+    _Pragma("unroll") for (int d = 0; d < NT; ++d)                                                                           \
+        _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                     \
+            acc[ig * 2 + ii][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[TA][ii]), __builtin_bit_cast(f16x8, bw[d][s][TB]), acc[ig * 2 + ii][d], 0, 0, 0);
+                R16_PRODUCT(1, 0)
+                R16_PRODUCT(0, 1)
+                R16_PRODUCT(0, 0)
+#undef R16_PRODUCT
+            }
+            // (the conversion has no branch: the compiler's scheduler weaves it and the next k-step's fragment reads between the MFMAs.
+            // Measured without gain: explicit sched_group_barrier interleaving, hand double-buffered fragments -- 244 registers in the
+            // data-gradient instance, slower.)
+#pragma unroll
+            for (int it = 0; it < XIT; ++it)
+                if (it * KS / XIT == s) commit_item(it, cok, cbase, xr[it]);
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned n = aaddr[s][r] + G::SLOT;
+                aaddr[s][r] = min(n, n - R16_SLOTS * G::SLOT);
+            }
+    };
+
+    // ---- epilogue.  Lane (q, g) holds, per m-tile i, rows p = 16 (m0 + i) + 4 g + r of its column.
+    const int up_addr = (((g + 3) & 3) * 16 + q) * 4;     // same column, previous 4-row group (wraps to the previous m-tile's last group)
+    const int dn_addr = (((g + 1) & 3) * 16 + q) * 4;     // same column, next 4-row group
+    unsigned okbits = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = 16 * (m0 + i) + 4 * g;
+        if (useful && i < nm && p >= 4 && p < 4 + RW_P && f_base - 4 + p < a.F) okbits |= 1u << i;
+    }
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (long)b * a.T * COUT * a.F, 0, (unsigned)((long)a.T * COUT * a.F * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ylrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNRED ? a.yl + (long)b * a.T * COUT * a.F : a.x), 0,
+                                                                            BNRED ? (unsigned)((long)a.T * COUT * a.F * 4) : 0u, 0x00020000);
+    const int yvo = (co * a.F + f_base - 4 + 16 * m0 + 4 * g) * 4;       // + 64 i
+    // WIDE: D0 / D1 / D2 = tiles 0 / 1 / 2, same lane.  Narrow (group 2): D0 = tile 0 lanes 0-7, D1 = tile 0 lanes 8-15 (row rotate by 8),
+    // D2 = tile 1 lanes 0-7.
+    // data gradient: yl at this lane's output positions, fetched BEFORE the multiply of the row (in flight under the MFMAs)
+    f32x4 ylv[BNRED ? 4 : 1];
+    auto yl_fetch = [&](int t) {
+        if (!BNRED) return;
+        const int yrow_off = t * COUT * a.F * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nm) ylv[BNRED ? i : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ylrsrc, yvo + 64 * i, yrow_off, 0));
+    };
+    auto epilogue = [&](auto WIDEc, int t, int par) {
+        constexpr bool WIDE = decltype(WIDEc)::value;
+        constexpr int NM = WIDE ? 4 : 2, D2 = WIDE ? 2 : 1;
+        const int yrow_off = t * COUT * a.F * 4;
+        // rows across the boundaries to the neighbouring column ranges (true values -> this wave's sign)
+        const float xl = bnd_l >= 0 ? xch[par][bnd_l >= 0 ? bnd_l : 0][0][q] * sg : 0.f;
+        const float xr_ = bnd_r >= 0 ? xch[par][bnd_r >= 0 ? bnd_r : 0][1][q] * sg : 0.f;
+        unsigned ob = okbits;
+        asm volatile("" : "+v"(ob));
+        float X[NM], Y[NM];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            // row p - 1 of D0 lives in the previous 4-row group (lane - 16; for g = 0: the previous m-tile's group 3, for the first
+            // m-tile of the range: the left neighbour's value), row p + 1 of D2 in the next one
+            const float up_src = (g == 3) ? (i > 0 ? acc[i > 0 ? i - 1 : 0][0][3] : xl) : acc[i][0][3];
+            const float dn_src = (g == 0) ? (i < NM - 1 ? acc[i < NM - 1 ? i + 1 : NM - 1][D2][0] : xr_) : acc[i][D2][0];
+            X[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(up_addr, __float_as_int(up_src)));
+            Y[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(dn_addr, __float_as_int(dn_src)));
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const bool ok = ob >> i & 1;
+            const float us = ok ? unsc : 0.f;
+            f32x4 d1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[r] = WIDE ? acc[i][1][r] : rw_ror8(acc[i][0][r]);
+            f32x4 o;
+            o[0] = ((X[i] + d1[0]) + acc[i][D2][1]) * us;
+            o[1] = ((acc[i][0][0] + d1[1]) + acc[i][D2][2]) * us;
+            o[2] = ((acc[i][0][1] + d1[2]) + acc[i][D2][3]) * us;
+            o[3] = ((acc[i][0][2] + d1[3]) + Y[i]) * us;
+            if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yvo + 64 * i, yrow_off, 0);
+            if (BNRED) {
+                const f32x4 xv = ylv[BNRED ? i : 0];
+                f32x4 gm, xh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gm[k] = (fmaf(xv[k], bsc, bsh) > 0.f) ? o[k] : 0.f;
+                    xh[k] = fmaf(xv[k], bi, -bm * bi);
+                }
+                st_s += (f32x2){gm[0], gm[1]}; st_s += (f32x2){gm[2], gm[3]};
+                st_s2 += (f32x2){gm[0], gm[1]} * (f32x2){xh[0], xh[1]}; st_s2 += (f32x2){gm[2], gm[3]} * (f32x2){xh[2], xh[3]};
+            } else {
+                st_s += (f32x2){o[0], o[1]}; st_s += (f32x2){o[2], o[3]};
+                st_s2 += (f32x2){o[0], o[1]} * (f32x2){o[0], o[1]}; st_s2 += (f32x2){o[2], o[3]} * (f32x2){o[2], o[3]};
+                st_m = fmaxf(fmaxf(st_m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            }
+        }
+    };
+
+    // ---- prologue: rows t_lo - 1, t_lo, t_lo + 1 into slots 0, 1, 2; row t_lo + 2 in flight
+    f32x4 xa[XIT];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        issue(t_lo - 1 + r, xa);
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) commit_item(it, t_lo - 1 + r >= 0 && t_lo - 1 + r < a.T && colok, ring + r * G::SLOT, xa[it]);
+    }
+    issue(t_lo + 2, xa);
+    __syncthreads();
+
+    int slot_w = 3, par = 0;
+#ifdef RW_TRACE
+    const int rp = wave & 1, ng = wave >> 1;  // (stamp slots: [workgroup][column half][iteration], waves 0 / 1 = channel group 0)
+    const int trace_first = (int)gridDim.x / 2;
+    const int trace_wg = ((int)blockIdx.x >= trace_first && (int)blockIdx.x < trace_first + RW_TRACE_WGS) ? (int)blockIdx.x - trace_first : -1;
+#endif
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+    for (int t = t_lo; t < t_hi; ++t) {
+#ifdef RW_TRACE
+        const int trace_it = t - t_lo - 40;
+#endif
+        RW_STAMP(0);
+        yl_fetch(t);
+        if (wide) multiply(I4{}, I3{}, t + 2, slot_w, xa);
+        else multiply(I2{}, I2{}, t + 2, slot_w, xa);
+        RW_STAMP(1);
+        // boundary rows for the neighbouring column ranges (lanes of 4-row group 3 / 0 hold them), as true values
+        if (bnd_r >= 0 && g == 3) xch[par][bnd_r >= 0 ? bnd_r : 0][0][q] = (wide ? acc[3][0][3] : acc[1][0][3]) * sg;
+        if (bnd_l >= 0 && g == 0) xch[par][bnd_l >= 0 ? bnd_l : 0][1][q] = (wide ? acc[0][2][0] : acc[0][1][0]) * sg;
+        __syncthreads();
+        RW_STAMP(2);
+        if (wide) epilogue(std::true_type{}, t, par);
+        else epilogue(std::false_type{}, t, par);
+        RW_STAMP(3);
+        issue(t + 3, xa);
+        RW_STAMP(4);
+        slot_w = slot_w == R16_SLOTS - 1 ? 0 : slot_w + 1;
+        par ^= 1;
+        advance();
+    }
+
+    // ---- statistics: a column's four 4-row groups, then the column ranges of the group
+    {
+        float s = st_s[0] + st_s[1], s2 = st_s2[0] + st_s2[1], m = st_m;
+        s += __shfl_xor(s, 16, 64); s2 += __shfl_xor(s2, 16, 64); m = fmaxf(m, __shfl_xor(m, 16, 64));
+        s += __shfl_xor(s, 32, 64); s2 += __shfl_xor(s2, 32, 64); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (g == 0) { red[wave][q][0] = s; red[wave][q][1] = s2; red[wave][q][2] = m; }
+    }
+    __syncthreads();
+    if (tid < COUT) {
+        float s = 0.f, s2 = 0.f, m = 0.f;
+        const int w0 = tid < 32 ? 2 * (tid >> 4) : 4, nw = tid < 32 ? 2 : 4, c = tid < 32 ? tid & 15 : tid - 32;
+        for (int k = 0; k < nw; ++k) { s += red[w0 + k][c][0]; s2 += red[w0 + k][c][1]; m = fmaxf(m, red[w0 + k][c][2]); }
+        if (a.stat_partial) {
+            a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 0] = s;
+            a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 1] = s2;
+        }
+        if (!BNRED && a.out_absmax) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(a.out_absmax + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(reinterpret_cast<unsigned*>(a.out_absmax + tid), bits);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- launcher
 static int g_conv_rows = -1;
 void a2s_conv_rows_set(int on) { g_conv_rows = on; }
 int a2s_conv_rows_enabled(void) {
-    if (g_conv_rows < 0) { const char* e = getenv("A2S_CONV_ROWS"); g_conv_rows = e ? atoi(e) : 1; }
+    // bit 0: the row-streaming kernels; bit 1: their second generation (conv3x3_rows16) where it exists (Cout = 40)
+    if (g_conv_rows < 0) { const char* e = getenv("A2S_CONV_ROWS"); g_conv_rows = e ? atoi(e) : 3; }
     return g_conv_rows;
 }
 bool a2s_conv_rows_eligible(int F, int Cin) { return a2s_conv_rows_enabled() && F % 4 == 0 && (Cin == 20 || Cin == 40); }
@@ -606,9 +1000,18 @@ int a2s_conv_rows_blocks(int B, int T, int F) {
 }
 size_t a2s_conv_rows_workspace_floats(int Cin) {
     // packed image for Cout = 40 (8 n-tiles) + header + per-channel max|x| scratch of the fallback path
-    return (size_t)8 * RwGeom<40>::KS * 2 * 1024 / 4 + RW_HDR + 64;
+    return (size_t)9 * RwGeom<40>::KS * 2 * 1024 / 4 + RW_HDR + 64;     // (rows16: 9 tiles)
 }
 
+template <int CIN, int COUT>
+static int rows16_launch(hipStream_t st, const RowsArgs& a, bool affine, bool bnred, int nwork) {
+    constexpr int NT = 512;
+    if (affine) hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, true, false>), dim3(nwork), dim3(NT), 0, st, a);
+    else if (bnred) hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, false, true>), dim3(nwork), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, false, false>), dim3(nwork), dim3(NT), 0, st, a);
+    A2S_CHECK_LAUNCH("conv3x3_rows16");
+    return A2S_OK;
+}
 template <int CIN, int COUT>
 static int rows_launch(hipStream_t st, const RowsArgs& a, bool affine, bool bnred, int nwork) {
     if (affine) hipLaunchKernelGGL((conv3x3_rows<CIN, COUT, true, false>), dim3(nwork), dim3(512), 0, st, a);
@@ -632,7 +1035,7 @@ int a2s_conv3x3_rows_impl(hipStream_t st, const float* x, const float* w, float*
     A2S_REQUIRE(F % 4 == 0 && (Cin == 20 || Cin == 40) && (Cout == 20 || Cout == 40), "conv3x3_rows: unsupported shape F=%d Cin=%d Cout=%d", F, Cin, Cout);
     A2S_REQUIRE(!(in_scale && yl), "conv3x3_rows: input affine and BatchNorm-backward statistics are exclusive");
     unsigned char* wimg = reinterpret_cast<unsigned char*>(ws);
-    float* hdr = ws + (size_t)8 * RwGeom<40>::KS * 2 * 1024 / 4;
+    float* hdr = ws + (size_t)9 * RwGeom<40>::KS * 2 * 1024 / 4;
     float* scratch = hdr + RW_HDR;
     // operand ranges the caller did not supply are measured here (one extra pass over x: the engine always supplies them)
     if (in_scale && !in_absmax) {
@@ -649,6 +1052,14 @@ int a2s_conv3x3_rows_impl(hipStream_t st, const float* x, const float* w, float*
     rows_geometry(B, T, F, &a.tilesF, &a.nstrips, &a.strip_len);
     a.nwork = B * a.tilesF * a.nstrips;
     const bool affine = in_scale != nullptr, bnred = yl != nullptr;
+#define R16_CASE(CI, CO)                                                                                                     \
+    if (Cin == CI && Cout == CO && (a2s_conv_rows_enabled() & 2)) {                                                          \
+        hipLaunchKernelGGL((rows16_pack<CI, CO>), dim3(8), dim3(256), 0, st, w, flip, in_scale, in_shift, in_absmax, x_absmax, wimg, hdr, out_absmax); \
+        A2S_CHECK_LAUNCH("rows16_pack");                                                                                     \
+        return rows16_launch<CI, CO>(st, a, affine, bnred, a.nwork);                                                         \
+    }
+    R16_CASE(20, 40) R16_CASE(40, 40)
+#undef R16_CASE
 #define RW_CASE(CI, CO)                                                                                                      \
     if (Cin == CI && Cout == CO) {                                                                                           \
         rows_pack_launch<CI, CO>(st, w, flip, in_scale, in_shift, in_absmax, x_absmax, wimg, hdr, out_absmax);               \

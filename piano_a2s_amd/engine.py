@@ -279,18 +279,22 @@ class Engine:
         x = spec_in.contiguous()
         chans = [(1, 20), (20, 20), (20, 40), (40, 40)]
         scale = shift = None
-        saved = {"x0": x, "y": [], "bn": []}
+        saved = {"x0": x, "y": [], "bn": [], "yabs": []}
+        yabs = None                          # per-channel max |y| of the previous layer's output, written by the launch that produced it
         for i, (ci, co) in enumerate(chans, start=1):
             y = self._empty(B, T, co, F, dev=dev)
             nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
             partial = self._empty(nblk, co, 2, dev=dev) if training else None
             cws = hip.conv_workspace(ci, dev)
-            hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(y), hip._p(scale),
-                                    hip._p(shift), hip._p(partial), B, T, F, ci, co, 0, hip._p(cws)), "a2s_conv3x3")
+            # the operand of layer i+1 is relu(scale_c y_c + shift_c): |scale_c| max|y_c| + |shift_c| bounds it, and the row-streaming
+            # kernel scales channel c by the matching power of two (nothing is clamped whatever BatchNorm's gamma is: DESIGN.md section 5)
+            yabs_out = self._empty(co, dev=dev)
+            hip.conv3x3_forward(x.view(B, T, ci, F), S[f"convstack.conv{i}.weight"], y, scale, shift, partial, cws, yabs, yabs_out)
             mean, invstd, scale, shift = self._bn(S, f"convstack.bn{i}", partial, nblk, co, float(B) * T * F, training)
             saved["y"].append(y)
             saved["bn"].append((mean, invstd, scale, shift))
-            x = y
+            saved["yabs"].append(yabs_out)
+            x, yabs = y, yabs_out
         # the (B*T, 40*F) operand of the 19200->256 Linear is relu(bn4(y4)): formed while the GEMM stages its A tiles (column k belongs
         # to channel k // F), never written to memory (A2S_MATERIALIZE_A4=1: the separate bn_relu_apply pass, for A/B measurements)
         y4 = x.view(B * T, 40 * F)

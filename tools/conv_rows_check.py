@@ -11,6 +11,7 @@ from piano_a2s_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 L = hip.lib()
+ROWS = int(os.environ.get("ROWS", "3"))          # conv_rows switch: 1 = first generation everywhere, 3 = rows16 where it exists (default)
 
 
 def fwd(x, w, scale, shift, rows):
@@ -54,7 +55,7 @@ def check():
             a64 = torch.relu(x.double().permute(0, 2, 1, 3) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
             ref = torch.nn.functional.conv2d(a64, w.double(), padding=1).permute(0, 2, 1, 3)
             mag = torch.nn.functional.conv2d(a64.abs(), w.double().abs(), padding=1).permute(0, 2, 1, 3) + 1e-300
-            y, sums, amax = fwd(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1)
+            y, sums, amax = fwd(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), ROWS)
             y = y.cpu().double()
             bad = int((~torch.isfinite(y)).sum())
             err = float(((y - ref).abs() / mag).nan_to_num(1e9).max())
@@ -76,7 +77,7 @@ def check():
             bsc, bsh = torch.rand(Cl_in, generator=g) + 0.5, torch.randn(Cl_in, generator=g) * 0.3
             bn = [t.to(dev) for t in (mean, invstd, bsc, bsh)]
             for stats in (True, False):
-                dx, sums = dgrad(dy.to(dev), w.to(dev), yl.to(dev), bn, 1, stats)
+                dx, sums = dgrad(dy.to(dev), w.to(dev), yl.to(dev), bn, ROWS, stats)
                 dx = dx.cpu().double()
                 bad = int((~torch.isfinite(dx)).sum())
                 err = float(((dx - ref).abs() / mag).nan_to_num(1e9).max())
@@ -121,7 +122,7 @@ def bench(B):
         yl = torch.randn(B, T, co, F, device=dev) if flip else None
         bn = [torch.randn(co, device=dev) * 0.1, torch.rand(co, device=dev) + 0.5, torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev) * 0.1]
         res = {}
-        for rows in (0, 1):
+        for rows in (0, 1, 3):
             hip.check(L.a2s_debug_set(b"conv_rows", rows), "set")
             nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
             partial = torch.empty(nblk, co, 2, device=dev)
@@ -134,10 +135,10 @@ def bench(B):
                 fn = lambda: hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(w), hip._p(y), hip._p(scale), hip._p(shift), hip._p(partial), B, T, F, ci, co, 0,
                                                      hip._p(cws)), "conv")
             res[rows] = timed(fn)
-        hip.check(L.a2s_debug_set(b"conv_rows", 1), "set")
+        hip.check(L.a2s_debug_set(b"conv_rows", 3), "set")
         fl = 2.0 * 9 * ci * co * B * T * F
         gb = 4.0 * B * T * F * (ci + co + (co if flip else 0))
-        print(f"{what:12s} {ci:2d}->{co:2d} B={B}: tiled {res[0]:7.2f} ms   rows {res[1]:7.2f} ms  = {fl / res[1] / 1e9:6.1f} TFLOP/s, {gb / res[1] / 1e6:5.0f} GB/s algorithmic", flush=True)
+        print(f"{what:12s} {ci:2d}->{co:2d} B={B}: tiled {res[0]:7.2f} ms   rows {res[1]:7.2f} ms   rows16 {res[3]:7.2f} ms = {fl / res[3] / 1e9:6.1f} TFLOP/s, {gb / res[3] / 1e6:5.0f} GB/s algorithmic", flush=True)
         del x, y, yl
 
 

@@ -43,6 +43,15 @@ def main():
     buf = np.zeros(n_wg * 2 * n_it * 8, dtype=np.uint64)
     assert L.a2s_rows_trace_read(buf.ctypes.data_as(C.c_void_p)) == 0
     t = buf.reshape(n_wg, 2, n_it, 8).astype(np.int64)
+    if os.environ.get("ROWS16", "1") == "1" and co == 40:
+        tt = t[:, :, :, :5]
+        for mh in (0, 1):
+            d = np.diff(tt[:, mh], axis=-1).reshape(-1, 4).mean(0)
+            period = np.diff(tt[:, mh, :, 0], axis=-1).mean()
+            print(f"rows16, column half {mh} of channel group 0: row period {period:.0f} clocks (1 output row x 120 columns)")
+            for n, v in zip(["multiply (+ conversion of row t+2)", "barrier wait", "epilogue", "issue next row's loads"], d):
+                print(f"    {n:40s} {v:8.0f}")
+        return
     names = ["M: multiply (even-row waves also convert row t+3)", "barrier wait", "odd-row waves: convert row t+4", "E: epilogue", "issue next row loads, advance", "barrier wait", "(loop)"]
     for rp, who in ((0, "even-row wave"), (1, "odd-row wave")):
         tt = t[:, rp, :, :7]
