@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no torchrun environment: print the launcher command as JSON and exit")
+    ap.add_argument("--launcher", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1 (RCCL world of one)")
     ap.add_argument("--master-port", type=int, default=int(os.environ.get("MASTER_PORT", "29533")))
     ap.add_argument("--no-straggler-sim", action="store_true", help="skip the 1-GPU data-parallel straggler simulation (predicted_dp_efficiency)")
     ap.add_argument("--no-inference", action="store_true", help="skip the greedy-decode (config 5) block")
@@ -63,7 +64,7 @@ def parse(argv=None):
 def launcher_command(args, argv):
     """The command a bare `python bench.py --gpus N` (N > 1, no RANK in the environment) starts as a CHILD process: one rank per GPU
     under torch.distributed.run, the reference's own launch shape (reference README.md:119-122, pretrain.py:257)."""
-    rest = [a for a in argv if a != "--dry-launch"]
+    rest = [a for a in argv if a not in ("--dry-launch", "--launcher")]
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
             "--master-port", str(args.master_port), os.path.abspath(__file__)] + rest
 
@@ -95,9 +96,11 @@ def self_launch(args, argv):
 
 
 def conv_roofline(B, T, F, iters=6):
-    """Average launch duration of the dominant kernel, conv3x3_mfma<40>, on conv4's forward launch at the step's own shapes
-    (40 -> 40 channels, BN+ReLU of the producer folded into the input staging, batch statistics partials written), HIP events on the
-    launch stream.  Algorithmic flops: 2 * 9 * Cin * Cout per output element, zero padding counted as work (0.4 % at 1201 x 480)."""
+    """Average launch duration of the dominant kernel by GPU time, the 40-channel row-streaming 3x3 convolution (conv3x3_rows16, two fp16
+    terms per fp32 operand), on conv4's forward launch at the step's own shapes (40 -> 40 channels, BatchNorm + ReLU of the producer
+    folded into the staging, batch statistics and per-channel output ranges written; the weight-packing pre-kernel is inside the
+    average), HIP events on the launch stream.  Put against BOTH roofs: HBM -- algorithmic bytes = input + output tensor once --, and
+    the matrix pipes -- algorithmic fp32 flops 2 * 9 * Cin * Cout per output element against the dense fp16 MFMA peak / 3 term products."""
     from piano_a2s_amd import hip
     L = hip.lib()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -106,13 +109,13 @@ def conv_roofline(B, T, F, iters=6):
     y = torch.empty(B, T, co, F, device=dev)
     w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
     scale, shift = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
-    nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
-    partial = torch.empty(nblk, co, 2, device=dev)
+    partial = torch.empty(L.a2s_conv3x3_stat_blocks(B, T, F, ci), co, 2, device=dev)
     cws = hip.conv_workspace(ci, dev)
+    in_absmax = x.abs().amax(dim=(0, 1, 3)).contiguous()      # (in the step: written by the launch that produced x)
+    out_absmax = torch.empty(co, device=dev)
 
     def launch():
-        hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(w), hip._p(y), hip._p(scale), hip._p(shift), hip._p(partial), B, T, F, ci, co, 0,
-                                hip._p(cws)), "a2s_conv3x3")
+        hip.conv3x3_forward(x, w, y, scale, shift, partial, cws, in_absmax, out_absmax)
     for _ in range(2):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -122,39 +125,32 @@ def conv_roofline(B, T, F, iters=6):
     e1.record()
     torch.cuda.synchronize()
     avg_s = e0.elapsed_time(e1) / iters / 1e3
+    rows = L.a2s_debug_get(b"conv_rows")
+    kernel = ("conv3x3_rows16<40, 40, affine> (conv4 forward launch, incl. its weight-packing pre-kernel)" if rows & 2 else
+              "conv3x3_rows<40, 40, affine>" if rows & 1 else "conv3x3_split<40, false, 2> (tiled kernel of round 2)")
     flops = 2.0 * 9 * ci * co * B * T * F
     achieved = flops / avg_s / 1e12
-    if L.a2s_debug_get(b"conv_bf16x3") & 1:
-        # forward convolutions run on the 16-bit matrix pipes with exactly split fp32 operands: two fp16 terms / three term products per
-        # fp32 product (default) or three bf16 terms / six products -- the roof of the fp32-equivalent rate is the dense 16-bit MFMA peak
-        # divided by the products per fp32 product (the achieved figure stays the ALGORITHMIC fp32 flops of the launch)
-        two = bool(L.a2s_debug_get(b"conv_f16x2") & 1)
-        products = 3 if two else 6
-        peak = MFMA_BF16_PEAK_TFS / products
-        mfma = {"achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "peak_note": f"fp32-equivalent: 2.5 PFLOP/s dense {'fp16' if two else 'bf16'} MFMA / {products} term products per fp32 product "
-                             f"({'two-term fp16' if two else 'three-term bf16'} exact operand split)",
-                "frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFS, 4), "algorithmic_flops_per_launch": int(flops)}
-        # The same launch against the HBM roof: algorithmic bytes = the input and the output tensor once each.  With three term products the
-        # kernel's arithmetic intensity (2*9*Cin*Cout / (4*(Cin+Cout)) = 90 flop/B) lies just below the ridge of the two roofs (833 TFLOP/s /
-        # 8 TB/s = 104 flop/B): it is the memory side that binds, and `bound` names whichever roof the launch is closer to.  `traffic`: the
-        # PMC measurement committed in profiles/r02_conv_analysis.txt (FETCH_SIZE x2 + WRITE_SIZE at B = 32: 1.289 x the algorithmic bytes
-        # -- the 6/4 x 66/64 tile halo is re-fetched), scaled to this launch's batch.
-        nbytes = 4.0 * B * T * F * (ci + co)
-        gbs = nbytes / avg_s / 1e9
-        hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-               "algorithmic_bytes_per_launch": int(nbytes)}
-        # (B = 256, profiles/r02_conv_traffic_b256.txt: FETCH_SIZE 18 180 796 KB x2 + WRITE_SIZE 23 085 836 KB = 60.87 GB; same ratio at B = 32)
-        traffic = (int((2 * 18180796.19 + 23085836.0) * 1024) if B == 256 else int(1.289 * nbytes)) if two else None
-        first, other, bound = (hbm, mfma, "hbm") if hbm["frac"] >= mfma["frac"] else (mfma, hbm, "mfma")
-        out = {"bound": bound, "kernel": f"conv3x3_split<40, false, {2 if two else 3}> (conv4 forward launch, incl. its weight split/packing pre-kernels)"}
-        out.update(first)
-        out.update({"traffic": traffic, "traffic_source": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, " + ("this launch at B=256: profiles/r02_conv_traffic_b256.txt" if B == 256 else "B=32 scaled by batch: profiles/r02_conv_traffic_b32.txt")) if traffic else None,
-                    "avg_launch_us": round(avg_s * 1e6, 1), ("mfma_view" if bound == "hbm" else "hbm_view"): other})
-        return out
-    return {"bound": "mfma", "kernel": "conv3x3_mfma<40, false> (conv4 forward launch, incl. its weight-packing pre-kernel)", "achieved": round(achieved, 2),
-            "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFS, 4), "traffic": None,
-            "avg_launch_us": round(avg_s * 1e6, 1), "algorithmic_flops_per_launch": int(flops)}
+    peak = MFMA_BF16_PEAK_TFS / 3
+    mfma = {"achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "peak_note": "fp32-equivalent: 2.5 PFLOP/s dense fp16 MFMA / 3 term products per fp32 product (two exact fp16 terms per operand)",
+            "frac_of_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFS, 4), "algorithmic_flops_per_launch": int(flops)}
+    nbytes = 4.0 * B * T * F * (ci + co)
+    gbs = nbytes / avg_s / 1e9
+    hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes)}
+    # measured HBM traffic of this very kernel: only from a committed rocprofv3 --pmc measurement that names the kernel and batch
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
+            m = json.load(f)
+        if m.get("per_gpu_batch") == B and m.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
+            traffic, traffic_src = m["traffic_bytes_per_launch"], m["source"]
+    except Exception:  # noqa: BLE001
+        pass
+    first, other, bound = (hbm, mfma, "hbm") if hbm["frac"] >= mfma["frac"] else (mfma, hbm, "mfma")
+    out = {"bound": bound, "bound_note": "the roof the launch is closer to; both fractions are given", "kernel": kernel}
+    out.update(first)
+    out.update({"traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(avg_s * 1e6, 1), ("mfma_view" if bound == "hbm" else "hbm_view"): other})
+    return out
 
 
 def attention_roofline(step, batch_dev, B, T, H, iters=50):
@@ -381,7 +377,7 @@ def main():
         from piano_a2s_amd import spec
         print(json.dumps(_cpu_baseline_child(spec.default_cfg(), args.cpu_clips, 1234, args.cpu_threads or (os.cpu_count() or 1), args.full_tail)), flush=True)
         return
-    if args.gpus > 1 and "RANK" not in os.environ:         # bare `python bench.py --gpus N`: start one rank per GPU as child processes
+    if (args.gpus > 1 or args.launcher) and "RANK" not in os.environ:     # bare `python bench.py --gpus N`: start one rank per GPU as child processes
         sys.exit(self_launch(args, argv))
     if args.dry_launch:
         print(json.dumps({"launch": None, "n_gpus": args.gpus}), flush=True)
@@ -389,7 +385,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or os.environ.get("A2S_FORCE_DIST") == "1"     # the latter: exercise the RCCL path on one GPU (debug)
+    use_dist = world > 1 or "RANK" in os.environ or os.environ.get("A2S_FORCE_DIST") == "1"     # under a launcher: the RCCL path even with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -497,12 +493,13 @@ def main():
                           "allocator": {"hipMalloc_calls": torch.cuda.memory_stats().get("segment.all.allocated", 0),
                                         "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0),
                                         "reserved_peak_GiB": round(torch.cuda.memory_stats().get("reserved_bytes.all.peak", 0) / 2 ** 30, 1)},
-                          "arithmetic": "fp32 data and fp32 accumulation everywhere; the 3x3 convolutions (forward, data gradient, conv3/conv4 weight "
-                                        "gradient) multiply on the fp16 matrix pipes with every fp32 operand carried as TWO exact fp16 terms under "
-                                        "power-of-two scales (three term products per fp32 product), the 128x128 GEMM tiles on the bf16 pipes with "
-                                        "three bf16 terms (six products); element error vs float64 equal to the fp32-input MFMA kernels' "
-                                        "(DESIGN.md section 3); A2S_CONV_F16X2=0 A2S_WGRAD_F16X2=0 select the three-term kernels, "
-                                        "A2S_CONV_BF16X3=0 A2S_GEMM_BF16X3=0 A2S_WGRAD_BF16X3=0 the fp32-input ones",
+                          "arithmetic": "fp32 data and fp32 accumulation everywhere; the 3x3 convolutions (forward, data gradient: row-streaming "
+                                        "kernels; conv3/conv4 weight gradient) and the 19200->256 Linear multiply on the fp16 matrix pipes with every "
+                                        "fp32 operand carried as TWO exact fp16 terms under power-of-two scales derived from operand ranges the producing "
+                                        "kernels write (three term products per fp32 product), the other 128x128 GEMM tiles on the bf16 pipes with three "
+                                        "bf16 terms (six products); element error vs float64 equal to the fp32-input MFMA kernels' (DESIGN.md section 5); "
+                                        "A2S_CONV_ROWS=0 selects round 2's tiled convolutions, A2S_CONV_F16X2=0 A2S_WGRAD_F16X2=0 the three-term "
+                                        "kernels, A2S_CONV_BF16X3=0 A2S_GEMM_BF16X3=0 A2S_WGRAD_BF16X3=0 the fp32-input ones",
                           "final_loss": round(loss, 4), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}}
         if secondary is not None:
             out["tail_off"] = secondary

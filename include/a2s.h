@@ -290,6 +290,14 @@ int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float
 /* ... with max |dy| (device scalar written by a2s_bn_bwd*_amax) for the two-term fp16 path of the split-operand kernel (NULL: as above) */
 int a2s_conv3x3_wgrad_scaled(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
                              float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax);
+/* ... with the RANGE of the activated operand relu(x * in_scale[c] + in_shift[c]) as well (round 3): act_absmax = device scalar from
+ * a2s_act_bound (NULL: operand used unscaled, as a2s_conv3x3_wgrad_scaled).  Reference: autograd of nn.Conv2d, models.py:525-534. */
+int a2s_conv3x3_wgrad_ranged(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
+                             size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax, const float* act_absmax);
+/* out[0] = max_c (|scale[c]| * absmax[c] + |shift[c]|): hard bound of relu(x * scale[c] + shift[c]) over a tensor whose producer wrote the
+ * per-channel max |x| (a2s_conv3x3_ranged); the operand range handed to the kernels that apply BatchNorm + ReLU while staging
+ * (a2s_conv3x3_wgrad_ranged, a2s_gemm_f32_affine_scaled).  Nothing comparable in the reference (fp32 throughout). */
+int a2s_act_bound(void* stream, const float* scale, const float* shift, const float* absmax, int C, float* out);
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
 /* The same with the BatchNorm backward of the layer's output folded into the staging of the dy operand: g = gradient wrt
  * relu(bn(y)), y = the layer's pre-BN output, c12 from a2s_bn_bwd(..., dx = NULL); dy = scale*(g' - c1 - xhat*c2) is formed on the fly

@@ -83,7 +83,8 @@ int a2s_bn_bwd_from_partial_impl(hipStream_t, const float*, const float*, const 
                                  const float*, int, float*, long, int, int, float*);
 
 int a2s_conv3x3_wgrad_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, size_t, int, int, int, int, int,
-                           const float*, const float*, const float*, const float*, const float*, const float*, float*, const float*);
+                           const float*, const float*, const float*, const float*, const float*, const float*, float*, const float*, const float*);
+int a2s_act_bound_impl(hipStream_t, const float*, const float*, const float*, int, float*);
 void a2s_wgrad_f16x2_set(int);
 int a2s_wgrad_f16x2_enabled(void);
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int, int);
@@ -332,18 +333,26 @@ size_t a2s_bn_bwd_partial_floats(long rows, int C, int F) { return a2s_bn_bwd_pa
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
                       size_t workspace_bytes, int B, int T, int F, int Cin, int Cout) {
     return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, nullptr, nullptr, nullptr);
+                                  nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+int a2s_conv3x3_wgrad_ranged(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
+                             size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax, const float* act_absmax) {
+    return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, dy_absmax, act_absmax);
+}
+int a2s_act_bound(void* stream, const float* scale, const float* shift, const float* absmax, int C, float* out) {
+    return a2s_act_bound_impl(ST, scale, shift, absmax, C, out);
 }
 int a2s_conv3x3_wgrad_scaled(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
                              size_t workspace_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax) {
     return a2s_conv3x3_wgrad_impl(ST, dy, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, nullptr, nullptr, nullptr, nullptr,
-                                  nullptr, nullptr, nullptr, dy_absmax);
+                                  nullptr, nullptr, nullptr, dy_absmax, nullptr);
 }
 int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
                          const float* c12, float* dy_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
                          size_t workspace_bytes, int B, int T, int F, int Cin, int Cout) {
     if (!y) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_wgrad_bn: y is required"); return A2S_ERR_ARG; }
-    return a2s_conv3x3_wgrad_impl(ST, g, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, y, mean, invstd, scale, shift, c12, dy_out, nullptr);
+    return a2s_conv3x3_wgrad_impl(ST, g, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, y, mean, invstd, scale, shift, c12, dy_out, nullptr, nullptr);
 }
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) { return a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout); }
 

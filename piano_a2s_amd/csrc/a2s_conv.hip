@@ -969,6 +969,21 @@ __global__ void bn1d_relu_dropout(const float* __restrict__ x, float* __restrict
     }
 }
 
+// out[0] = max_c (|scale_c| absmax_c + |shift_c|): a hard bound of relu(x scale_c + shift_c) over the tensor, given the per-channel
+// max |x_c| its producer wrote (a2s_conv3x3_ranged) -- the operand range of the kernels that read the activated tensor on the fly
+__global__ void act_bound_kernel(const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ absmax, int C, float* __restrict__ out) {
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) m = fmaxf(m, fabsf(scale[c]) * absmax[c] + fabsf(shift[c]));
+    m = wave_max(m);
+    if (threadIdx.x == 0) *out = m;
+}
+int a2s_act_bound_impl(hipStream_t st, const float* scale, const float* shift, const float* absmax, int C, float* out) {
+    A2S_REQUIRE(scale && shift && absmax && out && C > 0, "act_bound: null tensor");
+    hipLaunchKernelGGL(act_bound_kernel, dim3(1), dim3(64), 0, st, scale, shift, absmax, C, out);
+    A2S_CHECK_LAUNCH("act_bound");
+    return A2S_OK;
+}
+
 // ------------------------------------------------------------------------------------------- launchers
 static int g_conv_bf16x3 = 3;         // convolutions on the bf16 matrix pipes with 3-term split operands (conv3x3_split<.., 3>): bit 0 forward, bit 1 data-gradient launches
 void a2s_conv_bf16x3_set(int on) { g_conv_bf16x3 = on; }
@@ -1611,7 +1626,7 @@ template <int COUT, int TERMS>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                                                               float* __restrict__ partial, int B, int T, int F, int Cin,
-                                                              const float* __restrict__ dy_absmax) {
+                                                              const float* __restrict__ dy_absmax, const float* __restrict__ act_absmax) {
     constexpr int MT = (COUT + 15) / 16;
     constexpr int XPL = 48 * W4_XCI;          // bytes per term plane of the input image (48 channel planes; beyond Cin they stay zero)
     constexpr int DPL = MT * 16 * W4_DYCO;
@@ -1628,9 +1643,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split(const float* __res
         const int kd = pow2_scale_exp(*dy_absmax, 12);
         dscale = ldexpf(1.f, kd); unscale = ldexpf(1.f, -kd);
     }
+    // act_absmax: device scalar bounding the activated operand relu(x scale_c + shift_c) (a2s_act_bound).  Its power-of-two scale is
+    // folded into scale / shift (relu commutes with it) and undone with the slab: the operand's fp16 terms neither overflow nor sink
+    // into the subnormal range whatever BatchNorm's gamma is.  Without it the operand is used as it is (and clamped at +-65000).
+    int ka = 0;
+    if (TERMS == 2 && act_absmax && in_scale) {
+        ka = pow2_scale_exp(*act_absmax, 14);
+        unscale *= ldexpf(1.f, -ka);
+    }
     if (tid < 48) {
-        lsc[tid] = (in_scale && tid < Cin) ? in_scale[tid] : 0.f;
-        lsh[tid] = (in_scale && tid < Cin) ? in_shift[tid] : 0.f;
+        lsc[tid] = (in_scale && tid < Cin) ? ldexpf(in_scale[tid], ka) : 0.f;
+        lsh[tid] = (in_scale && tid < Cin) ? ldexpf(in_shift[tid], ka) : 0.f;
     }
     f32x4 acc[4][MT];
 #pragma unroll
@@ -1894,7 +1917,7 @@ size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
 int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
                            float* ws, size_t ws_bytes, int B, int T, int F, int Cin, int Cout, const float* bn_y, const float* bn_mean,
                            const float* bn_invstd, const float* bn_scale, const float* bn_shift, const float* bn_c12, float* dy_out,
-                           const float* dy_absmax) {
+                           const float* dy_absmax, const float* act_absmax) {
     A2S_REQUIRE(dy && x && dW && ws, "conv3x3_wgrad: null tensor");
     A2S_REQUIRE(!bn_y || (bn_mean && bn_invstd && bn_scale && bn_shift && bn_c12), "conv3x3_wgrad: the fused BatchNorm backward needs all of its tensors");
     A2S_REQUIRE(!dy_out || bn_y, "conv3x3_wgrad: dy_out is only written by the fused BatchNorm backward");
@@ -1918,10 +1941,10 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
     if (g_wgrad_split && !bn_y && Cin > 1 && Cin <= 40 && (Cout == 20 || Cout == 40) && split_here) {
         const int nslabs = 256;               // one 512-thread workgroup per CU
         A2S_REQUIRE(ws_bytes >= (size_t)nslabs * Cout * Cin * 9 * sizeof(float), "conv3x3_wgrad: workspace too small for the split-operand kernel");
-        if (two && Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_split<20, 2>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, dy_absmax);
-        else if (two) hipLaunchKernelGGL((conv3x3_wgrad_split<40, 2>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, dy_absmax);
-        else if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_split<20, 3>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, (const float*)nullptr);
-        else hipLaunchKernelGGL((conv3x3_wgrad_split<40, 3>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, (const float*)nullptr);
+        if (two && Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_split<20, 2>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, dy_absmax, act_absmax);
+        else if (two) hipLaunchKernelGGL((conv3x3_wgrad_split<40, 2>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, dy_absmax, act_absmax);
+        else if (Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_split<20, 3>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, (const float*)nullptr, (const float*)nullptr);
+        else hipLaunchKernelGGL((conv3x3_wgrad_split<40, 3>), dim3(nslabs), dim3(512), 0, st, dy, x, in_scale, in_shift, ws, B, T, F, Cin, (const float*)nullptr, (const float*)nullptr);
         A2S_CHECK_LAUNCH("conv3x3_wgrad_split");
         hipLaunchKernelGGL(wgrad_reduce_c1, dim3(a2s_cdiv(Cout * Cin * 9, 256)), dim3(256), 0, st, ws, dW, nslabs, Cout * Cin * 9);
         A2S_CHECK_LAUNCH("wgrad_reduce_c1");

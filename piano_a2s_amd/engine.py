@@ -294,6 +294,9 @@ class Engine:
             saved["y"].append(y)
             saved["bn"].append((mean, invstd, scale, shift))
             saved["yabs"].append(yabs_out)
+            # device scalar bounding relu(bn_i(y_i)) over the tensor: operand range of the kernels that re-form it on the fly (this layer's
+            # consumers in the backward pass -- weight gradient of layer i + 1 --, the 19200 -> 256 Linear)
+            saved.setdefault("abound", []).append(hip.act_bound(scale, shift, yabs_out))
             x, yabs = y, yabs_out
         # the (B*T, 40*F) operand of the 19200->256 Linear is relu(bn4(y4)): formed while the GEMM stages its A tiles (column k belongs
         # to channel k // F), never written to memory (A2S_MATERIALIZE_A4=1: the separate bn_relu_apply pass, for A/B measurements)
@@ -306,9 +309,9 @@ class Engine:
             z = hip.linear(a4, S["convstack.out.weight"])
         else:
             a4 = None
-            # two-term fp16 split: the activations are O(1) and used as they are, the weights get a power-of-two scale from max|W|
+            # two-term fp16 split: activations scaled by the power of two of their bound, the weights by that of max|W|
             saved["w_out_amax"] = hip.absmax(S["convstack.out.weight"])
-            z = hip.linear(y4, S["convstack.out.weight"], x_affine=(scale, shift, F), two_term=(None, saved["w_out_amax"]))
+            z = hip.linear(y4, S["convstack.out.weight"], x_affine=(scale, shift, F), two_term=(saved["abound"][3], saved["w_out_amax"]))
         rows = B * T
         rpb = 64
         nblk = (rows + rpb - 1) // rpb

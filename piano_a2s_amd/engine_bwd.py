@@ -39,7 +39,7 @@ def _colsum(x, ld, out, rows, ncol, x_off=0, out_off=0, beta=1.0):
                                     hip.f32(1.0), hip.f32(beta), hip._p(ws), C.c_size_t(ws.numel() if ws is not None else 0)), "a2s_col_sum")
 
 
-def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0, x_affine=None, dy_amax=None):
+def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0, x_affine=None, dy_amax=None, x_bound=None):
     """y = x W^T + b  (x (M,K) contiguous, W (N,K)):  dW += dy^T x ; db += colsum(dy) ; dx (+)= dy W.
     x_affine = (scale, shift, period): the layer's input was max(0, x*scale[k // period] + shift[k // period]) formed on the fly
     (hip.linear) -- the weight gradient re-forms it the same way while staging x.  dy_amax: device scalar max|dy| -- the weight
@@ -47,7 +47,7 @@ def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0, x_affine=None, 
     M, K = x.shape
     N = W.shape[0]
     sk = hip.lib().a2s_gemm_pick_splitk(N, K, M, 1)
-    hip.gemm(dy, 1, N, x, K, 1, G[wname], K, N, K, M, beta=1.0, splitk=sk, b_affine=x_affine, two_term=(dy_amax, None) if dy_amax is not None else None)
+    hip.gemm(dy, 1, N, x, K, 1, G[wname], K, N, K, M, beta=1.0, splitk=sk, b_affine=x_affine, two_term=(dy_amax, x_bound) if dy_amax is not None else None)
     if bname is not None:
         _colsum(dy, N, G[bname], M, N)
     if dx is not None:
@@ -561,7 +561,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         y4 = cs["y"][3].view(rows, 40 * F)
         da = torch.empty_like(y4)
         bn4 = cs["bn"][3]
-        _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax)
+        _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
         if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             nblk = L.a2s_gemm_bnstats_blocks(rows, F)
@@ -600,9 +600,8 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         dy_amax = torch.zeros(1, dtype=torch.float32, device=dev) if (i > 1 and not eng.sync_bn) else None
         if eng.sync_bn or not fuse_here:
             dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F, partial=g_partial, amax=dy_amax)
-            hip.check(L.a2s_conv3x3_wgrad_scaled(hip.stream(), hip._p(dy), hip._p(x_in), hip._p(in_bn[2]) if in_bn else NULL, hip._p(in_bn[3]) if in_bn else NULL,
-                                                 hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb), B, T, F, ci, co, hip._p(dy_amax)),
-                      "a2s_conv3x3_wgrad")
+            hip.conv3x3_wgrad(dy, x_in.view(B, T, ci, F), in_bn[2] if in_bn else None, in_bn[3] if in_bn else None, G[f"convstack.conv{i}.weight"], ws,
+                              dy_amax, cs["abound"][i - 2] if in_bn else None)
         else:
             # BatchNorm backward: statistics pass only; dy = scale (g' - c1 - xhat c2) is formed by the weight-gradient kernel while
             # it stages its dy operand (MFMA-bound, HBM to spare) and written out for the data-gradient convolution below

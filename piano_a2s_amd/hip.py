@@ -191,22 +191,40 @@ def conv3x3_dgrad_for_test(dy, w, yl):
     return dx
 
 
+def act_bound(scale, shift, x_absmax):
+    """Device scalar bounding relu(x * scale[c] + shift[c]) over the tensor, from the per-channel max |x| its producer wrote."""
+    out = torch.empty(1, dtype=torch.float32, device=scale.device)
+    check(lib().a2s_act_bound(stream(), _p(scale), _p(shift), _p(x_absmax), scale.numel(), _p(out)), "a2s_act_bound")
+    return out
+
+
+def conv3x3_wgrad(dy, x, scale, shift, dW, ws, dy_absmax, act_absmax):
+    """dW += weight gradient of a 3x3 layer from dy (B, T, Cout, F) and the layer input relu(x * scale + shift) (scale None: x as it is);
+    dy_absmax / act_absmax: device scalars max |dy| / bound of the activated input (None: unknown -> that operand unscaled)."""
+    B, T, Cout, F = dy.shape
+    Cin = x.shape[2]
+    check(lib().a2s_conv3x3_wgrad_ranged(stream(), _p(dy), _p(x), _p(scale), _p(shift), _p(dW), _p(ws), C.c_size_t(ws.numel() * 4), B, T, F, Cin, Cout,
+                                          _p(dy_absmax), _p(act_absmax)), "a2s_conv3x3_wgrad_ranged")
+
+
 def conv3x3_wgrad_for_test(dy, x, scale, shift):
-    """Weight gradient as engine_bwd issues it: dW (Cout, Cin, 3, 3) from dy (B, T, Cout, F) and the layer input relu(x * scale + shift)."""
+    """Weight gradient as engine_bwd issues it: dW (Cout, Cin, 3, 3) from dy (B, T, Cout, F) and the layer input relu(x * scale + shift),
+    with both operand ranges (max |dy|; the activation bound from the input's per-channel max)."""
     L = lib()
     B, T, Cout, F = dy.shape
     Cin = x.shape[2]
     dev = dy.device
     dW = torch.zeros(Cout, Cin, 3, 3, device=dev)
-    nb = L.a2s_conv3x3_wgrad_workspace_bytes(Cin, Cout)
-    ws = torch.empty(nb // 4, device=dev)
-    amax = absmax(dy)
-    check(L.a2s_conv3x3_wgrad_scaled(stream(), _p(dy), _p(x), _p(scale), _p(shift), _p(dW), _p(ws), C.c_size_t(nb), B, T, F, Cin, Cout, _p(amax)),
-          "a2s_conv3x3_wgrad_scaled")
+    ws = torch.empty(L.a2s_conv3x3_wgrad_workspace_bytes(Cin, Cout) // 4, device=dev)
+    bound = act_bound(scale, shift, x.abs().amax(dim=(0, 1, 3)).contiguous())
+    conv3x3_wgrad(dy, x, scale, shift, dW, ws, absmax(dy), bound)
     torch.cuda.synchronize()
     return dW
 
 
 def linear_forward_for_test(x, w, aff):
-    """The 19200 -> 256 Linear's forward as engine.convstack issues it (operand BatchNorm+ReLU while staging, two-term split)."""
-    return linear(x, w, x_affine=aff, two_term=(None, absmax(w)))
+    """The 19200 -> 256 Linear's forward as engine.convstack issues it (operand BatchNorm+ReLU while staging, two-term split with the
+    activation bound and max |w| as operand ranges)."""
+    period = aff[2]
+    xmax = x.view(x.shape[0], -1, period).abs().amax(dim=(0, 2)).contiguous()
+    return linear(x, w, x_affine=aff, two_term=(act_bound(aff[0], aff[1], xmax), absmax(w)))

@@ -20,3 +20,23 @@ def test_two_ranks_equal_one_process_on_the_whole_minibatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_check.py")], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ranks identical: max |p0 - p1| = 0.000e+00" in r.stdout, r.stdout[-1000:]
+
+
+def test_bench_launches_its_own_rank_through_torchrun():
+    """`python bench.py --launcher` (the N = 1 form of what `--gpus N` does without a launcher environment): torch.distributed.run child,
+    RCCL world of one, rank 0's JSON line relayed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--launcher", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--master-port", "29641",
+                        "--no-cpu-baseline", "--no-secondary", "--no-inference", "--no-straggler-sim"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0 and "data_parallel" in out
