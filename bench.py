@@ -434,10 +434,13 @@ def main():
         timed.launches0 = a2s_hip.lib().a2s_launch_count()
         t0 = time.time()
         marks[0].record()
+        segs = [torch.cuda.memory_stats().get("segment.all.allocated", 0)]
         for i in range(steps):
             step(batches[i % len(batches)], TF_RATIO)
             decode_steps.append(step.decode_steps)
             marks[i + 1].record()
+            segs.append(torch.cuda.memory_stats().get("segment.all.allocated", 0))
+        timed.new_segments = [b - a for a, b in zip(segs[:-1], segs[1:])]
         torch.cuda.synchronize()
         timed.step_ms = [round(a.elapsed_time(b), 1) for a, b in zip(marks[:-1], marks[1:])]
         if use_dist:
@@ -454,6 +457,7 @@ def main():
     elapsed, decode_steps = timed(batches, args.warmup, args.steps)
     launches_per_step = round((a2s_hip.lib().a2s_launch_count() - timed.launches0) / args.steps)
     main_step_ms = list(timed.step_ms)
+    main_new_segments = list(timed.new_segments)
     loss = float(step.total)
     groups = step._last[2] if step._last else None
     # data-parallel straggler terms: decode steps each rank executed per optimizer step, and how long each rank's stream
@@ -489,7 +493,7 @@ def main():
                                      "holding full-length bars decoded as a concurrent clip group (loss, gradients and update identical "
                                      "to the per-bar loop over the whole minibatch)",
                           "clip_groups": groups, "decode_steps_per_step": round(sum(decode_steps) / max(len(decode_steps), 1), 1),
-                          "step_ms": main_step_ms,
+                          "step_ms": main_step_ms, "hipMalloc_segments_per_step": main_new_segments,
                           "allocator": {"hipMalloc_calls": torch.cuda.memory_stats().get("segment.all.allocated", 0),
                                         "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0),
                                         "reserved_peak_GiB": round(torch.cuda.memory_stats().get("reserved_bytes.all.peak", 0) / 2 ** 30, 1)},

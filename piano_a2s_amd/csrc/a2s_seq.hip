@@ -716,23 +716,31 @@ __device__ __forceinline__ void attn_combine_row(const volatile float* pb, int G
     }
     __syncthreads();
     float acc0 = 0.f, acc1 = 0.f;
-    for (int g0 = 0; g0 < G; g0 += 8) {
-        float p0[8], p1[8];
+    for (int g0 = 0; g0 < G; g0 += 16) {              // (G <= 16 by default: every partial of the row in flight together)
+        float p0[16], p1[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const bool ok = g0 + u < G;
             p0[u] = ok ? pb[(long)(g0 + u) * PS + 4 + tid] : 0.f;
             p1[u] = ok ? pb[(long)(g0 + u) * PS + 4 + 256 + tid] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { acc0 = fmaf(p0[u], wgt[g0 + u], acc0); acc1 = fmaf(p1[u], wgt[g0 + u], acc1); }
+        for (int u = 0; u < 16; ++u) { acc0 = fmaf(p0[u], wgt[g0 + u], acc0); acc1 = fmaf(p1[u], wgt[g0 + u], acc1); }
     }
     o.ctx[tid] = acc0; o.ctx[256 + tid] = acc1;
     if (o.ctx2) { o.ctx2[tid] = acc0; o.ctx2[256 + tid] = acc1; }
     if (o.attw) {
         const float m = wgt[79], inv = wgt[78];
         volatile float* aw = o.attw;                  // raw scores written by the clip's other workgroups
-        for (int t = tid; t < o.T; t += 256) aw[t] = __expf(aw[t] - m) * inv;
+        // all of a thread's scores in flight together (T = 1201: 5 per thread): one memory round trip instead of one per score -- this
+        // kernel sits on every decode chain, and under the other streams' traffic a round trip costs microseconds
+        for (int t0 = tid; t0 < o.T; t0 += 8 * 256) {
+            float sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] = (t0 + 256 * u < o.T) ? aw[t0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (t0 + 256 * u < o.T) aw[t0 + 256 * u] = __expf(sv[u] - m) * inv;
+        }
     }
 }
 __device__ __forceinline__ void attn_zero_row(const AttnCombineOut& o) {       // skipped row: a finite, well-defined context (zeros)
