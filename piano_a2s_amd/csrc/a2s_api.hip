@@ -21,6 +21,8 @@ int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const floa
                      const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*);
 void a2s_conv_rows_set(int);
 int a2s_conv_rows_enabled(void);
+void a2s_wgrad_rows_set(int);
+int a2s_wgrad_rows_enabled(void);
 void a2s_conv_f16x2_set(int);
 int a2s_conv_f16x2_enabled(void);
 size_t a2s_conv3x3_workspace_floats_impl(int);
@@ -155,6 +157,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_rows")) { a2s_conv_rows_set(value); return A2S_OK; }
+    if (!strcmp(key, "wgrad_rows")) { a2s_wgrad_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_f16x2")) { a2s_conv_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_f16x2")) { a2s_wgrad_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_bf16x3")) { a2s_gemm_split_set(value); return A2S_OK; }
@@ -167,6 +170,7 @@ int a2s_debug_set(const char* key, int value) {
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
+    if (key && !strcmp(key, "wgrad_rows")) return a2s_wgrad_rows_enabled();
     if (key && !strcmp(key, "conv_f16x2")) return a2s_conv_f16x2_enabled();
     if (key && !strcmp(key, "wgrad_f16x2")) return a2s_wgrad_f16x2_enabled();
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();

@@ -179,8 +179,10 @@ __device__ __forceinline__ void split2_pair_f16(float x0, float x1, unsigned& p0
     f32x2 v = {x0, x1};
     const f16x2 t0 = __builtin_convertvector(v, f16x2);              // v_cvt_f16_f32: round to nearest even
     p0 = __builtin_bit_cast(unsigned, t0);
-    const f32x2 b = __builtin_convertvector(t0, f32x2);
-    v[0] -= b[0]; v[1] -= b[1];
+    // x - t0 with the fp16 -> fp32 extension riding on the operand (one instruction per element instead of convert + subtract; the
+    // compiler does not form it from fpext + fsub)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v[0]) : "v"(p0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v[1]) : "v"(p0));
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 // Fold a workgroup's running max |x| (am >= 0, per thread) into a device scalar: one candidate per workgroup, and the atomic only when

@@ -1909,6 +1909,10 @@ int a2s_wgrad_f16x2_enabled(void) {
     return g_wgrad_f16x2;
 }
 
+bool a2s_wgrad_rows_eligible(int F, int Cin, int Cout);
+int a2s_conv3x3_wgrad_rows_impl(hipStream_t st, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* ws,
+                                size_t ws_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax, const float* act_absmax);
+
 size_t a2s_conv3x3_wgrad_workspace_bytes_impl(int Cin, int Cout) {
     const int chunks = (Cin + CV_CK - 1) / CV_CK;
     return (size_t)chunks * 1024 * Cout * CV_CK * 9 * sizeof(float);
@@ -1934,6 +1938,9 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
         }
     }
     const bool two = a2s_wgrad_f16x2_enabled() && dy_absmax;          // two fp16 terms: with the operand's max |dy| only
+    // round 3: the row-streaming kernel (a2s_conv_wrows.hip) wherever its operand ranges are known
+    if (two && !bn_y && a2s_wgrad_rows_eligible(F, Cin, Cout) && (!in_scale || act_absmax))
+        return a2s_conv3x3_wgrad_rows_impl(st, dy, x, in_scale, in_shift, dW, ws, ws_bytes, B, T, F, Cin, Cout, dy_absmax, act_absmax);
     // measured at B = 64 (tools/conv_f16x2_check.py; fp32-input kernel / three bf16 terms / two fp16 terms): 40 -> 40: 12.3 / 9.9 / 7.1 ms,
     // 20 -> 40: 6.3 / 7.4 / 5.3 ms, 20 -> 20: 4.6 / 6.2 / 4.6 ms -- the three-term kernel only pays off at 40 -> 40 channels, the two-term
     // one for 40 output channels (wgrad_bf16x3 = 2 / wgrad_f16x2 = 2: every eligible launch regardless)
