@@ -401,7 +401,7 @@ def main():
     random.seed(1234 + (rank if COIN_POLICY == "rank_offset" else 0))      # teacher-forcing coins (COIN_POLICY above)
     from piano_a2s_amd import build as a2s_build
     build_info = dict(a2s_build.info(), lib=os.path.relpath(a2s_build.LIB, ROOT), stale_vs_sources=bool(a2s_build.needs_build()),
-                      note="last piano_a2s_amd.build.build() of the shipped .so; __graft_entry__.build() forces a from-scratch compile of all 8 .hip sources")
+                      note="last piano_a2s_amd.build.build() of the shipped .so; __graft_entry__.build() forces a from-scratch compile of every .hip source")
 
     import models
     from piano_a2s_amd import spec, synthetic, train

@@ -1,5 +1,5 @@
 """The row-streaming weight gradient (csrc/a2s_conv_wrows.hip) against float64 on small and ragged shapes, then its launch duration at
-the training shapes next to round 2's kernels (`wgrad_rows` = 0).  usage: python tools/wgrad_rows_check.py [B] [--no-check] [--no-time]"""
+the training shapes next to round 2's kernels (`wgrad_rows` = 0).  usage: python tools/wgrad_rows_check.py [B] [--no-check] [--no-time] | --trace (library built with -DWR_TRACE)"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ from piano_a2s_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 L = hip.lib()
-ROWS = int(os.environ.get("WGRAD_ROWS", str(L.a2s_debug_get(b"wgrad_rows"))))      # 1: one wave per SIMD, 2: role-split (multiply / staging waves)
+ROWS = 1
 
 
 def check():
@@ -82,7 +82,28 @@ def bench(B):
         del x, dy
 
 
+def trace(B):
+    """(library built with -DWR_TRACE) share of its time each role's lead wave waits in the per-row barrier"""
+    T, F = 1201, 480
+    for ci, co in ((40, 40), (20, 40), (20, 20)):
+        x = torch.randn(B, T, ci, F, device=dev)
+        dy = torch.randn(B, T, co, F, device=dev) * 1e-4
+        scale, shift = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+        dW = torch.zeros(co, ci, 3, 3, device=dev)
+        ws = torch.zeros(L.a2s_conv3x3_wgrad_workspace_bytes(ci, co) // 4, device=dev)
+        hip.check(L.a2s_debug_set(b"wgrad_rows", 1), "set")
+        hip.conv3x3_wgrad(dy, x, scale, shift, dW, ws, hip.absmax(dy), hip.act_bound(scale, shift, x.abs().amax(dim=(0, 1, 3)).contiguous()))
+        torch.cuda.synchronize()
+        n = min(256, B * 4) * co * ci * 9
+        tr = ws[n:n + 256 * 8].view(torch.int64).view(256, 2, 2).double().cpu()
+        print(f"{ci}->{co}: multiply wave waits {100 * float((tr[:, 0, 0] / tr[:, 0, 1]).mean()):.1f} % of {float(tr[:, 0, 1].mean()) / 1201:.0f} ticks per row; "
+              f"staging wave waits {100 * float((tr[:, 1, 0] / tr[:, 1, 1]).mean()):.1f} %", flush=True)
+
+
 if __name__ == "__main__":
+    if "--trace" in sys.argv:
+        trace(64)
+        sys.exit(0)
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     if "--no-check" not in sys.argv:
         check()
