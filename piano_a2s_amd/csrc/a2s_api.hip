@@ -23,6 +23,8 @@ void a2s_conv_rows_set(int);
 int a2s_conv_rows_enabled(void);
 void a2s_wgrad_rows_set(int);
 int a2s_wgrad_rows_enabled(void);
+void a2s_staff_emb_fast_set(int);
+int a2s_staff_emb_fast_enabled(void);
 void a2s_conv_f16x2_set(int);
 int a2s_conv_f16x2_enabled(void);
 size_t a2s_conv3x3_workspace_floats_impl(int);
@@ -158,6 +160,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_rows")) { a2s_conv_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_rows")) { a2s_wgrad_rows_set(value); return A2S_OK; }
+    if (!strcmp(key, "staff_emb_fast")) { a2s_staff_emb_fast_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_f16x2")) { a2s_conv_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_f16x2")) { a2s_wgrad_f16x2_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_bf16x3")) { a2s_gemm_split_set(value); return A2S_OK; }
@@ -171,6 +174,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
     if (key && !strcmp(key, "wgrad_rows")) return a2s_wgrad_rows_enabled();
+    if (key && !strcmp(key, "staff_emb_fast")) return a2s_staff_emb_fast_enabled();
     if (key && !strcmp(key, "conv_f16x2")) return a2s_conv_f16x2_enabled();
     if (key && !strcmp(key, "wgrad_f16x2")) return a2s_wgrad_f16x2_enabled();
     if (key && !strcmp(key, "gemm_bf16x3")) return a2s_gemm_split_enabled();

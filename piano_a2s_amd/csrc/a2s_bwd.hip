@@ -558,12 +558,141 @@ __global__ __launch_bounds__(128) void staff_emb_bwd(const float* __restrict__ n
     for (int i = tid; i < 3 * S; i += nt) { atomicAdd(gb1 + i, gbi[i]); atomicAdd(gb2 + i, gbh[i]); }
 }
 
+// BPTT for the model's sizes (E = 16, S = 32), 192 threads, nothing but vectors in LDS (the generic kernel above spends 10 us per step
+// of a <= 398-step chain: 16- / 32-way bank conflicts on W[r * E + k] with r = thread, and 4608 read-modify-writes of the weight-gradient
+// images in LDS per step).  Thread r < 96 owns row r of W_ih AND of its gradient (16 + 16 registers), thread 96 + r row r of W_hh and of
+// its gradient (32 + 32): the recomputed pre-activation and the rank-1 gradient update of a row are register arithmetic on operands
+// broadcast from LDS.  For the transposed products (dx = W_ih^T dgi, dh_prev += W_hh^T dgh) every thread also holds a quarter of a
+// COLUMN (24 registers): thread = (output k of 48, quarter of the 96 rows), the four partials meet in LDS.  The embedding row and
+// h_{s-2} of the next step are in flight during the current one.  Four barriers per step.
+int a2s_staff_emb_fast_enabled(void);
+__global__ __launch_bounds__(192) void staff_emb_bwd_e16s32(const float* __restrict__ note_emb, const float* __restrict__ w_ih_f,
+                                                            const float* __restrict__ w_hh_f, const float* __restrict__ b_ih_f,
+                                                            const float* __restrict__ b_hh_f, const float* __restrict__ w_ih_r,
+                                                            const float* __restrict__ w_hh_r, const float* __restrict__ b_ih_r,
+                                                            const float* __restrict__ b_hh_r, float* const* __restrict__ grads /* 8 */,
+                                                            float* __restrict__ note_emb_grad, const long long* __restrict__ ids64,
+                                                            const int* __restrict__ ids32, long id_bstride, const long long* __restrict__ lengths,
+                                                            long len_stride, const float* __restrict__ dout, long lddo, int col0,
+                                                            const float* __restrict__ hsave, int maxlen) {
+    constexpr int E = 16, S = 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xe = sm;                        // 16  x_s
+    float* hp = xe + E;                    // 32  h_{s-1}
+    float* g = hp + S;                     // 192 gi | gh, then the 4 x 48 partials of the transposed products
+    float* dgi = g + 6 * S;                // 96
+    float* dgh = dgi + 3 * S;              // 96
+    int* lid = reinterpret_cast<int*>(dgh + 3 * S);    // maxlen
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const float* w_ih = dir ? w_ih_r : w_ih_f; const float* w_hh = dir ? w_hh_r : w_hh_f;
+    const bool gi_role = tid < 3 * S;
+    const int r = gi_role ? tid : tid - 3 * S;
+    float w[S], gw[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) { w[k] = gi_role ? (k < E ? w_ih[r * E + k] : 0.f) : w_hh[r * S + k]; gw[k] = 0.f; }
+    const float bias = gi_role ? (dir ? b_ih_r : b_ih_f)[r] : (dir ? b_hh_r : b_hh_f)[r];
+    float gbias = 0.f;
+    // transposed products: output k = tid % 48 (k < 16: dx[k] from W_ih / dgi; else dh_prev[k - 16] from W_hh / dgh), rows 24 q .. 24 q + 23
+    const int tk = tid % 48, tq = tid / 48;
+    float wc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) wc[i] = tk < E ? w_ih[(24 * tq + i) * E + tk] : w_hh[(24 * tq + i) * S + tk - E];
+    const float* dgsrc = (tk < E ? dgi : dgh) + 24 * tq;
+    int len = (int)lengths[(long)b * len_stride];
+    len = max(0, min(len, maxlen));
+    for (int i = tid; i < len; i += 192) {
+        const int t = dir ? len - 1 - i : i;
+        lid[i] = ids64 ? (int)ids64[(long)b * id_bstride + t] : ids32[(long)b * id_bstride + t];
+    }
+    float dh = tid < S ? dout[(long)b * lddo + col0 + dir * S + tid] : 0.f;      // thread j < 32: dh[j]
+    __syncthreads();
+    const float* hrow = hsave + ((long)b * 2 + dir) * maxlen * S;
+    float xe_n = 0.f, hp_n = 0.f;
+    if (len > 0) {
+        if (tid < E) xe_n = note_emb[(long)lid[len - 1] * E + tid];
+        if (tid < S && len > 1) hp_n = hrow[(long)(len - 2) * S + tid];
+    }
+    for (int s = len - 1; s >= 0; --s) {
+        const long id = lid[s];
+        if (tid < E) xe[tid] = xe_n;
+        if (tid < S) hp[tid] = hp_n;
+        const float hp_own = hp_n;                          // thread j < 32: h_{s-1}[j]
+        if (s > 0) {                                         // the next step's operands: in flight during this step's arithmetic
+            if (tid < E) xe_n = note_emb[(long)lid[s - 1] * E + tid];
+            if (tid < S) hp_n = s > 1 ? hrow[(long)(s - 2) * S + tid] : 0.f;
+        }
+        __syncthreads();                                     // (A) x_s, h_{s-1} staged
+        f32x4 op[S / 4];                                     // this role's operand vector (x_s: 4 quads, h_{s-1}: 8), kept for the rank-1 update
+        float acc = bias;
+#pragma unroll
+        for (int k4 = 0; k4 < S / 4; ++k4) {
+            if (gi_role && k4 >= E / 4) { op[k4] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
+            op[k4] = gi_role ? reinterpret_cast<const f32x4*>(xe)[k4] : reinterpret_cast<const f32x4*>(hp)[k4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = fmaf(w[4 * k4 + c], op[k4][c], acc);
+        }
+        g[tid] = acc;
+        __syncthreads();                                     // (B) pre-activations
+        if (tid < S) {
+            const float rg = fast_sigmoid(g[tid] + g[3 * S + tid]);
+            const float zg = fast_sigmoid(g[S + tid] + g[4 * S + tid]);
+            const float ghn = g[5 * S + tid];
+            const float ng = fast_tanh(g[2 * S + tid] + rg * ghn);
+            const float d = dh;
+            const float dn = d * (1.f - zg) * (1.f - ng * ng);
+            const float dz = d * (hp_own - ng) * zg * (1.f - zg);
+            const float dr = dn * ghn * rg * (1.f - rg);
+            dgi[tid] = dr; dgi[S + tid] = dz; dgi[2 * S + tid] = dn;
+            dgh[tid] = dr; dgh[S + tid] = dz; dgh[2 * S + tid] = dn * rg;
+            dh = d * zg;                                     // direct path; the recurrent path is added below
+        }
+        __syncthreads();                                     // (C) dgi, dgh
+        {
+            const float dg = gi_role ? dgi[r] : dgh[r];      // rank-1 update of this thread's gradient row
+            gbias += dg;
+#pragma unroll
+            for (int k4 = 0; k4 < S / 4; ++k4) {
+                if (gi_role && k4 >= E / 4) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gw[4 * k4 + c] = fmaf(dg, op[k4][c], gw[4 * k4 + c]);
+            }
+            float part = 0.f;                                // quarter of a transposed product
+#pragma unroll
+            for (int i4 = 0; i4 < 6; ++i4) {
+                const f32x4 d4 = reinterpret_cast<const f32x4*>(dgsrc)[i4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) part = fmaf(d4[c], wc[4 * i4 + c], part);
+            }
+            g[tid] = part;                                   // (g is free again after the gate math)
+        }
+        __syncthreads();                                     // (D) partials
+        if (tid < S) dh += (g[E + tid] + g[48 + E + tid]) + (g[96 + E + tid] + g[144 + E + tid]);
+        else if (tid >= 64 && tid < 64 + E) {
+            const int k = tid - 64;
+            atomicAdd(note_emb_grad + id * E + k, (g[k] + g[48 + k]) + (g[96 + k] + g[144 + k]));
+        }
+    }
+    float* gwt = grads[dir * 4 + (gi_role ? 0 : 1)];
+    float* gbt = grads[dir * 4 + (gi_role ? 2 : 3)];
+    const int ncol = gi_role ? E : S;
+#pragma unroll
+    for (int k = 0; k < S; ++k) if (k < ncol) atomicAdd(gwt + r * ncol + k, gw[k]);
+    atomicAdd(gbt + r, gbias);
+}
+
 int a2s_staff_emb_bwd_impl(hipStream_t st, const float* note_emb, const float* const* w, float* const* grads_dev, float* note_emb_grad,
                            const long long* ids64, const int* ids32, long id_bstride, const long long* lengths, long len_stride,
                            const float* dout, long lddo, int col0, const float* hsave, int R, int maxlen, int E, int S) {
     A2S_REQUIRE((ids64 != nullptr) != (ids32 != nullptr), "staff_emb_bwd: exactly one of ids64/ids32");
     A2S_REQUIRE(hsave && grads_dev && note_emb_grad && dout, "staff_emb_bwd: null tensor");
     A2S_REQUIRE(E <= 5 * S && E + S <= 128, "staff_emb_bwd: note_emb_size <= 5 * staff_emb_size and note_emb_size + staff_emb_size <= 128 expected");
+    if (E == 16 && S == 32 && a2s_staff_emb_fast_enabled()) {
+        const size_t shm16 = sizeof(float) * (E + S + 6 * S + 6 * S) + sizeof(int) * (size_t)maxlen;
+        hipLaunchKernelGGL(staff_emb_bwd_e16s32, dim3(R, 2), dim3(192), shm16, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
+                           grads_dev, note_emb_grad, ids64, ids32, id_bstride, lengths, len_stride, dout, lddo, col0, hsave, maxlen);
+        A2S_CHECK_LAUNCH("staff_emb_bwd_e16s32");
+        return A2S_OK;
+    }
     const size_t shm = sizeof(float) * (2 * (3 * S * E + 3 * S * S) + 4 * 3 * S + E + S + 6 * S + 6 * S + S) + sizeof(int) * (size_t)maxlen;
     hipLaunchKernelGGL(staff_emb_bwd, dim3(R, 2), dim3(128), shm, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
                        grads_dev, note_emb_grad, ids64, ids32, id_bstride, lengths, len_stride, dout, lddo, col0, hsave, maxlen, E, S);

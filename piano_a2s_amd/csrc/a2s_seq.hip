@@ -629,6 +629,12 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
 }
 
 // ------------------------------------------------------------------------------------------- staff embedding
+static int g_staff_emb_fast = -1;       // the E = 16, S = 32 kernels (A2S_STAFF_EMB_FAST=0 / a2s_debug_set("staff_emb_fast", 0): the generic ones)
+void a2s_staff_emb_fast_set(int v) { g_staff_emb_fast = v ? 1 : 0; }
+int a2s_staff_emb_fast_enabled(void) {
+    if (g_staff_emb_fast < 0) { const char* e = getenv("A2S_STAFF_EMB_FAST"); g_staff_emb_fast = (e && e[0] == '0') ? 0 : 1; }
+    return g_staff_emb_fast;
+}
 // reference get_staff_token_* (models.py:164-189): packed bi-GRU (E -> S) final states.  One workgroup per
 // (row, direction); the 3S x (E+S) weights live in LDS and the whole (<= 398 step) recurrence runs in-kernel.
 // ids come as int32 (argmax buffer) or int64 (ground truth).  Saves per-step h for the backward pass.
@@ -684,10 +690,89 @@ __global__ __launch_bounds__(128) void staff_emb_fwd(const float* __restrict__ n
     for (int i = tid; i < S; i += blockDim.x) out[(long)b * ldo + col0 + dir * S + i] = h[i];
 }
 
+// The same recurrence for the model's sizes (E = 16, S = 32), 192 threads: thread r < 96 owns row r of W_ih (16 registers), thread
+// 96 + r row r of W_hh (32 registers) -- the weights never pass through LDS (the generic kernel reads W[r * E + k] with r = thread:
+// a 16- or 32-way bank conflict on every load, 3.9 us per step of a <= 398-step chain) --, the token ids of the row sit in LDS, the
+// embedding row of step s + 1 is fetched while step s computes, x_s and h broadcast from LDS as 16-byte reads.  Two barriers per step.
+__global__ __launch_bounds__(192) void staff_emb_fwd_e16s32(const float* __restrict__ note_emb, const float* __restrict__ w_ih_f,
+                                                            const float* __restrict__ w_hh_f, const float* __restrict__ b_ih_f,
+                                                            const float* __restrict__ b_hh_f, const float* __restrict__ w_ih_r,
+                                                            const float* __restrict__ w_hh_r, const float* __restrict__ b_ih_r,
+                                                            const float* __restrict__ b_hh_r, const long long* __restrict__ ids64,
+                                                            const int* __restrict__ ids32, long id_bstride,
+                                                            const long long* __restrict__ lengths, long len_stride,
+                                                            float* __restrict__ out, long ldo, int col0, float* __restrict__ hsave, int maxlen) {
+    constexpr int E = 16, S = 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xe = sm;                        // 16
+    float* hb = xe + E;                    // 32
+    float* g = hb + S;                     // 192: gi | gh
+    int* lid = reinterpret_cast<int*>(g + 6 * S);      // maxlen
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const bool gi_role = tid < 3 * S;
+    const int r = gi_role ? tid : tid - 3 * S;
+    const float* wsrc = gi_role ? (dir ? w_ih_r : w_ih_f) + r * E : (dir ? w_hh_r : w_hh_f) + r * S;
+    float w[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) w[k] = (gi_role && k >= E) ? 0.f : wsrc[k];
+    const float bias = gi_role ? (dir ? b_ih_r : b_ih_f)[r] : (dir ? b_hh_r : b_hh_f)[r];
+    int len = (int)lengths[(long)b * len_stride];
+    len = max(0, min(len, maxlen));
+    for (int i = tid; i < len; i += 192) {
+        const int t = dir ? len - 1 - i : i;
+        lid[i] = ids64 ? (int)ids64[(long)b * id_bstride + t] : ids32[(long)b * id_bstride + t];
+    }
+    if (tid < S) hb[tid] = 0.f;
+    float h = 0.f;                          // thread j < 32: h[j]
+    __syncthreads();
+    float xe_n = (tid < E && len > 0) ? note_emb[(long)lid[0] * E + tid] : 0.f;
+    for (int s = 0; s < len; ++s) {
+        if (tid < E) {
+            xe[tid] = xe_n;
+            if (s + 1 < len) xe_n = note_emb[(long)lid[s + 1] * E + tid];
+        }
+        __syncthreads();                    // x_s and h_{s-1} are in LDS
+        float acc = bias;
+        if (gi_role) {
+#pragma unroll
+            for (int k4 = 0; k4 < E / 4; ++k4) {
+                const f32x4 x4 = reinterpret_cast<const f32x4*>(xe)[k4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = fmaf(w[4 * k4 + c], x4[c], acc);
+            }
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < S / 4; ++k4) {
+                const f32x4 h4 = reinterpret_cast<const f32x4*>(hb)[k4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = fmaf(w[4 * k4 + c], h4[c], acc);
+            }
+        }
+        g[tid] = acc;
+        __syncthreads();
+        if (tid < S) {
+            const float rg = fast_sigmoid(g[tid] + g[3 * S + tid]);
+            const float zg = fast_sigmoid(g[S + tid] + g[4 * S + tid]);
+            const float ng = fast_tanh(g[2 * S + tid] + rg * g[5 * S + tid]);
+            h = (1.f - zg) * ng + zg * h;
+            hb[tid] = h;
+            if (hsave) hsave[(((long)b * 2 + dir) * maxlen + s) * S + tid] = h;
+        }
+    }
+    if (tid < S) out[(long)b * ldo + col0 + dir * S + tid] = h;
+}
+
 int a2s_staff_emb_fwd_impl(hipStream_t st, const float* note_emb, const float* const* w /* 8 GRU tensors f then r */,
                            const long long* ids64, const int* ids32, long id_bstride, const long long* lengths,
                            long len_stride, float* out, long ldo, int col0, float* hsave, int R, int maxlen, int E, int S) {
     A2S_REQUIRE((ids64 != nullptr) != (ids32 != nullptr), "staff_emb_fwd: exactly one of ids64/ids32");
+    if (E == 16 && S == 32 && a2s_staff_emb_fast_enabled()) {
+        const size_t shm16 = sizeof(float) * (E + S + 6 * S) + sizeof(int) * (size_t)maxlen;
+        hipLaunchKernelGGL(staff_emb_fwd_e16s32, dim3(R, 2), dim3(192), shm16, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
+                           ids64, ids32, id_bstride, lengths, len_stride, out, ldo, col0, hsave, maxlen);
+        A2S_CHECK_LAUNCH("staff_emb_fwd_e16s32");
+        return A2S_OK;
+    }
     const size_t shm = sizeof(float) * (3 * S * E + 3 * S * S + 6 * S + S + E + 6 * S);
     hipLaunchKernelGGL(staff_emb_fwd, dim3(R, 2), dim3(128), shm, st, note_emb, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7],
                        ids64, ids32, id_bstride, lengths, len_stride, out, ldo, col0, hsave, maxlen, E, S);

@@ -205,6 +205,9 @@ def plan_clip_groups(until_up, until_lo, max_tail_frac=0.5, min_gain=0.08, step_
         c = max(ct, cm, wt + wm)
         if c < best:
             best_k, best = k, c
+    extra = int(_os.environ.get("A2S_GROUP_EXTRA", "0"))          # measurement switch: that many more of the longest clips join the long group
+    if best_k is not None and extra > 0:
+        best_k = min(best_k + extra, B - 1)
     if best_k is None:
         return ident, B
     return np.concatenate([np.sort(by_len[best_k:]), np.sort(by_len[:best_k])]), B - best_k

@@ -50,11 +50,40 @@ def main():
     wrap(engine_bwd, "_convstack_bwd", "convstack bwd")
     wrap(engine_bwd, "backward", "backward tail")
     wrap(train.Objective, "__call__", "loss")
+    # per clip group: when its decoder forward starts, when its backward starts (= its forward has been issued) and ends, on the group's
+    # own stream, relative to the start of the step
+    gmarks = []
+
+    def gmark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                                   # on the calling thread's current stream
+        gmarks.append((name, e))
+
+    orig_rcg = engine.run_clip_groups
+
+    def rcg(device, fns):
+        def timed(g, fn):
+            def f():
+                gmark(f"group {g} decoder forward starts")
+                r = fn()
+                gmark(f"group {g} done")
+                return r
+            return f
+        return orig_rcg(device, [timed(g, fn) for g, fn in enumerate(fns)])
+    engine.run_clip_groups = rcg
+    orig_dg = engine_bwd.Backward.decoder_group
+
+    def dg(self, gidx, *args):
+        gmark(f"group {gidx} decoder backward starts")
+        return orig_dg(self, gidx, *args)
+    engine_bwd.Backward.decoder_group = dg
+    gtot = {}
     totals = {}
     import time
     walls = []
     for k in range(a.steps + 1):
         marks.clear()
+        gmarks.clear()
         mark("start")
         t0 = time.time()
         step(b, 0.7, rng=random.Random(100 + k))
@@ -63,12 +92,16 @@ def main():
         walls.append((time.time() - t0) * 1e3)
         if k == 0:
             continue
+        for n, e in list(gmarks):
+            gtot.setdefault(n, []).append(marks[0][1].elapsed_time(e))
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
             name = n1 if not n1.startswith("before ") else {"before encoder bwd": "decoder bwd", "before convstack bwd": "encoder->conv glue"}.get(n1, "(gap) " + n1)
             totals[name] = totals.get(name, 0.0) + e0.elapsed_time(e1)
     tot = sum(totals.values())
     for n, t in totals.items():
         print(f"{t / a.steps:9.1f} ms  {100 * t / tot:5.1f} %  {n}")
+    for n, t in sorted(gtot.items(), key=lambda kv: sorted(kv[1])[len(kv[1]) // 2]):
+        print(f"{sorted(t)[len(t) // 2]:9.1f} ms after the start of the step (median; per step " + " ".join(f"{x:.0f}" for x in t) + f"): {n}")
     print("wall ms per step (host clock, first = warm-up):", " ".join(f"{w:.0f}" for w in walls), " groups:", step._last[2])
     print(f"{tot / a.steps:9.1f} ms  total  -> {a.batch / (tot / a.steps) * 1e3:.1f} clips/s")
 

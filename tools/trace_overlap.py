@@ -60,3 +60,37 @@ for q, v in sorted(queues.items()):
     for k in v:
         tot[k[0]] = tot.get(k[0], 0.0) + k[2] - k[1]
     print("    " + ", ".join(f"{n[:28]} {t / 1e3:.0f}" for n, t in sorted(tot.items(), key=lambda kv: -kv[1])[:8]))
+
+# ---- a window of the long-clip queue in the middle of its backward chain and of its forward chain (what runs between two steps?)
+for label, seq in (("backward", bs), ("forward", gs)):
+    if len(seq) < 200:
+        continue
+    mid = seq[len(seq) // 2]
+    i0 = g1.index(mid)
+    print(f"\n{label} chain, 36 consecutive kernels on queue {q1} (start us relative to the first, duration, stream, kernel):")
+    for k in g1[i0:i0 + 36]:
+        print(f"  {k[1] - mid[1]:9.1f} {k[2] - k[1]:7.1f}  s{k[4]}  {k[0][:60]}")
+
+# ---- the bulk group's chains (note_step_finalize is issued by the library-path decode step only): a window of each queue carrying them
+fin = [k for k in K if k[0].startswith("note_step_finalize")]
+for q in sorted(set(k[3] for k in fin)):
+    v = queues[q]
+    fq = [k for k in fin if k[3] == q]
+    if len(fq) < 100:
+        continue
+    mid = fq[len(fq) // 3]
+    i0 = v.index(mid)
+    print(f"\nbulk group, forward, queue {q}: 30 consecutive kernels (start us relative to the first, duration, stream, kernel):")
+    for k in v[i0:i0 + 30]:
+        print(f"  {k[1] - mid[1]:9.1f} {k[2] - k[1]:7.1f}  s{k[4]}  {k[0][:70]}")
+gb = [k for k in K if k[0].startswith("gru_gates_bwd") and k[3] != q1]
+for q in sorted(set(k[3] for k in gb)):
+    v = queues[q]
+    fq = [k for k in gb if k[3] == q]
+    if len(fq) < 100:
+        continue
+    mid = fq[len(fq) // 3]
+    i0 = v.index(mid)
+    print(f"\nbulk group, backward, queue {q}: 30 consecutive kernels:")
+    for k in v[i0:i0 + 30]:
+        print(f"  {k[1] - mid[1]:9.1f} {k[2] - k[1]:7.1f}  s{k[4]}  {k[0][:70]}")
