@@ -55,6 +55,17 @@ def _linear_bwd(x, W, dy, G, wname, bname, dx=None, dx_beta=0.0, x_affine=None, 
     return dx
 
 
+_ONES = {}
+
+
+def _one(dev):
+    """Device scalar 1.0: the range of an operand bounded by 1 (softmax weights, GRU states) for the two-term fp16 products."""
+    key = torch.device(dev).index
+    if key not in _ONES:
+        _ONES[key] = torch.ones(1, dtype=torch.float32, device=dev)
+    return _ONES[key]
+
+
 def _staff_token_bwd(eng, S, G, rec, dtok):
     """Backward of one _staff_token call; dtok: (R, >= col0+2S) gradient buffer holding the token gradient."""
     L = hip.lib()
@@ -77,7 +88,9 @@ def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_a
     The per-step tensors hold groups*B rows per step, row = group*B + clip (fused bars): (step, group) is one flat reduction index."""
     L = hip.lib()
     # dEnc[b] += sum_{s,g} a_sg[b,:]^T dctx_sg[b,:]   -- batched over clips: (T x steps*groups)(steps*groups x 2H)
-    hip.gemm(attw_all, 1, B * T, dctx_all, B * 2 * H, 1, dEnc, 2 * H, T, 2 * H, steps * groups, beta=1.0, batch=B, bsA=T, bsB=2 * H, bsC=T * 2 * H)
+    # (operand ranges for the two-term fp16 product: softmax weights <= 1, max |dctx| measured; K = steps * groups < 256 runs fp32-input)
+    hip.gemm(attw_all, 1, B * T, dctx_all, B * 2 * H, 1, dEnc, 2 * H, T, 2 * H, steps * groups, beta=1.0, batch=B, bsA=T, bsB=2 * H, bsC=T * 2 * H,
+             two_term=(_one(enc.device), hip.absmax(dctx_all)) if dctx_all.is_contiguous() else None)
     nblk = L.a2s_attn_dk_blocks(B, T)
     dvp = torch.empty((nblk, H), dtype=torch.float32, device=enc.device)
     hip.check(L.a2s_attn_dk_accum(hip.stream(), hip._p(keys), hip._p(q_all), hip._p(ds_all), hip._p(S[prefix + ".v.weight"]), hip._p(dK),
@@ -85,7 +98,7 @@ def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_a
     _colsum(dvp, H, G[prefix + ".v.weight"], nblk, H)
 
 
-def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T, deferred=None):
+def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T, deferred=None, enc_amax=None):
     """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (rows, 2H); rows = groups * n_clips.
     deferred: optional HIP stream for everything that does not gate the recurrence (weight gradients, the deferred key / encoder-
     output gradients, embedding scatter): a staff's stream executes in order, so leaving them on it would put ~20 % of MFMA-bound GEMM
@@ -132,14 +145,22 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) everything nobody in the recurrence waits for
     def deferred_work():
-        _linear_bwd(o2d, Wo, dlog2d, G, prefix + ".out.weight", prefix + ".out.bias")               # dW_out += dlog^T o ; db_out += colsum
+        # Operand ranges of the weight-gradient products (two-term fp16 split): the GRU state lies in (-1, 1), the
+        # context is a convex combination of encoder rows, the token half of x an embedding row; the gradients' max magnitudes are measured.
+        one = _one(dev)
+        xb = torch.maximum(hip.absmax(S[prefix + ".embedding.weight"]), enc_amax) if enc_amax is not None else None
+        ob = torch.maximum(one, enc_amax) if enc_amax is not None else None
+        am = (lambda t: hip.absmax(t)) if enc_amax is not None else (lambda t: None)
+        _linear_bwd(o2d, Wo, dlog2d, G, prefix + ".out.weight", prefix + ".out.bias", dy_amax=am(dlog), x_bound=ob)       # dW_out += dlog^T o ; db_out += colsum
         x2d, h2d = sv["x"][:n].view(R, ldx), sv["h"][:n].view(R, H2)
-        _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_all.view(R, 3 * H2), G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0")
-        _linear_bwd(h2d, S[prefix + ".gru.weight_hh_l0"], dgh_all.view(R, 3 * H2), G, prefix + ".gru.weight_hh_l0", prefix + ".gru.bias_hh_l0")
+        _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_all.view(R, 3 * H2), G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0",
+                    dy_amax=am(dgi_all), x_bound=xb)
+        _linear_bwd(h2d, S[prefix + ".gru.weight_hh_l0"], dgh_all.view(R, 3 * H2), G, prefix + ".gru.weight_hh_l0", prefix + ".gru.bias_hh_l0",
+                    dy_amax=am(dgh_all), x_bound=one)
         # attention query half: dW[:, :2H] += dq^T h ; db += colsum(dq)
         Gw = G[prefix + ".attn.attn.weight"]
         sk = L.a2s_gemm_pick_splitk(H, H2, R, 1)
-        hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk)
+        hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk, two_term=(hip.absmax(dq_all), one) if enc_amax is not None else None)
         _colsum(dq_all, H, G[prefix + ".attn.attn.bias"], R, H)
         _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, n_clips, T, H, n, sv.get("active"), groups)
         # embedding rows of the tokens consumed at each step: <sos> at step 0, then gt or argmax of the previous step
@@ -212,6 +233,9 @@ class Backward:
         # hardware queues the runtime has (engine.group_stream) -- off by default since the clip groups need a queue (A2S_DEFER_STREAM=1)
         self.use_deferred = self.concurrent and os.environ.get("A2S_DEFER_STREAM", "0") == "1"
         self.clip_groups = list(clip_groups) if clip_groups else [(0, B)]
+        # the deferred products of the decoder backward (weight gradients, key / encoder-output gradients) with measured operand ranges on
+        # the two-term fp16 split instead of three bf16 terms (A2S_BWD_TWO_TERM=0: as in round 2)
+        self.two_term = os.environ.get("A2S_BWD_TWO_TERM", "1") != "0"
         self.d_hidden = torch.empty((B, H2), dtype=torch.float32, device=dev)       # gradient wrt the encoder's bridge output (initial bar-level hidden)
         self.group_flat = [self.flat] + [torch.zeros_like(self.flat) for _ in self.clip_groups[1:]]
         self.group_ptrs = [self.G["__staff_emb_ptrs__"]]
@@ -239,6 +263,7 @@ class Backward:
         Gg = G if gidx == 0 else {k: group_flat[gidx][off:off + S[k].numel()].view(S[k].shape) for k, off in zip(names, offs)}
         Gg["__staff_emb_ptrs__"] = group_ptrs[gidx]
         enc_g, keys_g = gs["enc"], gs["keys"]
+        enc_amax_g = hip.absmax(enc_g) if (self.two_term and enc_g.is_contiguous()) else None      # max |enc| of the group's clips
         dEnc_g = dEnc[b0:b1]
         dK_g = {p: t[b0:b1] for p, t in dK.items()}
         dEnc_staff_g = [t[b0:b1] for t in dEnc_staff]
@@ -262,7 +287,7 @@ class Backward:
                 else:
                     dpr, pr = dout[:, bar0], out_t[:, bar0]
                 calls.append((eng, S, Gg, seg["staff"][name][2], keys_g[prefix], enc_g, dpr, pr, dK_g[prefix], dEnc_staff_g[si], Bg, T,
-                              deferred_streams[si] if use_deferred_g else None))
+                              deferred_streams[si] if use_deferred_g else None, enc_amax_g))
             if concurrent_g:    # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
                 res, events = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
                 seg_dh0[si_seg] = ([r[0] for r in res], events)
@@ -276,6 +301,7 @@ class Backward:
         for si_seg in reversed(range(len(gs["segments"]))):
             segment_decoders_bwd(si_seg)
 
+        bar_attn = []               # (q, ds, attention weights, dctx) of every bar: their key / encoder-output gradients in ONE call below
         d_hid_carry = None          # gradient wrt the bar-level hidden after bar k, coming from bar k+1
         d_token_next = None         # gradient wrt the (pre-dropout) token that bar k produced for bar k+1
         for bar in reversed(range(bars)):
@@ -333,13 +359,15 @@ class Backward:
             hip.gemm(dq, H, 1, Wa, 4 * H, 1, dhp, H2, Bg, H2, H, beta=1.0)                              # d hprev += dq W_h
             hip.gemm(dq, 1, H, b["hprev"], H2, 1, Gg["decoder.attn.attn.weight"], 4 * H, H, H2, Bg, beta=1.0)   # dW_h += dq^T hprev
             _colsum(dq, H, Gg["decoder.attn.attn.bias"], Bg, H)
-            _attn_deferred(eng, S, Gg, "decoder.attn", keys_g["decoder"], enc_g, b["qb"].view(1, Bg, H), ds, b["attw"].view(1, Bg, T), dctx,
-                           dK_g["decoder"], dEnc_g, Bg, T, H, 1)
+            bar_attn.append((b["qb"].view(1, Bg, H), ds, b["attw"].view(1, Bg, T), dctx))
             d_hid_carry = dhp
             d_token = d_xbar[:, :tokw].contiguous()
             if b["keep"] is not None:
                 d_token = d_token * b["keep"] / 0.9
             d_token_next = d_token
+        # the bars' key / encoder-output gradients: one K = bars product per clip instead of `bars` rank-1 updates of the (T, 2H) gradient
+        qs, dss, aws, dcs = [torch.cat(t, 0) for t in zip(*bar_attn)]
+        _attn_deferred(eng, S, Gg, "decoder.attn", keys_g["decoder"], enc_g, qs, dss, aws, dcs, dK_g["decoder"], dEnc_g, Bg, T, H, len(bar_attn))
         # ---- initial token: <sos>/<eos> staff token (used for both staves) + time-signature / key <sos> rows
         d_sos = d_token_next.clone()
         d_sos[:, :2 * Sz] += d_sos[:, 2 * Sz:4 * Sz]
@@ -372,11 +400,15 @@ class Backward:
             dEnc.add_(self.dEnc_staff[0]).add_(self.dEnc_staff[1])
         # ---- attention keys: K = enc W_e^T  ->  dW_e += dK^T enc ; dEnc += dK W_e
         enc2d = enc.view(B * T, H2)
+        enc_amax = hip.absmax(enc) if self.two_term else None
         for p, dKp in dK.items():
             Wn = p + ".attn.attn.weight"
             sk = L.a2s_gemm_pick_splitk(H, H2, B * T, 1)
-            hip.gemm(dKp, 1, H, enc2d, H2, 1, G[Wn], 4 * H, H, H2, B * T, beta=1.0, splitk=sk, c_off=H2)
-            hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2)
+            dk_amax = hip.absmax(dKp) if self.two_term else None
+            hip.gemm(dKp, 1, H, enc2d, H2, 1, G[Wn], 4 * H, H, H2, B * T, beta=1.0, splitk=sk, c_off=H2,
+                     two_term=(dk_amax, enc_amax) if self.two_term else None)
+            hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2,
+                     two_term=(dk_amax, hip.absmax(S[Wn])) if self.two_term else None)
         d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T)
         n_conv = next(off for k, off in zip(names, offs) if not k.startswith("convstack."))      # state_dict order: convstack first
         if grad_ready is not None:
