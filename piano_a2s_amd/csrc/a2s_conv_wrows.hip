@@ -38,7 +38,7 @@
 #define WR_SLABS 256
 #ifndef WR_X
 // ablation bits (timing only, results are wrong): 1 no MFMA, 4 no df shifts, 8 no conversion arithmetic, 16 no global loads,
-// 32 all loads from row 0 (cache-resident), 64 staging waves idle
+// 32 all loads from row 0 (cache-resident), 64 staging waves idle, 128 no neighbour reads (the shifts use the lane's own window)
 #define WR_X 0
 #endif
 #ifndef WR_SCHED2
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
                         for (int tm = 0; tm < 2; ++tm) {
                             const unsigned char* p = bsrc[j] + tm * bts[j] + ks * 64;
                             r.v[j][tm] = *reinterpret_cast<const u32x4*>(p);
-                            r.wb[j][tm] = *reinterpret_cast<const unsigned*>(p - 4);          // positions p - 2, p - 1
-                            r.wa[j][tm] = *reinterpret_cast<const unsigned*>(p + 16);         // positions p + 8, p + 9
+                            r.wb[j][tm] = (WR_X & 128) ? r.v[j][tm][0] : *reinterpret_cast<const unsigned*>(p - 4);          // positions p - 2, p - 1
+                            r.wa[j][tm] = (WR_X & 128) ? r.v[j][tm][3] : *reinterpret_cast<const unsigned*>(p + 16);         // positions p + 8, p + 9
                         }
                 };
                 auto compute = [&](const Raw& r) {

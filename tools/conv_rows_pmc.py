@@ -1,6 +1,7 @@
 """Three launches of each row-streaming convolution at the training shapes (for rocprofv3 --pmc passes): conv4 forward (40 -> 40,
 conv3x3_rows16), conv3 forward (20 -> 40, rows16), conv2 forward (20 -> 20, conv3x3_rows), conv4 data gradient with the
-BatchNorm-backward statistics epilogue.  usage: python tools/conv_rows_pmc.py [B]"""
+BatchNorm-backward statistics epilogue, and the row-streaming weight gradients (conv3x3_wgrad_rows 40 -> 40, 20 -> 40, 20 -> 20).
+usage: python tools/conv_rows_pmc.py [B]"""
 import os
 import sys
 
@@ -33,3 +34,15 @@ for ci, co, flip in ((40, 40, 0), (20, 40, 0), (20, 20, 0), (40, 40, 1)):
             hip.conv3x3_forward(x, w, y, scale, shift, partial, cws, in_amax, out_amax)
     torch.cuda.synchronize()
     del x, y, yl
+for ci, co in ((40, 40), (20, 40), (20, 20)):
+    x = torch.randn(B, T, ci, F, device=dev)
+    dy = torch.randn(B, T, co, F, device=dev) * 1e-4
+    scale, shift = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+    dW = torch.zeros(co, ci, 3, 3, device=dev)
+    ws = torch.empty(L.a2s_conv3x3_wgrad_workspace_bytes(ci, co) // 4, device=dev)
+    bound = hip.act_bound(scale, shift, x.abs().amax(dim=(0, 1, 3)).contiguous())
+    dmax = hip.absmax(dy)
+    for _ in range(3):
+        hip.conv3x3_wgrad(dy, x, scale, shift, dW, ws, dmax, bound)
+    torch.cuda.synchronize()
+    del x, dy
