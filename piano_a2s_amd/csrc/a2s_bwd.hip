@@ -807,6 +807,7 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
 }
 
 // Fused bars (see attn_fwd_split256_mq): NQ rows of one clip per workgroup, the clip's enc and K chunk streamed once for all of them.
+#define ATT_DCS 516             // floats per row of the dctx image in LDS (2H + 4: the rows of a clip land 4 banks apart)
 template <int NQ>
 __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                             const float* __restrict__ q, long ldq, const float* __restrict__ v,
@@ -829,67 +830,83 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     for (int j = 0; j < NQ; ++j) on[j] = !row_until || step < row_until[j * n_clips + b];
     const float* Kb = Kmat + ((long)b * T + t0) * H;
     const float* Eb = enc + ((long)b * T + t0) * 2 * H;
-    f32x4 dc0[NQ], dc1[NQ];
-    float dot_ctx[NQ];
+    // dctx of the clip's rows (dctx_a + dctx_b) -> LDS as the B operand of pass A, their dot products with the saved contexts beside them
+    float* dcT = reinterpret_cast<float*>(red4 + NQ * 3 * 64);            // NQ x ATT_DCS floats
+    float* dots = dcT + NQ * ATT_DCS;                                      // 16
+    int onmask = 0;
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        dc0[j] = dc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dot_ctx[j] = 0.f;
-        if (!on[j]) continue;
-        const long row = (long)j * n_clips + b;
-        dc0[j] = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + lane * 4);
-        dc1[j] = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + H + lane * 4);
-        if (dctx_b) {
-            const f32x4 o0 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + lane * 4);
-            const f32x4 o1 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + H + lane * 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { dc0[j][c] += o0[c]; dc1[j][c] += o1[c]; }
-        }
-        if (dctx_out && g == 0 && wave == 0) {
-            *reinterpret_cast<f32x4*>(dctx_out + row * lddo + lane * 4) = dc0[j];
-            *reinterpret_cast<f32x4*>(dctx_out + row * lddo + H + lane * 4) = dc1[j];
-        }
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + lane * 4);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + H + lane * 4);
-        float d = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d += dc0[j][c] * c0[c] + dc1[j][c] * c1[c];
-        dot_ctx[j] = wave_sum(d);
-    }
-    // ---- pass A: da_t = dctx_j . enc_t, one wave per frame, 4 frames in flight
-    for (int r = wave * 4; r < n; r += 16) {
-        f32x4 e0[4], e1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (r + u < n) {
-                e0[u] = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + lane * 4);
-                e1[u] = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + H + lane * 4);
-            } else { e0[u] = e1[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        }
+    for (int j = 0; j < NQ; ++j) onmask |= on[j] ? (1 << j) : 0;
+    if (wave == 0) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            if (!on[j]) continue;
-            float sj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                sj[u] = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) sj[u] += dc0[j][c] * e0[u][c] + dc1[j][c] * e1[u][c];
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) sj[u] += __shfl_xor(sj[u], o, 64);
-            }
-            if (lane == 0) {
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            float dot = 0.f;
+            if (on[j]) {
                 const long row = (long)j * n_clips + b;
+                d0 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + lane * 4);
+                d1 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + H + lane * 4);
+                if (dctx_b) {
+                    const f32x4 o0 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + lane * 4);
+                    const f32x4 o1 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + H + lane * 4);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (r + u < n) {
-                        const float d_s = attw[row * T + t0 + r + u] * (sj[u] - dot_ctx[j]);
-                        dsv[j * chunk + r + u] = d_s;
-                        if (ds_out) ds_out[row * T + t0 + r + u] = d_s;
+                    for (int c = 0; c < 4; ++c) { d0[c] += o0[c]; d1[c] += o1[c]; }
+                }
+                if (dctx_out && g == 0) {
+                    *reinterpret_cast<f32x4*>(dctx_out + row * lddo + lane * 4) = d0;
+                    *reinterpret_cast<f32x4*>(dctx_out + row * lddo + H + lane * 4) = d1;
+                }
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + lane * 4);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + H + lane * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dot += d0[c] * c0[c] + d1[c] * c1[c];
+                dot = wave_sum(dot);
+            }
+            *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + lane * 4) = d0;
+            *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + H + lane * 4) = d1;
+            if (lane == 0) dots[j] = dot;
+        }
+    }
+    __syncthreads();
+    // ---- pass A: da[t][j] = enc_t . dctx_j on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation): a wave
+    // takes 16 frames, lane (i, g) feeds frame i's columns 32 u + 8 g .. + 7 as the A operand and row min(i, NQ - 1) of dctx at the same
+    // columns as the B operand -- 128 MFMAs per 32 KB of enc instead of 8 FMAs + a 6-step cross-lane reduction per lane, frame and row
+    // (with 2-5 rows per clip that arithmetic, not HBM, set the launch time: 4.5 / 3.1 TB/s at 2 / 5 rows against 5.4 at one).
+    {
+        const int li = lane & 15, lg = lane >> 4;
+        const float* brow = dcT + min(li, NQ - 1) * ATT_DCS + 8 * lg;
+        const float dotn = dots[min(li, NQ - 1)];
+        const bool mine = li < NQ && ((onmask >> li) & 1);
+        const long arow = ((long)min(li, NQ - 1) * n_clips + b) * T + t0;
+        for (int blk = wave; blk * 16 < n; blk += 4) {
+            const int fr = blk * 16 + li;
+            const bool valid = fr < n;
+            const float* ep = Eb + (long)min(fr, n - 1) * 2 * H + 8 * lg;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};       // two chains: a dependent 16x16x4 waits 40 cycles, an independent one 32
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) {
+                f32x4 e0 = *reinterpret_cast<const f32x4*>(ep + 32 * u);
+                f32x4 e1 = *reinterpret_cast<const f32x4*>(ep + 32 * u + 4);
+                if (!valid) e0 = e1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[c], b0[c], acc, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[c], b1[c], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+            // acc[r] = da[frame 16 blk + 4 lg + r][row li]
+            if (mine) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f2 = blk * 16 + 4 * lg + r;
+                    if (f2 < n) {
+                        const float d_s = attw[arow + f2] * (acc[r] - dotn);
+                        dsv[li * chunk + f2] = d_s;
+                        if (ds_out) ds_out[arow + f2] = d_s;
                     }
+                }
             }
         }
     }
@@ -1012,7 +1029,7 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
             hipLaunchKernelGGL(attn_bwd_split256, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
                                dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
         } else {
-            const size_t shm = ((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4) * sizeof(float);
+            const size_t shm = ((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4 + (size_t)groups * ATT_DCS + 16) * sizeof(float);
 #define A2S_BWD_MQ(N) launch_bwd_mq<N>(st, nwg, shm, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r)
             switch (groups) {
                 case 2: A2S_BWD_MQ(2); break;
