@@ -1015,6 +1015,7 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
                 "attn_step_bwd_split: 16-byte alignment");
     a2s_attn_rows r = {nullptr, nullptr, nullptr, B, B, 0};
     if (rows) r = *rows;
+    T = a2s_attn_fake_t(T, r.n_clips);
     A2S_REQUIRE(r.n_clips > 0 && B % r.n_clips == 0, "attn_step_bwd_split: rows (%d) must be a multiple of the clips (%d)", B, r.n_clips);
     const int groups = B / r.n_clips;
     A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_bwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);

@@ -61,6 +61,13 @@ static inline int a2s_attn_max_split(void) {
     if (!v) { const char* e = getenv("A2S_ATTN_MAX_SPLIT"); v = e ? atoi(e) : 16; if (v < 1) v = 16; }
     return v;
 }
+// measurement only (results are wrong): the split attention kernels of calls with more than 64 clips read this percentage of the frames --
+// predicts what a launch that moves fewer bytes would be worth to the training step
+static inline int a2s_attn_fake_t(int T, int n_clips) {
+    static int pct = -1;
+    if (pct < 0) { const char* e = getenv("A2S_ATTN_FAKE_T"); pct = e ? atoi(e) : 100; if (pct < 1 || pct > 100) pct = 100; }
+    return (pct == 100 || n_clips <= 64) ? T : ((T * pct / 100) & ~3);
+}
 static inline void a2s_attn_split_geometry(int B, int T, int* G, int* chunk) {
     const int target = a2s_attn_target_wgs();
     int g = (target + B - 1) / B;

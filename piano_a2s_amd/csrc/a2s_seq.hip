@@ -1155,6 +1155,7 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     A2S_REQUIRE(ldq % 4 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)Kmat % 16 == 0) && ((uintptr_t)enc % 16 == 0), "attn_step_fwd_split: 16-byte alignment");
     a2s_attn_rows r = {nullptr, nullptr, nullptr, B, B, 0};
     if (rows) r = *rows;
+    T = a2s_attn_fake_t(T, r.n_clips);
     A2S_REQUIRE(r.n_clips > 0 && B % r.n_clips == 0, "attn_step_fwd_split: rows (%d) must be a multiple of the clips (%d)", B, r.n_clips);
     const int groups = B / r.n_clips;
     A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_fwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);
