@@ -41,6 +41,9 @@
 // 32 all loads from row 0 (cache-resident), 64 staging waves idle, 128 no neighbour reads (the shifts use the lane's own window)
 #define WR_X 0
 #endif
+#ifndef WR_KD
+#define WR_KD 14              // exponent the largest |dz| is scaled to
+#endif
 #ifndef WR_SCHED2
 #define WR_SCHED2 1            // multiply waves: ask the scheduler for 3 MFMA : 1 LDS read : 2 VALU groups
 #endif
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
     const bool affine = a.in_scale != nullptr;                      // without: scale 1, shift 0 and no relu -- the same arithmetic, exact
     const float relu_floor = affine ? 0.f : -INFINITY;
     const int ka = (affine && a.act_absmax) ? pow2_scale_exp(*a.act_absmax, 14) : 0;
-    const int kd = a.dy_absmax ? pow2_scale_exp(*a.dy_absmax, 14) : 0;
+    const int kd = a.dy_absmax ? pow2_scale_exp(*a.dy_absmax, WR_KD) : 0;
     const float dscale = ldexpf(1.f, kd), unscale = ldexpf(1.f, -(ka + kd));
     if (tid < CIN) {
         tab[tid] = affine ? ldexpf(a.in_scale[tid], ka) : 1.f;

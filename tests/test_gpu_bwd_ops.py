@@ -500,3 +500,82 @@ def test_conv_weight_gradient_two_term_fp16(dev, ci, co, gmag):
         L.a2s_debug_set(b"wgrad_f16x2", 1)
     err = ((dW.cpu().double() - ref).abs() / mag).max().item()
     assert err < 2e-7, err
+
+
+def test_staff_embedding_kernels_for_the_model_sizes_match_the_generic_ones(dev):
+    """Round 3: for note_emb_size 16 / staff_emb_size 32 the staff-embedding recurrence runs on register-resident kernels (a2s_seq.hip
+    staff_emb_fwd_e16s32, a2s_bwd.hip staff_emb_bwd_e16s32).  Same calls through both implementations (switch `staff_emb_fast`) at the
+    model's real lengths: a full-length row (398), a one-token row, a zero-length row, duplicates among the ids."""
+    from piano_a2s_amd import hip, spec
+    L = hip.lib()
+    cfg = spec.default_cfg()
+    st = spec.procedural_state(cfg, 5)
+    P, _ = spec.split_state(st)
+    names = [f"decoder.staff_emb.{w}_{sfx}" for sfx in ("l0", "l0_reverse") for w in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    Sd = {k: v.to(dev) for k, v in P.items() if k in names or k == "decoder.note_emb.weight"}
+    E, S = cfg["note_emb_size"], cfg["staff_emb_size"]
+    assert (E, S) == (16, 32)
+    g = torch.Generator().manual_seed(9)
+    R, maxlen = 37, 398
+    ids = torch.randint(0, 40, (R, maxlen), generator=g).to(dev)
+    lengths = torch.randint(1, 200, (R,), generator=g)
+    lengths[0], lengths[1], lengths[2] = maxlen, 1, 0
+    lengths = lengths.to(dev)
+    dtok = torch.randn(R, 2 * S + 6, generator=g).to(dev)
+    warr = (C.c_void_p * 8)(*[Sd[n].data_ptr() for n in names])
+    res = {}
+    prev = L.a2s_debug_get(b"staff_emb_fast")
+    try:
+        for fast in (0, 1):
+            hip.check(L.a2s_debug_set(b"staff_emb_fast", fast), "set")
+            out = torch.zeros(R, 2 * S + 6, device=dev)
+            hsave = torch.zeros(R, 2, maxlen, S, device=dev)
+            hip.check(L.a2s_staff_emb_fwd(hip.stream(), hip._p(Sd["decoder.note_emb.weight"]), warr, hip._p(ids), NULL, C.c_long(maxlen), hip._p(lengths),
+                                          C.c_long(1), hip._p(out), C.c_long(out.stride(0)), 3, hip._p(hsave), R, maxlen, E, S), "fwd")
+            grads = [torch.zeros_like(Sd[n]) for n in names]
+            gptrs = torch.tensor([t.data_ptr() for t in grads], dtype=torch.int64, device=dev)
+            emb_grad = torch.zeros_like(Sd["decoder.note_emb.weight"])
+            hip.check(L.a2s_staff_emb_bwd(hip.stream(), hip._p(Sd["decoder.note_emb.weight"]), warr, hip._p(gptrs), hip._p(emb_grad), hip._p(ids), NULL,
+                                          C.c_long(maxlen), hip._p(lengths), C.c_long(1), hip._p(dtok), C.c_long(dtok.stride(0)), 3, hip._p(hsave), R, maxlen, E, S), "bwd")
+            torch.cuda.synchronize()
+            res[fast] = [out, hsave, emb_grad] + grads
+    finally:
+        L.a2s_debug_set(b"staff_emb_fast", prev)
+    assert torch.isfinite(res[1][0]).all()
+    worst = max(_rel(a, b) for a, b in zip(res[1], res[0]))
+    _report("staff_emb e16s32 vs generic", worst)
+    assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize("Cin,Cout", [(40, 40), (20, 40), (20, 20)])
+def test_row_streaming_weight_gradient_matches_the_tiled_kernels(dev, Cin, Cout):
+    """csrc/a2s_conv_wrows.hip against round 2's weight-gradient kernels (switch `wgrad_rows`) and float64: F not a multiple of the 128-column
+    strip, more work items than workgroups (the accumulators change sign between items), T = 1 and T = 2 clips' worth of halo rows.
+    The row kernel keeps ONE fp32 accumulator chain per (co, ci, tap) and workgroup over all of a strip's positions, the tiled kernels many
+    short ones: its error is that of a long fp32 sum (2-7e-7 of sum |dz||a|; independent of the operand scales: tools/wgrad_rows_check.py
+    with -DWR_KD=10 / 12 / 14 gives the same digits), hence the bar of 1e-6 and 8x the tiled kernels' error."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    g = torch.Generator().manual_seed(Cin + Cout)
+    worst = 0.0
+    for (B, T, F) in ((3, 17, 132), (280, 2, 260), (2, 1, 24)):
+        x = torch.randn(B, T, Cin, F, generator=g) * torch.exp(torch.randn(B, T, Cin, F, generator=g))
+        dy = 1e-4 * torch.randn(B, T, Cout, F, generator=g) * torch.exp(torch.randn(B, T, Cout, F, generator=g))
+        scale, shift = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+        a64 = torch.relu(x.double().permute(0, 2, 1, 3) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+        ref = torch.nn.grad.conv2d_weight(a64, (Cout, Cin, 3, 3), dy.double().permute(0, 2, 1, 3), padding=1)
+        mag = torch.nn.grad.conv2d_weight(a64.abs(), (Cout, Cin, 3, 3), dy.double().permute(0, 2, 1, 3).abs(), padding=1) + 1e-300
+        prev = L.a2s_debug_get(b"wgrad_rows")
+        errs = {}
+        try:
+            for rows in (1, 0):
+                hip.check(L.a2s_debug_set(b"wgrad_rows", rows), "set")
+                dW = hip.conv3x3_wgrad_for_test(dy.to(dev), x.to(dev), scale.to(dev), shift.to(dev)).cpu().double()
+                assert torch.isfinite(dW).all()
+                errs[rows] = float(((dW - ref).abs() / mag).max())
+        finally:
+            L.a2s_debug_set(b"wgrad_rows", prev)
+        _report(f"wgrad rows {Cin}->{Cout} B{B} T{T} F{F}: rows / tiled", errs[1])
+        assert errs[1] < 1e-6 and errs[1] <= 8 * errs[0] + 2e-7, (B, T, F, errs)
+        worst = max(worst, errs[1])
+    assert worst < 1e-6
