@@ -707,6 +707,13 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
     g.vecA = (akc ? (sAk == 1 && aligned(A, sAm, bsA)) : (sAm == 1 && aligned(A, sAk, bsA))) ? 1 : 0;
     g.vecB = (bkc ? (sBk == 1 && aligned(B, sBn, bsB)) : (sBn == 1 && aligned(B, sBk, bsB))) ? 1 : 0;
 
+    {
+        static int log_on = -1;           // A2S_GEMM_LOG=1: one line per large product (which tile path it takes); tools only
+        if (log_on < 0) { const char* e = getenv("A2S_GEMM_LOG"); log_on = e ? atoi(e) : 0; }
+        if (log_on && (long)M * N * K >= (1L << 30))
+            fprintf(stderr, "gemm M=%d N=%d K=%d batch=%d splitk=%d akc=%d bkc=%d two_term=%d big=%d ep=%d\n", M, N, K, batch, splitk, (int)akc, (int)bkc,
+                    two_term, (int)(!g_force_tile && big_two_term_ok(g, akc, bkc)), ep_y != nullptr);
+    }
     if (!g_force_tile && big_two_term_ok(g, akc, bkc)) launch_big_two_term(g, akc, bkc, st);
     else if (ep_y) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);
     else if (!g_force_tile && mid_tile == 2 && g.splitk >= 1 && M * (long)N < (1L << 22)) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);

@@ -40,6 +40,9 @@ import os as _os
 # than eager launches on MI355X (B=8: 0.232 s vs 0.212 s for 2223 steps) -- the step is bound by the GPU-side execution of ~13 small
 # kernels, not by host launch cost -- so it is opt-in.
 _GREEDY_GRAPH = _os.environ.get("A2S_GREEDY_GRAPH") == "1"
+# the encoder's input projections and the attention key images on the two-term fp16 split (operand ranges known: DESIGN.md section 5)
+# instead of three bf16 terms; A2S_ENC_TWO_TERM=0: as in round 2
+_ENC_TWO_TERM = _os.environ.get("A2S_ENC_TWO_TERM", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -340,7 +343,10 @@ class Engine:
         for layer in (0, 1):
             out = self._empty(B, T, 2 * H, dev=dev)
             lsave = {"in": inp, "dirs": []}
-            gis = [hip.linear(inp, S[f"encoder.gru.weight_ih_{sfx}"], S[f"encoder.gru.bias_ih_{sfx}"])      # (B*T, 3H) per direction
+            # input projections on the two-term fp16 split: layer 0 reads the ConvStack features (max measured), layer 1 GRU states (< 1)
+            in_amax = (hip.absmax(inp) if layer == 0 else hip.one(dev)) if _ENC_TWO_TERM else None
+            gis = [hip.linear(inp, S[f"encoder.gru.weight_ih_{sfx}"], S[f"encoder.gru.bias_ih_{sfx}"],
+                              two_term=(in_amax, hip.absmax(S[f"encoder.gru.weight_ih_{sfx}"])) if _ENC_TWO_TERM else None)      # (B*T, 3H) per direction
                    for sfx in (f"l{layer}", f"l{layer}_reverse")]
             def direction(d, sfx, gi):
                 hbuf = self._empty(2, B, H, dev=dev)
@@ -380,7 +386,9 @@ class Engine:
         attention kernels form tanh(K + q) as 1 - 2 / (1 + exp(2K) exp(2q)) -- see include/a2s.h."""
         W = S[prefix + ".attn.weight"]
         K = self._empty(enc2d.shape[0], H, dev=enc2d.device)
-        hip.gemm(enc2d, 2 * H, 1, W, 1, 4 * H, K, H, enc2d.shape[0], H, 2 * H, b_off=2 * H, act=3)
+        # (encoder outputs are GRU states, |enc| < 1; max |W| over the whole attention Linear bounds its key half)
+        hip.gemm(enc2d, 2 * H, 1, W, 1, 4 * H, K, H, enc2d.shape[0], H, 2 * H, b_off=2 * H, act=3,
+                 two_term=(hip.one(enc2d.device), hip.absmax(W)) if _ENC_TWO_TERM else None)
         return K
 
     def _staff_token(self, S, ids, lengths, len_stride, out, col0, maxlen, id_bstride, ids_are_i64, record=None):

@@ -484,6 +484,8 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
             dhn.append(d)
         _colsum(dpre, 2 * H, G["encoder.fc.bias"], B, H, x_off=l * H)
     gws = [hip.gemm_workspace(B, dev), hip.gemm_workspace(B, dev)]
+    two_term = os.environ.get("A2S_BWD_TWO_TERM", "1") != "0"
+    in_amax = hip.absmax(es["layers"][0]["in"]) if two_term else None        # max of the ConvStack features (layer 0's input)
     dout = dEnc                                              # gradient wrt layer-1 outputs (B,T,2H)
     for layer in (1, 0):
         ls = es["layers"][layer]
@@ -505,14 +507,17 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
             return (dgi, dghs, dgh_first, dhbuf, dgh_tmp)
 
         res = fork_on_streams(dev, streams, [lambda d=d, sfx=sfx: direction(d, sfx) for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse"))])()
+        dgi_amax = []
         # input gradient (what the next recurrence / the ConvStack needs) on the current stream ...
         for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
             dgi2 = res[d][0].view(B * T, 3 * H)
             Wih = S[f"encoder.gru.weight_ih_{sfx}"]
+            tt = (hip.absmax(dgi2), hip.absmax(Wih)) if two_term else None        # measured ranges: the two-term fp16 split
+            dgi_amax.append(tt[0] if tt else None)
             if L.a2s_debug_get(b"gemm_bf16x3") > 0:      # k-contiguous weight copy (<= 1.5 MB): both operands on the GEMM's split-operand path
-                hip.gemm(dgi2, 3 * H, 1, Wih.t().contiguous(), 1, 3 * H, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0)
+                hip.gemm(dgi2, 3 * H, 1, Wih.t().contiguous(), 1, 3 * H, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0, two_term=tt)
             else:
-                hip.gemm(dgi2, 3 * H, 1, Wih, I, 1, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0)
+                hip.gemm(dgi2, 3 * H, 1, Wih, I, 1, dX, I, B * T, I, 3 * H, beta=0.0 if d == 0 else 1.0, two_term=tt)
         # ... the weight gradients (MFMA-bound, nobody waits for them) on a third stream, under the next layer's latency-bound recurrence
         wg = _weight_grad_stream(dev)
         ev = torch.cuda.Event()
@@ -524,9 +529,11 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
                 t.record_stream(wg)
             with torch.cuda.stream(wg):
                 dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)
-                _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}")
+                _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}",
+                            dy_amax=dgi_amax[d], x_bound=(in_amax if layer == 0 else hip.one(dev)) if two_term else None)
                 sk = L.a2s_gemm_pick_splitk(3 * H, H, B * T, 1)
-                hip.gemm(dghs2, 1, 3 * H, out, 2 * H, 1, G[f"encoder.gru.weight_hh_{sfx}"], H, 3 * H, H, B * T, beta=1.0, splitk=sk, b_off=d * H)
+                hip.gemm(dghs2, 1, 3 * H, out, 2 * H, 1, G[f"encoder.gru.weight_hh_{sfx}"], H, 3 * H, H, B * T, beta=1.0, splitk=sk, b_off=d * H,
+                         two_term=(hip.absmax(dghs2), hip.one(dev)) if two_term else None)
                 _colsum(dghs2, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B * T, 3 * H)
                 _colsum(dgh_first, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B, 3 * H)
         dout = dX.view(B, T, I)

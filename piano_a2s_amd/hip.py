@@ -144,6 +144,17 @@ def gemm(A, sAm, sAk, B, sBk, sBn, Cout, ldc, M, N, K, alpha=1.0, beta=0.0, bias
                                 splitk, _p(ws), C.c_size_t(ws_bytes), _p(asc), _p(ash), ap, _p(bsc), _p(bsh), bp), "a2s_gemm_f32_affine")
 
 
+_ONES = {}
+
+
+def one(device):
+    """Device scalar 1.0: the range of an operand bounded by 1 (GRU states, softmax weights) for the two-term fp16 products."""
+    key = torch.device(device).index
+    if key not in _ONES:
+        _ONES[key] = torch.ones(1, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
 def absmax(x, out=None):
     """max |x| of a contiguous float32 tensor as a device scalar (operand scale of the two-term fp16 kernels)."""
     if out is None:
