@@ -547,7 +547,7 @@ static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
     if constexpr (BM == 128 && BN == 128) {
         // row-contiguous operands need unit row stride and 16-byte loads for the transposed staging (else the fp32-input path)
         const bool a_ok = akc || (g.sAm == 1 && g.vecA), b_ok = bkc || (g.sBn == 1 && g.vecB);
-        if (g_gemm_split && g.K >= 256 && a_ok && b_ok) {
+        if (g_gemm_split && g.K >= (g.two_term ? 128 : 256) && a_ok && b_ok) {      // (a short K amortises the two-term staging, not the three-term one)
             if (g.two_term && a2s_gemm_f16x2_enabled()) {
                 if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, 2>), grid, dim3(256), 0, st, g);
                 else if (akc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, 2>), grid, dim3(256), 0, st, g);
@@ -577,7 +577,7 @@ static bool big_two_term_ok(const GemmArgs& g, bool akc, bool bkc) {
     const bool a_ok = akc || (g.sAm == 1 && g.vecA), b_ok = bkc || (g.sBn == 1 && g.vecB);
     // (the BatchNorm-statistics epilogue keeps its partial layout: a 256-column tile touches at most two channels of period >= 256 and
     // at most as many tiles per channel as the 128-column layout has slots; unused partial rows stay zero)
-    return on && g.two_term && a2s_gemm_f16x2_enabled() && g_gemm_split && (!g.ep_y || g.ep_period >= 256) && g.K >= 256 && a_ok && b_ok && g.M >= 256 && g.N >= 256 &&
+    return on && g.two_term && a2s_gemm_f16x2_enabled() && g_gemm_split && (!g.ep_y || g.ep_period >= 256) && g.K >= 128 && a_ok && b_ok && g.M >= 256 && g.N >= 256 &&
            (long)a2s_cdiv(g.M, 256) * a2s_cdiv(g.N, 256) * g.batch * g.splitk >= 192;
 }
 static void launch_big_two_term(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {

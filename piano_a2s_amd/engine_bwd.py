@@ -119,7 +119,9 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     o2d, dlog2d = sv["o"].view(R, 2 * H2), dlog.view(R, V)
     do_all = torch.empty((n, B, 2 * H2), dtype=torch.float32, device=dev)
     Wo = S[prefix + ".out.weight"]
-    hip.gemm(dlog2d, V, 1, Wo, 2 * H2, 1, do_all.view(R, 2 * H2), 2 * H2, R, 2 * H2, V)          # do_all = dlog W_out  (gates the recurrence)
+    dlog_amax = hip.absmax(dlog) if enc_amax is not None else None
+    hip.gemm(dlog2d, V, 1, Wo, 2 * H2, 1, do_all.view(R, 2 * H2), 2 * H2, R, 2 * H2, V,          # do_all = dlog W_out  (gates the recurrence)
+             two_term=(dlog_amax, hip.absmax(Wo)) if enc_amax is not None else None)
     # (c) reverse recurrence
     dgi_all = torch.empty((n, B, 3 * H2), dtype=torch.float32, device=dev)
     dgh_all = torch.empty((n, B, 3 * H2), dtype=torch.float32, device=dev)
@@ -151,7 +153,7 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
         xb = torch.maximum(hip.absmax(S[prefix + ".embedding.weight"]), enc_amax) if enc_amax is not None else None
         ob = torch.maximum(one, enc_amax) if enc_amax is not None else None
         am = (lambda t: hip.absmax(t)) if enc_amax is not None else (lambda t: None)
-        _linear_bwd(o2d, Wo, dlog2d, G, prefix + ".out.weight", prefix + ".out.bias", dy_amax=am(dlog), x_bound=ob)       # dW_out += dlog^T o ; db_out += colsum
+        _linear_bwd(o2d, Wo, dlog2d, G, prefix + ".out.weight", prefix + ".out.bias", dy_amax=dlog_amax, x_bound=ob)       # dW_out += dlog^T o ; db_out += colsum
         x2d, h2d = sv["x"][:n].view(R, ldx), sv["h"][:n].view(R, H2)
         _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_all.view(R, 3 * H2), G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0",
                     dy_amax=am(dgi_all), x_bound=xb)
