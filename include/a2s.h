@@ -192,6 +192,10 @@ typedef struct a2s_note_dec_args {
     const int* row_until;             /* device, R ints */
     const int* n_active;              /* HOST, `steps` ints: clips with an unfinished row at step t; NULL = none of (1)/(2) */
     int n_clips;                      /* 0 = R (one group) */
+    const int* m_active;              /* HOST, `steps` ints or NULL: 1 + the largest clip index (position in the call, not in clip_order)
+                                         that still has an unfinished row at step t.  When that is at most half of n_clips the per-step
+                                         products run on the leading m_active[t] clips of every fused bar only (round 3: the few
+                                         full-length rows of a large call no longer drag every row through ~100 further steps) */
     int R, T, H, E, V, steps, poll, eos_id;
     int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
     float* step_ws; size_t step_ws_floats;   /* a2s_note_step_workspace_floats(H, E) floats or NULL: scratch of the fused few-row step kernels
@@ -252,6 +256,7 @@ typedef struct a2s_note_dec_bwd_args {
     const int* row_until;
     const int* n_active;                 /* HOST */
     int n_clips;
+    const int* m_active;                 /* HOST or NULL: as in the forward call; dx must then be zero-filled by the caller */
     int R, T, H, E, steps;
     float* step_ws; size_t step_ws_floats;   /* as in the forward call (holds the transposed weight copies of the fused backward step) */
 } a2s_note_dec_bwd_args;

@@ -314,6 +314,9 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
             cur ^= 1;
             continue;
         }
+        int gM = R, gB = 1;                  // rows of the per-step products: see enqueue_note_step (a2s_seq.hip); rows left out carry zero gradients
+        long gS = 0;
+        if (a.m_active && a.n_clips > 0 && 2 * a.m_active[s] <= a.n_clips && a.m_active[s] > 0) { gM = a.m_active[s]; gB = R / a.n_clips; gS = a.n_clips; }
         const float* dos = a.do_all + (long)s * R * 2 * H2;
         float* dgi = a.dgi_all + (long)s * R * 3 * H2;
         float* dgh = a.dgh_all + (long)s * R * 3 * H2;
@@ -324,7 +327,7 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
                                     dgi, 3 * H2, dgh, 3 * H2, nullptr, 0, dh_out, H2, R, H2);
         if (rc) return rc;
         // dx = dgi W_ih   (R x ldx): [dtok | dctx_from_gru]
-        rc = a2s_gemm_impl(st, R, ldx, 3 * H2, 1.f, dgi, 3 * H2, 1, a.w_ih, ldx, 1, 0.f, dxs, ldx, nullptr, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+        rc = a2s_gemm_impl(st, gM, ldx, 3 * H2, 1.f, dgi, 3 * H2, 1, a.w_ih, ldx, 1, 0.f, dxs, ldx, nullptr, 0, gB, gS * 3 * H2, 0, gS * ldx, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         // attention: dctx = dx[:, E:] + do[:, 2H:]
         rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
@@ -333,9 +336,9 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
                                     a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
         if (rc) return rc;
         // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
-        rc = a2s_gemm_impl(st, R, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+        rc = a2s_gemm_impl(st, gM, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * 3 * H2, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
-        rc = a2s_gemm_impl(st, R, H2, a.H, 1.f, a.dq_all + (long)s * R * a.H, a.H, 1, a.attn_w, 2 * H2, 1, 1.f, dh_out, H2, nullptr, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+        rc = a2s_gemm_impl(st, gM, H2, a.H, 1.f, a.dq_all + (long)s * R * a.H, a.H, 1, a.attn_w, 2 * H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * a.H, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         cur ^= 1;
     }

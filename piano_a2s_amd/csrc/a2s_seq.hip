@@ -524,6 +524,12 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
         if (rc) return rc;
         return a2s_note_step_fused_fwd(st, a, si, so, sv, sv_next, t, t_base, tf, last);
     }
+    // Rows the per-step products run on: all R, or -- late in a large call, when only a few leading clips still have an unfinished row --
+    // the first m clips of every fused bar (batch = bars, row stride n_clips).  The elementwise kernels below keep running over all rows:
+    // finished rows are never read again (models.py:401-419 stops writing them, their targets are <pad>).
+    int gM = a.R, gB = 1;
+    long gS = 0;
+    if (a.m_active && a.n_clips > 0 && 2 * a.m_active[t] <= a.n_clips && a.m_active[t] > 0) { gM = a.m_active[t]; gB = a.R / a.n_clips; gS = a.n_clips; }
     const float* hp = a.h + (long)si * a.R * H2;
     float* hq = a.h + (long)so * a.R * H2;
     float* xs = a.x + (long)si * a.R * ldx;
@@ -533,10 +539,10 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : a.R, a.n_active ? a.n_active[t] : 0, t};
     const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
     // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
-    rc = a2s_gemm_impl(st, a.R, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    rc = a2s_gemm_impl(st, gM, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, gB, gS * H2, 0, gS * a.H, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
     // gh = h W_hh^T + b_hh
-    rc = a2s_gemm_impl(st, a.R, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    rc = a2s_gemm_impl(st, gM, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, gB, gS * H2, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
     // attention -> ctx into x[si][:, E:] and o[sv][:, 2H:]
     rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
@@ -544,14 +550,14 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
                                 rows);
     if (rc) return rc;
     // gi = x W_ih^T + b_ih
-    rc = a2s_gemm_impl(st, a.R, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    rc = a2s_gemm_impl(st, gM, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, gB, gS * ldx, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
     // h' -> h[so] and o[sv][:, :2H]
     rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
                                 a.gates ? a.gates + (long)sv * a.R * 4 * H2 : nullptr, a.R, H2);
     if (rc) return rc;
     // logits = o W_out^T + b_out
-    rc = a2s_gemm_impl(st, a.R, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, 1, 0, 0, 0, 0, a.gemm_ws, a.gemm_ws_bytes);
+    rc = a2s_gemm_impl(st, gM, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, gB, gS * 2 * H2, 0, gS * a.V, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
     StepFinArgs f;
     f.logits = a.logits; f.ldl = a.V; f.probs = a.probs; f.probs_bstride = a.probs_bstride;

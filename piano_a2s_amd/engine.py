@@ -43,6 +43,8 @@ _GREEDY_GRAPH = _os.environ.get("A2S_GREEDY_GRAPH") == "1"
 # the encoder's input projections and the attention key images on the two-term fp16 split (operand ranges known: DESIGN.md section 5)
 # instead of three bf16 terms; A2S_ENC_TWO_TERM=0: as in round 2
 _ENC_TWO_TERM = _os.environ.get("A2S_ENC_TWO_TERM", "1") != "0"
+# late steps of a large decoder call: the per-step products only on the leading clips that still have an unfinished row (A2S_TAIL_PREFIX=0: all rows)
+_TAIL_PREFIX = _os.environ.get("A2S_TAIL_PREFIX", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -458,6 +460,7 @@ class Engine:
         a.step_ws, a.step_ws_floats = step_ws.data_ptr(), step_ws.numel()
         a.n_active = C.cast(active["n_active"], C.c_void_p).value if active else None
         a.n_clips = active["n_clips"] if active else 0
+        a.m_active = C.cast(active["m_active"], C.c_void_p).value if (active and active.get("m_active") is not None) else None
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
         if gt_bar is not None:
             a.gt, a.gt_bstride = gt_bar.data_ptr(), gt_bar.stride(0)
@@ -622,8 +625,15 @@ class Engine:
                 rank[order.long()] = torch.arange(Bg, dtype=torch.int32)
                 cnt = torch.bincount(clip_until.long(), minlength=n + 1)
                 n_act = Bg - torch.cumsum(cnt, 0)[:n]                                                               # clips with until > t
+                # 1 + the largest clip POSITION still unfinished at step t (the per-step products of the tail run on that prefix of every
+                # fused bar only: a2s_note_dec_args.m_active; train.plan_clip_groups puts the clips with the longest rows first)
+                last = torch.zeros(n + 1, dtype=torch.long)
+                cu = clip_until.long().clamp(max=n)
+                last.scatter_reduce_(0, cu, torch.arange(1, Bg + 1), reduce="amax")                                 # last[u] = 1 + max position with until == u
+                m_act = torch.flip(torch.cummax(torch.flip(last, [0]), 0)[0], [0])[1:n + 1]                          # max over until > t
                 return dict(until=upload(until.reshape(-1)), order=upload(order), rank=upload(rank),
-                            n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=Bg)
+                            n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=Bg,
+                            m_active=(C.c_int * max(n, 1))(*m_act.tolist()) if _TAIL_PREFIX else None)
 
             # Every host-side decision of the decoder and every small upload happens HERE, while the GPU is busy with the ConvStack and
             # the encoder enqueued above -- not once per (segment, staff) in the middle of the decoder.

@@ -169,7 +169,8 @@ def plan_clip_groups(until_up, until_lo, max_tail_frac=0.5, min_gain=0.08, step_
     remain -- summed over the steps of the longer staff of every bar.  Two groups run CONCURRENTLY but share the HBM, so a cut costs
     max(cost of either group, attention work of both).  Candidate cuts: the places where the clips' longest rows, sorted, jump by
     `jump`x.  The best cut is taken if it beats the uncut minibatch by min_gain.  Returns (order, n_main): `order` = clip permutation
-    (ordinary clips first, original order kept inside each group), n_main = size of the first group (== B: do not split)."""
+    (ordinary clips first, sorted by their longest row, longest first; the long clips in their original order), n_main = size of the
+    first group (== B: do not split)."""
     import numpy as np
     up, lo = np.asarray(until_up, dtype=np.int64), np.asarray(until_lo, dtype=np.int64)
     B = up.shape[0]
@@ -210,7 +211,9 @@ def plan_clip_groups(until_up, until_lo, max_tail_frac=0.5, min_gain=0.08, step_
         best_k = min(best_k + extra, B - 1)
     if best_k is None:
         return ident, B
-    return np.concatenate([np.sort(by_len[best_k:]), np.sort(by_len[:best_k])]), B - best_k
+    # inside the ordinary group the clips with the longest rows come first (by_len is a stable descending sort): late in a decoder call
+    # only a prefix of the clips is still running (engine.active_rows: m_active); the long clips keep their original order
+    return np.concatenate([by_len[best_k:], np.sort(by_len[:best_k])]), B - best_k
 
 
 class TrainStep:

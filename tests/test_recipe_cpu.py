@@ -197,7 +197,7 @@ def test_fused_adadelta_state_is_torch_adadelta_state():
 
 def test_clip_group_planner():
     """train.plan_clip_groups: no cut for a homogeneous minibatch; the clips holding full-length bars become the second group when
-    there are a few of them; the permutation keeps the original order inside each group."""
+    there are a few of them; inside the first group the clips with the longest rows come first (stable), the second keeps its order."""
     import numpy as np
     from piano_a2s_amd import spec, synthetic
     from piano_a2s_amd.train import plan_clip_groups
@@ -214,5 +214,8 @@ def test_clip_group_planner():
     up, lo = untils(0.01, 3)
     order, n_main = plan_clip_groups(up, lo)
     assert 0 < 256 - n_main <= 128 and sorted(order.tolist()) == list(range(256))
-    assert order[:n_main].tolist() == sorted(order[:n_main].tolist()) and order[n_main:].tolist() == sorted(order[n_main:].tolist())
+    longest = np.maximum(up.max(1), lo.max(1))
+    main = order[:n_main].tolist()
+    assert all(longest[a] > longest[b] or (longest[a] == longest[b] and a < b) for a, b in zip(main[:-1], main[1:]))
+    assert order[n_main:].tolist() == sorted(order[n_main:].tolist())
     assert up[order[:n_main]].max() <= 121 and all(up[c].max() == 398 for c in order[n_main:])

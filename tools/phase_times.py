@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--full-tail", type=float, default=0.01)
+    ap.add_argument("--segments", action="store_true")
     a = ap.parse_args()
     import models
     from piano_a2s_amd import engine, engine_bwd, spec, synthetic, train
@@ -78,12 +79,43 @@ def main():
         return orig_dg(self, gidx, *args)
     engine_bwd.Backward.decoder_group = dg
     gtot = {}
+    # --segments: every note-decoder call (one staff of one segment of one clip group) with its start, duration and time per decode step, on
+    # the stream it runs on (events around the call; no profiler attached)
+    seg_marks = []
+    if a.segments:
+        import threading
+        lock = threading.Lock()
+        orig_ds = engine.Engine._decode_staff
+
+        def ds(self, S, prefix, keys, enc, h0, maxs, probs, gt_bar, steps, *rest):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_ds(self, S, prefix, keys, enc, h0, maxs, probs, gt_bar, steps, *rest)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            with lock:
+                seg_marks.append((f"fwd {prefix.split('.')[-1][:5]} rows {h0.shape[0]:4d} steps {steps:3d}", e0, e1, steps))
+            return r
+        engine.Engine._decode_staff = ds
+        orig_nb = engine_bwd._note_decoder_bwd
+
+        def nb(eng, S, G, sv, keys, enc, *rest, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_nb(eng, S, G, sv, keys, enc, *rest, **kw)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            with lock:
+                seg_marks.append((f"bwd {sv['prefix'].split('.')[-1][:5]} rows {sv['groups'] * enc.shape[0]:4d} steps {sv['steps']:3d} (incl. its deferred products)", e0, e1, sv["steps"]))
+            return r
+        engine_bwd._note_decoder_bwd = nb
     totals = {}
     import time
     walls = []
     for k in range(a.steps + 1):
         marks.clear()
         gmarks.clear()
+        seg_marks.clear()
         mark("start")
         t0 = time.time()
         step(b, 0.7, rng=random.Random(100 + k))
@@ -100,6 +132,11 @@ def main():
     tot = sum(totals.values())
     for n, t in totals.items():
         print(f"{t / a.steps:9.1f} ms  {100 * t / tot:5.1f} %  {n}")
+    if a.segments:
+        print("note-decoder calls of the LAST step (start ms after the step's start, duration ms, us per decode step):")
+        for n, e0, e1, st in sorted(seg_marks, key=lambda m: marks[0][1].elapsed_time(m[1])):
+            t0, d = marks[0][1].elapsed_time(e0), e0.elapsed_time(e1)
+            print(f"  {t0:7.1f} {d:7.1f} {1e3 * d / max(st, 1):7.1f}  {n}")
     for n, t in sorted(gtot.items(), key=lambda kv: sorted(kv[1])[len(kv[1]) // 2]):
         print(f"{sorted(t)[len(t) // 2]:9.1f} ms after the start of the step (median; per step " + " ".join(f"{x:.0f}" for x in t) + f"): {n}")
     print("wall ms per step (host clock, first = warm-up):", " ".join(f"{w:.0f}" for w in walls), " groups:", step._last[2])
