@@ -4,3 +4,4 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- pyt
 python tools/kernel_stats.py $O/kt 70 > $O/kernel_stats.txt 2>&1
 python tools/trace_overlap.py $O/kt > $O/trace_overlap.txt 2>&1
 rm -rf $O/kt
+timeout 300 python tools/phase_times.py --steps 6 --segments > $O/phase_times.txt 2>&1

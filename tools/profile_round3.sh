@@ -18,7 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
     echo "== $c (KB per launch, B = 256)"; python tools/pmc_summary.py $O/pmc_$c | grep -A1 "^conv3x3_rows\|^conv3x3_wgrad_rows"
     rm -rf $O/pmc_$c
 done > $O/conv_traffic_b256.txt
-timeout 300 python tools/phase_times.py --steps 6 > $O/phase_times.txt 2>&1
+timeout 300 python tools/phase_times.py --steps 6 --segments > $O/phase_times.txt 2>&1
 timeout 300 python tools/wgrad_rows_check.py 256 --no-check > $O/wgrad_rows_b256.txt 2>&1
 timeout 300 python tools/conv_rows_check.py 256 --no-check > $O/conv_rows_b256.txt 2>&1
 timeout 100 python tools/staff_emb_time.py > $O/staff_emb.txt 2>&1
