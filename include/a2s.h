@@ -196,6 +196,9 @@ typedef struct a2s_note_dec_args {
                                          that still has an unfinished row at step t.  When that is at most half of n_clips the per-step
                                          products run on the leading m_active[t] clips of every fused bar only (round 3: the few
                                          full-length rows of a large call no longer drag every row through ~100 further steps) */
+    const int* row_list;              /* device, R ints or NULL: the rows sorted by row_until, latest first (stable) -- the rows still running
+                                         at step t are its first n_rows_active[t] entries; the few-row step kernels then cover those only */
+    const int* n_rows_active;         /* HOST, `steps` ints (with row_list) */
     int R, T, H, E, V, steps, poll, eos_id;
     int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
     float* step_ws; size_t step_ws_floats;   /* a2s_note_step_workspace_floats(H, E) floats or NULL: scratch of the fused few-row step kernels
@@ -257,6 +260,8 @@ typedef struct a2s_note_dec_bwd_args {
     const int* n_active;                 /* HOST */
     int n_clips;
     const int* m_active;                 /* HOST or NULL: as in the forward call; dx must then be zero-filled by the caller */
+    const int* row_list;                 /* device or NULL, and */
+    const int* n_rows_active;            /* HOST: as in the forward call (dx zero-filled as well) */
     int R, T, H, E, steps;
     float* step_ws; size_t step_ws_floats;   /* as in the forward call (holds the transposed weight copies of the fused backward step) */
 } a2s_note_dec_bwd_args;

@@ -293,7 +293,8 @@ int a2s_ew_act_bwd_impl(hipStream_t st, const float* g, const float* y, float* d
 
 bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats);
 int a2s_note_step_fused_bwd_prepare(hipStream_t st, const a2s_note_dec_bwd_args& a);
-int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const float* dh_in, float* dh_out, const a2s_attn_rows* rows);
+int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const float* dh_in, float* dh_out, const a2s_attn_rows* rows,
+                            int nrows, const int* rowmap);
 
 int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
@@ -301,15 +302,20 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd memset: %s", hipGetErrorString(e));
     int cur = 0;
     const void* ptrs[] = {a.dgi_all, a.dgh_all, a.dq_all, a.dx, a.dh, a.w_ih, a.w_hh, a.attn_w};
-    const bool fused = a.steps > 0 && a2s_dec_step_fusable(R, a.H, a.E, 173, ptrs, 8, a.step_ws, a.step_ws_floats);      // (the vocabulary size plays no role here)
-    if (fused) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }
+    // rows step s covers on the few-row kernels: all R, or the rows still running (a prefix of row_list); the kernels take over for the steps
+    // whose rows fit them (see a2s_note_decoder_fwd_impl)
+    auto step_rows = [&](int s) { return (a.row_list && a.n_rows_active) ? a.n_rows_active[s] : R; };
+    auto step_fused = [&](int s) { const int n = step_rows(s); return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, 173, ptrs, 8, a.step_ws, a.step_ws_floats); };      // (the vocabulary size plays no role here)
+    if (a.steps > 0 && step_fused(a.steps - 1)) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }       // (the last step has the fewest rows)
     for (int s = a.steps - 1; s >= 0; --s) {
+        const bool fused = step_fused(s);
         a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : R, a.n_active ? a.n_active[s] : 0, s};
         const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
         float* dh_in = a.dh + (long)cur * R * H2;
         float* dh_out = a.dh + (long)(cur ^ 1) * R * H2;
         if (fused) {
-            int rc = a2s_note_step_fused_bwd(st, a, s, dh_in, dh_out, rows);
+            const int nrows = step_rows(s);
+            int rc = a2s_note_step_fused_bwd(st, a, s, dh_in, dh_out, rows, nrows, nrows < R ? a.row_list : nullptr);
             if (rc) return rc;
             cur ^= 1;
             continue;

@@ -496,10 +496,14 @@ int a2s_embed_rows_impl(hipStream_t st, const float* table, const long long* ids
 typedef a2s_note_dec_args NoteDecArgs;   // one definition only: the public C struct (include/a2s.h)
 
 bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats);
-int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last);
-static bool note_step_fusable(const NoteDecArgs& a) {
+int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last,
+                            int nrows, const int* rowmap);
+// rows the fused step of step t would cover: all R, or (training, finished rows skipped) the rows still running, a prefix of row_list
+static int note_step_rows(const NoteDecArgs& a, int t) { return (a.row_list && a.n_rows_active && t >= 0) ? a.n_rows_active[t] : a.R; }
+static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
     const void* ptrs[] = {a.x, a.h, a.o, a.q, a.w_ih, a.w_hh, a.out_w, a.attn_w};
-    return a2s_dec_step_fusable(a.R, a.H, a.E, a.V, ptrs, 8, a.step_ws, a.step_ws_floats);
+    const int n = note_step_rows(a, t);
+    return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, a.V, ptrs, 8, a.step_ws, a.step_ws_floats);
 }
 // q of slot `sv` from the state in slot `si` (the fused path computes every later query in the previous step's last launch)
 static int enqueue_query(hipStream_t st, const NoteDecArgs& a, int si, int sv) {
@@ -522,7 +526,8 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
                                         a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws,
                                         a.n_active ? &rows_v : nullptr);
         if (rc) return rc;
-        return a2s_note_step_fused_fwd(st, a, si, so, sv, sv_next, t, t_base, tf, last);
+        const int nrows = note_step_rows(a, t_base ? -1 : t);
+        return a2s_note_step_fused_fwd(st, a, si, so, sv, sv_next, t, t_base, tf, last, nrows, nrows < a.R ? a.row_list : nullptr);
     }
     // Rows the per-step products run on: all R, or -- late in a large call, when only a few leading clips still have an unfinished row --
     // the first m clips of every fused bar (batch = bars, row stride n_clips).  The elementwise kernels below keep running over all rows:
@@ -617,9 +622,14 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
     // stream capture is not allowed on the legacy default stream: callers that want the graph path run on a created stream
     if (!a.gt && a.use_graph && a.t_base && !a.gates && !a.attw && !a.drop && st != nullptr) return note_decoder_greedy_graph(st, a, steps_done);
     int s = 0;
-    const bool fused = note_step_fusable(a);
-    if (fused && a.steps > 0) { int rc = enqueue_query(st, a, 0, 0); if (rc) return rc; }
+    // The few-row step kernels take over as soon as the rows still running fit them (the whole call when it is small; the tail of a large
+    // training call otherwise: the handful of full-length rows then decode in 4 launches per step instead of 12 over every row).  The
+    // first fused step finds no query left behind by a fused predecessor: it is computed for all rows first.
+    bool prev_fused = false;
     for (; s < a.steps; ++s) {
+        const bool fused = note_step_fusable(a, s);
+        if (fused && !prev_fused) { int rc = enqueue_query(st, a, s, s); if (rc) return rc; }
+        prev_fused = fused;
         int rc = enqueue_note_step(st, a, s, s + 1, s, s, nullptr, a.tf_flags ? a.tf_flags[s] : 0, fused, s + 1, s + 1 == a.steps);
         if (rc) return rc;
         if (!a.gt && a.poll > 0 && ((s + 1) % a.poll == 0) && s + 1 < a.steps) {

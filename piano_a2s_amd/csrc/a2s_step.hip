@@ -93,8 +93,11 @@ struct DecGruArgs {
     const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;
     float* hout; float* o; long ldo; float* save;       // h' -> hout (R, H2) and o[:, :H2]; save (R, 4 H2) [r|z|n|gh_n] or null
     const int* n_done; int* skip;                       // greedy: the step is a no-op once *n_done >= R; *skip tells the step's later kernels
+    const int* rowmap;                                  // optional: the launch covers rows rowmap[0 .. R) of the call (rows still running), not 0 .. R
     int R, H2;
 };
+// physical row of the v-th row a launch covers
+__device__ __forceinline__ int dec_row(const int* __restrict__ rowmap, int v) { return rowmap ? rowmap[v] : v; }
 
 __global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
     __shared__ f32x4 part[4 * 4 * 64];
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
     if (wave == 0) {                                      // epilogue operands: in flight while the products run
         br = a.b_ih[j] + a.b_hh[j]; bz = a.b_ih[H2 + j] + a.b_hh[H2 + j]; bin = a.b_ih[2 * H2 + j]; bhn = a.b_hh[2 * H2 + j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hp[r] = a.h[(long)min(row0 + lk * 4 + r, R - 1) * H2 + j];
+        for (int r = 0; r < 4; ++r) hp[r] = a.h[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * H2 + j];
     }
-    const int arow_i = min(row0 + li, R - 1);
+    const int arow_i = dec_row(a.rowmap, min(row0 + li, R - 1));
     const float* bi[3];
     const float* bh[3];
 #pragma unroll
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
     if (wave > 0) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = row0 + lk * 4 + r;
-        if (row >= R) continue;
+        if (row0 + lk * 4 + r >= R) continue;
+        const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
         const float ghn = acc[3][r] + bhn;
         const float rg = fast_sigmoid(acc[0][r] + br);
         const float zg = fast_sigmoid(acc[1][r] + bz);
@@ -170,13 +173,15 @@ struct DecOutArgs {
     const int* t_base; const int* row_until; const int* skip;
     // next step's attention query
     const float* hnew; const float* attn_w; long ld_aw; const float* attn_b; float* q_next; int H;
+    const int* rowmap;                                  // as in DecGruArgs; the logits scratch and the tickets are indexed by the launch's own row numbers
     int n_clips, R, V, E, t, teacher_force, eos_id, max_t, H2;
 };
 
 // the step epilogue for one row, executed by one wave (reference models.py:401-419); lg: the row's logits, read past the L1 (they
 // were written by other workgroups of this launch)
-__device__ __forceinline__ void dec_row_epilogue(const DecOutArgs& a, int row, int t, int lane) {
-    const volatile float* lg = a.logits + (long)row * a.ldl;
+__device__ __forceinline__ void dec_row_epilogue(const DecOutArgs& a, int vrow, int t, int lane) {
+    const volatile float* lg = a.logits + (long)vrow * a.ldl;
+    const int row = dec_row(a.rowmap, vrow);
     const bool finished = a.row_until && t >= a.row_until[row];    // its bar's loop has ended in the reference or only <pad> targets remain
     float v[3];
     float m = -INFINITY; int mi = 0x7fffffff;
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) brow[g] = Bm + (long)min(n0 + g * 16 + li, ncols - 1) * ldb;
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    const float* arow = (vocab ? a.o + (long)min(row0 + li, R - 1) * a.ldo : a.hnew + (long)min(row0 + li, R - 1) * a.H2);
+    const int arow_p = dec_row(a.rowmap, min(row0 + li, R - 1));
+    const float* arow = (vocab ? a.o + (long)arow_p * a.ldo : a.hnew + (long)arow_p * a.H2);
     mfma_rows8<2, 4>(arow, brow, K / 16, wave, lk, acc);
     reduce_waves<2>(acc, part, wave, lane);
     if (wave == 0) {
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + lk * 4 + r;
-                if (row < R) out[(long)row * ldo + col] = acc[g][r] + b;
+                if (row < R) out[(long)(vocab ? row : dec_row(a.rowmap, row)) * ldo + col] = acc[g][r] + b;
             }
         }
     }
@@ -284,6 +290,7 @@ struct DecBwdProdArgs {
     const float* dgi; const float* dgh;                 // (R, 3 H2) each
     const float* wih_t; const float* whh_t;             // (kx, 3 H2), (H2, 3 H2)
     float* dx; long ldx; float* dh;                     // (R, ldx) overwritten; (R, H2) accumulated
+    const int* rowmap;                                  // as in DecGruArgs
     int nxa, kx, R, H2;
 };
 
@@ -305,10 +312,10 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)min(row0 + lk * 4 + r, R - 1) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
+            for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
     }
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8<2, 4>(A + (long)min(row0 + li, R - 1) * K, brow, K / 16, wave, lk, acc);
+    mfma_rows8<2, 4>(A + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K, brow, K / 16, wave, lk, acc);
     reduce_waves<2>(acc, part, wave, lane);
     if (wave > 0) return;
 #pragma unroll
@@ -317,8 +324,8 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
         if (col >= ncols) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row0 + lk * 4 + r;
-            if (row >= R) continue;
+            if (row0 + lk * 4 + r >= R) continue;
+            const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
             if (role_a) a.dx[(long)row * a.ldx + col] = acc[g][r];
             else a.dh[(long)row * a.H2 + col] = c0[g][r] + acc[g][r];
         }
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
 
 // dh[:, n] += dq . W_h[:, n]  (B rows = W_h^T rows, (H2, H)); 32 columns per workgroup
 __global__ __launch_bounds__(64 * NW) void dec_bwd_query(const float* __restrict__ dq, const float* __restrict__ wh_t, float* __restrict__ dh,
-                                                         int R, int H, int H2) {
+                                                         int R, int H, int H2, const int* __restrict__ rowmap) {
     __shared__ f32x4 part[4 * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -340,10 +347,10 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_query(const float* __restrict
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c0[g][r] = dh[(long)min(row0 + lk * 4 + r, R - 1) * H2 + min(n0 + g * 16 + li, H2 - 1)];
+            for (int r = 0; r < 4; ++r) c0[g][r] = dh[(long)dec_row(rowmap, min(row0 + lk * 4 + r, R - 1)) * H2 + min(n0 + g * 16 + li, H2 - 1)];
     }
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8<2, 2>(dq + (long)min(row0 + li, R - 1) * H, brow, H / 16, wave, lk, acc);
+    mfma_rows8<2, 2>(dq + (long)dec_row(rowmap, min(row0 + li, R - 1)) * H, brow, H / 16, wave, lk, acc);
     reduce_waves<2>(acc, part, wave, lane);
     if (wave > 0) return;
 #pragma unroll
@@ -352,8 +359,7 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_query(const float* __restrict
         if (col >= H2) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = row0 + lk * 4 + r;
-            if (row < R) dh[(long)row * H2 + col] = c0[g][r] + acc[g][r];
+            if (row0 + lk * 4 + r < R) dh[(long)dec_row(rowmap, row0 + lk * 4 + r) * H2 + col] = c0[g][r] + acc[g][r];
         }
     }
 }
@@ -394,7 +400,9 @@ bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, i
 }
 
 // ------------------------------------------------------------------------------------------- forward step (after the attention)
-int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last) {
+// nrows / rowmap: the step covers rows rowmap[0 .. nrows) of the call's R rows (rowmap NULL: rows 0 .. nrows = R)
+int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last,
+                            int nrows, const int* rowmap) {
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
     int* flags = reinterpret_cast<int*>(a.step_ws);
     const bool greedy = a.gt == nullptr;
@@ -405,8 +413,9 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
     g.hout = a.h + (long)so * R * H2; g.o = a.o + (long)sv * R * 2 * H2; g.ldo = 2 * H2;
     g.save = a.gates ? a.gates + (long)sv * R * 4 * H2 : nullptr;
     g.n_done = greedy ? a.n_done : nullptr; g.skip = flags;
-    g.R = R; g.H2 = H2;
-    hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(R, 16)), dim3(64 * NW), 0, st, g);
+    g.rowmap = rowmap;
+    g.R = nrows; g.H2 = H2;
+    hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, g);
     A2S_CHECK_LAUNCH("dec_gru_step");
     DecOutArgs f;
     f.o = g.o; f.ldo = 2 * H2; f.ko = 2 * H2; f.out_w = a.out_w; f.out_b = a.out_b;
@@ -419,9 +428,10 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
     f.t_base = t_base; f.row_until = a.n_active ? a.row_until : nullptr; f.skip = greedy ? flags : nullptr;
     f.hnew = g.hout; f.attn_w = a.attn_w; f.ld_aw = 2 * H2; f.attn_b = a.attn_b;
     f.q_next = last ? nullptr : a.q + (long)sv_next * R * a.H; f.H = a.H;
-    f.n_clips = a.n_clips > 0 ? a.n_clips : R; f.R = R; f.V = a.V; f.E = a.E; f.t = t; f.teacher_force = tf; f.eos_id = a.eos_id;
+    f.rowmap = rowmap;
+    f.n_clips = a.n_clips > 0 ? a.n_clips : R; f.R = nrows; f.V = a.V; f.E = a.E; f.t = t; f.teacher_force = tf; f.eos_id = a.eos_id;
     f.max_t = a.steps; f.H2 = H2;
-    hipLaunchKernelGGL(dec_out_step, dim3(a2s_cdiv(R, 16), NVW + a2s_cdiv(a.H, 32)), dim3(64 * NW), 0, st, f);
+    hipLaunchKernelGGL(dec_out_step, dim3(a2s_cdiv(nrows, 16), NVW + a2s_cdiv(a.H, 32)), dim3(64 * NW), 0, st, f);
     A2S_CHECK_LAUNCH("dec_out_step");
     return A2S_OK;
 }
@@ -439,7 +449,8 @@ int a2s_note_step_fused_bwd_prepare(hipStream_t st, const a2s_note_dec_bwd_args&
     return A2S_OK;
 }
 
-int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const float* dh_in, float* dh_out, const a2s_attn_rows* rows) {
+int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const float* dh_in, float* dh_out, const a2s_attn_rows* rows,
+                            int nrows, const int* rowmap) {
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
     const float* dos = a.do_all + (long)s * R * 2 * H2;
     float* dgi = a.dgi_all + (long)s * R * 3 * H2;
@@ -454,8 +465,9 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
     if (rc) return rc;
     DecBwdProdArgs p;
     p.dgi = dgi; p.dgh = dgh; p.wih_t = wih_t; p.whh_t = whh_t; p.dx = dxs; p.ldx = ldx; p.dh = dh_out;
-    p.nxa = a2s_cdiv(ldx, 32); p.kx = ldx; p.R = R; p.H2 = H2;
-    hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(R, 16)), dim3(64 * NW), 0, st, p);
+    p.rowmap = rowmap;
+    p.nxa = a2s_cdiv(ldx, 32); p.kx = ldx; p.R = nrows; p.H2 = H2;
+    hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, p);
     A2S_CHECK_LAUNCH("dec_bwd_products");
     // attention: dctx = dx[:, E:] + do[:, 2H:]
     rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
@@ -463,7 +475,8 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
                                 a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
                                 a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
     if (rc) return rc;
-    hipLaunchKernelGGL(dec_bwd_query, dim3(a2s_cdiv(H2, 32), a2s_cdiv(R, 16)), dim3(64 * NW), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, R, a.H, H2);
+    hipLaunchKernelGGL(dec_bwd_query, dim3(a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, nrows, a.H, H2,
+                       rowmap);
     A2S_CHECK_LAUNCH("dec_bwd_query");
     return A2S_OK;
 }

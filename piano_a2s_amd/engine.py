@@ -45,6 +45,8 @@ _GREEDY_GRAPH = _os.environ.get("A2S_GREEDY_GRAPH") == "1"
 _ENC_TWO_TERM = _os.environ.get("A2S_ENC_TWO_TERM", "1") != "0"
 # late steps of a large decoder call: the per-step products only on the leading clips that still have an unfinished row (A2S_TAIL_PREFIX=0: all rows)
 _TAIL_PREFIX = _os.environ.get("A2S_TAIL_PREFIX", "1") != "0"
+# ... and the few-row step kernels on the rows still running once those fit them (A2S_TAIL_ROWS=0: only calls that are small as a whole)
+_TAIL_ROWS = _os.environ.get("A2S_TAIL_ROWS", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -423,12 +425,15 @@ class Engine:
         n = steps
         graph = gt_bar is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH)     # greedy decode: replayed hipGraph
         t_base = torch.zeros(1, dtype=torch.int32, device=dev) if graph else None
-        h = self._empty(n + 1, B, H2, dev=dev)
+        # (with row_list the tail steps write only the rows still running: what the backward pass reads of the others -- operands of the
+        # weight-gradient products over all rows and steps -- must be finite, so these buffers start as zeros: ~6 GB, ~1.3 ms per step)
+        mk = (lambda *sh, dev: torch.zeros(sh, dtype=torch.float32, device=dev)) if (active and active.get("row_list") is not None) else self._empty
+        h = mk(n + 1, B, H2, dev=dev)
         h[0].copy_(h0)
-        x = self._empty(n + 1, B, ldx, dev=dev)
-        q = self._empty(n, B, H, dev=dev)
-        o = self._empty(n, B, 2 * H2, dev=dev)
-        gates = self._empty(n, B, 4 * H2, dev=dev) if training else None
+        x = mk(n + 1, B, ldx, dev=dev)
+        q = mk(n, B, H, dev=dev)
+        o = mk(n, B, 2 * H2, dev=dev)
+        gates = mk(n, B, 4 * H2, dev=dev) if training else None
         attw = self._empty(n, B, T, dev=dev) if training else None
         gh, gi = self._empty(B, 3 * H2, dev=dev), self._empty(B, 3 * H2, dev=dev)
         logits = self._empty(B, V, dev=dev)
@@ -461,6 +466,10 @@ class Engine:
         a.n_active = C.cast(active["n_active"], C.c_void_p).value if active else None
         a.n_clips = active["n_clips"] if active else 0
         a.m_active = C.cast(active["m_active"], C.c_void_p).value if (active and active.get("m_active") is not None) else None
+        if active and active.get("row_list") is not None:
+            a.row_list, a.n_rows_active = active["row_list"].data_ptr(), C.cast(active["n_rows_active"], C.c_void_p).value
+        else:
+            a.row_list, a.n_rows_active = None, None
         a.probs, a.probs_bstride = probs_bar.data_ptr(), probs_bar.stride(0)
         if gt_bar is not None:
             a.gt, a.gt_bstride = gt_bar.data_ptr(), gt_bar.stride(0)
@@ -631,9 +640,16 @@ class Engine:
                 cu = clip_until.long().clamp(max=n)
                 last.scatter_reduce_(0, cu, torch.arange(1, Bg + 1), reduce="amax")                                 # last[u] = 1 + max position with until == u
                 m_act = torch.flip(torch.cummax(torch.flip(last, [0]), 0)[0], [0])[1:n + 1]                          # max over until > t
-                return dict(until=upload(until.reshape(-1)), order=upload(order), rank=upload(rank),
+                # the rows themselves, latest-finishing first: the few-row step kernels cover the rows still running (a2s_note_dec_args.row_list)
+                uflat = until.reshape(-1)
+                row_list = torch.argsort(uflat, descending=True, stable=True).to(torch.int32)
+                rcnt = torch.bincount(uflat.long().clamp(max=n), minlength=n + 1)
+                n_rows = uflat.numel() - torch.cumsum(rcnt, 0)[:n]                                                  # rows with until > t
+                return dict(until=upload(uflat), order=upload(order), rank=upload(rank),
                             n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=Bg,
-                            m_active=(C.c_int * max(n, 1))(*m_act.tolist()) if _TAIL_PREFIX else None)
+                            m_active=(C.c_int * max(n, 1))(*m_act.tolist()) if _TAIL_PREFIX else None,
+                            row_list=upload(row_list) if _TAIL_ROWS else None,
+                            n_rows_active=(C.c_int * max(n, 1))(*n_rows.tolist()) if _TAIL_ROWS else None)
 
             # Every host-side decision of the decoder and every small upload happens HERE, while the GPU is busy with the ConvStack and
             # the encoder enqueued above -- not once per (segment, staff) in the middle of the decoder.

@@ -130,7 +130,7 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     dctx_all = torch.empty((n, B, H2), dtype=torch.float32, device=dev)
     m_active = sv["active"].get("m_active") if sv.get("active") else None
     # (with m_active the per-step products skip the rows of finished clips: their dx rows are never written and must read as zero)
-    dx = (torch.zeros if m_active is not None else torch.empty)((n, B, ldx), dtype=torch.float32, device=dev)
+    dx = (torch.zeros if sv.get("active") else torch.empty)((n, B, ldx), dtype=torch.float32, device=dev)
     dh = torch.empty((2, B, H2), dtype=torch.float32, device=dev)
     a = hip.NoteDecBwdArgs()
     for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),
@@ -146,6 +146,10 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     a.n_active = C.cast(sv["active"]["n_active"], C.c_void_p).value if sv.get("active") else None
     a.n_clips = sv["active"]["n_clips"] if sv.get("active") else 0
     a.m_active = C.cast(m_active, C.c_void_p).value if m_active is not None else None
+    if sv.get("active") and sv["active"].get("row_list") is not None:
+        a.row_list, a.n_rows_active = sv["active"]["row_list"].data_ptr(), C.cast(sv["active"]["n_rows_active"], C.c_void_p).value
+    else:
+        a.row_list, a.n_rows_active = None, None
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) everything nobody in the recurrence waits for

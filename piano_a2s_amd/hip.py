@@ -29,6 +29,7 @@ class NoteDecArgs(C.Structure):
         ("eos_seen", C.c_void_p), ("lengths", C.c_void_p), ("n_done", C.c_void_p), ("steps_exec", C.c_void_p), ("attn_ws", C.c_void_p),
         ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("t_base", C.c_void_p), ("clip_order", C.c_void_p), ("clip_rank", C.c_void_p),
         ("row_until", C.c_void_p), ("n_active", C.c_void_p), ("n_clips", C.c_int), ("m_active", C.c_void_p),
+        ("row_list", C.c_void_p), ("n_rows_active", C.c_void_p),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("V", C.c_int),
         ("steps", C.c_int), ("poll", C.c_int), ("eos_id", C.c_int), ("use_graph", C.c_int),
         ("step_ws", C.c_void_p), ("step_ws_floats", C.c_size_t)]
@@ -40,7 +41,7 @@ class NoteDecBwdArgs(C.Structure):
         "attn_w", "attn_v", "w_ih", "w_hh", "keys", "enc", "h", "x", "q", "gates", "attw", "do_all",
         "dgi_all", "dgh_all", "dq_all", "ds_all", "dctx_all", "dx", "dh", "attn_ws", "gemm_ws")] + [
         ("gemm_ws_bytes", C.c_size_t), ("clip_order", C.c_void_p), ("clip_rank", C.c_void_p), ("row_until", C.c_void_p),
-        ("n_active", C.c_void_p), ("n_clips", C.c_int), ("m_active", C.c_void_p),
+        ("n_active", C.c_void_p), ("n_clips", C.c_int), ("m_active", C.c_void_p), ("row_list", C.c_void_p), ("n_rows_active", C.c_void_p),
         ("R", C.c_int), ("T", C.c_int), ("H", C.c_int), ("E", C.c_int), ("steps", C.c_int),
         ("step_ws", C.c_void_p), ("step_ws_floats", C.c_size_t)]
 
