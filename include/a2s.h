@@ -259,9 +259,9 @@ typedef struct a2s_note_dec_bwd_args {
     const int* row_until;
     const int* n_active;                 /* HOST */
     int n_clips;
-    const int* m_active;                 /* HOST or NULL: as in the forward call; dx must then be zero-filled by the caller */
+    const int* m_active;                 /* HOST or NULL: as in the forward call (the call zero-fills dx first) */
     const int* row_list;                 /* device or NULL, and */
-    const int* n_rows_active;            /* HOST: as in the forward call (dx zero-filled as well) */
+    const int* n_rows_active;            /* HOST: as in the forward call */
     int R, T, H, E, steps;
     float* step_ws; size_t step_ws_floats;   /* as in the forward call (holds the transposed weight copies of the fused backward step) */
 } a2s_note_dec_bwd_args;

@@ -299,6 +299,8 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
 int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
     hipError_t e = hipMemsetAsync(a.dh, 0, sizeof(float) * 2 * R * H2, st);
+    // (steps that skip finished rows leave their dx rows unwritten: they must read as zero gradients)
+    if (e == hipSuccess && (a.m_active || a.row_list)) e = hipMemsetAsync(a.dx, 0, sizeof(float) * (size_t)a.steps * R * ldx, st);
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd memset: %s", hipGetErrorString(e));
     int cur = 0;
     const void* ptrs[] = {a.dgi_all, a.dgh_all, a.dq_all, a.dx, a.dh, a.w_ih, a.w_hh, a.attn_w};

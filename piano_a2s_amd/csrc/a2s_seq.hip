@@ -621,6 +621,18 @@ static int note_decoder_greedy_graph(hipStream_t st, const NoteDecArgs& a, int* 
 int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_done) {
     // stream capture is not allowed on the legacy default stream: callers that want the graph path run on a created stream
     if (!a.gt && a.use_graph && a.t_base && !a.gates && !a.attw && !a.drop && st != nullptr) return note_decoder_greedy_graph(st, a, steps_done);
+    if (a.row_list && a.n_rows_active && a.steps > 0) {
+        // Tail steps on the few-row kernels write only the rows still running.  What the backward pass reads of the others (operands of its
+        // weight-gradient products over all rows and steps, the saved gates) must be finite: everything behind slot 0 starts as zeros
+        // (~6 GB per training step at B = 256, ~1.3 ms; issued here and not by the Python host: see engine.Engine._decode_staff).
+        const long H2 = 2L * a.H, ldx = a.E + H2, n = a.steps, R = a.R;
+        hipError_t e = hipMemsetAsync(a.h + R * H2, 0, sizeof(float) * n * R * H2, st);
+        if (e == hipSuccess) e = hipMemsetAsync(a.x + R * ldx, 0, sizeof(float) * n * R * ldx, st);
+        if (e == hipSuccess) e = hipMemsetAsync(a.q, 0, sizeof(float) * n * R * a.H, st);
+        if (e == hipSuccess) e = hipMemsetAsync(a.o, 0, sizeof(float) * n * R * 2 * H2, st);
+        if (e == hipSuccess && a.gates) e = hipMemsetAsync(a.gates, 0, sizeof(float) * n * R * 4 * H2, st);
+        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder memset: %s", hipGetErrorString(e));
+    }
     int s = 0;
     // The few-row step kernels take over as soon as the rows still running fit them (the whole call when it is small; the tail of a large
     // training call otherwise: the handful of full-length rows then decode in 4 launches per step instead of 12 over every row).  The

@@ -64,6 +64,15 @@ def side_streams(device, group=0):
     return _SIDE_STREAMS[key]
 
 
+_HOST_TRACE = None        # tools/phase_times.py --segments: a list that receives (label, host time) at the decoder's host-side milestones
+
+
+def _trace(label):
+    if _HOST_TRACE is not None:
+        import time
+        _HOST_TRACE.append((label, time.time()))
+
+
 _GROUP_STREAMS = {}
 _GROUP_POOL = None
 
@@ -425,15 +434,14 @@ class Engine:
         n = steps
         graph = gt_bar is None and not training and getattr(self, "greedy_graph", _GREEDY_GRAPH)     # greedy decode: replayed hipGraph
         t_base = torch.zeros(1, dtype=torch.int32, device=dev) if graph else None
-        # (with row_list the tail steps write only the rows still running: what the backward pass reads of the others -- operands of the
-        # weight-gradient products over all rows and steps -- must be finite, so these buffers start as zeros: ~6 GB, ~1.3 ms per step)
-        mk = (lambda *sh, dev: torch.zeros(sh, dtype=torch.float32, device=dev)) if (active and active.get("row_list") is not None) else self._empty
-        h = mk(n + 1, B, H2, dev=dev)
+        # (with row_list the tail steps write only the rows still running; a2s_note_decoder_fwd zero-fills these buffers itself -- from C,
+        # where a memset that has to wait for room in a busy stream's queue does not hold the interpreter lock)
+        h = self._empty(n + 1, B, H2, dev=dev)
         h[0].copy_(h0)
-        x = mk(n + 1, B, ldx, dev=dev)
-        q = mk(n, B, H, dev=dev)
-        o = mk(n, B, 2 * H2, dev=dev)
-        gates = mk(n, B, 4 * H2, dev=dev) if training else None
+        x = self._empty(n + 1, B, ldx, dev=dev)
+        q = self._empty(n, B, H, dev=dev)
+        o = self._empty(n, B, 2 * H2, dev=dev)
+        gates = self._empty(n, B, 4 * H2, dev=dev) if training else None
         attw = self._empty(n, B, T, dev=dev) if training else None
         gh, gi = self._empty(B, 3 * H2, dev=dev), self._empty(B, 3 * H2, dev=dev)
         logits = self._empty(B, V, dev=dev)
@@ -599,6 +607,7 @@ class Engine:
             """The decoder (reference HierarchicalDecoder.decode_bars, models.py:191-316) over the clips [b0, b1).  Runs on the calling
             thread's current stream plus that group's two staff streams; `gen`: the torch generator its dropout masks come from."""
             Bg = b1 - b0
+            _trace(f"g{gidx} decode_group entered")
             hidden = enc_hidden[b0:b1]
             enc_g = enc[b0:b1]
             keys_g = {p: k.view(B, T, H)[b0:b1] for p, k in keys.items()}
@@ -624,6 +633,8 @@ class Engine:
             if plan is not None:
                 gsteps = [{gi_idx: min(plan[bar][gi_idx][0], plan_note_steps(gt_cpu_g[gi_idx][:, bar, :], maxlen[gi_idx])[0]) for gi_idx in (0, 1)}
                           for bar in range(bars)]
+
+            _trace(f"g{gidx} step counts planned")
 
             def active_rows(gi_idx, seg, n):
                 """Row / clip bookkeeping of one decoder call over the bars `seg` (n steps launched)."""
@@ -653,6 +664,7 @@ class Engine:
 
             # Every host-side decision of the decoder and every small upload happens HERE, while the GPU is busy with the ConvStack and
             # the encoder enqueued above -- not once per (segment, staff) in the middle of the decoder.
+            _trace(f"g{gidx} planning starts")
             seg_plan = []
             for seg in segments:
                 sp = {}
@@ -750,6 +762,7 @@ class Engine:
                 nb = len(seg)
                 # (1) bar-level chain of the segment: inside a segment every next token comes from the ground truth
                 for j, bar in enumerate(seg):
+                    _trace(f"g{gidx} bar {bar} step")
                     rec = bar_step(bar, token, hidden)
                     rec["seg"] = (len(seg_saved), j)
                     bar_saved.append(rec)
@@ -778,6 +791,7 @@ class Engine:
                     calls.append((name, (S, prefix, keys_g[prefix], enc_g, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
                                          attn_ws[gi_idx], gemm_ws[gi_idx], active, drop, flags_dev)))
                 if concurrent_g:
+                    _trace(f"g{gidx} seg {seg_i} staves forked")
                     join = fork_on_streams(dev, streams, [lambda args=args: self._decode_staff(*args) for _, args in calls])
                 elif greedy_graph:
                     # greedy decode replays a captured hipGraph: capture needs a created (non-default) stream
@@ -802,6 +816,7 @@ class Engine:
                 # (3) heads do not depend on the note decoders: they overlap with them on the main stream
                 for bar in seg:
                     bar_saved[bar]["heads"] = bar_heads(bar, bar_saved[bar]["headin"])
+                _trace(f"g{gidx} seg {seg_i} heads issued, joining")
                 for (name, _), (ids, lengths, sv) in zip(calls, join()):     # the next token / next bar may read what the staves produced
                     sv["groups"] = nb
                     staff[name] = (ids, lengths, sv)
@@ -816,6 +831,7 @@ class Engine:
                 teacher_force = plan[last]["tf"] if plan is not None else (rng.random() < teacher_forcing_ratio)
                 rec = bar_saved[last]
                 last_rows = {name: (staff[name][0][(nb - 1) * Bg:], staff[name][1][(nb - 1) * Bg:]) for name in staff}
+                _trace(f"g{gidx} seg {seg_i} joined")
                 token, rec["tok_rec"], rec["next_ids"] = next_token(last, teacher_force, last_rows, rec["heads"])
                 rec["teacher_force"] = teacher_force
             gs = dict(range=(b0, b1), bars=bar_saved, segments=seg_saved, sos_rec=sos_rec, keys=keys_g, enc=enc_g,

@@ -130,7 +130,7 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     dctx_all = torch.empty((n, B, H2), dtype=torch.float32, device=dev)
     m_active = sv["active"].get("m_active") if sv.get("active") else None
     # (with m_active the per-step products skip the rows of finished clips: their dx rows are never written and must read as zero)
-    dx = (torch.zeros if sv.get("active") else torch.empty)((n, B, ldx), dtype=torch.float32, device=dev)
+    dx = torch.empty((n, B, ldx), dtype=torch.float32, device=dev)          # (zero-filled by a2s_note_decoder_bwd when rows are skipped)
     dh = torch.empty((2, B, H2), dtype=torch.float32, device=dev)
     a = hip.NoteDecBwdArgs()
     for name, t in (("attn_w", S[prefix + ".attn.attn.weight"]), ("attn_v", S[prefix + ".attn.v.weight"]), ("w_ih", S[prefix + ".gru.weight_ih_l0"]),

@@ -28,6 +28,8 @@ def main():
     b = synthetic.make_batch(a.batch, cfg, 1234, full_tail=a.full_tail)
     b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
     marks = []
+    host_marks = []
+    import time
 
     def mark(name):
         e = torch.cuda.Event(enable_timing=True)
@@ -39,7 +41,9 @@ def main():
 
         def f(*args, **kw):
             mark("before " + name)
+            host_marks.append((name + " called", time.time()))
             r = orig(*args, **kw)
+            host_marks.append((name + " returned", time.time()))
             mark(name)
             return r
         setattr(obj, attr, f)
@@ -84,10 +88,25 @@ def main():
     seg_marks = []
     if a.segments:
         import threading
+
+        def hwrap(obj, attr, name):
+            orig = getattr(obj, attr)
+
+            def f(*args, **kw):
+                host_marks.append((name + " called", time.time()))
+                r = orig(*args, **kw)
+                host_marks.append((name + " returned", time.time()))
+                return r
+            setattr(obj, attr, f)
+        engine._HOST_TRACE = host_marks
+        hwrap(train, "plan_clip_groups", "plan_clip_groups")
+        hwrap(engine.Engine, "_keys", "keys")
+
         lock = threading.Lock()
         orig_ds = engine.Engine._decode_staff
 
         def ds(self, S, prefix, keys, enc, h0, maxs, probs, gt_bar, steps, *rest):
+            host_marks.append((f"host reaches fwd {prefix.split('.')[-1][:5]} rows {h0.shape[0]}", time.time()))
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig_ds(self, S, prefix, keys, enc, h0, maxs, probs, gt_bar, steps, *rest)
@@ -110,12 +129,12 @@ def main():
             return r
         engine_bwd._note_decoder_bwd = nb
     totals = {}
-    import time
     walls = []
     for k in range(a.steps + 1):
         marks.clear()
         gmarks.clear()
         seg_marks.clear()
+        host_marks.clear()
         mark("start")
         t0 = time.time()
         step(b, 0.7, rng=random.Random(100 + k))
@@ -133,6 +152,7 @@ def main():
     for n, t in totals.items():
         print(f"{t / a.steps:9.1f} ms  {100 * t / tot:5.1f} %  {n}")
     if a.segments:
+        print("host clock of the LAST step (ms after the step was called): " + "; ".join(f"{n} {1e3 * (t - t0):.1f}" for n, t in host_marks))
         print("note-decoder calls of the LAST step (start ms after the step's start, duration ms, us per decode step):")
         for n, e0, e1, st in sorted(seg_marks, key=lambda m: marks[0][1].elapsed_time(m[1])):
             t0, d = marks[0][1].elapsed_time(e0), e0.elapsed_time(e1)

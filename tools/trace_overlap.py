@@ -94,3 +94,18 @@ for q in sorted(set(k[3] for k in gb)):
     print(f"\nbulk group, backward, queue {q}: 30 consecutive kernels:")
     for k in v[i0:i0 + 30]:
         print(f"  {k[1] - mid[1]:9.1f} {k[2] - k[1]:7.1f}  s{k[4]}  {k[0][:70]}")
+
+# ---- the bar-level chain: what the main stream runs between the end of the encoder and the first note-decoder step of a training step
+enc = [i for i, k in enumerate(K) if k[0].startswith("gru_step_fwd_fused")]
+if enc:
+    # last encoder step kernel of the LAST training step in the trace
+    last = enc[-1]
+    stream0 = K[last][4]
+    print(f"\nafter the encoder of the last traced step: the next 70 kernels of every stream (start us relative to the encoder's last step, duration, queue, stream, kernel):")
+    t_ref = K[last][2]
+    n = 0
+    for k in K[last + 1:]:
+        print(f"  {k[1] - t_ref:9.1f} {k[2] - k[1]:7.1f}  q{k[3]} s{k[4]}  {k[0][:70]}")
+        n += 1
+        if n >= 70:
+            break
