@@ -64,6 +64,38 @@ def side_streams(device, group=0):
     return _SIDE_STREAMS[key]
 
 
+class _PinnedPool:
+    """Two pinned staging areas per device, used alternately by consecutive forward passes (the uploads of pass k have long completed when
+    pass k + 2 starts: every pass ends with the caller's stream waiting for all of its streams, and the training step synchronises once
+    per step)."""
+
+    def __init__(self, nbytes=8 << 20):
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.cur, self.off = 0, 0
+
+    def next_pass(self):
+        self.cur ^= 1
+        self.off = 0
+
+    def take(self, nbytes, dtype, shape):
+        off = (self.off + 63) & ~63
+        if nbytes == 0 or off + nbytes > self.bufs[self.cur].numel():
+            return None
+        self.off = off + nbytes
+        return self.bufs[self.cur][off:off + nbytes].view(dtype).view(shape)
+
+
+_PINNED_POOLS = {}
+
+
+def _pinned_pool(device):
+    key = _dev_index(device)
+    if key not in _PINNED_POOLS:
+        _PINNED_POOLS[key] = _PinnedPool()
+    _PINNED_POOLS[key].next_pass()
+    return _PINNED_POOLS[key]
+
+
 _HOST_TRACE = None        # tools/phase_times.py --segments: a list that receives (label, host time) at the decoder's host-side milestones
 
 
@@ -527,16 +559,26 @@ class Engine:
         # host->device uploads go through pinned memory without synchronising (a pageable upload would drain the stream each time).
         mask = (torch.rand((B * T, cfg["conv_feature_size"]), device=dev) >= 0.2).to(torch.uint8) if drop_on else None
         conv_out, conv_saved = self.convstack(S, spectrogram, training, mask)
-        enc, hidden, enc_saved = self.encoder(S, conv_out, training)
-        enc2d = enc.view(B * T, 2 * H)
-        keys = {p: self._keys(S, p + ".attn", enc2d, H) for p in ("decoder", "decoder.upper_decoder", "decoder.lower_decoder")}
+        # (the encoder is enqueued AFTER the host plan below: its ~4800 launches can block the issuing threads until the GPU has worked
+        # most of them off, and a plan made after that wait reaches the decoder late -- tools/phase_times.py --segments: 195 ms into the
+        # step on the host against 90 ms on the GPU)
         pinned = []                                      # keeps the staging buffers alive until the step is over
         pin_lock = threading.Lock()
+        pool = _pinned_pool(dev)
 
         def upload(t):
-            p = t.contiguous().pin_memory()
+            # small host -> device uploads of the plan, staged in a pinned pool that lives as long as the process: Tensor.pin_memory()
+            # calls hipHostMalloc whenever a size has no cached block -- tens of milliseconds during which every thread of the step
+            # stands still (tools/phase_times.py --segments showed both clip groups frozen for 85 ms in steps whose segmentation had not
+            # occurred before)
+            t = t.contiguous()
+            nbytes = t.numel() * t.element_size()
             with pin_lock:
-                pinned.append(p)
+                p = pool.take(nbytes, t.dtype, t.shape)
+                if p is None:
+                    p = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                    pinned.append(p)
+            p.copy_(t)
             return p.to(dev, non_blocking=True)
 
         maxlen = (U, Lo)
@@ -601,6 +643,9 @@ class Engine:
         # the two staves of a segment run on two streams, each issued by its own host thread -- also in greedy decoding, where each
         # thread polls the done counter of its own stream (the hipGraph variant captures on one created stream and stays sequential)
         concurrent = getattr(self, "concurrent_staves", True) and not greedy_graph
+        enc, hidden, enc_saved = self.encoder(S, conv_out, training)
+        enc2d = enc.view(B * T, 2 * H)
+        keys = {p: self._keys(S, p + ".attn", enc2d, H) for p in ("decoder", "decoder.upper_decoder", "decoder.lower_decoder")}
         enc_hidden = hidden
 
         def decode_group(gidx, b0, b1, gen):
@@ -849,11 +894,13 @@ class Engine:
             # group 0 on the caller's thread and stream; every other group on a host thread and stream set of its own, forked from and
             # joined to the caller's stream.  Dropout masks: one generator per group, seeded from torch's (seeded) CPU generator, so
             # that a seed still fixes the run whatever the interleaving of the threads.
+            _trace("decoder about to start (generators next)")
             gens = []
             for _ in clip_groups:
                 g_ = torch.Generator(device=dev)
                 g_.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
                 gens.append(g_)
+            _trace("generators made")
             group_saved = run_clip_groups(dev, [lambda gi=gi, r=r: decode_group(gi, r[0], r[1], gens[gi]) for gi, r in enumerate(clip_groups)])
         self.saved = dict(conv=conv_saved, enc=enc_saved, keys=keys, groups=group_saved, enc_out=enc,
                           bars=group_saved[0]["bars"], segments=group_saved[0]["segments"], sos_rec=group_saved[0]["sos_rec"],
