@@ -48,11 +48,13 @@ def _ridge_spectrogram(rng, frames, bins):
 
 
 def make_batch(batch, cfg, seed, frames=1201, upper_range=(20, 120), lower_range=(10, 80),
-               full_tail=0.01, device="cpu", spectrogram="uniform"):
+               full_tail=0.01, device="cpu", spectrogram="uniform", full_rows=()):
     """Deterministic batch.  Lengths ~ U{range}; with probability ``full_tail`` per (clip, bar, staff)
     the row is full-length with no <eos> (exercises the max-steps cap).  ``spectrogram``: "uniform"
     (U[0,1) noise) or "ridges" (clip-specific sustained partials on a noise floor, so that
-    different clips encode differently -- used by parity fixtures to catch batch-indexing errors)."""
+    different clips encode differently -- used by parity fixtures to catch batch-indexing errors).  ``full_rows``: (clip, bar, "up" | "lo")
+    rows that are full-length whatever the draw says (parity fixtures place the max-steps cap where they want it)."""
+    forced = {(int(b), int(k), str(s)) for b, k, s in full_rows}
     rng = np.random.default_rng(seed)
     bars = cfg["max_bars"]
     U, L = cfg["max_length"]
@@ -71,19 +73,21 @@ def make_batch(batch, cfg, seed, frames=1201, upper_range=(20, 120), lower_range
             if rng.random() > 0.9:
                 key[b, k:] = rng.integers(0, cfg["num_keys"])
 
-    def staff(maxlen, lo, hi):
+    def staff(maxlen, lo, hi, which):
         rows = np.empty((batch, bars, maxlen), dtype=np.int64)
         lens = np.empty((batch, bars), dtype=np.int64)
         for b in range(batch):
             for k in range(bars):
                 n = maxlen if rng.random() < full_tail else int(rng.integers(min(lo, maxlen), min(hi, maxlen) + 1))
+                if (b, k, which) in forced:
+                    n = maxlen
                 toks = _NOTE_IDS[rng.integers(0, len(_NOTE_IDS), size=n)]
                 rows[b, k] = pad_measure(toks, maxlen)
                 lens[b, k] = min(n, maxlen)
         return rows, lens
 
-    up, up_len = staff(U, *upper_range)
-    lo, lo_len = staff(L, *lower_range)
+    up, up_len = staff(U, *upper_range, "up")
+    lo, lo_len = staff(L, *lower_range, "lo")
     t = lambda a: torch.from_numpy(a).to(device)
     names = [f"syn{seed}_{b}~synthetic" for b in range(batch)]
     return (t(spec), t(ts), t(key), t(up), t(up_len), t(lo), t(lo_len), names,

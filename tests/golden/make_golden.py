@@ -7,7 +7,7 @@ procedural weights (piano_a2s_amd.spec.procedural_state) and synthetic batches
 (piano_a2s_amd.synthetic.make_batch), and stores inputs' checksums + the reference's outputs.
 Nothing of the reference's text is stored: fixtures are numbers.
 
-Usage:  python tests/golden/make_golden.py [g1] [g2] [g2tf] [tok]
+Usage:  python tests/golden/make_golden.py [g1] [g2] [g2tf] [g3] [tok]
 The fixtures are committed; this script documents how they were made and can regenerate them.
 """
 import hashlib
@@ -299,6 +299,96 @@ def make_g2_tf(ref_models, seed=2032, eb=2.5, tf=0.7, rseeds=(3, 5, 9, 12)):
     print("g2_tf written: seed", rseed, "losses", out["losses"].tolist())
 
 
+def margin_summary(o):
+    """Top-2 margins of the decoded rows of a staff output: histogram over decades + the smallest ones (how far every argmax is from a tie)."""
+    o = o.detach()
+    decoded = o.abs().sum(-1) > 0
+    top2 = o.topk(2, dim=-1).values
+    mg = (top2[..., 0] - top2[..., 1])
+    vals = mg[decoded].double().numpy()
+    edges = [0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, float("inf")]
+    hist = np.histogram(vals, bins=edges)[0].tolist() if vals.size else [0] * 8
+    return mg.numpy().astype(np.float32), {"decisions": int(vals.size), "hist_edges": edges[:-1] + ["inf"], "hist": hist,
+                                           "below_1e-3": int((vals < 1e-3).sum()), "min": float(vals.min()) if vals.size else None}
+
+
+G3_BATCH = dict(frames=1201, upper_range=(6, 24), lower_range=(4, 16), full_tail=0.0, spectrogram="ridges")
+G3_CASES = {
+    # name: (weights seed, eos bias, batch size, batch seed, rows forced to full length, mode, tf, python-random seed)
+    "s2041_greedy": (2041, 2.5, 2, 78, (), "greedy", 0.0, None),
+    "s2057_greedy": (2057, 2.5, 2, 79, (), "greedy", 0.0, None),
+    "b4_greedy": (2032, 2.5, 4, 80, (), "greedy", 0.0, None),
+    "tail_tf1": (2041, 2.5, 2, 81, ((0, 1, "up"), (1, 3, "lo")), "train", 1.0, None),        # full-length bars WITHOUT <eos>, teacher forced
+    "tf06": (2057, 2.5, 2, 78, (), "train", 0.6, 4),                                       # reference finetune.py:44 ratio
+}
+
+
+def make_g3(ref_models, only=None):
+    """Round 4: more weight seeds, a B = 4 batch, a train-mode case with full-length bars that never show <eos>, and the
+    finetune teacher-forcing ratio.  Seeds are NOT screened for margins: the margin histogram of every case is stored and the parity test
+    reports how many decisions lie below 1e-3 (two correct fp32 implementations may legitimately part ways at such a decision)."""
+    cfg = spec.default_cfg()
+    meta_path = os.path.join(HERE, "g3_full.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {"batch_kwargs": {k: list(v) if isinstance(v, tuple) else v for k, v in G3_BATCH.items()},
+                                                                         "cases": {}}
+    no_dropout()
+    for name, (wseed, eb, B, bseed, full_rows, mode, tf, rseed) in G3_CASES.items():
+        if only and name not in only:
+            continue
+        st = spec.procedural_state(cfg, wseed, eos_bias=eb, lively="token")
+        batch = synthetic.make_batch(B, cfg, bseed, full_rows=full_rows, **G3_BATCH)
+        m = ref_models.ScoreTranscription(**cfg)
+        m.load_state_dict(st)
+        out = {}
+        cm = {"weights_seed": wseed, "eos_bias": eb, "lively": "token", "batch": B, "batch_seed": bseed, "full_rows": [list(r) for r in full_rows],
+              "mode": mode, "tf": tf, "random_seed": rseed, "state_sha256": digest(st.values()),
+              "batch_sha256": digest([batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]])}
+        g = np.random.default_rng(2)
+        if mode == "greedy":
+            m.eval()
+            with torch.no_grad():
+                outs = m(spectrogram=batch[0], inference=True, ground_truth=None, teacher_forcing_ratio=0., device="cpu")
+        else:
+            m.train()
+            if rseed is not None:
+                random.seed(rseed)
+            state0 = random.getstate()
+            outs = m(spectrogram=batch[0], inference=False, ground_truth=gt_of(batch), teacher_forcing_ratio=tf, device="cpu")
+            state1 = random.getstate()
+            random.setstate(state0)
+            draws = 0
+            while random.getstate() != state1 and draws < 100000:
+                random.random()
+                draws += 1
+            cm["draws"] = draws
+            losses = ref_losses(outs, batch)
+            losses[0].backward()
+            out["losses"] = np.array([float(l) for l in losses], dtype=np.float64)
+            names, norms = [], []
+            for k, p in m.named_parameters():
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+            out["gradnorms"] = np.array(norms)
+            cm["grad_names"] = names
+        ts, key, up, lo = [o.detach() for o in outs]
+        out["ts"], out["key"] = ts.numpy(), key.numpy()
+        cm["margins"] = {}
+        for nm, o in (("up", up), ("lo", lo)):
+            out[f"{nm}_ids"] = o.argmax(-1).numpy().astype(np.int16)
+            out[f"{nm}_rows"] = (o.abs().sum(-1) > 0).sum(-1).numpy().astype(np.int16)
+            idx = g.integers(0, o.numel(), size=2000)
+            out[f"{nm}_sample_idx"], out[f"{nm}_sample"] = idx, o.flatten()[idx].numpy()
+            out[f"{nm}_margin"], cm["margins"][nm] = margin_summary(o)
+        print("g3", name, "rows", out["up_rows"].tolist(), out["lo_rows"].tolist(), "margins", {k: (v["below_1e-3"], v["min"]) for k, v in cm["margins"].items()},
+              "losses", out.get("losses", np.zeros(0)).tolist(), flush=True)
+        np.savez_compressed(os.path.join(HERE, f"g3_{name}.npz"), **out)
+        meta["cases"][name] = cm
+        with open(meta_path, "w") as f:
+            json.dump(meta, f, indent=1)
+        del m, outs
+    print("g3 written")
+
+
 def make_tok(RefLabels):
     lab = RefLabels(extended=True)
     cases = ["4c", "4c\t8e 8g\n4r", "[2.CC#_ 4ee-;]\t.\n16ffff", "8.r\t4c 4e 4g", "16.BBB#]\t[8cccc-",
@@ -335,3 +425,6 @@ if __name__ == "__main__":
         make_g2(ref_models)
     if "g2tf" in what:
         make_g2_tf(ref_models)
+    if "g3" in what or any(w.startswith("g3:") for w in what):
+        only = [w[3:] for w in what if w.startswith("g3:")]
+        make_g3(ref_models, only or None)
