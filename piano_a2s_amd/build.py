@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liba2s_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
-SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_conv_rows.hip", "a2s_conv_wrows.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip", "a2s_vqt.hip", "a2s_step.hip"]
+SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_conv_rows.hip", "a2s_conv_wrows.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip", "a2s_vqt.hip", "a2s_step.hip", "a2s_persist.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
@@ -53,7 +53,10 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as pool:
         list(pool.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    # link next to the target and rename: a process that has the old library mapped keeps its (unlinked) file instead of seeing it rewritten
+    tmp = LIB + f".tmp{os.getpid()}"
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
+    os.replace(tmp, LIB)
     import json
     import time
     with open(os.path.join(OBJ, "build_info.json"), "w") as f:

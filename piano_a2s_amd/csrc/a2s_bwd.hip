@@ -308,7 +308,11 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     // whose rows fit them (see a2s_note_decoder_fwd_impl)
     auto step_rows = [&](int s) { return (a.row_list && a.n_rows_active) ? a.n_rows_active[s] : R; };
     auto step_fused = [&](int s) { const int n = step_rows(s); return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, 173, ptrs, 8, a.step_ws, a.step_ws_floats); };      // (the vocabulary size plays no role here)
-    if (a.steps > 0 && step_fused(a.steps - 1)) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }       // (the last step has the fewest rows)
+    // transposed weight copies for the few-row kernels: needed as soon as ANY step of the call runs on them (the last step has the fewest rows,
+    // but it may have none at all -- a row without <eos> whose last targets are <pad> -- while earlier steps still have 1 .. max_rows)
+    bool any_fused = false;
+    for (int s = a.steps - 1; s >= 0 && !any_fused; --s) any_fused = step_fused(s);
+    if (any_fused) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }
     for (int s = a.steps - 1; s >= 0; --s) {
         const bool fused = step_fused(s);
         a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : R, a.n_active ? a.n_active[s] : 0, s};
@@ -369,6 +373,11 @@ int a2s_gru_bptt_step_impl(hipStream_t st, const float* dgh, const float* w_hh_t
                            const float* save, const float* hprev, long ld_hprev, float* dgi, long ld_dgi, float* dgh_out, float* dgh2,
                            long ld_dgh2, float* dhz_out, int R, int H);
 
+bool a2s_gru_seq_bwd_persist_ok(int B, int T, int H, float* ws, size_t ws_bytes, size_t ws_used);
+int a2s_gru_seq_bwd_persist_impl(hipStream_t st, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride, long out_tstride,
+                                 const float* gates, const float* w_hh_t, const float* dhn, float* dgi_all, float* dgh_shift, float* dgh_first, int B, int T,
+                                 int H, int reverse, float* ws, size_t ws_off, size_t ws_bytes);
+
 // out[c][r] = in[r][c]  (rows x cols -> cols x rows); small parameter matrices only
 __global__ void transpose_f32(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,6 +403,10 @@ int a2s_gru_seq_bwd_impl(hipStream_t st, const float* dout, long do_bstride, lon
         hipLaunchKernelGGL(transpose_f32, dim3(a2s_cdiv(3 * H * H, 256)), dim3(256), 0, st, w_hh, ws, 3 * H, H);
         A2S_CHECK_LAUNCH("transpose_f32");
     }
+    // one persistent launch for all T steps (a2s_persist.hip); its granule buffers live behind W_hh^T in the workspace
+    if (fused && a2s_gru_seq_bwd_persist_ok(B, T, H, ws, ws_bytes, sizeof(float) * 3 * (size_t)H * H))
+        return a2s_gru_seq_bwd_persist_impl(st, dout, do_bstride, do_tstride, out, out_bstride, out_tstride, gates, ws, dhn, dgi_all, dgh_shift, dgh_first, B, T, H,
+                                            reverse, ws, sizeof(float) * 3 * (size_t)H * H, ws_bytes);
     if (fused && ws_bytes >= sizeof(float) * (3 * (size_t)H * H + 3 * (size_t)B * H) && (3 * H * H) % 4 == 0) {
         // ONE launch per step: the carry product of step s with the gate backward of step s-1 on its accumulators
         // (gru_bptt_step_fused); the two dgh scratch buffers alternate (this launch reads one as its A operand and writes the other)
@@ -714,6 +727,7 @@ int a2s_staff_emb_bwd_impl(hipStream_t st, const float* note_emb, const float* c
 // =========================================================================================== split-T attention backward (H = 256)
 // Same decomposition as attn_fwd_split256: G workgroups per clip, each streams its chunk of enc (for da_t) and of K (for dq) once
 // with 16-byte loads; partial dq per (clip, g) merged by a small combine kernel.
+template <bool NT>
 __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                          const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                          const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
@@ -757,18 +771,15 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
         for (int u = 0; u < 4; ++u) {
             s[u] = 0.f;
             if (r + u < n) {
-                const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + lane * 4);
-                const f32x4 e1 = *reinterpret_cast<const f32x4*>(Eb + (long)(r + u) * 2 * H + H + lane * 4);
+                const f32x4 e0 = ld_kv<NT>(Eb + (long)(r + u) * 2 * H + lane * 4);
+                const f32x4 e1 = ld_kv<NT>(Eb + (long)(r + u) * 2 * H + H + lane * 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) s[u] += dc0[c] * e0[c] + dc1[c] * e1[c];
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o, 64);
-        }
-        if (lane == 0) {
+        for (int u = 0; u < 4; ++u) s[u] = wave_sum_lane63(s[u]);
+        if (lane == 63) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (r + u < n) {
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
     for (; i + 12 < n; i += 16) {
         f32x4 k[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = *reinterpret_cast<const f32x4*>(Kb + (long)(i + 4 * u) * H + c4 * 4);
+        for (int u = 0; u < 4; ++u) k[u] = ld_kv<NT>(Kb + (long)(i + 4 * u) * H + c4 * 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float w = dsv[i + 4 * u];
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
         }
     }
     for (; i < n; i += 4) {
-        const f32x4 k0 = *reinterpret_cast<const f32x4*>(Kb + (long)i * H + c4 * 4);
+        const f32x4 k0 = ld_kv<NT>(Kb + (long)i * H + c4 * 4);
         const float w = dsv[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = fmaf(w, sech2_ek(k0[c], q4[c]), acc[c]);
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
 
 // Fused bars (see attn_fwd_split256_mq): NQ rows of one clip per workgroup, the clip's enc and K chunk streamed once for all of them.
 #define ATT_DCS 516             // floats per row of the dctx image in LDS (2H + 4: the rows of a clip land 4 banks apart)
-template <int NQ>
+template <int NQ, bool NT>
 __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                             const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                             const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
@@ -895,8 +906,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};       // two chains: a dependent 16x16x4 waits 40 cycles, an independent one 32
 #pragma unroll 4
             for (int u = 0; u < 16; ++u) {
-                f32x4 e0 = *reinterpret_cast<const f32x4*>(ep + 32 * u);
-                f32x4 e1 = *reinterpret_cast<const f32x4*>(ep + 32 * u + 4);
+                f32x4 e0 = ld_kv<NT>(ep + 32 * u);
+                f32x4 e1 = ld_kv<NT>(ep + 32 * u + 4);
                 if (!valid) e0 = e1 = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     for (; i + 12 < n; i += 16) {
         f32x4 k[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = *reinterpret_cast<const f32x4*>(Kb + (long)(i + 4 * u) * H + c4 * 4);
+        for (int u = 0; u < 4; ++u) k[u] = ld_kv<NT>(Kb + (long)(i + 4 * u) * H + c4 * 4);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (!on[j]) continue;
@@ -949,7 +960,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
         }
     }
     for (; i < n; i += 4) {
-        const f32x4 k0 = *reinterpret_cast<const f32x4*>(Kb + (long)i * H + c4 * 4);
+        const f32x4 k0 = ld_kv<NT>(Kb + (long)i * H + c4 * 4);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (!on[j]) continue;
@@ -1010,9 +1021,11 @@ __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restri
 template <int NQ>
 static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                           const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
-                          float* dctx_out, long lddo, float* ws, float* ds_out, int T, int G, int chunk, const a2s_attn_rows& r) {
-    hipLaunchKernelGGL(attn_bwd_split256_mq<NQ>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
-                       dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
+                          float* dctx_out, long lddo, float* ws, float* ds_out, int T, int G, int chunk, const a2s_attn_rows& r, bool nt) {
+    if (nt) hipLaunchKernelGGL((attn_bwd_split256_mq<NQ, true>), dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                               dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
+    else hipLaunchKernelGGL((attn_bwd_split256_mq<NQ, false>), dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                            dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
 }
 
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
@@ -1033,16 +1046,19 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     A2S_REQUIRE(r.n_active >= 0 && r.n_active <= r.n_clips && (!r.clip_order || r.clip_rank), "attn_step_bwd_split: bad row compaction");
     int G = 1, chunk = T;
     ws += A2S_ATTN_TICKETS;                 // the head of the workspace holds the arrival counters of the fused combines (a2s_seq.hip)
+    const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled();      // see a2s_attn_step_fwd_split_impl
     if (r.n_active > 0) {
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G;
         if (groups == 1) {
             const size_t shm = (chunk + 3 * 64 * 4) * sizeof(float);
-            hipLaunchKernelGGL(attn_bwd_split256, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
-                               dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
+            if (nt) hipLaunchKernelGGL(attn_bwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                                       dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
+            else hipLaunchKernelGGL(attn_bwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                                    dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
         } else {
             const size_t shm = ((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4 + (size_t)groups * ATT_DCS + 16) * sizeof(float);
-#define A2S_BWD_MQ(N) launch_bwd_mq<N>(st, nwg, shm, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r)
+#define A2S_BWD_MQ(N) launch_bwd_mq<N>(st, nwg, shm, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r, nt)
             switch (groups) {
                 case 2: A2S_BWD_MQ(2); break;
                 case 3: A2S_BWD_MQ(3); break;

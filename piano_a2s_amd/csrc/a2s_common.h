@@ -61,12 +61,18 @@ static inline int a2s_attn_max_split(void) {
     if (!v) { const char* e = getenv("A2S_ATTN_MAX_SPLIT"); v = e ? atoi(e) : 16; if (v < 1) v = 16; }
     return v;
 }
-// measurement only (results are wrong): the split attention kernels of calls with more than 64 clips read this percentage of the frames --
-// predicts what a launch that moves fewer bytes would be worth to the training step
+// measurement only (results are wrong; compiled in only with -DA2S_MEASURE_FAKE_T, piano_a2s_amd.build.build_variant): the split attention
+// kernels of calls with more than 64 clips read A2S_ATTN_FAKE_T percent of the frames -- predicts what a launch that moves fewer bytes would be
+// worth to the training step.  The product library ignores the variable.
 static inline int a2s_attn_fake_t(int T, int n_clips) {
+#ifdef A2S_MEASURE_FAKE_T
     static int pct = -1;
     if (pct < 0) { const char* e = getenv("A2S_ATTN_FAKE_T"); pct = e ? atoi(e) : 100; if (pct < 1 || pct > 100) pct = 100; }
     return (pct == 100 || n_clips <= 64) ? T : ((T * pct / 100) & ~3);
+#else
+    (void)n_clips;
+    return T;
+#endif
 }
 static inline void a2s_attn_split_geometry(int B, int T, int* G, int* chunk) {
     const int target = a2s_attn_target_wgs();
@@ -96,19 +102,55 @@ struct a2s_attn_rows {
 // head of the attention workspace: arrival counters of the fused combine (forward: [0, 4096), backward: [4096, 8192)), in floats
 #define A2S_ATTN_TICKETS 8192
 
+// Streaming K / enc loads of the split attention kernels: 0 = off, n > 0 = launches covering at least n clips use non-temporal loads
+// (A2S_ATTN_NT / a2s_debug_set("attn_nt", n)).
+int a2s_attn_nt_enabled(void);
+void a2s_attn_nt_set(int v);
+
 // ----------------------------------------------------------------------------- device helpers
 #ifdef __HIPCC__
 #define A2S_WAVE 64
+// 16-byte load of 4 floats, optionally non-temporal (a stream that is read once per launch and is far larger than the caches)
+template <bool NT>
+__device__ __forceinline__ f32x4 ld_kv(const float* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    else return *reinterpret_cast<const f32x4*>(p);
+}
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide reductions on the DPP data path (row shifts / mirrors / broadcasts riding on VALU instructions) -- `__shfl_xor` compiles to
+// ds_bpermute_b32, i.e. every step of a butterfly goes through the LDS crossbar: ~6 dependent LDS round trips per reduced value, and the
+// attention kernels reduce one value per (frame, row).  Six DPP adds leave the total in lane 63; v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float dpp_take(float oldv, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+#define A2S_DPP_QUAD_1032 0xB1
+#define A2S_DPP_QUAD_2301 0x4E
+#define A2S_DPP_ROW_HALF_MIRROR 0x141
+#define A2S_DPP_ROW_MIRROR 0x140
+#define A2S_DPP_ROW_BCAST15 0x142
+#define A2S_DPP_ROW_BCAST31 0x143
+// sum over the 64 lanes, valid in lane 63 only
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_take<A2S_DPP_QUAD_1032>(0.f, v);
+    v += dpp_take<A2S_DPP_QUAD_2301>(0.f, v);
+    v += dpp_take<A2S_DPP_ROW_HALF_MIRROR>(0.f, v);
+    v += dpp_take<A2S_DPP_ROW_MIRROR>(0.f, v);                      // every lane: the sum of its row of 16
+    v += dpp_take<A2S_DPP_ROW_BCAST15, 0xA>(0.f, v);                // rows 1, 3 += lane 15 of the row below
+    v += dpp_take<A2S_DPP_ROW_BCAST31, 0xC>(0.f, v);                // rows 2, 3 += lane 31
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_lane63(v)), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_take<A2S_DPP_QUAD_1032>(v, v));
+    v = fmaxf(v, dpp_take<A2S_DPP_QUAD_2301>(v, v));
+    v = fmaxf(v, dpp_take<A2S_DPP_ROW_HALF_MIRROR>(v, v));
+    v = fmaxf(v, dpp_take<A2S_DPP_ROW_MIRROR>(v, v));
+    v = fmaxf(v, dpp_take<A2S_DPP_ROW_BCAST15, 0xA, false>(v, v));
+    v = fmaxf(v, dpp_take<A2S_DPP_ROW_BCAST31, 0xC, false>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

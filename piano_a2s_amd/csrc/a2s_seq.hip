@@ -252,6 +252,10 @@ bool a2s_gru_step_fused_enabled(void) {
 }
 static bool gru_step_fusable(const float* w_hh, int H) { return a2s_gru_step_fused_enabled() && H % 16 == 0 && ((uintptr_t)w_hh % 16 == 0); }
 
+bool a2s_gru_seq_fwd_persist_ok(const float* w_hh, const float* gi, int B, int T, int H, float* ws, size_t ws_bytes);
+int a2s_gru_seq_fwd_persist_impl(hipStream_t st, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh, const float* b_hh, float* out,
+                                 long out_bstride, long out_tstride, float* save, float* hn, int B, int T, int H, int reverse, float* ws, size_t ws_bytes);
+
 // One direction of one encoder GRU layer over all T steps (h0 = 0).
 //   gi_all : (B, T, 3H) = x W_ih^T + b_ih for this direction (row stride ld_gi between time steps of a clip)
 //   out    : (B, T, ldo) -- h_t is written at column offset `col0` (fwd dir 0, reverse dir H)
@@ -261,6 +265,9 @@ int a2s_gru_seq_fwd_impl(hipStream_t st, const float* gi_all, long gi_bstride, l
                          const float* b_hh, float* out, long out_bstride, long out_tstride, float* hbuf, float* gh,
                          float* save, float* hn, int B, int T, int H, int reverse, float* ws, size_t ws_bytes) {
     A2S_REQUIRE(gi_all && w_hh && b_hh && out && hbuf && gh && hn, "gru_seq_fwd: null tensor");
+    // one persistent launch for all T steps (a2s_persist.hip) when the shape allows it
+    if (a2s_gru_seq_fwd_persist_ok(w_hh, gi_all, B, T, H, ws, ws_bytes))
+        return a2s_gru_seq_fwd_persist_impl(st, gi_all, gi_bstride, gi_tstride, w_hh, b_hh, out, out_bstride, out_tstride, save, hn, B, T, H, reverse, ws, ws_bytes);
     hipError_t e = hipMemsetAsync(hbuf, 0, sizeof(float) * B * H, st);
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "gru_seq_fwd memset: %s", hipGetErrorString(e));
     for (int s = 0; s < T; ++s) {
@@ -883,6 +890,7 @@ struct AttnFusedTail { int* tickets; float* ctx; long ldctx; float* ctx2; long l
 // streams its chunk of K and enc ONCE with 16-byte loads and produces a partial softmax (m_g, l_g, ctx_g); a small combine
 // kernel merges the G partials per clip.  Grid = B*G workgroups, G chosen so the grid is a few waves of the 256 CUs.
 //   partial layout per (clip, g): [m, l, pad, pad, ctx(2H)]  -> (2H + 4) floats
+template <bool NT>
 __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                          const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                          float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
@@ -915,7 +923,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
         f32x4 k[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            k[u] = (r + u < n) ? *reinterpret_cast<const f32x4*>(Kb + (long)(r + u) * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            k[u] = (r + u < n) ? ld_kv<NT>(Kb + (long)(r + u) * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         float s[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -923,11 +931,8 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
                  + v4[2] * tanh_ek(k[u][2], q4[2]) + v4[3] * tanh_ek(k[u][3], q4[3]);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o, 64);
-        }
-        if (lane == 0) {
+        for (int u = 0; u < 4; ++u) s[u] = wave_sum_lane63(s[u]);
+        if (lane == 63) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (r + u < n) pw[r + u] = s[u];
         }
@@ -950,16 +955,16 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int i = rp;
     for (; i + 6 < n; i += 8) {
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 0) * 2 * H + c4 * 4);
-        const f32x4 e1 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 2) * 2 * H + c4 * 4);
-        const f32x4 e2 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 4) * 2 * H + c4 * 4);
-        const f32x4 e3 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 6) * 2 * H + c4 * 4);
+        const f32x4 e0 = ld_kv<NT>(Eb + (long)(i + 0) * 2 * H + c4 * 4);
+        const f32x4 e1 = ld_kv<NT>(Eb + (long)(i + 2) * 2 * H + c4 * 4);
+        const f32x4 e2 = ld_kv<NT>(Eb + (long)(i + 4) * 2 * H + c4 * 4);
+        const f32x4 e3 = ld_kv<NT>(Eb + (long)(i + 6) * 2 * H + c4 * 4);
         const float w0 = pw[i], w1 = pw[i + 2], w2 = pw[i + 4], w3 = pw[i + 6];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] += w0 * e0[c] + w1 * e1[c] + w2 * e2[c] + w3 * e3[c];
     }
     for (; i < n; i += 2) {
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)i * 2 * H + c4 * 4);
+        const f32x4 e0 = ld_kv<NT>(Eb + (long)i * 2 * H + c4 * 4);
         const float w0 = pw[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] += w0 * e0[c];
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split256(const float* __restrict
 // Fused bars: NQ rows (bars) of one clip per workgroup -- the clip's K and enc chunk is streamed ONCE and applied to every unfinished
 // row of the clip, so the HBM bytes per decoded row drop by the number of rows sharing the clip.  Same two passes and the same
 // partial layout as attn_fwd_split256; partial of (slot, j, g) at ((slot * NQ + j) * G + g).
-template <int NQ>
+template <int NQ, bool NT>
 __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                             const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                             float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
@@ -1027,7 +1032,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
         f32x4 k[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            k[u] = (r + u < n) ? *reinterpret_cast<const f32x4*>(Kb + (long)(r + u) * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            k[u] = (r + u < n) ? ld_kv<NT>(Kb + (long)(r + u) * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (!on[j]) continue;
@@ -1037,11 +1042,8 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
                 sj[u] = v4[0] * tanh_ek(k[u][0], q4[j][0]) + v4[1] * tanh_ek(k[u][1], q4[j][1])
                       + v4[2] * tanh_ek(k[u][2], q4[j][2]) + v4[3] * tanh_ek(k[u][3], q4[j][3]);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) sj[u] += __shfl_xor(sj[u], o, 64);
-            }
-            if (lane == 0) {
+            for (int u = 0; u < 4; ++u) sj[u] = wave_sum_lane63(sj[u]);
+            if (lane == 63) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (r + u < n) pw[j * chunk + r + u] = sj[u];
             }
@@ -1074,10 +1076,10 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
     for (int j = 0; j < NQ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int i = rp;
     for (; i + 6 < n; i += 8) {
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 0) * 2 * H + c4 * 4);
-        const f32x4 e1 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 2) * 2 * H + c4 * 4);
-        const f32x4 e2 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 4) * 2 * H + c4 * 4);
-        const f32x4 e3 = *reinterpret_cast<const f32x4*>(Eb + (long)(i + 6) * 2 * H + c4 * 4);
+        const f32x4 e0 = ld_kv<NT>(Eb + (long)(i + 0) * 2 * H + c4 * 4);
+        const f32x4 e1 = ld_kv<NT>(Eb + (long)(i + 2) * 2 * H + c4 * 4);
+        const f32x4 e2 = ld_kv<NT>(Eb + (long)(i + 4) * 2 * H + c4 * 4);
+        const f32x4 e3 = ld_kv<NT>(Eb + (long)(i + 6) * 2 * H + c4 * 4);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (!on[j]) continue;
@@ -1088,7 +1090,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
         }
     }
     for (; i < n; i += 2) {
-        const f32x4 e0 = *reinterpret_cast<const f32x4*>(Eb + (long)i * 2 * H + c4 * 4);
+        const f32x4 e0 = ld_kv<NT>(Eb + (long)i * 2 * H + c4 * 4);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (!on[j]) continue;
@@ -1169,11 +1171,19 @@ int a2s_attn_fused_combine_enabled(void) {
     return g_attn_fused_combine;
 }
 static bool attn_fused_combine(void) { return a2s_attn_fused_combine_enabled() != 0; }
+static int g_attn_nt = -1;
+void a2s_attn_nt_set(int v) { g_attn_nt = v < 0 ? 0 : v; }
+int a2s_attn_nt_enabled(void) {
+    if (g_attn_nt < 0) { const char* e = getenv("A2S_ATTN_NT"); g_attn_nt = e ? atoi(e) : 0; if (g_attn_nt < 0) g_attn_nt = 0; }
+    return g_attn_nt;
+}
 template <int NQ>
 static void launch_fwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
-                          float* ws, float* attw, int T, int G, int chunk, const a2s_attn_rows& r, const AttnFusedTail& ft) {
-    hipLaunchKernelGGL(attn_fwd_split256_mq<NQ>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk,
-                       r.clip_order, r.row_until, r.step, r.n_clips, ft);
+                          float* ws, float* attw, int T, int G, int chunk, const a2s_attn_rows& r, const AttnFusedTail& ft, bool nt) {
+    if (nt) hipLaunchKernelGGL((attn_fwd_split256_mq<NQ, true>), dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk,
+                               r.clip_order, r.row_until, r.step, r.n_clips, ft);
+    else hipLaunchKernelGGL((attn_fwd_split256_mq<NQ, false>), dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk,
+                            r.clip_order, r.row_until, r.step, r.n_clips, ft);
 }
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
@@ -1198,20 +1208,24 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     // fused tail: one extra workgroup per clip (row) WITHOUT unfinished rows zero-fills its outputs
     const int n_zero = fused ? r.n_clips - r.n_active : 0;
     const AttnFusedTail ft = {fused ? tickets : nullptr, ctx, ldctx, ctx2, ldctx2, r.n_active, B};
+    // streaming (non-temporal) K / enc loads when many clips are active: the sweep is far larger than any cache, and the lines of a
+    // concurrently decoding few-clip group (its K / enc and its weights) then survive in L2 / Infinity Cache (A2S_ATTN_NT)
+    const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled();
     if (r.n_active > 0 || n_zero > 0) {
         // the grid covers the clips that still have unfinished rows, re-split so that it still fills the chip
         if (r.n_active > 0) a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G + n_zero;
         if (groups == 1) {
             const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
-            hipLaunchKernelGGL(attn_fwd_split256, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
+            if (nt) hipLaunchKernelGGL(attn_fwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
+            else hipLaunchKernelGGL(attn_fwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
         } else {
             const size_t shm = ((size_t)groups * chunk + 16 + (size_t)groups * 128 * 4) * sizeof(float);
             switch (groups) {
-                case 2: launch_fwd_mq<2>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
-                case 3: launch_fwd_mq<3>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
-                case 4: launch_fwd_mq<4>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
-                default: launch_fwd_mq<5>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft); break;
+                case 2: launch_fwd_mq<2>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;
+                case 3: launch_fwd_mq<3>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;
+                case 4: launch_fwd_mq<4>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;
+                default: launch_fwd_mq<5>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;
             }
         }
         A2S_CHECK_LAUNCH("attn_fwd_split256");

@@ -666,6 +666,7 @@ class Engine:
             else:
                 up_out_g, lo_out_g = up_out[b0:b1], lo_out[b0:b1]
                 gt_bm = None
+            _trace(f"g{gidx} views made")
             concurrent_g = concurrent and gidx <= 1           # (a third group would have no stream left: everything in order on its own)
             streams = staff_streams(dev, gidx) if concurrent_g else None
 

@@ -94,9 +94,11 @@ class ASR(sb.Brain):
     def _fused_step(self):
         """The fused HIP step needs the HIP model, Adadelta and the yaml's NLL objective; otherwise fall back to the generic path."""
         if getattr(self, "_fused", None) is None:
-            self._fused = False
             model = self.modules.transcription
-            opt = self.optimizer
+            opt = getattr(self, "optimizer", None)
+            if opt is None:
+                return False              # no optimizer yet (evaluate() before fit()): decide once there is one, do not cache "no"
+            self._fused = False
             if hasattr(model, "flatten_") and isinstance(opt, torch.optim.Adadelta) and str(self.device).startswith("cuda"):
                 from piano_a2s_amd import train
                 g = opt.param_groups[0]

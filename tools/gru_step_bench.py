@@ -39,8 +39,9 @@ def main():
                                     C.c_void_p(0), hip._p(x["dgi"]), hip._p(x["dghs"]), hip._p(x["dgh_first"]), hip._p(x["dhbuf"]), hip._p(x["dgh_tmp"]),
                                     B, T, H, d, hip._p(x["ws"]), C.c_size_t(x["ws"].numel() * 4)), "bwd")
 
-    for fused in (0, 1):
-        hip.check(L.a2s_debug_set(b"gru_fused", fused), "set")
+    for fused in (0, 1, 2):                      # 0: three launches per step, 1: one fused launch per step, 2: one persistent launch for all steps
+        hip.check(L.a2s_debug_set(b"gru_fused", 1 if fused else 0), "set")
+        hip.check(L.a2s_debug_set(b"gru_persist", 1 if fused == 2 else 0), "set")
         for name, fn in (("fwd", fwd), ("bwd", bwd)):
             for conc in (1, 2):
                 for _ in range(2):
@@ -51,7 +52,12 @@ def main():
                             fn(d)
                     torch.cuda.synchronize()
                     dt = time.time() - t0
-                print(f"fused={fused} {name} directions={conc}: {dt / T * 1e6:6.1f} us per step (B={B}, T={T})")
+                mode = ""
+                if fused == 2:
+                    w = bufs[0]["ws"].view(torch.int32)
+                    off = 0 if name == "fwd" else 3 * H * H
+                    mode = f"  [workgroups exchanging through their XCD's L2: {int(w[off + 1])}, abort word {int(w[off])}]"
+                print(f"fused={fused} {name} directions={conc}: {dt / T * 1e6:6.1f} us per step (B={B}, T={T}){mode}")
 
 
 if __name__ == "__main__":

@@ -143,6 +143,16 @@ def main():
         walls.append((time.time() - t0) * 1e3)
         if k == 0:
             continue
+        if a.segments:
+            # host-side stalls of THIS step: consecutive milestones of one host thread (g0 / g1 / the caller) more than 15 ms apart
+            by = {}
+            for n, t in host_marks:
+                key = n[:2] if n[:2] in ("g0", "g1") else "main"
+                by.setdefault(key, []).append((n, t))
+            for key, seq in sorted(by.items()):
+                for (n0, ta), (n1, tb) in zip(seq[:-1], seq[1:]):
+                    if tb - ta > 0.015:
+                        print(f"step {k} ({walls[-1]:.0f} ms) host thread {key}: {1e3 * (tb - ta):6.1f} ms between '{n0}' (at {1e3 * (ta - t0):.1f}) and '{n1}'")
         for n, e in list(gmarks):
             gtot.setdefault(n, []).append(marks[0][1].elapsed_time(e))
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
