@@ -1046,7 +1046,9 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     A2S_REQUIRE(r.n_active >= 0 && r.n_active <= r.n_clips && (!r.clip_order || r.clip_rank), "attn_step_bwd_split: bad row compaction");
     int G = 1, chunk = T;
     ws += A2S_ATTN_TICKETS;                 // the head of the workspace holds the arrival counters of the fused combines (a2s_seq.hip)
-    const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled();      // see a2s_attn_step_fwd_split_impl
+    // streaming loads as in a2s_attn_step_fwd_split_impl -- single-row launches only: measured +12 % on attn_bwd_split256, -0 .. 5 % on the
+    // fused-rows kernels, whose enc pass feeds the matrix cores (profiles/r04_attn_mq_bench.txt)
+    const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled() && groups == 1;
     if (r.n_active > 0) {
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G;

@@ -1174,7 +1174,7 @@ static bool attn_fused_combine(void) { return a2s_attn_fused_combine_enabled() !
 static int g_attn_nt = -1;
 void a2s_attn_nt_set(int v) { g_attn_nt = v < 0 ? 0 : v; }
 int a2s_attn_nt_enabled(void) {
-    if (g_attn_nt < 0) { const char* e = getenv("A2S_ATTN_NT"); g_attn_nt = e ? atoi(e) : 0; if (g_attn_nt < 0) g_attn_nt = 0; }
+    if (g_attn_nt < 0) { const char* e = getenv("A2S_ATTN_NT"); g_attn_nt = e ? atoi(e) : 64; if (g_attn_nt < 0) g_attn_nt = 0; }      // default: launches over >= 64 clips
     return g_attn_nt;
 }
 template <int NQ>

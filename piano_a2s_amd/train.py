@@ -229,6 +229,13 @@ class TrainStep:
         clips holding exceptionally long bars decode as a group of their own, concurrently with the ordinary ones (plan_clip_groups;
         Engine.forward) -- the minibatch is permuted for that, which no loss term, gradient or statistic depends on."""
         self.model = model
+        # The host side of a step is a few hundred small CPU tensor operations (the decode plan).  Above ~32 k elements torch runs each of them
+        # as an OpenMP region over every core of the box (256 here): one descheduled worker stalls the region, and the thread waiting for it
+        # holds the interpreter lock -- measured as 70-90 ms freezes of ALL issuing threads in one step out of ten (tools/host_stalls.py).
+        # One intra-op thread is plenty for this work.  A2S_HOST_THREADS overrides (0: leave torch's setting alone).
+        nthreads = int(_os.environ.get("A2S_HOST_THREADS", "1"))
+        if nthreads > 0 and torch.get_num_threads() != nthreads:
+            torch.set_num_threads(nthreads)
         self.sync_bn = (_os.environ.get("A2S_SYNC_BN") == "1") if sync_bn is None else bool(sync_bn)
         self.skip_finished_rows = (_os.environ.get("A2S_SKIP_FINISHED", "1") != "0") if skip_finished_rows is None else bool(skip_finished_rows)
         self.fuse_bars = (_os.environ.get("A2S_FUSE_BARS", "1") != "0") if fuse_bars is None else bool(fuse_bars)
@@ -346,7 +353,13 @@ class TrainStep:
             gate = self.total.clone()
             dist.all_reduce(gate, op=dist.ReduceOp.SUM)
         self.opt.step(flat_g, gate, zero_grad=False)
+        # the engine, its group hook (a closure over the backward context) and the backward context (which holds the engine) form a reference
+        # cycle: left to the cyclic collector, ~3.3 GiB of per-step gradient buffers stayed allocated for several steps and the caching
+        # allocator answered with a fresh 11 GiB segment every third step -- a hipMalloc of 340 ms under load, with every other host thread
+        # queued behind the allocator's lock (tools/alloc_stalls.py).  Break the cycle here.
         eng.saved = None
+        eng.group_hook = None
+        self._keep_alive, eng._keep_alive = getattr(eng, "_keep_alive", None), None      # (pinned staging of this step: released by the next one)
         self._last = (outs, eng.bar_major, groups, perm)
         return losses
 
