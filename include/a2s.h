@@ -203,9 +203,15 @@ typedef struct a2s_note_dec_args {
     int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
     float* step_ws; size_t step_ws_floats;   /* a2s_note_step_workspace_floats(H, E) floats or NULL: scratch of the fused few-row step kernels
                                                 (csrc/a2s_step.hip: 4 launches per step instead of 9-13; used when R <= A2S_DEC_FUSED_MAX_ROWS) */
+    /* round 4: ONE persistent launch for every step of the call when it covers at most 8 clips (csrc/a2s_dec_persist.hip: one clip per XCD,
+       keys / encoder outputs resident in LDS, weights in registers).  Needs the teacher-forcing flags on the device too and a scratch area: */
+    const int* tf_flags_dev;          /* device, `steps` ints: the same bits as tf_flags (NULL with tf_flags NULL) */
+    float* persist_ws; size_t persist_ws_bytes;   /* a2s_note_decoder_persist_ws_bytes(n_clips, R, steps) bytes, 256-byte aligned, or NULL */
 } a2s_note_dec_args;
 int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done);
 size_t a2s_note_step_workspace_floats(int H, int E);
+/* scratch of the persistent path (0: that many clips are not supported) */
+size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
 
 /* ---- packed staff-embedding bi-GRU final states (get_staff_token_from_{gt,probs}, models.py:164-189).
  * gru_w: 8 device pointers {w_ih,w_hh,b_ih,b_hh} forward then reverse. */

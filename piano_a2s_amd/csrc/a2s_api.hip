@@ -55,6 +55,9 @@ void a2s_gemm_debug_tile_impl(int);
 void a2s_gru_step_fused_set(int);
 void a2s_gru_persist_set(int);
 int a2s_gru_persist_enabled(void);
+void a2s_dec_persist_set(int);
+int a2s_dec_persist_enabled(void);
+size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
 int a2s_nll_grad_impl(hipStream_t st, float* dlogp, const long long* target, const float* loss_out, float gscale, long rows, int V, long long ignore_index);
 void a2s_attn_fused_combine_set(int v);
 int a2s_attn_fused_combine_enabled(void);
@@ -160,6 +163,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
+    if (!strcmp(key, "dec_persist")) { a2s_dec_persist_set(value); return A2S_OK; }
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_rows")) { a2s_conv_rows_set(value); return A2S_OK; }
@@ -186,6 +190,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "wgrad_bf16x3")) return a2s_wgrad_split_enabled();
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
     if (key && !strcmp(key, "gru_persist")) return a2s_gru_persist_enabled();
+    if (key && !strcmp(key, "dec_persist")) return a2s_dec_persist_enabled();
     if (key && !strcmp(key, "dec_fused")) return a2s_dec_fused_enabled();
     if (key && !strcmp(key, "attn_fused_combine")) return a2s_attn_fused_combine_enabled();
     if (key && !strcmp(key, "attn_nt")) return a2s_attn_nt_enabled();

@@ -625,7 +625,12 @@ static int note_decoder_greedy_graph(hipStream_t st, const NoteDecArgs& a, int* 
     return A2S_OK;
 }
 
+bool a2s_note_decoder_fwd_persist_ok(const a2s_note_dec_args& a);
+int a2s_note_decoder_fwd_persist(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
+
 int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_done) {
+    // few clips: one persistent launch for the whole call (a2s_dec_persist.hip)
+    if (a2s_note_decoder_fwd_persist_ok(a)) return a2s_note_decoder_fwd_persist(st, a, steps_done);
     // stream capture is not allowed on the legacy default stream: callers that want the graph path run on a created stream
     if (!a.gt && a.use_graph && a.t_base && !a.gates && !a.attw && !a.drop && st != nullptr) return note_decoder_greedy_graph(st, a, steps_done);
     if (a.row_list && a.n_rows_active && a.steps > 0) {
