@@ -28,8 +28,8 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define SPIN_LIMIT (1u << 23)          // failed polls of one wave over the whole call before it gives up
 #define NWG 32                      // workgroups per clip (= CUs of an XCD)
-#define NTH 1024                    // threads per workgroup (16 waves: the weights are ~58 registers per thread this way, ~116 with 8 waves)
-#define NWV 16                      // waves per workgroup
+#define NTH 512                     // threads per workgroup
+#define NWV 8                       // waves per workgroup (the weights: ~140 registers per thread; 16 waves at 128 registers spilled)
 #define CHF 38                      // frames per workgroup (32 x 38 >= 1201)
 #define MAXR 5                      // rows (fused bars) per clip
 #define HH 256                      // hidden_size
@@ -39,6 +39,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define VV 173
 #define VP 176                      // logits row in granules (11 tiles of 16)
 #define AUX_SC1V ((int)(16u | 0x80000000u))
+#define DP_PART_FLOATS (((NWV - 1) * 4 * 80) > (NTH > 512 ? MAXR * H2 : 0) ? ((NWV - 1) * 4 * 80) : (MAXR * H2))
 
 __device__ __forceinline__ bool dp_aborted(unsigned* flag) { return __hip_atomic_load((gu32*)(flag), RLX_AGENT) != 0; }
 __device__ __forceinline__ void dp_raise(unsigned* flag, unsigned code) { __hip_atomic_store((gu32*)(flag), code, RLX_AGENT); }
@@ -132,17 +133,18 @@ struct DecPersistFwd {
 #define G_PC (G_PM + NWG * MAXR * 2)            // [NWG][MAXR][H2]
 #define DP_REGION (G_PC + NWG * MAXR * H2)
 
-__global__ __launch_bounds__(NTH) void dec_persist_fwd(DecPersistFwd a) {
+__global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Kc = sm;                                     // [CHF][HH]
     float* Ec = Kc + CHF * HH;                          // [CHF][H2]
     float* Eq = Ec + CHF * H2;                          // [MAXR][HH]  exp(2 q)
     float* sc = Eq + MAXR * HH;                         // [MAXR][64]  scores / chunk weights
     float* part = sc + MAXR * 64;                       // (NWV - 1) * 4 * 80 floats: cross-wave reduction; also the second half of the partial contexts
-    float* red = part + (NWV - 1) * 4 * 80;             // 64 floats: small broadcasts
+    float* red = part + DP_PART_FLOATS;                 // 64 floats: small broadcasts
     const int L = blockIdx.x, c = L & 7, w = L >> 3;            // clip (XCD under the observed dispatch), member
     if (c >= a.C) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
+    const int tid = tid0, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int NR = a.NR, R = a.R, C = a.C, T = a.T;
     u64* G = a.xg + (long)c * DP_REGION;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(NTH) void dec_persist_fwd(DecPersistFwd a) {
     }
     const f32x4 v4 = {a.attn_v[lane * 4], a.attn_v[lane * 4 + 1], a.attn_v[lane * 4 + 2], a.attn_v[lane * 4 + 3]};
     // GRU tile w: hidden units 16 w .. + 15; k-steps u = wave + 8 cc (u < 65): u = 0 token, 1..32 context, 33..64 previous state
-    constexpr int GKS = 5;
+    constexpr int GKS = (65 + NWV - 1) / NWV;
     f32x4 wg_[3][GKS];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -191,9 +193,9 @@ __global__ __launch_bounds__(NTH) void dec_persist_fwd(DecPersistFwd a) {
             wg_[g][cc] = u < 33 ? *reinterpret_cast<const f32x4*>(a.w_ih + row * KX + 16 * u + 4 * lk)
                                 : (u < 65 ? *reinterpret_cast<const f32x4*>(a.w_hh + row * H2 + 16 * (u - 33) + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f});
         }
-    // second role: w < 11 vocabulary tile w (K = 1024: 4 k-steps per wave), 11 <= w < 27 query tile w - 11 (K = 512: 2 per wave), w == 27 epilogue
+    // second role: w < 11 vocabulary tile w (K = 1024: 4 k-steps per wave), 11 <= w < 27 query tile w - 11 (K = 512: 32 / NWV per wave), w == 27 epilogue
     const bool role_out = w < 11, role_q = w >= 11 && w < 27, role_epi = w == 27;
-    constexpr int OKS = 4;
+    constexpr int OKS = 64 / NWV;
     f32x4 wo_[OKS];
 #pragma unroll
     for (int cc = 0; cc < OKS; ++cc) {
@@ -232,6 +234,11 @@ __global__ __launch_bounds__(NTH) void dec_persist_fwd(DecPersistFwd a) {
     // -------------------------------------------------------------------------------------------------------------------- step loop
     // (step index s; "slot" = s & 1 for the double-buffered granule arrays; tags: consumer step + 1)
     for (int s = -1; s < a.steps && !spin.dead; ++s) {
+        // per-iteration copies of the thread coordinates the optimiser cannot see through: without them every address that only depends on
+        // the lane is hoisted out of this (very long) loop body -- a hundred VGPRs of loop-invariant offsets, and the kernel spilled
+        int tid_ = tid0;
+        asm volatile("" : "+v"(tid_));
+        const int tid = tid_, lane = tid & 63, li = lane & 15, lk = lane >> 4;
         const unsigned tag = (unsigned)(s + 1);          // tag of what step s consumes
         int onmask = 0;                                   // bit j: row j of this clip decodes at step s
 #pragma unroll
@@ -289,27 +296,35 @@ __global__ __launch_bounds__(NTH) void dec_persist_fwd(DecPersistFwd a) {
                 }
             }
             __syncthreads();
-            // partial contexts: thread (column d = tid & 511, frame parity tid >> 9); the odd half hands its sums over through LDS
+            // partial contexts: thread (column d = tid & 511, frame residue tid >> 9 of NTH / 512); with 1024 threads the second half hands its
+            // sums over through LDS
             {
+                constexpr int NHF = NTH / H2;
                 const int d = tid & (H2 - 1), hf = tid >> 9;
                 float accc[MAXR];
 #pragma unroll
                 for (int j = 0; j < MAXR; ++j) accc[j] = 0.f;
-                for (int f = hf; f < nf; f += 2) {
+                for (int f = hf; f < nf; f += NHF) {
                     const float e = Ec[f * H2 + d];
 #pragma unroll
                     for (int j = 0; j < MAXR; ++j) if (ON(j)) accc[j] = fmaf(sc[j * 64 + f], e, accc[j]);
                 }
-                if (hf == 1) {
+                if (NHF > 1) {
+                    if (hf == 1) {
 #pragma unroll
-                    for (int j = 0; j < MAXR; ++j) part[j * H2 + d] = accc[j];
+                        for (int j = 0; j < MAXR; ++j) part[j * H2 + d] = accc[j];
+                    }
+                    __syncthreads();
+                    if (hf == 0) {
+#pragma unroll
+                        for (int j = 0; j < MAXR; ++j) accc[j] += part[j * H2 + d];
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
                 if (hf == 0) {
 #pragma unroll
-                    for (int j = 0; j < MAXR; ++j) if (ON(j)) put(G + G_PC + (long)(w * MAXR + j) * H2 + d, tag, accc[j] + part[j * H2 + d], same_xcd);
+                    for (int j = 0; j < MAXR; ++j) if (ON(j)) put(G + G_PC + (long)(w * MAXR + j) * H2 + d, tag, accc[j], same_xcd);
                 }
-                __syncthreads();
             }
             // ================================================================ softmax combine, column slice 16 w .. + 15 of every row
             // thread (col = tid / 32, chunk g = tid % 32): half-waves reduce over the 32 chunks
@@ -494,10 +509,10 @@ __global__ __launch_bounds__(NTH) void dec_persist_fwd(DecPersistFwd a) {
                 const long long gtok = a.gt ? a.gt[grow * a.gt_bstride + s] : -1;
                 const int tf = a.flags ? ((a.flags[s] >> j) & 1) : 0;
                 const int next_id = (a.gt && tf) ? (int)gtok : mi;
-                if (lane < EE && s + 1 < a.steps) {
+                if (lane < EE) {                        // (also after the last step: the state slot `steps` exists, as in the launch-per-step path)
                     float e = a.emb[(long)next_id * EE + lane];
                     if (a.drop) e = a.drop[((long)(s + 1) * R + grow) * EE + lane] ? e * a.inv_keep : 0.f;
-                    put(G + G_TOK + (long)(((s + 1) & 1) * MAXR + j) * EE + lane, tag + 1, e, same_xcd);
+                    if (s + 1 < a.steps) put(G + G_TOK + (long)(((s + 1) & 1) * MAXR + j) * EE + lane, tag + 1, e, same_xcd);
                     a.x[((long)(s + 1) * R + grow) * KX + lane] = e;
                 }
                 if (lane == 0) {
@@ -535,7 +550,7 @@ int a2s_dec_persist_enabled(void) {
     if (g_dec_persist < 0) { const char* e = getenv("A2S_DEC_PERSIST"); g_dec_persist = (e && e[0] == '0') ? 0 : 1; }
     return g_dec_persist;
 }
-static size_t dp_lds_bytes(void) { return sizeof(float) * (CHF * HH + CHF * H2 + MAXR * HH + MAXR * 64 + 64 + (NWV - 1) * 4 * 80); }
+static size_t dp_lds_bytes(void) { return sizeof(float) * (CHF * HH + CHF * H2 + MAXR * HH + MAXR * 64 + 64 + DP_PART_FLOATS); }
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps) {
     if (n_clips < 1 || n_clips > 8) return 0;
     return 512 + sizeof(unsigned) * 8 * NWG + sizeof(u64) * (size_t)n_clips * DP_REGION + sizeof(float) * 2 * (size_t)(steps > 0 ? steps : 1) * R;

@@ -453,7 +453,7 @@ class Engine:
                                i64=ids_are_i64, hsave=hsave))
 
     def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None,
-                      active=None, drop=None, flags_dev=None):
+                      active=None, drop=None, flags_dev=None, persist=False):
         """One NoteDecoder.decode_notes call over B rows.  probs_bar: view (B, max_steps, V) of the output tensor (strided).
         tf_flags: per step, bit g = teacher-force the rows of group g.
         active: optional dict(until: (B,) int32, order / rank: (n_clips,) int32 device tensors; n_active: host int array per step;
@@ -520,6 +520,16 @@ class Engine:
         a.am_bstride = max_steps
         a.R, a.T, a.H, a.E, a.V, a.steps, a.poll, a.eos_id = B, T, H, E, V, n, (self.poll if gt_bar is None else 0), EOS
         a.use_graph = 1 if graph else 0
+        # few clips: the whole call as ONE persistent launch (csrc/a2s_dec_persist.hip).  Only when the caller says so: two such launches must
+        # never be in flight together (each wants every CU's LDS; see decode_group)
+        persist_ws = None
+        a.tf_flags_dev, a.persist_ws, a.persist_ws_bytes = None, None, 0
+        if persist and gt_bar is not None and n > 0 and (tf_flags is None or flags_dev is not None):
+            nb_ws = L.a2s_note_decoder_persist_ws_bytes(active["n_clips"] if active else B, B, n)
+            if nb_ws:
+                persist_ws = torch.empty(nb_ws, dtype=torch.uint8, device=dev)
+                a.persist_ws, a.persist_ws_bytes = persist_ws.data_ptr(), nb_ws
+                a.tf_flags_dev = flags_dev.data_ptr() if flags_dev is not None else None
         done = C.c_int(0)
         hip.check(L.a2s_note_decoder_fwd(hip.stream(), C.byref(a), C.byref(done)), "a2s_note_decoder_fwd")
         # steps the reference would have executed: known from the plan with ground truth; read back from the device
@@ -527,7 +537,7 @@ class Engine:
         executed = n if gt_bar is not None else int(steps_exec.item())
         saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
                      gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active, flags_dev=flags_dev,
-                     step_ws=step_ws)
+                     step_ws=step_ws, persist_ws=persist_ws)
         return ids, lengths, saved
 
     # ------------------------------------------------------------------ full forward
@@ -667,7 +677,13 @@ class Engine:
                 up_out_g, lo_out_g = up_out[b0:b1], lo_out[b0:b1]
                 gt_bm = None
             _trace(f"g{gidx} views made")
-            concurrent_g = concurrent and gidx <= 1           # (a third group would have no stream left: everything in order on its own)
+            # A group of at most 8 clips decodes each (segment, staff) call as ONE persistent launch (csrc/a2s_dec_persist.hip) whose workgroups
+            # hold a clip's keys / encoder outputs in LDS and wait for each other: two such launches in flight at once would share the CUs and
+            # starve each other.  So only the LAST group may take that path (the long clips; or the whole minibatch when it is that small), and
+            # its two staves then run one after the other on the group's stream.
+            persist_g = (plan is not None and Bg <= 8 and gidx == len(clip_groups) - 1 and H == 256 and E == 16 and not inference
+                         and _os.environ.get("A2S_DEC_PERSIST", "1") != "0")
+            concurrent_g = concurrent and gidx <= 1 and not persist_g      # (a third group would have no stream left: everything in order on its own)
             streams = staff_streams(dev, gidx) if concurrent_g else None
 
             def rand(shape):
@@ -721,7 +737,7 @@ class Engine:
                     steps = max(gsteps[bar][gi_idx] for bar in seg)
                     flags = [sum(int(t < gsteps[bar][gi_idx] and plan[bar][gi_idx][1][t]) << j for j, bar in enumerate(seg)) for t in range(steps)]
                     # the backward pass needs the flags on the device (which token each step consumed)
-                    flags_dev = upload(torch.tensor(flags[:steps - 1], dtype=torch.int32)) if training and steps > 1 else None
+                    flags_dev = upload(torch.tensor(flags[:steps], dtype=torch.int32)) if training and steps > 0 else None
                     sp[gi_idx] = (steps, flags, active_rows(gi_idx, seg, steps) if skip else None, flags_dev)
                 seg_plan.append(sp)
 
@@ -835,7 +851,7 @@ class Engine:
                     # the dropout masks are drawn here, on the caller's thread and stream: one deterministic draw order per seed
                     drop = (rand((steps + 1, R, E)) >= 0.1).to(torch.uint8) if drop_on else None
                     calls.append((name, (S, prefix, keys_g[prefix], enc_g, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
-                                         attn_ws[gi_idx], gemm_ws[gi_idx], active, drop, flags_dev)))
+                                         attn_ws[gi_idx], gemm_ws[gi_idx], active, drop, flags_dev, persist_g)))
                 if concurrent_g:
                     _trace(f"g{gidx} seg {seg_i} staves forked")
                     join = fork_on_streams(dev, streams, [lambda args=args: self._decode_staff(*args) for _, args in calls])
