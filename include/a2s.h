@@ -212,6 +212,7 @@ int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps
 size_t a2s_note_step_workspace_floats(int H, int E);
 /* scratch of the persistent path (0: that many clips are not supported) */
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
+size_t a2s_note_decoder_bwd_persist_ws_bytes(int n_clips);
 
 /* ---- packed staff-embedding bi-GRU final states (get_staff_token_from_{gt,probs}, models.py:164-189).
  * gru_w: 8 device pointers {w_ih,w_hh,b_ih,b_hh} forward then reverse. */
@@ -270,6 +271,9 @@ typedef struct a2s_note_dec_bwd_args {
     const int* n_rows_active;            /* HOST: as in the forward call */
     int R, T, H, E, steps;
     float* step_ws; size_t step_ws_floats;   /* as in the forward call (holds the transposed weight copies of the fused backward step) */
+    float* persist_ws; size_t persist_ws_bytes;   /* round 4: a2s_note_decoder_bwd_persist_ws_bytes(n_clips) bytes (256-byte aligned) or NULL:
+                                                     at most 8 clips run the reverse loop as ONE persistent launch (csrc/a2s_dec_persist.hip) */
+    const float* w_ih_full;                  /* unused (reserved) */
 } a2s_note_dec_bwd_args;
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);
 

@@ -58,6 +58,7 @@ int a2s_gru_persist_enabled(void);
 void a2s_dec_persist_set(int);
 int a2s_dec_persist_enabled(void);
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
+size_t a2s_note_decoder_bwd_persist_ws_bytes(int n_clips);
 int a2s_nll_grad_impl(hipStream_t st, float* dlogp, const long long* target, const float* loss_out, float gscale, long rows, int V, long long ignore_index);
 void a2s_attn_fused_combine_set(int v);
 int a2s_attn_fused_combine_enabled(void);

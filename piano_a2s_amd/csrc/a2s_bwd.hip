@@ -296,7 +296,12 @@ int a2s_note_step_fused_bwd_prepare(hipStream_t st, const a2s_note_dec_bwd_args&
 int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const float* dh_in, float* dh_out, const a2s_attn_rows* rows,
                             int nrows, const int* rowmap);
 
+bool a2s_note_decoder_bwd_persist_ok(const a2s_note_dec_bwd_args& a);
+int a2s_note_decoder_bwd_persist(hipStream_t st, const a2s_note_dec_bwd_args& a);
+
 int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
+    // few clips: one persistent launch for the whole reverse loop (a2s_dec_persist.hip)
+    if (a2s_note_decoder_bwd_persist_ok(a)) return a2s_note_decoder_bwd_persist(st, a);
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
     hipError_t e = hipMemsetAsync(a.dh, 0, sizeof(float) * 2 * R * H2, st);
     // (steps that skip finished rows leave their dx rows unwritten: they must read as zero gradients)

@@ -40,6 +40,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define VP 176                      // logits row in granules (11 tiles of 16)
 #define AUX_SC1V ((int)(16u | 0x80000000u))
 #define DP_PART_FLOATS (((NWV - 1) * 4 * 80) > (NTH > 512 ? MAXR * H2 : 0) ? ((NWV - 1) * 4 * 80) : (MAXR * H2))
+#define DPB_PART_FLOATS (((NWV - 1) * 2 * 80) > (MAXR * HH) ? ((NWV - 1) * 2 * 80) : (MAXR * HH))
 
 __device__ __forceinline__ bool dp_aborted(unsigned* flag) { return __hip_atomic_load((gu32*)(flag), RLX_AGENT) != 0; }
 __device__ __forceinline__ void dp_raise(unsigned* flag, unsigned code) { __hip_atomic_store((gu32*)(flag), code, RLX_AGENT); }
@@ -543,6 +544,302 @@ __global__ __launch_bounds__(256) void dec_persist_attw_normalise(float* __restr
     for (int t = threadIdx.x; t < T; t += 256) aw[t] = __expf(aw[t] - m) * inv;
 }
 
+// =========================================================================================== backward
+// Reverse of the above for one call (see a2s_note_decoder_bwd_impl for the per-step math).  Same placement: clip c on XCD c, its keys and
+// encoder outputs in LDS, the transposed weight tiles (W_ih^T, W_hh^T, W_h^T: made once per call by a2s_note_step_fused_bwd_prepare) in
+// registers.  A step is four hand-offs:
+//   gate backward of the workgroup's 16 hidden units (dgi, dgh)  ->  [allgather]  ->  dx = dgi W_ih (context columns 16 w ..) and the
+//   recurrent carry dgh W_hh (state columns 16 w ..)  ->  [dctx rows]  ->  attention backward over the workgroup's frames (ds, partial dq)
+//   ->  [32 partials]  ->  dq, column slice 8 w ..  ->  [dq rows]  ->  carry += dq W_h.
+// The token columns of dx (only the deferred embedding gradient reads them) are one GEMM over all steps after the loop.
+struct DecPersistBwd {
+    const float* attn_v; const float* wih_t; const float* whh_t; const float* wh_t;      // (KX, 3 H2), (H2, 3 H2), (H2, HH)
+    const float* keys; const float* enc;
+    const float* h; const float* x; const float* q; const float* gates; const float* attw; const float* do_all;
+    float* dgi_all; float* dgh_all; float* dq_all; float* ds_all; float* dctx_all; float* dx; float* dh;
+    const int* row_until;
+    u64* xg; unsigned* abort_flag; unsigned* xcc;
+    int C, NR, R, T, steps;
+};
+#define B_DG 0                                  // [MAXR][6 * H2]   dgi | dgh rows
+#define B_DC (B_DG + MAXR * 6 * H2)             // [MAXR][H2]       dctx rows
+#define B_DQP (B_DC + MAXR * H2)                // [NWG][MAXR][HH]  partial dq
+#define B_DQ (B_DQP + NWG * MAXR * HH)          // [MAXR][HH]
+#define DPB_REGION (B_DQ + MAXR * HH)
+
+__global__ __launch_bounds__(NTH, 2) void dec_persist_bwd(DecPersistBwd a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Kc = sm;                                     // [CHF][HH]
+    float* Ec = Kc + CHF * HH;                          // [CHF][H2]
+    float* Eq = Ec + CHF * H2;                          // [MAXR][HH]
+    float* dcx = Eq + MAXR * HH;                        // [MAXR][H2]  dctx rows
+    float* dsv = dcx + MAXR * H2;                       // [MAXR][64]  ds of this workgroup's frames
+    float* aw = dsv + MAXR * 64;                        // [MAXR][64]  saved attention weights of these frames
+    float* part = aw + MAXR * 64;                       // DP_PART_FLOATS (>= MAXR * HH for the dq halves)
+    float* red = part + DPB_PART_FLOATS;                // 64
+    const int L = blockIdx.x, c = L & 7, w = L >> 3;
+    if (c >= a.C) return;
+    const int tid0 = threadIdx.x;
+    const int wave = tid0 >> 6;
+    const int NR = a.NR, R = a.R, C = a.C, T = a.T, n = a.steps;
+    u64* G = a.xg + (long)c * DPB_REGION;
+    bool same_xcd;
+    {
+        const int lane = tid0 & 63;
+        const unsigned mine = (__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20) & 0xf) + 1;
+        unsigned* ids = a.xcc + c * NWG;
+        if (tid0 == 0) __hip_atomic_store((gu32*)(ids + w), mine, RLX_AGENT);
+        if (wave == 0) {
+            int ok = 0;
+            for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+                const unsigned v = lane < NWG ? __hip_atomic_load((gu32*)(ids + lane), RLX_AGENT) : mine;
+                if (__all(v != 0)) { ok = __all(v == mine) ? 1 : 0; break; }
+                if ((spins & 63) == 63 && dp_aborted(a.abort_flag)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) red[0] = (float)ok;
+        }
+        __syncthreads();
+        same_xcd = red[0] != 0.f;
+        __syncthreads();
+        if (tid0 == 0 && same_xcd) atomicAdd(a.abort_flag + 1, 1u);
+    }
+    Spin spin{a.abort_flag, 64u + (unsigned)w, 0u, false};
+    const int t0 = w * CHF, nf = max(0, min(T, t0 + CHF) - t0);
+    for (int i = tid0; i < CHF * HH / 4; i += NTH) {
+        const int f = i / (HH / 4);
+        reinterpret_cast<f32x4*>(Kc)[i] = f < nf ? *reinterpret_cast<const f32x4*>(a.keys + ((long)c * T + t0 + f) * HH + 4 * (i % (HH / 4))) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i = tid0; i < CHF * H2 / 4; i += NTH) {
+        const int f = i / (H2 / 4);
+        reinterpret_cast<f32x4*>(Ec)[i] = f < nf ? *reinterpret_cast<const f32x4*>(a.enc + ((long)c * T + t0 + f) * H2 + 4 * (i % (H2 / 4))) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // B fragments: k-steps u = wave + 8 cc over K = 3 H2 (gate columns) for the two product tiles, over K = HH for the query product
+    constexpr int PKS = 3 * H2 / 16 / NWV;              // 12
+    constexpr int QKS = HH / 16 / NWV;                  // 2
+    f32x4 wx_[PKS], wh_[PKS], wq_[QKS];
+    {
+        const int lane = tid0 & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int cc = 0; cc < PKS; ++cc) {
+            const int u = wave + NWV * cc;
+            wx_[cc] = *reinterpret_cast<const f32x4*>(a.wih_t + (long)(EE + 16 * w + li) * (3 * H2) + 16 * u + 4 * lk);
+            wh_[cc] = *reinterpret_cast<const f32x4*>(a.whh_t + (long)(16 * w + li) * (3 * H2) + 16 * u + 4 * lk);
+        }
+#pragma unroll
+        for (int cc = 0; cc < QKS; ++cc) wq_[cc] = *reinterpret_cast<const f32x4*>(a.wh_t + (long)(16 * w + li) * HH + 16 * (wave + NWV * cc) + 4 * lk);
+    }
+    float dhc[4] = {0.f, 0.f, 0.f, 0.f};                 // wave 0: carry dh[row 4 lk + r][16 w + li]
+    __syncthreads();
+    for (int s = n - 1; s >= 0 && !spin.dead; --s) {
+        int tid_ = tid0;
+        asm volatile("" : "+v"(tid_));
+        const int tid = tid_, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        const unsigned tag = (unsigned)(n - s);
+        int onmask = 0;
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j) onmask |= (j < NR && (!a.row_until || s < a.row_until[j * C + c])) ? (1 << j) : 0;
+#define ON(j) ((onmask >> (j)) & 1)
+        if (onmask == 0) continue;
+        // ================================================================ (1) gate backward of units 16 w .. + 15
+        float dhz[4] = {0.f, 0.f, 0.f, 0.f}, doc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wave == 0) {
+            const int jn = 16 * w + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = lk * 4 + r;
+                if (j >= NR || !ON(j)) continue;
+                const long grow = (long)j * C + c, sr = (long)s * R + grow;
+                const float* sv = a.gates + sr * 4 * H2;
+                const float rg = sv[jn], zg = sv[H2 + jn], ng = sv[2 * H2 + jn], ghn = sv[3 * H2 + jn];
+                const float hp = a.h[sr * H2 + jn];
+                const float dh = dhc[r] + a.do_all[sr * (2 * H2) + jn];
+                doc[r] = a.do_all[sr * (2 * H2) + H2 + jn];                  // the output projection's share of dctx, column 16 w + li
+                const float dn = dh * (1.f - zg) * (1.f - ng * ng);
+                const float dz = dh * (hp - ng) * zg * (1.f - zg);
+                const float dr = dn * ghn * rg * (1.f - rg);
+                const float dnr = dn * rg;
+                dhz[r] = dh * zg;
+                u64* gr = G + B_DG + (long)j * 6 * H2;
+                put(gr + jn, tag, dr, same_xcd); put(gr + H2 + jn, tag, dz, same_xcd); put(gr + 2 * H2 + jn, tag, dn, same_xcd);
+                put(gr + 3 * H2 + jn, tag, dr, same_xcd); put(gr + 4 * H2 + jn, tag, dz, same_xcd); put(gr + 5 * H2 + jn, tag, dnr, same_xcd);
+                float* gi = a.dgi_all + sr * 3 * H2; float* gh = a.dgh_all + sr * 3 * H2;
+                gi[jn] = dr; gi[H2 + jn] = dz; gi[2 * H2 + jn] = dn;
+                gh[jn] = dr; gh[H2 + jn] = dz; gh[2 * H2 + jn] = dnr;
+            }
+        }
+        // saved operands of the attention backward that do not depend on the recurrence: E_q, the frames' attention weights
+        {
+            const int j = tid >> 6;                           // waves 0 .. NR-1: one row each
+            if (j < NR && ON(j)) {
+                const long sr = (long)s * R + (long)j * C + c;
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.q + sr * HH + 4 * lane);
+                f32x4 e4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e4[i] = exp2x_clamped(q4[i]);
+                reinterpret_cast<f32x4*>(Eq + j * HH)[lane] = e4;
+                aw[j * 64 + lane] = lane < nf ? a.attw[sr * T + t0 + lane] : 0.f;
+            }
+        }
+        // ================================================================ (2) dx context columns 16 w .. and carry columns 16 w ..
+        {
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(G + B_DG, MAXR * 6 * H2 * 8);
+#pragma unroll
+            for (int cc = 0; cc < PKS; ++cc) {
+                const int u = wave + NWV * cc;
+                float ai[4], ah[4];
+                for (;;) {
+                    bool ok = frag_load(rs, 6 * H2, NR, li, lk, 16 * u, tag, ai);
+                    ok &= frag_load(rs, 6 * H2, NR, li, lk, 3 * H2 + 16 * u, tag, ah);
+                    if (li < NR && !ON(li)) { ok = true; ai[0] = ai[1] = ai[2] = ai[3] = 0.f; ah[0] = ah[1] = ah[2] = ah[3] = 0.f; }
+                    if (__all(ok)) break;
+                    if (!spin.again()) break;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[i], wx_[cc][i], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i], wh_[cc][i], acc[1], 0, 0, 0);
+                }
+            }
+            reduce_rows<2>(acc, part, wave, li, lk);
+            if (wave == 0) {
+                const int jn = 16 * w + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = lk * 4 + r;
+                    if (j >= NR || !ON(j)) continue;
+                    const long sr = (long)s * R + (long)j * C + c;
+                    const float dcg = acc[0][r], dct = dcg + doc[r];
+                    put(G + B_DC + (long)j * H2 + jn, tag, dct, same_xcd);
+                    a.dx[sr * KX + EE + jn] = dcg;
+                    a.dctx_all[sr * H2 + jn] = dct;
+                    dhc[r] = dhz[r] + acc[1][r];
+                }
+            }
+        }
+        // ================================================================ (3) attention backward over this workgroup's frames
+        {   // dctx rows -> LDS (thread = column)
+#pragma unroll
+            for (int j = 0; j < MAXR; ++j) {
+                if (!ON(j)) continue;
+                float vv = 0.f;
+                for (;;) {
+                    const u64 xv = __hip_atomic_load((gu64*)(G + B_DC + (long)j * H2 + tid), RLX_AGENT);
+                    vv = __uint_as_float((unsigned)xv);
+                    if (__all((unsigned)(xv >> 32) == tag)) break;
+                    if (!spin.again()) break;
+                }
+                dcx[j * H2 + tid] = vv;
+            }
+        }
+        __syncthreads();
+        if (wave < NR && ON(wave)) {                          // dot = dctx . ctx of row `wave`
+            const long sr = (long)s * R + (long)wave * C + c;
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p = fmaf(dcx[wave * H2 + lane + 64 * i], a.x[sr * KX + EE + lane + 64 * i], p);
+            p = wave_sum(p);
+            if (lane == 0) red[8 + wave] = p;
+        }
+        __syncthreads();
+        for (int f = wave; f < nf; f += NWV) {                // da_t = dctx . enc_t, one wave per frame
+            const f32x4 e0 = reinterpret_cast<const f32x4*>(Ec + f * H2)[lane], e1 = reinterpret_cast<const f32x4*>(Ec + f * H2)[64 + lane];
+#pragma unroll
+            for (int j = 0; j < MAXR; ++j) {
+                if (!ON(j)) continue;
+                const f32x4 d0 = reinterpret_cast<const f32x4*>(dcx + j * H2)[lane], d1 = reinterpret_cast<const f32x4*>(dcx + j * H2)[64 + lane];
+                float da = d0[0] * e0[0] + d0[1] * e0[1] + d0[2] * e0[2] + d0[3] * e0[3] + d1[0] * e1[0] + d1[1] * e1[1] + d1[2] * e1[2] + d1[3] * e1[3];
+                da = wave_sum_lane63(da);
+                if (lane == 63) {
+                    const float d_s = aw[j * 64 + f] * (da - red[8 + j]);
+                    dsv[j * 64 + f] = d_s;
+                    a.ds_all[((long)s * R + (long)j * C + c) * T + t0 + f] = d_s;
+                }
+            }
+        }
+        __syncthreads();
+        {   // partial dq: thread (unit jq = tid & 255, frame parity tid >> 8); the odd half hands over through LDS
+            const int jq = tid & (HH - 1), hf = tid >> 8;
+            float accq[MAXR];
+#pragma unroll
+            for (int j = 0; j < MAXR; ++j) accq[j] = 0.f;
+            for (int f = hf; f < nf; f += NTH / HH) {
+                const float kk = Kc[f * HH + jq];
+#pragma unroll
+                for (int j = 0; j < MAXR; ++j) if (ON(j)) accq[j] = fmaf(dsv[j * 64 + f], sech2_ek(kk, Eq[j * HH + jq]), accq[j]);
+            }
+            if (hf == 1) {
+#pragma unroll
+                for (int j = 0; j < MAXR; ++j) part[j * HH + jq] = accq[j];
+            }
+            __syncthreads();
+            if (hf == 0) {
+                const float vj = a.attn_v[jq];
+#pragma unroll
+                for (int j = 0; j < MAXR; ++j) if (ON(j)) put(G + B_DQP + (long)(w * MAXR + j) * HH + jq, tag, (accq[j] + part[j * HH + jq]) * vj, same_xcd);
+            }
+            __syncthreads();
+        }
+        // ================================================================ (4) dq, columns 8 w .. + 7: sum of the 32 partials (half-waves)
+        if (tid < 256) {
+            const int col = tid >> 5, g = tid & 31;
+#pragma unroll
+            for (int j = 0; j < MAXR; ++j) {
+                if (!ON(j)) continue;
+                float pv = 0.f;
+                for (;;) {
+                    const u64 xv = __hip_atomic_load((gu64*)(G + B_DQP + (long)(g * MAXR + j) * HH + 8 * w + col), RLX_AGENT);
+                    pv = __uint_as_float((unsigned)xv);
+                    if (__all((unsigned)(xv >> 32) == tag)) break;
+                    if (!spin.again()) break;
+                }
+                pv += dpp_take<A2S_DPP_QUAD_1032>(0.f, pv);
+                pv += dpp_take<A2S_DPP_QUAD_2301>(0.f, pv);
+                pv += dpp_take<A2S_DPP_ROW_HALF_MIRROR>(0.f, pv);
+                pv += dpp_take<A2S_DPP_ROW_MIRROR>(0.f, pv);
+                pv += dpp_take<A2S_DPP_ROW_BCAST15, 0xA>(0.f, pv);
+                if ((lane & 31) == 31) {
+                    put(G + B_DQ + (long)j * HH + 8 * w + col, tag, pv, same_xcd);
+                    a.dq_all[((long)s * R + (long)j * C + c) * HH + 8 * w + col] = pv;
+                }
+            }
+        }
+        // ================================================================ (5) carry += dq W_h, columns 16 w ..
+        {
+            f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(G + B_DQ, MAXR * HH * 8);
+#pragma unroll
+            for (int cc = 0; cc < QKS; ++cc) {
+                float av[4];
+                for (;;) {
+                    bool ok = frag_load(rs, HH, NR, li, lk, 16 * (wave + NWV * cc), tag, av);
+                    if (li < NR && !ON(li)) { ok = true; av[0] = av[1] = av[2] = av[3] = 0.f; }
+                    if (__all(ok)) break;
+                    if (!spin.again()) break;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wq_[cc][i], acc[0], 0, 0, 0);
+            }
+            reduce_rows<1>(acc, part, wave, li, lk);
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (lk * 4 + r < NR && ON(lk * 4 + r)) dhc[r] += acc[0][r];
+            }
+        }
+#undef ON
+    }
+    if (wave == 0) {
+        const int lane = tid0 & 63, li = lane & 15, lk = lane >> 4;
+        const bool bad = spin.dead || dp_aborted(a.abort_flag);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = lk * 4 + r;
+            if (j < NR) a.dh[(long)(j * C + c) * H2 + 16 * w + li] = bad ? __builtin_nanf("") : dhc[r];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- launcher
 static int g_dec_persist = -1;                          // A2S_DEC_PERSIST=0 / a2s_debug_set("dec_persist", 0): the launch-per-step kernels
 void a2s_dec_persist_set(int v) { g_dec_persist = v ? 1 : 0; }
@@ -607,4 +904,63 @@ int a2s_note_decoder_fwd_persist(hipStream_t st, const a2s_note_dec_args& a, int
     }
     if (steps_done) *steps_done = a.steps;
     return A2S_OK;
+}
+
+// ------------------------------------------------------------------------------------------- backward launcher
+int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
+                  const float* B, long sBk, long sBn, float beta, float* C, long ldc, const float* bias, int act,
+                  int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes);
+int a2s_note_step_fused_bwd_prepare(hipStream_t st, const a2s_note_dec_bwd_args& a);
+size_t a2s_note_step_fused_head_floats(void);
+static size_t dpb_lds_bytes(void) { return sizeof(float) * (CHF * HH + CHF * H2 + MAXR * HH + MAXR * H2 + 2 * MAXR * 64 + 64 + DPB_PART_FLOATS); }
+size_t a2s_note_decoder_bwd_persist_ws_bytes(int n_clips) {
+    if (n_clips < 1 || n_clips > 8) return 0;
+    return 512 + sizeof(unsigned) * 8 * NWG + sizeof(u64) * (size_t)n_clips * DPB_REGION;
+}
+bool a2s_note_decoder_bwd_persist_ok(const a2s_note_dec_bwd_args& a) {
+    if (!a2s_dec_persist_enabled() || !a.persist_ws) return false;
+    const int C = a.n_clips > 0 ? a.n_clips : a.R;
+    if (C < 1 || C > 8 || a.R % C || a.R / C > MAXR) return false;
+    if (a.H != HH || a.E != EE || a.T > NWG * CHF || a.steps < 1 || !a.step_ws) return false;
+    if (a.persist_ws_bytes < a2s_note_decoder_bwd_persist_ws_bytes(C) || ((uintptr_t)a.persist_ws & 255)) return false;
+    const size_t need_ws = a2s_note_step_fused_head_floats() + (size_t)KX * 3 * H2 + (size_t)H2 * 3 * H2 + (size_t)H2 * HH;
+    if (a.step_ws_floats < need_ws || ((uintptr_t)(a.step_ws + a2s_note_step_fused_head_floats()) & 15)) return false;
+    return aligned16p(a.keys) && aligned16p(a.enc) && aligned16p(a.q);
+}
+int a2s_note_decoder_bwd_persist(hipStream_t st, const a2s_note_dec_bwd_args& a) {
+    const int C = a.n_clips > 0 ? a.n_clips : a.R;
+    const long n = a.steps, R = a.R;
+    char* base = reinterpret_cast<char*>(a.persist_ws);
+    hipError_t e = hipMemsetAsync(base, 0, a2s_note_decoder_bwd_persist_ws_bytes(C), st);
+    // rows / steps this call never touches read as zero gradients in the deferred products
+    if (e == hipSuccess) e = hipMemsetAsync(a.dgi_all, 0, sizeof(float) * n * R * 3 * H2, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.dgh_all, 0, sizeof(float) * n * R * 3 * H2, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.dq_all, 0, sizeof(float) * n * R * HH, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.ds_all, 0, sizeof(float) * n * R * a.T, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.dctx_all, 0, sizeof(float) * n * R * H2, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.dx, 0, sizeof(float) * n * R * KX, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd_persist memset: %s", hipGetErrorString(e));
+    int rc = a2s_note_step_fused_bwd_prepare(st, a);       // W_ih^T, W_hh^T, W_h^T into the step workspace
+    if (rc) return rc;
+    DecPersistBwd p;
+    p.attn_v = a.attn_v;
+    p.wih_t = a.step_ws + a2s_note_step_fused_head_floats();
+    p.whh_t = p.wih_t + (long)KX * 3 * H2;
+    p.wh_t = p.whh_t + (long)H2 * 3 * H2;
+    p.keys = a.keys; p.enc = a.enc; p.h = a.h; p.x = a.x; p.q = a.q; p.gates = a.gates; p.attw = a.attw; p.do_all = a.do_all;
+    p.dgi_all = a.dgi_all; p.dgh_all = a.dgh_all; p.dq_all = a.dq_all; p.ds_all = a.ds_all; p.dctx_all = a.dctx_all; p.dx = a.dx; p.dh = a.dh;
+    p.row_until = a.n_active ? a.row_until : nullptr;
+    p.abort_flag = reinterpret_cast<unsigned*>(base); p.xcc = reinterpret_cast<unsigned*>(base + 512);
+    p.xg = reinterpret_cast<u64*>(base + 512 + sizeof(unsigned) * 8 * NWG);
+    p.C = C; p.NR = a.R / C; p.R = a.R; p.T = a.T; p.steps = a.steps;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dpb_lds_bytes());
+        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "dec_persist_bwd: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dec_persist_bwd, dim3(8 * NWG), dim3(NTH), dpb_lds_bytes(), st, p);
+    A2S_CHECK_LAUNCH("dec_persist_bwd");
+    // token columns of dx for all steps at once: dx[:, :E] = dgi_all W_ih[:, :E]  (W_ih (3 H2, KX): B(k, n) = w_ih[k * KX + n])
+    return a2s_gemm_impl(st, (int)(n * R), EE, 3 * H2, 1.f, a.dgi_all, 3 * H2, 1, a.w_ih, KX, 1, 0.f, a.dx, KX, nullptr, 0, 1, 0, 0, 0, 0, nullptr, 0);
 }

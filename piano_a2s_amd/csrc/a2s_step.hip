@@ -387,6 +387,7 @@ int a2s_dec_fused_max_rows(void) {
 // scratch layout (floats): [16: flags | FUSED_MAX_RB: tickets | max_rows x 176: logits] then [W_ih^T | W_hh^T | W_h^T] for the backward
 #define FUSED_MAX_ROWS_CAP 1024
 #define FUSED_HEAD (16 + FUSED_MAX_ROWS_CAP / 16 + (long)FUSED_MAX_ROWS_CAP * 16 * NTV)
+size_t a2s_note_step_fused_head_floats(void) { return (size_t)FUSED_HEAD; }
 size_t a2s_note_step_workspace_floats_impl(int H, int E) {
     const long H2 = 2L * H, kx = E + H2;
     return (size_t)(FUSED_HEAD + kx * 3 * H2 + H2 * 3 * H2 + H2 * H);

@@ -681,7 +681,12 @@ class Engine:
             # hold a clip's keys / encoder outputs in LDS and wait for each other: two such launches in flight at once would share the CUs and
             # starve each other.  So only the LAST group may take that path (the long clips; or the whole minibatch when it is that small), and
             # its two staves then run one after the other on the group's stream.
-            persist_g = (plan is not None and Bg <= 8 and gidx == len(clip_groups) - 1 and H == 256 and E == 16 and not inference
+            # ... and only when no other clip group decodes beside it (A2S_DEC_PERSIST_BESIDE=1 lifts that): a persistent launch occupies the
+            # registers and LDS of every CU, so a bulk group that runs concurrently is stopped for as long as it is resident -- measured at
+            # B = 256 with 8 long clips: the long-clip chain went from ~230 to ~85 ms per step, the bulk group's first segment from 280 to 825 us
+            # per step, and the step from 514 to 540 ms (profiles/r04_dec_persist_beside_bulk.txt).
+            alone = len(clip_groups) == 1 or _os.environ.get("A2S_DEC_PERSIST_BESIDE") == "1"
+            persist_g = (plan is not None and Bg <= 8 and gidx == len(clip_groups) - 1 and alone and H == 256 and E == 16 and not inference
                          and _os.environ.get("A2S_DEC_PERSIST", "1") != "0")
             concurrent_g = concurrent and gidx <= 1 and not persist_g      # (a third group would have no stream left: everything in order on its own)
             streams = staff_streams(dev, gidx) if concurrent_g else None

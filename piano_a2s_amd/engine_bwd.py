@@ -151,6 +151,14 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
     else:
         a.row_list, a.n_rows_active = None, None
     a.R, a.T, a.H, a.E, a.steps = B, T, H, E, n
+    # the forward ran this call as one persistent launch (at most 8 clips): so does the reverse loop (csrc/a2s_dec_persist.hip)
+    a.persist_ws, a.persist_ws_bytes, a.w_ih_full = None, 0, None
+    persist_ws = None
+    if sv.get("persist_ws") is not None:
+        nb_ws = L.a2s_note_decoder_bwd_persist_ws_bytes(n_clips)
+        if nb_ws:
+            persist_ws = torch.empty(nb_ws, dtype=torch.uint8, device=dev)
+            a.persist_ws, a.persist_ws_bytes = persist_ws.data_ptr(), nb_ws
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) everything nobody in the recurrence waits for
     def deferred_work():
@@ -277,7 +285,10 @@ class Backward:
         dK_g = {p: t[b0:b1] for p, t in dK.items()}
         dEnc_staff_g = [t[b0:b1] for t in dEnc_staff]
         ts_out_g, key_out_g, up_out_g, lo_out_g = gs["outs"]
-        concurrent_g = concurrent and gidx <= 1           # as in Engine.forward (engine.staff_streams)
+        # as in Engine.forward (engine.staff_streams); a group whose calls ran as persistent launches back-propagates its staves one after
+        # the other (two persistent launches must never be in flight together)
+        persist_g = any(seg["staff"][k][2].get("persist_ws") is not None for seg in gs["segments"] for k in ("up", "lo"))
+        concurrent_g = concurrent and gidx <= 1 and not persist_g
         streams = staff_streams(dev, gidx) if concurrent_g else None
         use_deferred_g = use_deferred and gidx == 0
         deferred_streams = _deferred_streams(dev, gidx) if use_deferred_g else None

@@ -84,6 +84,7 @@ def test_fused_training_step_with_the_persistent_long_clip_group(dev):
     torch.manual_seed(5)
     init = models.ScoreTranscription(**cfg).state_dict()
     res = []
+    os.environ["A2S_DEC_PERSIST_BESIDE"] = "1"          # (off by default: it stops the other group while resident; correctness is what is tested here)
     for persist in (False, True):
         os.environ["A2S_DEC_PERSIST"] = "1" if persist else "0"
         hip.check(hip.lib().a2s_debug_set(b"dec_persist", 1 if persist else 0), "debug_set")
@@ -96,6 +97,7 @@ def test_fused_training_step_with_the_persistent_long_clip_group(dev):
         res.append((losses[:, 0].double().cpu(), step.opt.ctl.double().cpu(), step.flat.double().cpu(), step._last[2]))
         del step, m
     os.environ["A2S_DEC_PERSIST"] = "1"
+    os.environ.pop("A2S_DEC_PERSIST_BESIDE", None)
     hip.check(hip.lib().a2s_debug_set(b"dec_persist", 1), "debug_set")
     (l0, c0, p0, g0), (l1, c1, p1, g1) = res
     assert g1 is not None and len(g1) == 2 and g1[1][1] - g1[1][0] <= 8, f"expected a long-clip group of at most 8 clips, got {g1}"
@@ -103,3 +105,36 @@ def test_fused_training_step_with_the_persistent_long_clip_group(dev):
     assert torch.allclose(l0, l1, rtol=2e-5, atol=0), (l0, l1)
     assert abs(float(c0[0]) - float(c1[0])) <= 1e-4 * float(c0[0])
     assert float((p0 - p1).abs().max()) <= 2e-5 * float(p0.abs().max())
+
+
+@pytest.mark.parametrize("B,frames,tf", [(3, 97, 1.0), (8, 1201, 0.6), (5, 301, 0.0)])
+def test_persistent_decoder_backward_equals_stepwise(dev, B, frames, tf):
+    """Same forward (persistent), then the reverse loops once as launches per step and once as persistent launches: every parameter
+    gradient must agree (the two paths sum in different orders: fp32 round-off only)."""
+    import os
+    from piano_a2s_amd import engine_bwd, hip, spec, synthetic
+    from tests.test_gpu_backward import _loss_grads
+    cfg = _cfg()
+    st = spec.procedural_state(cfg, 60 + B, eos_bias=2.0, lively="token")
+    S = {k: v.to(dev) for k, v in st.items()}
+    batch = synthetic.make_batch(B, cfg, 17 + B, frames=frames, upper_range=(5, 30), lower_range=(3, 18), full_tail=0.15, spectrogram="ridges")
+    grads = []
+    for persist_bwd in (False, True):
+        Sx = {k: v.clone() for k, v in S.items()}
+        outs, calls, eng = _forward(cfg, Sx, batch, dev, True, tf, 4)
+        assert all(c["used"] for c in calls)
+        _, gouts = _loss_grads(outs, batch, dev)
+        hip.check(hip.lib().a2s_debug_set(b"dec_persist", 1 if persist_bwd else 0), "debug_set")
+        G = engine_bwd.backward(eng, Sx, gouts)
+        torch.cuda.synchronize()
+        grads.append({k: v.clone() for k, v in G.items() if isinstance(k, str) and not k.startswith("__")})
+    hip.check(hip.lib().a2s_debug_set(b"dec_persist", 1), "debug_set")
+    os.environ["A2S_DEC_PERSIST"] = "1"
+    bad = []
+    for k in grads[0]:
+        a, b = grads[0][k].double(), grads[1][k].double()
+        assert torch.isfinite(b).all(), f"{k}: non-finite (a wait timed out?)"
+        err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-12)
+        if err > 5e-5:
+            bad.append((k, err))
+    assert not bad, bad[:8]
