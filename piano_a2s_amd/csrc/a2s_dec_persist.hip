@@ -39,6 +39,7 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define VV 173
 #define VP 176                      // logits row in granules (11 tiles of 16)
 #define AUX_SC1V ((int)(16u | 0x80000000u))
+#define XLD (EE + 2 * H2 + 4)          // floats per staged row (+4: rows land 4 banks apart)
 #define DP_PART_FLOATS (((NWV - 1) * 4 * 80) > (NTH > 512 ? MAXR * H2 : 0) ? ((NWV - 1) * 4 * 80) : (MAXR * H2))
 #define DPB_PART_FLOATS (((NWV - 1) * 2 * 80) > (MAXR * HH) ? ((NWV - 1) * 2 * 80) : (MAXR * HH))
 
@@ -74,6 +75,47 @@ __device__ __forceinline__ bool frag_load(const __amdgpu_buffer_rsrc_t rs, int l
     const u32x4_t x1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, AUX_SC1V);
     a[0] = __uint_as_float(x0[0]); a[1] = __uint_as_float(x0[2]); a[2] = __uint_as_float(x1[0]); a[3] = __uint_as_float(x1[2]);
     return (x0[1] == tag) & (x0[3] == tag) & (x1[1] == tag) & (x1[3] == tag);
+}
+
+
+// All threads of the workgroup copy `ncols` (even) columns of the ON rows of a row-major granule matrix (`ld` granules per row, region `rs`,
+// first column c0 of the matrix) into the LDS image dst[row * dld + dcol0 + col]: every thread issues ALL of its 16-byte loads (two granules
+// each) before it looks at a tag, and the whole batch is repeated until every granule of every thread's share carries `tag` -- one memory
+// round trip per hand-off instead of one per k-step.  Rows that are off get zeros.  MAXP: loads per thread (>= ceil(nrows * ncols / 2 / NTH)).
+template <int MAXP>
+__device__ __forceinline__ void stage_rows(const __amdgpu_buffer_rsrc_t rs, int ld, int c0, int nrows, int ncols, int onmask, unsigned tag, float* dst, int dld,
+                                           int dcol0, int tid, Spin& spin) {
+    const int half = ncols >> 1, total = nrows * half;
+    for (;;) {
+        u32x4_t x[MAXP];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = tid + NTH * i;
+            if (p < total) {
+                const int row = p / half, c2 = p - row * half;
+                if ((onmask >> row) & 1) {
+                    x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (row * ld + c0 + 2 * c2) * 8, 0, AUX_SC1V);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = tid + NTH * i;
+            if (p < total) {
+                const int row = p / half, c2 = p - row * half;
+                float v0 = 0.f, v1 = 0.f;
+                if ((onmask >> row) & 1) { ok &= (x[i][1] == tag) & (x[i][3] == tag); v0 = __uint_as_float(x[i][0]); v1 = __uint_as_float(x[i][2]); }
+                dst[row * dld + dcol0 + 2 * c2] = v0; dst[row * dld + dcol0 + 2 * c2 + 1] = v1;
+            }
+        }
+        if (__all(ok)) break;
+        if (!spin.again()) break;
+    }
+}
+// A fragment of a 16-wide k-step from an LDS image: lane (li = row, lk) reads 4 consecutive floats at column k0 + 4 lk of row li (rows >= nrows: zeros)
+__device__ __forceinline__ f32x4 frag_lds(const float* img, int ld, int nrows, int li, int lk, int k0) {
+    return li < nrows ? *reinterpret_cast<const f32x4*>(img + li * ld + k0 + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 // Sum of the NWV waves' partial tiles in wave 0, fixed order (wave 1, 2, ...), ONE barrier pair.  Only the rows of the clip matter (<= 5 of
@@ -120,6 +162,8 @@ struct DecPersistFwd {
     int* argmax_out; long am_bstride;
     int* eos_seen; long long* lengths; int* n_done; int* steps_exec;
     const int* row_until;                               // device, R ints or null
+    int* eos_first;                                     // greedy: step of every row's first <eos> (-1: none yet); R ints
+    unsigned* stop;                                     // greedy: per clip, first step NOT to run (0: keep going); 8 words, zeroed
     u64* xg;                                            // granule workspace (zeroed): C regions of DP_REGION granules
     unsigned* abort_flag; unsigned* xcc;                // zeroed; xcc: C x 32 words
     int C, NR, R, T, steps, eos_id;
@@ -142,6 +186,7 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
     float* sc = Eq + MAXR * HH;                         // [MAXR][64]  scores / chunk weights
     float* part = sc + MAXR * 64;                       // (NWV - 1) * 4 * 80 floats: cross-wave reduction; also the second half of the partial contexts
     float* red = part + DP_PART_FLOATS;                 // 64 floats: small broadcasts
+    float* XH = red + 64;                               // [MAXR][XLD]: staged rows [token | context | state] of the GRU / output products
     const int L = blockIdx.x, c = L & 7, w = L >> 3;            // clip (XCD under the observed dispatch), member
     if (c >= a.C) return;
     const int tid0 = threadIdx.x;
@@ -331,29 +376,35 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
             // thread (col = tid / 32, chunk g = tid % 32): half-waves reduce over the 32 chunks
             if (tid < 512) {
                 const int col = tid >> 5, g = tid & 31;
+                float mg[MAXR], lg[MAXR], pc[MAXR];
+                for (;;) {                                       // all rows' granules in flight together
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < MAXR; ++j) {
+                        mg[j] = 0.f; lg[j] = 0.f; pc[j] = 0.f;
+                        if (!ON(j)) continue;
+                        const u64* pm = G + G_PM + (long)(g * MAXR + j) * 2;
+                        const u64 xm = __hip_atomic_load((gu64*)(const_cast<u64*>(pm)), RLX_AGENT), xl = __hip_atomic_load((gu64*)(const_cast<u64*>(pm + 1)), RLX_AGENT);
+                        const u64 xc = __hip_atomic_load((gu64*)(G + G_PC + (long)(g * MAXR + j) * H2 + 16 * w + col), RLX_AGENT);
+                        mg[j] = __uint_as_float((unsigned)xm); lg[j] = __uint_as_float((unsigned)xl); pc[j] = __uint_as_float((unsigned)xc);
+                        ok &= ((unsigned)(xm >> 32) == tag) & ((unsigned)(xl >> 32) == tag) & ((unsigned)(xc >> 32) == tag);
+                    }
+                    if (__all(ok)) break;
+                    if (!spin.again()) break;
+                }
 #pragma unroll
                 for (int j = 0; j < MAXR; ++j) {
                     if (!ON(j)) continue;
-                    float mg = 0.f, lg = 0.f, pc = 0.f;
-                    const u64* pm = G + G_PM + (long)(g * MAXR + j) * 2;
-                    const u64* pcp = G + G_PC + (long)(g * MAXR + j) * H2 + 16 * w + col;
-                    for (;;) {
-                        const u64 xm = __hip_atomic_load((gu64*)(const_cast<u64*>(pm)), RLX_AGENT), xl = __hip_atomic_load((gu64*)(const_cast<u64*>(pm + 1)), RLX_AGENT);
-                        const u64 xc = __hip_atomic_load((gu64*)(const_cast<u64*>(pcp)), RLX_AGENT);
-                        mg = __uint_as_float((unsigned)xm); lg = __uint_as_float((unsigned)xl); pc = __uint_as_float((unsigned)xc);
-                        if (__all(((unsigned)(xm >> 32) == tag) & ((unsigned)(xl >> 32) == tag) & ((unsigned)(xc >> 32) == tag))) break;
-                        if (!spin.again()) break;
-                    }
                     // max over the 32 chunks of this half-wave
-                    float M = mg;
+                    float M = mg[j];
                     M = fmaxf(M, dpp_take<A2S_DPP_QUAD_1032>(M, M));
                     M = fmaxf(M, dpp_take<A2S_DPP_QUAD_2301>(M, M));
                     M = fmaxf(M, dpp_take<A2S_DPP_ROW_HALF_MIRROR>(M, M));
                     M = fmaxf(M, dpp_take<A2S_DPP_ROW_MIRROR>(M, M));
                     M = fmaxf(M, dpp_take<A2S_DPP_ROW_BCAST15, 0xA, false>(M, M));         // lanes 16..31 / 48..63: the half's max
-                    M = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M), 31 + 32 * 0));   // (both halves hold the same 32 chunks' statistics)
-                    const float eg = __expf(mg - M);
-                    float Lsum = lg * eg, cs = pc * eg;
+                    M = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M), 31));   // (both halves hold the same 32 chunks' statistics)
+                    const float eg = __expf(mg[j] - M);
+                    float Lsum = lg[j] * eg, cs = pc[j] * eg;
                     Lsum += dpp_take<A2S_DPP_QUAD_1032>(0.f, Lsum); cs += dpp_take<A2S_DPP_QUAD_1032>(0.f, cs);
                     Lsum += dpp_take<A2S_DPP_QUAD_2301>(0.f, Lsum); cs += dpp_take<A2S_DPP_QUAD_2301>(0.f, cs);
                     Lsum += dpp_take<A2S_DPP_ROW_HALF_MIRROR>(0.f, Lsum); cs += dpp_take<A2S_DPP_ROW_HALF_MIRROR>(0.f, cs);
@@ -375,22 +426,23 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
                 f32x4 acc[4];                                    // r, z, n (input part), n (state part)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const int ldt = EE, ldc = H2;
+                // [token | context | previous state] rows of the clip -> LDS, one batched pass each (three sources)
+                stage_rows<1>(rsrc_of(G + G_TOK + (long)(s & 1) * MAXR * EE, MAXR * EE * 8), EE, 0, NR, EE, onmask, tag, XH, XLD, 0, tid, spin);
+                if (!a.gt) {                                       // greedy: did the epilogue of the previous step end the decode?  (uniform over the clip)
+                    if (tid == 0) { const unsigned st = __hip_atomic_load((gu32*)(a.stop + c), RLX_AGENT); red[1] = (st != 0 && st <= (unsigned)s) ? 1.f : 0.f; }
+                    __syncthreads();
+                    const bool stop_now = red[1] != 0.f;
+                    __syncthreads();
+                    if (stop_now) break;
+                }
+                stage_rows<3>(rsrc_of(G + G_CTX + (long)(s & 1) * MAXR * H2, MAXR * H2 * 8), H2, 0, NR, H2, onmask, tag, XH, XLD, EE, tid, spin);
+                stage_rows<3>(rsrc_of(G + G_H + (long)(s & 1) * MAXR * H2, MAXR * H2 * 8), H2, 0, NR, H2, onmask, tag, XH, XLD, EE + H2, tid, spin);
+                __syncthreads();
 #pragma unroll
                 for (int cc = 0; cc < GKS; ++cc) {
                     const int u = wave + NWV * cc;
                     if (u >= 65) break;
-                    float av[4];
-                    for (;;) {
-                        bool ok;
-                        if (u == 0) ok = frag_load(rsrc_of(G + G_TOK + (long)(s & 1) * MAXR * EE, MAXR * EE * 8), ldt, NR, li, lk, 0, tag, av);
-                        else if (u < 33) ok = frag_load(rsrc_of(G + G_CTX + (long)(s & 1) * MAXR * H2, MAXR * H2 * 8), ldc, NR, li, lk, 16 * (u - 1), tag, av);
-                        else ok = frag_load(rsrc_of(G + G_H + (long)(s & 1) * MAXR * H2, MAXR * H2 * 8), ldc, NR, li, lk, 16 * (u - 33), tag, av);
-                        // rows that are switched off carry stale granules: their lanes do not count
-                        if (li < NR && !ON(li)) { ok = true; av[0] = av[1] = av[2] = av[3] = 0.f; }
-                        if (__all(ok)) break;
-                        if (!spin.again()) break;
-                    }
+                    const f32x4 av = frag_lds(XH, XLD, NR, li, lk, 16 * u);
                     if (u < 33) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -438,19 +490,17 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
             if (have && !(role_out && s < 0)) {
                 f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
                 const unsigned htag = (unsigned)(s + 2);
+                // the new state rows h[s + 1] -> LDS behind the context rows staged for the GRU ([token | context | state] image: the output
+                // projection's operand [state | context] is read from there; before the first step only the state exists)
+                const int hmask = s < 0 ? ((1 << NR) - 1) : onmask;
+                __syncthreads();                                   // (the GRU's readers of the image are done)
+                stage_rows<3>(rsrc_of(G + G_H + (long)((s + 1) & 1) * MAXR * H2, MAXR * H2 * 8), H2, 0, NR, H2, hmask, htag, XH, XLD, EE + H2, tid, spin);
+                __syncthreads();
 #pragma unroll
                 for (int cc = 0; cc < OKS; ++cc) {
                     const int u = wave + NWV * cc;
                     if (u >= (role_out ? 64 : 32)) break;
-                    float av[4];
-                    for (;;) {
-                        bool ok;
-                        if (u < 32) ok = frag_load(rsrc_of(G + G_H + (long)((s + 1) & 1) * MAXR * H2, MAXR * H2 * 8), H2, NR, li, lk, 16 * u, htag, av);
-                        else ok = frag_load(rsrc_of(G + G_CTX + (long)(s & 1) * MAXR * H2, MAXR * H2 * 8), H2, NR, li, lk, 16 * (u - 32), tag, av);
-                        if (s >= 0 && li < NR && !ON(li)) { ok = true; av[0] = av[1] = av[2] = av[3] = 0.f; }
-                        if (__all(ok)) break;
-                        if (!spin.again()) break;
-                    }
+                    const f32x4 av = frag_lds(XH, XLD, NR, li, lk, u < 32 ? EE + H2 + 16 * u : EE + 16 * (u - 32));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wo_[cc][i], acc[0], 0, 0, 0);
                 }
@@ -510,19 +560,29 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
                 const long long gtok = a.gt ? a.gt[grow * a.gt_bstride + s] : -1;
                 const int tf = a.flags ? ((a.flags[s] >> j) & 1) : 0;
                 const int next_id = (a.gt && tf) ? (int)gtok : mi;
+                if (lane == 0) {
+                    if (a.argmax_out) a.argmax_out[grow * a.am_bstride + s] = mi;
+                    const bool hit = a.gt ? (gtok == a.eos_id) : (mi == a.eos_id);
+                    if (hit) {
+                        if (!a.eos_seen[grow]) { a.eos_seen[grow] = 1; if (a.eos_first) a.eos_first[grow] = s; atomicAdd(a.n_done, 1); }
+                        a.lengths[grow] = s + 1;
+                    }
+                    if (!a.gt) {
+                        // greedy decoding ends (for everybody) once every row of every clip has shown <eos> (reference models.py:389).  The clips
+                        // run on their own: whoever sees the count complete tells its clip's workgroups, through a word stored BEFORE this
+                        // row's token granules -- the GRU stage of the next step reads it after those granules.  A clip that notices late runs
+                        // a few steps too many; dec_persist_greedy_fixup erases them (the true end is a function of the first-<eos> steps).
+                        if (__hip_atomic_load((gu32*)(reinterpret_cast<unsigned*>(a.n_done)), RLX_AGENT) >= (unsigned)R) {
+                            __hip_atomic_store((gu32*)(a.stop + c), (unsigned)(s + 1), RLX_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
+                }
                 if (lane < EE) {                        // (also after the last step: the state slot `steps` exists, as in the launch-per-step path)
                     float e = a.emb[(long)next_id * EE + lane];
                     if (a.drop) e = a.drop[((long)(s + 1) * R + grow) * EE + lane] ? e * a.inv_keep : 0.f;
                     if (s + 1 < a.steps) put(G + G_TOK + (long)(((s + 1) & 1) * MAXR + j) * EE + lane, tag + 1, e, same_xcd);
                     a.x[((long)(s + 1) * R + grow) * KX + lane] = e;
-                }
-                if (lane == 0) {
-                    if (a.argmax_out) a.argmax_out[grow * a.am_bstride + s] = mi;
-                    const bool hit = a.gt ? (gtok == a.eos_id) : (mi == a.eos_id);
-                    if (hit) {
-                        if (!a.eos_seen[grow]) { a.eos_seen[grow] = 1; atomicAdd(a.n_done, 1); }
-                        a.lengths[grow] = s + 1;
-                    }
                 }
             }
         }
@@ -840,6 +900,29 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_bwd(DecPersistBwd a) {
     }
 }
 
+// Greedy decoding: the true end of the loop is S = 1 + the latest first-<eos> step over all rows (when every row has one; else `steps`); a clip
+// may have run past it.  Erase what the reference would not have written, rebuild lengths from the ids below S, report S.
+__global__ __launch_bounds__(256) void dec_persist_greedy_fixup(float* __restrict__ probs, long probs_bstride, int* __restrict__ ids, long am_bstride,
+                                                                long long* __restrict__ lengths, const int* __restrict__ eos_first, int* __restrict__ steps_exec,
+                                                                int R, int steps, int V, int eos_id, int max_steps) {
+    __shared__ int S;
+    if (threadIdx.x == 0) {
+        int m = -1; bool all = true;
+        for (int r = 0; r < R; ++r) { all &= eos_first[r] >= 0; m = max(m, eos_first[r]); }
+        S = all ? min(m + 1, steps) : steps;
+        if (blockIdx.x == 0) *steps_exec = S;
+    }
+    __syncthreads();
+    const int row = blockIdx.x;
+    for (long i = (long)S * V + threadIdx.x; i < (long)steps * V; i += 256) probs[row * probs_bstride + i] = 0.f;
+    if (threadIdx.x == 0) {
+        int last = 0;
+        for (int t = 0; t < S; ++t) if (ids[row * am_bstride + t] == eos_id) last = t + 1;
+        lengths[row] = last > 0 ? last : max_steps;
+    }
+    for (int t = S + threadIdx.x; t < steps; t += 256) ids[row * am_bstride + t] = 0;
+}
+
 // ------------------------------------------------------------------------------------------- launcher
 static int g_dec_persist = -1;                          // A2S_DEC_PERSIST=0 / a2s_debug_set("dec_persist", 0): the launch-per-step kernels
 void a2s_dec_persist_set(int v) { g_dec_persist = v ? 1 : 0; }
@@ -847,19 +930,21 @@ int a2s_dec_persist_enabled(void) {
     if (g_dec_persist < 0) { const char* e = getenv("A2S_DEC_PERSIST"); g_dec_persist = (e && e[0] == '0') ? 0 : 1; }
     return g_dec_persist;
 }
-static size_t dp_lds_bytes(void) { return sizeof(float) * (CHF * HH + CHF * H2 + MAXR * HH + MAXR * 64 + 64 + DP_PART_FLOATS); }
+static size_t dp_lds_bytes(void) { return sizeof(float) * (CHF * HH + CHF * H2 + MAXR * HH + MAXR * 64 + 64 + DP_PART_FLOATS + MAXR * XLD); }
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps) {
     if (n_clips < 1 || n_clips > 8) return 0;
-    return 512 + sizeof(unsigned) * 8 * NWG + sizeof(u64) * (size_t)n_clips * DP_REGION + sizeof(float) * 2 * (size_t)(steps > 0 ? steps : 1) * R;
+    return 512 + sizeof(unsigned) * 8 * NWG + sizeof(u64) * (size_t)n_clips * DP_REGION + sizeof(float) * 2 * (size_t)(steps > 0 ? steps : 1) * R
+           + sizeof(int) * (size_t)R + 256;
 }
 static bool aligned16p(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 bool a2s_note_decoder_fwd_persist_ok(const a2s_note_dec_args& a) {
-    if (!a2s_dec_persist_enabled() || !a.gt || !a.persist_ws || a.use_graph) return false;
+    if (!a2s_dec_persist_enabled() || !a.persist_ws || a.use_graph) return false;
+    if (!a.gt && (a.gates || a.attw || a.drop || a.n_active)) return false;      // greedy: inference only
     const int C = a.n_clips > 0 ? a.n_clips : a.R;
     if (C < 1 || C > 8 || a.R % C || a.R / C > MAXR) return false;
     if (a.H != HH || a.E != EE || a.V != VV || a.T > NWG * CHF || a.steps < 1) return false;
-    if (a.tf_flags && !a.tf_flags_dev) return false;
+    if (a.gt && a.tf_flags && !a.tf_flags_dev) return false;
     if (a.persist_ws_bytes < a2s_note_decoder_persist_ws_bytes(C, a.R, a.steps) || ((uintptr_t)a.persist_ws & 255)) return false;
     return aligned16p(a.w_ih) && aligned16p(a.w_hh) && aligned16p(a.out_w) && aligned16p(a.attn_w) && aligned16p(a.keys) && aligned16p(a.enc);
 }
@@ -883,6 +968,12 @@ int a2s_note_decoder_fwd_persist(hipStream_t st, const a2s_note_dec_args& a, int
     p.out_w = a.out_w; p.out_b = a.out_b; p.emb = a.emb; p.keys = a.keys; p.enc = a.enc;
     p.h = a.h; p.x = a.x; p.q = a.q; p.o = a.o; p.gates = a.gates; p.attw = a.attw;
     p.stats = reinterpret_cast<float*>(base + head);
+    p.eos_first = reinterpret_cast<int*>(base + head + sizeof(float) * 2 * (size_t)n * R);
+    p.stop = reinterpret_cast<unsigned*>(base) + 16;              // (inside the zeroed head: words 16 .. 23)
+    if (!a.gt) {
+        e = hipMemsetAsync(p.eos_first, 0xff, sizeof(int) * R, st);
+        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_fwd_persist memset: %s", hipGetErrorString(e));
+    }
     p.probs = a.probs; p.probs_bstride = a.probs_bstride; p.gt = a.gt; p.gt_bstride = a.gt_bstride; p.flags = a.tf_flags_dev;
     p.drop = a.drop; p.inv_keep = a.inv_keep; p.argmax_out = a.argmax_out; p.am_bstride = a.am_bstride;
     p.eos_seen = a.eos_seen; p.lengths = a.lengths; p.n_done = a.n_done; p.steps_exec = a.steps_exec;
@@ -901,6 +992,11 @@ int a2s_note_decoder_fwd_persist(hipStream_t st, const a2s_note_dec_args& a, int
     if (a.attw) {
         hipLaunchKernelGGL(dec_persist_attw_normalise, dim3((unsigned)(n * R)), dim3(256), 0, st, a.attw, p.stats, p.row_until, a.steps, a.R, a.T);
         A2S_CHECK_LAUNCH("dec_persist_attw_normalise");
+    }
+    if (!a.gt) {
+        hipLaunchKernelGGL(dec_persist_greedy_fixup, dim3(a.R), dim3(256), 0, st, a.probs, a.probs_bstride, a.argmax_out, a.am_bstride, a.lengths, p.eos_first,
+                           a.steps_exec, a.R, a.steps, a.V, a.eos_id, (int)a.am_bstride);
+        A2S_CHECK_LAUNCH("dec_persist_greedy_fixup");
     }
     if (steps_done) *steps_done = a.steps;
     return A2S_OK;

@@ -524,7 +524,7 @@ class Engine:
         # never be in flight together (each wants every CU's LDS; see decode_group)
         persist_ws = None
         a.tf_flags_dev, a.persist_ws, a.persist_ws_bytes = None, None, 0
-        if persist and gt_bar is not None and n > 0 and (tf_flags is None or flags_dev is not None):
+        if persist and n > 0 and (gt_bar is not None or not training) and (tf_flags is None or flags_dev is not None):
             nb_ws = L.a2s_note_decoder_persist_ws_bytes(active["n_clips"] if active else B, B, n)
             if nb_ws:
                 persist_ws = torch.empty(nb_ws, dtype=torch.uint8, device=dev)
@@ -686,7 +686,7 @@ class Engine:
             # B = 256 with 8 long clips: the long-clip chain went from ~230 to ~85 ms per step, the bulk group's first segment from 280 to 825 us
             # per step, and the step from 514 to 540 ms (profiles/r04_dec_persist_beside_bulk.txt).
             alone = len(clip_groups) == 1 or _os.environ.get("A2S_DEC_PERSIST_BESIDE") == "1"
-            persist_g = (plan is not None and Bg <= 8 and gidx == len(clip_groups) - 1 and alone and H == 256 and E == 16 and not inference
+            persist_g = (Bg <= 8 and gidx == len(clip_groups) - 1 and alone and H == 256 and E == 16 and (plan is not None or (inference and not greedy_graph))
                          and _os.environ.get("A2S_DEC_PERSIST", "1") != "0")
             concurrent_g = concurrent and gidx <= 1 and not persist_g      # (a third group would have no stream left: everything in order on its own)
             streams = staff_streams(dev, gidx) if concurrent_g else None
