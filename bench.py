@@ -153,6 +153,142 @@ def conv_roofline(B, T, F, iters=6):
     return out
 
 
+def step_roofline(B, T, F, H, clip_steps, ms_per_step):
+    """Whole-step HBM roofline: ALGORITHMIC bytes of one optimizer step (derivation: DESIGN.md section 6) / measured step time / 8 TB/s.
+      ConvStack, per clip, in units u = T x F x 4 bytes (one channel plane): forward = input (1) + every activation tensor written once and
+        read once by its consumer (2 x 120 channels); backward = every activation read once more (120) + every activation gradient written
+        once and read once (2 x 120) + the layer input of each weight gradient (80)  ->  681 u;
+      encoder: features, the four input projections and the two layers' outputs, forward + backward  ~ 60 MB per clip;
+      decoder: every (clip, decode step) pair that is still running streams the clip's key image and encoder outputs once in the forward
+        and once in the backward pass: 2 x T x 3H x 4 bytes per pair (pairs counted by the step's own plan)."""
+    u = T * F * 4.0
+    conv = B * 681.0 * u
+    enc = B * 60e6
+    attn = 2.0 * clip_steps * T * 3 * H * 4.0
+    total = conv + enc + attn
+    gbs = total / (ms_per_step * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_step": int(total), "parts_GB": {"convstack": round(conv / 1e9, 1), "encoder": round(enc / 1e9, 1), "decoder_attention": round(attn / 1e9, 1)},
+            "attention_clip_steps_per_step": int(clip_steps), "ms_per_step": ms_per_step,
+            "what": "algorithmic HBM bytes of one optimizer step / the timed step / HBM peak (the profile is flat: no single kernel is more than 5 % of the step)"}
+
+
+def linear_roofline(B, T, F, Cf=256, iters=5):
+    """The three products of the 19200 -> 256 Linear (reference models.py:504,537-539) at the step's shapes, as the step issues them (two
+    exact fp16 terms per fp32 operand, BatchNorm+ReLU of the operand folded into the staging, BatchNorm-backward statistics in the data
+    gradient's epilogue): time, fraction of the two-term matrix roof (2.5 PF / 3 products) and of the HBM roof (operand tensor once)."""
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rows, K = B * T, 40 * F
+    y4 = torch.randn(rows, K, device=dev)
+    W = torch.randn(Cf, K, device=dev) * 0.007
+    Wt = W.t().contiguous()
+    dz = torch.randn(rows, Cf, device=dev) * 1e-5
+    scale, shift = torch.rand(40, device=dev) + 0.5, torch.randn(40, device=dev) * 0.1
+    mean, invstd = torch.zeros(40, device=dev), torch.ones(40, device=dev)
+    wmax, dmax = hip.absmax(W), hip.absmax(dz)
+    z = torch.empty(rows, Cf, device=dev)
+    da = torch.empty(rows, K, device=dev)
+    G = torch.zeros(Cf, K, device=dev)
+    part = torch.empty((L.a2s_gemm_bnstats_blocks(rows, F), 40, 2), device=dev)
+    sk = L.a2s_gemm_pick_splitk(Cf, K, rows, 1)
+
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    ms = {"forward": timed(lambda: hip.linear(y4, W, out=z, x_affine=(scale, shift, F), two_term=(None, wmax))),
+          "data_gradient": timed(lambda: hip.check(L.a2s_gemm_f32_bnstats_scaled(hip.stream(), rows, K, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(Wt), C.c_long(1),
+                                                                                  C.c_long(Cf), hip._p(da), C.c_long(K), hip._p(y4), hip._p(mean), hip._p(invstd),
+                                                                                  hip._p(scale), hip._p(shift), F, hip._p(part), hip._p(dmax), hip._p(wmax)), "bnstats")),
+          "weight_gradient": timed(lambda: hip.gemm(dz, 1, Cf, y4, K, 1, G, K, Cf, K, rows, beta=1.0, splitk=sk, b_affine=(scale, shift, F), two_term=(dmax, None)))}
+    flops = 2.0 * rows * K * Cf
+    big = 4.0 * rows * K                                   # the (rows, 19200) operand / result: read (written) once
+    byts = {"forward": big, "data_gradient": 2 * big, "weight_gradient": big}        # (the data gradient writes da and reads y4 for the statistics)
+    out = {"kernel": "gemm_f32_kernel<256, 256, 4, 2, ..., 2> (two-term fp16 tiles)", "peak_TFLOPs": round(MFMA_BF16_PEAK_TFS / 3, 1), "peak_GBs": HBM_PEAK_GBS}
+    for k, t in ms.items():
+        out[k] = {"ms": round(t, 2), "TFLOPs": round(flops / t / 1e9, 1), "frac_mfma": round(flops / t / 1e9 / (MFMA_BF16_PEAK_TFS / 3), 4),
+                  "GBs": round(byts[k] / t / 1e6, 1), "frac_hbm": round(byts[k] / t / 1e6 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def vqt_block(cfg, dev, B=64, iters=3):
+    """The VQT front end (reference utilities.py:240-254: librosa.vqt + amplitude_to_db, offline) as framed GEMMs on the GPU: clips/s and the
+    algorithmic rates (waveform in, (1201, 480) features out; direct kernel-bank flops).  Parity with librosa itself is UNPINNED (DESIGN.md
+    section 9); B = 64 here (the front end is not in the training step)."""
+    from piano_a2s_amd import synthetic, vqt
+    wave = synthetic.make_waveforms(B, 5, device=dev)
+    front = vqt.VQT(dev)
+    front(wave)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = front(wave)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = sum(2.0 * 2 * (o["hi"] - o["lo"]) * o["n_fft"] for o in front.octaves) * out.shape[2] * B        # complex bank: 2 real GEMMs per octave
+    nbytes = wave.numel() * 4.0 + out.numel() * 4.0
+    return {"clips_per_s": round(B / ms * 1e3, 1), "ms_per_batch": round(ms, 2), "batch": B, "frames": int(out.shape[2]), "bins": int(out.shape[3]),
+            "algorithmic_TFLOPs": round(flops / ms / 1e9, 2), "frac_of_fp32_mfma_peak": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFS, 4),
+            "algorithmic_GBs": round(nbytes / ms / 1e6, 1), "frac_hbm": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 5),
+            "parity": "vs oracle/vqt_ref.py <= 0.012 dB (tests/test_gpu_vqt.py); vs librosa 0.10.1: UNPINNED (librosa / numba / soxr absent, no network)"}
+
+
+def dp_settings_block(model, cfg, B, dev, full_tail, steps=3):
+    """Collectives per optimizer step and step time under a ONE-rank process group (RCCL through the launcher-less path) for both BatchNorm
+    settings: per-rank statistics (default, plain DDP semantics) and synchronised statistics (A2S_SYNC_BN=1: what SpeechBrain's
+    SyncBatchNorm conversion gives the reference when it wraps the model in DDP)."""
+    from piano_a2s_amd import synthetic, train
+    created = False
+    if not (dist.is_available() and dist.is_initialized()):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        created = True
+    out = {}
+    try:
+        b = synthetic.make_batch(B, cfg, 1234, full_tail=full_tail)
+        b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
+        for name, sync in (("per_rank_batchnorm", False), ("synchronised_batchnorm", True)):
+            st = train.TrainStep(model, dropout=True, sync_bn=sync)
+            calls = {"n": 0}
+            orig = dist.all_reduce
+
+            def counting(*a, **k):
+                calls["n"] += 1
+                return orig(*a, **k)
+            dist.all_reduce = counting
+            try:
+                rng = random.Random(7)
+                st(b, TF_RATIO, rng=rng)
+                torch.cuda.synchronize()
+                calls["n"] = 0
+                t0 = time.time()
+                for _ in range(steps):
+                    st(b, TF_RATIO, rng=rng)
+                torch.cuda.synchronize()
+                dt = (time.time() - t0) / steps
+            finally:
+                dist.all_reduce = orig
+            out[name] = {"all_reduces_per_step": round(calls["n"] / steps, 1), "ms_per_step_one_rank": round(dt * 1e3, 1)}
+            del st
+        out["note"] = ("gradient exchange: 2 overlapped all-reduces of the flat gradient buffer (the loss gate rides in the first); synchronised BatchNorm adds "
+                       "1 batch-shape check + 5 statistics exchanges forward + 5 backward, each a few hundred floats")
+    finally:
+        if created:
+            dist.destroy_process_group()
+    return out
+
+
+
 def attention_roofline(step, batch_dev, B, T, H, iters=50):
     """Average launch duration of the dominant kernel (attn_step_fwd) at the step's own shapes, HIP events on the launch stream."""
     from piano_a2s_amd import hip
@@ -298,7 +434,7 @@ def loss_parity(dev):
                       "TrainStep; total + 4 loss terms vs the reference's CPU values (tests/golden/g2_full.npz, g2_full_tf07.npz)"}
 
 
-def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=3):
+def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=10, steps_shared=3):
     """Data-parallel straggler term WITHOUT an 8-GPU box: every rank of an N-rank job meets the others at the gradient
     all-reduce, so a job step lasts as long as its slowest rank's.  A rank's step time is a function of its minibatch (target lengths) and
     of the teacher-forcing coins it draws (how bars fuse, reference models.py:289,404) -- not of the weights -- so the 8 ranks' step
@@ -308,7 +444,7 @@ def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=3):
     reference does on one GPU with the N-fold batch).  Communication is not in this number (65.4 MB over xGMI, overlapped)."""
     from piano_a2s_amd import synthetic
 
-    def run(rank, coin_seed):
+    def run(rank, coin_seed, steps=steps):
         rng = random.Random(coin_seed)
         ms = []
         for k in range(steps + 1):
@@ -324,13 +460,14 @@ def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=3):
         return ms
 
     def efficiency(table):
-        mean = sum(sum(r) for r in table) / (len(table) * steps)
-        worst = sum(max(r[k] for r in table) for k in range(steps)) / steps
+        k_ = len(table[0])
+        mean = sum(sum(r) for r in table) / (len(table) * k_)
+        worst = sum(max(r[k] for r in table) for k in range(k_)) / k_
         return mean / worst
 
     offset = [run(r, 1234 + r) for r in range(ranks)]
-    shared = [offset[0]] + [run(r, 1234) for r in range(1, ranks)]
-    out = {"ranks": ranks, "steps_per_rank": steps,
+    shared = [offset[0][:steps_shared]] + [run(r, 1234, steps_shared) for r in range(1, ranks)]
+    out = {"ranks": ranks, "steps_per_rank": steps, "steps_per_rank_shared_coins": steps_shared,
            "rank_offset_coins": {"predicted_dp_efficiency": round(efficiency(offset), 4), "step_ms_by_rank": [[round(t, 1) for t in r] for r in offset]},
            "shared_coins": {"predicted_dp_efficiency": round(efficiency(shared), 4), "step_ms_by_rank": [[round(t, 1) for t in r] for r in shared]},
            "what": "8 ranks' step sequences run one after another on this GPU; efficiency = mean step time / mean over steps of the slowest "
@@ -344,7 +481,9 @@ def inference_block(cfg, dev, batches=(256, 8)):
     from piano_a2s_amd import engine, hip, spec, synthetic
     L = hip.lib()
     S = {k: v.to(dev) for k, v in spec.procedural_state(cfg, 2032, eos_bias=2.5, lively="token").items()}
-    out = {"weights": "procedural (seed 2032, <eos> bias 2.5)", "mode": "eval, greedy, device-side <eos> bookkeeping polled every 16 steps"}
+    out = {"weights": "procedural (seed 2032, <eos> bias 2.5)",
+           "mode": "eval, greedy; B > 8: launch-per-step kernels, device-side <eos> bookkeeping polled every 16 steps; B <= 8: ONE persistent launch per "
+                   "(bar, staff) call (csrc/a2s_dec_persist.hip), the end of the decode decided on the device"}
     for B in batches:
         x = synthetic.make_batch(B, cfg, 77, spectrogram="ridges", full_tail=0.0)[0].to(dev)
         eng = engine.Engine(cfg)
@@ -424,6 +563,7 @@ def main():
     def timed(batches, warmup, steps):
         """W untimed + K timed steps, bracketed by barrier + synchronize on both sides; max over ranks; decode steps executed per step."""
         decode_steps = []
+        timed.clip_steps = []
         for i in range(warmup):
             step(batches[i % len(batches)], TF_RATIO)
         torch.cuda.synchronize()
@@ -438,6 +578,7 @@ def main():
         for i in range(steps):
             step(batches[i % len(batches)], TF_RATIO)
             decode_steps.append(step.decode_steps)
+            timed.clip_steps.append(getattr(step, "attn_clip_steps", 0))
             marks[i + 1].record()
             segs.append(torch.cuda.memory_stats().get("segment.all.allocated", 0))
         timed.new_segments = [b - a for a, b in zip(segs[:-1], segs[1:])]
@@ -456,6 +597,7 @@ def main():
     from piano_a2s_amd import hip as a2s_hip
     elapsed, decode_steps = timed(batches, args.warmup, args.steps)
     launches_per_step = round((a2s_hip.lib().a2s_launch_count() - timed.launches0) / args.steps)
+    clip_steps_per_step = sum(timed.clip_steps) / max(len(timed.clip_steps), 1)
     main_step_ms = list(timed.step_ms)
     main_new_segments = list(timed.new_segments)
     loss = float(step.total)
@@ -483,7 +625,10 @@ def main():
         clips = B * world * args.steps
         out = {"metric": "training clips/sec (12 s, 5-bar)", "value": round(clips / elapsed, 3), "unit": "clips/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "dtype_note": "fp32 data, fp32 accumulation and fp32 results; the large contractions multiply on the fp16 matrix pipes with every fp32 operand "
+                             "EMULATED as two exact fp16 terms (22 of 24 significand bits, element error measured equal to the fp32-input MFMA kernels')",
+               "data": "synthetic",
                "config": {"workload": "pretrain.yaml model (16.36M params), 12 s clips = 1201x480 frames, 5 bars, max 398/189 tokens; "
                                       "random-init weights; tf_ratio 0.7; dropout on; fwd+loss+bwd+clip+Adadelta",
                           "per_gpu_batch": B, "global_batch": B * world, "upper_len": "U{20..120}", "lower_len": "U{10..80}",
@@ -513,6 +658,8 @@ def main():
         batches = None
         torch.cuda.empty_cache()
         out["roofline"] = conv_roofline(B, 1201, cfg["freq_bins"])
+        out["roofline_step"] = step_roofline(B, 1201, cfg["freq_bins"], cfg["hidden_size"], clip_steps_per_step, out["ms_per_step"])
+        out["roofline_linear"] = linear_roofline(B, 1201, cfg["freq_bins"])
         out["roofline_attention"] = attention_roofline(step, None, B, 1201, cfg["hidden_size"])
         if not args.no_secondary and not use_dist:
             # (single-process runs only: with a process group every TrainStep call takes part in the gradient all-reduce, and rank 0 is
@@ -521,6 +668,10 @@ def main():
         if world == 1 and not args.no_inference:
             out["inference"] = inference_block(cfg, dev)
             out["inference"]["attention_roofline_frac"] = out["roofline_attention"]["frac"]
+        if world == 1 and not args.no_inference:
+            out["vqt"] = vqt_block(cfg, dev)
+        if world == 1 and not use_dist and not args.no_straggler_sim:
+            out["data_parallel_settings"] = dp_settings_block(model, cfg, B, dev, args.full_tail)
         if world == 1 and not args.no_straggler_sim:
             out["dp_straggler_simulation"] = straggler_simulation(step, cfg, B, dev, args.full_tail)
             out["predicted_dp_efficiency"] = out["dp_straggler_simulation"][COIN_POLICY + "_coins"]["predicted_dp_efficiency"]

@@ -254,6 +254,7 @@ def _dist_world():
 class Engine:
     def __init__(self, cfg, sync_bn=False):
         self.cfg = cfg
+        self.attn_clip_steps = []
         self.poll = 16            # greedy decode: host looks at the device-side done counter every `poll` steps
         # Synchronised BatchNorm (what SpeechBrain's DDP wrapping gives the reference): batch statistics over the
         # GLOBAL minibatch -- per-channel (sum, sum of squares, count) are all-reduced between the ranks.  Off by default:
@@ -262,42 +263,28 @@ class Engine:
 
     def _global_stats(self, partial, nblocks, C_, count):
         """(nblocks, C, 2) per-block partial sums of this rank -> (1, C, 2) sums of ALL ranks, global element count.
-        The count is world x the local count, on the host: every rank of a data-parallel step holds the same number of clips and frames
-        (DistributedSampler pads the index list; the batches of one step have one shape), so no device-to-host read stalls the forward
-        pass five times per step (round 1 all-reduced the count and fetched it with .item())."""
+        The count is world x the local count, on the host: train.TrainStep has verified at the start of the step that every rank holds the
+        same batch shape (Engine.check_counts), so no device-to-host read stalls the forward pass five times per step."""
         import torch.distributed as dist
         sums = torch.empty(2 * C_, dtype=torch.float32, device=partial.device)
         hip.check(hip.lib().a2s_col_sum(hip.stream(), hip._p(partial), C.c_long(2 * C_), hip._p(sums), C.c_long(nblocks), 2 * C_,
                                         hip.f32(1.0), hip.f32(0.0), C.c_void_p(0), C.c_size_t(0)), "a2s_col_sum (bn stats)")
         dist.all_reduce(sums)
-        self._queue_count_check(count, partial.device)
         return sums, float(count) * dist.get_world_size()
 
-    def _queue_count_check(self, count, dev):
-        """world x local count is the global count only when every rank holds the same number of frames.  Every rank queues the SAME
-        tiny collective per statistics exchange (MAX of [count, -count]; no rank may skip it on a local condition, that would mismatch
-        the collectives) and nobody waits for it: `check_counts` reads the queued results later, at a point that synchronises anyway
-        (TrainStep.report, or the next forward)."""
+    @staticmethod
+    def check_counts(count, dev):
+        """world x local count is the global count only when every rank holds the same number of frames (DistributedSampler pads the index
+        list; a user DataLoader's uneven last batch does not).  ONE tiny collective per step, issued and read at the start of the step -- the
+        step begins with a host read of the targets anyway, nothing is in flight yet -- instead of one queued collective per BatchNorm layer
+        (round 3: five extra all-reduces per step and, as the advisor noted, a blocking read in the middle of the ConvStack)."""
         import torch.distributed as dist
-        self.check_counts()
         t = torch.tensor([float(count), -float(count)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        Engine._count_checks.append(t)
-
-    _count_checks = []                 # per process (a TrainStep builds a fresh Engine every step)
-
-    @staticmethod
-    def check_counts(all_pending=False):
-        """Raise if a queued frame-count exchange found ranks with different batch shapes (a user DataLoader's uneven last batch, a
-        custom sampler): the batch statistics of that step were wrong.  Reads results older than the current step only, unless asked."""
-        pend = Engine._count_checks
-        keep = 0 if all_pending else 5
-        while len(pend) > keep:
-            t = pend.pop(0)
-            hi, lo = float(t[0]), -float(t[1])
-            if hi != lo:
-                raise RuntimeError(f"synchronised BatchNorm: the ranks held different numbers of frames in one step ({lo:.0f} .. {hi:.0f}); "
-                                   "give every rank the same batch shape (DistributedSampler pads; drop or pad an uneven last batch)")
+        hi, lo = float(t[0]), -float(t[1])
+        if hi != lo:
+            raise RuntimeError(f"synchronised BatchNorm: the ranks hold different numbers of frames in this step ({lo:.0f} .. {hi:.0f}); "
+                               "give every rank the same batch shape (DistributedSampler pads; drop or pad an uneven last batch)")
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -712,6 +699,7 @@ class Engine:
                 rank[order.long()] = torch.arange(Bg, dtype=torch.int32)
                 cnt = torch.bincount(clip_until.long(), minlength=n + 1)
                 n_act = Bg - torch.cumsum(cnt, 0)[:n]                                                               # clips with until > t
+                self.attn_clip_steps.append(int(n_act.sum()))          # (clip, step) pairs whose keys / encoder outputs this call streams: bench.py's step roofline
                 # 1 + the largest clip POSITION still unfinished at step t (the per-step products of the tail run on that prefix of every
                 # fused bar only: a2s_note_dec_args.m_active; train.plan_clip_groups puts the clips with the longest rows first)
                 last = torch.zeros(n + 1, dtype=torch.long)

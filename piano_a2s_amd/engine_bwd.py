@@ -232,7 +232,10 @@ class Backward:
         H2 = 2 * H
         self.names = [k for k in S if not is_buffer(k)]
         self.offs, self.total = flat_layout([S[k].numel() for k in self.names])          # same layout as models.ScoreTranscription.flatten_()
-        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        # one word behind the gradients: the step's loss (train.TrainStep writes it before finish()).  It rides in the FIRST slice that is
+        # all-reduced, so the data-parallel skip / apply decision ("is every rank's loss finite?") needs no collective of its own.
+        self.flat_full = torch.zeros(self.total + 1, dtype=torch.float32, device=dev)
+        self.flat = self.flat_full[:self.total]
         self.G = {k: self.flat[off:off + S[k].numel()].view(S[k].shape) for k, off in zip(self.names, self.offs)}
         # device table of the staff-embedding gradient pointers: uploaded once, before the first kernel of the backward pass
         ptrs_host = torch.tensor([self.G[f"decoder.staff_emb.{w}_{sfx}"].data_ptr() for sfx in ("l0", "l0_reverse")
@@ -432,18 +435,19 @@ class Backward:
         d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T)
         n_conv = next(off for k, off in zip(names, offs) if not k.startswith("convstack."))      # state_dict order: convstack first
         if grad_ready is not None:
-            grad_ready(flat, n_conv, total)
+            grad_ready(self.flat_full, n_conv, total + 1)           # (+ the loss word)
         _convstack_bwd(eng, S, G, sv["conv"], d_conv, B, T, F)
         if grad_ready is not None:
             grad_ready(flat, 0, n_conv)
         G[None] = flat
+        G["__loss_gate__"] = self.flat_full[total:]
         eng._keep_alive = self.keep_alive
         return G
 
 
 
 
-def backward(eng, S, grad_outputs, grad_ready=None):
+def backward(eng, S, grad_outputs, grad_ready=None, loss_total=None):
     """Gradients of sum_i <out_i, grad_outputs_i> wrt every parameter.  Returns dict name -> tensor (views of ONE flat buffer,
     also returned as `flat` under key None) in state_dict parameter order.
     grad_ready(flat, start, end): optional callback, called when flat[start:end] is final (everything that writes it has been
@@ -466,6 +470,8 @@ def backward(eng, S, grad_outputs, grad_ready=None):
         ctx.decoder_group(gidx, sv["groups"][gidx], dts[b0:b1], dkey[b0:b1], dup_g, dlo_g)
 
     run_clip_groups(dev, [lambda gi=gi: group(gi) for gi in range(len(clip_groups))])
+    if loss_total is not None:
+        ctx.flat_full[ctx.total:].copy_(loss_total.reshape(1))
     return ctx.finish(grad_ready)
 
 

@@ -283,6 +283,8 @@ class TrainStep:
                 spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len)]
                 eng.clip_groups = [(0, n_main), (n_main, B)]
         S = self.state()
+        if self.sync_bn and eng.sync_bn:
+            engine.Engine.check_counts(spectrogram.shape[0] * spectrogram.shape[2] * spectrogram.shape[3], spectrogram.device)
         exchange = GradientExchange(self.world)
         fwd = dict(inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len], teacher_forcing_ratio=teacher_forcing_ratio, training=True,
                    rng=rng, dropout=self.dropout, gt_host=gt_host)
@@ -322,6 +324,7 @@ class TrainStep:
             outs = eng.forward(S, spectrogram, **fwd)
             groups = eng.clip_groups_used
             losses, _ = self.objective(outs, (ts_t, key_t, up_lay, lo_lay), want_grad=False)
+            torch.sum(losses[:, 0], dim=0, keepdim=True, out=ctx.flat_full[ctx.total:])      # the loss word of the gradient buffer (see finish)
             G = ctx.finish(grad_ready=exchange.slice_ready)
         else:
             outs = eng.forward(S, spectrogram, **fwd)
@@ -333,8 +336,9 @@ class TrainStep:
                 losses, gouts = self.objective(outs, (ts_t, key_t, lay(up_t), lay(lo_t)))
             else:
                 losses, gouts = self.objective(outs, (ts_t, key_t, up_t, lo_t))
-            G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready)
+            G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready, loss_total=losses[:, 0].sum())
         self.decode_steps = sum(seg["staff"][k][2]["steps"] for g in eng.saved["groups"] for seg in g["segments"] for k in ("up", "lo"))
+        self.attn_clip_steps = sum(eng.attn_clip_steps)        # forward; the backward streams the same pairs once more
         if self.time_exchange and exchange.active:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -345,13 +349,11 @@ class TrainStep:
             flat_g = exchange.finish(G[None])
         self.collectives += exchange.issued
         torch.sum(losses[:, 0], dim=0, keepdim=True, out=self.total)          # total loss stays on the device
-        gate = self.total
-        if exchange.active:
-            # every replica must take the SAME skip / apply decision (reference check_gradients looks at the local loss only, which
-            # under data parallelism lets one rank skip while the others apply): the gate is the sum of all ranks' losses -- finite
-            # iff every rank's is; non-finite gradients reach every rank through the all-reduce and gate via the norm
-            gate = self.total.clone()
-            dist.all_reduce(gate, op=dist.ReduceOp.SUM)
+        # every replica must take the SAME skip / apply decision (reference check_gradients looks at the local loss only, which under data
+        # parallelism lets one rank skip while the others apply): the gate is the sum of all ranks' losses -- finite iff every rank's is.  It
+        # travelled as the last word of the first gradient slice (engine_bwd.Backward.flat_full), so it costs no collective of its own;
+        # non-finite gradients reach every rank through the all-reduce and gate via the norm.
+        gate = G["__loss_gate__"] if exchange.active else self.total
         self.opt.step(flat_g, gate, zero_grad=False)
         # the engine, its group hook (a closure over the backward context) and the backward context (which holds the engine) form a reference
         # cycle: left to the cyclic collector, ~3.3 GiB of per-step gradient buffers stayed allocated for several steps and the caching
@@ -386,6 +388,4 @@ class TrainStep:
     def report(self):
         """Host copy of the last step's [time-sig, key, upper, lower loss, applied flag] -- ONE small device-to-host read (the
         reference recipe does four .cpu() reads per step, pretrain.py:90-93)."""
-        if self.sync_bn:
-            engine.Engine.check_counts(all_pending=True)
         return torch.cat([self.objective.losses[:, 0], self.opt.ctl[2:3]]).tolist()
