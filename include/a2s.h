@@ -65,6 +65,17 @@ int a2s_gemm_f32_affine_scaled(void* stream, int M, int N, int K, float alpha, c
 int a2s_gemm_f32_bnstats_scaled(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
                                 const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
                                 const float* a_absmax, const float* b_absmax);
+/* Round 4: the data gradient of the ConvStack's 19200 -> 256 Linear (reference models.py:68; backward of y = relu(bn4(y4)) W^T) as a kernel of
+ * its own (csrc/a2s_linear.hip): da (M x N) = dz (M x 256, leading dimension lda) * Wt^T with Wt (N x 256) the k-contiguous copy of the weight,
+ * plus the BatchNorm-backward statistics of a2s_gemm_f32_bnstats_scaled into partial[a2s_linear_dgrad_blocks(M)][N / period][2] (same
+ * consumer).  K must be 256, N % 32 == 0, period % 32 == 0; workspace: a2s_linear_dgrad_ws_bytes(N, 256) bytes (the weight as fp16 term
+ * planes), 16-byte aligned.  a2s_linear_dgrad_eligible says whether a shape qualifies (otherwise call a2s_gemm_f32_bnstats_scaled). */
+int a2s_linear_dgrad_bnstats(void* stream, int M, int N, int K, const float* dz, long lda, const float* Wt, float* da, long ldc, const float* y,
+                             const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
+                             const float* dz_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes);
+size_t a2s_linear_dgrad_ws_bytes(int N, int K);
+int a2s_linear_dgrad_blocks(int M);
+int a2s_linear_dgrad_eligible(int M, int N, int K, int period);
 /* out[0] = max |x[i]| over n floats (device scalar) */
 int a2s_absmax(void* stream, const float* x, long n, float* out);
 int a2s_gemm_bnstats_blocks(int M, int period);

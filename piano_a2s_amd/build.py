@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liba2s_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
-SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_conv_rows.hip", "a2s_conv_wrows.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip", "a2s_vqt.hip", "a2s_step.hip", "a2s_persist.hip", "a2s_dec_persist.hip"]
+SOURCES = ["a2s_api.hip", "a2s_gemm.hip", "a2s_conv.hip", "a2s_conv_rows.hip", "a2s_conv_wrows.hip", "a2s_seq.hip", "a2s_bwd.hip", "a2s_opt.hip", "a2s_vqt.hip", "a2s_step.hip", "a2s_persist.hip", "a2s_dec_persist.hip", "a2s_linear.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 

@@ -109,6 +109,13 @@ int a2s_bn_bwd_stats_impl(hipStream_t, const float*, const float*, const float*,
 int a2s_bn_bwd_apply_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
                           const float*, const float*, double, float*, float*, float*, float*, long, int, int);
 
+int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* Wt, long sBk, long sBn, float* C, long ldc,
+                                  const float* ep_y, const float* mean, const float* invstd, const float* scale, const float* shift, int period,
+                                  float* partial, const float* a_absmax, const float* b_absmax, float* ws, size_t ws_bytes);
+size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K);
+int a2s_linear_dgrad_blocks_impl(int M);
+bool a2s_linear_dgrad_ok(int M, int N, int K, long lda, long sBk, long sBn, long ldc, int period, const void* A, const void* B, const void* C, const void* y);
+
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -146,6 +153,17 @@ int a2s_gemm_f32_bnstats_scaled(void* stream, int M, int N, int K, const float* 
                                 nullptr, nullptr, 0, nullptr, nullptr, 0, y, mean, invstd, scale, shift, partial, period, 1, a_absmax, b_absmax);
 }
 int a2s_absmax(void* stream, const float* x, long n, float* out) { return a2s_absmax_impl(ST, x, n, out); }
+int a2s_linear_dgrad_bnstats(void* stream, int M, int N, int K, const float* dz, long lda, const float* Wt, float* da, long ldc, const float* y,
+                             const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
+                             const float* dz_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes) {
+    return a2s_linear_dgrad_bnstats_impl(ST, M, N, K, dz, lda, Wt, 1, K, da, ldc, y, mean, invstd, scale, shift, period, partial, dz_absmax, w_absmax,
+                                         workspace, workspace_bytes);
+}
+size_t a2s_linear_dgrad_ws_bytes(int N, int K) { return a2s_linear_dgrad_ws_bytes_impl(N, K); }
+int a2s_linear_dgrad_blocks(int M) { return a2s_linear_dgrad_blocks_impl(M); }
+int a2s_linear_dgrad_eligible(int M, int N, int K, int period) {
+    return a2s_linear_dgrad_ok(M, N, K, 4, 1, K, 4, period, nullptr, nullptr, nullptr, nullptr) ? 1 : 0;
+}
 int a2s_gemm_f32_bnstats(void* stream, int M, int N, int K, const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc,
                          const float* y, const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial) {
     return a2s_gemm_affine_impl(ST, M, N, K, 1.f, A, sAm, sAk, B, sBk, sBn, 0.f, C, ldc, nullptr, 0, 1, 0, 0, 0, 1, nullptr, 0,

@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restri
     dq[(long)b * lddq + j] = s;
 }
 
+size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward);
 template <int NQ>
 static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                           const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
@@ -1058,13 +1059,13 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G;
         if (groups == 1) {
-            const size_t shm = (chunk + 3 * 64 * 4) * sizeof(float);
+            const size_t shm = a2s_attn_bulk_lds((chunk + 3 * 64 * 4) * sizeof(float), r.n_active, 1);
             if (nt) hipLaunchKernelGGL(attn_bwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
                                        dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
             else hipLaunchKernelGGL(attn_bwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
                                     dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
         } else {
-            const size_t shm = ((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4 + (size_t)groups * ATT_DCS + 16) * sizeof(float);
+            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4 + (size_t)groups * ATT_DCS + 16) * sizeof(float), r.n_active, 1);
 #define A2S_BWD_MQ(N) launch_bwd_mq<N>(st, nwg, shm, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r, nt)
             switch (groups) {
                 case 2: A2S_BWD_MQ(2); break;

@@ -1,0 +1,232 @@
+// Data gradient of the ConvStack's 19200 -> 256 Linear with the layer-4 BatchNorm-backward statistics in its epilogue
+// (reference models.py:68 `self.out = nn.Linear(...)`, backward of y = relu(bn4(y4)) W^T):
+//
+//   da[m][n] = sum_k dz[m][k] Wt[n][k]        M = B*T rows (307 456 at B = 256), N = 40 * F = 19200 columns, K = 256
+//   s1[c] += g' , s2[c] += g' xhat            g' = da where bn4(y4) > 0, c = n / F
+//
+// The generic two-term tile of a2s_gemm.hip (256 x 256, one workgroup per tile) spends this launch outside the matrix pipe: K is only 8
+// k-tiles, every workgroup re-splits its 256 x 256 slice of W into fp16 terms (the whole of W 1201 times per launch), and its epilogue -- a
+// 256 KB store and a 256 KB re-read of y4 per tile, 47 GB per launch -- overlaps with nothing (one workgroup per CU, 256 registers):
+// 23.8 ms at B = 256 against ~9.5 ms of HBM time and 3.6 ms of matrix time.  Here:
+//   * W is split ONCE per launch into fp16 term planes laid out in MFMA-fragment order (lin_pack_planes: 19.7 MB, 1 KB contiguous per
+//     fragment); the sweep below reads its B fragments straight from those planes (L2-resident: all workgroups of an XCD walk the
+//     column tiles together) -- no conversion, no LDS, no barrier for B;
+//   * a workgroup owns 128 ROWS for ALL column tiles: its slice of dz is split once into LDS (147 KB: [64-k block][term][row][128 B + 16])
+//     and is read-only from then on, so the sweep over the 75 column tiles of 256 has NO barrier at all: the 8 waves (32 columns each)
+//     drift apart and one wave's epilogue (stores, the y4 re-read, the statistics) runs under the other waves' MFMAs on the same SIMD;
+//   * the statistics of a wave's 32-column slices (one channel each: F % 32 == 0) stay in registers until the channel changes.
+// Measured at B = 256 (tools/linear_bench.py 256; profiles/r04_linear_dgrad.txt): 15.1 ms (generic tile: 23.8).  Ablations (-DLIN_X): multiply
+// alone 7.2 ms (553 M MFMAs = 3.6 ms at the nominal clock; without the B loads 6.4), + stores 9.6, + the y4 re-read alone 10.9, both 15.1-15.6:
+// the two streams together cost more than their sum -- the launch is bound by the mixed read / write HBM traffic of 64-byte pieces of 16 rows
+// per instruction (PMC: 25.6 GB fetched = y4 + dz, the B fragments are L2 hits: 722 M hits against 392 M misses; non-temporal stores wrote
+// 32.7 GB for 23.6 GB of output, plain stores the exact bytes: hence plain).  Wave priorities or a start-up stagger between the two waves of
+// a SIMD change nothing.
+#include "a2s_common.h"
+#include "../../include/a2s.h"
+
+#define LIN_BM 128
+#define LIN_K 256
+#define LIN_RS 144                       // bytes per LDS row of one 64-k block: 128 of fp16 + 16 (16-byte slots of 16 rows all distinct mod 256)
+#define LIN_NTH 512
+#define LIN_LDS (4 * 2 * LIN_BM * LIN_RS)
+
+typedef unsigned lu32x4 __attribute__((ext_vector_type(4)));
+
+struct LinDgradArgs {
+    const float* A; long lda;            // dz (M x 256)
+    const unsigned char* planes;         // packed fp16 term planes of Wt (lin_pack_planes)
+    float* C; long ldc;                  // da (M x N)
+    const float* ep_y;                   // y4 (M x N, leading dimension ldc)
+    const float* mean; const float* invstd; const float* scale; const float* shift;
+    float* partial;                      // [M / 128 rounded up][8 waves][channels][2]
+    const float* a_absmax; const float* b_absmax;
+    int M, N, period, channels;
+};
+
+// Wt (N x 256, k contiguous) -> [n-tile][k-step][term][lane][8 halves]: the 16 bytes lane (lr = n % 16, lk) of the fragment of k-step ks
+// holds k = 32 ks + 8 lk .. + 7 of row n.  One thread per (n, 8 k).
+__global__ __launch_bounds__(256) void lin_pack_planes(const float* __restrict__ Wt, long ld, int N, const float* __restrict__ absmax,
+                                                       unsigned char* __restrict__ out) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(id >> 5), kg = (int)(id & 31);
+    if (n >= N) return;
+    const float ps = ldexpf(1.f, pow2_scale_exp(*absmax, 12));
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Wt + (long)n * ld + kg * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Wt + (long)n * ld + kg * 8 + 4);
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[i] = __builtin_amdgcn_fmed3f(v0[i] * ps, -65000.f, 65000.f); x[4 + i] = __builtin_amdgcn_fmed3f(v1[i] * ps, -65000.f, 65000.f); }
+    lu32x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned h, l; split2_pair_f16(x[2 * i], x[2 * i + 1], h, l); hi[i] = h; lo[i] = l; }
+    const int nt = n >> 4, lr = n & 15, ks = kg >> 2, lk = kg & 3;
+    unsigned char* o = out + ((((long)nt * 8 + ks) * 2) * 64 + (lk * 16 + lr)) * 16;
+    *reinterpret_cast<lu32x4*>(o) = hi;
+    *reinterpret_cast<lu32x4*>(o + 64 * 16) = lo;
+}
+
+__global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LIN_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.x * LIN_BM;
+    const int ka = pow2_scale_exp(*a.a_absmax, 12), kb = pow2_scale_exp(*a.b_absmax, 12);
+    const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kb));
+
+    // ---- this workgroup's 128 rows of dz -> two fp16 term images in LDS (rows beyond M: zeros)
+    {
+        f32x4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int slot = tid + LIN_NTH * i, row = slot >> 6, k = (slot & 63) * 4;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (m0 + row < a.M) v[i] = *reinterpret_cast<const f32x4*>(a.A + (long)(m0 + row) * a.lda + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int slot = tid + LIN_NTH * i, row = slot >> 6, k = (slot & 63) * 4;
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(v[i][j] * psa, -65000.f, 65000.f);
+            uint2 hi, lo;
+            split2_pair_f16(x[0], x[1], hi.x, lo.x);
+            split2_pair_f16(x[2], x[3], hi.y, lo.y);
+            const int blk = k >> 6, off = (k & 63) * 2;
+            *reinterpret_cast<uint2*>(lds + ((blk * 2 + 0) * LIN_BM + row) * LIN_RS + off) = hi;
+            *reinterpret_cast<uint2*>(lds + ((blk * 2 + 1) * LIN_BM + row) * LIN_RS + off) = lo;
+        }
+    }
+    __syncthreads();                     // the only barrier: the images are read-only from here on
+
+    const int ntiles = (a.N + 255) >> 8;
+    // addresses as (workgroup-uniform base) + (32-bit lane offset that never changes): the bases live in scalar registers
+    const unsigned lane_off = (unsigned)(lr * a.ldc + lk * 4) * 4u;
+    float s1 = 0.f, s2 = 0.f;
+    int cur_c = -1;
+    auto flush = [&]() {
+        if (cur_c < 0) return;
+        const float w1 = wave_sum(s1), w2 = wave_sum(s2);
+        if (lane == 0) {
+            float* p = a.partial + (((long)blockIdx.x * 8 + wave) * a.channels + cur_c) * 2;
+            p[0] = w1; p[1] = w2;
+        }
+    };
+    // B fragments of k-step ks of the 32-column slice at n0: planes + ((((n0 / 16 + nt) * 8 + ks) * 2 + term) * 64 + lane) * 16.  They come straight
+    // from L2 (~1 us under load) while a k-step is 0.3 us of MFMA per wave: a ring of three k-steps keeps two in flight, and the first two of the
+    // NEXT column tile are issued before the epilogue of this one.
+    lu32x4 bf[3][2][2];
+    auto load_b = [&](int n0, int ks, lu32x4 (&dst)[2][2]) {
+        const unsigned char* bp = a.planes + (long)(n0 >> 4) * 8 * 2 * 64 * 16;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) dst[nt][sp] = *reinterpret_cast<const lu32x4*>(bp + ((long)(nt * 8 + ks) * 2 + sp) * 1024 + (unsigned)lane * 16u);
+    };
+    if (wave * 32 < a.N) { load_b(wave * 32, 0, bf[0]); load_b(wave * 32, 1, bf[1]); }
+    for (int j = 0; j < ntiles; ++j) {
+        const int n0 = j * 256 + wave * 32;
+        if (n0 >= a.N) break;             // (wave-uniform; N % 32 == 0)
+        // the epilogue's re-read of y4 (16 bytes per lane and tile: 64 registers) is issued BEFORE the multiply: it costs 6.7 of 17 ms when the
+        // loads are issued where they are used (eight dependent round trips per column tile)
+        f32x4 yq[8][2];
+        auto load_y = [&](int mt) {
+            const int m = m0 + mt * 16 + lr;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#if defined(LIN_X) && LIN_X >= 1 && LIN_X != 4      /* timing ablations (-DLIN_X=: 1 no re-read of y4, 2 nor stores, 3 nor B loads in the k loop, 4 no stores only) */
+                yq[mt][nt] = (f32x4){1.f, 1.f, 1.f, 1.f};
+#else
+                yq[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (m < a.M)
+                    yq[mt][nt] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.ep_y + (long)(m0 + mt * 16) * a.ldc + n0 + nt * 16) + lane_off);
+#endif
+            }
+        };
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) load_y(mt);                      // (the other half once the multiply has released its registers)
+        f32x4 acc[8][2];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#if defined(LIN_X) && LIN_X >= 3
+            if (ks + 2 < 8 && a.M < 0) load_b(n0, ks + 2, bf[(ks + 2) % 3]);      // (timing experiment: no B traffic inside the k loop)
+#else
+            if (ks + 2 < 8) load_b(n0, ks + 2, bf[(ks + 2) % 3]);
+#endif
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                lu32x4 af[2][4];
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        af[sp][q] = *reinterpret_cast<const lu32x4*>(lds + (((ks >> 1) * 2 + sp) * LIN_BM + (half * 4 + q) * 16 + lr) * LIN_RS + (ks & 1) * 64 + lk * 16);
+#define LIN_PRODUCT(SA, SB)                                                                                                   \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                              \
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                             \
+                        acc[half * 4 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[ks % 3][nt][SB]), \
+                                                                                       __builtin_bit_cast(f16x8, af[SA][q]), acc[half * 4 + q][nt], 0, 0, 0);
+                LIN_PRODUCT(1, 0) LIN_PRODUCT(0, 1) LIN_PRODUCT(0, 0)
+#undef LIN_PRODUCT
+            }
+        }
+        if (n0 + 256 < a.N) { load_b(n0 + 256, 0, bf[0]); load_b(n0 + 256, 1, bf[1]); }
+#pragma unroll
+        for (int mt = 4; mt < 8; ++mt) load_y(mt);
+        // ---- epilogue: lane (lr, lk) of tile (mt, nt) owns da[m0 + 16 mt + lr][n0 + 16 nt + 4 lk .. + 3] (transposed accumulators)
+        const int c = n0 / a.period;
+        if (c != cur_c) { flush(); s1 = 0.f; s2 = 0.f; cur_c = c; }
+        const float mean = a.mean[c], invstd = a.invstd[c], sc = a.scale[c], sh = a.shift[c];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + mt * 16 + lr;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 v = acc[mt][nt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= unscale;
+#if defined(LIN_X) && LIN_X >= 2
+                if (v[0] == 123.456f)
+#endif
+                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.C + (long)(m0 + mt * 16) * a.ldc + n0 + nt * 16) + lane_off) = v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gm = (fmaf(yq[mt][nt][r], sc, sh) > 0.f) ? v[r] : 0.f;
+                    s1 += gm; s2 = fmaf(gm * (yq[mt][nt][r] - mean), invstd, s2);
+                }
+            }
+        }
+    }
+    flush();
+}
+
+size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K) { return (K == LIN_K && N > 0) ? (size_t)N * K * 2 * 2 : 0; }
+int a2s_linear_dgrad_blocks_impl(int M) { return M > 0 ? ((M + LIN_BM - 1) / LIN_BM) * 8 : 0; }
+
+bool a2s_linear_dgrad_ok(int M, int N, int K, long lda, long sBk, long sBn, long ldc, int period, const void* A, const void* B, const void* C, const void* y) {
+    return K == LIN_K && M >= LIN_BM && N >= 256 && N % 32 == 0 && period > 0 && period % 32 == 0 && N % period == 0 && N / period <= 4096 && sBk == 1 && sBn == K &&
+           lda % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)y) % 16 == 0);
+}
+
+int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* Wt, long sBk, long sBn, float* C, long ldc,
+                                  const float* ep_y, const float* mean, const float* invstd, const float* scale, const float* shift, int period,
+                                  float* partial, const float* a_absmax, const float* b_absmax, float* ws, size_t ws_bytes) {
+    A2S_REQUIRE(A && Wt && C && ep_y && mean && invstd && scale && shift && partial && a_absmax && b_absmax && ws, "linear_dgrad_bnstats: null argument");
+    A2S_REQUIRE(a2s_linear_dgrad_ok(M, N, K, lda, sBk, sBn, ldc, period, A, Wt, C, ep_y),
+                "linear_dgrad_bnstats: needs K = 256, M >= 128, N >= 256, N %% 32 == 0, period %% 32 == 0, a k-contiguous weight (N x K) and 16-byte aligned rows");
+    A2S_REQUIRE(((uintptr_t)ws % 16 == 0) && ws_bytes >= a2s_linear_dgrad_ws_bytes_impl(N, K), "linear_dgrad_bnstats: workspace too small (%zu bytes needed)",
+                a2s_linear_dgrad_ws_bytes_impl(N, K));
+    const int channels = N / period, nblk = a2s_linear_dgrad_blocks_impl(M);
+    hipError_t e = hipMemsetAsync(partial, 0, sizeof(float) * 2 * (size_t)nblk * channels, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "linear_dgrad_bnstats memset: %s", hipGetErrorString(e));
+    unsigned char* planes = reinterpret_cast<unsigned char*>(ws);
+    hipLaunchKernelGGL(lin_pack_planes, dim3((unsigned)(((long)N * 32 + 255) / 256)), dim3(256), 0, st, Wt, (long)K, N, b_absmax, planes);
+    A2S_CHECK_LAUNCH("lin_pack_planes");
+    LinDgradArgs a{A, lda, planes, C, ldc, ep_y, mean, invstd, scale, shift, partial, a_absmax, b_absmax, M, N, period, channels};
+    hipLaunchKernelGGL(lin_dgrad_bnstats, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
+    A2S_CHECK_LAUNCH("lin_dgrad_bnstats");
+    return A2S_OK;
+}

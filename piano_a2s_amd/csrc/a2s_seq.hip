@@ -1182,6 +1182,25 @@ int a2s_attn_nt_enabled(void) {
     if (g_attn_nt < 0) { const char* e = getenv("A2S_ATTN_NT"); g_attn_nt = e ? atoi(e) : 64; if (g_attn_nt < 0) g_attn_nt = 0; }      // default: launches over >= 64 clips
     return g_attn_nt;
 }
+// Occupancy cap of the bulk launches.  A launch over >= 64 clips asks for at least this much LDS -- 64 KB forward (2 workgroups per CU),
+// 32 KB backward (5) -- although its kernel needs ~2-3 KB: the loaded HBM latency that every OTHER kernel on the chip sees goes with the
+// bytes the bulk launches keep in flight (8 workgroups x 256 lanes x several 16-byte loads per CU = ~30 MB against the ~6 MB that saturate the
+// memory), and the long-clip group's chain of short dependent kernels -- the step's critical path -- pays that latency several times per
+// decode step.  Measured (profiles/r04_attn_occupancy_cap.txt, B = 256, same box): forward launch alone 155 -> 159 us at 2 per CU, backward
+// 152 -> 203 us (hence 5 there); in the step the long-clip group finishes 11 ms earlier, the bulk group 8 ms later, the step 507 -> 498 ms.
+// A2S_ATTN_BULK_LDS / A2S_ATTN_BULK_LDS_BWD = bytes (0: no cap).
+size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward) {
+    static long cap[2] = {-1, -1};
+    if (cap[0] < 0) {
+        const char* e = getenv("A2S_ATTN_BULK_LDS");
+        const char* b = getenv("A2S_ATTN_BULK_LDS_BWD");
+        cap[1] = b ? atol(b) : (e ? atol(e) : 32768);
+        cap[0] = e ? atol(e) : 65536;
+        for (int i = 0; i < 2; ++i) cap[i] = cap[i] < 0 ? 0 : (cap[i] > 65536 ? 65536 : cap[i]);
+    }
+    const size_t c = (size_t)cap[backward ? 1 : 0];
+    return (n_active >= 64 && c > shm) ? c : shm;
+}
 template <int NQ>
 static void launch_fwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                           float* ws, float* attw, int T, int G, int chunk, const a2s_attn_rows& r, const AttnFusedTail& ft, bool nt) {
@@ -1221,11 +1240,11 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
         if (r.n_active > 0) a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G + n_zero;
         if (groups == 1) {
-            const size_t shm = (chunk + 16 + 128 * 4) * sizeof(float);
+            const size_t shm = a2s_attn_bulk_lds((chunk + 16 + 128 * 4) * sizeof(float), r.n_active, 0);
             if (nt) hipLaunchKernelGGL(attn_fwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
             else hipLaunchKernelGGL(attn_fwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
         } else {
-            const size_t shm = ((size_t)groups * chunk + 16 + (size_t)groups * 128 * 4) * sizeof(float);
+            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + 16 + (size_t)groups * 128 * 4) * sizeof(float), r.n_active, 0);
             switch (groups) {
                 case 2: launch_fwd_mq<2>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;
                 case 3: launch_fwd_mq<3>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;

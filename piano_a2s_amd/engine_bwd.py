@@ -573,6 +573,24 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
 _FUSE_BN_APPLY = os.environ.get("A2S_FUSE_BN_APPLY", "0") == "1"
 _FUSE_BN_APPLY_L1 = os.environ.get("A2S_FUSE_BN_APPLY_L1", "1") != "0"
 _DGRAD_BNSTATS = os.environ.get("A2S_DGRAD_BNSTATS", "1") != "0"      # BatchNorm-backward statistics in the data-gradient conv's epilogue
+_LINEAR_DGRAD = os.environ.get("A2S_LINEAR_DGRAD", "1") != "0"        # the Linear's data gradient on its own kernel (csrc/a2s_linear.hip)
+
+
+def _linear_dgrad_generic(L, dev, rows, F, Cf, dz, Wout, da, y4, bn4, dz_amax, w_amax):
+    """Data gradient of the 19200 -> Cf Linear + layer-4 BatchNorm-backward statistics on the generic two-term GEMM tiles (shapes the kernel of
+    csrc/a2s_linear.hip does not take, or A2S_LINEAR_DGRAD=0).  Returns (partials, blocks)."""
+    nblk = L.a2s_gemm_bnstats_blocks(rows, F)
+    part = torch.empty((nblk, 40, 2), dtype=torch.float32, device=dev)
+    if L.a2s_debug_get(b"gemm_bf16x3") > 0:
+        # a k-contiguous copy of the weight (19.7 MB) puts this product on the split-operand path of the GEMM (both operands k-contiguous)
+        Wt = Wout.t().contiguous()
+        wb, s_bk, s_bn = Wt, 1, Cf
+    else:
+        wb, s_bk, s_bn = Wout, 40 * F, 1
+    hip.check(L.a2s_gemm_f32_bnstats_scaled(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(wb), C.c_long(s_bk), C.c_long(s_bn),
+                                            hip._p(da), C.c_long(40 * F), hip._p(y4), hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F,
+                                            hip._p(part), hip._p(dz_amax), hip._p(w_amax)), "a2s_gemm_f32_bnstats_scaled")
+    return part, nblk
 
 
 def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
@@ -629,20 +647,22 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
         if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
-            nblk = L.a2s_gemm_bnstats_blocks(rows, F)
-            part = torch.empty((nblk, 40, 2), dtype=torch.float32, device=dev)
-            if L.a2s_debug_get(b"gemm_bf16x3") > 0:
-                # a k-contiguous copy of the weight (19.7 MB) puts this product on the split-operand path of the GEMM (both operands k-contiguous)
-                Wt = Wout.t().contiguous()
-                wb, s_bk, s_bn = Wt, 1, Cf
-            else:
-                wb, s_bk, s_bn = Wout, 40 * F, 1
             if w_amax is None:
                 w_amax = hip.absmax(Wout)
-            hip.check(L.a2s_gemm_f32_bnstats_scaled(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(wb), C.c_long(s_bk), C.c_long(s_bn),
-                                                    hip._p(da), C.c_long(40 * F), hip._p(y4), hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F,
-                                                    hip._p(part), hip._p(dz_amax), hip._p(w_amax)), "a2s_gemm_f32_bnstats_scaled")
-            g_partial = (part, nblk)
+            if _LINEAR_DGRAD and L.a2s_linear_dgrad_eligible(rows, 40 * F, Cf, F):
+                # round 4: the kernel of its own (csrc/a2s_linear.hip): the weight pre-split once per launch, a workgroup's rows of dz resident in LDS
+                # for all column tiles, no barrier in the sweep
+                nblk = L.a2s_linear_dgrad_blocks(rows)
+                part = torch.empty((nblk, 40, 2), dtype=torch.float32, device=dev)
+                Wt = Wout.t().contiguous()
+                nb = L.a2s_linear_dgrad_ws_bytes(40 * F, Cf)
+                lws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+                hip.check(L.a2s_linear_dgrad_bnstats(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), hip._p(Wt), hip._p(da), C.c_long(40 * F), hip._p(y4),
+                                                     hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F, hip._p(part), hip._p(dz_amax), hip._p(w_amax),
+                                                     hip._p(lws), C.c_size_t(nb)), "a2s_linear_dgrad_bnstats")
+                g_partial = (part, nblk)
+            else:
+                g_partial = _linear_dgrad_generic(L, dev, rows, F, Cf, dz, Wout, da, y4, bn4, dz_amax, w_amax)
         else:
             hip.gemm(dz, Cf, 1, Wout, 40 * F, 1, da, 40 * F, rows, 40 * F, Cf)
     else:

@@ -56,7 +56,7 @@ def lib():
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
         _lib.a2s_launch_count.restype = C.c_longlong
-        for fn in ("a2s_note_step_workspace_floats", "a2s_note_decoder_persist_ws_bytes", "a2s_note_decoder_bwd_persist_ws_bytes", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
+        for fn in ("a2s_note_step_workspace_floats", "a2s_note_decoder_persist_ws_bytes", "a2s_note_decoder_bwd_persist_ws_bytes", "a2s_linear_dgrad_ws_bytes", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
                    "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
         for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_CONV_ROWS", b"conv_rows"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"), ("A2S_CONV_F16X2", b"conv_f16x2"), ("A2S_WGRAD_F16X2", b"wgrad_f16x2"),

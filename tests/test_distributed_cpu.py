@@ -60,7 +60,21 @@ def _worker(rank, world, port, outdir):
     ex.slice_ready(g2, cut, g2.numel())
     ex.slice_ready(g2, 0, cut)
     g2 = ex.finish(g2)
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=flat_p.numpy(), g_local=g_local.numpy(), g=g.numpy(), g2=g2.numpy())
+    # the loss gate of the fused step: the loss is one more word behind the gradients (engine_bwd.Backward.flat_full) and travels inside the
+    # FIRST slice's all-reduce, so every rank sees the same (mean) loss and takes the same skip-the-update decision with two collectives
+    # per step, not three.  Rank 1 of the second exchange holds a non-finite loss.
+    gate = []
+    for poison in (False, True):
+        full = torch.cat([g_local, torch.tensor([1.5 + rank if not (poison and rank == 1) else float("inf")])])
+        ex = train.GradientExchange(world)
+        ex.slice_ready(full, cut, full.numel())          # decoder + encoder slice + the loss word
+        ex.slice_ready(full, 0, cut)                     # ConvStack slice
+        full = ex.finish(full)
+        assert ex.issued == 2
+        gate.append(float(full[-1]))
+        if not poison:
+            assert torch.equal(full[:-1], g), "the extra word must not change the reduced gradient"
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=flat_p.numpy(), g_local=g_local.numpy(), g=g.numpy(), g2=g2.numpy(), gate=np.array(gate))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,3 +94,5 @@ def test_two_rank_gradient_exchange(tmp_path):
     mean = (r[0]["g_local"].astype(np.float64) + r[1]["g_local"].astype(np.float64)) / 2
     assert np.abs(r[0]["g"] - mean).max() <= 1e-6 * max(1.0, np.abs(mean).max())
     assert np.abs(r[0]["g_local"] - r[1]["g_local"]).max() > 0, "ranks must have seen different minibatches"
+    assert r[0]["gate"][0] == r[1]["gate"][0] == 2.0, "mean of the ranks' losses 1.5 and 2.5, identical on both ranks"
+    assert not np.isfinite(r[0]["gate"][1]) and not np.isfinite(r[1]["gate"][1]), "one rank's non-finite loss must gate the update on every rank"
