@@ -69,10 +69,11 @@ int a2s_gemm_f32_bnstats_scaled(void* stream, int M, int N, int K, const float* 
  * its own (csrc/a2s_linear.hip): da (M x N) = dz (M x 256, leading dimension lda) * Wt^T with Wt (N x 256) the k-contiguous copy of the weight,
  * plus the BatchNorm-backward statistics of a2s_gemm_f32_bnstats_scaled into partial[a2s_linear_dgrad_blocks(M)][N / period][2] (same
  * consumer).  K must be 256, N % 32 == 0, period % 32 == 0; workspace: a2s_linear_dgrad_ws_bytes(N, 256) bytes (the weight as fp16 term
- * planes), 16-byte aligned.  a2s_linear_dgrad_eligible says whether a shape qualifies (otherwise call a2s_gemm_f32_bnstats_scaled). */
+ * planes), 16-byte aligned.  da_absmax_out (device scalar, may be NULL): max |da| is folded into it by atomic max (zero it before the call).
+ * a2s_linear_dgrad_eligible says whether a shape qualifies (otherwise call a2s_gemm_f32_bnstats_scaled). */
 int a2s_linear_dgrad_bnstats(void* stream, int M, int N, int K, const float* dz, long lda, const float* Wt, float* da, long ldc, const float* y,
                              const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
-                             const float* dz_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes);
+                             const float* dz_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes, float* da_absmax_out);
 size_t a2s_linear_dgrad_ws_bytes(int N, int K);
 int a2s_linear_dgrad_blocks(int M);
 int a2s_linear_dgrad_eligible(int M, int N, int K, int period);
@@ -122,6 +123,11 @@ int a2s_bn_bwd_from_partial(void* stream, const float* g, const float* x, const 
 int a2s_conv3x3_dgrad_bnstats_scaled(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
                                      const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
                                      float* workspace, const float* dy_absmax);
+/* Round 4: the same, also writing g_absmax_out[Cout] = max |g| per channel of the gradient it writes (the launch zeroes it): the range from which
+ * a2s_conv3x3_wgrad_bn_ranged bounds the BatchNorm backward of the layer below. */
+int a2s_conv3x3_dgrad_bnstats_ranged(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
+                                     const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
+                                     float* workspace, const float* dy_absmax, float* g_absmax_out);
 int a2s_bn_bwd_from_partial_amax(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
                                  float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12, long rows, int C, int F,
                                  float* dx_absmax);
@@ -336,6 +342,17 @@ size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout);
 int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
                          const float* c12, float* dy_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* workspace,
                          size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);
+/* Round 4: the same fusion on the row-streaming weight-gradient kernel (csrc/a2s_conv_wrows.hip, two-term fp16 operands), for the shapes
+ * a2s_conv3x3_wgrad_bn_ranged_eligible accepts (F % 4 == 0, 20 / 40 channels): its staging waves form dz from (g, y), write it to dy_out
+ * (required: the data-gradient convolution reads it) and fold max |dz| into dy_absmax_out (device scalar, zeroed by the call).  The operand
+ * scale of dz comes from a BOUND derived on the device from g_absmax[g_absmax_n] (max |g|, one value or one per channel, reduced by the kernel
+ * that wrote g: a2s_linear_dgrad_bnstats, a2s_conv3x3_dgrad_bnstats_ranged) and y_absmax[Cout] (max |y_c|, written by the forward
+ * convolution: a2s_conv3x3_ranged); act_absmax as in a2s_conv3x3_wgrad_ranged. */
+int a2s_conv3x3_wgrad_bn_ranged(void* stream, const float* g, const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                const float* c12, const float* g_absmax, int g_absmax_n, const float* y_absmax, float* dy_out, float* dy_absmax_out, const float* x,
+                                const float* in_scale, const float* in_shift, float* dW, float* workspace, size_t workspace_bytes, int B, int T, int F,
+                                int Cin, int Cout, const float* act_absmax);
+int a2s_conv3x3_wgrad_bn_ranged_eligible(int F, int Cin, int Cout);
 
 /* ---- objective and optimizer of the recipe (pretrain.py:72-88,:125-128; pretrain.yaml:44-54)
  * NLL, mean over targets != ignore_index (pass -1 for "none"): loss_out[0] = loss, loss_out[1] = 1/count;

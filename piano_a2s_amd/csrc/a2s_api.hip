@@ -111,10 +111,16 @@ int a2s_bn_bwd_apply_impl(hipStream_t, const float*, const float*, const float*,
 
 int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* Wt, long sBk, long sBn, float* C, long ldc,
                                   const float* ep_y, const float* mean, const float* invstd, const float* scale, const float* shift, int period,
-                                  float* partial, const float* a_absmax, const float* b_absmax, float* ws, size_t ws_bytes);
+                                  float* partial, const float* a_absmax, const float* b_absmax, float* ws, size_t ws_bytes, float* c_absmax_out);
 size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K);
 int a2s_linear_dgrad_blocks_impl(int M);
 bool a2s_linear_dgrad_ok(int M, int N, int K, long lda, long sBk, long sBn, long ldc, int period, const void* A, const void* B, const void* C, const void* y);
+
+bool a2s_wgrad_rows_eligible(int F, int Cin, int Cout);
+int a2s_conv3x3_wgrad_rows_bn_impl(hipStream_t st, const float* g, const float* y, const float* mean, const float* invstd, const float* scale,
+                                   const float* shift, const float* c12, const float* g_absmax, int g_absmax_n, const float* y_absmax, float* dz_out,
+                                   float* dz_absmax_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* ws, size_t ws_bytes,
+                                   int B, int T, int F, int Cin, int Cout, const float* act_absmax);
 
 #define ST ((hipStream_t)stream)
 
@@ -155,9 +161,9 @@ int a2s_gemm_f32_bnstats_scaled(void* stream, int M, int N, int K, const float* 
 int a2s_absmax(void* stream, const float* x, long n, float* out) { return a2s_absmax_impl(ST, x, n, out); }
 int a2s_linear_dgrad_bnstats(void* stream, int M, int N, int K, const float* dz, long lda, const float* Wt, float* da, long ldc, const float* y,
                              const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
-                             const float* dz_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes) {
+                             const float* dz_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes, float* da_absmax_out) {
     return a2s_linear_dgrad_bnstats_impl(ST, M, N, K, dz, lda, Wt, 1, K, da, ldc, y, mean, invstd, scale, shift, period, partial, dz_absmax, w_absmax,
-                                         workspace, workspace_bytes);
+                                         workspace, workspace_bytes, da_absmax_out);
 }
 size_t a2s_linear_dgrad_ws_bytes(int N, int K) { return a2s_linear_dgrad_ws_bytes_impl(N, K); }
 int a2s_linear_dgrad_blocks(int M) { return a2s_linear_dgrad_blocks_impl(M); }
@@ -238,6 +244,12 @@ int a2s_conv3x3_dgrad_bnstats_scaled(void* stream, const float* dy, const float*
                                      float* workspace, const float* dy_absmax) {
     if (!yl) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_dgrad_bnstats_scaled: yl is required"); return A2S_ERR_ARG; }
     return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, dy_absmax, nullptr, nullptr);
+}
+int a2s_conv3x3_dgrad_bnstats_ranged(void* stream, const float* dy, const float* w, float* g, const float* yl, const float* yl_mean, const float* yl_invstd,
+                                     const float* yl_scale, const float* yl_shift, float* stat_partial, int B, int T, int F, int Cin, int Cout,
+                                     float* workspace, const float* dy_absmax, float* g_absmax_out) {
+    if (!yl) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_dgrad_bnstats_ranged: yl is required"); return A2S_ERR_ARG; }
+    return a2s_conv3x3_impl(ST, dy, w, g, nullptr, nullptr, stat_partial, B, T, F, Cin, Cout, 1, workspace, yl, yl_mean, yl_invstd, yl_scale, yl_shift, dy_absmax, nullptr, g_absmax_out);
 }
 int a2s_bn_bwd_from_partial(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale, const float* shift,
                             float* dgamma, float* dbeta, float* dx, const float* partial, int nblocks, float* c12, long rows, int C, int F) {
@@ -393,6 +405,15 @@ int a2s_conv3x3_wgrad_bn(void* stream, const float* g, const float* y, const flo
     return a2s_conv3x3_wgrad_impl(ST, g, x, in_scale, in_shift, dW, workspace, workspace_bytes, B, T, F, Cin, Cout, y, mean, invstd, scale, shift, c12, dy_out, nullptr, nullptr);
 }
 size_t a2s_conv3x3_wgrad_workspace_bytes(int Cin, int Cout) { return a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout); }
+int a2s_conv3x3_wgrad_bn_ranged_eligible(int F, int Cin, int Cout) { return (a2s_wgrad_rows_eligible(F, Cin, Cout) && !(Cin == 40 && Cout == 20)) ? 1 : 0; }
+int a2s_conv3x3_wgrad_bn_ranged(void* stream, const float* g, const float* y, const float* mean, const float* invstd, const float* scale, const float* shift,
+                                const float* c12, const float* g_absmax, int g_absmax_n, const float* y_absmax, float* dy_out, float* dy_absmax_out, const float* x,
+                                const float* in_scale, const float* in_shift, float* dW, float* workspace, size_t workspace_bytes, int B, int T, int F,
+                                int Cin, int Cout, const float* act_absmax) {
+    if (!a2s_conv3x3_wgrad_bn_ranged_eligible(F, Cin, Cout)) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "conv3x3_wgrad_bn_ranged: shape not eligible"); return A2S_ERR_ARG; }
+    return a2s_conv3x3_wgrad_rows_bn_impl(ST, g, y, mean, invstd, scale, shift, c12, g_absmax, g_absmax_n, y_absmax, dy_out, dy_absmax_out, x, in_scale, in_shift, dW,
+                                          workspace, workspace_bytes, B, T, F, Cin, Cout, act_absmax);
+}
 
 int a2s_nll_grad(void* stream, float* dlogp, const long long* target, const float* loss_out, float gscale, long rows, int V, long long ignore_index) {
     return a2s_nll_grad_impl(ST, dlogp, target, loss_out, gscale, rows, V, ignore_index);

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
                     }
                     st_s[j] += (f32x2){gm[0], gm[1]}; st_s[j] += (f32x2){gm[2], gm[3]};
                     st_s2[j] += (f32x2){gm[0], gm[1]} * (f32x2){xh[0], xh[1]}; st_s2[j] += (f32x2){gm[2], gm[3]} * (f32x2){xh[2], xh[3]};
+                    if (a.out_absmax) st_m[j] = fmaxf(fmaxf(st_m[j], fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));      // max |g|: round 4
                 } else {
 #ifndef RW_X_NOSTATS
                     st_s[j] += (f32x2){o[0], o[1]}; st_s[j] += (f32x2){o[2], o[3]};
@@ -496,8 +497,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
 #endif
                 }
                 // pin the accumulation to this quad (left alone, the adds sink below all 16 quads and keep 64 output registers alive)
-                if (BNRED) asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]));
-                else asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]), "+v"(st_m[j]));
+                asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]), "+v"(st_m[j]));
             }
             __builtin_amdgcn_sched_barrier(0);
             }
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
             a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 0] = s;
             a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 1] = s2;
         }
-        if (!BNRED && a.out_absmax) {
+        if (a.out_absmax) {
             const unsigned bits = __float_as_uint(m);
             if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(a.out_absmax + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                 atomicMax(reinterpret_cast<unsigned*>(a.out_absmax + tid), bits);
@@ -898,6 +898,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
                 }
                 st_s += (f32x2){gm[0], gm[1]}; st_s += (f32x2){gm[2], gm[3]};
                 st_s2 += (f32x2){gm[0], gm[1]} * (f32x2){xh[0], xh[1]}; st_s2 += (f32x2){gm[2], gm[3]} * (f32x2){xh[2], xh[3]};
+                if (a.out_absmax) st_m = fmaxf(fmaxf(st_m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));                  // max |g|: round 4
             } else {
                 st_s += (f32x2){o[0], o[1]}; st_s += (f32x2){o[2], o[3]};
                 st_s2 += (f32x2){o[0], o[1]} * (f32x2){o[0], o[1]}; st_s2 += (f32x2){o[2], o[3]} * (f32x2){o[2], o[3]};
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
             a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 0] = s;
             a.stat_partial[((long)blockIdx.x * COUT + tid) * 2 + 1] = s2;
         }
-        if (!BNRED && a.out_absmax) {
+        if (a.out_absmax) {
             const unsigned bits = __float_as_uint(m);
             if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(a.out_absmax + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                 atomicMax(reinterpret_cast<unsigned*>(a.out_absmax + tid), bits);

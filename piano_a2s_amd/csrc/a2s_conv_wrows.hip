@@ -66,14 +66,19 @@
 #define WR_BAR_OUT(role)
 #endif
 
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 struct WgRowsArgs {
     const float* dy; const float* x; const float* in_scale; const float* in_shift;
     const float* dy_absmax; const float* act_absmax;
     float* partial;
     int B, T, F, tilesF, nwork;
+    // fused BatchNorm backward (BNF instances): `dy` is then g = the gradient wrt relu(bn(y)); the staging waves form dz = bn_bwd(g, y) per
+    // element (constants bn_k[Cout][6] = mean, invstd, scale, shift, c1, c2), write it to dz_out for the data-gradient convolution and fold
+    // max |dz| into dz_absmax_out; dy_absmax is then an upper BOUND of |dz| (a2s_bn_bwd_bound)
+    const float* bn_y; const float* bn_k; float* dz_out; float* dz_absmax_out;
 };
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool BNF = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
     constexpr int NT = (3 * CIN + 15) / 16;          // (dt, ci) column tiles: 8 / 4
     constexpr int NTW = NT / 4;                      // per multiply wave: 2 / 1
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char dzbuf[2 * DBUF];
     __shared__ __attribute__((aligned(16))) unsigned char zrow[WR_SROW];
     __shared__ float tab[2 * CIN];
+    __shared__ __attribute__((aligned(16))) float tabk[BNF ? 8 * COUT : 4];      // per channel: mean, invstd, scale, shift, c1, c2, -, -
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
         tab[tid] = affine ? ldexpf(a.in_scale[tid], ka) : 1.f;
         tab[CIN + tid] = affine ? ldexpf(a.in_shift[tid], ka) : 0.f;
     }
+    if (BNF) for (int e = tid; e < 8 * COUT; e += 512) tabk[e] = (e & 7) < 6 ? a.bn_k[(e >> 3) * 6 + (e & 7)] : 0.f;
     __syncthreads();
 
     if (wave < 4) {
@@ -262,12 +269,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
         const int hch = st >> 1, hside = st & 1;      // the halo of the input rows: thread h < 2 CIN carries channel h >> 1, position -1 or 128
         const bool hthread = st < 2 * CIN;
         const float hsc = hthread ? tab[hch] : 0.f, hsh = hthread ? tab[CIN + hch] : 0.f;
+        float dzmax = 0.f;
         for (int work = blockIdx.x; work < a.nwork; work += gridDim.x) {
             const int ft = work % a.tilesF, b = work / a.tilesF;
             const int f_base = ft * WR_TP;
             const float dsc = (work & 1) ? -dscale : dscale;
             const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.T * CIN * a.F), 0, (unsigned)((long)a.T * CIN * a.F * 4), 0x00020000);
             const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (long)b * a.T * COUT * a.F), 0, (unsigned)((long)a.T * COUT * a.F * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((BNF ? a.bn_y : a.dy) + (long)b * a.T * COUT * a.F), 0, (unsigned)((long)a.T * COUT * a.F * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((BNF ? a.dz_out : a.partial) + (BNF ? (long)b * a.T * COUT * a.F : 0), 0, BNF ? (unsigned)((long)a.T * COUT * a.F * 4) : 0u, 0x00020000);
             const int fcol = f_base + 4 * (st & 31);
             const bool colok = fcol < a.F;            // (F % 4 == 0: a 4-position item is inside or outside as a whole)
             const int hf = hside ? f_base + WR_TP : f_base - 1;
@@ -292,14 +302,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
                 }
                 xh = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, hok ? rbase + (hch * a.F + hf) * 4 : -4, 0, 0));
             };
-            auto issue_d = [&](int row, f32x4 (&dr)[DIT]) {
+            auto issue_d = [&](int row, f32x4 (&dr)[DIT], f32x4 (&yr)[BNF ? DIT : 1]) {
                 const int rbase = (WR_X & 32) ? 0 : row * COUT * a.F * 4;
 #pragma unroll
                 for (int it = 0; it < DIT; ++it) {
                     const bool has = (it + 1) * 256 <= DITEMS || st + 256 * it < DITEMS;
                     dr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drsrc, (colok && has && !(WR_X & 16)) ? rbase + xoff + 32 * it * a.F : -4, 0, 0));
+                    if (BNF) yr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (colok && has && !(WR_X & 16)) ? rbase + xoff + 32 * it * a.F : -4, 0, 0));
                 }
             };
+
             // threads without an item in the last round store into bytes 0..7 / 256..263 of an image row: positions no fragment uses
             auto commit_x = [&](int slot, const f32x4 (&xr)[XIT], float xh) {
 #pragma unroll
@@ -323,11 +335,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
                 *reinterpret_cast<unsigned short*>(dst) = (unsigned short)p0;
                 *reinterpret_cast<unsigned short*>(dst + TSX) = (unsigned short)p1;
             };
-            auto commit_d = [&](int buf, const f32x4 (&dr)[DIT]) {
+            auto commit_d = [&](int buf, int row, f32x4 (&dr)[DIT], const f32x4 (&yr)[BNF ? DIT : 1]) {
 #pragma unroll
                 for (int it = 0; it < DIT; ++it) {
                     const bool has = (it + 1) * 256 <= DITEMS || st + 256 * it < DITEMS;
                     unsigned char* const p0 = dzbuf + buf * DBUF + (has ? ((st >> 5) + 8 * it) * WR_SROW + (st & 31) * 8 : (st >> 5) * WR_SROW + 256);
+                    if (BNF) {
+                        // dz = scale (g' - c1 - xhat c2), g' = g where bn(y) > 0 (bn_bwd_value of a2s_conv.hip): formed here, written once for the
+                        // data-gradient convolution (every dz element lies in exactly one strip), then split like a loaded dz row
+                        const int ch = min((st >> 5) + 8 * it, COUT - 1);
+                        const f32x4 k0 = *reinterpret_cast<const f32x4*>(tabk + 8 * ch);
+                        const float c1 = tabk[8 * ch + 4], c2 = tabk[8 * ch + 5];
+                        const bool live = colok && has && row < a.T;
+                        f32x4 v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float gm = (fmaf(yr[it][k], k0[2], k0[3]) > 0.f) ? dr[it][k] : 0.f;
+                            v[k] = live ? k0[2] * (gm - c1 - (yr[it][k] - k0[0]) * k0[1] * c2) : 0.f;
+                            dzmax = fmaxf(dzmax, fabsf(v[k]));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), zrsrc, live ? row * COUT * a.F * 4 + xoff + 32 * it * a.F : -4, 0, 0);
+                        dr[it] = v;
+                    }
                     uint2 t0, t1;
                     if (WR_X & 8) { t0 = make_uint2(__float_as_uint(dr[it][0]), __float_as_uint(dr[it][1])); t1 = make_uint2(__float_as_uint(dr[it][2]), __float_as_uint(dr[it][3])); } else {
                     split2_pair_f16(dr[it][0] * dsc, dr[it][1] * dsc, t0.x, t1.x);
@@ -339,13 +368,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
             };
             // WR_NS register sets keep the global loads of WR_NS rows in flight (one row per CU = 40 KB x 256 CUs does not cover HBM's
             // latency x bandwidth product).
-            f32x4 xr[WR_NS][XIT], dr[WR_NS][DIT];
+            f32x4 xr[WR_NS][XIT], dr[WR_NS][DIT], yr[WR_NS][BNF ? DIT : 1];
             float xh[WR_NS];
             __syncthreads();                          // (A) the previous strip's last multiply is over
-            issue_x(0, xr[0], xh[0]); issue_x(1, xr[1], xh[1]); issue_d(0, dr[0]);
-            commit_x(1, xr[0], xh[0]); commit_x(2, xr[1], xh[1]); commit_d(0, dr[0]);
+            issue_x(0, xr[0], xh[0]); issue_x(1, xr[1], xh[1]); issue_d(0, dr[0], yr[0]);
+            commit_x(1, xr[0], xh[0]); commit_x(2, xr[1], xh[1]); commit_d(0, 0, dr[0], yr[0]);
 #pragma unroll
-            for (int u = 0; u < WR_NS; ++u) { issue_x(2 + u, xr[u], xh[u]); issue_d(1 + u, dr[u]); }
+            for (int u = 0; u < WR_NS; ++u) { issue_x(2 + u, xr[u], xh[u]); issue_d(1 + u, dr[u], yr[u]); }
             __syncthreads();                          // (B)
 #pragma unroll 1
             for (int t0 = 0; t0 < a.T; t0 += WR_NS) {
@@ -354,8 +383,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
                     const int t = t0 + u;
                     if (t < a.T) {
                         if (!(WR_X & 64)) {
-                        commit_x((t + 3) & 3, xr[u], xh[u]); commit_d((t + 1) & 1, dr[u]);            // input row t + 2, dz row t + 1
-                        issue_x(t + 2 + WR_NS, xr[u], xh[u]); issue_d(t + 1 + WR_NS, dr[u]);
+                        commit_x((t + 3) & 3, xr[u], xh[u]); commit_d((t + 1) & 1, t + 1, dr[u], yr[u]);            // input row t + 2, dz row t + 1
+                        issue_x(t + 2 + WR_NS, xr[u], xh[u]); issue_d(t + 1 + WR_NS, dr[u], yr[u]);
                         }
                         WR_BAR();
                     }
@@ -363,6 +392,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_rows(WgRowsArgs a) {
             }
         }
         WR_BAR_OUT(1);
+        if (BNF && a.dz_absmax_out) {              // non-negative floats order like their bit patterns
+            const float m = wave_max(dzmax);
+            if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.dz_absmax_out), __float_as_uint(m));
+        }
     }
 }
 
@@ -384,12 +417,60 @@ __global__ void wgrad_rows_reduce(const float* __restrict__ partial, float* __re
     dW[idx] += s;
 }
 
+// Upper bound of |dz| of a BatchNorm backward dz = scale (g' - c1 - xhat c2) from ranges: max |g| (one scalar, reduced by the kernel that wrote
+// g) and max |y_c| per channel (written by the forward convolution): out[0] = max_c |scale_c| (gmax + |c1_c| + xhatmax_c |c2_c|).  Also packs
+// the six per-channel constants of the fused weight gradient: k[c] = mean, invstd, scale, shift, c1, c2.
+__global__ void bn_bwd_bound_kernel(const float* __restrict__ g_absmax, int g_n, const float* __restrict__ y_absmax, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ c12, int C, float* __restrict__ k, float* __restrict__ out) {
+    __shared__ float red[16];
+    const int c = threadIdx.x;
+    float gmax = 0.f;
+    for (int i = 0; i < g_n; ++i) gmax = fmaxf(gmax, g_absmax[i]);
+    float b = 0.f;
+    if (c < C) {
+        const float xh = (y_absmax[c] + fabsf(mean[c])) * fabsf(invstd[c]);
+        b = fabsf(scale[c]) * (gmax + fabsf(c12[2 * c]) + xh * fabsf(c12[2 * c + 1]));
+        k[6 * c + 0] = mean[c]; k[6 * c + 1] = invstd[c]; k[6 * c + 2] = scale[c]; k[6 * c + 3] = shift[c]; k[6 * c + 4] = c12[2 * c]; k[6 * c + 5] = c12[2 * c + 1];
+    }
+    b = block_max(b, red);
+    if (threadIdx.x == 0) out[0] = b;
+}
+
+int a2s_conv3x3_wgrad_rows_bn_impl(hipStream_t st, const float* g, const float* y, const float* mean, const float* invstd, const float* scale,
+                                   const float* shift, const float* c12, const float* g_absmax, int g_absmax_n, const float* y_absmax, float* dz_out,
+                                   float* dz_absmax_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* ws, size_t ws_bytes,
+                                   int B, int T, int F, int Cin, int Cout, const float* act_absmax) {
+    const int tilesF = a2s_cdiv(F, WR_TP), nwork = B * tilesF;
+    const int nslabs = nwork < WR_SLABS ? nwork : WR_SLABS;
+    const size_t slab_bytes = (size_t)nslabs * Cout * Cin * 9 * sizeof(float);
+    // workspace: [slabs][k: Cout x 6][bound: 1 float (+3 pad)]
+    A2S_REQUIRE(ws_bytes >= slab_bytes + sizeof(float) * (6 * (size_t)Cout + 4), "conv3x3_wgrad_rows_bn: workspace too small");
+    A2S_REQUIRE(g && y && mean && invstd && scale && shift && c12 && g_absmax && g_absmax_n >= 1 && y_absmax && dz_out && dz_absmax_out, "conv3x3_wgrad_rows_bn: null argument");
+    A2S_REQUIRE((long)T * Cout * F * 4 < (1L << 31), "conv3x3_wgrad_rows_bn: a clip's dz must stay below 2 GiB");
+    float* k = ws + slab_bytes / sizeof(float);
+    float* bound = k + 6 * Cout;
+    hipLaunchKernelGGL(bn_bwd_bound_kernel, dim3(1), dim3(64), 0, st, g_absmax, g_absmax_n, y_absmax, mean, invstd, scale, shift, c12, Cout, k, bound);
+    A2S_CHECK_LAUNCH("bn_bwd_bound");
+    hipError_t e = hipMemsetAsync(dz_absmax_out, 0, sizeof(float), st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "conv3x3_wgrad_rows_bn memset: %s", hipGetErrorString(e));
+    WgRowsArgs a{g, x, in_scale, in_shift, bound, act_absmax, ws, B, T, F, tilesF, nwork, y, k, dz_out, dz_absmax_out};
+    if (Cin == 40 && Cout == 40) hipLaunchKernelGGL((conv3x3_wgrad_rows<40, 40, true>), dim3(nslabs), dim3(512), 0, st, a);
+    else if (Cin == 20 && Cout == 40) hipLaunchKernelGGL((conv3x3_wgrad_rows<20, 40, true>), dim3(nslabs), dim3(512), 0, st, a);
+    else if (Cin == 20 && Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_rows<20, 20, true>), dim3(nslabs), dim3(512), 0, st, a);
+    else A2S_FAIL(A2S_ERR_ARG, "conv3x3_wgrad_rows_bn: no instance for %d -> %d", Cin, Cout);
+    A2S_CHECK_LAUNCH("conv3x3_wgrad_rows_bn");
+    hipLaunchKernelGGL(wgrad_rows_reduce, dim3(a2s_cdiv(Cout * Cin * 9, 256)), dim3(256), 0, st, ws, dW, nslabs, Cout * Cin * 9);
+    A2S_CHECK_LAUNCH("wgrad_rows_reduce");
+    return A2S_OK;
+}
+
 int a2s_conv3x3_wgrad_rows_impl(hipStream_t st, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW, float* ws,
                                 size_t ws_bytes, int B, int T, int F, int Cin, int Cout, const float* dy_absmax, const float* act_absmax) {
     const int tilesF = a2s_cdiv(F, WR_TP), nwork = B * tilesF;
     const int nslabs = nwork < WR_SLABS ? nwork : WR_SLABS;
     A2S_REQUIRE(ws_bytes >= (size_t)nslabs * Cout * Cin * 9 * sizeof(float), "conv3x3_wgrad_rows: workspace too small");
-    WgRowsArgs a{dy, x, in_scale, in_shift, dy_absmax, act_absmax, ws, B, T, F, tilesF, nwork};
+    WgRowsArgs a{dy, x, in_scale, in_shift, dy_absmax, act_absmax, ws, B, T, F, tilesF, nwork, nullptr, nullptr, nullptr, nullptr};
     if (Cin == 40 && Cout == 40) hipLaunchKernelGGL((conv3x3_wgrad_rows<40, 40>), dim3(nslabs), dim3(512), 0, st, a);
     else if (Cin == 20 && Cout == 40) hipLaunchKernelGGL((conv3x3_wgrad_rows<20, 40>), dim3(nslabs), dim3(512), 0, st, a);
     else if (Cin == 20 && Cout == 20) hipLaunchKernelGGL((conv3x3_wgrad_rows<20, 20>), dim3(nslabs), dim3(512), 0, st, a);

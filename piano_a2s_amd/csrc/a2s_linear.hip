@@ -41,6 +41,7 @@ struct LinDgradArgs {
     float* partial;                      // [M / 128 rounded up][8 waves][channels][2]
     const float* a_absmax; const float* b_absmax;
     int M, N, period, channels;
+    float* c_absmax_out;                 // max |da| folded in by atomic max (may be null): the range of the BatchNorm backward that follows
 };
 
 // Wt (N x 256, k contiguous) -> [n-tile][k-step][term][lane][8 halves]: the 16 bytes lane (lr = n % 16, lk) of the fragment of k-step ks
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
     const int ntiles = (a.N + 255) >> 8;
     // addresses as (workgroup-uniform base) + (32-bit lane offset that never changes): the bases live in scalar registers
     const unsigned lane_off = (unsigned)(lr * a.ldc + lk * 4) * 4u;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, vmax = 0.f;
     int cur_c = -1;
     auto flush = [&]() {
         if (cur_c < 0) return;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
             for (int nt = 0; nt < 2; ++nt) {
                 f32x4 v = acc[mt][nt];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= unscale;
+                for (int r = 0; r < 4; ++r) { v[r] *= unscale; vmax = fmaxf(vmax, fabsf(v[r])); }
 #if defined(LIN_X) && LIN_X >= 2
                 if (v[0] == 123.456f)
 #endif
@@ -201,6 +202,10 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
         }
     }
     flush();
+    if (a.c_absmax_out) {                // non-negative floats order like their bit patterns
+        const float m = wave_max(vmax);
+        if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.c_absmax_out), __float_as_uint(m));
+    }
 }
 
 size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K) { return (K == LIN_K && N > 0) ? (size_t)N * K * 2 * 2 : 0; }
@@ -213,7 +218,7 @@ bool a2s_linear_dgrad_ok(int M, int N, int K, long lda, long sBk, long sBn, long
 
 int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* Wt, long sBk, long sBn, float* C, long ldc,
                                   const float* ep_y, const float* mean, const float* invstd, const float* scale, const float* shift, int period,
-                                  float* partial, const float* a_absmax, const float* b_absmax, float* ws, size_t ws_bytes) {
+                                  float* partial, const float* a_absmax, const float* b_absmax, float* ws, size_t ws_bytes, float* c_absmax_out) {
     A2S_REQUIRE(A && Wt && C && ep_y && mean && invstd && scale && shift && partial && a_absmax && b_absmax && ws, "linear_dgrad_bnstats: null argument");
     A2S_REQUIRE(a2s_linear_dgrad_ok(M, N, K, lda, sBk, sBn, ldc, period, A, Wt, C, ep_y),
                 "linear_dgrad_bnstats: needs K = 256, M >= 128, N >= 256, N %% 32 == 0, period %% 32 == 0, a k-contiguous weight (N x K) and 16-byte aligned rows");
@@ -225,7 +230,7 @@ int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const flo
     unsigned char* planes = reinterpret_cast<unsigned char*>(ws);
     hipLaunchKernelGGL(lin_pack_planes, dim3((unsigned)(((long)N * 32 + 255) / 256)), dim3(256), 0, st, Wt, (long)K, N, b_absmax, planes);
     A2S_CHECK_LAUNCH("lin_pack_planes");
-    LinDgradArgs a{A, lda, planes, C, ldc, ep_y, mean, invstd, scale, shift, partial, a_absmax, b_absmax, M, N, period, channels};
+    LinDgradArgs a{A, lda, planes, C, ldc, ep_y, mean, invstd, scale, shift, partial, a_absmax, b_absmax, M, N, period, channels, c_absmax_out};
     hipLaunchKernelGGL(lin_dgrad_bnstats, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
     A2S_CHECK_LAUNCH("lin_dgrad_bnstats");
     return A2S_OK;

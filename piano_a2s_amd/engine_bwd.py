@@ -573,6 +573,7 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
 _FUSE_BN_APPLY = os.environ.get("A2S_FUSE_BN_APPLY", "0") == "1"
 _FUSE_BN_APPLY_L1 = os.environ.get("A2S_FUSE_BN_APPLY_L1", "1") != "0"
 _DGRAD_BNSTATS = os.environ.get("A2S_DGRAD_BNSTATS", "1") != "0"      # BatchNorm-backward statistics in the data-gradient conv's epilogue
+_FUSE_BN_ROWS = os.environ.get("A2S_FUSE_BN_ROWS", "1") != "0"        # BatchNorm-backward apply inside the row-streaming weight gradient's staging
 _LINEAR_DGRAD = os.environ.get("A2S_LINEAR_DGRAD", "1") != "0"        # the Linear's data gradient on its own kernel (csrc/a2s_linear.hip)
 
 
@@ -639,6 +640,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
     # Linear 19200 -> Cf, no bias:  dW += dz^T a4 ; da4 = dz W
     a4 = cs["a4"]
     g_partial = None                     # BatchNorm-backward statistics partials of g, when the kernel that produced g also reduced them
+    g_amax = None                        # max |g| (device scalar), when the kernel that produced g also reduced it
     Wout = S["convstack.out.weight"]
     if a4 is None:                         # the Linear read relu(bn4(y4)) on the fly: so does its weight gradient
         y4 = cs["y"][3].view(rows, 40 * F)
@@ -657,9 +659,10 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                 Wt = Wout.t().contiguous()
                 nb = L.a2s_linear_dgrad_ws_bytes(40 * F, Cf)
                 lws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+                g_amax = torch.zeros(1, dtype=torch.float32, device=dev)          # max |da|: the range of the BatchNorm backward fused into conv4's weight gradient
                 hip.check(L.a2s_linear_dgrad_bnstats(hip.stream(), rows, 40 * F, Cf, hip._p(dz), C.c_long(Cf), hip._p(Wt), hip._p(da), C.c_long(40 * F), hip._p(y4),
                                                      hip._p(bn4[0]), hip._p(bn4[1]), hip._p(bn4[2]), hip._p(bn4[3]), F, hip._p(part), hip._p(dz_amax), hip._p(w_amax),
-                                                     hip._p(lws), C.c_size_t(nb)), "a2s_linear_dgrad_bnstats")
+                                                     hip._p(lws), C.c_size_t(nb), hip._p(g_amax)), "a2s_linear_dgrad_bnstats")
                 g_partial = (part, nblk)
             else:
                 g_partial = _linear_dgrad_generic(L, dev, rows, F, Cf, dz, Wout, da, y4, bn4, dz_amax, w_amax)
@@ -683,7 +686,19 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         # max |dy| of this layer's output gradient, reduced by the kernel that writes dy: the two-term fp16 data-gradient convolution
         # below scales its operand by the matching power of two (gradients would otherwise sit in fp16's subnormal range)
         dy_amax = torch.zeros(1, dtype=torch.float32, device=dev) if (i > 1 and not eng.sync_bn) else None
-        if eng.sync_bn or not fuse_here:
+        fuse_rows = (_FUSE_BN_ROWS and not eng.sync_bn and i > 1 and g_amax is not None and g_partial is not None and in_bn is not None
+                     and L.a2s_conv3x3_wgrad_bn_ranged_eligible(F, ci, co))
+        if fuse_rows:
+            # round 4: BatchNorm backward as statistics only; dy is formed by the STAGING waves of the row-streaming weight-gradient kernel (they
+            # wait 40-57 % of their time for the multiply waves), written once for the data-gradient convolution: one pass over (g, y) less
+            bn_i = cs["bn"][i - 1]
+            c12 = bn_bwd(g, y, bn_i, f"convstack.bn{i}", None, rows, co, F, stats_only=True, partial=g_partial)
+            dy = g                                                 # in place: every element is read and written once, by the same thread
+            hip.check(L.a2s_conv3x3_wgrad_bn_ranged(hip.stream(), hip._p(g), hip._p(y), hip._p(bn_i[0]), hip._p(bn_i[1]), hip._p(bn_i[2]), hip._p(bn_i[3]),
+                                                    hip._p(c12), hip._p(g_amax), g_amax.numel(), hip._p(cs["yabs"][i - 1]), hip._p(dy), hip._p(dy_amax), hip._p(x_in),
+                                                    hip._p(in_bn[2]), hip._p(in_bn[3]), hip._p(G[f"convstack.conv{i}.weight"]), hip._p(ws), C.c_size_t(nb),
+                                                    B, T, F, ci, co, hip._p(cs["abound"][i - 2])), "a2s_conv3x3_wgrad_bn_ranged")
+        elif eng.sync_bn or not fuse_here:
             dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F, partial=g_partial, amax=dy_amax)
             hip.conv3x3_wgrad(dy, x_in.view(B, T, ci, F), in_bn[2] if in_bn else None, in_bn[3] if in_bn else None, G[f"convstack.conv{i}.weight"], ws,
                               dy_amax, cs["abound"][i - 2] if in_bn else None)
@@ -704,13 +719,15 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                 bn_l = cs["bn"][i - 2]
                 nblk = L.a2s_conv3x3_stat_blocks(B, T, F, co)
                 part = torch.empty((nblk, ci, 2), dtype=torch.float32, device=dev)
-                hip.check(L.a2s_conv3x3_dgrad_bnstats_scaled(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev),
+                g_amax_next = torch.empty(ci, dtype=torch.float32, device=dev) if (_FUSE_BN_ROWS and i > 2) else None      # max |g| per channel (zeroed by the launch)
+                hip.check(L.a2s_conv3x3_dgrad_bnstats_ranged(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev),
                                                              hip._p(cs["y"][i - 2]), hip._p(bn_l[0]), hip._p(bn_l[1]), hip._p(bn_l[2]), hip._p(bn_l[3]),
                                                              hip._p(part), B, T, F, co, ci, hip._p(cws),
-                                                             hip._p(dy_amax) if not fuse_here else NULL), "a2s_conv3x3_dgrad_bnstats")
+                                                             hip._p(dy_amax) if not fuse_here else NULL, hip._p(g_amax_next)), "a2s_conv3x3_dgrad_bnstats")
                 g_partial = (part, nblk)
             else:
                 hip.check(L.a2s_conv3x3(hip.stream(), hip._p(dy), hip._p(S[f"convstack.conv{i}.weight"]), hip._p(gprev), NULL, NULL, NULL, B, T, F, co, ci, 1,
                                         hip._p(cws)), "a2s_conv3x3 dgrad")
                 g_partial = None
             g = gprev
+            g_amax = g_amax_next if (_DGRAD_BNSTATS and not eng.sync_bn) else None

@@ -26,9 +26,10 @@ def _run(L, hip, dev, dz, Wt, y, mean, invstd, scale, shift, period, new):
         part = torch.full((nblk, N // period, 2), float("nan"), device=dev)
         nb = L.a2s_linear_dgrad_ws_bytes(N, K)
         ws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+        damax = torch.zeros(1, device=dev)
         hip.check(L.a2s_linear_dgrad_bnstats(hip.stream(), M, N, K, hip._p(dz), C.c_long(K), hip._p(Wt), hip._p(da), C.c_long(N), hip._p(y), hip._p(mean),
                                              hip._p(invstd), hip._p(scale), hip._p(shift), period, hip._p(part), hip._p(dmax), hip._p(wmax), hip._p(ws),
-                                             C.c_size_t(nb)), "linear_dgrad")
+                                             C.c_size_t(nb), hip._p(damax)), "linear_dgrad")
     else:
         nblk = L.a2s_gemm_bnstats_blocks(M, period)
         part = torch.full((nblk, N // period, 2), float("nan"), device=dev)
@@ -36,6 +37,8 @@ def _run(L, hip, dev, dz, Wt, y, mean, invstd, scale, shift, period, new):
                                                 C.c_long(N), hip._p(y), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), period, hip._p(part),
                                                 hip._p(dmax), hip._p(wmax)), "gemm bnstats")
     torch.cuda.synchronize()
+    if new:
+        assert float(damax) == float(da.abs().max()), "max |da| written beside the product"
     return da, part.double().sum(0)
 
 

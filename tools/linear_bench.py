@@ -61,7 +61,7 @@ def main():
         part2 = torch.empty((L.a2s_linear_dgrad_blocks(rows), 40, 2), device=dev)
         ms = timed(lambda: hip.check(L.a2s_linear_dgrad_bnstats(hip.stream(), rows, K, Cf, hip._p(dz), C.c_long(Cf), hip._p(Wt), hip._p(da), C.c_long(K), hip._p(y4),
                                                                 hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), F, hip._p(part2), hip._p(dmax), hip._p(wmax),
-                                                                hip._p(lws), C.c_size_t(nb)), "linear_dgrad"))
+                                                                hip._p(lws), C.c_size_t(nb), C.c_void_p(0)), "linear_dgrad"))
         print(f"data gradient  {ms:7.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s   {(2.0 * rows * K * 4 + rows * Cf * 4) / ms / 1e6:6.0f} GB/s  (csrc/a2s_linear.hip)")
     sk = L.a2s_gemm_pick_splitk(Cf, K, rows, 1)
     ms = timed(lambda: hip.gemm(dz, 1, Cf, y4, K, 1, G, K, Cf, K, rows, beta=1.0, splitk=sk, b_affine=(scale, shift, F), two_term=(dmax, None)))
