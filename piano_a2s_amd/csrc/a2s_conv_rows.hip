@@ -488,7 +488,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
                     }
                     st_s[j] += (f32x2){gm[0], gm[1]}; st_s[j] += (f32x2){gm[2], gm[3]};
                     st_s2[j] += (f32x2){gm[0], gm[1]} * (f32x2){xh[0], xh[1]}; st_s2[j] += (f32x2){gm[2], gm[3]} * (f32x2){xh[2], xh[3]};
-                    if (a.out_absmax) st_m[j] = fmaxf(fmaxf(st_m[j], fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));      // max |g|: round 4
+                    // max |g| (round 4: the range of the BatchNorm backward fused into the next weight gradient).  ONE running maximum per lane, kept in
+                    // st_m[0] whatever the n-tile: its consumer takes the maximum over the channels anyway, and a register per n-tile costs the
+                    // 20 -> 20 instance its fourth wave per SIMD (130 registers: 9.0 -> 11.8 ms)
+                    // (the 20 -> 20 data gradient -- conv2's, whose consumer below is conv1's own kernel -- does not track it at all: see the launcher)
+                    if (!(CIN == 20 && COUT == 20) && a.out_absmax) st_m[0] = fmaxf(fmaxf(st_m[0], fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
                 } else {
 #ifndef RW_X_NOSTATS
                     st_s[j] += (f32x2){o[0], o[1]}; st_s[j] += (f32x2){o[2], o[3]};
@@ -497,7 +501,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows(RowsArgs a) {
 #endif
                 }
                 // pin the accumulation to this quad (left alone, the adds sink below all 16 quads and keep 64 output registers alive)
-                asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]), "+v"(st_m[j]));
+                if (BNRED && CIN == 20 && COUT == 20) asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]));
+                else asm volatile("" : "+v"(st_s[j]), "+v"(st_s2[j]), "+v"(st_m[BNRED ? 0 : j]));
             }
             __builtin_amdgcn_sched_barrier(0);
             }
@@ -1035,6 +1040,11 @@ int a2s_conv3x3_rows_impl(hipStream_t st, const float* x, const float* w, float*
                           const float* x_absmax) {
     A2S_REQUIRE(F % 4 == 0 && (Cin == 20 || Cin == 40) && (Cout == 20 || Cout == 40), "conv3x3_rows: unsupported shape F=%d Cin=%d Cout=%d", F, Cin, Cout);
     A2S_REQUIRE(!(in_scale && yl), "conv3x3_rows: input affine and BatchNorm-backward statistics are exclusive");
+    if (yl && Cin == 20 && Cout == 20 && out_absmax) {       // the one data-gradient instance that does not track max |g| in its epilogue: an extra pass
+        const int rc = a2s_conv3x3_rows_impl(st, x, w, y, in_scale, in_shift, in_absmax, stat_partial, nullptr, B, T, F, Cin, Cout, flip, ws, yl, yl_mean, yl_invstd,
+                                             yl_scale, yl_shift, x_absmax);
+        return rc != A2S_OK ? rc : a2s_channel_absmax_impl(st, y, (long)B * T, Cout, F, out_absmax);
+    }
     unsigned char* wimg = reinterpret_cast<unsigned char*>(ws);
     float* hdr = ws + (size_t)9 * RwGeom<40>::KS * 2 * 1024 / 4;
     float* scratch = hdr + RW_HDR;
