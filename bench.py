@@ -203,15 +203,33 @@ def linear_roofline(B, T, F, Cf=256, iters=5):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
-    ms = {"forward": timed(lambda: hip.linear(y4, W, out=z, x_affine=(scale, shift, F), two_term=(None, wmax))),
-          "data_gradient": timed(lambda: hip.check(L.a2s_gemm_f32_bnstats_scaled(hip.stream(), rows, K, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(Wt), C.c_long(1),
-                                                                                  C.c_long(Cf), hip._p(da), C.c_long(K), hip._p(y4), hip._p(mean), hip._p(invstd),
-                                                                                  hip._p(scale), hip._p(shift), F, hip._p(part), hip._p(dmax), hip._p(wmax)), "bnstats")),
+    own = bool(L.a2s_linear_dgrad_eligible(rows, K, Cf, F)) and os.environ.get("A2S_LINEAR_DGRAD", "1") != "0"      # what engine_bwd runs
+    if own:
+        nb = L.a2s_linear_dgrad_ws_bytes(K, Cf)
+        lws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+        part2 = torch.empty((L.a2s_linear_dgrad_blocks(rows), 40, 2), device=dev)
+        damax = torch.zeros(1, device=dev)
+
+        def dgrad():
+            hip.check(L.a2s_linear_dgrad_bnstats(hip.stream(), rows, K, Cf, hip._p(dz), C.c_long(Cf), hip._p(Wt), hip._p(da), C.c_long(K), hip._p(y4), hip._p(mean),
+                                                 hip._p(invstd), hip._p(scale), hip._p(shift), F, hip._p(part2), hip._p(dmax), hip._p(wmax), hip._p(lws),
+                                                 C.c_size_t(nb), hip._p(damax)), "linear_dgrad")
+    else:
+        def dgrad():
+            hip.check(L.a2s_gemm_f32_bnstats_scaled(hip.stream(), rows, K, Cf, hip._p(dz), C.c_long(Cf), C.c_long(1), hip._p(Wt), C.c_long(1), C.c_long(Cf), hip._p(da),
+                                                    C.c_long(K), hip._p(y4), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), F, hip._p(part), hip._p(dmax),
+                                                    hip._p(wmax)), "bnstats")
+    bound = hip.act_bound(scale, shift, y4.view(rows, 40, F).abs().amax(dim=(0, 2)).contiguous())
+    own_fwd = bool(L.a2s_linear_fwd_eligible(rows, Cf, K, F)) and os.environ.get("A2S_LINEAR_FWD", "1") != "0"
+    ms = {"forward": timed(lambda: hip.linear_forward(y4, W, (scale, shift, F), bound, wmax, out=z)),
+          "data_gradient": timed(dgrad),
           "weight_gradient": timed(lambda: hip.gemm(dz, 1, Cf, y4, K, 1, G, K, Cf, K, rows, beta=1.0, splitk=sk, b_affine=(scale, shift, F), two_term=(dmax, None)))}
     flops = 2.0 * rows * K * Cf
     big = 4.0 * rows * K                                   # the (rows, 19200) operand / result: read (written) once
     byts = {"forward": big, "data_gradient": 2 * big, "weight_gradient": big}        # (the data gradient writes da and reads y4 for the statistics)
-    out = {"kernel": "gemm_f32_kernel<256, 256, 4, 2, ..., 2> (two-term fp16 tiles)", "peak_TFLOPs": round(MFMA_BF16_PEAK_TFS / 3, 1), "peak_GBs": HBM_PEAK_GBS}
+    out = {"kernel": "weight gradient: gemm_f32_kernel<256, 256, 4, 2, ..., 2> (two-term fp16 tiles); forward: " + ("lin_fwd (csrc/a2s_linear.hip)" if own_fwd else "the same tile")
+                     + "; data gradient: " + ("lin_dgrad_bnstats (csrc/a2s_linear.hip); both incl. lin_pack_planes_k" if own else "the same tile"),
+           "peak_TFLOPs": round(MFMA_BF16_PEAK_TFS / 3, 1), "peak_GBs": HBM_PEAK_GBS}
     for k, t in ms.items():
         out[k] = {"ms": round(t, 2), "TFLOPs": round(flops / t / 1e9, 1), "frac_mfma": round(flops / t / 1e9 / (MFMA_BF16_PEAK_TFS / 3), 4),
                   "GBs": round(byts[k] / t / 1e6, 1), "frac_hbm": round(byts[k] / t / 1e6 / HBM_PEAK_GBS, 4)}

@@ -74,6 +74,13 @@ int a2s_gemm_f32_bnstats_scaled(void* stream, int M, int N, int K, const float* 
 int a2s_linear_dgrad_bnstats(void* stream, int M, int N, int K, const float* dz, long lda, const float* Wt, float* da, long ldc, const float* y,
                              const float* mean, const float* invstd, const float* scale, const float* shift, int period, float* partial,
                              const float* dz_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes, float* da_absmax_out);
+/* ... and its forward (reference models.py:68,537-539): z (M x 256, leading dimension ldc) = relu(y * scale[k / period] + shift[k / period]) W^T
+ * with y (M x K, leading dimension lda) and W (256 x K) row-major; scale / shift NULL: y as it is.  N must be 256, K % 64 == 0, period % 32 == 0;
+ * y_absmax: device scalar bounding the ACTIVATED operand (a2s_act_bound; NULL: O(1)); workspace: a2s_linear_dgrad_ws_bytes(256, K) bytes.
+ * a2s_linear_fwd_eligible says whether a shape qualifies (otherwise a2s_gemm_f32_affine_scaled). */
+int a2s_linear_fwd(void* stream, int M, int N, int K, const float* y, long lda, const float* W, float* z, long ldc, const float* scale, const float* shift,
+                   int period, const float* y_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes);
+int a2s_linear_fwd_eligible(int M, int N, int K, int period);
 size_t a2s_linear_dgrad_ws_bytes(int N, int K);
 int a2s_linear_dgrad_blocks(int M);
 int a2s_linear_dgrad_eligible(int M, int N, int K, int period);

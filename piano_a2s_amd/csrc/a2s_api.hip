@@ -113,6 +113,9 @@ int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const flo
                                   const float* ep_y, const float* mean, const float* invstd, const float* scale, const float* shift, int period,
                                   float* partial, const float* a_absmax, const float* b_absmax, float* ws, size_t ws_bytes, float* c_absmax_out);
 size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K);
+int a2s_linear_fwd_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* W, float* C, long ldc, const float* a_scale,
+                        const float* a_shift, int period, const float* a_absmax, const float* w_absmax, float* ws, size_t ws_bytes);
+bool a2s_linear_fwd_ok(int M, int N, int K, long lda, long ldc, int period, const void* A, const void* W, const void* C);
 int a2s_linear_dgrad_blocks_impl(int M);
 bool a2s_linear_dgrad_ok(int M, int N, int K, long lda, long sBk, long sBn, long ldc, int period, const void* A, const void* B, const void* C, const void* y);
 
@@ -122,6 +125,8 @@ int a2s_conv3x3_wgrad_rows_bn_impl(hipStream_t st, const float* g, const float* 
                                    float* dz_absmax_out, const float* x, const float* in_scale, const float* in_shift, float* dW, float* ws, size_t ws_bytes,
                                    int B, int T, int F, int Cin, int Cout, const float* act_absmax);
 
+void a2s_attn_bulk_cap_set(int on);
+int a2s_attn_bulk_cap_enabled(void);
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -166,6 +171,11 @@ int a2s_linear_dgrad_bnstats(void* stream, int M, int N, int K, const float* dz,
                                          workspace, workspace_bytes, da_absmax_out);
 }
 size_t a2s_linear_dgrad_ws_bytes(int N, int K) { return a2s_linear_dgrad_ws_bytes_impl(N, K); }
+int a2s_linear_fwd(void* stream, int M, int N, int K, const float* y, long lda, const float* W, float* z, long ldc, const float* scale, const float* shift,
+                   int period, const float* y_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes) {
+    return a2s_linear_fwd_impl(ST, M, N, K, y, lda, W, z, ldc, scale, shift, period, y_absmax, w_absmax, workspace, workspace_bytes);
+}
+int a2s_linear_fwd_eligible(int M, int N, int K, int period) { return a2s_linear_fwd_ok(M, N, K, 4, 4, period, nullptr, nullptr, nullptr) ? 1 : 0; }
 int a2s_linear_dgrad_blocks(int M) { return a2s_linear_dgrad_blocks_impl(M); }
 int a2s_linear_dgrad_eligible(int M, int N, int K, int period) {
     return a2s_linear_dgrad_ok(M, N, K, 4, 1, K, 4, period, nullptr, nullptr, nullptr, nullptr) ? 1 : 0;
@@ -185,6 +195,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "dec_fused")) { a2s_dec_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_fused_combine")) { a2s_attn_fused_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_nt")) { a2s_attn_nt_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_bulk_cap")) { a2s_attn_bulk_cap_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
@@ -204,6 +215,7 @@ int a2s_debug_set(const char* key, int value) {
 }
 
 int a2s_debug_get(const char* key) {
+    if (key && !strcmp(key, "attn_bulk_cap")) return a2s_attn_bulk_cap_enabled();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
     if (key && !strcmp(key, "wgrad_rows")) return a2s_wgrad_rows_enabled();

@@ -8,7 +8,7 @@
 // k-tiles, every workgroup re-splits its 256 x 256 slice of W into fp16 terms (the whole of W 1201 times per launch), and its epilogue -- a
 // 256 KB store and a 256 KB re-read of y4 per tile, 47 GB per launch -- overlaps with nothing (one workgroup per CU, 256 registers):
 // 23.8 ms at B = 256 against ~9.5 ms of HBM time and 3.6 ms of matrix time.  Here:
-//   * W is split ONCE per launch into fp16 term planes laid out in MFMA-fragment order (lin_pack_planes: 19.7 MB, 1 KB contiguous per
+//   * W is split ONCE per launch into fp16 term planes laid out in MFMA-fragment order (lin_pack_planes_k: 19.7 MB, 1 KB contiguous per
 //     fragment); the sweep below reads its B fragments straight from those planes (L2-resident: all workgroups of an XCD walk the
 //     column tiles together) -- no conversion, no LDS, no barrier for B;
 //   * a workgroup owns 128 ROWS for ALL column tiles: its slice of dz is split once into LDS (147 KB: [64-k block][term][row][128 B + 16])
@@ -34,7 +34,7 @@ typedef unsigned lu32x4 __attribute__((ext_vector_type(4)));
 
 struct LinDgradArgs {
     const float* A; long lda;            // dz (M x 256)
-    const unsigned char* planes;         // packed fp16 term planes of Wt (lin_pack_planes)
+    const unsigned char* planes;         // packed fp16 term planes of Wt (lin_pack_planes_k)
     float* C; long ldc;                  // da (M x N)
     const float* ep_y;                   // y4 (M x N, leading dimension ldc)
     const float* mean; const float* invstd; const float* scale; const float* shift;
@@ -44,16 +44,17 @@ struct LinDgradArgs {
     float* c_absmax_out;                 // max |da| folded in by atomic max (may be null): the range of the BatchNorm backward that follows
 };
 
-// Wt (N x 256, k contiguous) -> [n-tile][k-step][term][lane][8 halves]: the 16 bytes lane (lr = n % 16, lk) of the fragment of k-step ks
-// holds k = 32 ks + 8 lk .. + 7 of row n.  One thread per (n, 8 k).
-__global__ __launch_bounds__(256) void lin_pack_planes(const float* __restrict__ Wt, long ld, int N, const float* __restrict__ absmax,
-                                                       unsigned char* __restrict__ out) {
+// W (N x K, k contiguous, K % 32 == 0) -> [n-tile][k-step][term][lane][8 halves]: the 16 bytes of lane (lr = n % 16, lk) of the fragment of
+// k-step ks hold k = 32 ks + 8 lk .. + 7 of row n, scaled by the power of two that brings max |W| to 2^12.  One thread per (n, 8 k).
+__global__ __launch_bounds__(256) void lin_pack_planes_k(const float* __restrict__ W, long ld, int N, int K, const float* __restrict__ absmax,
+                                                         unsigned char* __restrict__ out) {
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    const int n = (int)(id >> 5), kg = (int)(id & 31);
+    const int kgroups = K >> 3, nks = K >> 5;
+    const int n = (int)(id / kgroups), kg = (int)(id % kgroups);
     if (n >= N) return;
     const float ps = ldexpf(1.f, pow2_scale_exp(*absmax, 12));
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Wt + (long)n * ld + kg * 8);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Wt + (long)n * ld + kg * 8 + 4);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(W + (long)n * ld + kg * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(W + (long)n * ld + kg * 8 + 4);
     float x[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x[i] = __builtin_amdgcn_fmed3f(v0[i] * ps, -65000.f, 65000.f); x[4 + i] = __builtin_amdgcn_fmed3f(v1[i] * ps, -65000.f, 65000.f); }
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void lin_pack_planes(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) { unsigned h, l; split2_pair_f16(x[2 * i], x[2 * i + 1], h, l); hi[i] = h; lo[i] = l; }
     const int nt = n >> 4, lr = n & 15, ks = kg >> 2, lk = kg & 3;
-    unsigned char* o = out + ((((long)nt * 8 + ks) * 2) * 64 + (lk * 16 + lr)) * 16;
+    unsigned char* o = out + ((((long)nt * nks + ks) * 2) * 64 + (lk * 16 + lr)) * 16;
     *reinterpret_cast<lu32x4*>(o) = hi;
     *reinterpret_cast<lu32x4*>(o + 64 * 16) = lo;
 }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
             }
         };
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) load_y(mt);                      // (the other half once the multiply has released its registers)
+        for (int mt = 0; mt < 3; ++mt) load_y(mt);                      // (the rest once the multiply has released its registers)
         f32x4 acc[8][2];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
         }
         if (n0 + 256 < a.N) { load_b(n0 + 256, 0, bf[0]); load_b(n0 + 256, 1, bf[1]); }
 #pragma unroll
-        for (int mt = 4; mt < 8; ++mt) load_y(mt);
+        for (int mt = 3; mt < 8; ++mt) load_y(mt);
         // ---- epilogue: lane (lr, lk) of tile (mt, nt) owns da[m0 + 16 mt + lr][n0 + 16 nt + 4 lk .. + 3] (transposed accumulators)
         const int c = n0 / a.period;
         if (c != cur_c) { flush(); s1 = 0.f; s2 = 0.f; cur_c = c; }
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
     }
 }
 
-size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K) { return (K == LIN_K && N > 0) ? (size_t)N * K * 2 * 2 : 0; }
+size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K) { return (K > 0 && K % 32 == 0 && N > 0) ? (size_t)N * K * 2 * 2 : 0; }      // the weight as two fp16 planes
 int a2s_linear_dgrad_blocks_impl(int M) { return M > 0 ? ((M + LIN_BM - 1) / LIN_BM) * 8 : 0; }
 
 bool a2s_linear_dgrad_ok(int M, int N, int K, long lda, long sBk, long sBn, long ldc, int period, const void* A, const void* B, const void* C, const void* y) {
@@ -228,10 +229,203 @@ int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const flo
     hipError_t e = hipMemsetAsync(partial, 0, sizeof(float) * 2 * (size_t)nblk * channels, st);
     if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "linear_dgrad_bnstats memset: %s", hipGetErrorString(e));
     unsigned char* planes = reinterpret_cast<unsigned char*>(ws);
-    hipLaunchKernelGGL(lin_pack_planes, dim3((unsigned)(((long)N * 32 + 255) / 256)), dim3(256), 0, st, Wt, (long)K, N, b_absmax, planes);
-    A2S_CHECK_LAUNCH("lin_pack_planes");
+    hipLaunchKernelGGL(lin_pack_planes_k, dim3((unsigned)(((long)N * (K / 8) + 255) / 256)), dim3(256), 0, st, Wt, (long)K, N, K, b_absmax, planes);
+    A2S_CHECK_LAUNCH("lin_pack_planes_k");
     LinDgradArgs a{A, lda, planes, C, ldc, ep_y, mean, invstd, scale, shift, partial, a_absmax, b_absmax, M, N, period, channels, c_absmax_out};
     hipLaunchKernelGGL(lin_dgrad_bnstats, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
     A2S_CHECK_LAUNCH("lin_dgrad_bnstats");
+    return A2S_OK;
+}
+
+// =========================================================================================== forward
+// z[m][n] = sum_k relu(y4[m][k] * scale[c] + shift[c]) * W[n][k]      (reference models.py:68,537-539: ConvStack.out applied to relu(bn4(y4)));
+// M = B*T rows, N = 256, K = 40 * F = 19200, c = k / F.
+// The generic tile (256 x 256, a2s_gemm.hip) re-splits its 256 x 32 slice of W in every k-tile of every workgroup (as much conversion work as
+// the activations themselves), stages both operands through ONE LDS buffer with two barriers per k-tile and gives the next tile's global loads
+// one multiply phase to arrive: 12.9 ms at B = 256 against 4.7 ms of HBM time (y4 once) and 3.6 ms of matrix time.  Here:
+//   * W as fp16 term planes in fragment order (lin_pack_planes_k, as for the data gradient): B fragments straight from L2, ring of three k-steps;
+//   * a workgroup owns 128 rows x all 256 columns (8 waves x 32 columns, 64 accumulators): y4 is read exactly once;
+//   * the activations go global -> registers (two 64-k blocks in flight) -> BatchNorm + ReLU + split -> a ring of FOUR LDS stages (36 KB each):
+//     one barrier per 64 k, the stage written in iteration b is read in iteration b + 1 (32-k stages, a barrier per k-step: 11.0 ms at B = 256;
+//     the barrier and the conversion block stand between the k-steps' MFMAs);
+//   * F % 32 == 0: a k-step lies inside one channel, so the BatchNorm constants of a k-step are two scalars.
+// Measured at B = 256 (profiles/r04_linear_fwd.txt): 11.0 ms (generic tile 13.2).  Ablations (-DLF_X, additive almost to the millisecond): matrix work
+// + fragment reads alone 4.9 ms, + the barrier 5.6, + the B fragment loads 7.4 (1.8), + conversion and LDS writes 9.5 (2.0), + the y4 loads 11.5
+// (3.5): all eight waves leave the barrier in the same phase, so whatever is not an MFMA is time the matrix pipe idles.  Reading the next quarter's
+// fragments under this quarter's MFMAs, spreading the conversion over the quarters (sched_group_barrier) and issuing the L2-hit B loads ahead of the
+// HBM loads (in-order completion) moved it from 11.5 to 11.0; what is left needs the staging in waves of its own (as in a2s_conv_wrows.hip).
+#define LF_RS 144                        // bytes per LDS row of a stage: 64 k of fp16 + 16
+#define LF_STAGE (2 * LIN_BM * LF_RS)
+#define LF_NS 4
+
+struct LinFwdArgs {
+    const float* A; long lda;            // y4 (M x K)
+    const unsigned char* planes;         // packed fp16 term planes of W (N x K): lin_pack_planes_k
+    float* C; long ldc;                  // z (M x 256)
+    const float* a_scale; const float* a_shift;     // per channel (may be null: the operand is used as is, no ReLU)
+    const float* a_absmax; const float* b_absmax;
+    int M, K, period;
+};
+
+__global__ __launch_bounds__(LIN_NTH) void lin_fwd(LinFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LF_NS * LF_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.x * LIN_BM;
+    const int ka = a.a_absmax ? pow2_scale_exp(*a.a_absmax, 12) : 0, kb = pow2_scale_exp(*a.b_absmax, 12);
+    const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kb));
+    const int nks = a.K >> 5, nblk = a.K >> 6, kpc = a.period >> 5;          // k-steps of 32, blocks of 64 (one barrier each), k-steps per channel
+    const bool affine = a.a_scale != nullptr;
+    // staging: item i of a thread = (row, 4 k) of a 64-k block: slot = tid + 512 i -> row = slot >> 4, k = 4 (slot & 15)
+    const int sk = (tid & 15) * 4;
+    const bool second = sk >= 32;                      // which of the block's two k-steps (they may lie in different channels: F % 64 != 0)
+    f32x4 ar[2][4];
+    auto issue_a = [&](int blk, f32x4 (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid + LIN_NTH * i) >> 4;
+            r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if defined(LF_X) && (LF_X & 1)        /* timing ablations (-DLF_X= bits: 1 no y4 loads, 2 no conversion / LDS writes, 4 no B loads in the loop, 8 no barrier) */
+            const bool want = m0 + row < a.M && blk < 1;
+#else
+            const bool want = m0 + row < a.M && blk < nblk;
+#endif
+            if (want) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)(m0 + row) * a.lda + (long)blk * 64 + sk));
+        }
+    };
+    // one item (4 k of one row) of block blk: BatchNorm + ReLU + split -> both term images of the block's stage
+    auto commit_item = [&](int blk, int i, const f32x4 (&r)[4]) {
+        if (blk >= nblk) return;
+#if defined(LF_X) && (LF_X & 2)
+        if (blk >= LF_NS) return;
+#endif
+        const int c0 = (2 * blk) / kpc, c1 = (2 * blk + 1) / kpc;
+        const float sc = affine ? (second ? a.a_scale[c1] : a.a_scale[c0]) * psa : psa, sh = affine ? (second ? a.a_shift[c1] : a.a_shift[c0]) * psa : 0.f;
+        const float floor_ = affine ? 0.f : -INFINITY;
+        unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        const int row = (tid + LIN_NTH * i) >> 4;
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[i][j], sc, sh), floor_), -65000.f, 65000.f);
+        uint2 hi, lo;
+        split2_pair_f16(x[0], x[1], hi.x, lo.x);
+        split2_pair_f16(x[2], x[3], hi.y, lo.y);
+        *reinterpret_cast<uint2*>(st + (0 * LIN_BM + row) * LF_RS + sk * 2) = hi;
+        *reinterpret_cast<uint2*>(st + (1 * LIN_BM + row) * LF_RS + sk * 2) = lo;
+    };
+    auto commit_a = [&](int blk, const f32x4 (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) commit_item(blk, i, r);
+    };
+    // B fragments of block blk: planes + (((nt * nks + ks) * 2 + term) * 64 + lane) * 16, nt = wave * 2 + {0, 1}, ks = 2 blk + {0, 1}
+    lu32x4 bf[2][2][2][2];                             // [ring][k-step of the block][nt][term]
+    auto load_b = [&](int blk, lu32x4 (&dst)[2][2][2]) {
+        if (blk >= nblk) return;
+#if defined(LF_X) && (LF_X & 4)
+        if (blk >= 2) return;
+#endif
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+                    dst[h][nt][sp] = *reinterpret_cast<const lu32x4*>(a.planes + (((long)(wave * 2 + nt) * nks + 2 * blk + h) * 2 + sp) * 1024 + (unsigned)lane * 16u);
+    };
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // block b: activations in ar[b & 1] (issued two iterations before they are committed), B fragments in bf[b & 1]
+    issue_a(0, ar[0]);
+    load_b(0, bf[0]); load_b(1, bf[1]);
+    commit_a(0, ar[0]);
+    issue_a(1, ar[1]); issue_a(2, ar[0]);
+    auto body = [&](int blk, f32x4 (&rnext)[4], lu32x4 (&bcur)[2][2][2]) {
+        if (blk >= nblk) return;
+#if !(defined(LF_X) && (LF_X & 8))
+        __syncthreads();                     // stage blk is complete; stage blk + 1 (= blk - 3) is free
+#endif
+        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        // four quarters (k-step h, row half): the A fragments of the NEXT quarter are read while this one multiplies -- two waves per SIMD do not
+        // cover the LDS latency of 8 reads in front of every 24 MFMAs (measured: 11.0 -> see the header)
+        auto load_af = [&](int h, int half, lu32x4 (&af)[2][4]) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) af[sp][q] = *reinterpret_cast<const lu32x4*>(st + (sp * LIN_BM + (half * 4 + q) * 16 + lr) * LF_RS + h * 64 + lk * 16);
+        };
+        auto multiply = [&](int h, int half, const lu32x4 (&af)[2][4]) {
+#define LF_PRODUCT(SA, SB)                                                                                                       \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                    \
+                    acc[half * 4 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bcur[h][nt][SB]),   \
+                                                                                   __builtin_bit_cast(f16x8, af[SA][q]), acc[half * 4 + q][nt], 0, 0, 0);
+            LF_PRODUCT(1, 0) LF_PRODUCT(0, 1) LF_PRODUCT(0, 0)
+#undef LF_PRODUCT
+        };
+        // the conversion of the NEXT block (registers loaded two iterations ago) rides in the issue slots the MFMAs leave (a quarter of it per
+        // quarter): all waves leave the barrier together, so work placed in front of the MFMAs is time the matrix pipe idles (ablation: 2.0 ms)
+        auto interleave = [&]() {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // 3 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read (next quarter's fragments)
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // 4 VALU (conversion)
+            }
+        };
+        lu32x4 afa[2][4], afb[2][4];
+        load_af(0, 0, afa);
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(0, 1, afb); commit_item(blk + 1, 0, rnext); multiply(0, 0, afa); interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(1, 0, afa); commit_item(blk + 1, 1, rnext); multiply(0, 1, afb); interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(1, 1, afb); commit_item(blk + 1, 2, rnext); multiply(1, 0, afa); interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        commit_item(blk + 1, 3, rnext); multiply(1, 1, afb); interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        // vector-memory loads complete in order: the B fragments of block blk + 2 (L2 hits) go out BEFORE the y4 loads of block blk + 3 (HBM), and
+        // after those of block blk + 2, which have had two iterations by the time these fragments are waited for
+        load_b(blk + 2, bcur);
+        issue_a(blk + 3, rnext);
+    };
+#pragma unroll 1
+    for (int b0 = 0; b0 < nblk; b0 += 2) {
+        body(b0 + 0, ar[1], bf[0]);
+        body(b0 + 1, ar[0], bf[1]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + mt * 16 + lr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= unscale;
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + wave * 32 + nt * 16 + lk * 4) = v;
+        }
+    }
+}
+
+bool a2s_linear_fwd_ok(int M, int N, int K, long lda, long ldc, int period, const void* A, const void* W, const void* C) {
+    return N == 256 && M >= 1 && K >= 128 && K % 64 == 0 && (period == 0 || (period % 32 == 0 && K % period == 0)) && lda % 4 == 0 && ldc % 4 == 0 &&
+           (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0);
+}
+
+int a2s_linear_fwd_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* W, float* C, long ldc, const float* a_scale,
+                        const float* a_shift, int period, const float* a_absmax, const float* w_absmax, float* ws, size_t ws_bytes) {
+    A2S_REQUIRE(A && W && C && w_absmax && ws && ((a_scale == nullptr) == (a_shift == nullptr)), "linear_fwd: null argument");
+    A2S_REQUIRE(a2s_linear_fwd_ok(M, N, K, lda, ldc, a_scale ? period : 0, A, W, C),
+                "linear_fwd: needs N = 256, K %% 64 == 0, period %% 32 == 0 and 16-byte aligned rows");
+    A2S_REQUIRE(((uintptr_t)ws % 16 == 0) && ws_bytes >= (size_t)N * K * 4, "linear_fwd: workspace too small (%zu bytes needed)", (size_t)N * K * 4);
+    unsigned char* planes = reinterpret_cast<unsigned char*>(ws);
+    hipLaunchKernelGGL(lin_pack_planes_k, dim3((unsigned)(((long)N * (K / 8) + 255) / 256)), dim3(256), 0, st, W, (long)K, N, K, w_absmax, planes);
+    A2S_CHECK_LAUNCH("lin_pack_planes_k");
+    LinFwdArgs a{A, lda, planes, C, ldc, a_scale, a_shift, a_absmax, w_absmax, M, K, a_scale ? period : K};
+    hipLaunchKernelGGL(lin_fwd, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
+    A2S_CHECK_LAUNCH("lin_fwd");
     return A2S_OK;
 }

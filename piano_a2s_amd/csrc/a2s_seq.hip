@@ -1188,8 +1188,13 @@ int a2s_attn_nt_enabled(void) {
 // memory), and the long-clip group's chain of short dependent kernels -- the step's critical path -- pays that latency several times per
 // decode step.  Measured (profiles/r04_attn_occupancy_cap.txt, B = 256, same box): forward launch alone 155 -> 159 us at 2 per CU, backward
 // 152 -> 203 us (hence 5 there); in the step the long-clip group finishes 11 ms earlier, the bulk group 8 ms later, the step 507 -> 498 ms.
-// A2S_ATTN_BULK_LDS / A2S_ATTN_BULK_LDS_BWD = bytes (0: no cap).
+// A2S_ATTN_BULK_LDS / A2S_ATTN_BULK_LDS_BWD = bytes (0: no cap).  The cap only pays while ANOTHER clip group decodes beside the bulk one: the host
+// switches it on for exactly those passes (a2s_debug_set("attn_bulk_cap", 1); off by default: greedy decoding of 256 clips 495 -> 468 clips/s with it).
+static int g_attn_bulk_cap = 0;
+void a2s_attn_bulk_cap_set(int on) { g_attn_bulk_cap = on ? 1 : 0; }
+int a2s_attn_bulk_cap_enabled(void) { return g_attn_bulk_cap; }
 size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward) {
+    if (!g_attn_bulk_cap) return shm;
     static long cap[2] = {-1, -1};
     if (cap[0] < 0) {
         const char* e = getenv("A2S_ATTN_BULK_LDS");

@@ -346,7 +346,7 @@ class Engine:
             a4 = None
             # two-term fp16 split: activations scaled by the power of two of their bound, the weights by that of max|W|
             saved["w_out_amax"] = hip.absmax(S["convstack.out.weight"])
-            z = hip.linear(y4, S["convstack.out.weight"], x_affine=(scale, shift, F), two_term=(saved["abound"][3], saved["w_out_amax"]))
+            z = hip.linear_forward(y4, S["convstack.out.weight"], (scale, shift, F), saved["abound"][3], saved["w_out_amax"])
         rows = B * T
         rpb = 64
         nblk = (rows + rpb - 1) // rpb
@@ -622,6 +622,8 @@ class Engine:
         if not clip_groups or len(clip_groups) < 2:
             clip_groups = [(0, B)]
         assert clip_groups[0][0] == 0 and clip_groups[-1][1] == B and all(a[1] == b[0] for a, b in zip(clip_groups[:-1], clip_groups[1:]))
+        # occupancy cap of the bulk group's attention launches (csrc/a2s_seq.hip a2s_attn_bulk_lds): only while another group decodes beside it
+        hip.check(hip.lib().a2s_debug_set(b"attn_bulk_cap", 1 if (len(clip_groups) > 1 and _os.environ.get("A2S_ATTN_BULK_CAP", "1") != "0") else 0), "debug_set")
 
         bar_major = fuse
         self.bar_major = bar_major

@@ -235,9 +235,28 @@ def conv3x3_wgrad_for_test(dy, x, scale, shift):
     return dW
 
 
+def linear_forward(x2d, weight, x_affine, x_bound, w_absmax, out=None):
+    """The ConvStack's 19200 -> 256 Linear forward as the engine issues it: the kernel of its own (csrc/a2s_linear.hip: weight pre-split once,
+    activations through a four-stage LDS ring) where the shape qualifies (A2S_LINEAR_FWD=0: never), the generic two-term GEMM tile otherwise."""
+    M, K = x2d.shape
+    N = weight.shape[0]
+    L = lib()
+    period = x_affine[2]
+    if (os.environ.get("A2S_LINEAR_FWD", "1") != "0" and x2d.is_contiguous() and weight.is_contiguous() and x_bound is not None
+            and L.a2s_linear_fwd_eligible(M, N, K, period)):
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+        nb = L.a2s_linear_dgrad_ws_bytes(N, K)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=x2d.device)
+        check(L.a2s_linear_fwd(stream(), M, N, K, _p(x2d), C.c_long(K), _p(weight), _p(out), C.c_long(N), _p(x_affine[0]), _p(x_affine[1]), period,
+                               _p(x_bound), _p(w_absmax), _p(ws), C.c_size_t(nb)), "a2s_linear_fwd")
+        return out
+    return linear(x2d, weight, out=out, x_affine=x_affine, two_term=(x_bound, w_absmax))
+
+
 def linear_forward_for_test(x, w, aff):
     """The 19200 -> 256 Linear's forward as engine.convstack issues it (operand BatchNorm+ReLU while staging, two-term split with the
     activation bound and max |w| as operand ranges)."""
     period = aff[2]
     xmax = x.view(x.shape[0], -1, period).abs().amax(dim=(0, 2)).contiguous()
-    return linear(x, w, x_affine=aff, two_term=(act_bound(aff[0], aff[1], xmax), absmax(w)))
+    return linear_forward(x, w, aff, act_bound(aff[0], aff[1], xmax), absmax(w))

@@ -81,3 +81,37 @@ def test_linear_dgrad_kernel(dev, M, channels, period, gscale):
     for k in range(2):
         mag = a1 if k == 0 else a2
         assert float(((st_new[:, k] - st_old[:, k]).abs() / mag.clamp_min(1e-300)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("M,channels,period", [(300, 40, 128), (77, 6, 96), (1201 * 2, 40, 480), (128, 4, 32)])
+def test_linear_forward_kernel(dev, M, channels, period):
+    """z = relu(bn(y)) W^T on the kernel of csrc/a2s_linear.hip against float64 and against the generic two-term tile (an odd number of 64-k blocks in one case, channels that
+    straddle a block in two, rows that are not a multiple of 128)."""
+    import os
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    K, N = channels * period, 256
+    assert L.a2s_linear_fwd_eligible(M, N, K, period) == 1
+    g = torch.Generator().manual_seed(M + K)
+    y = (torch.randn(M, K, generator=g) * 3.0).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.007).to(dev)
+    scale = (torch.randn(channels, generator=g)).to(dev)
+    shift = (torch.randn(channels, generator=g) * 0.3).to(dev)
+    ymax = y.view(M, channels, period).abs().amax(dim=(0, 2)).contiguous()
+    bound, wmax = hip.act_bound(scale, shift, ymax), hip.absmax(W)
+    z_new = hip.linear_forward(y, W, (scale, shift, period), bound, wmax)
+    os.environ["A2S_LINEAR_FWD"] = "0"
+    try:
+        z_old = hip.linear_forward(y, W, (scale, shift, period), bound, wmax)
+    finally:
+        os.environ.pop("A2S_LINEAR_FWD", None)
+    torch.cuda.synchronize()
+    ch = torch.arange(K, device=dev) // period
+    a = torch.relu(y.double() * scale.double()[ch] + shift.double()[ch])
+    ref = a @ W.double().t()
+    mag = a.abs() @ W.double().abs().t()
+    assert torch.isfinite(z_new).all()
+    err_new = float(((z_new.double() - ref).abs() / mag.clamp_min(1e-300)).max())
+    err_old = float(((z_old.double() - ref).abs() / mag.clamp_min(1e-300)).max())
+    assert err_new < 1e-6, f"{err_new:.3e} of sum|a||w| (generic tile: {err_old:.3e})"
+    assert err_new <= 2.0 * err_old + 1e-7, f"{err_new:.3e} vs the generic tile's {err_old:.3e}"

@@ -41,7 +41,11 @@ def main():
     part = torch.empty((nblk, 40, 2), device=dev)
     fl = 2.0 * rows * K * Cf
     ms = timed(lambda: hip.linear(y4, W, out=z, x_affine=(scale, shift, F), two_term=(None, wmax)))
-    print(f"forward        {ms:7.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s")
+    print(f"forward        {ms:7.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s   (generic 256x256 two-term tile)")
+    if L.a2s_linear_fwd_eligible(rows, Cf, K, F):
+        bound = hip.act_bound(scale, shift, y4.view(rows, 40, F).abs().amax(dim=(0, 2)).contiguous())
+        ms2 = timed(lambda: hip.linear_forward(y4, W, (scale, shift, F), bound, wmax, out=z))
+        print(f"forward        {ms2:7.2f} ms  {fl / ms2 / 1e9:6.1f} TFLOP/s   {rows * K * 4.0 / ms2 / 1e6:6.0f} GB/s  (csrc/a2s_linear.hip)")
     if hasattr(L, "a2s_gemm_trace_read"):                # library built with -DGEMM_TRACE: phase timeline of the forward launch
         import numpy as np
         buf = np.zeros(8 * 24 * 8, dtype=np.uint64)
