@@ -249,11 +249,14 @@ int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const flo
 //     one barrier per 64 k, the stage written in iteration b is read in iteration b + 1 (32-k stages, a barrier per k-step: 11.0 ms at B = 256;
 //     the barrier and the conversion block stand between the k-steps' MFMAs);
 //   * F % 32 == 0: a k-step lies inside one channel, so the BatchNorm constants of a k-step are two scalars.
-// Measured at B = 256 (profiles/r04_linear_fwd.txt): 11.0 ms (generic tile 13.2).  Ablations (-DLF_X, additive almost to the millisecond): matrix work
+// Measured at B = 256 (profiles/r04_linear_fwd.txt): 10.4 ms (generic tile 13.2).  Ablations (-DLF_X, additive almost to the millisecond): matrix work
 // + fragment reads alone 4.9 ms, + the barrier 5.6, + the B fragment loads 7.4 (1.8), + conversion and LDS writes 9.5 (2.0), + the y4 loads 11.5
 // (3.5): all eight waves leave the barrier in the same phase, so whatever is not an MFMA is time the matrix pipe idles.  Reading the next quarter's
 // fragments under this quarter's MFMAs, spreading the conversion over the quarters (sched_group_barrier) and issuing the L2-hit B loads ahead of the
-// HBM loads (in-order completion) moved it from 11.5 to 11.0; what is left needs the staging in waves of its own (as in a2s_conv_wrows.hip).
+// HBM loads (in-order completion) moved it from 11.5 to 11.0, running the two waves of a SIMD in opposite order (convert-then-multiply /
+// multiply-then-convert) to 10.4.  The y4 loads still cost ~3 ms although they are in flight for two blocks (7 us) and although one contiguous
+// 32 KB run per block instead of 128 x 256 B changes nothing (10.34): with the HBM stream beside the matrix pipes the shader clock drops
+// (a2s_conv_wrows.hip: 2.3 -> 1.7 GHz), i.e. the "cost of the loads" is largely the multiply running slower.
 // Two independent workgroups per CU instead (64 rows x 256 columns, 4 waves x 64 columns, so that one's staging runs under the other's MFMAs):
 // 15.1 ms -- every B fragment is then fetched from L2 by twice as many workgroups.
 #define LF_RS 144                        // bytes per LDS row of a stage: 64 k of fp16 + 16
@@ -291,7 +294,11 @@ __global__ __launch_bounds__(LIN_NTH) void lin_fwd(LinFwdArgs a) {
 #else
             const bool want = m0 + row < a.M && blk < nblk;
 #endif
+#if defined(LF_X) && (LF_X & 16)       /* 16: the block's 32 KB as ONE contiguous run (same bytes per workgroup, wrong values) */
+            if (want) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)m0 * a.lda + (long)blk * 8192 + (long)(tid + LIN_NTH * i) * 4));
+#else
             if (want) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)(m0 + row) * a.lda + (long)blk * 64 + sk));
+#endif
         }
     };
     // one item (4 k of one row) of block blk: BatchNorm + ReLU + split -> both term images of the block's stage
@@ -367,27 +374,31 @@ __global__ __launch_bounds__(LIN_NTH) void lin_fwd(LinFwdArgs a) {
             LF_PRODUCT(1, 0) LF_PRODUCT(0, 1) LF_PRODUCT(0, 0)
 #undef LF_PRODUCT
         };
-        // the conversion of the NEXT block (registers loaded two iterations ago) rides in the issue slots the MFMAs leave (a quarter of it per
-        // quarter): all waves leave the barrier together, so work placed in front of the MFMAs is time the matrix pipe idles (ablation: 2.0 ms)
-        auto interleave = [&]() {
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // 3 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read (next quarter's fragments)
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // 4 VALU (conversion)
-            }
-        };
         lu32x4 afa[2][4], afb[2][4];
-        load_af(0, 0, afa);
-        __builtin_amdgcn_sched_barrier(0);
-        load_af(0, 1, afb); commit_item(blk + 1, 0, rnext); multiply(0, 0, afa); interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        load_af(1, 0, afa); commit_item(blk + 1, 1, rnext); multiply(0, 1, afb); interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        load_af(1, 1, afb); commit_item(blk + 1, 2, rnext); multiply(1, 0, afa); interleave();
-        __builtin_amdgcn_sched_barrier(0);
-        commit_item(blk + 1, 3, rnext); multiply(1, 1, afb); interleave();
-        __builtin_amdgcn_sched_barrier(0);
+        // The two waves of a SIMD run the interval between two barriers in OPPOSITE order: waves 0-3 convert the next block first and multiply
+        // second, waves 4-7 multiply first -- all eight waves leave the barrier together, and with one order for all of them a SIMD's matrix
+        // pipe idles while both of its waves convert (ablation: conversion 2.0 ms + loads 3.5 ms of the 11 ms are such time)
+        auto quarters = [&]() {
+            load_af(0, 0, afa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_af(0, 1, afb); multiply(0, 0, afa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_af(1, 0, afa); multiply(0, 1, afb);
+            __builtin_amdgcn_sched_barrier(0);
+            load_af(1, 1, afb); multiply(1, 0, afa);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(1, 1, afb);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (wave < 4) {
+            commit_a(blk + 1, rnext);
+            __builtin_amdgcn_sched_barrier(0);
+            quarters();
+        } else {
+            quarters();
+            commit_a(blk + 1, rnext);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // vector-memory loads complete in order: the B fragments of block blk + 2 (L2 hits) go out BEFORE the y4 loads of block blk + 3 (HBM), and
         // after those of block blk + 2, which have had two iterations by the time these fragments are waited for
         load_b(blk + 2, bcur);
