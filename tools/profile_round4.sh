@@ -26,6 +26,11 @@ for c in "MfmaUtil SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES";
 done
 python tools/pmc_summary.py $O/pmcl > $O/linear_pmc_summary_b256.txt 2>&1
 rm -rf $O/pmcl
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+    rm -rf $O/pmcl; timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmcl -- python3 tools/linear_bench.py 256 > $O/pmc.log 2>&1
+    echo "== $c (per launch, B = 256, tools/linear_bench.py: generic tile and csrc/a2s_linear.hip kernels)"; python tools/pmc_summary.py $O/pmcl | grep -A2 "^lin_\|^gemm_f32_kernel<256"
+    rm -rf $O/pmcl
+done > $O/linear_traffic_b256.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 tools/conv_rows_pmc.py 256 > $O/pmc.log 2>&1
     echo "== $c (KB per launch, B = 256)"; python tools/pmc_summary.py $O/pmc_$c | grep -A1 "^conv3x3_rows\|^conv3x3_wgrad_rows"
