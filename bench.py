@@ -223,12 +223,15 @@ def linear_roofline(B, T, F, Cf=256, iters=5):
     own_fwd = bool(L.a2s_linear_fwd_eligible(rows, Cf, K, F)) and os.environ.get("A2S_LINEAR_FWD", "1") != "0"
     ms = {"forward": timed(lambda: hip.linear_forward(y4, W, (scale, shift, F), bound, wmax, out=z)),
           "data_gradient": timed(dgrad),
-          "weight_gradient": timed(lambda: hip.gemm(dz, 1, Cf, y4, K, 1, G, K, Cf, K, rows, beta=1.0, splitk=sk, b_affine=(scale, shift, F), two_term=(dmax, None)))}
+          "weight_gradient": timed(lambda: hip.linear_wgrad(dz, y4, (scale, shift, F), dmax, bound, G)
+                                   or hip.gemm(dz, 1, Cf, y4, K, 1, G, K, Cf, K, rows, beta=1.0, splitk=sk, b_affine=(scale, shift, F), two_term=(dmax, bound)))}
     flops = 2.0 * rows * K * Cf
     big = 4.0 * rows * K                                   # the (rows, 19200) operand / result: read (written) once
     byts = {"forward": big, "data_gradient": 2 * big, "weight_gradient": big}        # (the data gradient writes da and reads y4 for the statistics)
-    out = {"kernel": "weight gradient: gemm_f32_kernel<256, 256, 4, 2, ..., 2> (two-term fp16 tiles); forward: " + ("lin_fwd (csrc/a2s_linear.hip)" if own_fwd else "the same tile")
-                     + "; data gradient: " + ("lin_dgrad_bnstats (csrc/a2s_linear.hip); both incl. lin_pack_planes_k" if own else "the same tile"),
+    own_wg = bool(L.a2s_linear_wgrad_eligible(rows, Cf, K, F)) and os.environ.get("A2S_LINEAR_WGRAD", "1") != "0"
+    generic = "gemm_f32_kernel<256, 256, 4, 2, ..., 2> (two-term fp16 tiles)"
+    out = {"kernel": "csrc/a2s_linear.hip where the shape qualifies, each incl. its operand-plane pre-pass: forward " + ("lin_fwd" if own_fwd else generic)
+                     + "; data gradient " + ("lin_dgrad_bnstats" if own else generic) + "; weight gradient " + ("lin_wgrad (+ lin_wgrad_reduce)" if own_wg else generic),
            "peak_TFLOPs": round(MFMA_BF16_PEAK_TFS / 3, 1), "peak_GBs": HBM_PEAK_GBS}
     for k, t in ms.items():
         out[k] = {"ms": round(t, 2), "TFLOPs": round(flops / t / 1e9, 1), "frac_mfma": round(flops / t / 1e9 / (MFMA_BF16_PEAK_TFS / 3), 4),

@@ -81,6 +81,13 @@ int a2s_linear_dgrad_bnstats(void* stream, int M, int N, int K, const float* dz,
 int a2s_linear_fwd(void* stream, int M, int N, int K, const float* y, long lda, const float* W, float* z, long ldc, const float* scale, const float* shift,
                    int period, const float* y_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes);
 int a2s_linear_fwd_eligible(int M, int N, int K, int period);
+/* ... and its weight gradient: G (256 x K, leading dimension ldg) += dz^T relu(y * scale[k / period] + shift[k / period]) with dz (M x 256, leading
+ * dimension ldz); N must be 256, K % 128 == 0, period % 4 == 0, M >= 64; dz_absmax: device scalar max |dz|; y_absmax as in a2s_linear_fwd;
+ * workspace: a2s_linear_wgrad_ws_bytes(M, K) bytes (dz as fp16 term planes + the split-K slabs).  Deterministic (fixed-order reduction). */
+int a2s_linear_wgrad(void* stream, int M, int N, int K, const float* dz, long ldz, const float* y, long lda, float* G, long ldg, const float* scale,
+                     const float* shift, int period, const float* dz_absmax, const float* y_absmax, float* workspace, size_t workspace_bytes);
+size_t a2s_linear_wgrad_ws_bytes(int M, int K);
+int a2s_linear_wgrad_eligible(int M, int N, int K, int period);
 size_t a2s_linear_dgrad_ws_bytes(int N, int K);
 int a2s_linear_dgrad_blocks(int M);
 int a2s_linear_dgrad_eligible(int M, int N, int K, int period);

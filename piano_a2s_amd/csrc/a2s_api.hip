@@ -116,6 +116,10 @@ size_t a2s_linear_dgrad_ws_bytes_impl(int N, int K);
 int a2s_linear_fwd_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* W, float* C, long ldc, const float* a_scale,
                         const float* a_shift, int period, const float* a_absmax, const float* w_absmax, float* ws, size_t ws_bytes);
 bool a2s_linear_fwd_ok(int M, int N, int K, long lda, long ldc, int period, const void* A, const void* W, const void* C);
+int a2s_linear_wgrad_impl(hipStream_t st, int M, int N, int K, const float* dz, long ldz, const float* A, long lda, float* G, long ldg, const float* a_scale,
+                          const float* a_shift, int period, const float* dz_absmax, const float* a_absmax, float* ws, size_t ws_bytes);
+size_t a2s_linear_wgrad_ws_bytes_impl(int M, int K);
+bool a2s_linear_wgrad_ok(int M, int N, int K, long ldz, long lda, long ldg, int period, const void* dz, const void* A, const void* G);
 int a2s_linear_dgrad_blocks_impl(int M);
 bool a2s_linear_dgrad_ok(int M, int N, int K, long lda, long sBk, long sBn, long ldc, int period, const void* A, const void* B, const void* C, const void* y);
 
@@ -175,6 +179,12 @@ int a2s_linear_fwd(void* stream, int M, int N, int K, const float* y, long lda, 
                    int period, const float* y_absmax, const float* w_absmax, float* workspace, size_t workspace_bytes) {
     return a2s_linear_fwd_impl(ST, M, N, K, y, lda, W, z, ldc, scale, shift, period, y_absmax, w_absmax, workspace, workspace_bytes);
 }
+int a2s_linear_wgrad(void* stream, int M, int N, int K, const float* dz, long ldz, const float* y, long lda, float* G, long ldg, const float* scale,
+                     const float* shift, int period, const float* dz_absmax, const float* y_absmax, float* workspace, size_t workspace_bytes) {
+    return a2s_linear_wgrad_impl(ST, M, N, K, dz, ldz, y, lda, G, ldg, scale, shift, period, dz_absmax, y_absmax, workspace, workspace_bytes);
+}
+size_t a2s_linear_wgrad_ws_bytes(int M, int K) { return a2s_linear_wgrad_ws_bytes_impl(M, K); }
+int a2s_linear_wgrad_eligible(int M, int N, int K, int period) { return a2s_linear_wgrad_ok(M, N, K, 256, 4, 4, period, nullptr, nullptr, nullptr) ? 1 : 0; }
 int a2s_linear_fwd_eligible(int M, int N, int K, int period) { return a2s_linear_fwd_ok(M, N, K, 4, 4, period, nullptr, nullptr, nullptr) ? 1 : 0; }
 int a2s_linear_dgrad_blocks(int M) { return a2s_linear_dgrad_blocks_impl(M); }
 int a2s_linear_dgrad_eligible(int M, int N, int K, int period) {

@@ -442,3 +442,233 @@ int a2s_linear_fwd_impl(hipStream_t st, int M, int N, int K, const float* A, lon
     A2S_CHECK_LAUNCH("lin_fwd");
     return A2S_OK;
 }
+
+// =========================================================================================== weight gradient
+// G[n][k] += sum_m dz[m][n] * relu(y4[m][k] * scale[c] + shift[c])      (dW of ConvStack.out, reference models.py:68; N = 256, K = 19200, M = B*T)
+// The reduction index is the ROW m, the slow dimension of both tensors.  Same skeleton as lin_fwd with the roles turned:
+//   * dz (M x 256, small) is transposed, scaled and split ONCE per launch into fragment-order planes [32-row step][n-tile][term][lane][8 m]
+//     (lin_pack_dz_planes; every workgroup reads them from L2 -- they play the part the weight planes play in the forward);
+//   * a workgroup owns 128 columns k and a range of 64-row blocks (split-K over the rows: 150 column tiles x 5 ranges = three full rounds of the
+//     chip); the activations go global -> registers (a 4 rows x 4 columns block per thread) -> BatchNorm + ReLU + split -> the LDS stage
+//     TRANSPOSED, [column][64 m]: for each of its 4 columns a thread writes 4 consecutive m as one 8-byte store, and a fragment (8 consecutive m
+//     of one column) is one ds_read_b128 exactly as in the forward;
+//   * the matrix pipe's internal sum truncates toward -infinity: every other group of 8 row steps is accumulated negated (dz negated in the
+//     planes, accumulators flipped), as the generic tiles do (a2s_gemm.hip);
+//   * partial slabs [range][256][K], summed in fixed order into G by lin_wgrad_reduce.
+struct LinWgradArgs {
+    const float* A; long lda;            // y4 (M x K)
+    const unsigned char* planes;         // dz planes (lin_pack_dz_planes)
+    float* partial;                      // [splits][256][K]
+    const float* a_scale; const float* a_shift;
+    const float* a_absmax; const float* d_absmax;
+    int M, K, period, nblk, blk_per_split;
+};
+
+// dz (M x 256) -> [step s = m / 32][n-tile][term][lane][8 halves]: lane (lr = n % 16, lk) holds dz[32 s + 8 lk .. + 7][n], scaled by the power of
+// two that brings max |dz| to 2^12, negated where (s >> 3) is odd; rows >= M: zeros.  One thread per (s, lk, n).
+__global__ __launch_bounds__(256) void lin_pack_dz_planes(const float* __restrict__ dz, long ld, int M, int nsteps, const float* __restrict__ absmax,
+                                                          unsigned char* __restrict__ out) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(id & 255), lk = (int)((id >> 8) & 3), s = (int)(id >> 10);
+    if (s >= nsteps) return;
+    float ps = ldexpf(1.f, pow2_scale_exp(*absmax, 12));
+    if ((s >> 3) & 1) ps = -ps;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = s * 32 + lk * 8 + j;
+        x[j] = m < M ? __builtin_amdgcn_fmed3f(dz[(long)m * ld + n] * ps, -65000.f, 65000.f) : 0.f;
+    }
+    lu32x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned h, l; split2_pair_f16(x[2 * i], x[2 * i + 1], h, l); hi[i] = h; lo[i] = l; }
+    unsigned char* o = out + ((((long)s * 16 + (n >> 4)) * 2) * 64 + (lk * 16 + (n & 15))) * 16;
+    *reinterpret_cast<lu32x4*>(o) = hi;
+    *reinterpret_cast<lu32x4*>(o + 64 * 16) = lo;
+}
+
+__global__ __launch_bounds__(LIN_NTH) void lin_wgrad(LinWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LF_NS * LF_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int k0 = blockIdx.x * LIN_BM;                       // 128 columns
+    const int b_lo = blockIdx.y * a.blk_per_split, b_hi = min(a.nblk, b_lo + a.blk_per_split);
+    const int ka = a.a_absmax ? pow2_scale_exp(*a.a_absmax, 12) : 0, kd = pow2_scale_exp(*a.d_absmax, 12);
+    const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kd));
+    const bool affine = a.a_scale != nullptr;
+    // staging: a thread owns rows 4 rq .. + 3 x columns 4 cq .. + 3 of a 64-row block; its columns lie in one channel (period % 4 == 0)
+    const int cq = tid & 31, rq = tid >> 5;
+    const int ch = affine ? (k0 + 4 * cq) / a.period : 0;
+    const float sc = affine ? a.a_scale[ch] * psa : psa, sh = affine ? a.a_shift[ch] * psa : 0.f, floor_ = affine ? 0.f : -INFINITY;
+    f32x4 ar[2][4];
+    auto issue_a = [&](int blk, f32x4 (&r)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = blk * 64 + 4 * rq + j;
+            r[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (m < a.M && blk < b_hi) r[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + 4 * cq));
+        }
+    };
+    auto commit_a = [&](int blk, const f32x4 (&r)[4]) {
+        if (blk >= b_hi) return;
+        unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                          // column 4 cq + c: rows 4 rq .. + 3 are 4 consecutive "k" of the stage row
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[j][c], sc, sh), floor_), -65000.f, 65000.f);
+            uint2 hi, lo;
+            split2_pair_f16(x[0], x[1], hi.x, lo.x);
+            split2_pair_f16(x[2], x[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(st + (0 * LIN_BM + 4 * cq + c) * LF_RS + rq * 8) = hi;
+            *reinterpret_cast<uint2*>(st + (1 * LIN_BM + 4 * cq + c) * LF_RS + rq * 8) = lo;
+        }
+    };
+    // dz fragments of block blk: steps 2 blk + {0, 1}, n-tiles wave * 2 + {0, 1}
+    lu32x4 df[2][2][2][2];                             // [ring][step of the block][nt][term]
+    auto load_d = [&](int blk, lu32x4 (&dst)[2][2][2]) {
+        if (blk >= b_hi) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+                    dst[h][nt][sp] = *reinterpret_cast<const lu32x4*>(a.planes + ((((long)(2 * blk + h)) * 16 + wave * 2 + nt) * 2 + sp) * 1024 + (unsigned)lane * 16u);
+    };
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool neg = false;
+    auto flip = [&]() {
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[kt][nt][r] = -acc[kt][nt][r];
+    };
+    if (b_lo < b_hi) {
+        issue_a(b_lo, ar[0]);
+        load_d(b_lo, df[0]); load_d(b_lo + 1, df[1]);
+        commit_a(b_lo, ar[0]);
+        issue_a(b_lo + 1, ar[1]); issue_a(b_lo + 2, ar[0]);
+    }
+    // block b (relative index i = b - b_lo): activations in ar[i & 1], dz fragments in df[i & 1]
+    auto body = [&](int blk, f32x4 (&rnext)[4], lu32x4 (&dcur)[2][2][2]) {
+        if (blk >= b_hi) return;
+        const bool want = ((2 * blk) >> 3) & 1;                // sign of this block's steps in the planes (both steps of a block share it)
+        if (want != neg) { flip(); neg = want; }
+        __syncthreads();
+        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        auto load_bf = [&](int h, int half, lu32x4 (&bfr)[2][4]) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bfr[sp][q] = *reinterpret_cast<const lu32x4*>(st + (sp * LIN_BM + (half * 4 + q) * 16 + lr) * LF_RS + h * 64 + lk * 16);
+        };
+        auto multiply = [&](int h, int half, const lu32x4 (&bfr)[2][4]) {
+#define LW_PRODUCT(SX, SD)                                                                                                        \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                      \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                     \
+                    acc[half * 4 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bfr[SX][q]),         \
+                                                                                   __builtin_bit_cast(f16x8, dcur[h][nt][SD]), acc[half * 4 + q][nt], 0, 0, 0);
+            LW_PRODUCT(1, 0) LW_PRODUCT(0, 1) LW_PRODUCT(0, 0)
+#undef LW_PRODUCT
+        };
+        lu32x4 fa[2][4], fb[2][4];
+        auto quarters = [&]() {
+            load_bf(0, 0, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_bf(0, 1, fb); multiply(0, 0, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_bf(1, 0, fa); multiply(0, 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            load_bf(1, 1, fb); multiply(1, 0, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(1, 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (wave < 4) {                                        // (opposite phase order of the two waves of a SIMD: see lin_fwd)
+            commit_a(blk + 1, rnext);
+            __builtin_amdgcn_sched_barrier(0);
+            quarters();
+        } else {
+            quarters();
+            commit_a(blk + 1, rnext);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_d(blk + 2, dcur);
+        issue_a(blk + 3, rnext);
+    };
+#pragma unroll 1
+    for (int b = b_lo; b < b_hi; b += 2) {
+        body(b + 0, ar[1], df[0]);
+        body(b + 1, ar[0], df[1]);
+    }
+    if (neg) flip();
+    // lane (lr, lk) of tile (kt, nt) owns G[n = 32 wave + 16 nt + lr][k0 + 16 kt + 4 lk .. + 3]
+    float* slab = a.partial + (long)blockIdx.y * 256 * a.K;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x4 v = acc[kt][nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= unscale;
+            *reinterpret_cast<f32x4*>(slab + (long)(wave * 32 + nt * 16 + lr) * a.K + k0 + kt * 16 + lk * 4) = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void lin_wgrad_reduce(const float* __restrict__ partial, int splits, long n, float* __restrict__ G, long ldg, int K) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
+    for (int p = 1; p < splits; ++p) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long)p * n + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += v[r];
+    }
+    float* g = G + (i / K) * ldg + (i % K);
+    const f32x4 o = *reinterpret_cast<const f32x4*>(g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] += o[r];
+    *reinterpret_cast<f32x4*>(g) = s;
+}
+
+static int lin_wgrad_splits(int M, int K) {
+    const int ncol = K / LIN_BM, nblk = (M + 63) / 64;
+    int s = (768 + ncol - 1) / ncol;
+    if (s > 16) s = 16;
+    if (s > nblk) s = nblk;
+    return s < 1 ? 1 : s;
+}
+size_t a2s_linear_wgrad_ws_bytes_impl(int M, int K) {
+    if (M < 1 || K < LIN_BM || K % LIN_BM) return 0;
+    const size_t nsteps = 2 * (size_t)((M + 63) / 64);
+    return nsteps * 16 * 2 * 1024 + (size_t)lin_wgrad_splits(M, K) * 256 * K * sizeof(float);
+}
+bool a2s_linear_wgrad_ok(int M, int N, int K, long ldz, long lda, long ldg, int period, const void* dz, const void* A, const void* G) {
+    return N == 256 && M >= 64 && K >= LIN_BM && K % LIN_BM == 0 && (period == 0 || (period % 4 == 0 && K % period == 0)) && lda % 4 == 0 && ldg % 4 == 0 && ldz >= 256 &&
+           (((uintptr_t)dz | (uintptr_t)A | (uintptr_t)G) % 16 == 0);
+}
+int a2s_linear_wgrad_impl(hipStream_t st, int M, int N, int K, const float* dz, long ldz, const float* A, long lda, float* G, long ldg, const float* a_scale,
+                          const float* a_shift, int period, const float* dz_absmax, const float* a_absmax, float* ws, size_t ws_bytes) {
+    A2S_REQUIRE(dz && A && G && dz_absmax && ws && ((a_scale == nullptr) == (a_shift == nullptr)), "linear_wgrad: null argument");
+    A2S_REQUIRE(a2s_linear_wgrad_ok(M, N, K, ldz, lda, ldg, a_scale ? period : 0, dz, A, G), "linear_wgrad: needs N = 256, K %% 128 == 0, period %% 4 == 0, 16-byte aligned rows");
+    A2S_REQUIRE(((uintptr_t)ws % 16 == 0) && ws_bytes >= a2s_linear_wgrad_ws_bytes_impl(M, K), "linear_wgrad: workspace too small (%zu bytes needed)",
+                a2s_linear_wgrad_ws_bytes_impl(M, K));
+    const int nblk = (M + 63) / 64, nsteps = 2 * nblk, splits = lin_wgrad_splits(M, K);
+    unsigned char* planes = reinterpret_cast<unsigned char*>(ws);
+    float* partial = reinterpret_cast<float*>(planes + (size_t)nsteps * 16 * 2 * 1024);
+    hipLaunchKernelGGL(lin_pack_dz_planes, dim3((unsigned)(((long)nsteps * 1024 + 255) / 256)), dim3(256), 0, st, dz, ldz, M, nsteps, dz_absmax, planes);
+    A2S_CHECK_LAUNCH("lin_pack_dz_planes");
+    LinWgradArgs a{A, lda, planes, partial, a_scale, a_shift, a_absmax, dz_absmax, M, K, a_scale ? period : K, nblk, (nblk + splits - 1) / splits};
+    hipLaunchKernelGGL(lin_wgrad, dim3(K / LIN_BM, splits), dim3(LIN_NTH), 0, st, a);
+    A2S_CHECK_LAUNCH("lin_wgrad");
+    const long n = 256L * K;
+    hipLaunchKernelGGL(lin_wgrad_reduce, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, partial, splits, n, G, ldg, K);
+    A2S_CHECK_LAUNCH("lin_wgrad_reduce");
+    return A2S_OK;
+}

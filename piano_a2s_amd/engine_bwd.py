@@ -646,7 +646,8 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         y4 = cs["y"][3].view(rows, 40 * F)
         da = torch.empty_like(y4)
         bn4 = cs["bn"][3]
-        _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
+        if not hip.linear_wgrad(dz, y4, (bn4[2], bn4[3], F), dz_amax, cs["abound"][3], G["convstack.out.weight"]):       # round 4: csrc/a2s_linear.hip
+            _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
         if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             if w_amax is None:

@@ -56,7 +56,7 @@ def lib():
         _lib = C.CDLL(LIB)
         _lib.a2s_last_error.restype = C.c_char_p
         _lib.a2s_launch_count.restype = C.c_longlong
-        for fn in ("a2s_note_step_workspace_floats", "a2s_note_decoder_persist_ws_bytes", "a2s_note_decoder_bwd_persist_ws_bytes", "a2s_linear_dgrad_ws_bytes", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
+        for fn in ("a2s_note_step_workspace_floats", "a2s_note_decoder_persist_ws_bytes", "a2s_note_decoder_bwd_persist_ws_bytes", "a2s_linear_dgrad_ws_bytes", "a2s_linear_wgrad_ws_bytes", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
                    "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
         for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_CONV_ROWS", b"conv_rows"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"), ("A2S_CONV_F16X2", b"conv_f16x2"), ("A2S_WGRAD_F16X2", b"wgrad_f16x2"),
@@ -252,6 +252,22 @@ def linear_forward(x2d, weight, x_affine, x_bound, w_absmax, out=None):
                                _p(x_bound), _p(w_absmax), _p(ws), C.c_size_t(nb)), "a2s_linear_fwd")
         return out
     return linear(x2d, weight, out=out, x_affine=x_affine, two_term=(x_bound, w_absmax))
+
+
+def linear_wgrad(dz, x2d, x_affine, dz_absmax, x_bound, G):
+    """G (N, K) += dz^T relu(bn(x)) for the ConvStack's 19200 -> 256 Linear on the kernel of csrc/a2s_linear.hip; returns False when the shape
+    does not qualify (A2S_LINEAR_WGRAD=0: never) -- the caller then runs the generic split-K GEMM."""
+    M, K = x2d.shape
+    N = dz.shape[1]
+    L = lib()
+    if (os.environ.get("A2S_LINEAR_WGRAD", "1") == "0" or not (x2d.is_contiguous() and dz.is_contiguous() and G.is_contiguous()) or dz_absmax is None
+            or x_bound is None or not L.a2s_linear_wgrad_eligible(M, N, K, x_affine[2])):
+        return False
+    nb = L.a2s_linear_wgrad_ws_bytes(M, K)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=x2d.device)
+    check(L.a2s_linear_wgrad(stream(), M, N, K, _p(dz), C.c_long(N), _p(x2d), C.c_long(K), _p(G), C.c_long(K), _p(x_affine[0]), _p(x_affine[1]), x_affine[2],
+                             _p(dz_absmax), _p(x_bound), _p(ws), C.c_size_t(nb)), "a2s_linear_wgrad")
+    return True
 
 
 def linear_forward_for_test(x, w, aff):

@@ -115,3 +115,38 @@ def test_linear_forward_kernel(dev, M, channels, period):
     err_old = float(((z_old.double() - ref).abs() / mag.clamp_min(1e-300)).max())
     assert err_new < 1e-6, f"{err_new:.3e} of sum|a||w| (generic tile: {err_old:.3e})"
     assert err_new <= 2.0 * err_old + 1e-7, f"{err_new:.3e} vs the generic tile's {err_old:.3e}"
+
+
+@pytest.mark.parametrize("M,channels,period,gscale", [(300, 40, 128, 1e-5), (64 * 37 + 5, 6, 64, 1.0), (1201 * 2, 40, 480, 3e-7), (2048 + 64, 1, 128, 1e2)])
+def test_linear_weight_gradient_kernel(dev, M, channels, period, gscale):
+    """G += dz^T relu(bn(y)) on the kernel of csrc/a2s_linear.hip (dz as transposed fp16 term planes, activations staged transposed, split-K over
+    the rows with alternating accumulation sign) against float64 and against the generic split-K two-term tile; G starts non-zero."""
+    import os
+    from piano_a2s_amd import hip
+    L = hip.lib()
+    K, N = channels * period, 256
+    assert L.a2s_linear_wgrad_eligible(M, N, K, period) == 1
+    g = torch.Generator().manual_seed(M + K)
+    y = (torch.randn(M, K, generator=g) * 2.0).to(dev)
+    dz = (torch.randn(M, N, generator=g) * gscale).to(dev)
+    dz[M // 3] *= 2.0 ** -12
+    scale = (torch.randn(channels, generator=g)).to(dev)
+    shift = (torch.randn(channels, generator=g) * 0.3).to(dev)
+    ymax = y.view(M, channels, period).abs().amax(dim=(0, 2)).contiguous()
+    bound, dmax = hip.act_bound(scale, shift, ymax), hip.absmax(dz)
+    G0 = (torch.randn(N, K, generator=g) * gscale).to(dev)
+    G_new = G0.clone()
+    assert hip.linear_wgrad(dz, y, (scale, shift, period), dmax, bound, G_new)
+    G_old = G0.clone()
+    sk = L.a2s_gemm_pick_splitk(N, K, M, 1)
+    hip.gemm(dz, 1, N, y, K, 1, G_old, K, N, K, M, beta=1.0, splitk=sk, b_affine=(scale, shift, period), two_term=(dmax, bound))
+    torch.cuda.synchronize()
+    ch = torch.arange(K, device=dev) // period
+    a = torch.relu(y.double() * scale.double()[ch] + shift.double()[ch])
+    ref = G0.double() + dz.double().t() @ a
+    mag = G0.double().abs() + dz.double().abs().t() @ a.abs()
+    assert torch.isfinite(G_new).all()
+    err_new = float(((G_new.double() - ref).abs() / mag.clamp_min(1e-300)).max())
+    err_old = float(((G_old.double() - ref).abs() / mag.clamp_min(1e-300)).max())
+    assert err_new < 1e-6, f"{err_new:.3e} of sum|dz||a| (generic tile: {err_old:.3e})"
+    assert err_new <= 2.0 * err_old + 1e-7, f"{err_new:.3e} vs the generic tile's {err_old:.3e}"

@@ -69,7 +69,11 @@ def main():
         print(f"data gradient  {ms:7.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s   {(2.0 * rows * K * 4 + rows * Cf * 4) / ms / 1e6:6.0f} GB/s  (csrc/a2s_linear.hip)")
     sk = L.a2s_gemm_pick_splitk(Cf, K, rows, 1)
     ms = timed(lambda: hip.gemm(dz, 1, Cf, y4, K, 1, G, K, Cf, K, rows, beta=1.0, splitk=sk, b_affine=(scale, shift, F), two_term=(dmax, None)))
-    print(f"weight gradient{ms:7.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s  (split-K {sk})")
+    print(f"weight gradient{ms:7.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s  (generic 256x256 two-term tile, split-K {sk})")
+    if L.a2s_linear_wgrad_eligible(rows, Cf, K, F):
+        bound = hip.act_bound(scale, shift, y4.view(rows, 40, F).abs().amax(dim=(0, 2)).contiguous())
+        ms = timed(lambda: hip.linear_wgrad(dz, y4, (scale, shift, F), dmax, bound, G))
+        print(f"weight gradient{ms:7.2f} ms  {fl / ms / 1e9:6.1f} TFLOP/s   {rows * K * 4.0 / ms / 1e6:6.0f} GB/s  (csrc/a2s_linear.hip)")
 
 
 if __name__ == "__main__":
