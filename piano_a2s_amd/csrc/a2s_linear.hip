@@ -423,6 +423,138 @@ __global__ __launch_bounds__(LIN_NTH) void lin_fwd(LinFwdArgs a) {
     }
 }
 
+// ---- the same forward with the two waves of a SIMD in FIXED ROLES (the split of a2s_conv_wrows.hip): waves 0-3 only read fragments and
+// multiply (128 rows x 64 columns each: 128 accumulators), waves 4-7 only load, convert and write the next stages -- the conversion, the
+// global-load issue and their waits never stand in front of an MFMA.
+__global__ __launch_bounds__(LIN_NTH) void lin_fwd_roles(LinFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LF_NS * LF_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * LIN_BM;
+    const int ka = a.a_absmax ? pow2_scale_exp(*a.a_absmax, 12) : 0, kb = pow2_scale_exp(*a.b_absmax, 12);
+    const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kb));
+    const int nks = a.K >> 5, nblk = a.K >> 6, kpc = a.period >> 5;
+    const bool affine = a.a_scale != nullptr;
+    if (wave >= 4) {
+        // ================================================================ staging role: 256 threads, 8 items (row, 4 k) per 64-k block each
+        const int st_ = tid - 256;
+        const int sk = (st_ & 15) * 4;
+        const bool second = sk >= 32;
+        f32x4 ar[2][8];
+        auto issue_a = [&](int blk, f32x4 (&r)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (st_ + 256 * i) >> 4;
+                r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (m0 + row < a.M && blk < nblk) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)(m0 + row) * a.lda + (long)blk * 64 + sk));
+            }
+        };
+        auto commit_a = [&](int blk, const f32x4 (&r)[8]) {
+            if (blk >= nblk) return;
+            const int c0 = (2 * blk) / kpc, c1 = (2 * blk + 1) / kpc;
+            const float sc = affine ? (second ? a.a_scale[c1] : a.a_scale[c0]) * psa : psa, sh = affine ? (second ? a.a_shift[c1] : a.a_shift[c0]) * psa : 0.f;
+            const float floor_ = affine ? 0.f : -INFINITY;
+            unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (st_ + 256 * i) >> 4;
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[i][j], sc, sh), floor_), -65000.f, 65000.f);
+                uint2 hi, lo;
+                split2_pair_f16(x[0], x[1], hi.x, lo.x);
+                split2_pair_f16(x[2], x[3], hi.y, lo.y);
+                *reinterpret_cast<uint2*>(st + (0 * LIN_BM + row) * LF_RS + sk * 2) = hi;
+                *reinterpret_cast<uint2*>(st + (1 * LIN_BM + row) * LF_RS + sk * 2) = lo;
+            }
+        };
+        issue_a(0, ar[0]);
+        commit_a(0, ar[0]);
+        issue_a(1, ar[1]); issue_a(2, ar[0]);
+#pragma unroll 1
+        for (int b0 = 0; b0 < nblk; b0 += 2) {
+            // iteration blk: (barrier) stage blk is complete and stage blk + 1 free; write stage blk + 1, fetch block blk + 3
+            __syncthreads();
+            commit_a(b0 + 1, ar[1]); issue_a(b0 + 3, ar[1]);
+            if (b0 + 1 < nblk) {
+                __syncthreads();
+                commit_a(b0 + 2, ar[0]); issue_a(b0 + 4, ar[0]);
+            }
+        }
+        return;
+    }
+    // ==================================================================== multiply role: wave w = columns 64 w .. + 63, all 128 rows
+    lu32x4 bf[2][4][2];                                // [ring of two k-steps][nt][term]
+    auto load_b = [&](int ks, lu32x4 (&dst)[4][2]) {
+        if (ks >= nks) return;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+                dst[nt][sp] = *reinterpret_cast<const lu32x4*>(a.planes + (((long)(wave * 4 + nt) * nks + ks) * 2 + sp) * 1024 + (unsigned)lane * 16u);
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_b(0, bf[0]);
+    // two row tiles at a time (16 fragment registers), the next pair read while this one multiplies
+    auto load_af = [&](const unsigned char* st, int h, int qt, lu32x4 (&af)[2][2]) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) af[sp][q] = *reinterpret_cast<const lu32x4*>(st + (sp * LIN_BM + (qt * 2 + q) * 16 + lr) * LF_RS + h * 64 + lk * 16);
+    };
+    auto multiply = [&](int qt, const lu32x4 (&af)[2][2], const lu32x4 (&b)[4][2]) {
+#define LR_PRODUCT(SA, SB)                                                                                                        \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                          \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                         \
+                acc[qt * 2 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[nt][SB]),                \
+                                                                             __builtin_bit_cast(f16x8, af[SA][q]), acc[qt * 2 + q][nt], 0, 0, 0);
+        LR_PRODUCT(1, 0) LR_PRODUCT(0, 1) LR_PRODUCT(0, 0)
+#undef LR_PRODUCT
+    };
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; ++blk) {
+        __syncthreads();
+        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        lu32x4 fa[2][2], fb[2][2];
+        load_af(st, 0, 0, fa);
+        load_b(2 * blk + 1, bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(st, 0, 1, fb); multiply(0, fa, bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(st, 0, 2, fa); multiply(1, fb, bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(st, 0, 3, fb); multiply(2, fa, bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(st, 1, 0, fa); multiply(3, fb, bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(2 * blk + 2, bf[0]);
+        load_af(st, 1, 1, fb); multiply(0, fa, bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(st, 1, 2, fa); multiply(1, fb, bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_af(st, 1, 3, fb); multiply(2, fa, bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(3, fb, bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + mt * 16 + lr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[mt][nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= unscale;
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + wave * 64 + nt * 16 + lk * 4) = v;
+        }
+    }
+}
+
 bool a2s_linear_fwd_ok(int M, int N, int K, long lda, long ldc, int period, const void* A, const void* W, const void* C) {
     return N == 256 && M >= 1 && K >= 128 && K % 64 == 0 && (period == 0 || (period % 32 == 0 && K % period == 0)) && lda % 4 == 0 && ldc % 4 == 0 &&
            (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0);
@@ -438,7 +570,10 @@ int a2s_linear_fwd_impl(hipStream_t st, int M, int N, int K, const float* A, lon
     hipLaunchKernelGGL(lin_pack_planes_k, dim3((unsigned)(((long)N * (K / 8) + 255) / 256)), dim3(256), 0, st, W, (long)K, N, K, w_absmax, planes);
     A2S_CHECK_LAUNCH("lin_pack_planes_k");
     LinFwdArgs a{A, lda, planes, C, ldc, a_scale, a_shift, a_absmax, w_absmax, M, K, a_scale ? period : K};
-    hipLaunchKernelGGL(lin_fwd, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
+    static int roles = -1;                    // A2S_LINEAR_ROLES=0: all eight waves stage and multiply (lin_fwd)
+    if (roles < 0) { const char* e = getenv("A2S_LINEAR_ROLES"); roles = e ? atoi(e) : 1; }
+    if (roles) hipLaunchKernelGGL(lin_fwd_roles, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
+    else hipLaunchKernelGGL(lin_fwd, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
     A2S_CHECK_LAUNCH("lin_fwd");
     return A2S_OK;
 }
@@ -621,6 +756,147 @@ __global__ __launch_bounds__(LIN_NTH) void lin_wgrad(LinWgradArgs a) {
         }
 }
 
+// ---- the same with fixed wave roles (see lin_fwd_roles): waves 0-3 multiply (128 columns x 64 n each: 128 accumulators), waves 4-7 stage
+__global__ __launch_bounds__(LIN_NTH) void lin_wgrad_roles(LinWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LF_NS * LF_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k0 = blockIdx.x * LIN_BM;
+    const int b_lo = blockIdx.y * a.blk_per_split, b_hi = min(a.nblk, b_lo + a.blk_per_split);
+    const int ka = a.a_absmax ? pow2_scale_exp(*a.a_absmax, 12) : 0, kd = pow2_scale_exp(*a.d_absmax, 12);
+    const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kd));
+    const bool affine = a.a_scale != nullptr;
+    if (wave >= 4) {
+        // ================================================================ staging role: two 4 rows x 4 columns blocks per thread and 64-row block
+        const int st_ = tid - 256;
+        const int cq = st_ & 31, rq0 = st_ >> 5;             // row quads rq0 and rq0 + 8
+        const int ch = affine ? (k0 + 4 * cq) / a.period : 0;
+        const float sc = affine ? a.a_scale[ch] * psa : psa, sh = affine ? a.a_shift[ch] * psa : 0.f, floor_ = affine ? 0.f : -INFINITY;
+        f32x4 ar[2][8];
+        auto issue_a = [&](int blk, f32x4 (&r)[8]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = blk * 64 + 4 * (rq0 + 8 * u) + j;
+                    r[4 * u + j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (m < a.M && blk < b_hi) r[4 * u + j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + 4 * cq));
+                }
+        };
+        auto commit_a = [&](int blk, const f32x4 (&r)[8]) {
+            if (blk >= b_hi) return;
+            unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[4 * u + j][c], sc, sh), floor_), -65000.f, 65000.f);
+                    uint2 hi, lo;
+                    split2_pair_f16(x[0], x[1], hi.x, lo.x);
+                    split2_pair_f16(x[2], x[3], hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(st + (0 * LIN_BM + 4 * cq + c) * LF_RS + (rq0 + 8 * u) * 8) = hi;
+                    *reinterpret_cast<uint2*>(st + (1 * LIN_BM + 4 * cq + c) * LF_RS + (rq0 + 8 * u) * 8) = lo;
+                }
+        };
+        if (b_lo < b_hi) {
+            issue_a(b_lo, ar[0]);
+            commit_a(b_lo, ar[0]);
+            issue_a(b_lo + 1, ar[1]); issue_a(b_lo + 2, ar[0]);
+        }
+#pragma unroll 1
+        for (int b = b_lo; b < b_hi; b += 2) {
+            __syncthreads();
+            commit_a(b + 1, ar[1]); issue_a(b + 3, ar[1]);
+            if (b + 1 < b_hi) {
+                __syncthreads();
+                commit_a(b + 2, ar[0]); issue_a(b + 4, ar[0]);
+            }
+        }
+        return;
+    }
+    // ==================================================================== multiply role: wave w = n 64 w .. + 63 (dz planes), all 128 columns (LDS)
+    lu32x4 df[2][4][2];                                // [ring of two steps][nt][term]
+    auto load_d = [&](int step, lu32x4 (&dst)[4][2]) {
+        if (step >= 2 * b_hi) return;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+                dst[nt][sp] = *reinterpret_cast<const lu32x4*>(a.planes + ((((long)step) * 16 + wave * 4 + nt) * 2 + sp) * 1024 + (unsigned)lane * 16u);
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool neg = false;
+    auto flip = [&]() {
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[kt][nt][r] = -acc[kt][nt][r];
+    };
+    auto load_bf = [&](const unsigned char* st, int h, int qt, lu32x4 (&f)[2][2]) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) f[sp][q] = *reinterpret_cast<const lu32x4*>(st + (sp * LIN_BM + (qt * 2 + q) * 16 + lr) * LF_RS + h * 64 + lk * 16);
+    };
+    auto multiply = [&](int qt, const lu32x4 (&f)[2][2], const lu32x4 (&d)[4][2]) {
+#define LW_PRODUCT(SX, SD)                                                                                                        \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                                          \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                         \
+                acc[qt * 2 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f[SX][q]),                 \
+                                                                             __builtin_bit_cast(f16x8, d[nt][SD]), acc[qt * 2 + q][nt], 0, 0, 0);
+        LW_PRODUCT(1, 0) LW_PRODUCT(0, 1) LW_PRODUCT(0, 0)
+#undef LW_PRODUCT
+    };
+    load_d(2 * b_lo, df[0]);
+#pragma unroll 1
+    for (int blk = b_lo; blk < b_hi; ++blk) {
+        const bool want = ((2 * blk) >> 3) & 1;
+        if (want != neg) { flip(); neg = want; }
+        __syncthreads();
+        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        lu32x4 fa[2][2], fb[2][2];
+        load_bf(st, 0, 0, fa);
+        load_d(2 * blk + 1, df[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bf(st, 0, 1, fb); multiply(0, fa, df[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bf(st, 0, 2, fa); multiply(1, fb, df[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bf(st, 0, 3, fb); multiply(2, fa, df[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bf(st, 1, 0, fa); multiply(3, fb, df[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_d(2 * blk + 2, df[0]);
+        load_bf(st, 1, 1, fb); multiply(0, fa, df[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bf(st, 1, 2, fa); multiply(1, fb, df[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_bf(st, 1, 3, fb); multiply(2, fa, df[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(3, fb, df[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (neg) flip();
+    float* slab = a.partial + (long)blockIdx.y * 256 * a.K;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[kt][nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= unscale;
+            *reinterpret_cast<f32x4*>(slab + (long)(wave * 64 + nt * 16 + lr) * a.K + k0 + kt * 16 + lk * 4) = v;
+        }
+}
+
 __global__ __launch_bounds__(256) void lin_wgrad_reduce(const float* __restrict__ partial, int splits, long n, float* __restrict__ G, long ldg, int K) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
@@ -665,7 +941,10 @@ int a2s_linear_wgrad_impl(hipStream_t st, int M, int N, int K, const float* dz, 
     hipLaunchKernelGGL(lin_pack_dz_planes, dim3((unsigned)(((long)nsteps * 1024 + 255) / 256)), dim3(256), 0, st, dz, ldz, M, nsteps, dz_absmax, planes);
     A2S_CHECK_LAUNCH("lin_pack_dz_planes");
     LinWgradArgs a{A, lda, planes, partial, a_scale, a_shift, a_absmax, dz_absmax, M, K, a_scale ? period : K, nblk, (nblk + splits - 1) / splits};
-    hipLaunchKernelGGL(lin_wgrad, dim3(K / LIN_BM, splits), dim3(LIN_NTH), 0, st, a);
+    static int roles = -1;                    // A2S_LINEAR_ROLES=0: all eight waves stage and multiply (lin_wgrad)
+    if (roles < 0) { const char* e = getenv("A2S_LINEAR_ROLES"); roles = e ? atoi(e) : 1; }
+    if (roles) hipLaunchKernelGGL(lin_wgrad_roles, dim3(K / LIN_BM, splits), dim3(LIN_NTH), 0, st, a);
+    else hipLaunchKernelGGL(lin_wgrad, dim3(K / LIN_BM, splits), dim3(LIN_NTH), 0, st, a);
     A2S_CHECK_LAUNCH("lin_wgrad");
     const long n = 256L * K;
     hipLaunchKernelGGL(lin_wgrad_reduce, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, partial, splits, n, G, ldg, K);
