@@ -823,15 +823,30 @@ int a2s_staff_emb_fwd_impl(hipStream_t st, const float* note_emb, const float* c
 // ---- combine of a row's G partials, shared by the stand-alone combine kernel and by the split kernels' fused tail (the workgroup that
 // finishes LAST for its clip -- ticket counter, release / acquire through L2 as in dec_out_step -- merges the partials itself: one launch
 // and one dependent-launch gap less per decode step; on the long-clip chain the combine was 7 us + ~4.5 us of gap in a 92 us step).
-// pb: the row's G partials [m, l, pad, pad, ctx(2H)]; one memory round trip for the statistics, one for the contexts.  wgt: 80 floats of LDS.
+// pb: the row's G partials [m, l, pad, pad, ctx(2H)]; wgt: 80 floats of LDS.
 struct AttnCombineOut { float* ctx; float* ctx2; float* attw; int T; };
 __device__ __forceinline__ void attn_combine_row(const volatile float* pb, int G, const AttnCombineOut& o, float* wgt) {
     constexpr int H = 256, PS = 2 * H + 4;
     const int tid = threadIdx.x;
+    // Round 4: EVERYTHING the row needs is requested before anything is waited for -- the partial statistics, the first 16 partial contexts
+    // (G <= 16 by default: all of them) and the thread's share of the saved scores.  The kernel sits on every decode chain and under the other
+    // streams' traffic a dependent round trip costs ~7 us: as statistics -> barrier -> contexts -> scores it took 23.8 us (median on the
+    // long-clip group's queue, profiles/r04_trace_overlap.txt) for a few hundred KB.
+    const bool have = tid < 64 && tid < G;
+    const float mg = have ? pb[(long)tid * PS] : -INFINITY, lg = have ? pb[(long)tid * PS + 1] : 0.f;
+    float p0[16], p1[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const bool ok = u < G;
+        p0[u] = ok ? pb[(long)u * PS + 4 + tid] : 0.f;
+        p1[u] = ok ? pb[(long)u * PS + 4 + 256 + tid] : 0.f;
+    }
+    volatile float* aw = o.attw;                      // raw scores written by the clip's other workgroups
+    float sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sv[u] = (o.attw && tid + 256 * u < o.T) ? aw[tid + 256 * u] : 0.f;
     __syncthreads();                                  // wgt free (previous row / the caller's scratch)
     if (tid < 64) {                                   // G <= 64 (a2s_attn_max_split)
-        const bool have = tid < G;
-        const float mg = have ? pb[(long)tid * PS] : -INFINITY, lg = have ? pb[(long)tid * PS + 1] : 0.f;
         const float m = wave_max(mg);
         const float e = have ? __expf(mg - m) : 0.f;
         const float l = wave_sum(lg * e);
@@ -841,30 +856,31 @@ __device__ __forceinline__ void attn_combine_row(const volatile float* pb, int G
     }
     __syncthreads();
     float acc0 = 0.f, acc1 = 0.f;
-    for (int g0 = 0; g0 < G; g0 += 16) {              // (G <= 16 by default: every partial of the row in flight together)
-        float p0[16], p1[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { acc0 = fmaf(p0[u], wgt[u], acc0); acc1 = fmaf(p1[u], wgt[u], acc1); }
+    for (int g0 = 16; g0 < G; g0 += 16) {             // (only with A2S_ATTN_MAX_SPLIT > 16)
+        float q0[16], q1[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const bool ok = g0 + u < G;
-            p0[u] = ok ? pb[(long)(g0 + u) * PS + 4 + tid] : 0.f;
-            p1[u] = ok ? pb[(long)(g0 + u) * PS + 4 + 256 + tid] : 0.f;
+            q0[u] = ok ? pb[(long)(g0 + u) * PS + 4 + tid] : 0.f;
+            q1[u] = ok ? pb[(long)(g0 + u) * PS + 4 + 256 + tid] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { acc0 = fmaf(p0[u], wgt[g0 + u], acc0); acc1 = fmaf(p1[u], wgt[g0 + u], acc1); }
+        for (int u = 0; u < 16; ++u) { acc0 = fmaf(q0[u], wgt[g0 + u], acc0); acc1 = fmaf(q1[u], wgt[g0 + u], acc1); }
     }
     o.ctx[tid] = acc0; o.ctx[256 + tid] = acc1;
     if (o.ctx2) { o.ctx2[tid] = acc0; o.ctx2[256 + tid] = acc1; }
     if (o.attw) {
         const float m = wgt[79], inv = wgt[78];
-        volatile float* aw = o.attw;                  // raw scores written by the clip's other workgroups
-        // all of a thread's scores in flight together (T = 1201: 5 per thread): one memory round trip instead of one per score -- this
-        // kernel sits on every decode chain, and under the other streams' traffic a round trip costs microseconds
-        for (int t0 = tid; t0 < o.T; t0 += 8 * 256) {
-            float sv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sv[u] = (t0 + 256 * u < o.T) ? aw[t0 + 256 * u] : 0.f;
+        for (int u = 0; u < 8; ++u) if (tid + 256 * u < o.T) aw[tid + 256 * u] = __expf(sv[u] - m) * inv;
+        for (int t0 = tid + 8 * 256; t0 < o.T; t0 += 8 * 256) {       // (T > 2048 only)
+            float sw[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (t0 + 256 * u < o.T) aw[t0 + 256 * u] = __expf(sv[u] - m) * inv;
+            for (int u = 0; u < 8; ++u) sw[u] = (t0 + 256 * u < o.T) ? aw[t0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (t0 + 256 * u < o.T) aw[t0 + 256 * u] = __expf(sw[u] - m) * inv;
         }
     }
 }
