@@ -19,6 +19,10 @@ from .spec import SOS, VOCAB_SIZE
 NULL = C.c_void_p(0)
 
 
+def _os_env(name, default):
+    return os.environ.get(name, default)
+
+
 def _ptr(t, off=0):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
@@ -432,11 +436,22 @@ class Backward:
                      two_term=(dk_amax, enc_amax) if self.two_term else None)
             hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2,
                      two_term=(dk_amax, hip.absmax(S[Wn])) if self.two_term else None)
-        d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T)
+        # The encoder's last weight gradients (layer 0: ~5 ms of GEMMs on the weight-gradient stream, nothing of the encoder left to run beside
+        # them) overlap with the START of the ConvStack backward: the caller's stream does not wait for them here.  The decoder + encoder slice
+        # is announced from that stream (a collective issued there is ordered behind its work, which itself waited for everything the main
+        # stream had enqueued when those GEMMs were launched), and the main stream joins it after the ConvStack backward.
+        defer = _os_env("A2S_DEFER_ENC_WGRAD", "1") != "0"
+        d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T, wait_weight_grads=not defer)
         n_conv = next(off for k, off in zip(names, offs) if not k.startswith("convstack."))      # state_dict order: convstack first
         if grad_ready is not None:
-            grad_ready(self.flat_full, n_conv, total + 1)           # (+ the loss word)
+            if defer:
+                with torch.cuda.stream(_weight_grad_stream(dev)):
+                    grad_ready(self.flat_full, n_conv, total + 1)
+            else:
+                grad_ready(self.flat_full, n_conv, total + 1)           # (+ the loss word)
         _convstack_bwd(eng, S, G, sv["conv"], d_conv, B, T, F)
+        if defer:
+            torch.cuda.current_stream().wait_stream(_weight_grad_stream(dev))
         if grad_ready is not None:
             grad_ready(flat, 0, n_conv)
         G[None] = flat
@@ -493,7 +508,10 @@ def _weight_grad_stream(dev):
     return group_stream(dev, 1)             # the fourth stream of the budget: idle while the encoder back-propagates
 
 
-def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
+def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T, wait_weight_grads=True):
+    """wait_weight_grads=False: the caller's stream is NOT made to wait for the weight gradients on _weight_grad_stream(dev) (layer 0's run
+    after its recurrence, with nothing left to hide them under): the caller waits for that stream before anything reads the encoder's
+    gradient slice (Backward.finish announces the slice FROM that stream and joins it after the ConvStack backward)."""
     L = hip.lib()
     H = eng.cfg["hidden_size"]
     dev = dEnc.device
@@ -551,8 +569,11 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
         wg.wait_event(ev)
         for d, sfx in enumerate((f"l{layer}", f"l{layer}_reverse")):
             dgi, dghs, dgh_first = res[d][:3]
-            for t in (dgi, dghs, dgh_first):
-                t.record_stream(wg)
+            # (everything the weight-gradient stream reads that was allocated on another stream -- the operand-range scalars included: freed by
+            # this function's return, their blocks would be handed to the next small allocation of the main stream while these GEMMs still run)
+            for t in (dgi, dghs, dgh_first, dgi_amax[d], in_amax):
+                if t is not None:
+                    t.record_stream(wg)
             with torch.cuda.stream(wg):
                 dgi2, dghs2 = dgi.view(B * T, 3 * H), dghs.view(B * T, 3 * H)
                 _linear_bwd(inp, S[f"encoder.gru.weight_ih_{sfx}"], dgi2, G, f"encoder.gru.weight_ih_{sfx}", f"encoder.gru.bias_ih_{sfx}",
@@ -563,7 +584,8 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T):
                 _colsum(dghs2, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B * T, 3 * H)
                 _colsum(dgh_first, 3 * H, G[f"encoder.gru.bias_hh_{sfx}"], B, 3 * H)
         dout = dX.view(B, T, I)
-    torch.cuda.current_stream().wait_stream(_weight_grad_stream(dev))     # the encoder gradients are complete past this point
+    if wait_weight_grads:
+        torch.cuda.current_stream().wait_stream(_weight_grad_stream(dev))     # the encoder gradients are complete past this point
     return dout                                              # (B, T, conv_feature_size)
 
 
