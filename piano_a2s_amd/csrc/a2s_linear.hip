@@ -11,7 +11,7 @@
 //   * W is split ONCE per launch into fp16 term planes laid out in MFMA-fragment order (lin_pack_planes_k: 19.7 MB, 1 KB contiguous per
 //     fragment); the sweep below reads its B fragments straight from those planes (L2-resident: all workgroups of an XCD walk the
 //     column tiles together) -- no conversion, no LDS, no barrier for B;
-//   * a workgroup owns 128 ROWS for ALL column tiles: its slice of dz is split once into LDS (147 KB: [64-k block][term][row][128 B + 16])
+//   * a workgroup owns 128 ROWS for ALL column tiles: its slice of dz is split once into LDS (147 KB: [128-k block][term][row][256 B + 32])
 //     and is read-only from then on, so the sweep over the 75 column tiles of 256 has NO barrier at all: the 8 waves (32 columns each)
 //     drift apart and one wave's epilogue (stores, the y4 re-read, the statistics) runs under the other waves' MFMAs on the same SIMD;
 //   * the statistics of a wave's 32-column slices (one channel each: F % 32 == 0) stay in registers until the channel changes.
@@ -26,9 +26,11 @@
 
 #define LIN_BM 128
 #define LIN_K 256
-#define LIN_RS 144                       // bytes per LDS row of one 64-k block: 128 of fp16 + 16 (16-byte slots of 16 rows all distinct mod 256)
+#define LIN_RS 288                       // bytes per LDS row of one 128-k block: 256 of fp16 + 32.  ds_read_b128 of the fragment pattern (16 rows x 64 B):
+                                         // 4.0 clocks per wave-level read with a row stride that is an ODD multiple of 32 bytes (96, 160, 224, 288), 6.7
+                                         // with 80 / 144 / 272 (tools/ubench/b128_read.hip: profiles/r04_lds_patterns.txt)
 #define LIN_NTH 512
-#define LIN_LDS (4 * 2 * LIN_BM * LIN_RS)
+#define LIN_LDS (2 * 2 * LIN_BM * LIN_RS)
 
 typedef unsigned lu32x4 __attribute__((ext_vector_type(4)));
 
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
             uint2 hi, lo;
             split2_pair_f16(x[0], x[1], hi.x, lo.x);
             split2_pair_f16(x[2], x[3], hi.y, lo.y);
-            const int blk = k >> 6, off = (k & 63) * 2;
+            const int blk = k >> 7, off = (k & 127) * 2;
             *reinterpret_cast<uint2*>(lds + ((blk * 2 + 0) * LIN_BM + row) * LIN_RS + off) = hi;
             *reinterpret_cast<uint2*>(lds + ((blk * 2 + 1) * LIN_BM + row) * LIN_RS + off) = lo;
         }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_dgrad_bnstats(LinDgradArgs a) {
                 for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        af[sp][q] = *reinterpret_cast<const lu32x4*>(lds + (((ks >> 1) * 2 + sp) * LIN_BM + (half * 4 + q) * 16 + lr) * LIN_RS + (ks & 1) * 64 + lk * 16);
+                        af[sp][q] = *reinterpret_cast<const lu32x4*>(lds + (((ks >> 2) * 2 + sp) * LIN_BM + (half * 4 + q) * 16 + lr) * LIN_RS + (ks & 3) * 64 + lk * 16);
 #define LIN_PRODUCT(SA, SB)                                                                                                   \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                              \
                     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                             \
@@ -245,7 +247,7 @@ int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const flo
 // one multiply phase to arrive: 12.9 ms at B = 256 against 4.7 ms of HBM time (y4 once) and 3.6 ms of matrix time.  Here:
 //   * W as fp16 term planes in fragment order (lin_pack_planes_k, as for the data gradient): B fragments straight from L2, ring of three k-steps;
 //   * a workgroup owns 128 rows x all 256 columns (8 waves x 32 columns, 64 accumulators): y4 is read exactly once;
-//   * the activations go global -> registers (two 64-k blocks in flight) -> BatchNorm + ReLU + split -> a ring of FOUR LDS stages (36 KB each):
+//   * the activations go global -> registers (two 64-k blocks in flight) -> BatchNorm + ReLU + split -> a ring of THREE LDS stages (40 KB each):
 //     one barrier per 64 k, the stage written in iteration b is read in iteration b + 1 (32-k stages, a barrier per k-step: 11.0 ms at B = 256;
 //     the barrier and the conversion block stand between the k-steps' MFMAs);
 //   * F % 32 == 0: a k-step lies inside one channel, so the BatchNorm constants of a k-step are two scalars.
@@ -259,9 +261,9 @@ int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const flo
 // (a2s_conv_wrows.hip: 2.3 -> 1.7 GHz), i.e. the "cost of the loads" is largely the multiply running slower.
 // Two independent workgroups per CU instead (64 rows x 256 columns, 4 waves x 64 columns, so that one's staging runs under the other's MFMAs):
 // 15.1 ms -- every B fragment is then fetched from L2 by twice as many workgroups.
-#define LF_RS 144                        // bytes per LDS row of a stage: 64 k of fp16 + 16
+#define LF_RS 160                        // bytes per LDS row of a stage: 64 k of fp16 + 32 (odd multiple of 32 B: conflict-free fragment reads, see LIN_RS)
 #define LF_STAGE (2 * LIN_BM * LF_RS)
-#define LF_NS 4
+#define LF_NS 3
 
 struct LinFwdArgs {
     const float* A; long lda;            // y4 (M x K)
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_fwd(LinFwdArgs a) {
         const int c0 = (2 * blk) / kpc, c1 = (2 * blk + 1) / kpc;
         const float sc = affine ? (second ? a.a_scale[c1] : a.a_scale[c0]) * psa : psa, sh = affine ? (second ? a.a_shift[c1] : a.a_shift[c0]) * psa : 0.f;
         const float floor_ = affine ? 0.f : -INFINITY;
-        unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
         const int row = (tid + LIN_NTH * i) >> 4;
         float x[4];
 #pragma unroll
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_fwd(LinFwdArgs a) {
 #if !(defined(LF_X) && (LF_X & 8))
         __syncthreads();                     // stage blk is complete; stage blk + 1 (= blk - 3) is free
 #endif
-        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        const unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
         // four quarters (k-step h, row half): the A fragments of the NEXT quarter are read while this one multiplies -- two waves per SIMD do not
         // cover the LDS latency of 8 reads in front of every 24 MFMAs (measured: 11.0 -> see the header)
         auto load_af = [&](int h, int half, lu32x4 (&af)[2][4]) {
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_fwd_roles(LinFwdArgs a) {
             const int c0 = (2 * blk) / kpc, c1 = (2 * blk + 1) / kpc;
             const float sc = affine ? (second ? a.a_scale[c1] : a.a_scale[c0]) * psa : psa, sh = affine ? (second ? a.a_shift[c1] : a.a_shift[c0]) * psa : 0.f;
             const float floor_ = affine ? 0.f : -INFINITY;
-            unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+            unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = (st_ + 256 * i) >> 4;
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_fwd_roles(LinFwdArgs a) {
 #pragma unroll 1
     for (int blk = 0; blk < nblk; ++blk) {
         __syncthreads();
-        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        const unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
         lu32x4 fa[2][2], fb[2][2];
         load_af(st, 0, 0, fa);
         load_b(2 * blk + 1, bf[1]);
@@ -630,8 +632,10 @@ __global__ __launch_bounds__(LIN_NTH) void lin_wgrad(LinWgradArgs a) {
     const int ka = a.a_absmax ? pow2_scale_exp(*a.a_absmax, 12) : 0, kd = pow2_scale_exp(*a.d_absmax, 12);
     const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kd));
     const bool affine = a.a_scale != nullptr;
-    // staging: a thread owns rows 4 rq .. + 3 x columns 4 cq .. + 3 of a 64-row block; its columns lie in one channel (period % 4 == 0)
-    const int cq = tid & 31, rq = tid >> 5;
+    // staging: a thread owns rows 4 rq .. + 3 x columns 4 cq .. + 3 of a 64-row block; its columns lie in one channel (period % 4 == 0).  The 16
+    // lanes rq = 0 .. 15 of a column quad write the 128 bytes of one stage row: 10 LDS clocks per wave-level 8-byte store; with the column quad
+    // in the low lane bits (512-byte runs for the global loads) the stores hit two bank groups: 32 clocks (tools/ubench/b128_read.hip)
+    const int rq = tid & 15, cq = tid >> 4;
     const int ch = affine ? (k0 + 4 * cq) / a.period : 0;
     const float sc = affine ? a.a_scale[ch] * psa : psa, sh = affine ? a.a_shift[ch] * psa : 0.f, floor_ = affine ? 0.f : -INFINITY;
     f32x4 ar[2][4];
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_wgrad(LinWgradArgs a) {
     };
     auto commit_a = [&](int blk, const f32x4 (&r)[4]) {
         if (blk >= b_hi) return;
-        unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                          // column 4 cq + c: rows 4 rq .. + 3 are 4 consecutive "k" of the stage row
             float x[4];
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_wgrad(LinWgradArgs a) {
         const bool want = ((2 * blk) >> 3) & 1;                // sign of this block's steps in the planes (both steps of a block share it)
         if (want != neg) { flip(); neg = want; }
         __syncthreads();
-        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        const unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
         auto load_bf = [&](int h, int half, lu32x4 (&bfr)[2][4]) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp)
@@ -769,35 +773,40 @@ __global__ __launch_bounds__(LIN_NTH) void lin_wgrad_roles(LinWgradArgs a) {
     if (wave >= 4) {
         // ================================================================ staging role: two 4 rows x 4 columns blocks per thread and 64-row block
         const int st_ = tid - 256;
-        const int cq = st_ & 31, rq0 = st_ >> 5;             // row quads rq0 and rq0 + 8
-        const int ch = affine ? (k0 + 4 * cq) / a.period : 0;
-        const float sc = affine ? a.a_scale[ch] * psa : psa, sh = affine ? a.a_shift[ch] * psa : 0.f, floor_ = affine ? 0.f : -INFINITY;
+        const int rq = st_ & 15, cq0 = st_ >> 4;             // row quad rq; column quads cq0 and cq0 + 16 (16 lanes fill one stage row: see lin_wgrad)
+        float sc[2], sh[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = affine ? (k0 + 4 * (cq0 + 16 * u)) / a.period : 0;
+            sc[u] = affine ? a.a_scale[ch] * psa : psa; sh[u] = affine ? a.a_shift[ch] * psa : 0.f;
+        }
+        const float floor_ = affine ? 0.f : -INFINITY;
         f32x4 ar[2][8];
         auto issue_a = [&](int blk, f32x4 (&r)[8]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int m = blk * 64 + 4 * (rq0 + 8 * u) + j;
+                    const int m = blk * 64 + 4 * rq + j;
                     r[4 * u + j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (m < a.M && blk < b_hi) r[4 * u + j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + 4 * cq));
+                    if (m < a.M && blk < b_hi) r[4 * u + j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + 4 * (cq0 + 16 * u)));
                 }
         };
         auto commit_a = [&](int blk, const f32x4 (&r)[8]) {
             if (blk >= b_hi) return;
-            unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+            unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float x[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[4 * u + j][c], sc, sh), floor_), -65000.f, 65000.f);
+                    for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[4 * u + j][c], sc[u], sh[u]), floor_), -65000.f, 65000.f);
                     uint2 hi, lo;
                     split2_pair_f16(x[0], x[1], hi.x, lo.x);
                     split2_pair_f16(x[2], x[3], hi.y, lo.y);
-                    *reinterpret_cast<uint2*>(st + (0 * LIN_BM + 4 * cq + c) * LF_RS + (rq0 + 8 * u) * 8) = hi;
-                    *reinterpret_cast<uint2*>(st + (1 * LIN_BM + 4 * cq + c) * LF_RS + (rq0 + 8 * u) * 8) = lo;
+                    *reinterpret_cast<uint2*>(st + (0 * LIN_BM + 4 * (cq0 + 16 * u) + c) * LF_RS + rq * 8) = hi;
+                    *reinterpret_cast<uint2*>(st + (1 * LIN_BM + 4 * (cq0 + 16 * u) + c) * LF_RS + rq * 8) = lo;
                 }
         };
         if (b_lo < b_hi) {
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(LIN_NTH) void lin_wgrad_roles(LinWgradArgs a) {
         const bool want = ((2 * blk) >> 3) & 1;
         if (want != neg) { flip(); neg = want; }
         __syncthreads();
-        const unsigned char* st = lds + (blk & (LF_NS - 1)) * LF_STAGE;
+        const unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
         lu32x4 fa[2][2], fb[2][2];
         load_bf(st, 0, 0, fa);
         load_d(2 * blk + 1, df[1]);
