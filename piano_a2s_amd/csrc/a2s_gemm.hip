@@ -129,9 +129,11 @@ __device__ __forceinline__ void tile_store(float* __restrict__ lds, const f32x4 
     }
 }
 
-// Split path (both operands k-contiguous): registers -> LDS as three bf16 term planes [term][ROWS][32 k (+8 pad)], 80-byte rows so
+// Split path (both operands k-contiguous): registers -> LDS as three bf16 term planes [term][ROWS][32 k (+16 pad)], 96-byte rows so
 // that a lane's fragment (8 consecutive k of one row) is one ds_read_b128.  Same optional operand BatchNorm+ReLU as tile_store.
-#define GEMM_SPLIT_RS 80
+#ifndef GEMM_SPLIT_RS
+#define GEMM_SPLIT_RS 96           // (64 bytes of k + 32: an odd multiple of 32 bytes -- ds_read_b128 fragment reads at 4.0 instead of 6.7 clocks: profiles/r04_lds_patterns.txt)
+#endif
 template <int ROWS, int NLD, int TERMS = 3, int NTH = 256>
 __device__ __forceinline__ void tile_store_split(unsigned char* __restrict__ lds, const f32x4 (&reg)[NLD], const float (&aff)[NLD][2], int r0, int k0,
                                                  int rmax, int kmax, const float* __restrict__ scale, const float* __restrict__ shift, int period,
