@@ -1065,7 +1065,7 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
             else hipLaunchKernelGGL(attn_bwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
                                     dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
         } else {
-            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4 + (size_t)groups * ATT_DCS + 16) * sizeof(float), r.n_active, 1);
+            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4 + (size_t)groups * ATT_DCS + 16) * sizeof(float), r.n_active, 3);
 #define A2S_BWD_MQ(N) launch_bwd_mq<N>(st, nwg, shm, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r, nt)
             switch (groups) {
                 case 2: A2S_BWD_MQ(2); break;

@@ -1211,15 +1211,20 @@ void a2s_attn_bulk_cap_set(int on) { g_attn_bulk_cap = on ? 1 : 0; }
 int a2s_attn_bulk_cap_enabled(void) { return g_attn_bulk_cap; }
 size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward) {
     if (!g_attn_bulk_cap) return shm;
-    static long cap[2] = {-1, -1};
+    // kind: 0 forward single row, 1 backward single row, 2 forward fused bars, 3 backward fused bars (backward & 2: fused bars)
+    static long cap[4] = {-1, -1, -1, -1};
     if (cap[0] < 0) {
         const char* e = getenv("A2S_ATTN_BULK_LDS");
         const char* b = getenv("A2S_ATTN_BULK_LDS_BWD");
-        cap[1] = b ? atol(b) : (e ? atol(e) : 32768);
+        const char* m = getenv("A2S_ATTN_BULK_LDS_MQ");
+        const char* mb = getenv("A2S_ATTN_BULK_LDS_MQ_BWD");
         cap[0] = e ? atol(e) : 65536;
-        for (int i = 0; i < 2; ++i) cap[i] = cap[i] < 0 ? 0 : (cap[i] > 65536 ? 65536 : cap[i]);
+        cap[1] = b ? atol(b) : (e ? atol(e) : 32768);
+        cap[2] = m ? atol(m) : cap[0];
+        cap[3] = mb ? atol(mb) : cap[1];
+        for (int i = 0; i < 4; ++i) cap[i] = cap[i] < 0 ? 0 : (cap[i] > 65536 ? 65536 : cap[i]);
     }
-    const size_t c = (size_t)cap[backward ? 1 : 0];
+    const size_t c = (size_t)cap[backward & 3];
     return (n_active >= 64 && c > shm) ? c : shm;
 }
 template <int NQ>
@@ -1265,7 +1270,7 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
             if (nt) hipLaunchKernelGGL(attn_fwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
             else hipLaunchKernelGGL(attn_fwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
         } else {
-            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + 16 + (size_t)groups * 128 * 4) * sizeof(float), r.n_active, 0);
+            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + 16 + (size_t)groups * 128 * 4) * sizeof(float), r.n_active, 2);
             switch (groups) {
                 case 2: launch_fwd_mq<2>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;
                 case 3: launch_fwd_mq<3>(st, nwg, shm, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r, ft, nt); break;
