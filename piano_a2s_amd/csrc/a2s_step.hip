@@ -269,14 +269,18 @@ __global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
     // ---- last vocabulary workgroup of this row block: the epilogue
     __syncthreads();
     if (tid == 0) {
+#ifndef DEC_X_NOFENCE          /* timing ablation (results may be wrong): what the two device-scope fences of this kernel cost */
         __threadfence();                                           // this workgroup's logits tile is visible device-wide before its ticket
+#endif
         const int ticket = atomicAdd(a.tickets + blockIdx.x, 1);
         last_flag = (ticket == NVW - 1);
         if (last_flag) a.tickets[blockIdx.x] = 0;                  // ready for the next launch
     }
     __syncthreads();
     if (!last_flag) return;
+#ifndef DEC_X_NOFENCE
     __threadfence();
+#endif
     for (int rr = wave; rr < 16; rr += NW) {
         const int row = row0 + rr;
         if (row < R) dec_row_epilogue(a, row, t, lane);
