@@ -105,7 +105,17 @@ void a2s_gemm_debug_tile(int cfg);
  * operands are k- or row-contiguous (default 1); "wgrad_bf16x3" 0/1/2 -- the split-operand weight-gradient convolution: 1 (default) where it is
  * faster than conv3x3_wgrad (40 -> 40 channels), 2 every eligible launch */
 int a2s_debug_set(const char* key, int value);
-int a2s_debug_get(const char* key);   /* current value of "conv_bf16x3" / "gemm_bf16x3" / "wgrad_bf16x3" / "gru_fused"; -1 for an unknown key */
+int a2s_debug_get(const char* key);   /* current value of "conv_bf16x3" / "gemm_bf16x3" / "wgrad_bf16x3" / "gru_fused"; -1 for an unknown key;
+                                        * also "device_cus" / "device_xccs": compute units and XCDs the runtime reports for the current device */
+/* Persistent kernels (encoder recurrences, few-clip note decoder: one launch whose workgroups wait for each other, replacing the per-step
+ * launches of nn.GRU / NoteDecoder.decode_notes, models.py:63-67,388-419).  Their waits are bounded; a launch that gives up poisons its outputs
+ * with NaN (the loss becomes non-finite, the update is skipped) and ORs a bit into *device_word (a 4-byte device word the caller owns, zeroed by
+ * the caller; NULL unregisters).  The host reads the word at a synchronisation point it has anyway and switches the persistent paths off
+ * (a2s_debug_set("gru_persist" / "dec_persist", 0)) for the rest of the process.  The paths are only taken when the runtime reports a chip
+ * they fit (compute units x workgroups per CU >= the launch; 8 XCDs x 32 CUs for the decoder).
+ * Test hooks: a2s_debug_set("persist_force_agent", 1) = never use the one-XCD plain-store hand-off, "persist_inject_abort", 1 = every
+ * persistent launch behaves as if a wait had timed out. */
+int a2s_persist_abort_latch(void* device_word);
 
 /* ---- ConvStack (models.py:475-502,:523-534).  Activations are (B, T, C, F); see csrc/a2s_conv.hip.
  * conv3x3: y = conv(relu(x*in_scale+in_shift)) (scale/shift NULL: plain x), zero padding 1, no bias;

@@ -56,6 +56,7 @@ void a2s_gru_step_fused_set(int);
 void a2s_gru_persist_set(int);
 int a2s_gru_persist_enabled(void);
 void a2s_dec_persist_set(int);
+int a2s_dec_persist_launches(void);
 int a2s_dec_persist_enabled(void);
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
 size_t a2s_note_decoder_bwd_persist_ws_bytes(int n_clips);
@@ -210,6 +211,8 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_persist")) { a2s_dec_persist_set(value); return A2S_OK; }
+    if (!strcmp(key, "persist_force_agent")) { a2s_persist_dbg_set(PERSIST_DBG_FORCE_AGENT, value); return A2S_OK; }
+    if (!strcmp(key, "persist_inject_abort")) { a2s_persist_dbg_set(PERSIST_DBG_INJECT_ABORT, value); return A2S_OK; }
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_rows")) { a2s_conv_rows_set(value); return A2S_OK; }
@@ -223,6 +226,8 @@ int a2s_debug_set(const char* key, int value) {
     snprintf(a2s_err_msg, sizeof(a2s_err_msg), "a2s_debug_set: unknown key %s", key);
     return A2S_ERR_ARG;
 }
+
+int a2s_persist_abort_latch(void* device_word) { a2s_persist_latch_set(device_word); return A2S_OK; }
 
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_bulk_cap")) return a2s_attn_bulk_cap_enabled();
@@ -238,6 +243,11 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
     if (key && !strcmp(key, "gru_persist")) return a2s_gru_persist_enabled();
     if (key && !strcmp(key, "dec_persist")) return a2s_dec_persist_enabled();
+    if (key && !strcmp(key, "dec_persist_launches")) return a2s_dec_persist_launches();
+    if (key && !strcmp(key, "persist_force_agent")) return a2s_persist_dbg_get(PERSIST_DBG_FORCE_AGENT);
+    if (key && !strcmp(key, "persist_inject_abort")) return a2s_persist_dbg_get(PERSIST_DBG_INJECT_ABORT);
+    if (key && !strcmp(key, "device_cus")) return a2s_device_geometry().cus;
+    if (key && !strcmp(key, "device_xccs")) return a2s_device_geometry().xccs;
     if (key && !strcmp(key, "dec_fused")) return a2s_dec_fused_enabled();
     if (key && !strcmp(key, "attn_fused_combine")) return a2s_attn_fused_combine_enabled();
     if (key && !strcmp(key, "attn_nt")) return a2s_attn_nt_enabled();

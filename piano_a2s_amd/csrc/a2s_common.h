@@ -44,6 +44,17 @@ extern long long a2s_launch_counter;
 
 static inline int a2s_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- persistent kernels (csrc/a2s_persist.hip, csrc/a2s_dec_persist.hip): what the device offers, the process-wide abort latch, test hooks
+struct a2s_device_geom { int cus, xccs; };             // compute units and XCDs visible to this process (current device; cached)
+a2s_device_geom a2s_device_geometry(void);
+unsigned* a2s_persist_latch_ptr(void);                  // device word the kernels OR a bit into when a bounded wait gave up (null: none registered)
+void a2s_persist_latch_set(void* dev_word);
+#define PERSIST_DBG_FORCE_AGENT 1u                      // a2s_debug_set("persist_force_agent", 1): never take the plain-store (one-XCD) hand-off
+#define PERSIST_DBG_INJECT_ABORT 2u                     // a2s_debug_set("persist_inject_abort", 1): every persistent launch behaves as if a wait had timed out
+unsigned a2s_persist_dbg(void);
+void a2s_persist_dbg_set(unsigned bit, int on);
+int a2s_persist_dbg_get(unsigned bit);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Split of the T frames of a clip over G workgroups for the attention kernels (forward and backward must agree):

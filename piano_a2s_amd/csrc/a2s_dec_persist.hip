@@ -167,6 +167,7 @@ struct DecPersistFwd {
     u64* xg;                                            // granule workspace (zeroed): C regions of DP_REGION granules
     unsigned* abort_flag; unsigned* xcc;                // zeroed; xcc: C x 32 words
     int C, NR, R, T, steps, eos_id;
+    unsigned* latch; unsigned dbg;                      // process-wide abort latch (or null); PERSIST_DBG_* bits
 };
 // granule region of one clip (offsets in granules)
 #define G_Q 0                                   // [2][MAXR][HH]
@@ -211,9 +212,10 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
             if (lane == 0) red[0] = (float)ok;
         }
         __syncthreads();
-        same_xcd = red[0] != 0.f;
+        same_xcd = red[0] != 0.f && !(a.dbg & PERSIST_DBG_FORCE_AGENT);
         __syncthreads();
         if (tid == 0 && same_xcd) atomicAdd(a.abort_flag + 1, 1u);
+        if ((a.dbg & PERSIST_DBG_INJECT_ABORT) && L == 0 && tid == 0) dp_raise(a.abort_flag, 99u);      // test hook: as if a wait had timed out
     }
     Spin spin{a.abort_flag, 16u + (unsigned)w, 0u, false};
     // ---- resident operands
@@ -588,8 +590,13 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_fwd(DecPersistFwd a) {
         }
     }
 #undef ON
-    if (spin.dead || dp_aborted(a.abort_flag)) {        // poison: the caller's loss becomes non-finite, the update is skipped, nothing hangs
+    if (spin.dead || dp_aborted(a.abort_flag)) {
+        // Poison what the caller READS: the first log-probability row of every row of this clip (the loss gathers its target there -- a bar
+        // has at least one real target --, so the loss becomes non-finite and the update is skipped; greedy decoding: the host reads the
+        // abort word with the step count and raises), and the state after the last step.  Nothing hangs.
+        for (int i = tid; i < NR * VV; i += NTH) a.probs[(long)((i / VV) * C + c) * a.probs_bstride + (i % VV)] = __builtin_nanf("");
         if (tid < NR) a.h[((long)a.steps * R + (long)tid * C + c) * H2 + 16 * w] = __builtin_nanf("");
+        if (tid == 0 && a.latch) atomicOr(a.latch, 4u);
     }
 }
 
@@ -620,6 +627,7 @@ struct DecPersistBwd {
     const int* row_until;
     u64* xg; unsigned* abort_flag; unsigned* xcc;
     int C, NR, R, T, steps;
+    unsigned* latch; unsigned dbg;
 };
 #define B_DG 0                                  // [MAXR][6 * H2]   dgi | dgh rows
 #define B_DC (B_DG + MAXR * 6 * H2)             // [MAXR][H2]       dctx rows
@@ -660,9 +668,10 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_bwd(DecPersistBwd a) {
             if (lane == 0) red[0] = (float)ok;
         }
         __syncthreads();
-        same_xcd = red[0] != 0.f;
+        same_xcd = red[0] != 0.f && !(a.dbg & PERSIST_DBG_FORCE_AGENT);
         __syncthreads();
         if (tid0 == 0 && same_xcd) atomicAdd(a.abort_flag + 1, 1u);
+        if ((a.dbg & PERSIST_DBG_INJECT_ABORT) && L == 0 && tid0 == 0) dp_raise(a.abort_flag, 99u);
     }
     Spin spin{a.abort_flag, 64u + (unsigned)w, 0u, false};
     const int t0 = w * CHF, nf = max(0, min(T, t0 + CHF) - t0);
@@ -897,6 +906,7 @@ __global__ __launch_bounds__(NTH, 2) void dec_persist_bwd(DecPersistBwd a) {
             const int j = lk * 4 + r;
             if (j < NR) a.dh[(long)(j * C + c) * H2 + 16 * w + li] = bad ? __builtin_nanf("") : dhc[r];
         }
+        if (bad && lane == 0 && a.latch) atomicOr(a.latch, 8u);
     }
 }
 
@@ -924,6 +934,8 @@ __global__ __launch_bounds__(256) void dec_persist_greedy_fixup(float* __restric
 }
 
 // ------------------------------------------------------------------------------------------- launcher
+static int g_dec_persist_launches = 0;                  // persistent forward + backward launches so far (a2s_debug_get("dec_persist_launches"): tests)
+int a2s_dec_persist_launches(void) { return g_dec_persist_launches; }
 static int g_dec_persist = -1;                          // A2S_DEC_PERSIST=0 / a2s_debug_set("dec_persist", 0): the launch-per-step kernels
 void a2s_dec_persist_set(int v) { g_dec_persist = v ? 1 : 0; }
 int a2s_dec_persist_enabled(void) {
@@ -937,9 +949,26 @@ size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps) {
            + sizeof(int) * (size_t)R + 256;
 }
 static bool aligned16p(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// One clip per XCD, its NWG workgroups one per CU, all 8 x NWG resident at once: needs a whole MI355X (8 XCDs x 32 CUs visible to this process --
+// a CPX / DPX partition or a CU mask reports fewer) and a CU that admits the kernel's LDS request.  Asked of the runtime once per kernel.
+static size_t dpb_lds_bytes(void);
+static bool dp_chip_ok(bool bwd) {
+    static int occ[2] = {-1, -1};
+    if (occ[bwd] < 0) {
+        int n = 0;
+        hipError_t e = bwd ? hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dpb_lds_bytes())
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds_bytes());
+        if (e == hipSuccess) e = bwd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dec_persist_bwd, NTH, dpb_lds_bytes())
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dec_persist_fwd, NTH, dp_lds_bytes());
+        if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        occ[bwd] = n;
+    }
+    const a2s_device_geom g = a2s_device_geometry();
+    return occ[bwd] >= 1 && g.xccs == 8 && g.cus >= 8 * NWG;
+}
 
 bool a2s_note_decoder_fwd_persist_ok(const a2s_note_dec_args& a) {
-    if (!a2s_dec_persist_enabled() || !a.persist_ws || a.use_graph) return false;
+    if (!a2s_dec_persist_enabled() || !a.persist_ws || a.use_graph || !dp_chip_ok(false)) return false;
     if (!a.gt && (a.gates || a.attw || a.drop || a.n_active)) return false;      // greedy: inference only
     const int C = a.n_clips > 0 ? a.n_clips : a.R;
     if (C < 1 || C > 8 || a.R % C || a.R / C > MAXR) return false;
@@ -981,6 +1010,7 @@ int a2s_note_decoder_fwd_persist(hipStream_t st, const a2s_note_dec_args& a, int
     p.xg = reinterpret_cast<u64*>(base + 512 + sizeof(unsigned) * 8 * NWG);
     p.abort_flag = reinterpret_cast<unsigned*>(base); p.xcc = reinterpret_cast<unsigned*>(base + 512);
     p.C = C; p.NR = a.R / C; p.R = a.R; p.T = a.T; p.steps = a.steps; p.eos_id = a.eos_id;
+    p.latch = a2s_persist_latch_ptr(); p.dbg = a2s_persist_dbg();
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds_bytes());
@@ -989,6 +1019,7 @@ int a2s_note_decoder_fwd_persist(hipStream_t st, const a2s_note_dec_args& a, int
     }
     hipLaunchKernelGGL(dec_persist_fwd, dim3(8 * NWG), dim3(NTH), dp_lds_bytes(), st, p);
     A2S_CHECK_LAUNCH("dec_persist_fwd");
+    __atomic_fetch_add(&g_dec_persist_launches, 1, __ATOMIC_RELAXED);
     if (a.attw) {
         hipLaunchKernelGGL(dec_persist_attw_normalise, dim3((unsigned)(n * R)), dim3(256), 0, st, a.attw, p.stats, p.row_until, a.steps, a.R, a.T);
         A2S_CHECK_LAUNCH("dec_persist_attw_normalise");
@@ -1014,7 +1045,7 @@ size_t a2s_note_decoder_bwd_persist_ws_bytes(int n_clips) {
     return 512 + sizeof(unsigned) * 8 * NWG + sizeof(u64) * (size_t)n_clips * DPB_REGION;
 }
 bool a2s_note_decoder_bwd_persist_ok(const a2s_note_dec_bwd_args& a) {
-    if (!a2s_dec_persist_enabled() || !a.persist_ws) return false;
+    if (!a2s_dec_persist_enabled() || !a.persist_ws || !dp_chip_ok(true)) return false;
     const int C = a.n_clips > 0 ? a.n_clips : a.R;
     if (C < 1 || C > 8 || a.R % C || a.R / C > MAXR) return false;
     if (a.H != HH || a.E != EE || a.T > NWG * CHF || a.steps < 1 || !a.step_ws) return false;
@@ -1049,6 +1080,7 @@ int a2s_note_decoder_bwd_persist(hipStream_t st, const a2s_note_dec_bwd_args& a)
     p.abort_flag = reinterpret_cast<unsigned*>(base); p.xcc = reinterpret_cast<unsigned*>(base + 512);
     p.xg = reinterpret_cast<u64*>(base + 512 + sizeof(unsigned) * 8 * NWG);
     p.C = C; p.NR = a.R / C; p.R = a.R; p.T = a.T; p.steps = a.steps;
+    p.latch = a2s_persist_latch_ptr(); p.dbg = a2s_persist_dbg();
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dpb_lds_bytes());
@@ -1057,6 +1089,7 @@ int a2s_note_decoder_bwd_persist(hipStream_t st, const a2s_note_dec_bwd_args& a)
     }
     hipLaunchKernelGGL(dec_persist_bwd, dim3(8 * NWG), dim3(NTH), dpb_lds_bytes(), st, p);
     A2S_CHECK_LAUNCH("dec_persist_bwd");
+    __atomic_fetch_add(&g_dec_persist_launches, 1, __ATOMIC_RELAXED);
     // token columns of dx for all steps at once: dx[:, :E] = dgi_all W_ih[:, :E]  (W_ih (3 H2, KX): B(k, n) = w_ih[k * KX + n])
     return a2s_gemm_impl(st, (int)(n * R), EE, 3 * H2, 1.f, a.dgi_all, 3 * H2, 1, a.w_ih, KX, 1, 0.f, a.dx, KX, nullptr, 0, 1, 0, 0, 0, 0, nullptr, 0);
 }

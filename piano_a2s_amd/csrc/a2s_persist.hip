@@ -132,6 +132,7 @@ struct GruPersistFwd {
     unsigned* abort_flag;                               // zeroed before the launch
     unsigned* xcc;                                      // RB x 16 words, zeroed before the launch
     int B, T, reverse, nrb;
+    unsigned* latch; unsigned dbg;                      // process-wide abort latch (or null); PERSIST_DBG_* bits
 };
 
 template <int H>
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void gru_seq_fwd_persist(GruPersistFwd a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int j = j0 + li, R = a.B;
-    const bool same_xcd = wave == 0 && row_block_on_one_xcd(a.xcc + by * 16, bx, H / 16, lane, a.abort_flag);
+    if ((a.dbg & PERSIST_DBG_INJECT_ABORT) && blockIdx.x == 0 && tid == 0) raise_abort(a.abort_flag, 99u);      // test hook: as if a wait had timed out
+    const bool same_xcd = wave == 0 && row_block_on_one_xcd(a.xcc + by * 16, bx, H / 16, lane, a.abort_flag) && !(a.dbg & PERSIST_DBG_FORCE_AGENT);
     if (tid == 0 && same_xcd) atomicAdd(a.abort_flag + 1, 1u);          // diagnostic: workgroups that exchange through their XCD's L2
     // B fragments of this wave's k-steps: W_hh rows (g H + j0 + li), columns 16 (wave + 4 c) + 4 lk .. + 3
     f32x4 bw[3][KS];
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void gru_seq_fwd_persist(GruPersistFwd a) {
             const int row = row0 + lk * 4 + r;
             if (row < R) a.hn[(long)row * H + j] = bad ? __builtin_nanf("") : hp[r];
         }
+        if (bad && lane == 0 && a.latch) atomicOr(a.latch, 1u);
     }
 }
 
@@ -251,6 +254,7 @@ struct GruPersistBwd {
     unsigned* abort_flag;
     unsigned* xcc;                                      // RB x 16 words, zeroed before the launch
     int B, T, reverse, nrb;
+    unsigned* latch; unsigned dbg;
 };
 
 template <int H>
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void gru_seq_bwd_persist(GruPersistBwd a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int j = j0 + li, R = a.B, T = a.T;
-    const bool same_xcd = wave == 0 && row_block_on_one_xcd(a.xcc + by * 16, bx, H / 16, lane, a.abort_flag);
+    if ((a.dbg & PERSIST_DBG_INJECT_ABORT) && blockIdx.x == 0 && tid == 0) raise_abort(a.abort_flag, 99u);      // test hook: as if a wait had timed out
+    const bool same_xcd = wave == 0 && row_block_on_one_xcd(a.xcc + by * 16, bx, H / 16, lane, a.abort_flag) && !(a.dbg & PERSIST_DBG_FORCE_AGENT);
     if (tid == 0 && same_xcd) atomicAdd(a.abort_flag + 1, 1u);          // diagnostic: workgroups that exchange through their XCD's L2
     f32x4 bw[KS];
 #pragma unroll
@@ -355,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void gru_seq_bwd_persist(GruPersistBwd a) {
             const int row = row0 + lk * 4 + r;
             if (row < R) a.dgh_first[(long)row * 3 * H + j] = __builtin_nanf("");
         }
+        if (lane == 0 && a.latch) atomicOr(a.latch, 2u);
     }
 }
 
@@ -371,12 +377,51 @@ size_t a2s_gru_persist_ws_bytes(int B, int H, int bwd) {
     const size_t rb = (size_t)(B + 15) / 16;
     return 256 + ((rb * 16 * sizeof(unsigned) + 255) & ~(size_t)255) + sizeof(u64) * 2 * rb * 16 * (size_t)(bwd ? 3 * H : H);
 }
-// every workgroup of the launch must be resident (they wait for each other): one CU admits at least 2 of these (the two directions of a
-// layer run side by side), 256 CUs
-static bool persist_fits(int B, int H) { return (long)(H / 16) * ((B + 15) / 16) <= 256; }
+// ---- device geometry, abort latch, test hooks (shared with csrc/a2s_dec_persist.hip)
+// The persistent kernels are ordinary launches whose workgroups wait for each other, so every workgroup of a launch must be resident at
+// once.  What the chip offers is asked of the runtime, once per device: compute units visible to this process (a CPX / DPX partition or a CU
+// mask reports fewer than 256), XCDs, and how many workgroups of each kernel one CU admits.  A resident foreign process cannot be seen from
+// here; that case ends in a bounded-wait abort, which sets the process-wide latch, and the host then switches the persistent paths off
+// (piano_a2s_amd/hip.py check_persist_abort).
+static unsigned* g_abort_latch = nullptr;
+static unsigned g_persist_dbg = 0;
+unsigned* a2s_persist_latch_ptr(void) { return g_abort_latch; }
+void a2s_persist_latch_set(void* p) { g_abort_latch = reinterpret_cast<unsigned*>(p); }
+unsigned a2s_persist_dbg(void) { return g_persist_dbg; }
+void a2s_persist_dbg_set(unsigned bit, int on) { g_persist_dbg = on ? (g_persist_dbg | bit) : (g_persist_dbg & ~bit); }
+int a2s_persist_dbg_get(unsigned bit) { return (g_persist_dbg & bit) ? 1 : 0; }
+a2s_device_geom a2s_device_geometry(void) {
+    static a2s_device_geom cache[16];
+    static bool have[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return a2s_device_geom{0, 0};
+    if (!have[dev]) {
+        int cus = 0, xccs = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) xccs = 0;
+        (void)hipGetLastError();
+        cache[dev] = a2s_device_geom{cus, xccs};
+        have[dev] = true;
+    }
+    return cache[dev];
+}
+// every workgroup of the launch must be resident (they wait for each other) -- and so must those of the OTHER direction of the layer, which
+// runs beside it: 2 x grid <= compute units x workgroups of this kernel a CU admits (measured: 2 on gfx950, 256 CUs -> grid <= 256)
+template <typename K>
+static int persist_blocks_per_cu(K kernel) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    return n;
+}
+static bool persist_fits(int B, int H, bool bwd) {
+    static int occ[2] = {-1, -1};
+    if (occ[bwd] < 0) occ[bwd] = bwd ? persist_blocks_per_cu(gru_seq_bwd_persist<256>) : persist_blocks_per_cu(gru_seq_fwd_persist<256>);
+    const a2s_device_geom g = a2s_device_geometry();
+    return 2L * (H / 16) * ((B + 15) / 16) <= (long)g.cus * occ[bwd];
+}
 
 bool a2s_gru_seq_fwd_persist_ok(const float* w_hh, const float* gi, int B, int T, int H, float* ws, size_t ws_bytes) {
-    return a2s_gru_persist_enabled() && H == 256 && T >= 2 && persist_fits(B, H) && ws && ((uintptr_t)ws % 256 == 0) && ws_bytes >= a2s_gru_persist_ws_bytes(B, H, 0) &&
+    return a2s_gru_persist_enabled() && H == 256 && T >= 2 && persist_fits(B, H, false) && ws && ((uintptr_t)ws % 256 == 0) && ws_bytes >= a2s_gru_persist_ws_bytes(B, H, 0) &&
            ((uintptr_t)w_hh % 16 == 0) && gi;
 }
 int a2s_gru_seq_fwd_persist_impl(hipStream_t st, const float* gi_all, long gi_bstride, long gi_tstride, const float* w_hh, const float* b_hh, float* out,
@@ -389,14 +434,15 @@ int a2s_gru_seq_fwd_persist_impl(hipStream_t st, const float* gi_all, long gi_bs
     char* base = reinterpret_cast<char*>(ws);
     const size_t xcc_bytes = ((size_t)nrb * 16 * sizeof(unsigned) + 255) & ~(size_t)255;
     GruPersistFwd a{gi_all, gi_bstride, gi_tstride, w_hh, b_hh, out, out_bstride, out_tstride, save, hn,
-                    reinterpret_cast<u64*>(base + 256 + xcc_bytes), reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(base + 256), B, T, reverse, nrb};
+                    reinterpret_cast<u64*>(base + 256 + xcc_bytes), reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(base + 256), B, T, reverse, nrb,
+                    g_abort_latch, g_persist_dbg};
     hipLaunchKernelGGL(gru_seq_fwd_persist<256>, dim3((H / 16) * nrb), dim3(256), 0, st, a);
     A2S_CHECK_LAUNCH("gru_seq_fwd_persist");
     return A2S_OK;
 }
 
 bool a2s_gru_seq_bwd_persist_ok(int B, int T, int H, float* ws, size_t ws_bytes, size_t ws_used) {
-    return a2s_gru_persist_enabled() && H == 256 && T >= 2 && persist_fits(B, H) && ws && ((uintptr_t)ws % 256 == 0) && ws_used % 256 == 0 &&
+    return a2s_gru_persist_enabled() && H == 256 && T >= 2 && persist_fits(B, H, true) && ws && ((uintptr_t)ws % 256 == 0) && ws_used % 256 == 0 &&
            ws_bytes >= ws_used + a2s_gru_persist_ws_bytes(B, H, 1);
 }
 // ws_off: bytes at the start of the workspace the caller keeps (W_hh^T)
@@ -411,7 +457,8 @@ int a2s_gru_seq_bwd_persist_impl(hipStream_t st, const float* dout, long do_bstr
     const int nrb = a2s_cdiv(B, 16);
     const size_t xcc_bytes = ((size_t)nrb * 16 * sizeof(unsigned) + 255) & ~(size_t)255;
     GruPersistBwd a{dout, do_bstride, do_tstride, out, out_bstride, out_tstride, gates, w_hh_t, dhn, dgi_all, dgh_shift, dgh_first,
-                    reinterpret_cast<u64*>(base + 256 + xcc_bytes), reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(base + 256), B, T, reverse, nrb};
+                    reinterpret_cast<u64*>(base + 256 + xcc_bytes), reinterpret_cast<unsigned*>(base), reinterpret_cast<unsigned*>(base + 256), B, T, reverse, nrb,
+                    g_abort_latch, g_persist_dbg};
     hipLaunchKernelGGL(gru_seq_bwd_persist<256>, dim3((H / 16) * nrb), dim3(256), 0, st, a);
     A2S_CHECK_LAUNCH("gru_seq_bwd_persist");
     return A2S_OK;

@@ -522,6 +522,8 @@ class Engine:
         # steps the reference would have executed: known from the plan with ground truth; read back from the device
         # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
         executed = n if gt_bar is not None else int(steps_exec.item())
+        if gt_bar is None and a.persist_ws:
+            hip.check_persist_abort(dev, raise_error=True)       # (the host has just synchronised: a persistent launch that gave up returns unusable ids)
         saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
                      gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active, flags_dev=flags_dev,
                      step_ws=step_ws, persist_ws=persist_ws)
@@ -551,6 +553,8 @@ class Engine:
             ts_gt, key_gt, up_gt, up_len_gt, lo_gt, lo_len_gt = [g.contiguous() for g in ground_truth]
             # ONE host sync per forward, before anything is enqueued
             gt_cpu = tuple(gt_host) if gt_host is not None else (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())
+        # did a persistent launch of the PREVIOUS pass give up a wait?  (its loss was non-finite, the update skipped; from now on launch per step)
+        hip.check_persist_abort(dev)
 
         # ConvStack + encoder are enqueued first: the host-side planning of the decoder below runs while they execute.  Its small
         # host->device uploads go through pinned memory without synchronising (a pageable upload would drain the stream each time).

@@ -66,6 +66,49 @@ def lib():
     return _lib
 
 
+_ABORT_LATCH = {}
+PERSIST_ABORTS = 0          # persistent launches of this process that gave up a bounded wait (observed through the latch)
+
+
+def abort_latch(device):
+    """The device word the persistent kernels OR a bit into when one of their bounded waits gives up (a2s_persist_abort_latch): allocated
+    and registered on first use; one process drives one GPU, so the library keeps one pointer."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    t = _ABORT_LATCH.get(idx)
+    if t is None:
+        t = _ABORT_LATCH[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        _ABORT_LATCH["registered"] = None
+    if _ABORT_LATCH.get("registered") != idx:
+        check(lib().a2s_persist_abort_latch(C.c_void_p(t.data_ptr())), "a2s_persist_abort_latch")
+        _ABORT_LATCH["registered"] = idx
+    return t
+
+
+def check_persist_abort(device, raise_error=False):
+    """Call where the host has just synchronised with the device anyway (a 4-byte read).  If a persistent launch gave up since the last call:
+    its outputs were poisoned (NaN loss -> the update was skipped) -- switch the persistent paths off for the rest of the process (the chip is
+    evidently shared or partitioned in a way the residency check cannot see) and warn, or raise (greedy decoding: the ids are unusable)."""
+    global PERSIST_ABORTS
+    t = abort_latch(device)
+    bits = int(t.item())
+    if not bits:
+        return 0
+    t.zero_()
+    PERSIST_ABORTS += 1
+    L = lib()
+    L.a2s_debug_set(b"gru_persist", 0)
+    L.a2s_debug_set(b"dec_persist", 0)
+    os.environ["A2S_DEC_PERSIST"] = "0"
+    os.environ["A2S_GRU_PERSIST"] = "0"
+    msg = (f"a persistent kernel gave up a bounded wait (latch bits {bits:#x}: 1/2 encoder fwd/bwd, 4/8 note decoder fwd/bwd); its outputs were "
+           "poisoned with NaN and the persistent paths are switched off for the rest of this process (launch-per-step kernels from now on)")
+    if raise_error:
+        raise A2SError(msg)
+    import warnings
+    warnings.warn(msg, RuntimeWarning)
+    return bits
+
+
 def _p(t):
     """device pointer of a tensor (None -> NULL); tensors must be CUDA(HIP) and of the dtype the C side expects."""
     if t is None:

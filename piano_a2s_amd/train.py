@@ -220,14 +220,16 @@ class TrainStep:
     """model: models.ScoreTranscription on a GPU.  One call = one optimizer step on one minibatch."""
 
     def __init__(self, model, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=True, sync_bn=None, skip_finished_rows=None,
-                 fuse_bars=None, clip_groups=None):
+                 fuse_bars=None, clip_groups=None, group_plan=None):
         """skip_finished_rows (default on; A2S_SKIP_FINISHED=0 turns it off): the note decoders skip the attention of rows whose
         remaining targets are all <pad>.  fuse_bars (default on with the former; A2S_FUSE_BARS=0 turns it off): consecutive bars
         whose bar-level input is teacher-forced are decoded in one call (Engine.forward).  Loss, gradients and the update are
         unchanged (skipped rows are ignore_index positions and nothing else reads them); only `last_outputs` positions whose target
         is <pad> differ from the reference's values.  clip_groups (default on with fuse_bars; A2S_CLIP_GROUPS=0 turns it off): the
         clips holding exceptionally long bars decode as a group of their own, concurrently with the ordinary ones (plan_clip_groups;
-        Engine.forward) -- the minibatch is permuted for that, which no loss term, gradient or statistic depends on."""
+        Engine.forward) -- the minibatch is permuted for that, which no loss term, gradient or statistic depends on.  group_plan: keyword
+        overrides of plan_clip_groups' cost model (e.g. dict(step_cost=4.0) makes a 12-clip minibatch split the way a 256-clip one does with
+        the default 150: tests/test_gpu_g4.py); A2S_GROUP_STEP_COST sets step_cost from the environment."""
         self.model = model
         # The host side of a step is a few hundred small CPU tensor operations (the decode plan).  Above ~32 k elements torch runs each of them
         # as an OpenMP region over every core of the box (256 here): one descheduled worker stalls the region, and the thread waiting for it
@@ -244,6 +246,11 @@ class TrainStep:
         # each clip group's decoder backward follows its forward at once (see __call__); A2S_PIPELINE_GROUPS=0: forward of every group,
         # then the objective, then backward of every group
         self.pipeline_groups = _os.environ.get("A2S_PIPELINE_GROUPS", "1") != "0"
+        self.group_plan = dict(group_plan or {})
+        if "step_cost" not in self.group_plan and _os.environ.get("A2S_GROUP_STEP_COST"):
+            self.group_plan["step_cost"] = float(_os.environ["A2S_GROUP_STEP_COST"])
+        self.keep_grads = False            # tests: keep the last step's gradient views (name -> tensor) in self.last_grads
+        self.last_grads = None
         self._last = None
         self.flat = model.flatten_()
         self.opt = FusedAdadelta(self.flat, lr, rho, eps, max_grad_norm, layout=model.flat_layout())
@@ -274,7 +281,8 @@ class TrainStep:
             gt_host = [up_t.cpu(), lo_t.cpu(), up_len.cpu(), lo_len.cpu()]       # the one host sync of the step (Engine.forward reuses it)
             idx_u = torch.arange(1, up_t.shape[-1] + 1)
             idx_l = torch.arange(1, lo_t.shape[-1] + 1)
-            order, n_main = plan_clip_groups(((gt_host[0] != PAD).long() * idx_u).amax(-1).numpy(), ((gt_host[1] != PAD).long() * idx_l).amax(-1).numpy())
+            order, n_main = plan_clip_groups(((gt_host[0] != PAD).long() * idx_u).amax(-1).numpy(), ((gt_host[1] != PAD).long() * idx_l).amax(-1).numpy(),
+                                             **self.group_plan)
             B = up_t.shape[0]
             if n_main < B:
                 perm = torch.from_numpy(order)
@@ -355,6 +363,7 @@ class TrainStep:
         # non-finite gradients reach every rank through the all-reduce and gate via the norm.
         gate = G["__loss_gate__"] if exchange.active else self.total
         self.opt.step(flat_g, gate, zero_grad=False)
+        self.last_grads = {k: v for k, v in G.items() if isinstance(k, str) and not k.startswith("__")} if self.keep_grads else None
         # the engine, its group hook (a closure over the backward context) and the backward context (which holds the engine) form a reference
         # cycle: left to the cyclic collector, ~3.3 GiB of per-step gradient buffers stayed allocated for several steps and the caching
         # allocator answered with a fresh 11 GiB segment every third step -- a hipMalloc of 340 ms under load, with every other host thread

@@ -104,7 +104,7 @@ def test_small_train_forward_and_buffers(g1, dev, name):
             assert err <= 1e-5, f"BN buffer {k}: {err:.3e}"
 
 
-def test_full_size_greedy_ids_exact(golden_dir, dev):
+def test_full_size_greedy_ids_exact(golden_dir, dev, decoder_path):
     """16.36 M-parameter model, 1201 frames, 5 bars x (398 + 189) steps: reference ids must be reproduced exactly.
     Fair only because the fixture has no near-tie (asserted); on a mismatch the margin at the first differing
     decision is reported so a tie flip can be told from a real defect."""
@@ -118,8 +118,10 @@ def test_full_size_greedy_ids_exact(golden_dir, dev):
     kw["upper_range"], kw["lower_range"] = tuple(kw["upper_range"]), tuple(kw["lower_range"])
     batch = synthetic.make_batch(2, cfg, meta["batch_seed"], **kw)
     S = {k: v.to(dev) for k, v in st.items()}
-    ts, key, up, lo = engine.Engine(cfg).forward(S, batch[0].to(dev), inference=True)
+    eng = engine.Engine(cfg)
+    ts, key, up, lo = eng.forward(S, batch[0].to(dev), inference=True)
     torch.cuda.synchronize()
+    decoder_path(eng)
     for nm, t in (("up", up), ("lo", lo)):
         ids = t.argmax(-1).cpu().numpy()
         ref = data[f"greedy.{nm}_ids"]

@@ -81,11 +81,14 @@ def _compare_ids(name, case, data, up, lo, free_running):
 
 
 @pytest.mark.parametrize("name", ["s2041_greedy", "s2057_greedy", "b4_greedy"])
-def test_g3_greedy(g3, golden_dir, dev, name):
+def test_g3_greedy(g3, golden_dir, dev, name, decoder_path):
     from piano_a2s_amd import engine
     case, data, cfg, batch, S = _setup(g3, golden_dir, name, dev)
-    ts, key, up, lo = engine.Engine(cfg).forward(S, batch[0].to(dev), inference=True)
+    eng = engine.Engine(cfg)
+    ts, key, up, lo = eng.forward(S, batch[0].to(dev), inference=True)
     torch.cuda.synchronize()
+    decoder_path(eng)
+    name = f"{name}[{decoder_path.name}]"
     diverged = _compare_ids(name, case, data, up, lo, free_running=True)
     if not diverged:
         for nm, t in (("up", up), ("lo", lo)):
@@ -99,7 +102,7 @@ def test_g3_greedy(g3, golden_dir, dev, name):
 
 
 @pytest.mark.parametrize("name", ["tail_tf1", "tf06"])
-def test_g3_train_mode(g3, golden_dir, dev, name):
+def test_g3_train_mode(g3, golden_dir, dev, name, decoder_path):
     """Train mode (batch-statistics BatchNorm, dropout neutralised as in the fixture): draw count, executed steps, ids, log-probabilities,
     the four loss terms + total within 1e-4 relative, all gradient norms.  tail_tf1 holds a 398-step upper bar and a 189-step lower bar
     without <eos> -- the rows the benchmark's 1 % tail consists of."""
@@ -117,12 +120,15 @@ def test_g3_train_mode(g3, golden_dir, dev, name):
     gt = [b.to(dev) for b in batch[1:7]]
     outs = eng.forward(S, batch[0].to(dev), inference=False, ground_truth=gt, teacher_forcing_ratio=case["tf"], training=True, dropout=False, rng=Counting())
     torch.cuda.synchronize()
+    decoder_path(eng)
     assert draws["n"] == case["draws"], f"python-random draws {draws['n']} vs reference {case['draws']}"
     up, lo = outs[2], outs[3]
     for nm, t in (("up", up), ("lo", lo)):
         rows = (t.abs().sum(-1) > 0).sum(-1).cpu().numpy()
         assert np.array_equal(rows, data[f"{nm}_rows"]), f"{nm} executed steps {rows.tolist()} vs {data[f'{nm}_rows'].tolist()}"
-    if name == "tail_tf1":
+    full_length_case = name == "tail_tf1"
+    name = f"{name}[{decoder_path.name}]"
+    if full_length_case:
         assert int(data["up_rows"].max()) == cfg["max_length"][0] and int(data["lo_rows"].max()) == cfg["max_length"][1], "fixture: full-length bars"
     diverged = _compare_ids(name, case, data, up, lo, free_running=case["tf"] < 1.0)
     if diverged:
