@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 MFMA_BF16_PEAK_TFS = 2500.0    # dense bf16 MFMA peak (same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense")
 MFMA_F32_PEAK_TFS = 157.3      # dense fp32-input MFMA peak (same guide: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD)
 TF_RATIO = 0.7                 # hparams/pretrain.yaml teacher_forcing_ratio at epoch 0
+N_MINIBATCHES = 8              # distinct synthetic minibatches the timed steps cycle over
 # Teacher-forcing coin stream across data-parallel ranks: "rank_offset" = random.seed(1234 + rank) (the reference's
 # processes draw independently), "shared" = every rank seeds Python's random alike.  dp_straggler_simulation measures
 # both: the spread between ranks comes from the data, not from the coins (0.90 either way), so the reference's behaviour stays.
@@ -172,6 +173,81 @@ def step_roofline(B, T, F, H, clip_steps, ms_per_step):
             "attention_clip_steps_per_step": int(clip_steps), "ms_per_step": ms_per_step,
             "what": "algorithmic HBM bytes of one optimizer step / the timed step / HBM peak (the profile is flat: no single kernel is more than 5 % of the step)"}
 
+
+
+def phase_roofline(step, batches, B, T, F, H, n_steps=6):
+    """Every phase of the optimizer step against its roofs, FROM THIS RUN: HIP events on the step's main stream at the phase boundaries (the main
+    stream joins every side stream where a phase ends), averaged over n_steps steps on the bench's own minibatches and coins.  Algorithmic
+    work per phase: ConvStack in units u = T x F x 4 bytes per clip -- forward 241 u (input + every activation written
+    once and read once), backward 440 u (every activation read once more, every activation gradient written and read once, the layer inputs
+    of the weight gradients); convolution + Linear flops 41.07 GFLOP per clip forward, twice that backward, against the two-term matrix
+    roof (2.5 PFLOP/s fp16 dense / 3 products); encoder 30 MB per clip each way, 4.72 + 0.94 GFLOP forward (recurrences + key images);
+    decoder = the window from the first decoder launch to the start of the encoder backward (forward AND pipelined backward of all clip
+    groups): 2 x (clip, step) pairs x T x 3H x 4 bytes."""
+    from piano_a2s_amd import engine, engine_bwd
+    marks = []
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((name, e))
+    saved = []
+
+    def wrap(obj, attr, name):
+        orig = getattr(obj, attr)
+        saved.append((obj, attr, orig))
+
+        def f(*args, **kw):
+            mark("before " + name)
+            r = orig(*args, **kw)
+            mark(name)
+            return r
+        setattr(obj, attr, f)
+    wrap(engine.Engine, "convstack", "convstack_fwd")
+    wrap(engine.Engine, "encoder", "encoder_fwd")
+    wrap(engine_bwd, "_encoder_bwd", "encoder_bwd")
+    wrap(engine_bwd, "_convstack_bwd", "convstack_bwd")
+    tot, clip_steps, walls = {}, [], []
+    try:
+        for k in range(n_steps + 1):
+            marks.clear()
+            mark("start")
+            step(batches[k % len(batches)], TF_RATIO)
+            mark("end")
+            torch.cuda.synchronize()
+            if k == 0:
+                continue
+            clip_steps.append(getattr(step, "attn_clip_steps", 0))
+            walls.append(marks[0][1].elapsed_time(marks[-1][1]))
+            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                name = {"before encoder_bwd": "decoder", "end": "clip_adadelta", "before convstack_fwd": "host_plan_gap"}.get(n1, n1)
+                if name.startswith("before "):
+                    name = "gaps"
+                tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+    finally:
+        for obj, attr, orig in saved:
+            setattr(obj, attr, orig)
+    ms = {k: v / n_steps for k, v in tot.items()}
+    u = T * F * 4.0
+    cs = sum(clip_steps) / max(len(clip_steps), 1)
+    flop_fwd = B * 41.07e9
+    work = {"convstack_fwd": (B * 241.0 * u, flop_fwd), "convstack_bwd": (B * 440.0 * u, 2 * flop_fwd),
+            "encoder_fwd": (B * 30e6, B * 5.66e9), "encoder_bwd": (B * 30e6, B * 2 * 5.66e9), "decoder": (2.0 * cs * T * 3 * H * 4.0, None)}
+    peak_tf = MFMA_BF16_PEAK_TFS / 3
+    out = {"steps": n_steps, "ms_per_step": round(sum(walls) / len(walls), 2), "attention_clip_steps_per_step": int(cs),
+           "peak_GBs": HBM_PEAK_GBS, "peak_TFLOPs_two_term": round(peak_tf, 1),
+           "what": "per phase: measured ms (HIP events on the main stream, this run), algorithmic bytes and flops (DESIGN.md section 6), fractions of the "
+                   "HBM roof and of the two-term matrix roof; the decoder phase holds the forward and the pipelined backward of all clip groups"}
+    for name, (nbytes, flops) in work.items():
+        t = ms.get(name)
+        if not t:
+            continue
+        ph = {"ms": round(t, 2), "algorithmic_GB": round(nbytes / 1e9, 1), "GBs": round(nbytes / t / 1e6, 1), "frac_hbm": round(nbytes / t / 1e6 / HBM_PEAK_GBS, 4)}
+        if flops:
+            ph.update({"algorithmic_TFLOP": round(flops / 1e12, 2), "TFLOPs": round(flops / t / 1e9, 1), "frac_mfma": round(flops / t / 1e9 / peak_tf, 4)})
+        out[name] = ph
+    out["other_ms"] = {k: round(v, 2) for k, v in ms.items() if k not in work}
+    return out
 
 def linear_roofline(B, T, F, Cf=256, iters=5):
     """The three products of the 19200 -> 256 Linear (reference models.py:504,537-539) at the step's shapes, as the step issues them (two
@@ -382,8 +458,8 @@ def cpu_baseline(full_tail):
             for line in reversed(r.stdout.strip().splitlines()):
                 if line.startswith("{"):
                     out = json.loads(line)
-                    if notes:
-                        out["sample"] += "; fell back after: " + "; ".join(notes)
+                    if notes:                      # first, so that a truncated line still says it
+                        out["sample"] = "FELL BACK after: " + "; ".join(notes) + " -- " + out["sample"]
                     return out
             notes.append(f"B={clips}/{threads} threads produced no result ({r.stderr[-120:]!r})")
         except subprocess.TimeoutExpired:
@@ -417,8 +493,8 @@ def _cpu_baseline_child(cfg, n_clips, seed, threads, full_tail):
         times.append(time.time() - t0)
     dt = sum(times[1:])
     return {"value": round(2 * n_clips / dt, 5), "unit": "clips/s", "cores": threads, "kind": "port", "cpu": _cpu_model(), "host_threads": os.cpu_count(),
-            "sample": f"2 timed training steps after 1 warm-up (fwd+loss+bwd+clip+Adadelta) of the oracle on {n_clips} synthetic 12 s clips per step, fp32, "
-                      f"full-length tail {full_tail}, {threads} threads: {times[1]:.1f} + {times[2]:.1f} s (warm-up {times[0]:.1f} s)"}
+            "sample": f"{threads} of {os.cpu_count()} host threads, {n_clips} clips per step: 2 timed training steps after 1 warm-up (fwd+loss+bwd+clip+Adadelta) of the "
+                      f"oracle on synthetic 12 s clips, fp32, full-length tail {full_tail}: {times[1]:.1f} + {times[2]:.1f} s (warm-up {times[0]:.1f} s)"}
 
 
 def loss_parity(dev):
@@ -455,7 +531,7 @@ def loss_parity(dev):
                       "TrainStep; total + 4 loss terms vs the reference's CPU values (tests/golden/g2_full.npz, g2_full_tf07.npz)"}
 
 
-def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=10, steps_shared=3):
+def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=20, steps_shared=3):
     """Data-parallel straggler term WITHOUT an 8-GPU box: every rank of an N-rank job meets the others at the gradient
     all-reduce, so a job step lasts as long as its slowest rank's.  A rank's step time is a function of its minibatch (target lengths) and
     of the teacher-forcing coins it draws (how bars fuse, reference models.py:289,404) -- not of the weights -- so the 8 ranks' step
@@ -469,7 +545,7 @@ def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=10, steps_
         rng = random.Random(coin_seed)
         ms = []
         for k in range(steps + 1):
-            b = synthetic.make_batch(B, cfg, 1234 + 1000 * rank + (k % 2), full_tail=full_tail)
+            b = synthetic.make_batch(B, cfg, 1234 + 1000 * rank + (k % N_MINIBATCHES), full_tail=full_tail)
             b = [t.to(dev) if torch.is_tensor(t) else t for t in b]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -488,7 +564,11 @@ def straggler_simulation(step, cfg, B, dev, full_tail, ranks=8, steps=10, steps_
 
     offset = [run(r, 1234 + r) for r in range(ranks)]
     shared = [offset[0][:steps_shared]] + [run(r, 1234, steps_shared) for r in range(1, ranks)]
+    flat = [t for r in offset for t in r]
+    slowest = [max(r[k] for r in offset) for k in range(steps)]
     out = {"ranks": ranks, "steps_per_rank": steps, "steps_per_rank_shared_coins": steps_shared,
+           "step_ms_min_mean_max": [round(min(flat), 1), round(sum(flat) / len(flat), 1), round(max(flat), 1)],
+           "slowest_rank_step_ms_min_mean_max": [round(min(slowest), 1), round(sum(slowest) / len(slowest), 1), round(max(slowest), 1)],
            "rank_offset_coins": {"predicted_dp_efficiency": round(efficiency(offset), 4), "step_ms_by_rank": [[round(t, 1) for t in r] for r in offset]},
            "shared_coins": {"predicted_dp_efficiency": round(efficiency(shared), 4), "step_ms_by_rank": [[round(t, 1) for t in r] for r in shared]},
            "what": "8 ranks' step sequences run one after another on this GPU; efficiency = mean step time / mean over steps of the slowest "
@@ -576,7 +656,7 @@ def main():
 
     def make_batches(full_tail):
         out = []
-        for i in range(min(2, args.steps + args.warmup)):      # a couple of distinct minibatches, resident in HBM before timing
+        for i in range(min(N_MINIBATCHES, args.steps + args.warmup)):      # distinct minibatches (0.6 GB each), resident in HBM before timing
             b = synthetic.make_batch(B, cfg, 1234 + 1000 * rank + i, full_tail=full_tail)
             out.append([t.to(dev) if torch.is_tensor(t) else t for t in b])
         return out
@@ -621,6 +701,7 @@ def main():
     clip_steps_per_step = sum(timed.clip_steps) / max(len(timed.clip_steps), 1)
     main_step_ms = list(timed.step_ms)
     main_new_segments = list(timed.new_segments)
+    phases = phase_roofline(step, batches, B, 1201, cfg["freq_bins"], cfg["hidden_size"]) if (rank == 0 and world == 1 and not args.no_secondary) else None
     loss = float(step.total)
     groups = step._last[2] if step._last else None
     # data-parallel straggler terms: decode steps each rank executed per optimizer step, and how long each rank's stream
@@ -653,7 +734,8 @@ def main():
                "config": {"workload": "pretrain.yaml model (16.36M params), 12 s clips = 1201x480 frames, 5 bars, max 398/189 tokens; "
                                       "random-init weights; tf_ratio 0.7; dropout on; fwd+loss+bwd+clip+Adadelta",
                           "per_gpu_batch": B, "global_batch": B * world, "upper_len": "U{20..120}", "lower_len": "U{10..80}",
-                          "full_length_tail": args.full_tail, "parallelism": f"dp{world}", "batchnorm": "per-rank statistics",
+                          "full_length_tail": args.full_tail, "distinct_minibatches": min(N_MINIBATCHES, args.steps + args.warmup),
+                          "parallelism": f"dp{world}", "batchnorm": "per-rank statistics",
                           "coin_policy": COIN_POLICY, "kernel_launches_per_step": launches_per_step,
                           "decoder": "rows whose remaining targets are all <pad> skipped; teacher-forced bars decoded in one call; clips "
                                      "holding full-length bars decoded as a concurrent clip group (loss, gradients and update identical "
@@ -680,6 +762,8 @@ def main():
         torch.cuda.empty_cache()
         out["roofline"] = conv_roofline(B, 1201, cfg["freq_bins"])
         out["roofline_step"] = step_roofline(B, 1201, cfg["freq_bins"], cfg["hidden_size"], clip_steps_per_step, out["ms_per_step"])
+        if phases is not None:
+            out["roofline_phases"] = phases
         out["roofline_linear"] = linear_roofline(B, 1201, cfg["freq_bins"])
         out["roofline_attention"] = attention_roofline(step, None, B, 1201, cfg["hidden_size"])
         if not args.no_secondary and not use_dist:

@@ -234,10 +234,10 @@ class TrainStep:
         # The host side of a step is a few hundred small CPU tensor operations (the decode plan).  Above ~32 k elements torch runs each of them
         # as an OpenMP region over every core of the box (256 here): one descheduled worker stalls the region, and the thread waiting for it
         # holds the interpreter lock -- measured as 70-90 ms freezes of ALL issuing threads in one step out of ten (tools/host_stalls.py).
-        # One intra-op thread is plenty for this work.  A2S_HOST_THREADS overrides (0: leave torch's setting alone).
-        nthreads = int(_os.environ.get("A2S_HOST_THREADS", "1"))
-        if nthreads > 0 and torch.get_num_threads() != nthreads:
-            torch.set_num_threads(nthreads)
+        # One intra-op thread is plenty for this work.  A2S_HOST_THREADS overrides (0: leave torch's setting alone).  The setting is process-wide
+        # in torch, so it is applied for the duration of a step only and the caller's value is restored afterwards (__call__): CPU work the
+        # user does between steps (a CPU front end, metrics) keeps its threads.
+        self.host_threads = int(_os.environ.get("A2S_HOST_THREADS", "1"))
         self.sync_bn = (_os.environ.get("A2S_SYNC_BN") == "1") if sync_bn is None else bool(sync_bn)
         self.skip_finished_rows = (_os.environ.get("A2S_SKIP_FINISHED", "1") != "0") if skip_finished_rows is None else bool(skip_finished_rows)
         self.fuse_bars = (_os.environ.get("A2S_FUSE_BARS", "1") != "0") if fuse_bars is None else bool(fuse_bars)
@@ -270,6 +270,17 @@ class TrainStep:
 
     def __call__(self, batch, teacher_forcing_ratio, rng=_py_random):
         """batch: the reference's 9-tuple (device tensors).  Returns the (4,2) device tensor of loss terms (col 0)."""
+        prev = torch.get_num_threads()
+        scoped = self.host_threads > 0 and prev != self.host_threads
+        if scoped:
+            torch.set_num_threads(self.host_threads)
+        try:
+            return self._step(batch, teacher_forcing_ratio, rng)
+        finally:
+            if scoped:
+                torch.set_num_threads(prev)
+
+    def _step(self, batch, teacher_forcing_ratio, rng):
         spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = batch[:7]
         eng = engine.Engine(self.model.cfg, sync_bn=self.sync_bn)
         eng.skip_finished_rows = self.skip_finished_rows

@@ -22,6 +22,18 @@ def test_two_ranks_equal_one_process_on_the_whole_minibatch():
     assert "ranks identical: max |p0 - p1| = 0.000e+00" in r.stdout, r.stdout[-1000:]
 
 
+@pytest.mark.timeout(330)
+def test_two_ranks_with_per_rank_batchnorm_equal_averaged_gradients():
+    """The DEFAULT data-parallel setting (per-rank BatchNorm statistics) through the whole fused step on two ranks: identical parameters on both
+    ranks, equal to one process averaging the two halves' gradients before the fused clip + Adadelta (DDP's all-reduce-mean)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_check.py"), "--local-bn"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ranks identical: max |p0 - p1| = 0.000e+00" in r.stdout and "per-rank BatchNorm" in r.stdout, r.stdout[-1000:]
+
+
 def test_bench_launches_its_own_rank_through_torchrun():
     """`python bench.py --launcher` (the N = 1 form of what `--gpus N` does without a launcher environment): torch.distributed.run child,
     RCCL world of one, rank 0's JSON line relayed."""

@@ -127,7 +127,7 @@ def test_decoder_abort_skips_the_update_then_falls_back(dev, hooks):
     dbatch = [t.to(dev) if torch.is_tensor(t) else t for t in batch]
     torch.manual_seed(3)
     m = models.ScoreTranscription(**cfg).to(dev).train()
-    step = train.TrainStep(m, dropout=False)
+    step = train.TrainStep(m, dropout=False, clip_groups=False)       # (one clip group: the 4 clips decode on the persistent path)
     before = step.flat.clone()
     hooks(b"gru_persist", 0)                       # (the encoder's own abort would poison the step as well: this test is about the decoder's)
     hooks(b"persist_inject_abort", 1)
