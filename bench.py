@@ -583,11 +583,14 @@ def inference_block(cfg, dev, batches=(256, 8)):
     L = hip.lib()
     S = {k: v.to(dev) for k, v in spec.procedural_state(cfg, 2032, eos_bias=2.5, lively="token").items()}
     out = {"weights": "procedural (seed 2032, <eos> bias 2.5)",
-           "mode": "eval, greedy; B > 8: launch-per-step kernels, device-side <eos> bookkeeping polled every 16 steps; B <= 8: ONE persistent launch per "
-                   "(bar, staff) call (csrc/a2s_dec_persist.hip), the end of the decode decided on the device"}
-    for B in batches:
+           "mode": "eval, greedy; B > 8: 4-5 launches per decode step (attention sweep + combine, fused GRU step, fused projection / log-softmax / argmax / "
+                   "embedding / next query), device-side <eos> bookkeeping polled every 16 steps; B <= 8: ONE persistent launch per (bar, staff) call "
+                   "(csrc/a2s_dec_persist.hip), the end of the decode decided on the device; `hipgraph_replay`: the captured-chunk variant "
+                   "BASELINE.json configs[4] names (A2S_GREEDY_GRAPH=1), measured beside it -- slower, hence opt-in"}
+    for B, graph in [(b, False) for b in batches] + [(max(batches), True)]:
         x = synthetic.make_batch(B, cfg, 77, spectrogram="ridges", full_tail=0.0)[0].to(dev)
         eng = engine.Engine(cfg)
+        eng.greedy_graph = graph
         best = None
         for _ in range(3):
             torch.cuda.synchronize()
@@ -602,7 +605,7 @@ def inference_block(cfg, dev, batches=(256, 8)):
         steps = sum(b["staff"][k][2]["steps"] for b in eng.saved["bars"] for k in ("up", "lo"))
         launched = sum(b["staff"][k][2]["launched"] for b in eng.saved["bars"] for k in ("up", "lo"))
         tokens = int((up.abs().sum(-1) > 0).sum() + (lo.abs().sum(-1) > 0).sum())
-        out[f"B{B}"] = {"seconds": round(best, 4), "clips_per_s": round(B / best, 2), "tokens_per_s": round(tokens / best),
+        out[f"B{B}" + ("_hipgraph_replay" if graph else "")] = {"seconds": round(best, 4), "clips_per_s": round(B / best, 2), "tokens_per_s": round(tokens / best),
                          "executed_decode_steps": steps, "launched_decode_steps": launched,
                          "kernel_launches_per_decode_step": (round((n1 - n0) / max(launched, 1), 2) if n0 is not None else None)}
         del eng, x

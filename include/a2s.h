@@ -345,6 +345,13 @@ int a2s_bn_bwd_stats(void* stream, const float* g, const float* x, const float* 
 int a2s_bn_bwd_apply(void* stream, const float* g, const float* x, const float* mean, const float* invstd, const float* scale,
                      const float* shift, const uint8_t* keep_mask, float inv_keep, const float* sums_local, const float* sums_global,
                      double count_global, float* dgamma, float* dbeta, float* dx, float* c12, long rows, int C, int F);
+/* ... and for statistics the producer of g already reduced into per-block partials (a2s_conv3x3_dgrad_bnstats*, a2s_linear_dgrad_bnstats):
+ * (1) partial[nblocks][C][2] -> this rank's sums[2C]; [host: all-reduce]; (2) dgamma / dbeta += LOCAL sums, c12 = GLOBAL sums / global element
+ * count -- no pass over (g, x); the input gradient is formed by the fused consumer (a2s_conv3x3_wgrad_bn_ranged).  With these the synchronised
+ * BatchNorm of torch.nn.SyncBatchNorm (what SpeechBrain's DDP wrapping gives reference pretrain.py:257) keeps every fused path of the per-rank one. */
+int a2s_bn_bwd_sums_from_partial(void* stream, const float* partial, int nblocks, int C, float* sums);
+int a2s_bn_bwd_c12_from_sums(void* stream, const float* sums_local, const float* sums_global, double count_global, float* dgamma, float* dbeta,
+                             float* c12, int C);
 /* conv weight gradient dW += dy (*) relu(x*in_scale+in_shift)  (deterministic two-stage reduction) */
 int a2s_conv3x3_wgrad(void* stream, const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dW,
                       float* workspace, size_t workspace_bytes, int B, int T, int F, int Cin, int Cout);
@@ -396,6 +403,13 @@ int a2s_clip_adadelta(void* stream, float* params, float* grads, float* square_a
  * (run with a2s_gemm_f32, A row stride = hop) -> out (B, rows, bins) = dB relative to the clip maximum, floor 1e-5, top_db, /80 + 1.
  * partial: B*64 floats of scratch. */
 int a2s_vqt_logmag(void* stream, const float* C, float* out, float* partial, int B, long rows, int bins, float top_db);
+/* the same over a response laid out octave by octave: C (B, rows, n_oct * 2 * bins_per_octave), octave o (HIGHEST first) = [re | im] of its
+ * bins_per_octave bins -- what one framed GEMM per octave against the (n_fft, 2 * bins_per_octave) bank writes */
+int a2s_vqt_logmag_octaves(void* stream, const float* C, float* out, float* partial, int B, long rows, int bins, int bins_per_octave, float top_db);
+/* decimation by 2 between the octaves of librosa.vqt's recursion (librosa.resample(y, orig_sr=2, target_sr=1, scale=True); the filter is this
+ * build's stand-in for libsoxr, see piano_a2s_amd/vqt.py): out[b][m] = sum_j ypad[b][2 m + j] taps[j], ntaps even; ypad (B, padded_len) with
+ * padded_len >= 2 n_out + ntaps (reads beyond are taken as zero), out (B, n_out). */
+int a2s_vqt_decimate(void* stream, const float* ypad, long padded_len, const float* taps, int ntaps, float* out, long n_out, int B);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,10 @@ void a2s_gru_step_fused_set(int);
 void a2s_gru_persist_set(int);
 int a2s_gru_persist_enabled(void);
 void a2s_dec_persist_set(int);
+void a2s_attn_pace_set(int);
+int a2s_attn_pace_enabled(void);
+void a2s_attn_pace_min_set(int);
+int a2s_attn_pace_min(void);
 int a2s_dec_persist_launches(void);
 int a2s_dec_persist_enabled(void);
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
@@ -104,11 +108,15 @@ int a2s_nll_loss_impl(hipStream_t, const float*, const long long*, long, int, lo
 int a2s_clip_adadelta_impl(hipStream_t, float*, float*, float*, float*, long, const float*, float, float, float, float, float*, double*, int, int);
 
 int a2s_vqt_logmag_impl(hipStream_t, const float*, float*, float*, int, long, int, float);
+int a2s_vqt_logmag_octaves_impl(hipStream_t, const float*, float*, float*, int, long, int, int, float);
+int a2s_vqt_decimate_impl(hipStream_t, const float*, long, const float*, int, float*, long, int);
 
 int a2s_bn_bwd_stats_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
                           float*, float*, long, int, int);
 int a2s_bn_bwd_apply_impl(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, float,
                           const float*, const float*, double, float*, float*, float*, float*, long, int, int);
+int a2s_bn_bwd_sums_from_partial_impl(hipStream_t, const float*, int, int, float*);
+int a2s_bn_bwd_c12_from_sums_impl(hipStream_t, const float*, const float*, double, float*, float*, float*, int);
 
 int a2s_linear_dgrad_bnstats_impl(hipStream_t st, int M, int N, int K, const float* A, long lda, const float* Wt, long sBk, long sBn, float* C, long ldc,
                                   const float* ep_y, const float* mean, const float* invstd, const float* scale, const float* shift, int period,
@@ -207,6 +215,8 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_fused_combine")) { a2s_attn_fused_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_nt")) { a2s_attn_nt_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_bulk_cap")) { a2s_attn_bulk_cap_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_pace")) { a2s_attn_pace_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_pace_min")) { a2s_attn_pace_min_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
@@ -231,6 +241,8 @@ int a2s_persist_abort_latch(void* device_word) { a2s_persist_latch_set(device_wo
 
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_bulk_cap")) return a2s_attn_bulk_cap_enabled();
+    if (key && !strcmp(key, "attn_pace")) return a2s_attn_pace_enabled();
+    if (key && !strcmp(key, "attn_pace_min")) return a2s_attn_pace_min();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
     if (key && !strcmp(key, "wgrad_rows")) return a2s_wgrad_rows_enabled();
@@ -472,6 +484,19 @@ int a2s_bn_bwd_apply(void* stream, const float* g, const float* x, const float* 
                      float* dgamma, float* dbeta, float* dx, float* c12, long rows, int C, int F) {
     return a2s_bn_bwd_apply_impl(ST, g, x, mean, invstd, scale, shift, keep_mask, inv_keep, sums_local, sums_global, count_global, dgamma, dbeta,
                                  dx, c12, rows, C, F);
+}
+int a2s_vqt_logmag_octaves(void* stream, const float* C, float* out, float* partial, int B, long rows, int bins, int bins_per_octave, float top_db) {
+    return a2s_vqt_logmag_octaves_impl(ST, C, out, partial, B, rows, bins, bins_per_octave, top_db);
+}
+int a2s_vqt_decimate(void* stream, const float* ypad, long padded_len, const float* taps, int ntaps, float* out, long n_out, int B) {
+    return a2s_vqt_decimate_impl(ST, ypad, padded_len, taps, ntaps, out, n_out, B);
+}
+int a2s_bn_bwd_sums_from_partial(void* stream, const float* partial, int nblocks, int C, float* sums) {
+    return a2s_bn_bwd_sums_from_partial_impl(ST, partial, nblocks, C, sums);
+}
+int a2s_bn_bwd_c12_from_sums(void* stream, const float* sums_local, const float* sums_global, double count_global, float* dgamma, float* dbeta,
+                             float* c12, int C) {
+    return a2s_bn_bwd_c12_from_sums_impl(ST, sums_local, sums_global, count_global, dgamma, dbeta, c12, C);
 }
 
 }  // extern "C"

@@ -291,7 +291,7 @@ int a2s_ew_act_bwd_impl(hipStream_t st, const float* g, const float* y, float* d
 // Reverse of a2s_note_decoder_fwd for one (bar, staff); `steps` = steps the forward executed.
 // argument block: a2s_note_dec_bwd_args (single definition in include/a2s.h)
 
-bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats);
+bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats, bool greedy = false);
 int a2s_note_step_fused_bwd_prepare(hipStream_t st, const a2s_note_dec_bwd_args& a);
 int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const float* dh_in, float* dh_out, const a2s_attn_rows* rows,
                             int nrows, const int* rowmap);
@@ -1001,7 +1001,8 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
 __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int G,
                                                            const int* __restrict__ clip_rank, const int* __restrict__ row_until,
                                                            int n_clips, int groups, int n_active, int step, float* __restrict__ ds_out,
-                                                           int T, float* __restrict__ dctx_out, long lddo) {
+                                                           int T, float* __restrict__ dctx_out, long lddo, unsigned* __restrict__ pace_token) {
+    if (pace_token && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(pace_token, 0u);       // bandwidth token of the sweep in front (a2s_seq.hip)
     const int b = blockIdx.x, j = threadIdx.x;
     const int clip = b % n_clips, grp = b / n_clips;
     const int slot = clip_rank ? clip_rank[clip] : clip;
@@ -1024,6 +1025,7 @@ __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restri
 }
 
 size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward);
+unsigned* a2s_attn_pace_gate_impl(hipStream_t st, int n_active);
 template <int NQ>
 static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                           const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
@@ -1055,6 +1057,7 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     // streaming loads as in a2s_attn_step_fwd_split_impl -- single-row launches only: measured +12 % on attn_bwd_split256, -0 .. 5 % on the
     // fused-rows kernels, whose enc pass feeds the matrix cores (profiles/r04_attn_mq_bench.txt)
     const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled() && groups == 1;
+    unsigned* pace_token = r.n_active > 0 ? a2s_attn_pace_gate_impl(st, r.n_active) : nullptr;
     if (r.n_active > 0) {
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G;
@@ -1078,7 +1081,7 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
         A2S_CHECK_LAUNCH("attn_bwd_split256");
     }
     hipLaunchKernelGGL(attn_bwd_combine256, dim3(B), dim3(256), 0, st, ws, dq, lddq, G, r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step,
-                       ds_out, T, dctx_out, lddo);
+                       ds_out, T, dctx_out, lddo, pace_token);
     A2S_CHECK_LAUNCH("attn_bwd_combine256");
     return A2S_OK;
 }

@@ -2093,6 +2093,23 @@ int a2s_bn_bwd_apply_impl(hipStream_t st, const float* g, const float* x, const 
     return A2S_OK;
 }
 
+// The two halves again for statistics that were already reduced into per-block partials by the kernel that produced g (the data-gradient
+// convolutions' and the Linear data gradient's epilogues): (1) partials -> this rank's sums; [host: all-reduce]; (2) dgamma / dbeta += local sums,
+// c12 from the global sums -- no pass over (g, x) at all, the input gradient is then formed by the fused consumer (a2s_conv3x3_wgrad_bn_ranged).
+int a2s_bn_bwd_sums_from_partial_impl(hipStream_t st, const float* partial, int nblocks, int C, float* sums) {
+    A2S_REQUIRE(partial && sums && nblocks > 0 && C > 0, "bn_bwd_sums_from_partial: null tensor");
+    hipLaunchKernelGGL(bn_bwd_finalize_sums, dim3(C), dim3(256), 0, st, partial, nblocks, C, sums);
+    A2S_CHECK_LAUNCH("bn_bwd_finalize_sums");
+    return A2S_OK;
+}
+int a2s_bn_bwd_c12_from_sums_impl(hipStream_t st, const float* sums_local, const float* sums_global, double count_global, float* dgamma, float* dbeta,
+                                  float* c12, int C) {
+    A2S_REQUIRE(sums_local && sums_global && dgamma && dbeta && c12 && count_global > 0, "bn_bwd_c12_from_sums: null tensor");
+    hipLaunchKernelGGL(bn_bwd_c12_from_sums, dim3(a2s_cdiv(C, 256)), dim3(256), 0, st, sums_local, sums_global, count_global, dgamma, dbeta, c12, C);
+    A2S_CHECK_LAUNCH("bn_bwd_c12_from_sums");
+    return A2S_OK;
+}
+
 size_t a2s_bn_bwd_partial_floats_impl(long rows, int C, int F) {
     const long nblocks = F > 1 ? rows : (rows + 63) / 64;
     return (size_t)nblocks * C * 2;

@@ -502,7 +502,7 @@ int a2s_embed_rows_impl(hipStream_t st, const float* table, const long long* ids
 // no-op once n_done == R, and the host polls n_done every `poll` steps to stop launching.
 typedef a2s_note_dec_args NoteDecArgs;   // one definition only: the public C struct (include/a2s.h)
 
-bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats);
+bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats, bool greedy = false);
 int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last,
                             int nrows, const int* rowmap);
 // rows the fused step of step t would cover: all R, or (training, finished rows skipped) the rows still running, a prefix of row_list
@@ -510,7 +510,7 @@ static int note_step_rows(const NoteDecArgs& a, int t) { return (a.row_list && a
 static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
     const void* ptrs[] = {a.x, a.h, a.o, a.q, a.w_ih, a.w_hh, a.out_w, a.attn_w};
     const int n = note_step_rows(a, t);
-    return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, a.V, ptrs, 8, a.step_ws, a.step_ws_floats);
+    return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, a.V, ptrs, 8, a.step_ws, a.step_ws_floats, a.gt == nullptr && !a.gates);
 }
 // q of slot `sv` from the state in slot `si` (the fused path computes every later query in the previous step's last launch)
 static int enqueue_query(hipStream_t st, const NoteDecArgs& a, int si, int sv) {
@@ -1149,13 +1149,65 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------- the bandwidth token of the bulk attention launches
+// Round 5.  The two staves of a clip group run their step loops on two streams.  A decode step is  A  (the attention sweep: HBM-bound, ~150 us
+// over 248 clips) followed by  S  (the step's small dependent kernels: ~130-200 us).  Left alone the two streams fall INTO phase -- two
+// sweeps that overlap share the bandwidth, so they end together, then both streams sit in S with the memory idle: the period is A_up + A_lo + S
+// (profiles/r04_trace_overlap.txt: 280 us of overlapping sweeps + 110-200 us of S on both queues at once).  With the sweeps mutually exclusive
+// the streams fall OUT of phase by themselves -- one sweeps at full bandwidth while the other is in S -- and the period is max(A_up + A_lo, A + S).
+// Exclusion is done on the device, so that it follows the GPU's progress and not the order in which the host threads happen to issue: a
+// one-wave gate kernel in front of a heavy sweep spins (bounded) until it has swapped the token word 0 -> 1; the sweep's combine kernel, which
+// follows it on the stream, puts 0 back before it does anything else.  Light launches (< `min_clips` active clips: the few-row tails, the
+// long-clip group) neither take nor wait for the token.
+// MEASURED (profiles/r05_attn_pace_ab.txt, B = 256, 6 pairs of steps with the same coins): no gain -- 444.2 -> 448.5 ms with the 1 % tail,
+// 444.3 -> 450.9 without.  The small kernels of S run 2-3x slower while a sweep saturates the memory (as the long-clip chain's do: DESIGN.md
+// section 3.4), so S under the other stream's sweep costs what the overlap saves; the in-phase convoy, where both streams' S phases run on an
+// idle memory system, is as good an equilibrium.  OFF by default; A2S_ATTN_PACE=1 / a2s_debug_set("attn_pace", 1) switches it on.
+__device__ unsigned g_pace_token = 0;
+__global__ void attn_pace_gate(unsigned* token, unsigned limit) {
+    if (threadIdx.x == 0) {
+        unsigned n = 0;
+        while (atomicCAS(token, 0u, 1u) != 0u && ++n < limit) __builtin_amdgcn_s_sleep(24);       // ~0.7 us per poll; limit: a few ms, then go anyway
+    }
+}
+__global__ void attn_pace_release(unsigned* token) { if (threadIdx.x == 0) atomicExch(token, 0u); }
+static int g_attn_pace = -1, g_attn_pace_min = -1;
+void a2s_attn_pace_set(int v) { g_attn_pace = v ? 1 : 0; }
+int a2s_attn_pace_enabled(void) {
+    if (g_attn_pace < 0) { const char* e = getenv("A2S_ATTN_PACE"); g_attn_pace = (e && e[0] == '1') ? 1 : 0; }
+    return g_attn_pace;
+}
+void a2s_attn_pace_min_set(int v) { g_attn_pace_min = v > 0 ? v : 1; }
+int a2s_attn_pace_min(void) {
+    if (g_attn_pace_min < 0) { const char* e = getenv("A2S_ATTN_PACE_MIN"); g_attn_pace_min = e ? atoi(e) : 64; if (g_attn_pace_min < 1) g_attn_pace_min = 1; }
+    return g_attn_pace_min;
+}
+// Gate in front of a sweep over n_active clips.  Returns the token's device address when the launch holds the token afterwards (the caller
+// hands it to its combine kernel, or calls a2s_attn_pace_release_impl), else null.
+unsigned* a2s_attn_pace_gate_impl(hipStream_t st, int n_active) {
+    if (!a2s_attn_pace_enabled() || n_active < a2s_attn_pace_min()) return nullptr;
+    static unsigned* token = nullptr;
+    if (!token) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pace_token)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        token = reinterpret_cast<unsigned*>(p);
+    }
+    hipLaunchKernelGGL(attn_pace_gate, dim3(1), dim3(64), 0, st, token, 6000u);
+    return token;
+}
+void a2s_attn_pace_release_impl(hipStream_t st, unsigned* token) {
+    if (token) hipLaunchKernelGGL(attn_pace_release, dim3(1), dim3(64), 0, st, token);
+}
+
 // merge the G partials of a row: ctx = sum_g ctx_g e^{m_g-m} / l ; optional normalisation of the saved weights.  One workgroup per
 // row (= group * n_clips + clip); rows that are skipped this step get zeros.
 __global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restrict__ partial, float* __restrict__ ctx, long ldctx,
                                                            float* __restrict__ ctx2, long ldctx2, float* __restrict__ attw, int T, int G,
                                                            const int* __restrict__ n_done, int n_rows_total,
                                                            const int* __restrict__ clip_rank, const int* __restrict__ row_until,
-                                                           int n_clips, int groups, int n_active, int step) {
+                                                           int n_clips, int groups, int n_active, int step, unsigned* __restrict__ pace_token) {
+    if (pace_token && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(pace_token, 0u);       // the sweep in front of this launch is over: next sweep, please
     if (n_done && *n_done >= n_rows_total) return;
     constexpr int H = 256;
     const int b = blockIdx.x;
@@ -1261,6 +1313,7 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     // streaming (non-temporal) K / enc loads when many clips are active: the sweep is far larger than any cache, and the lines of a
     // concurrently decoding few-clip group (its K / enc and its weights) then survive in L2 / Infinity Cache (A2S_ATTN_NT)
     const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled();
+    unsigned* pace_token = r.n_active > 0 ? a2s_attn_pace_gate_impl(st, r.n_active) : nullptr;       // (greedy decoding: the combine releases it even when the step is a no-op)
     if (r.n_active > 0 || n_zero > 0) {
         // the grid covers the clips that still have unfinished rows, re-split so that it still fills the chip
         if (r.n_active > 0) a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
@@ -1280,9 +1333,9 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
         }
         A2S_CHECK_LAUNCH("attn_fwd_split256");
     }
-    if (fused) return A2S_OK;
+    if (fused) { a2s_attn_pace_release_impl(st, pace_token); return A2S_OK; }
     hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, part, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total,
-                       r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step);
+                       r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step, pace_token);
     A2S_CHECK_LAUNCH("attn_fwd_combine256");
     return A2S_OK;
 }

@@ -397,8 +397,18 @@ size_t a2s_note_step_workspace_floats_impl(int H, int E) {
     return (size_t)(FUSED_HEAD + kx * 3 * H2 + H2 * 3 * H2 + H2 * H);
 }
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats) {
-    if (!a2s_dec_fused_enabled() || R > a2s_dec_fused_max_rows() || R > FUSED_MAX_ROWS_CAP || !ws || ws_floats < a2s_note_step_workspace_floats_impl(H, E)) return false;
+// greedy: the call is a greedy decode (no ground truth, no backward).  There the 4-launch step wins at every batch size the workspace admits
+// (B = 256: 497 -> 536 clips/s, B = 64: 313 -> 317, profiles/r05_infer_variants.txt) -- one stream decodes a staff, nothing runs beside it that
+// the weight re-reads of the 16-row tiles could disturb -- so the row limit of the training path (A2S_DEC_FUSED_MAX_ROWS) does not apply;
+// A2S_DEC_FUSED_GREEDY_ALL=0 restores it.
+static int dec_fused_greedy_all(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("A2S_DEC_FUSED_GREEDY_ALL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats, bool greedy) {
+    const int max_rows = (greedy && dec_fused_greedy_all()) ? FUSED_MAX_ROWS_CAP : a2s_dec_fused_max_rows();
+    if (!a2s_dec_fused_enabled() || R > max_rows || R > FUSED_MAX_ROWS_CAP || !ws || ws_floats < a2s_note_step_workspace_floats_impl(H, E)) return false;
     if (H % 16 || E % 16 || (V + 15) / 16 != NTV || !aligned16(ws)) return false;
     for (int i = 0; i < nptrs; ++i) if (!aligned16(ptrs[i])) return false;
     return true;

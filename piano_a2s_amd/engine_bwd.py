@@ -595,6 +595,9 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T, wait_weight_grads=True):
 _FUSE_BN_APPLY = os.environ.get("A2S_FUSE_BN_APPLY", "0") == "1"
 _FUSE_BN_APPLY_L1 = os.environ.get("A2S_FUSE_BN_APPLY_L1", "1") != "0"
 _DGRAD_BNSTATS = os.environ.get("A2S_DGRAD_BNSTATS", "1") != "0"      # BatchNorm-backward statistics in the data-gradient conv's epilogue
+# synchronised BatchNorm keeps the fused backward paths (statistics from the producers' partials, ONE small all-reduce per layer, the input gradient
+# formed inside the weight-gradient kernel): round 5; A2S_SYNC_BN_FUSED=0 = round 4's separate statistics + apply passes
+_SYNC_FUSED = os.environ.get("A2S_SYNC_BN_FUSED", "1") != "0"
 _FUSE_BN_ROWS = os.environ.get("A2S_FUSE_BN_ROWS", "1") != "0"        # BatchNorm-backward apply inside the row-streaming weight gradient's staging
 _LINEAR_DGRAD = os.environ.get("A2S_LINEAR_DGRAD", "1") != "0"        # the Linear's data gradient on its own kernel (csrc/a2s_linear.hip)
 
@@ -627,6 +630,18 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         weight-gradient kernel (a2s_conv3x3_wgrad_bn).  partial = (tensor, nblocks): the statistics partials were already produced by
         the data-gradient convolution that wrote g (a2s_conv3x3_dgrad_bnstats): no statistics pass."""
         mean, invstd, scale, shift = bn
+        if partial is not None and eng.sync_bn and stats_only:
+            # synchronised statistics on the fused path (round 5): the producer's partials -> this rank's sums -> ONE small all-reduce ->
+            # c12 from the global sums; dgamma / dbeta from the local ones (torch.nn.SyncBatchNorm's rule).  No pass over (g, x).
+            import torch.distributed as dist
+            local = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+            hip.check(L.a2s_bn_bwd_sums_from_partial(hip.stream(), hip._p(partial[0]), partial[1], C_, hip._p(local)), "a2s_bn_bwd_sums_from_partial")
+            glob = local.clone()
+            dist.all_reduce(glob)
+            c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+            hip.check(L.a2s_bn_bwd_c12_from_sums(hip.stream(), hip._p(local), hip._p(glob), C.c_double(eng.bn_counts[name]), hip._p(G[name + ".weight"]),
+                                                 hip._p(G[name + ".bias"]), hip._p(c12), C_), "a2s_bn_bwd_c12_from_sums")
+            return c12
         if partial is not None and not eng.sync_bn:
             c12 = torch.empty(2 * C_, dtype=torch.float32, device=dev)
             hip.check(L.a2s_bn_bwd_from_partial_amax(hip.stream(), hip._p(g), hip._p(x), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift),
@@ -670,7 +685,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         bn4 = cs["bn"][3]
         if not hip.linear_wgrad(dz, y4, (bn4[2], bn4[3], F), dz_amax, cs["abound"][3], G["convstack.out.weight"]):       # round 4: csrc/a2s_linear.hip
             _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
-        if _DGRAD_BNSTATS and not eng.sync_bn and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
+        if _DGRAD_BNSTATS and (not eng.sync_bn or _SYNC_FUSED) and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             if w_amax is None:
                 w_amax = hip.absmax(Wout)
@@ -708,8 +723,8 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         fuse_here = _FUSE_BN_APPLY or (i == 1 and _FUSE_BN_APPLY_L1)
         # max |dy| of this layer's output gradient, reduced by the kernel that writes dy: the two-term fp16 data-gradient convolution
         # below scales its operand by the matching power of two (gradients would otherwise sit in fp16's subnormal range)
-        dy_amax = torch.zeros(1, dtype=torch.float32, device=dev) if (i > 1 and not eng.sync_bn) else None
-        fuse_rows = (_FUSE_BN_ROWS and not eng.sync_bn and i > 1 and g_amax is not None and g_partial is not None and in_bn is not None
+        dy_amax = torch.zeros(1, dtype=torch.float32, device=dev) if (i > 1 and (not eng.sync_bn or _SYNC_FUSED)) else None
+        fuse_rows = (_FUSE_BN_ROWS and (not eng.sync_bn or _SYNC_FUSED) and i > 1 and g_amax is not None and g_partial is not None and in_bn is not None
                      and L.a2s_conv3x3_wgrad_bn_ranged_eligible(F, ci, co))
         if fuse_rows:
             # round 4: BatchNorm backward as statistics only; dy is formed by the STAGING waves of the row-streaming weight-gradient kernel (they
@@ -723,6 +738,8 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                                                     B, T, F, ci, co, hip._p(cs["abound"][i - 2])), "a2s_conv3x3_wgrad_bn_ranged")
         elif eng.sync_bn or not fuse_here:
             dy = bn_bwd(g, y, cs["bn"][i - 1], f"convstack.bn{i}", None, rows, co, F, partial=g_partial, amax=dy_amax)
+            if eng.sync_bn and dy_amax is not None:            # (the synchronised apply pass does not reduce the range of what it writes)
+                hip.absmax(dy, dy_amax)
             hip.conv3x3_wgrad(dy, x_in.view(B, T, ci, F), in_bn[2] if in_bn else None, in_bn[3] if in_bn else None, G[f"convstack.conv{i}.weight"], ws,
                               dy_amax, cs["abound"][i - 2] if in_bn else None)
         else:
@@ -737,7 +754,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         if i > 1:
             gprev = torch.empty((B, T, ci, F), dtype=torch.float32, device=dev)
             cws = hip.conv_workspace(co, dev)
-            if _DGRAD_BNSTATS and not eng.sync_bn:
+            if _DGRAD_BNSTATS and (not eng.sync_bn or _SYNC_FUSED):
                 # the data-gradient convolution also accumulates the BatchNorm-backward statistics of the layer below in its epilogue
                 bn_l = cs["bn"][i - 2]
                 nblk = L.a2s_conv3x3_stat_blocks(B, T, F, co)
@@ -753,4 +770,4 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                                         hip._p(cws)), "a2s_conv3x3 dgrad")
                 g_partial = None
             g = gprev
-            g_amax = g_amax_next if (_DGRAD_BNSTATS and not eng.sync_bn) else None
+            g_amax = g_amax_next if (_DGRAD_BNSTATS and (not eng.sync_bn or _SYNC_FUSED)) else None

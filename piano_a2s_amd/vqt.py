@@ -115,6 +115,9 @@ class VQT:
         hb[:taps, 0] = h[::-1]                                                # y_out[m] = sum_j ypad[2m + j] h[half - j]  (h is symmetric)
         self.dec_bank = torch.from_numpy(hb).to(device)
         self.hop, self.n_bins, self.device = hop, n_bins, device
+        self.bpo = min(bins_per_octave, n_bins)
+        if any(o["hi"] - o["lo"] != self.bpo for o in self.octaves):
+            raise ValueError("VQT: the octave-by-octave response layout needs n_bins to be a multiple of bins_per_octave")
 
     def _decimate(self, y):
         B, N = y.shape
@@ -124,7 +127,8 @@ class VQT:
         yp = torch.zeros((B, plen), dtype=torch.float32, device=y.device)
         yp[:, self.half:self.half + N] = y
         out = torch.empty((B, n_out), dtype=torch.float32, device=y.device)
-        hip.gemm(yp, 2, 1, self.dec_bank, 1, 1, out, 1, n_out, 1, self.dec_taps, batch=B, bsA=plen, bsB=0, bsC=n_out)
+        hip.check(hip.lib().a2s_vqt_decimate(hip.stream(), hip._p(yp), C.c_long(plen), hip._p(self.dec_bank), self.dec_taps, hip._p(out), C.c_long(n_out), B),
+                  "a2s_vqt_decimate")
         return out
 
     def __call__(self, wave):
@@ -141,6 +145,7 @@ class VQT:
         frames = min(1 + s.shape[1] // o["hop"] for s, o in zip(sigs, self.octaves))
         nb2 = 2 * self.n_bins
         Cc = torch.empty((B, frames, nb2), dtype=torch.float32, device=wave.device)
+        col = 0
         for s, o in zip(sigs, self.octaves):
             n_fft, hop, nb = o["n_fft"], o["hop"], o["hi"] - o["lo"]
             plen = (frames - 1) * hop + n_fft
@@ -149,13 +154,12 @@ class VQT:
             plen += (-plen) % 4
             padded = torch.zeros((B, plen), dtype=torch.float32, device=wave.device)
             padded[:, n_fft // 2:n_fft // 2 + s.shape[1]] = s              # centre=True with zero padding
-            # framed complex GEMM: A(n, m) = padded[n*hop + m] (row stride = hop), B = [Re g | Im g]: real parts to column lo..hi,
-            # imaginary parts to n_bins + lo..hi of the (frames, 2*n_bins) response the epilogue reads
-            for part, col in ((0, o["lo"]), (1, self.n_bins + o["lo"])):
-                hip.gemm(padded, hop, 1, o["bank_dev"], 2 * nb, 1, Cc, nb2, frames, nb, n_fft, batch=B, bsA=plen, bsB=0, bsC=frames * nb2,
-                         b_off=part * nb, c_off=col)
+            # framed complex GEMM: A(n, m) = padded[n*hop + m] (row stride = hop), B = [Re g | Im g] (n_fft, 2 nb): ONE product per octave writes
+            # [re | im] of its bins side by side into the octave's 2 nb columns of the (frames, n_oct * 2 nb) response the epilogue reads
+            hip.gemm(padded, hop, 1, o["bank_dev"], 2 * nb, 1, Cc, nb2, frames, 2 * nb, n_fft, batch=B, bsA=plen, bsB=0, bsC=frames * nb2, c_off=col)
+            col += 2 * nb
         out = torch.empty((B, 1, frames, self.n_bins), dtype=torch.float32, device=wave.device)
         partial = torch.empty(B * 64, dtype=torch.float32, device=wave.device)
-        hip.check(hip.lib().a2s_vqt_logmag(hip.stream(), hip._p(Cc), hip._p(out), hip._p(partial), B, C.c_long(frames), self.n_bins, hip.f32(80.0)),
-                  "a2s_vqt_logmag")
+        hip.check(hip.lib().a2s_vqt_logmag_octaves(hip.stream(), hip._p(Cc), hip._p(out), hip._p(partial), B, C.c_long(frames), self.n_bins, self.bpo,
+                                                   hip.f32(80.0)), "a2s_vqt_logmag_octaves")
         return out
