@@ -86,6 +86,40 @@ __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NT], f32x4* part, int 
     }
 }
 
+
+// ---- the same products with RT 16-row tiles per workgroup (round 5): the B fragments (weights) a wave fetches serve RT x 16 rows, so a call over
+// hundreds of rows re-reads the weights R / (16 RT) times instead of R / 16 (496 rows, GRU step: 462 MB of L2 reads per launch with RT = 1 --
+// which is why the 16-row kernels lost to the tiled GEMMs above ~192 rows -- 170 MB with RT = 4).  acc[rt * NT + g].
+template <int NT, int RT, int CH>
+__device__ __forceinline__ void mfma_rows8_rt(const float* const (&arow)[RT], const float* const (&brow)[NT], int ksteps, int wave, int lk,
+                                              f32x4 (&acc)[RT * NT]) {
+    for (int u0 = wave; u0 < ksteps; u0 += NW * CH) {
+        f32x4 a[RT][CH], b[NT][CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int u = u0 + NW * c;
+            const bool ok = u < ksteps;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                a[rt][c] = ok ? *reinterpret_cast<const f32x4*>(arow[rt] + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NT; ++g)
+                b[g][c] = ok ? *reinterpret_cast<const f32x4*>(brow[g] + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (u0 + NW * c >= ksteps) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < NT; ++g)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[rt * NT + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][c][j], b[g][c][j], acc[rt * NT + g], 0, 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- forward: GRU cell
 struct DecGruArgs {
     const float* x; long ldx; int kx;                   // (R, ldx) rows [token | ctx]; kx = E + 2H
@@ -147,6 +181,73 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
             sv[j] = rg; sv[H2 + j] = zg; sv[2 * H2 + j] = ng; sv[3 * H2 + j] = ghn;
         }
     }
+}
+
+
+// dec_gru_step over RT x 16 rows per workgroup (same arithmetic, same summation order per output: k-steps round robin over the 8 waves, fixed-order tree)
+template <int RT>
+__global__ __launch_bounds__(64 * NW) void dec_gru_step_rt(DecGruArgs a) {
+    __shared__ f32x4 part[4 * 4 * RT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.n_done) {
+        const bool done = *a.n_done >= a.R;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.skip = done ? 1 : 0;
+        if (done) return;
+    }
+    const int H2 = a.H2, R = a.R;
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 16 * RT;
+    const int li = lane & 15, lk = lane >> 4;
+    const int j = j0 + li;
+    float hp[RT][4], br = 0.f, bz = 0.f, bin = 0.f, bhn = 0.f;
+    if (wave == 0) {
+        br = a.b_ih[j] + a.b_hh[j]; bz = a.b_ih[H2 + j] + a.b_hh[H2 + j]; bin = a.b_ih[2 * H2 + j]; bhn = a.b_hh[2 * H2 + j];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hp[rt][r] = a.h[(long)dec_row(a.rowmap, min(row0 + rt * 16 + lk * 4 + r, R - 1)) * H2 + j];
+    }
+    const float* ax[RT];
+    const float* ah[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int ar = dec_row(a.rowmap, min(row0 + rt * 16 + li, R - 1));
+        ax[rt] = a.x + (long)ar * a.ldx;
+        ah[rt] = a.h + (long)ar * H2;
+    }
+    const float* bi[3];
+    const float* bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { bi[g] = a.w_ih + ((long)g * H2 + j0 + li) * a.kx; bh[g] = a.w_hh + ((long)g * H2 + j0 + li) * H2; }
+    f32x4 t[RT * 3], u[RT * 3];
+#pragma unroll
+    for (int i = 0; i < RT * 3; ++i) t[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows8_rt<3, RT, 2>(ax, bi, a.kx / 16, wave, lk, t);               // gi: r, z, n
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { u[rt * 3 + 0] = t[rt * 3 + 0]; u[rt * 3 + 1] = t[rt * 3 + 1]; u[rt * 3 + 2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    mfma_rows8_rt<3, RT, 2>(ah, bh, H2 / 16, wave, lk, u);                 // + gh on r, z; gh_n apart
+    f32x4 acc[4 * RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { acc[rt * 4 + 0] = u[rt * 3 + 0]; acc[rt * 4 + 1] = u[rt * 3 + 1]; acc[rt * 4 + 2] = t[rt * 3 + 2]; acc[rt * 4 + 3] = u[rt * 3 + 2]; }
+    reduce_waves<4 * RT>(acc, part, wave, lane);
+    if (wave > 0) return;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (row0 + rt * 16 + lk * 4 + r >= R) continue;
+            const int row = dec_row(a.rowmap, row0 + rt * 16 + lk * 4 + r);
+            const float ghn = acc[rt * 4 + 3][r] + bhn;
+            const float rg = fast_sigmoid(acc[rt * 4 + 0][r] + br);
+            const float zg = fast_sigmoid(acc[rt * 4 + 1][r] + bz);
+            const float ng = fast_tanh(acc[rt * 4 + 2][r] + bin + rg * ghn);
+            const float hn = (1.f - zg) * ng + zg * hp[rt][r];
+            a.hout[(long)row * H2 + j] = hn;
+            a.o[(long)row * a.ldo + j] = hn;
+            if (a.save) {
+                float* sv = a.save + (long)row * 4 * H2;
+                sv[j] = rg; sv[H2 + j] = zg; sv[2 * H2 + j] = ng; sv[3 * H2 + j] = ghn;
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------- forward: output projection + epilogue + next query
@@ -336,6 +437,57 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
     }
 }
 
+
+// dec_bwd_products over RT x 16 rows per workgroup
+template <int RT>
+__global__ __launch_bounds__(64 * NW) void dec_bwd_products_rt(DecBwdProdArgs a) {
+    __shared__ f32x4 part[4 * 2 * RT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = a.R, K = 3 * a.H2, row0 = blockIdx.y * 16 * RT;
+    const bool role_a = (int)blockIdx.x < a.nxa;
+    const int n0 = (role_a ? blockIdx.x : blockIdx.x - a.nxa) * 32;
+    const int ncols = role_a ? a.kx : a.H2;
+    const float* A = role_a ? a.dgi : a.dgh;
+    const float* Bt = role_a ? a.wih_t : a.whh_t;
+    const float* brow[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) brow[g] = Bt + (long)min(n0 + g * 16 + li, ncols - 1) * K;
+    float c0[RT][2][4];
+    if (wave == 0 && !role_a) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    c0[rt][g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + rt * 16 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
+    }
+    const float* arow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) arow[rt] = A + (long)dec_row(a.rowmap, min(row0 + rt * 16 + li, R - 1)) * K;
+    f32x4 acc[RT * 2];
+#pragma unroll
+    for (int i = 0; i < RT * 2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows8_rt<2, RT, 2>(arow, brow, K / 16, wave, lk, acc);
+    reduce_waves<2 * RT>(acc, part, wave, lane);
+    if (wave > 0) return;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int col = n0 + g * 16 + li;
+            if (col >= ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (row0 + rt * 16 + lk * 4 + r >= R) continue;
+                const int row = dec_row(a.rowmap, row0 + rt * 16 + lk * 4 + r);
+                if (role_a) a.dx[(long)row * a.ldx + col] = acc[rt * 2 + g][r];
+                else a.dh[(long)row * a.H2 + col] = c0[rt][g][r] + acc[rt * 2 + g][r];
+            }
+        }
+}
+
 // dh[:, n] += dq . W_h[:, n]  (B rows = W_h^T rows, (H2, H)); 32 columns per workgroup
 __global__ __launch_bounds__(64 * NW) void dec_bwd_query(const float* __restrict__ dq, const float* __restrict__ wh_t, float* __restrict__ dh,
                                                          int R, int H, int H2, const int* __restrict__ rowmap) {
@@ -389,7 +541,7 @@ int a2s_dec_fused_max_rows(void) {
     return g_dec_fused_max_rows;
 }
 // scratch layout (floats): [16: flags | FUSED_MAX_RB: tickets | max_rows x 176: logits] then [W_ih^T | W_hh^T | W_h^T] for the backward
-#define FUSED_MAX_ROWS_CAP 1024
+#define FUSED_MAX_ROWS_CAP 2048
 #define FUSED_HEAD (16 + FUSED_MAX_ROWS_CAP / 16 + (long)FUSED_MAX_ROWS_CAP * 16 * NTV)
 size_t a2s_note_step_fused_head_floats(void) { return (size_t)FUSED_HEAD; }
 size_t a2s_note_step_workspace_floats_impl(int H, int E) {
@@ -397,6 +549,14 @@ size_t a2s_note_step_workspace_floats_impl(int H, int E) {
     return (size_t)(FUSED_HEAD + kx * 3 * H2 + H2 * 3 * H2 + H2 * H);
 }
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+// 16-row tiles per workgroup of the GRU / backward-product kernels: 1 while the launch would otherwise not fill the chip (32-33 column tiles x
+// rows / 16 workgroups), 2 / 4 above (A2S_DEC_ROW_TILES=1|2|4 forces one)
+static int dec_row_tiles(int nrows) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("A2S_DEC_ROW_TILES"); forced = e ? atoi(e) : 0; }
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return nrows > 384 ? 4 : (nrows > 160 ? 2 : 1);
+}
 // greedy: the call is a greedy decode (no ground truth, no backward).  There the 4-launch step wins at every batch size the workspace admits
 // (B = 256: 497 -> 536 clips/s, B = 64: 313 -> 317, profiles/r05_infer_variants.txt) -- one stream decodes a staff, nothing runs beside it that
 // the weight re-reads of the 16-row tiles could disturb -- so the row limit of the training path (A2S_DEC_FUSED_MAX_ROWS) does not apply;
@@ -430,7 +590,10 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
     g.n_done = greedy ? a.n_done : nullptr; g.skip = flags;
     g.rowmap = rowmap;
     g.R = nrows; g.H2 = H2;
-    hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, g);
+    const int rt = dec_row_tiles(nrows);
+    if (rt == 4) hipLaunchKernelGGL(dec_gru_step_rt<4>, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(64 * NW), 0, st, g);
+    else if (rt == 2) hipLaunchKernelGGL(dec_gru_step_rt<2>, dim3(H2 / 16, a2s_cdiv(nrows, 32)), dim3(64 * NW), 0, st, g);
+    else hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, g);
     A2S_CHECK_LAUNCH("dec_gru_step");
     DecOutArgs f;
     f.o = g.o; f.ldo = 2 * H2; f.ko = 2 * H2; f.out_w = a.out_w; f.out_b = a.out_b;
@@ -482,7 +645,10 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
     p.dgi = dgi; p.dgh = dgh; p.wih_t = wih_t; p.whh_t = whh_t; p.dx = dxs; p.ldx = ldx; p.dh = dh_out;
     p.rowmap = rowmap;
     p.nxa = a2s_cdiv(ldx, 32); p.kx = ldx; p.R = nrows; p.H2 = H2;
-    hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, p);
+    const int rt = dec_row_tiles(nrows);
+    if (rt == 4) hipLaunchKernelGGL(dec_bwd_products_rt<4>, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(64 * NW), 0, st, p);
+    else if (rt == 2) hipLaunchKernelGGL(dec_bwd_products_rt<2>, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 32)), dim3(64 * NW), 0, st, p);
+    else hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, p);
     A2S_CHECK_LAUNCH("dec_bwd_products");
     // attention: dctx = dx[:, E:] + do[:, 2H:]
     rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
