@@ -640,6 +640,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X: the transcription hot path has no CPU implementation"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.cuda.set_per_process_memory_fraction(float(os.environ.get("A2S_MEM_FRACTION", "0.96")), local)     # an over-sized batch raises in torch instead of taking the box down
     torch.manual_seed(1234)
     random.seed(1234 + (rank if COIN_POLICY == "rank_offset" else 0))      # teacher-forcing coins (COIN_POLICY above)
     from piano_a2s_amd import build as a2s_build

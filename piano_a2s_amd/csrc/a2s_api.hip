@@ -56,6 +56,8 @@ void a2s_gru_step_fused_set(int);
 void a2s_gru_persist_set(int);
 int a2s_gru_persist_enabled(void);
 void a2s_dec_persist_set(int);
+void a2s_gru_persist_alone_set(int);
+int a2s_gru_persist_alone(void);
 void a2s_attn_pace_set(int);
 int a2s_attn_pace_enabled(void);
 void a2s_attn_pace_min_set(int);
@@ -220,6 +222,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
+    if (!strcmp(key, "gru_persist_alone")) { a2s_gru_persist_alone_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_persist")) { a2s_dec_persist_set(value); return A2S_OK; }
     if (!strcmp(key, "persist_force_agent")) { a2s_persist_dbg_set(PERSIST_DBG_FORCE_AGENT, value); return A2S_OK; }
     if (!strcmp(key, "persist_inject_abort")) { a2s_persist_dbg_set(PERSIST_DBG_INJECT_ABORT, value); return A2S_OK; }
@@ -254,6 +257,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "wgrad_bf16x3")) return a2s_wgrad_split_enabled();
     if (key && !strcmp(key, "gru_fused")) return a2s_gru_step_fused_enabled();
     if (key && !strcmp(key, "gru_persist")) return a2s_gru_persist_enabled();
+    if (key && !strcmp(key, "gru_persist_alone")) return a2s_gru_persist_alone();
     if (key && !strcmp(key, "dec_persist")) return a2s_dec_persist_enabled();
     if (key && !strcmp(key, "dec_persist_launches")) return a2s_dec_persist_launches();
     if (key && !strcmp(key, "persist_force_agent")) return a2s_persist_dbg_get(PERSIST_DBG_FORCE_AGENT);

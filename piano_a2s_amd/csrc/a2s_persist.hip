@@ -413,11 +413,14 @@ static int persist_blocks_per_cu(K kernel) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
     return n;
 }
+static int g_gru_persist_alone = 0;      // a2s_debug_set("gru_persist_alone", 1): the host runs the directions of a layer one after the other
+void a2s_gru_persist_alone_set(int v) { g_gru_persist_alone = v ? 1 : 0; }
+int a2s_gru_persist_alone(void) { return g_gru_persist_alone; }
 static bool persist_fits(int B, int H, bool bwd) {
     static int occ[2] = {-1, -1};
     if (occ[bwd] < 0) occ[bwd] = bwd ? persist_blocks_per_cu(gru_seq_bwd_persist<256>) : persist_blocks_per_cu(gru_seq_fwd_persist<256>);
     const a2s_device_geom g = a2s_device_geometry();
-    return 2L * (H / 16) * ((B + 15) / 16) <= (long)g.cus * occ[bwd];
+    return (g_gru_persist_alone ? 1L : 2L) * (H / 16) * ((B + 15) / 16) <= (long)g.cus * occ[bwd];
 }
 
 bool a2s_gru_seq_fwd_persist_ok(const float* w_hh, const float* gi, int B, int T, int H, float* ws, size_t ws_bytes) {

@@ -1238,12 +1238,11 @@ size_t a2s_attn_workspace_floats_impl(int B, int T, int H, int groups) {
 // 692 ms): every one of the ~770 workgroups of a launch pays a device-scope release (L2 write-back) before its ticket and the last one
 // an acquire (L2 invalidate) -- on an 8-XCD part that costs more than the 7 us launch it saves and evicts the other streams' lines.
 static int g_attn_fused_combine = -1;
-void a2s_attn_fused_combine_set(int v) { g_attn_fused_combine = v ? 1 : 0; }
+void a2s_attn_fused_combine_set(int v) { g_attn_fused_combine = v < 0 ? 0 : v; }      // 0 never, 1 always, n >= 2: launches over at most n clips
 int a2s_attn_fused_combine_enabled(void) {
-    if (g_attn_fused_combine < 0) { const char* e = getenv("A2S_ATTN_FUSED_COMBINE"); g_attn_fused_combine = e ? (atoi(e) != 0) : 0; }
+    if (g_attn_fused_combine < 0) { const char* e = getenv("A2S_ATTN_FUSED_COMBINE"); g_attn_fused_combine = e ? (atoi(e) < 0 ? 0 : atoi(e)) : 0; }
     return g_attn_fused_combine;
 }
-static bool attn_fused_combine(void) { return a2s_attn_fused_combine_enabled() != 0; }
 static int g_attn_nt = -1;
 void a2s_attn_nt_set(int v) { g_attn_nt = v < 0 ? 0 : v; }
 int a2s_attn_nt_enabled(void) {
@@ -1306,7 +1305,10 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     // workspace: [A2S_ATTN_TICKETS ints: arrival counters, zero between launches (the allocation must be zero-initialised once)] [partials]
     int* tickets = reinterpret_cast<int*>(ws);
     float* part = ws + A2S_ATTN_TICKETS;
-    const bool fused = attn_fused_combine() && r.n_clips <= A2S_ATTN_TICKETS / 2;
+    // (mode n >= 2: only launches over at most n active clips -- the long-clip group's latency chain, where one launch and one dependent round
+    // trip less per step count and the per-workgroup release is paid by a few dozen workgroups instead of ~770)
+    const int fmode = a2s_attn_fused_combine_enabled();
+    const bool fused = fmode && (fmode == 1 || r.n_active <= fmode) && r.n_clips <= A2S_ATTN_TICKETS / 2;
     // fused tail: one extra workgroup per clip (row) WITHOUT unfinished rows zero-fills its outputs
     const int n_zero = fused ? r.n_clips - r.n_active : 0;
     const AttnFusedTail ft = {fused ? tickets : nullptr, ctx, ldctx, ctx2, ldctx2, r.n_active, B};

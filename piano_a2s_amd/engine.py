@@ -190,9 +190,14 @@ def run_clip_groups(device, fns):
     return [first] + [r for r, _ in rest]
 
 
-def encoder_streams(device):
-    """Streams for the two directions of an encoder GRU layer (A2S_ENC_SERIAL=1: both on the current stream, for A/B measurements)."""
-    if _os.environ.get("A2S_ENC_SERIAL") == "1":
+def encoder_streams(device, batch=0):
+    """Streams for the two directions of an encoder GRU layer (A2S_ENC_SERIAL=1: both on the current stream, for A/B measurements).
+    batch: clips of the call.  The persistent recurrences (csrc/a2s_persist.hip) need every workgroup of a launch resident: 16 per 16 clips, two per
+    CU.  Up to 256 clips both directions fit side by side (2 x 256 workgroups on 256 CUs); above that (up to 512 clips) ONE direction fits, so the two run
+    one after the other on the current stream and the library is told that nothing persistent runs beside a launch ("gru_persist_alone")."""
+    serial = _os.environ.get("A2S_ENC_SERIAL") == "1" or batch > 256
+    hip.check(hip.lib().a2s_debug_set(b"gru_persist_alone", 1 if batch > 256 else 0), "a2s_debug_set")
+    if serial:
         cur = torch.cuda.current_stream()
         return (cur, cur)
     return side_streams(device)
@@ -369,7 +374,7 @@ class Engine:
         dev = x.device
         saved = {"layers": []}
         gws = [hip.gemm_workspace(B, dev), hip.gemm_workspace(B, dev)]
-        streams = encoder_streams(dev)           # the two directions of a layer are independent 1201-step chains: one stream each
+        streams = encoder_streams(dev, B)        # the two directions of a layer are independent 1201-step chains: one stream each
         inp = x.reshape(B * T, -1)
         finals = []
         for layer in (0, 1):
@@ -531,9 +536,13 @@ class Engine:
 
     # ------------------------------------------------------------------ full forward
     def forward(self, S, spectrogram, inference=True, ground_truth=None, teacher_forcing_ratio=0.0, training=False,
-                rng=_py_random, dropout=True, gt_host=None):
+                rng=_py_random, dropout=True, gt_host=None, conv_pre=None):
         """S: dict name -> device tensor (parameters and BN buffers, reference state_dict names).
-        gt_host: optional host copies (upper, lower, upper_len, lower_len) of the ground truth, when the caller already has them."""
+        gt_host: optional host copies (upper, lower, upper_len, lower_len) of the ground truth, when the caller already has them.
+        conv_pre: optional (conv_out (B, T, Cf), saved, unperm) of a ConvStack pass the caller has ALREADY enqueued on this stream for the same clips
+        (train.TrainStep launches it before it plans the decoder: the planning then runs under it); `spectrogram` is then only looked at for its
+        shape.  unperm: None, or the int64 device index that maps this call's clip order back to the order the ConvStack ran in (its backward
+        then gets its gradient in that order: engine_bwd)."""
         if inference:
             assert teacher_forcing_ratio == 0 and ground_truth is None     # models.py:202-204
         if not spectrogram.is_cuda:
@@ -558,8 +567,12 @@ class Engine:
 
         # ConvStack + encoder are enqueued first: the host-side planning of the decoder below runs while they execute.  Its small
         # host->device uploads go through pinned memory without synchronising (a pageable upload would drain the stream each time).
-        mask = (torch.rand((B * T, cfg["conv_feature_size"]), device=dev) >= 0.2).to(torch.uint8) if drop_on else None
-        conv_out, conv_saved = self.convstack(S, spectrogram, training, mask)
+        self.conv_unperm = None
+        if conv_pre is not None:
+            conv_out, conv_saved, self.conv_unperm = conv_pre
+        else:
+            mask = (torch.rand((B * T, cfg["conv_feature_size"]), device=dev) >= 0.2).to(torch.uint8) if drop_on else None
+            conv_out, conv_saved = self.convstack(S, spectrogram, training, mask)
         # (the encoder is enqueued AFTER the host plan below: its ~4800 launches can block the issuing threads until the GPU has worked
         # most of them off, and a plan made after that wait reaches the decoder late -- tools/phase_times.py --segments: 195 ms into the
         # step on the host against 90 ms on the GPU)

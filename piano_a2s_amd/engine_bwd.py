@@ -449,6 +449,8 @@ class Backward:
                     grad_ready(self.flat_full, n_conv, total + 1)
             else:
                 grad_ready(self.flat_full, n_conv, total + 1)           # (+ the loss word)
+        if getattr(eng, "conv_unperm", None) is not None:       # the ConvStack ran before the clips were permuted into their groups (train.TrainStep)
+            d_conv = d_conv.reshape(B, T, -1).index_select(0, eng.conv_unperm)
         _convstack_bwd(eng, S, G, sv["conv"], d_conv, B, T, F)
         if defer:
             torch.cuda.current_stream().wait_stream(_weight_grad_stream(dev))
@@ -538,7 +540,7 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T, wait_weight_grads=True):
         out = ls["out"]
         dX = torch.empty((B * T, I), device=dev)
         from .engine import encoder_streams, fork_on_streams
-        streams = encoder_streams(dev)                    # the two directions' BPTT chains are independent: one stream (and host thread) each
+        streams = encoder_streams(dev, B)                 # the two directions' BPTT chains are independent: one stream (and host thread) each
 
         def direction(d, sfx):
             dgi = torch.empty((B, T, 3 * H), device=dev)
@@ -598,6 +600,8 @@ _DGRAD_BNSTATS = os.environ.get("A2S_DGRAD_BNSTATS", "1") != "0"      # BatchNor
 # synchronised BatchNorm keeps the fused backward paths (statistics from the producers' partials, ONE small all-reduce per layer, the input gradient
 # formed inside the weight-gradient kernel): round 5; A2S_SYNC_BN_FUSED=0 = round 4's separate statistics + apply passes
 _SYNC_FUSED = os.environ.get("A2S_SYNC_BN_FUSED", "1") != "0"
+def _lin_wgrad_overlap():       # the 19200 -> 256 Linear's weight gradient beside its data gradient (round 5); read per step (tools/ab_step.py env:)
+    return os.environ.get("A2S_LINEAR_WGRAD_OVERLAP", "1") != "0"
 _FUSE_BN_ROWS = os.environ.get("A2S_FUSE_BN_ROWS", "1") != "0"        # BatchNorm-backward apply inside the row-streaming weight gradient's staging
 _LINEAR_DGRAD = os.environ.get("A2S_LINEAR_DGRAD", "1") != "0"        # the Linear's data gradient on its own kernel (csrc/a2s_linear.hip)
 
@@ -683,8 +687,22 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         y4 = cs["y"][3].view(rows, 40 * F)
         da = torch.empty_like(y4)
         bn4 = cs["bn"][3]
-        if not hip.linear_wgrad(dz, y4, (bn4[2], bn4[3], F), dz_amax, cs["abound"][3], G["convstack.out.weight"]):       # round 4: csrc/a2s_linear.hip
-            _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
+        def lin_wgrad():
+            if not hip.linear_wgrad(dz, y4, (bn4[2], bn4[3], F), dz_amax, cs["abound"][3], G["convstack.out.weight"]):       # round 4: csrc/a2s_linear.hip
+                _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
+        lin_overlap = _lin_wgrad_overlap()
+        if lin_overlap:
+            # round 5: the Linear's weight gradient (reads y4 once, 10-13 ms) and its data gradient (writes da, re-reads y4, 15 ms) only share dz: the
+            # weight gradient goes to the weight-gradient stream (idle by now: the decoder is over) and runs BESIDE the data gradient; the main stream
+            # joins it at the end of the ConvStack backward
+            wg_stream = _weight_grad_stream(dev)
+            ev = torch.cuda.Event()
+            ev.record()
+            wg_stream.wait_event(ev)
+            with torch.cuda.stream(wg_stream):
+                lin_wgrad()
+        else:
+            lin_wgrad()
         if _DGRAD_BNSTATS and (not eng.sync_bn or _SYNC_FUSED) and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             if w_amax is None:
@@ -771,3 +789,5 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
                 g_partial = None
             g = gprev
             g_amax = g_amax_next if (_DGRAD_BNSTATS and (not eng.sync_bn or _SYNC_FUSED)) else None
+    if a4 is None and lin_overlap:
+        torch.cuda.current_stream().wait_stream(_weight_grad_stream(dev))      # the Linear's weight gradient (issued beside the data gradient above)

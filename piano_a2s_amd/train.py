@@ -249,6 +249,8 @@ class TrainStep:
         self.group_plan = dict(group_plan or {})
         if "step_cost" not in self.group_plan and _os.environ.get("A2S_GROUP_STEP_COST"):
             self.group_plan["step_cost"] = float(_os.environ["A2S_GROUP_STEP_COST"])
+        # the ConvStack is enqueued before the host plans the decoder (see _step); A2S_EARLY_CONVSTACK=0: after, as in round 4
+        self.early_convstack = _os.environ.get("A2S_EARLY_CONVSTACK", "1") != "0"
         self.keep_grads = False            # tests: keep the last step's gradient views (name -> tensor) in self.last_grads
         self.last_grads = None
         self._last = None
@@ -286,10 +288,37 @@ class TrainStep:
         eng.skip_finished_rows = self.skip_finished_rows
         eng.fuse_bars = self.skip_finished_rows and self.fuse_bars
         gt_host, perm = None, None
+        S = self.state()
+        conv_pre = None
+        plan_groups = eng.fuse_bars and not isinstance(self.clip_groups, (list, tuple)) and self.clip_groups
+        if plan_groups and self.early_convstack and spectrogram.is_cuda:
+            # Round 5: the ConvStack does not depend on the decoder's plan (nor on the clip order), so it is ENQUEUED FIRST -- before the host
+            # reads the targets and cuts the clip groups (4-5 ms during which the GPU used to idle at the start of every step).  The targets come
+            # over on a side stream, so that the read does not wait for the ConvStack just enqueued on this one.
+            if self.sync_bn and eng.sync_bn:
+                engine.Engine.check_counts(spectrogram.shape[0] * spectrogram.shape[2] * spectrogram.shape[3], spectrogram.device)
+            Bc, _, Tc, _ = spectrogram.shape
+            mask = (torch.rand((Bc * Tc, self.model.cfg["conv_feature_size"]), device=spectrogram.device) >= 0.2).to(torch.uint8) if self.dropout else None
+            conv_out, conv_saved = eng.convstack(S, spectrogram, True, mask)
+            copy_stream = engine.side_streams(spectrogram.device)[0]         # (the targets exist before the step: the copy waits for nothing)
+            srcs = (up_t, lo_t, up_len, lo_len)
+            key = tuple((tuple(t.shape), t.dtype) for t in srcs)
+            if getattr(self, "_gt_pinned_key", None) != key:              # pinned staging, allocated once per batch shape
+                self._gt_pinned = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in srcs]
+                self._gt_pinned_key = key
+            with torch.cuda.stream(copy_stream):
+                for dst, t in zip(self._gt_pinned, srcs):
+                    dst.copy_(t, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+            done.synchronize()
+            gt_host = [p.clone() for p in self._gt_pinned]
+            conv_pre = [conv_out, conv_saved, None]
         if eng.fuse_bars and isinstance(self.clip_groups, (list, tuple)):
             eng.clip_groups = [tuple(r) for r in self.clip_groups]
         elif eng.fuse_bars and self.clip_groups:
-            gt_host = [up_t.cpu(), lo_t.cpu(), up_len.cpu(), lo_len.cpu()]       # the one host sync of the step (Engine.forward reuses it)
+            if gt_host is None:
+                gt_host = [up_t.cpu(), lo_t.cpu(), up_len.cpu(), lo_len.cpu()]       # the one host sync of the step (Engine.forward reuses it)
             idx_u = torch.arange(1, up_t.shape[-1] + 1)
             idx_l = torch.arange(1, lo_t.shape[-1] + 1)
             order, n_main = plan_clip_groups(((gt_host[0] != PAD).long() * idx_u).amax(-1).numpy(), ((gt_host[1] != PAD).long() * idx_l).amax(-1).numpy(),
@@ -299,14 +328,21 @@ class TrainStep:
                 perm = torch.from_numpy(order)
                 gt_host = [t[perm] for t in gt_host]
                 pd = perm.to(spectrogram.device, non_blocking=True)
-                spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len)]
+                if conv_pre is not None:
+                    # the ConvStack ran in the caller's clip order: its output goes into group order, its backward gets the gradient back in the caller's
+                    inv = torch.empty_like(perm)
+                    inv[perm] = torch.arange(perm.numel())
+                    conv_pre[0] = conv_pre[0].index_select(0, pd)
+                    conv_pre[2] = inv.to(spectrogram.device, non_blocking=True)
+                    ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (ts_t, key_t, up_t, up_len, lo_t, lo_len)]
+                else:
+                    spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len)]
                 eng.clip_groups = [(0, n_main), (n_main, B)]
-        S = self.state()
-        if self.sync_bn and eng.sync_bn:
+        if self.sync_bn and eng.sync_bn and conv_pre is None:
             engine.Engine.check_counts(spectrogram.shape[0] * spectrogram.shape[2] * spectrogram.shape[3], spectrogram.device)
         exchange = GradientExchange(self.world)
         fwd = dict(inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len], teacher_forcing_ratio=teacher_forcing_ratio, training=True,
-                   rng=rng, dropout=self.dropout, gt_host=gt_host)
+                   rng=rng, dropout=self.dropout, gt_host=gt_host, conv_pre=tuple(conv_pre) if conv_pre is not None else None)
         if eng.fuse_bars and self.pipeline_groups:
             # Pipelined clip groups.  The gradient of the 4-term objective wrt a row's log-probabilities is -1/count at its target --
             # and the counts (denominators of the NLL means) are functions of the TARGETS alone.  So a clip group does not have to
