@@ -700,6 +700,17 @@ def main():
 
     batches = make_batches(args.full_tail)
     from piano_a2s_amd import hip as a2s_hip
+    # One segment for the caching allocator's pool, before anything is timed: a step's tensor shapes follow its coins (how many bars fuse), so new
+    # block sizes keep turning up for dozens of steps, and each one the pool cannot serve is a hipMalloc of several GiB -- 50-130 ms during which the
+    # step stands still (round 4: `hipMalloc_segments_per_step`).  A trainer that knows its memory budget reserves it up front; so does the bench
+    # (A2S_POOL_RESERVE_GIB, default 200 of the 268 GiB; 0: off).  Blocks are then split off this segment; the per-step count stays in the JSON.
+    pool_gib = float(os.environ.get("A2S_POOL_RESERVE_GIB", "200"))
+    if pool_gib > 0:
+        try:
+            pool = torch.empty(int(pool_gib * 2 ** 30), dtype=torch.uint8, device=dev)
+            del pool
+        except RuntimeError:
+            pool_gib = 0.0
     elapsed, decode_steps = timed(batches, args.warmup, args.steps)
     launches_per_step = round((a2s_hip.lib().a2s_launch_count() - timed.launches0) / args.steps)
     clip_steps_per_step = sum(timed.clip_steps) / max(len(timed.clip_steps), 1)
@@ -745,7 +756,7 @@ def main():
                                      "holding full-length bars decoded as a concurrent clip group (loss, gradients and update identical "
                                      "to the per-bar loop over the whole minibatch)",
                           "clip_groups": groups, "decode_steps_per_step": round(sum(decode_steps) / max(len(decode_steps), 1), 1),
-                          "step_ms": main_step_ms, "hipMalloc_segments_per_step": main_new_segments,
+                          "step_ms": main_step_ms, "hipMalloc_segments_per_step": main_new_segments, "allocator_pool_reserved_GiB": pool_gib,
                           "allocator": {"hipMalloc_calls": torch.cuda.memory_stats().get("segment.all.allocated", 0),
                                         "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0),
                                         "reserved_peak_GiB": round(torch.cuda.memory_stats().get("reserved_bytes.all.peak", 0) / 2 ** 30, 1)},
