@@ -705,12 +705,15 @@ def main():
     # step stands still (round 4: `hipMalloc_segments_per_step`).  A trainer that knows its memory budget reserves it up front; so does the bench
     # (A2S_POOL_RESERVE_GIB, default 200 of the 268 GiB; 0: off).  Blocks are then split off this segment; the per-step count stays in the JSON.
     pool_gib = float(os.environ.get("A2S_POOL_RESERVE_GIB", "200"))
-    if pool_gib > 0:
-        try:
-            pool = torch.empty(int(pool_gib * 2 ** 30), dtype=torch.uint8, device=dev)
-            del pool
-        except RuntimeError:
-            pool_gib = 0.0
+
+    def reserve_pool():
+        if pool_gib > 0:
+            try:
+                pool = torch.empty(int(pool_gib * 2 ** 30), dtype=torch.uint8, device=dev)
+                del pool
+            except RuntimeError:
+                pass
+    reserve_pool()
     elapsed, decode_steps = timed(batches, args.warmup, args.steps)
     launches_per_step = round((a2s_hip.lib().a2s_launch_count() - timed.launches0) / args.steps)
     clip_steps_per_step = sum(timed.clip_steps) / max(len(timed.clip_steps), 1)
@@ -734,6 +737,7 @@ def main():
         batches = None
         step._last = None
         torch.cuda.empty_cache()
+        reserve_pool()
         e2, _ = timed(make_batches(0.0), 1, max(2, min(args.steps, 4)))
         k2 = max(2, min(args.steps, 4))
         secondary = {"value": round(B * world * k2 / e2, 3), "unit": "clips/s", "ms_per_step": round(e2 / k2 * 1e3, 2), "steps": k2, "warmup": 1,

@@ -132,10 +132,46 @@ def group_stream(device, group):
     the two side streams (staves of group 0; encoder directions) and this one -- the long-clip group's latency chain gets a hardware
     queue to itself instead of waiting in line behind the bulk group's bandwidth-bound kernels.  The encoder's weight-gradient
     GEMMs reuse it (engine_bwd._weight_grad_stream): the decoder is done by then."""
+    if group >= 2:
+        # round 5: two long-clip sub-groups (train.split_long_group), each decoding its two staves one after the other on ONE stream: the
+        # first on the stream above, the second on the side stream the single long-clip group's lower staff would have used -- still four streams
+        return side_streams(device, 0)[0]
     key = (_dev_index(device), 1)
     if key not in _GROUP_STREAMS:
         _GROUP_STREAMS[key] = torch.cuda.Stream(device=key[0])
     return _GROUP_STREAMS[key]
+
+
+def staves_concurrent(gidx, n_groups):
+    """Do the two note decoders of clip group gidx run side by side on two streams?  Group 0 always; the long-clip group when it is the only one beside
+    it; with two long-clip sub-groups each of them runs upper then lower on its one stream (four streams in all, see group_stream)."""
+    return gidx == 0 or (gidx == 1 and n_groups == 2)
+
+
+def draw_plan(gt_cpu, bars, maxlen, rng, teacher_forcing_ratio):
+    """The host plan of a forward pass with ground truth: executed steps of every (bar, staff) and EVERY coin of the reference's protocol, drawn in the
+    reference's order (one per executed note step, upper then lower, then one per bar: models.py:404,289).  gt_cpu: (upper, lower, ...) host tensors
+    (B, bars, len); the step counts are batch-wide maxima, so the clip order does not matter."""
+    plan = []
+    for bar in range(bars):
+        p = {}
+        for gi_idx in (0, 1):
+            steps, _ = plan_note_steps(gt_cpu[gi_idx][:, bar, :], maxlen[gi_idx])
+            p[gi_idx] = (steps, [rng.random() < teacher_forcing_ratio for _ in range(steps)])
+        p["tf"] = rng.random() < teacher_forcing_ratio
+        plan.append(p)
+    return plan
+
+
+def plan_segments(plan, bars, fuse, inference=False):
+    """Bars decoded in one call each: consecutive bars whose predecessor's bar-level coin says "teacher-force" (at most 5 = A2S_ATTN_MAX_GROUPS)."""
+    segments = [[0]]
+    for bar in range(1, bars):
+        if fuse and plan[bar - 1]["tf"] and not inference and len(segments[-1]) < 5:
+            segments[-1].append(bar)
+        else:
+            segments.append([bar])
+    return segments
 
 
 def group_views(t, clip_groups, gidx):
@@ -536,13 +572,15 @@ class Engine:
 
     # ------------------------------------------------------------------ full forward
     def forward(self, S, spectrogram, inference=True, ground_truth=None, teacher_forcing_ratio=0.0, training=False,
-                rng=_py_random, dropout=True, gt_host=None, conv_pre=None):
+                rng=_py_random, dropout=True, gt_host=None, conv_pre=None, host_plan=None):
         """S: dict name -> device tensor (parameters and BN buffers, reference state_dict names).
         gt_host: optional host copies (upper, lower, upper_len, lower_len) of the ground truth, when the caller already has them.
         conv_pre: optional (conv_out (B, T, Cf), saved, unperm) of a ConvStack pass the caller has ALREADY enqueued on this stream for the same clips
         (train.TrainStep launches it before it plans the decoder: the planning then runs under it); `spectrogram` is then only looked at for its
         shape.  unperm: None, or the int64 device index that maps this call's clip order back to the order the ConvStack ran in (its backward
-        then gets its gradient in that order: engine_bwd)."""
+        then gets its gradient in that order: engine_bwd).
+        host_plan: optional result of draw_plan(...) for this very call (train.TrainStep draws it before it cuts the clip groups: the cut looks at the
+        bar segments); the coins are then NOT drawn again here."""
         if inference:
             assert teacher_forcing_ratio == 0 and ground_truth is None     # models.py:202-204
         if not spectrogram.is_cuda:
@@ -601,14 +639,7 @@ class Engine:
         # in the reference's order.
         plan = None
         if gt_cpu is not None:
-            plan = []
-            for bar in range(bars):
-                p = {}
-                for gi_idx in (0, 1):
-                    steps, _ = plan_note_steps(gt_cpu[gi_idx][:, bar, :], maxlen[gi_idx])
-                    p[gi_idx] = (steps, [rng.random() < teacher_forcing_ratio for _ in range(steps)])
-                p["tf"] = rng.random() < teacher_forcing_ratio
-                plan.append(p)
+            plan = host_plan if host_plan is not None else draw_plan(gt_cpu, bars, maxlen, rng, teacher_forcing_ratio)
         # Fused training step only (train.TrainStep sets these; never the drop-in module path, whose output rows must equal the
         # reference's everywhere):
         #  skip_finished_rows -- a row whose remaining targets are all <pad> no longer reaches the loss (ignore_index) nor the next
@@ -623,12 +654,7 @@ class Engine:
         #    segment) runs under the bandwidth-bound attention of the many ordinary ones instead of after it.
         skip = plan is not None and training and getattr(self, "skip_finished_rows", False)
         fuse = skip and getattr(self, "fuse_bars", False)
-        segments = [[0]]
-        for bar in range(1, bars):
-            if fuse and plan[bar - 1]["tf"] and not inference and len(segments[-1]) < 5:      # 5 = A2S_ATTN_MAX_GROUPS
-                segments[-1].append(bar)
-            else:
-                segments.append([bar])
+        segments = plan_segments(plan, bars, fuse, inference) if plan is not None else [[bar] for bar in range(bars)]
         until_all = None
         if skip:
             until_all = []
@@ -694,7 +720,7 @@ class Engine:
             alone = len(clip_groups) == 1 or _os.environ.get("A2S_DEC_PERSIST_BESIDE") == "1"
             persist_g = (Bg <= 8 and gidx == len(clip_groups) - 1 and alone and H == 256 and E == 16 and (plan is not None or (inference and not greedy_graph))
                          and _os.environ.get("A2S_DEC_PERSIST", "1") != "0")
-            concurrent_g = concurrent and gidx <= 1 and not persist_g      # (a third group would have no stream left: everything in order on its own)
+            concurrent_g = concurrent and staves_concurrent(gidx, len(clip_groups)) and not persist_g
             streams = staff_streams(dev, gidx) if concurrent_g else None
 
             def rand(shape):

@@ -295,7 +295,8 @@ class Backward:
         # as in Engine.forward (engine.staff_streams); a group whose calls ran as persistent launches back-propagates its staves one after
         # the other (two persistent launches must never be in flight together)
         persist_g = any(seg["staff"][k][2].get("persist_ws") is not None for seg in gs["segments"] for k in ("up", "lo"))
-        concurrent_g = concurrent and gidx <= 1 and not persist_g
+        from .engine import staves_concurrent
+        concurrent_g = concurrent and staves_concurrent(gidx, len(self.clip_groups)) and not persist_g
         streams = staff_streams(dev, gidx) if concurrent_g else None
         use_deferred_g = use_deferred and gidx == 0
         deferred_streams = _deferred_streams(dev, gidx) if use_deferred_g else None

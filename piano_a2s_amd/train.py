@@ -216,6 +216,43 @@ def plan_clip_groups(until_up, until_lo, max_tail_frac=0.5, min_gain=0.08, step_
     return np.concatenate([by_len[best_k:], np.sort(by_len[:best_k])]), B - best_k
 
 
+def split_long_group(long_ids, until_up, until_lo, segments, min_gain=0.1):
+    """Round 5.  The long-clip group's decode chain is, per bar SEGMENT of the step, as long as the longest row ANY of its clips has there -- typically a
+    full-length (398-step) upper bar in every segment, although each clip holds only one such bar.  Cut it by where the clips' longest bars lie:
+    sub-group A = clips whose longest upper bar is in segments 0..k, sub-group B = the rest; each then runs 398 steps only in "its" segments.  The two
+    sub-groups get one stream each (engine.group_stream) and decode their staves one after the other, so a sub-group's chain is the SUM of its
+    staves' steps per segment, against the MAXIMUM for the single group (staves side by side).  Returns (A, B) -- lists of clip ids -- for the
+    best k when max(chain A, chain B) < (1 - min_gain) x the single group's chain, else None.  Loss, gradients and update do not depend on the
+    grouping (clip groups are independent: Engine.forward)."""
+    import numpy as np
+    long_ids = list(long_ids)
+    if len(long_ids) < 2 or len(segments) < 2:
+        return None
+    up, lo = np.asarray(until_up), np.asarray(until_lo)
+
+    def chain(ids, sequential):
+        total = 0
+        for seg in segments:
+            u, l = int(up[np.ix_(ids, seg)].max()), int(lo[np.ix_(ids, seg)].max())
+            total += (u + l) if sequential else max(u, l)
+        return total
+    seg_of_bar = {bar: si for si, seg in enumerate(segments) for bar in seg}
+    where = [seg_of_bar[int(up[c].argmax())] for c in long_ids]
+    single = chain(long_ids, False)
+    best = None
+    for k in range(len(segments) - 1):
+        a = [c for c, w in zip(long_ids, where) if w <= k]
+        b = [c for c, w in zip(long_ids, where) if w > k]
+        if not a or not b:
+            continue
+        m = max(chain(a, True), chain(b, True))
+        if best is None or m < best[0]:
+            best = (m, a, b)
+    if best is not None and best[0] < (1.0 - min_gain) * single:
+        return best[1], best[2]
+    return None
+
+
 class TrainStep:
     """model: models.ScoreTranscription on a GPU.  One call = one optimizer step on one minibatch."""
 
@@ -251,6 +288,8 @@ class TrainStep:
             self.group_plan["step_cost"] = float(_os.environ["A2S_GROUP_STEP_COST"])
         # the ConvStack is enqueued before the host plans the decoder (see _step); A2S_EARLY_CONVSTACK=0: after, as in round 4
         self.early_convstack = _os.environ.get("A2S_EARLY_CONVSTACK", "1") != "0"
+        # the long-clip group cut in two by the bar segment of each clip's longest bar (split_long_group); A2S_LONG_SUBGROUPS=0: one long-clip group
+        self.long_subgroups = _os.environ.get("A2S_LONG_SUBGROUPS", "1") != "0"
         self.keep_grads = False            # tests: keep the last step's gradient views (name -> tensor) in self.last_grads
         self.last_grads = None
         self._last = None
@@ -287,7 +326,7 @@ class TrainStep:
         eng = engine.Engine(self.model.cfg, sync_bn=self.sync_bn)
         eng.skip_finished_rows = self.skip_finished_rows
         eng.fuse_bars = self.skip_finished_rows and self.fuse_bars
-        gt_host, perm = None, None
+        gt_host, perm, host_plan = None, None, None
         S = self.state()
         conv_pre = None
         plan_groups = eng.fuse_bars and not isinstance(self.clip_groups, (list, tuple)) and self.clip_groups
@@ -321,9 +360,19 @@ class TrainStep:
                 gt_host = [up_t.cpu(), lo_t.cpu(), up_len.cpu(), lo_len.cpu()]       # the one host sync of the step (Engine.forward reuses it)
             idx_u = torch.arange(1, up_t.shape[-1] + 1)
             idx_l = torch.arange(1, lo_t.shape[-1] + 1)
-            order, n_main = plan_clip_groups(((gt_host[0] != PAD).long() * idx_u).amax(-1).numpy(), ((gt_host[1] != PAD).long() * idx_l).amax(-1).numpy(),
-                                             **self.group_plan)
+            until_u, until_l = ((gt_host[0] != PAD).long() * idx_u).amax(-1).numpy(), ((gt_host[1] != PAD).long() * idx_l).amax(-1).numpy()
+            order, n_main = plan_clip_groups(until_u, until_l, **self.group_plan)
             B = up_t.shape[0]
+            group_cuts = [(0, n_main), (n_main, B)]
+            if n_main < B and self.long_subgroups:
+                # the coins of the step are drawn HERE, in the reference's order (Engine.forward takes them as host_plan): the cut looks at the bar segments
+                cfg_ = self.model.cfg
+                host_plan = engine.draw_plan(gt_host, cfg_["max_bars"], cfg_["max_length"], rng, teacher_forcing_ratio)
+                sub = split_long_group(order[n_main:].tolist(), until_u, until_l, engine.plan_segments(host_plan, cfg_["max_bars"], True))
+                if sub is not None:
+                    import numpy as _np
+                    order = _np.concatenate([order[:n_main], _np.asarray(sub[0], dtype=order.dtype), _np.asarray(sub[1], dtype=order.dtype)])
+                    group_cuts = [(0, n_main), (n_main, n_main + len(sub[0])), (n_main + len(sub[0]), B)]
             if n_main < B:
                 perm = torch.from_numpy(order)
                 gt_host = [t[perm] for t in gt_host]
@@ -337,12 +386,12 @@ class TrainStep:
                     ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (ts_t, key_t, up_t, up_len, lo_t, lo_len)]
                 else:
                     spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len = [t.index_select(0, pd) for t in (spectrogram, ts_t, key_t, up_t, up_len, lo_t, lo_len)]
-                eng.clip_groups = [(0, n_main), (n_main, B)]
+                eng.clip_groups = group_cuts
         if self.sync_bn and eng.sync_bn and conv_pre is None:
             engine.Engine.check_counts(spectrogram.shape[0] * spectrogram.shape[2] * spectrogram.shape[3], spectrogram.device)
         exchange = GradientExchange(self.world)
         fwd = dict(inference=False, ground_truth=[ts_t, key_t, up_t, up_len, lo_t, lo_len], teacher_forcing_ratio=teacher_forcing_ratio, training=True,
-                   rng=rng, dropout=self.dropout, gt_host=gt_host, conv_pre=tuple(conv_pre) if conv_pre is not None else None)
+                   rng=rng, dropout=self.dropout, gt_host=gt_host, conv_pre=tuple(conv_pre) if conv_pre is not None else None, host_plan=host_plan)
         if eng.fuse_bars and self.pipeline_groups:
             # Pipelined clip groups.  The gradient of the 4-term objective wrt a row's log-probabilities is -1/count at its target --
             # and the counts (denominators of the NLL means) are functions of the TARGETS alone.  So a clip group does not have to

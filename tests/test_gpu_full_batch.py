@@ -38,7 +38,7 @@ def test_full_size_minibatch_shortcuts_do_not_change_the_step(dev):
         losses = step(dbatch, 0.7, rng=random.Random(99))
         torch.cuda.synchronize()
         if fast:
-            assert step._last[2] is not None and len(step._last[2]) == 2, "the full-size minibatch did not split into two clip groups"
+            assert step._last[2] is not None and len(step._last[2]) >= 2, "the full-size minibatch did not split into clip groups"
         res.append((losses[:, 0].double().cpu(), step.opt.ctl.double().cpu(), step.flat.double().cpu(), step.decode_steps))
         del step, m
         torch.cuda.empty_cache()
@@ -81,3 +81,38 @@ def test_full_size_step_is_invariant_to_the_order_of_the_clips(dev):
     assert torch.allclose(l0, l1, rtol=2e-5, atol=0), (l0, l1)
     assert abs(float(c0[0]) - float(c1[0])) <= 1e-4 * float(c0[0]), (float(c0[0]), float(c1[0]))
     assert float((p0 - p1).abs().max()) <= 2e-5 * float(p0.abs().max()), float((p0 - p1).abs().max())
+
+
+def test_long_clip_subgroups_do_not_change_the_step(dev):
+    """Round 5: the long-clip group cut in two by the bar segment of each clip's longest bar (train.split_long_group; three clip groups, the two
+    long ones with their staves one after the other on one stream each) against the single long-clip group: same loss, gradient norm, update."""
+    import models
+    from piano_a2s_amd import spec, synthetic, train
+    cfg = spec.default_cfg()
+    B = 256
+    batch = synthetic.make_batch(B, cfg, 1234, full_tail=0.01)
+    dbatch = [t.to(dev) if torch.is_tensor(t) else t for t in batch]
+    torch.manual_seed(1234)
+    init = models.ScoreTranscription(**cfg).state_dict()
+    res = []
+    for sub in (False, True):
+        m = models.ScoreTranscription(**cfg)
+        m.load_state_dict(init)
+        m = m.to(dev).train()
+        step = train.TrainStep(m, dropout=False)
+        step.long_subgroups = sub
+        n3 = 0
+        for seed in (99, 100, 101):            # three coin sequences (1 .. 3 bar segments): at least one must make the sub-groups part
+            m.load_state_dict(init)
+            losses = step(dbatch, 0.7, rng=random.Random(seed))
+            torch.cuda.synchronize()
+            n3 += len(step._last[2]) == 3
+            res.append((losses[:, 0].double().cpu(), step.opt.ctl.double().cpu(), len(step._last[2])))
+        if sub:
+            assert n3 >= 1, "no step ran as three clip groups"
+        del step, m
+        torch.cuda.empty_cache()
+    for (l0, c0, g0), (l1, c1, g1) in zip(res[:3], res[3:]):
+        assert g0 == 2 and float(c0[2]) == 1.0 and float(c1[2]) == 1.0
+        assert torch.allclose(l0, l1, rtol=2e-5, atol=0), (l0, l1, g1)
+        assert abs(float(c0[0]) - float(c1[0])) <= 1e-4 * float(c0[0]), (float(c0[0]), float(c1[0]), g1)

@@ -47,8 +47,10 @@ def _report(line):
 
 # (planner settings, clip groups it must form on this minibatch): the default cost model cuts off the one clip with a 398-step upper bar
 # (the way the benchmark's 256-clip minibatches are cut); a latency floor scaled to 12 clips also sends the 189-step lower bar's clip there
-@pytest.mark.parametrize("plan_kw, expect", [({}, [(0, 11), (11, 12)]), ({"step_cost": 4.0}, [(0, 10), (10, 12)])], ids=["default_cost", "step_cost4"])
-def test_reference_step_through_planner(g4, dev, plan_kw, expect):
+# ... and (round 5) the two long clips as sub-groups of their own when their longest bars lie in different bar segments of the step (train.split_long_group)
+@pytest.mark.parametrize("plan_kw, expect, subgroups", [({}, [(0, 11), (11, 12)], False), ({"step_cost": 4.0}, [(0, 10), (10, 12)], False),
+                                                        ({"step_cost": 4.0}, None, True)], ids=["default_cost", "step_cost4", "step_cost4_subgroups"])
+def test_reference_step_through_planner(g4, dev, plan_kw, expect, subgroups):
     import models
     from piano_a2s_amd import spec, train
     from piano_a2s_amd.spec import PAD
@@ -59,6 +61,7 @@ def test_reference_step_through_planner(g4, dev, plan_kw, expect):
     m.train()
     step = train.TrainStep(m, lr=1.0, rho=0.95, eps=1e-8, max_grad_norm=5.0, dropout=False, group_plan=plan_kw)
     step.keep_grads = True
+    step.long_subgroups = subgroups
     rng = random.Random(meta["random_seed"])
     draws = {"n": 0}
 
@@ -69,11 +72,14 @@ def test_reference_step_through_planner(g4, dev, plan_kw, expect):
     dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
     losses = step(dbatch, teacher_forcing_ratio=meta["tf"], rng=Counting())
     torch.cuda.synchronize()
-    tag = "g4[" + (",".join(f"{k}={v}" for k, v in plan_kw.items()) or "default") + "]"
+    tag = "g4[" + (",".join(f"{k}={v}" for k, v in plan_kw.items()) or "default") + (",subgroups" if subgroups else "") + "]"
 
     # --- the planner's control flow really ran
     outs_raw, bar_major, groups, perm = step._last
-    assert [tuple(g) for g in groups] == expect, f"clip groups {groups}"
+    if expect is not None:
+        assert [tuple(g) for g in groups] == expect, f"clip groups {groups}"
+    else:       # (whether the two long clips part depends on the bar segments the seeded coins produce: 2 or 3 groups, both are the planner's control flow)
+        assert len(groups) in (2, 3) and groups[0][0] == 0 and groups[-1][1] == meta["batch"], f"clip groups {groups}"
     assert bar_major and perm is not None and not torch.equal(perm, torch.arange(meta["batch"])), "fused bars + a real clip permutation"
     assert draws["n"] == meta["draws"], f"python-random draws {draws['n']} vs reference {meta['draws']}"
     _report(f"{tag}: clip groups {groups}, permutation {perm.tolist()}, draws {draws['n']}")

@@ -192,7 +192,7 @@ def test_skipping_rows_and_fusing_bars_do_not_change_the_step(dev, tf_ratio, see
                 train.plan_clip_groups = step_plan
         torch.cuda.synchronize()
         if groups:
-            assert len(step._last[2]) == 2, "the step did not run as two clip groups"
+            assert len(step._last[2]) >= 2, "the step did not run as clip groups"
             assert (step._last[3] is not None) == (groups == "plan")
         res.append((losses[:, 0].cpu().clone(), step.opt.ctl.cpu().clone(), step.flat.cpu().clone(), [o.cpu() for o in step.last_outputs]))
     l0, c0, p0, o0 = res[0]
