@@ -703,8 +703,10 @@ def main():
     # One segment for the caching allocator's pool, before anything is timed: a step's tensor shapes follow its coins (how many bars fuse), so new
     # block sizes keep turning up for dozens of steps, and each one the pool cannot serve is a hipMalloc of several GiB -- 50-130 ms during which the
     # step stands still (round 4: `hipMalloc_segments_per_step`).  A trainer that knows its memory budget reserves it up front; so does the bench
-    # (A2S_POOL_RESERVE_GIB, default 200 of the 268 GiB; 0: off).  Blocks are then split off this segment; the per-step count stays in the JSON.
-    pool_gib = float(os.environ.get("A2S_POOL_RESERVE_GIB", "200"))
+    # (A2S_POOL_RESERVE_GIB; 0 = off, the default: measured, the segment only serves allocations made on the stream it was allocated on -- the caching
+    # allocator keeps one pool per stream and the step allocates on four -- so the per-step hipMalloc count did not fall (it stays in the JSON) and
+    # 200 GiB pushed the reserved peak to 239 GiB with an allocator retry).
+    pool_gib = float(os.environ.get("A2S_POOL_RESERVE_GIB", "0"))
 
     def reserve_pool():
         if pool_gib > 0:

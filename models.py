@@ -101,11 +101,10 @@ class ScoreTranscription(nn.Module):
                                     hidden_size=hidden_size, max_bars=max_bars, num_time_sig=num_time_sig, num_keys=num_keys,
                                     max_length=tuple(max_length), note_emb_size=note_emb_size, staff_emb_size=staff_emb_size,
                                     time_sig_emb_size=time_sig_emb_size, key_emb_size=key_emb_size)
-        if hidden_size not in (32, 64, 128, 256):
-            # boundary limitation: the additive-attention kernels keep a key row in registers and are instantiated for
-            # these widths (256 = hparams/*.yaml and the published checkpoints; the split-T / multi-row kernels exist for 256 only, the
-            # narrower widths use the one-workgroup-per-clip kernels); the reference constructor takes any width
-            raise ValueError(f"hidden_size {hidden_size}: the HIP attention kernels are instantiated for 32, 64, 128 and 256")
+        if not (isinstance(hidden_size, int) and 1 <= hidden_size <= 512):
+            # (the reference constructor takes any width; here the one-workgroup-per-clip attention kernels take any width up to 512 -- 256 = hparams/*.yaml
+            # and the published checkpoints runs on the split-T / multi-row / persistent kernels, widths that are multiples of 16 on the fused step kernels)
+            raise ValueError(f"hidden_size {hidden_size}: the HIP attention kernels take widths 1 .. 512")
         self._names = []
         P = {}
         for name, shape in spec.state_spec(self.cfg).items():

@@ -76,13 +76,12 @@ int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const fl
 // Given dctx (= dctx_a + dctx_b) for one step:  da_t = dctx . enc_t ; ds_t = a_t (da_t - dctx . ctx)   [softmax bwd,
 // sum_t a_t da_t = dctx . ctx];  dq_j = sum_t ds_t v_j (1 - e_tj^2), e = tanh(K_tj + q_j).
 // Writes dq (for the W_h / hidden gradient), ds (T per row, for the deferred dK / dv) and the summed dctx.
-template <int H>
 __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                      const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                      const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
                                                      const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
                                                      float* __restrict__ dctx_out, long lddo, float* __restrict__ dq, long lddq,
-                                                     float* __restrict__ ds_out, int T, int n_clips) {
+                                                     float* __restrict__ ds_out, int T, int n_clips, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dsv = sm;                               // T
     float* dc = sm + ((T + 3) & ~3);               // 2H
@@ -112,12 +111,12 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
         }
     }
     __syncthreads();
-    // pass over K: thread j accumulates dq_j over all frames (H <= 256 threads active)
-    if (tid < H) {
-        const float eq = exp2x_clamped(q[(long)b * ldq + tid]), vj = v[tid];      // Kmat holds the key image E_K = exp(2K)
+    // pass over K: thread j accumulates dq_j over all frames
+    for (int j = tid; j < H; j += 256) {
+        const float eq = exp2x_clamped(q[(long)b * ldq + j]), vj = v[j];      // Kmat holds the key image E_K = exp(2K)
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc = fmaf(dsv[t], sech2_ek(Kb[(long)t * H + tid], eq), acc);
-        dq[(long)b * lddq + tid] = acc * vj;
+        for (int t = 0; t < T; ++t) acc = fmaf(dsv[t], sech2_ek(Kb[(long)t * H + j], eq), acc);
+        dq[(long)b * lddq + j] = acc * vj;
     }
 }
 
@@ -134,11 +133,8 @@ int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, 
         return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H, rows);
     const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
-    if (H == 256) hipLaunchKernelGGL(attn_step_bwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
-    else if (H == 128) hipLaunchKernelGGL(attn_step_bwd<128>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
-    else if (H == 64) hipLaunchKernelGGL(attn_step_bwd<64>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
-    else if (H == 32) hipLaunchKernelGGL(attn_step_bwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips);
-    else A2S_FAIL(A2S_ERR_ARG, "attn_step_bwd: hidden_size must be 32, 64, 128 or 256 (got %d)", H);
+    A2S_REQUIRE(H >= 1 && H <= 512, "attn_step_bwd: hidden_size must be in 1 .. 512 (got %d)", H);
+    hipLaunchKernelGGL(attn_step_bwd, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, T, n_clips, H);
     A2S_CHECK_LAUNCH("attn_step_bwd");
     return A2S_OK;
 }
@@ -147,46 +143,48 @@ int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, 
 //   dK[b,t,j] += v_j * sum_s ds[s,b,t] (1 - e^2),  dv_j += sum_{s,b,t} ds[s,b,t] e,   e = tanh(K[b,t,j] + q[s,b,j]).
 // One workgroup per (b, tile of 16 frames); thread j keeps K[t,j] for its 16 frames in registers and streams the
 // S queries -- K is read once, traffic is S*(H + 16) floats per workgroup.  dv partials: [nblocks][H].
-template <int H>
 __global__ __launch_bounds__(256) void attn_dk_accum(const float* __restrict__ Kmat, const float* __restrict__ q_all,
                                                      const float* __restrict__ ds_all, const float* __restrict__ v,
                                                      float* __restrict__ dK, float* __restrict__ dv_partial, int B, int T, int S,
-                                                     const int* __restrict__ row_until, int groups) {
+                                                     const int* __restrict__ row_until, int groups, int H) {
     constexpr int TT = 16;
     const int tiles = (T + TT - 1) / TT;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * TT;
-    const int j = threadIdx.x;
     __shared__ float dss[TT];
-    float kreg[TT], acc[TT];
-    float dvj = 0.f;
-    if (j < H) {
-#pragma unroll
-        for (int i = 0; i < TT; ++i) { kreg[i] = (t0 + i < T) ? Kmat[((long)b * T + t0 + i) * H + j] : 0.f; acc[i] = 0.f; }
-    }
-    // rows of a step: `groups` bars of the same B clips (row = group * B + b); ds is exactly zero from step row_until[row] on
-    for (int sg = 0; sg < S * groups; ++sg) {
-        const int s = sg / groups, grp = sg % groups;
-        if (row_until && s >= row_until[grp * B + b]) continue;          // uniform over the workgroup
-        const long row = (long)sg * B + b;
-        __syncthreads();
-        if (threadIdx.x < TT) dss[threadIdx.x] = (t0 + threadIdx.x < T) ? ds_all[row * T + t0 + threadIdx.x] : 0.f;
-        __syncthreads();
+    for (int j0 = 0; j0 < H; j0 += blockDim.x) {          // (one pass for H <= the block size: every width the recipes use)
+        const int j = j0 + threadIdx.x;
+        float kreg[TT], acc[TT];
+        float dvj = 0.f;
         if (j < H) {
-            const float eq = exp2x_clamped(q_all[row * H + j]);               // kreg holds the key image E_K = exp(2K)
 #pragma unroll
-            for (int i = 0; i < TT; ++i) {
-                const float e = tanh_ek(kreg[i], eq);
-                acc[i] = fmaf(dss[i], 1.f - e * e, acc[i]);
-                dvj = fmaf(dss[i], e, dvj);
+            for (int i = 0; i < TT; ++i) { kreg[i] = (t0 + i < T) ? Kmat[((long)b * T + t0 + i) * H + j] : 0.f; acc[i] = 0.f; }
+        }
+        // rows of a step: `groups` bars of the same B clips (row = group * B + b); ds is exactly zero from step row_until[row] on
+        for (int sg = 0; sg < S * groups; ++sg) {
+            const int s = sg / groups, grp = sg % groups;
+            if (row_until && s >= row_until[grp * B + b]) continue;          // uniform over the workgroup
+            const long row = (long)sg * B + b;
+            __syncthreads();
+            if (threadIdx.x < TT) dss[threadIdx.x] = (t0 + threadIdx.x < T) ? ds_all[row * T + t0 + threadIdx.x] : 0.f;
+            __syncthreads();
+            if (j < H) {
+                const float eq = exp2x_clamped(q_all[row * H + j]);               // kreg holds the key image E_K = exp(2K)
+#pragma unroll
+                for (int i = 0; i < TT; ++i) {
+                    const float e = tanh_ek(kreg[i], eq);
+                    acc[i] = fmaf(dss[i], 1.f - e * e, acc[i]);
+                    dvj = fmaf(dss[i], e, dvj);
+                }
             }
         }
-    }
-    if (j < H) {
-        const float vj = v[j];
+        if (j < H) {
+            const float vj = v[j];
 #pragma unroll
-        for (int i = 0; i < TT; ++i)
-            if (t0 + i < T) dK[((long)b * T + t0 + i) * H + j] += vj * acc[i];
-        dv_partial[(long)blockIdx.x * H + j] = dvj;
+            for (int i = 0; i < TT; ++i)
+                if (t0 + i < T) dK[((long)b * T + t0 + i) * H + j] += vj * acc[i];
+            dv_partial[(long)blockIdx.x * H + j] = dvj;
+        }
+        __syncthreads();
     }
 }
 
@@ -194,11 +192,9 @@ int a2s_attn_dk_accum_impl(hipStream_t st, const float* Kmat, const float* q_all
                            float* dK, float* dv_partial, int B, int T, int S, int H, const int* row_until, int groups) {
     const int nblk = B * a2s_cdiv(T, 16);
     if (groups < 1) groups = 1;
-    if (H == 256) hipLaunchKernelGGL(attn_dk_accum<256>, dim3(nblk), dim3(256), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
-    else if (H == 128) hipLaunchKernelGGL(attn_dk_accum<128>, dim3(nblk), dim3(128), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
-    else if (H == 64) hipLaunchKernelGGL(attn_dk_accum<64>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
-    else if (H == 32) hipLaunchKernelGGL(attn_dk_accum<32>, dim3(nblk), dim3(64), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups);
-    else A2S_FAIL(A2S_ERR_ARG, "attn_dk_accum: hidden_size must be 32, 64, 128 or 256 (got %d)", H);
+    A2S_REQUIRE(H >= 1, "attn_dk_accum: hidden_size must be positive (got %d)", H);
+    const int nth = H >= 256 ? 256 : (H > 128 ? 256 : (H > 64 ? 128 : 64));
+    hipLaunchKernelGGL(attn_dk_accum, dim3(nblk), dim3(nth), 0, st, Kmat, q_all, ds_all, v, dK, dv_partial, B, T, S, row_until, groups, H);
     A2S_CHECK_LAUNCH("attn_dk_accum");
     return A2S_OK;
 }

@@ -293,12 +293,14 @@ int a2s_gru_seq_fwd_impl(hipStream_t st, const float* gi_all, long gi_bstride, l
 // ------------------------------------------------------------------------------------------- attention
 // One workgroup per row (clip).  Pass 1 streams K (T x H): score_t = v . tanh(K_t + q); softmax over T in LDS;
 // pass 2 streams enc (T x 2H): ctx = sum_t a_t enc_t.  Every byte of K and enc is read exactly once.
-template <int H>
+// (round 5: the width H is a run-time argument -- the reference constructor takes any hidden_size -- and only the number of key-row elements a lane
+// holds, PER = ceil(H / 64), is a template parameter)
+template <int PER>
 __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                      const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                      float* __restrict__ ctx, long ldctx, float* __restrict__ ctx2, long ldctx2,
                                                      float* __restrict__ attw, int T, const int* __restrict__ n_done, int n_rows_total,
-                                                     int n_clips) {
+                                                     int n_clips, int H) {
     if (n_done && *n_done >= n_rows_total) return;      // greedy decode: every clip already emitted <eos>
     extern __shared__ __attribute__((aligned(16))) float sm[];   // T scores + 16 reduction slots
     float* sc = sm;
@@ -307,8 +309,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ K
     const int clip = b % n_clips;                       // fused bars: row = bar * n_clips + clip
     const float* Kb = Kmat + (long)clip * T * H;
     const float* Eb = enc + (long)clip * T * 2 * H;
-    constexpr int PER = (H + 63) / 64;                   // elements of a K row per lane
-    float qv[PER], vv[PER];
+    float qv[PER], vv[PER];                               // PER = ceil(H / 64) elements of a K row per lane
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int j = lane + i * 64;
@@ -369,11 +370,19 @@ int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, 
     // one-workgroup-per-row kernels: every row is computed (no skipping); fused bars only change which clip a row reads
     const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 16) * sizeof(float);
-    if (H == 256) hipLaunchKernelGGL(attn_step_fwd<256>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
-    else if (H == 128) hipLaunchKernelGGL(attn_step_fwd<128>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
-    else if (H == 64) hipLaunchKernelGGL(attn_step_fwd<64>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
-    else if (H == 32) hipLaunchKernelGGL(attn_step_fwd<32>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips);
-    else A2S_FAIL(A2S_ERR_ARG, "attn_step_fwd: hidden_size must be 32, 64, 128 or 256 (got %d)", H);
+    A2S_REQUIRE(H >= 1 && H <= 512, "attn_step_fwd: hidden_size must be in 1 .. 512 (got %d)", H);
+#define A2S_ATTN_FWD(P) hipLaunchKernelGGL(attn_step_fwd<P>, dim3(B), dim3(256), shm, st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, T, n_done, n_rows_total, n_clips, H)
+    switch ((H + 63) / 64) {
+        case 1: A2S_ATTN_FWD(1); break;
+        case 2: A2S_ATTN_FWD(2); break;
+        case 3: A2S_ATTN_FWD(3); break;
+        case 4: A2S_ATTN_FWD(4); break;
+        case 5: A2S_ATTN_FWD(5); break;
+        case 6: A2S_ATTN_FWD(6); break;
+        case 7: A2S_ATTN_FWD(7); break;
+        default: A2S_ATTN_FWD(8); break;
+    }
+#undef A2S_ATTN_FWD
     A2S_CHECK_LAUNCH("attn_step_fwd");
     return A2S_OK;
 }

@@ -172,9 +172,10 @@ def test_full_size_seeded_teacher_forcing(golden_dir, dev):
     assert not failures, f"{len(failures)} gradient norms off: {failures[:8]}"
 
 
-@pytest.mark.parametrize("hidden", [64, 128])
+@pytest.mark.parametrize("hidden", [64, 128, 96, 40, 300])
 def test_other_hidden_sizes_forward_and_gradients(dev, hidden):
-    """hidden_size 64 / 128 (the reference constructor takes any width; the HIP attention kernels are instantiated for 32, 64, 128, 256):
+    """hidden_size 64 / 128 and (round 5) widths that are no power of two -- 96, 40 (not a multiple of 16 or 32: the generic step path) and 300 (> 256) -- the
+    reference constructor takes any width, the one-workgroup-per-clip attention kernels take the width as a run-time argument:
     forward log-probabilities, loss and all 83 gradients against the oracle on CPU, train mode, teacher forcing 0.6 (seeded)."""
     import random
     from oracle import model_ref, recipe_ref
