@@ -662,6 +662,13 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
         if (mid) {
             const long tiles = (long)a2s_cdiv(M, 64) * a2s_cdiv(N, mid_tile == 2 ? 32 : 64);
             if (ws && tiles < 256 && K >= 512 && a2s_gemm_workspace_bytes_impl(M, N, batch, 4) <= ws_bytes) splitk = 4;
+            else {
+                // measurement switch (A2S_GEMM_MID_SPLITK=n): split K also when the tiles already fill the chip -- a 64x32 tile walks K = 528 as 17
+                // barrier-separated k-tiles of ~3 us each (latency, not work); n shorter walks + one reduce launch
+                static int force = -1;
+                if (force < 0) { const char* e = getenv("A2S_GEMM_MID_SPLITK"); force = e ? atoi(e) : 0; }
+                if (force > 1 && ws && K >= 512 && a2s_gemm_workspace_bytes_impl(M, N, batch, force) <= ws_bytes) splitk = force;
+            }
         } else {
             const long bm = M <= 16 ? 16 : (M <= 32 ? 32 : 64), bn = M <= 64 ? (M <= 16 ? 64 : (M <= 32 ? 64 : 32)) : 64;
             const long tiles = (long)a2s_cdiv(M, bm) * a2s_cdiv(N, bn) * batch;
