@@ -10,8 +10,9 @@ backward, (gradient all-reduce,) clip_grad_norm_(5.0) + Adadelta -- piano_a2s_am
 
 Rank 0 prints ONE JSON line.  Workload (config.workload): BASELINE.json configs[1], the pretrain.yaml model on synthetic clips as
 SURVEY.md 8(d) specifies them -- including the 1 % tail of full-length (398 / 189 token, no <eos>) bars; `tail_off` repeats the
-measurement without that tail (round 1's default workload).  `roofline` describes the dominant kernel by GPU time, the 40-channel 3x3
-convolution (split-operand bf16 MFMA), measured live on conv4's forward launch; `roofline_attention` the HBM-bound additive-attention
+measurement without that tail (round 1's default workload).  `roofline` describes the 40-channel 3x3 convolution (two-term fp16 MFMA), measured
+live on conv4's forward launch; `roofline_phases` (round 5) EVERY phase of the step -- ConvStack forward / backward, encoder forward / backward,
+decoder -- against both roofs, from HIP events in this very run; `roofline_attention` the HBM-bound additive-attention
 step (streams a clip's keys and encoder outputs once per decode step); `loss_parity` checks the full-size model's loss against the
 reference's own CPU numbers in this very run; `cpu_baseline` is the oracle's as-written CPU restatement of the same training step timed
 on this box's host cores on a bounded sample (a reported baseline, not the target); with N > 1 `data_parallel` lists each rank's decode
