@@ -58,6 +58,8 @@ int a2s_gru_persist_enabled(void);
 void a2s_dec_persist_set(int);
 void a2s_gru_persist_alone_set(int);
 int a2s_gru_persist_alone(void);
+void a2s_attn_deep_set(int);
+int a2s_attn_deep_max_clips(void);
 void a2s_attn_pace_set(int);
 int a2s_attn_pace_enabled(void);
 void a2s_attn_pace_min_set(int);
@@ -218,6 +220,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_nt")) { a2s_attn_nt_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_bulk_cap")) { a2s_attn_bulk_cap_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_pace")) { a2s_attn_pace_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_deep")) { a2s_attn_deep_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_pace_min")) { a2s_attn_pace_min_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
@@ -245,6 +248,7 @@ int a2s_persist_abort_latch(void* device_word) { a2s_persist_latch_set(device_wo
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_bulk_cap")) return a2s_attn_bulk_cap_enabled();
     if (key && !strcmp(key, "attn_pace")) return a2s_attn_pace_enabled();
+    if (key && !strcmp(key, "attn_deep")) return a2s_attn_deep_max_clips();
     if (key && !strcmp(key, "attn_pace_min")) return a2s_attn_pace_min();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();

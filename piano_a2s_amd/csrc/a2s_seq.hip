@@ -1159,6 +1159,138 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
 }
 
 
+
+// ---- few-clip form of the sweep (round 5).  The kernels above stream a chunk in rounds of 4 frames per wave / 4 rows per thread -- 5 + 10 dependent
+// load rounds for a 76-frame chunk -- which is right for a launch that fills the chip many times over and wrong for the long-clip chain, where a launch
+// covers a handful of clips, every workgroup has a CU to itself and the kernel's time IS its dependent round trips (each 2-3x longer while the bulk group's
+// sweeps saturate the memory: DESIGN.md section 3.4).  Here every load of the chunk is issued before anything is waited for: 8 waves, a wave holds the
+// key rows of its <= 10 frames, a thread its float4 column of <= 20 encoder rows (116 registers), ONE round trip.  Same partial layout and raw scores
+// as attn_fwd_split256[_mq]: the combine kernel does not change.  Launches over at most A2S_ATTN_DEEP (default 24) clips, chunks of <= 80 frames.
+template <int NQ>
+__global__ __launch_bounds__(512) void attn_fwd_split256_deep(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                              const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                              float* __restrict__ partial, float* __restrict__ scores, int T, int G, int chunk,
+                                                              const int* __restrict__ clip_order, const int* __restrict__ row_until,
+                                                              int step, int n_clips) {
+    constexpr int H = 256, KF = 10, ER = 20;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pw = sm;                                   // NQ x chunk scores / weights
+    float* red = sm + NQ * chunk;                     // 16 + NQ * 3 * 128 * 4 floats
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = clip_order ? clip_order[slot] : slot;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 127, rp = tid >> 7;          // pass 2: float4 column, row residue mod 4
+    const float* Kb = Kmat + ((long)b * T + t0) * H;
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    bool on[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) on[j] = !row_until || step < row_until[j * n_clips + b];
+    // ---- every load of the chunk, then the queries
+    f32x4 k[KF], e[ER];
+#pragma unroll
+    for (int u = 0; u < KF; ++u) {
+        const int f = wave + 8 * u;
+        k[u] = f < n ? *reinterpret_cast<const f32x4*>(Kb + (long)f * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int m = 0; m < ER; ++m) {
+        const int i = rp + 4 * m;
+        e[m] = i < n ? *reinterpret_cast<const f32x4*>(Eb + (long)i * 2 * H + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 q4[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+        q4[j] = on[j] ? *reinterpret_cast<const f32x4*>(q + ((long)j * n_clips + b) * ldq + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 v4 = {v[lane * 4], v[lane * 4 + 1], v[lane * 4 + 2], v[lane * 4 + 3]};
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);
+    // ---- pass 1: scores (one wave per frame)
+#pragma unroll
+    for (int u = 0; u < KF; ++u) {
+        const int f = wave + 8 * u;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            float sj = v4[0] * tanh_ek(k[u][0], q4[j][0]) + v4[1] * tanh_ek(k[u][1], q4[j][1])
+                     + v4[2] * tanh_ek(k[u][2], q4[j][2]) + v4[3] * tanh_ek(k[u][3], q4[j][3]);
+            sj = wave_sum_lane63(sj);
+            if (lane == 63 && f < n) pw[j * chunk + f] = sj;
+        }
+    }
+    __syncthreads();
+    float mj[NQ], lj[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        mj[j] = 0.f; lj[j] = 0.f;
+        if (!on[j]) continue;                          // uniform over the workgroup
+        const float sc = tid < n ? pw[j * chunk + tid] : -INFINITY;          // (n <= 80 < 512: one score per thread)
+        const float m = block_max(sc, red);
+        const float p = tid < n ? __expf(sc - m) : 0.f;
+        if (tid < n) {
+            if (scores) scores[((long)j * n_clips + b) * T + t0 + tid] = sc;
+            pw[j * chunk + tid] = p;
+        }
+        lj[j] = block_sum(p, red);
+        mj[j] = m;
+    }
+    __syncthreads();
+    // ---- pass 2: partial contexts from the rows already in registers
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < ER; ++m) {
+        const int i = rp + 4 * m;
+        if (i < n) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (!on[j]) continue;
+                const float w = pw[j * chunk + i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, e[m][c], acc[j][c]);
+            }
+        }
+    }
+    f32x4* red4 = reinterpret_cast<f32x4*>(red + 16);
+    if (rp > 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) red4[(j * 3 + rp - 1) * 128 + c4] = acc[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        if (!on[j]) continue;
+        float* pout = partial + (((long)slot * NQ + j) * G + g) * (2 * H + 4);
+        if (rp == 0) {
+            f32x4 a = acc[j];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const f32x4 o = red4[(j * 3 + w) * 128 + c4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] += o[c];
+            }
+            *reinterpret_cast<f32x4*>(pout + 4 + c4 * 4) = a;
+        }
+        if (tid == 0) { pout[0] = mj[j]; pout[1] = lj[j]; }
+    }
+}
+static int g_attn_deep = -1;
+void a2s_attn_deep_set(int v) { g_attn_deep = v < 0 ? 0 : v; }
+int a2s_attn_deep_max_clips(void) {
+    if (g_attn_deep < 0) { const char* e = getenv("A2S_ATTN_DEEP"); g_attn_deep = e ? atoi(e) : 24; if (g_attn_deep < 0) g_attn_deep = 0; }
+    return g_attn_deep;
+}
+template <int NQ>
+static void launch_fwd_deep(hipStream_t st, int nwg, const float* Kmat, const float* enc, const float* q, long ldq, const float* v, float* ws, float* attw,
+                            int T, int G, int chunk, const a2s_attn_rows& r) {
+    const size_t shm = ((size_t)NQ * chunk + 16 + (size_t)NQ * 3 * 128 * 4) * sizeof(float);
+    hipLaunchKernelGGL((attn_fwd_split256_deep<NQ>), dim3(nwg), dim3(512), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk, r.clip_order, r.row_until, r.step,
+                       r.n_clips);
+}
+
 // ------------------------------------------------------------------------------------------- the bandwidth token of the bulk attention launches
 // Round 5.  The two staves of a clip group run their step loops on two streams.  A decode step is  A  (the attention sweep: HBM-bound, ~150 us
 // over 248 clips) followed by  S  (the step's small dependent kernels: ~130-200 us).  Left alone the two streams fall INTO phase -- two
@@ -1329,7 +1461,15 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
         // the grid covers the clips that still have unfinished rows, re-split so that it still fills the chip
         if (r.n_active > 0) a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G + n_zero;
-        if (groups == 1) {
+        if (!fused && !n_done && groups <= 4 && r.n_active <= a2s_attn_deep_max_clips() && chunk <= 80) {       // the few-clip form: every load of a chunk in one round trip
+            // (five fused bars: the instantiation needs scratch; measured slower on the one-segment steps, which are the only ones that fuse five)
+            switch (groups) {
+                case 1: launch_fwd_deep<1>(st, nwg, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r); break;
+                case 2: launch_fwd_deep<2>(st, nwg, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r); break;
+                case 3: launch_fwd_deep<3>(st, nwg, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r); break;
+                default: launch_fwd_deep<4>(st, nwg, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, r); break;
+            }
+        } else if (groups == 1) {
             const size_t shm = a2s_attn_bulk_lds((chunk + 16 + 128 * 4) * sizeof(float), r.n_active, 0);
             if (nt) hipLaunchKernelGGL(attn_fwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
             else hipLaunchKernelGGL(attn_fwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
