@@ -44,7 +44,7 @@ int a2s_gru_gates_fwd_impl(hipStream_t, const float*, long, const float*, long, 
 int a2s_gru_seq_fwd_impl(hipStream_t, const float*, long, long, const float*, const float*, float*, long, long, float*, float*,
                          float*, float*, int, int, int, int, float*, size_t);
 int a2s_attn_step_fwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, float*, long, float*, long,
-                           float*, int, int, int, const int*, int, float*, const a2s_attn_rows*);
+                           float*, int, int, int, const int*, int, float*, const a2s_attn_rows*, a2s_attn_deferred* = nullptr);
 size_t a2s_attn_workspace_floats_impl(int, int, int, int);
 int a2s_log_softmax_rows_impl(hipStream_t, const float*, long, float*, long, int*, int, int);
 int a2s_embed_rows_impl(hipStream_t, const float*, const long long*, const int*, long, int, float*, long, int, int, int, const uint8_t*, float);
@@ -59,6 +59,8 @@ void a2s_dec_persist_set(int);
 void a2s_gru_persist_alone_set(int);
 int a2s_gru_persist_alone(void);
 void a2s_attn_deep_set(int);
+void a2s_attn_defer_combine_set(int);
+int a2s_attn_defer_combine_enabled(void);
 int a2s_attn_deep_max_clips(void);
 void a2s_attn_pace_set(int);
 int a2s_attn_pace_enabled(void);
@@ -221,6 +223,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_bulk_cap")) { a2s_attn_bulk_cap_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_pace")) { a2s_attn_pace_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_deep")) { a2s_attn_deep_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_defer_combine")) { a2s_attn_defer_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_pace_min")) { a2s_attn_pace_min_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
@@ -249,6 +252,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_bulk_cap")) return a2s_attn_bulk_cap_enabled();
     if (key && !strcmp(key, "attn_pace")) return a2s_attn_pace_enabled();
     if (key && !strcmp(key, "attn_deep")) return a2s_attn_deep_max_clips();
+    if (key && !strcmp(key, "attn_defer_combine")) return a2s_attn_defer_combine_enabled();
     if (key && !strcmp(key, "attn_pace_min")) return a2s_attn_pace_min();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();

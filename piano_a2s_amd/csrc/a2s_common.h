@@ -110,6 +110,15 @@ struct a2s_attn_rows {
     int step;
 };
 #define A2S_ATTN_MAX_GROUPS 5
+// A forward attention launch whose combine has been left to its consumer (round 5: the few-row GRU step folds it into its prologue -- one
+// launch and one dependent-launch gap less per decode step on the long-clip chain, where a launch costs ~20 us + ~18 us of gap under the
+// other clip group's traffic: profiles/r05_trace_overlap.txt).  G == 0: nothing deferred, the combine has run.
+struct a2s_attn_deferred {
+    const float* part;       // partials [m, l, pad, pad, ctx(2H)] of (slot, group, g), as the combine kernel reads them
+    float* attw;             // raw scores of the step, (R, T), to be normalised in place (or NULL)
+    const int* clip_rank; const int* row_until;
+    int G, groups, n_clips, n_active, step, T;
+};
 // head of the attention workspace: arrival counters of the fused combine (forward: [0, 4096), backward: [4096, 8192)), in floats
 #define A2S_ATTN_TICKETS 8192
 
@@ -162,6 +171,20 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_take<A2S_DPP_ROW_BCAST15, 0xA, false>(v, v));
     v = fmaxf(v, dpp_take<A2S_DPP_ROW_BCAST31, 0xC, false>(v, v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// Merge weights of a row's attention partials, one partial per lane (lanes without one: have = false): e = exp(m_g - m) / l with m the row's
+// maximum and l = sum_g l_g exp(m_g - m).  ONE definition with floating-point contraction off, so that the combine kernel (a2s_seq.hip) and the
+// GRU step that folds the combine into its prologue (a2s_step.hip) produce the same bits wherever the compiler inlines it.
+__device__ __forceinline__ float attn_merge_weight(float mg, float lg, bool have, float& m_out, float& inv_l_out) {
+#pragma clang fp contract(off)
+    const float m = wave_max(mg);
+    const float d = mg - m;
+    const float e = have ? __expf(d) : 0.f;
+    const float t = lg * e;
+    const float l = wave_sum(t);
+    m_out = m;
+    inv_l_out = 1.f / l;
+    return e / l;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

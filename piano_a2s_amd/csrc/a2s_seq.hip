@@ -358,15 +358,19 @@ __global__ __launch_bounds__(256) void attn_step_fwd(const float* __restrict__ K
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
-                                 const int* n_done, int n_rows_total, const a2s_attn_rows* rows);
+                                 const int* n_done, int n_rows_total, const a2s_attn_rows* rows, a2s_attn_deferred* defer = nullptr);
 
+int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                           float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
+                           const int* n_done, int n_rows_total, float* ws, const a2s_attn_rows* rows = nullptr, a2s_attn_deferred* defer = nullptr);
 // rows (optional, split kernels only): which rows are computed and how they group by clip -- see a2s_attn_rows.  Used by the fused
 // training step: once a row's remaining targets are all <pad> nothing that reaches the loss depends on it any more.
 int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H,
-                           const int* n_done, int n_rows_total, float* ws, const a2s_attn_rows* rows = nullptr) {
+                           const int* n_done, int n_rows_total, float* ws, const a2s_attn_rows* rows, a2s_attn_deferred* defer) {
+    if (defer) defer->G = 0;
     if (H == 256 && ws)
-        return a2s_attn_step_fwd_split_impl(st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, ws, B, T, H, n_done, n_rows_total, rows);
+        return a2s_attn_step_fwd_split_impl(st, Kmat, enc, q, ldq, v, ctx, ldctx, ctx2, ldctx2, attw, ws, B, T, H, n_done, n_rows_total, rows, defer);
     // one-workgroup-per-row kernels: every row is computed (no skipping); fused bars only change which clip a row reads
     const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 16) * sizeof(float);
@@ -513,7 +517,7 @@ typedef a2s_note_dec_args NoteDecArgs;   // one definition only: the public C st
 
 bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats, bool greedy = false);
 int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last,
-                            int nrows, const int* rowmap);
+                            int nrows, const int* rowmap, const a2s_attn_deferred* defer = nullptr);
 // rows the fused step of step t would cover: all R, or (training, finished rows skipped) the rows still running, a prefix of row_list
 static int note_step_rows(const NoteDecArgs& a, int t) { return (a.row_list && a.n_rows_active && t >= 0) ? a.n_rows_active[t] : a.R; }
 static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
@@ -538,12 +542,14 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
         float* xs = a.x + (long)si * a.R * ldx;
         float* os = a.o + (long)sv * a.R * 2 * H2;
         a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : a.R, a.n_active ? a.n_active[t] : 0, t};
+        a2s_attn_deferred defer;
+        defer.G = 0;
         int rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, a.q + (long)sv * a.R * a.H, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
                                         a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws,
-                                        a.n_active ? &rows_v : nullptr);
+                                        a.n_active ? &rows_v : nullptr, (a.gt && a.n_active && !t_base) ? &defer : nullptr);
         if (rc) return rc;
         const int nrows = note_step_rows(a, t_base ? -1 : t);
-        return a2s_note_step_fused_fwd(st, a, si, so, sv, sv_next, t, t_base, tf, last, nrows, nrows < a.R ? a.row_list : nullptr);
+        return a2s_note_step_fused_fwd(st, a, si, so, sv, sv_next, t, t_base, tf, last, nrows, nrows < a.R ? a.row_list : nullptr, defer.G > 0 ? &defer : nullptr);
     }
     // Rows the per-step products run on: all R, or -- late in a large call, when only a few leading clips still have an unfinished row --
     // the first m clips of every fused bar (batch = bars, row stride n_clips).  The elementwise kernels below keep running over all rows:
@@ -856,12 +862,10 @@ __device__ __forceinline__ void attn_combine_row(const volatile float* pb, int G
     for (int u = 0; u < 8; ++u) sv[u] = (o.attw && tid + 256 * u < o.T) ? aw[tid + 256 * u] : 0.f;
     __syncthreads();                                  // wgt free (previous row / the caller's scratch)
     if (tid < 64) {                                   // G <= 64 (a2s_attn_max_split)
-        const float m = wave_max(mg);
-        const float e = have ? __expf(mg - m) : 0.f;
-        const float l = wave_sum(lg * e);
-        wgt[tid] = e / l;
+        float m, inv_l;
+        wgt[tid] = attn_merge_weight(mg, lg, have, m, inv_l);
         if (tid < 16) wgt[64 + tid] = 0.f;
-        if (tid == 0) { wgt[79] = m; wgt[78] = 1.f / l; }
+        if (tid == 0) { wgt[79] = m; wgt[78] = inv_l; }
     }
     __syncthreads();
     float acc0 = 0.f, acc1 = 0.f;
@@ -1283,6 +1287,13 @@ int a2s_attn_deep_max_clips(void) {
     if (g_attn_deep < 0) { const char* e = getenv("A2S_ATTN_DEEP"); g_attn_deep = e ? atoi(e) : 24; if (g_attn_deep < 0) g_attn_deep = 0; }
     return g_attn_deep;
 }
+// Combine of the few-clip training launches folded into the GRU step (A2S_ATTN_DEFER_COMBINE=0 / a2s_debug_set("attn_defer_combine", 0): off)
+static int g_attn_defer = -1;
+void a2s_attn_defer_combine_set(int v) { g_attn_defer = v ? 1 : 0; }
+int a2s_attn_defer_combine_enabled(void) {
+    if (g_attn_defer < 0) { const char* e = getenv("A2S_ATTN_DEFER_COMBINE"); g_attn_defer = (e && e[0] == '0') ? 0 : 1; }
+    return g_attn_defer;
+}
 template <int NQ>
 static void launch_fwd_deep(hipStream_t st, int nwg, const float* Kmat, const float* enc, const float* q, long ldq, const float* v, float* ws, float* attw,
                             int T, int G, int chunk, const a2s_attn_rows& r) {
@@ -1430,7 +1441,7 @@ static void launch_fwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat
 
 int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, float* ws, int B, int T, int H,
-                                 const int* n_done, int n_rows_total, const a2s_attn_rows* rows) {
+                                 const int* n_done, int n_rows_total, const a2s_attn_rows* rows, a2s_attn_deferred* defer) {
     A2S_REQUIRE(H == 256 && ws, "attn_step_fwd_split: needs hidden_size 256 and a workspace");
     A2S_REQUIRE(ldq % 4 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)Kmat % 16 == 0) && ((uintptr_t)enc % 16 == 0), "attn_step_fwd_split: 16-byte alignment");
     a2s_attn_rows r = {nullptr, nullptr, nullptr, B, B, 0};
@@ -1485,6 +1496,11 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
         A2S_CHECK_LAUNCH("attn_fwd_split256");
     }
     if (fused) { a2s_attn_pace_release_impl(st, pace_token); return A2S_OK; }
+    // the few-clip launches of a training step leave the combine to the GRU step that consumes the contexts (a2s_step.hip: dec_gru_step_cmb)
+    if (defer && !n_done && !pace_token && r.n_active > 0 && r.n_active <= a2s_attn_deep_max_clips() && groups <= 4 && G <= 16 && a2s_attn_defer_combine_enabled()) {
+        *defer = a2s_attn_deferred{part, attw, r.clip_rank, r.row_until, G, groups, r.n_clips, r.n_active, r.step, T};
+        return A2S_OK;
+    }
     hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, part, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total,
                        r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step, pace_token);
     A2S_CHECK_LAUNCH("attn_fwd_combine256");

@@ -27,7 +27,7 @@ int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float*
                   int batch, long bsA, long bsB, long bsC, int splitk, float* ws, size_t ws_bytes);
 int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            float* ctx, long ldctx, float* ctx2, long ldctx2, float* attw, int B, int T, int H, const int* n_done, int n_rows,
-                           float* ws, const a2s_attn_rows* rows);
+                           float* ws, const a2s_attn_rows* rows, a2s_attn_deferred* defer = nullptr);
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
                            float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws, const a2s_attn_rows* rows);
@@ -121,6 +121,24 @@ __device__ __forceinline__ void mfma_rows8_rt(const float* const (&arow)[RT], co
 }
 
 // ------------------------------------------------------------------------------------------- forward: GRU cell
+// GRU cell of one (row, hidden unit) from the four product sums (reference models.py NoteDecoder's nn.GRU): ONE definition with floating-point
+// contraction off, so that every kernel that ends in it (dec_gru_step, its row-tiled and combine-folding forms) rounds alike.
+struct GruCellOut { float rg, zg, ng, ghn, hn; };
+__device__ __forceinline__ GruCellOut gru_cell(float ar, float az, float an, float ahn, float br, float bz, float bin, float bhn, float hp) {
+#pragma clang fp contract(off)
+    GruCellOut o;
+    o.ghn = ahn + bhn;
+    o.rg = fast_sigmoid(ar + br);
+    o.zg = fast_sigmoid(az + bz);
+    const float pre = an + bin;
+    const float gate = o.rg * o.ghn;
+    o.ng = fast_tanh(pre + gate);
+    const float keep = (1.f - o.zg) * o.ng;
+    const float carry = o.zg * hp;
+    o.hn = keep + carry;
+    return o;
+}
+
 struct DecGruArgs {
     const float* x; long ldx; int kx;                   // (R, ldx) rows [token | ctx]; kx = E + 2H
     const float* h;                                     // (R, H2) previous state
@@ -169,11 +187,8 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
     for (int r = 0; r < 4; ++r) {
         if (row0 + lk * 4 + r >= R) continue;
         const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
-        const float ghn = acc[3][r] + bhn;
-        const float rg = fast_sigmoid(acc[0][r] + br);
-        const float zg = fast_sigmoid(acc[1][r] + bz);
-        const float ng = fast_tanh(acc[2][r] + bin + rg * ghn);
-        const float hn = (1.f - zg) * ng + zg * hp[r];
+        const GruCellOut cell = gru_cell(acc[0][r], acc[1][r], acc[2][r], acc[3][r], br, bz, bin, bhn, hp[r]);
+        const float rg = cell.rg, zg = cell.zg, ng = cell.ng, ghn = cell.ghn, hn = cell.hn;
         a.hout[(long)row * H2 + j] = hn;
         a.o[(long)row * a.ldo + j] = hn;
         if (a.save) {
@@ -183,6 +198,173 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
     }
 }
 
+
+// ---- dec_gru_step with the attention combine of its rows folded into the prologue (round 5; few-clip training launches: a2s_attn_deferred).
+// On the long-clip group's chain a decode step was  sweep -> combine -> GRU step -> output step,  and under the other clip group's traffic a
+// launch costs ~20 us of fixed time plus ~18 us of gap however little it does (profiles/r05_trace_overlap.txt: the combine 23 us median for a few
+// hundred KB).  Here every workgroup of the GRU step (32 hidden-unit tiles x row blocks) merges the G partials of ITS <= 16 rows into LDS --
+// redundantly: rows x G x 2 KB from L2 per workgroup, and late in a bar segment only 1-3 rows still run -- and reads the context k-steps of
+// its A operand from there; workgroup x < 16 of a row block also writes row x's context where the combine kernel wrote it (the GRU input row:
+// the deferred weight gradients read it; the output step's operand row), workgroup 16 + x normalises row x's saved scores, and every
+// workgroup zero-fills its share of the rows the attention skipped.  Arithmetic and summation order are the combine kernel's
+// (attn_combine_row) and dec_gru_step's: either path gives the same bits.  Requires H2 == 512 (one context column per thread).
+struct DecCmbArgs {
+    const float* part; float* attw; float* xw;          // partials; raw scores (Rall, T) or null; the GRU input rows, writable (row stride a.ldx)
+    const int* clip_rank; const int* row_until;
+    int G, groups, n_clips, n_active, step, T, Rall, E;
+};
+#define CMB_LD 516                 // floats per context row in LDS (rows land 4 banks apart: conflict-free 16-byte fragment reads)
+#define CMB_PS 516                 // floats per partial: [m, l, pad, pad, ctx(512)]
+
+template <int NT, int CH>
+__device__ __forceinline__ void mfma_rows8_split(const float* __restrict__ arow, int ke, const float* lrow, const float* const (&brow)[NT], int ksteps,
+                                                 int wave, int lk, f32x4 (&acc)[NT]) {
+    // as mfma_rows8; k-steps u < ke come from the global row, the others from the LDS row (columns 16 (u - ke) ..)
+    for (int u0 = wave; u0 < ksteps; u0 += NW * CH) {
+        f32x4 a[CH], b[NT][CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int u = u0 + NW * c;
+            const bool ok = u < ksteps;
+            a[c] = ok ? (u < ke ? *reinterpret_cast<const f32x4*>(arow + 16 * u + 4 * lk) : *reinterpret_cast<const f32x4*>(lrow + 16 * (u - ke) + 4 * lk))
+                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NT; ++g)
+                b[g][c] = ok ? *reinterpret_cast<const f32x4*>(brow[g] + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (u0 + NW * c >= ksteps) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < NT; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[g][c][j], acc[g], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * NW) void dec_gru_step_cmb(DecGruArgs a, DecCmbArgs c) {
+    __shared__ f32x4 part[4 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float ctxs[16 * CMB_LD];
+    __shared__ float cw[16 * 20];                         // per row: weights of the G partials [0, 16), max [16], 1 / sum [17], row computed [18]
+    __shared__ int cbase[16];                             // per row: index of its first partial
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H2 = a.H2, R = a.R;
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
+    const int nb = min(16, R - row0);
+    const int li = lane & 15, lk = lane >> 4;
+    const int j = j0 + li;
+    // ---- rows of the call that the attention skipped this step: zeros where the combine kernel wrote zeros
+    {
+        const int nwg = gridDim.x * gridDim.y, w = blockIdx.y * gridDim.x + blockIdx.x;
+        for (int b = w; b < c.Rall; b += nwg) {
+            const int clip = b % c.n_clips;
+            const int slot = c.clip_rank ? c.clip_rank[clip] : clip;
+            if (slot >= c.n_active || (c.row_until && c.step >= c.row_until[b])) {
+                c.xw[(long)b * a.ldx + c.E + tid] = 0.f;
+                a.o[(long)b * a.ldo + H2 + tid] = 0.f;
+                if (c.attw) for (int t = tid; t < c.T; t += 64 * NW) c.attw[(long)b * c.T + t] = 0.f;
+            }
+        }
+    }
+    float hp[4], br = 0.f, bz = 0.f, bin = 0.f, bhn = 0.f;
+    if (wave == 0) {                                      // epilogue operands: in flight while everything else runs
+        br = a.b_ih[j] + a.b_hh[j]; bz = a.b_ih[H2 + j] + a.b_hh[H2 + j]; bin = a.b_ih[2 * H2 + j]; bhn = a.b_hh[2 * H2 + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hp[r] = a.h[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * H2 + j];
+    }
+    // ---- softmax statistics of the block's rows: wave w takes rows 2 w, 2 w + 1 (lanes, reductions and expressions of attn_combine_row)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int i = 2 * wave + rr;
+        if (i >= nb) break;
+        const int b = dec_row(a.rowmap, row0 + i);
+        const int clip = b % c.n_clips, grp = b / c.n_clips;
+        const int slot = c.clip_rank ? c.clip_rank[clip] : clip;
+        const bool on = slot < c.n_active && !(c.row_until && c.step >= c.row_until[b]);
+        if (on) {
+            const int base = slot * c.groups + grp;
+            const float* pb = c.part + (long)base * c.G * CMB_PS;
+            const bool have = lane < c.G;
+            const float mg = have ? pb[(long)lane * CMB_PS] : -INFINITY, lg = have ? pb[(long)lane * CMB_PS + 1] : 0.f;
+            float m, inv_l;
+            const float wg = attn_merge_weight(mg, lg, have, m, inv_l);
+            if (lane < 16) cw[i * 20 + lane] = wg;
+            if (lane == 0) { cw[i * 20 + 16] = m; cw[i * 20 + 17] = inv_l; cw[i * 20 + 18] = 1.f; cbase[i] = base; }
+        } else if (lane == 0) { cw[i * 20 + 18] = 0.f; cbase[i] = 0; }
+    }
+    __syncthreads();
+    // ---- contexts: thread = column, two rows' partials in flight at a time; acc = fma chain over the partials in order, as the combine kernel
+    for (int i0 = 0; i0 < nb; i0 += 2) {
+        float p[2][16];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int i = min(i0 + rr, nb - 1);
+            const bool on = cw[i * 20 + 18] != 0.f;
+            const float* pb = c.part + (long)cbase[i] * c.G * CMB_PS + 4 + tid;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) p[rr][u] = (on && u < c.G) ? pb[(long)u * CMB_PS] : 0.f;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int i = i0 + rr;
+            if (i >= nb) break;
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fmaf(p[rr][u], cw[i * 20 + u], acc);
+            ctxs[i * CMB_LD + tid] = acc;
+        }
+    }
+    __syncthreads();
+    // ---- what the combine kernel left in memory: row x's context (workgroup x), row x's normalised weights (workgroup 16 + x)
+    if ((int)blockIdx.x < nb) {
+        const int i = blockIdx.x;
+        const long row = dec_row(a.rowmap, row0 + i);
+        const float v = ctxs[i * CMB_LD + tid];
+        c.xw[row * a.ldx + c.E + tid] = v;
+        a.o[row * a.ldo + H2 + tid] = v;
+    } else if ((int)blockIdx.x >= 16 && (int)blockIdx.x - 16 < nb && c.attw) {
+        const int i = blockIdx.x - 16;
+        float* aw = c.attw + (long)dec_row(a.rowmap, row0 + i) * c.T;
+        const bool on = cw[i * 20 + 18] != 0.f;
+        const float m = cw[i * 20 + 16], inv = cw[i * 20 + 17];
+        float sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sv[u] = (on && tid + 64 * NW * u < c.T) ? aw[tid + 64 * NW * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (tid + 64 * NW * u < c.T) aw[tid + 64 * NW * u] = on ? __expf(sv[u] - m) * inv : 0.f;
+        for (int t = tid + 4 * 64 * NW; t < c.T; t += 64 * NW) aw[t] = on ? __expf(aw[t] - m) * inv : 0.f;       // (T > 2048 only)
+    }
+    // ---- the GRU products, as dec_gru_step; the context k-steps of the A operand come from LDS
+    const int arow_i = dec_row(a.rowmap, min(row0 + li, R - 1));
+    const float* lrow = ctxs + min(li, nb - 1) * CMB_LD;
+    const float* bi[3];
+    const float* bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { bi[g] = a.w_ih + ((long)g * H2 + j0 + li) * a.kx; bh[g] = a.w_hh + ((long)g * H2 + j0 + li) * H2; }
+    f32x4 t[3], u[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) t[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows8_split<3, 4>(a.x + (long)arow_i * a.ldx, c.E / 16, lrow, bi, a.kx / 16, wave, lk, t);          // gi: r, z, n
+    u[0] = t[0]; u[1] = t[1]; u[2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows8<3, 4>(a.h + (long)arow_i * H2, bh, H2 / 16, wave, lk, u);               // + gh on r, z; gh_n apart
+    f32x4 acc[4] = {u[0], u[1], t[2], u[2]};
+    reduce_waves<4>(acc, part, wave, lane);
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (row0 + lk * 4 + r >= R) continue;
+        const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
+        const GruCellOut cell = gru_cell(acc[0][r], acc[1][r], acc[2][r], acc[3][r], br, bz, bin, bhn, hp[r]);
+        const float rg = cell.rg, zg = cell.zg, ng = cell.ng, ghn = cell.ghn, hn = cell.hn;
+        a.hout[(long)row * H2 + j] = hn;
+        a.o[(long)row * a.ldo + j] = hn;
+        if (a.save) {
+            float* sv = a.save + (long)row * 4 * H2;
+            sv[j] = rg; sv[H2 + j] = zg; sv[2 * H2 + j] = ng; sv[3 * H2 + j] = ghn;
+        }
+    }
+}
 
 // dec_gru_step over RT x 16 rows per workgroup (same arithmetic, same summation order per output: k-steps round robin over the 8 waves, fixed-order tree)
 template <int RT>
@@ -236,11 +418,8 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step_rt(DecGruArgs a) {
         for (int r = 0; r < 4; ++r) {
             if (row0 + rt * 16 + lk * 4 + r >= R) continue;
             const int row = dec_row(a.rowmap, row0 + rt * 16 + lk * 4 + r);
-            const float ghn = acc[rt * 4 + 3][r] + bhn;
-            const float rg = fast_sigmoid(acc[rt * 4 + 0][r] + br);
-            const float zg = fast_sigmoid(acc[rt * 4 + 1][r] + bz);
-            const float ng = fast_tanh(acc[rt * 4 + 2][r] + bin + rg * ghn);
-            const float hn = (1.f - zg) * ng + zg * hp[rt][r];
+            const GruCellOut cell = gru_cell(acc[rt * 4 + 0][r], acc[rt * 4 + 1][r], acc[rt * 4 + 2][r], acc[rt * 4 + 3][r], br, bz, bin, bhn, hp[rt][r]);
+            const float rg = cell.rg, zg = cell.zg, ng = cell.ng, ghn = cell.ghn, hn = cell.hn;
             a.hout[(long)row * H2 + j] = hn;
             a.o[(long)row * a.ldo + j] = hn;
             if (a.save) {
@@ -577,7 +756,7 @@ bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, i
 // ------------------------------------------------------------------------------------------- forward step (after the attention)
 // nrows / rowmap: the step covers rows rowmap[0 .. nrows) of the call's R rows (rowmap NULL: rows 0 .. nrows = R)
 int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last,
-                            int nrows, const int* rowmap) {
+                            int nrows, const int* rowmap, const a2s_attn_deferred* defer) {
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
     int* flags = reinterpret_cast<int*>(a.step_ws);
     const bool greedy = a.gt == nullptr;
@@ -591,6 +770,15 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
     g.rowmap = rowmap;
     g.R = nrows; g.H2 = H2;
     const int rt = dec_row_tiles(nrows);
+    if (defer && defer->G > 0) {                 // the attention launch in front of this step left its combine to us
+        A2S_REQUIRE(H2 == 64 * NW && defer->G <= 16 && a.E % 16 == 0, "note_step_fused_fwd: deferred combine needs 2 * hidden_size == %d and G <= 16", 64 * NW);
+        DecCmbArgs c;
+        c.part = defer->part; c.attw = defer->attw; c.xw = a.x + (long)si * R * ldx;
+        c.clip_rank = defer->clip_rank; c.row_until = defer->row_until;
+        c.G = defer->G; c.groups = defer->groups; c.n_clips = defer->n_clips; c.n_active = defer->n_active; c.step = defer->step; c.T = defer->T;
+        c.Rall = R; c.E = a.E;
+        hipLaunchKernelGGL(dec_gru_step_cmb, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, g, c);
+    } else
     if (rt == 4) hipLaunchKernelGGL(dec_gru_step_rt<4>, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(64 * NW), 0, st, g);
     else if (rt == 2) hipLaunchKernelGGL(dec_gru_step_rt<2>, dim3(H2 / 16, a2s_cdiv(nrows, 32)), dim3(64 * NW), 0, st, g);
     else hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, g);
