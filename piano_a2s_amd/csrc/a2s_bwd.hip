@@ -52,15 +52,14 @@ __global__ void gru_gates_bwd(const float* __restrict__ dh_a, long lda, const fl
     float dh = dh_a[(long)r_ * lda + j];
     if (dh_b) dh += dh_b[(long)r_ * ldb + j];
     const float hp = hprev ? hprev[(long)r_ * ldhp + j] : 0.f;
-    const float dn = dh * (1.f - zg) * (1.f - ng * ng);
-    const float dz = dh * (hp - ng) * zg * (1.f - zg);
-    const float dr = dn * ghn * rg * (1.f - rg);
+    const GruCellGrad cg = gru_cell_bwd(dh, rg, zg, ng, ghn, hp);
+    const float dn = cg.dn, dz = cg.dz, dr = cg.dr;
     float* a = dgi + (long)r_ * ldgi;
     a[j] = dr; a[H + j] = dz; a[2 * H + j] = dn;
     float* b = dgh + (long)r_ * ldgh;
-    b[j] = dr; b[H + j] = dz; b[2 * H + j] = dn * rg;
-    if (dgh2) { float* c = dgh2 + (long)r_ * ldgh2; c[j] = dr; c[H + j] = dz; c[2 * H + j] = dn * rg; }
-    dhprev[(long)r_ * lddp + j] = dh * zg;
+    b[j] = dr; b[H + j] = dz; b[2 * H + j] = cg.dnr;
+    if (dgh2) { float* c = dgh2 + (long)r_ * ldgh2; c[j] = dr; c[H + j] = dz; c[2 * H + j] = cg.dnr; }
+    dhprev[(long)r_ * lddp + j] = cg.dhz;
 }
 
 int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const float* dh_b, long ldb, const float* save,
@@ -123,14 +122,21 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                                  long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
-                                 const a2s_attn_rows* rows);
+                                 const a2s_attn_rows* rows, a2s_attn_deferred_bwd* defer = nullptr);
+int a2s_attn_deep_max_clips(void);
+int a2s_attn_defer_combine_enabled(void);
+int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                           const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
+                           long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws,
+                           const a2s_attn_rows* rows = nullptr, a2s_attn_deferred_bwd* defer = nullptr);
 
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                            long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws,
-                           const a2s_attn_rows* rows = nullptr) {
+                           const a2s_attn_rows* rows, a2s_attn_deferred_bwd* defer) {
+    if (defer) defer->G = 0;
     if (H == 256 && ws)
-        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H, rows);
+        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H, rows, defer);
     const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
     A2S_REQUIRE(H >= 1 && H <= 512, "attn_step_bwd: hidden_size must be in 1 .. 512 (got %d)", H);
@@ -1035,7 +1041,7 @@ static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                                  long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
-                                 const a2s_attn_rows* rows) {
+                                 const a2s_attn_rows* rows, a2s_attn_deferred_bwd* defer) {
     A2S_REQUIRE(H == 256 && ws, "attn_step_bwd_split: needs hidden_size 256 and a workspace");
     A2S_REQUIRE(ldq % 4 == 0 && ldctx % 4 == 0 && ldda % 4 == 0 && (!dctx_b || lddb % 4 == 0) && (!dctx_out || lddo % 4 == 0),
                 "attn_step_bwd_split: row strides must be multiples of 4 floats");
@@ -1075,6 +1081,11 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
 #undef A2S_BWD_MQ
         }
         A2S_CHECK_LAUNCH("attn_bwd_split256");
+    }
+    // the few-clip launches leave the sum of the partials to the query product that consumes dq (a2s_step.hip: dec_bwd_query_cmb)
+    if (defer && !pace_token && r.n_active > 0 && r.n_active <= a2s_attn_deep_max_clips() && groups <= 4 && G <= 16 && lddq == H && a2s_attn_defer_combine_enabled()) {
+        *defer = a2s_attn_deferred_bwd{ws, ds_out, dctx_out, lddo, r.clip_rank, r.row_until, G, groups, r.n_clips, r.n_active, r.step, T};
+        return A2S_OK;
     }
     hipLaunchKernelGGL(attn_bwd_combine256, dim3(B), dim3(256), 0, st, ws, dq, lddq, G, r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step,
                        ds_out, T, dctx_out, lddo, pace_token);

@@ -119,6 +119,13 @@ struct a2s_attn_deferred {
     const int* clip_rank; const int* row_until;
     int G, groups, n_clips, n_active, step, T;
 };
+// the backward counterpart: the sum of a row's dq partials (and the zeros of skipped rows) left to the query product that consumes dq
+struct a2s_attn_deferred_bwd {
+    const float* part;       // dq partials [H] of (slot, group, g), as attn_bwd_combine256 reads them
+    float* ds_out; float* dctx_out; long lddo;       // zero-filled for skipped rows (or NULL)
+    const int* clip_rank; const int* row_until;
+    int G, groups, n_clips, n_active, step, T;
+};
 // head of the attention workspace: arrival counters of the fused combine (forward: [0, 4096), backward: [4096, 8192)), in floats
 #define A2S_ATTN_TICKETS 8192
 
@@ -185,6 +192,19 @@ __device__ __forceinline__ float attn_merge_weight(float mg, float lg, bool have
     m_out = m;
     inv_l_out = 1.f / l;
     return e / l;
+}
+// GRU cell backward of one (row, hidden unit) (saved [r | z | n | gh_n]; see gru_gates_bwd, a2s_bwd.hip): ONE definition, contraction off, so
+// that the elementwise kernel and the product kernel that folds it into its prologue (a2s_step.hip) round alike.
+struct GruCellGrad { float dr, dz, dn, dnr, dhz; };
+__device__ __forceinline__ GruCellGrad gru_cell_bwd(float dh, float rg, float zg, float ng, float ghn, float hp) {
+#pragma clang fp contract(off)
+    GruCellGrad o;
+    o.dn = dh * (1.f - zg) * (1.f - ng * ng);
+    o.dz = dh * (hp - ng) * zg * (1.f - zg);
+    o.dr = o.dn * ghn * rg * (1.f - rg);
+    o.dnr = o.dn * rg;
+    o.dhz = dh * zg;
+    return o;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -40,6 +40,9 @@ struct GemmArgs {
 };
 
 #define GEMM_BK 32
+#ifndef GEMM_DEPTH
+#define GEMM_DEPTH 1              // k-tiles of global loads in flight in the small fp32-input tiles (-DGEMM_DEPTH=4: measured, see the main loop)
+#endif
 
 template <int ROWS, bool KC> struct LdsTile {
     // KC  : image [ROWS][BK+4]   (k contiguous, rows 16-byte aligned -> ds_write_b128)
@@ -382,34 +385,58 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(GemmArgs g) {
                     for (int r = 0; r < 4; ++r) acc[i][j][r] *= unscale;
         }
     } else {
-    for (int t = 0; t < ntiles; ++t) {
-            float* la = lds + (t & 1) * (LA::SIZE + LB::SIZE);
-            float* lb = la + LA::SIZE;
-            tile_store<BM, A_KC, NLA>(la, ra, fa, m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period);
-            tile_store<BN, B_KC, NLB>(lb, rb, fb, n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period);
-            __syncthreads();
-            if (t + 1 < ntiles) {   // prefetch next tile while this one is multiplied
-                const int k0 = kbeg + (t + 1) * GEMM_BK;
-                tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, ra, fa, g.a_scale, g.a_shift, g.a_period);
-                tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, rb, fb, g.b_scale, g.b_shift, g.b_period);
+        // fp32-input path.  GEMM_DEPTH register sets of global loads in a ring (small tiles only).  Round 5 measured depth 4 against 1 on the
+        // decoder's per-step products (M = 512 / 1280 rows, N = 1536, K = 528: profiles/r05_gemm_depth.txt): 23.9 -> 23.0 us alone -- these
+        // launches are bound by the L2 traffic of their 64x32 tiles (78 MB in 23 us), not by a memory round trip per k-tile -- and the training
+        // step 450 -> 460 ms (164-208 VGPRs instead of ~100: fewer workgroups per CU beside the attention sweeps).  Depth 1 stays.
+        constexpr int D = (BM * BN <= 64 * 64) ? GEMM_DEPTH : 1;
+        f32x4 qa[D][NLA], qb[D][NLB];
+        float ga[D][NLA][2], gb[D][NLB][2];
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) { qa[0][i] = ra[i]; ga[0][i][0] = fa[i][0]; ga[0][i][1] = fa[i][1]; }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) { qb[0][i] = rb[i]; gb[0][i][0] = fb[i][0]; gb[0][i][1] = fb[i][1]; }
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            if (d < ntiles) {
+                const int k0 = kbeg + d * GEMM_BK;
+                tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, qa[d], ga[d], g.a_scale, g.a_shift, g.a_period);
+                tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, qb[d], gb[d], g.b_scale, g.b_shift, g.b_period);
             }
-    #pragma unroll
-            for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
-                float a[TM], b[TN];
-    #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = la[LA::at(wm + i * 16 + lr, ks * 4 + lk)];
-    #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = lb[LB::at(wn + j * 16 + lr, ks * 4 + lk)];
-    #pragma unroll
-                for (int i = 0; i < TM; ++i)
-    #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);     // transposed tile: see the epilogue
-            }
-            // the other LDS buffer is written next iteration; its readers finished before the barrier above
         }
-    
-}
+        for (int t0 = 0; t0 < ntiles; t0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int t = t0 + d;
+                if (t >= ntiles) break;                   // (uniform over the workgroup)
+                float* la = lds + (t & 1) * (LA::SIZE + LB::SIZE);
+                float* lb = la + LA::SIZE;
+                tile_store<BM, A_KC, NLA>(la, qa[d], ga[d], m0, kbeg + t * GEMM_BK, g.M, kend, g.a_scale, g.a_shift, g.a_period);
+                tile_store<BN, B_KC, NLB>(lb, qb[d], gb[d], n0, kbeg + t * GEMM_BK, g.N, kend, g.b_scale, g.b_shift, g.b_period);
+                __syncthreads();
+                if (t + D < ntiles) {   // refill this register set: its tile is multiplied D iterations from now
+                    const int k0 = kbeg + (t + D) * GEMM_BK;
+                    tile_load<BM, A_KC, NLA>(A, g.sAm, g.sAk, m0, k0, g.M, kend, g.vecA, qa[d], ga[d], g.a_scale, g.a_shift, g.a_period);
+                    tile_load<BN, B_KC, NLB>(B, g.sBn, g.sBk, n0, k0, g.N, kend, g.vecB, qb[d], gb[d], g.b_scale, g.b_shift, g.b_period);
+                }
+#pragma unroll
+                for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
+                    float a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = la[LA::at(wm + i * 16 + lr, ks * 4 + lk)];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = lb[LB::at(wn + j * 16 + lr, ks * 4 + lk)];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);     // transposed tile: see the epilogue
+                }
+                // the other LDS buffer is written next iteration; its readers finished before the barrier above
+            }
+        }
+    }
+
 
     // epilogue.  The MFMAs were issued with the operands swapped (B fragment first), so every accumulator holds the TRANSPOSED 16x16 tile:
     // lane = (m = lane & 15, n-quad = lane >> 4) owns C[m][4q .. 4q+3] -- four CONSECUTIVE columns of one output row, i.e. one 16-byte

@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--pairs", type=int, default=6)
+    ap.add_argument("--reverse", action="store_true", help="run the True member of every pair first (first-occurrence effects -- a new segment structure's allocations -- then land on True)")
     ap.add_argument("--attr", default="skip_finished_rows", help="TrainStep attribute, lib:<key> for an a2s_debug_set switch, or env:<NAME> for an environment switch read per step")
     a = ap.parse_args()
     import models
@@ -50,7 +51,7 @@ def main():
     torch.cuda.synchronize()
     tot = {False: [], True: []}
     for k in range(a.pairs):
-        for v in (False, True):
+        for v in ((True, False) if a.reverse else (False, True)):
             setattr(target, a.attr, v)
             torch.cuda.synchronize()
             t0 = time.time()
