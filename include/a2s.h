@@ -103,7 +103,11 @@ void a2s_gemm_debug_tile(int cfg);
  * terms (six products, fp32-level accuracy; csrc/a2s_conv.hip conv3x3_bf16x3): bit 0 forward launches, bit 1 data-gradient launches
  * (default 3; 0 = the fp32-input MFMA kernel everywhere); "gemm_bf16x3" 0/1 -- the same split for 128x128 GEMM tiles whose two
  * operands are k- or row-contiguous (default 1); "wgrad_bf16x3" 0/1/2 -- the split-operand weight-gradient convolution: 1 (default) where it is
- * faster than conv3x3_wgrad (40 -> 40 channels), 2 every eligible launch */
+ * faster than conv3x3_wgrad (40 -> 40 channels), 2 every eligible launch;
+ * "attn_defer_combine" 0/1 (default 1, A2S_ATTN_DEFER_COMBINE): inside a2s_note_decoder_fwd, the few-clip attention launches of a training call
+ * leave their softmax combine to the GRU-step kernel that consumes the contexts (csrc/a2s_step.hip dec_gru_step_cmb; same bits as the combine
+ * kernel); "dec_bwd_fold" 0/1 (default 0, A2S_DEC_BWD_FOLD): the corresponding folds of a2s_note_decoder_bwd (measured slower, parity-tested);
+ * "attn_deep" n (A2S_ATTN_DEEP, default 24): training launches over at most n clips use the one-round-trip forward sweep */
 int a2s_debug_set(const char* key, int value);
 int a2s_debug_get(const char* key);   /* current value of "conv_bf16x3" / "gemm_bf16x3" / "wgrad_bf16x3" / "gru_fused"; -1 for an unknown key;
                                         * also "device_cus" / "device_xccs": compute units and XCDs the runtime reports for the current device */
