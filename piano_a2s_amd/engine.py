@@ -47,6 +47,9 @@ _ENC_TWO_TERM = _os.environ.get("A2S_ENC_TWO_TERM", "1") != "0"
 _TAIL_PREFIX = _os.environ.get("A2S_TAIL_PREFIX", "1") != "0"
 # ... and the few-row step kernels on the rows still running once those fit them (A2S_TAIL_ROWS=0: only calls that are small as a whole)
 _TAIL_ROWS = _os.environ.get("A2S_TAIL_ROWS", "1") != "0"
+# the (step, row) pairs of a decoder call that still ran, as a flat index list: the backward's weight-gradient products contract over those only
+# (A2S_LIVE_ROWS=0: over every row of every step, three quarters of which are the exact zeros of finished rows at the bench's lengths)
+_LIVE_ROWS = _os.environ.get("A2S_LIVE_ROWS", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -756,7 +759,11 @@ class Engine:
                 row_list = torch.argsort(uflat, descending=True, stable=True).to(torch.int32)
                 rcnt = torch.bincount(uflat.long().clamp(max=n), minlength=n + 1)
                 n_rows = uflat.numel() - torch.cumsum(rcnt, 0)[:n]                                                  # rows with until > t
+                live_idx = None
+                if _LIVE_ROWS:
+                    live_idx = (torch.arange(n).unsqueeze(1) < uflat.unsqueeze(0)).reshape(-1).nonzero().squeeze(1).to(torch.int32)    # k = step * rows + row
                 return dict(until=upload(uflat), order=upload(order), rank=upload(rank),
+                            live_idx=upload(live_idx) if live_idx is not None else None, live_steps=n,
                             n_active=(C.c_int * max(n, 1))(*n_act.tolist()), n_clips=Bg,
                             m_active=(C.c_int * max(n, 1))(*m_act.tolist()) if _TAIL_PREFIX else None,
                             row_list=upload(row_list) if _TAIL_ROWS else None,

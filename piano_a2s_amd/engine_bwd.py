@@ -102,8 +102,12 @@ def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_a
     _colsum(dvp, H, G[prefix + ".v.weight"], nblk, H)
 
 
-def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T, deferred=None, enc_amax=None):
+def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T, deferred=None, enc_amax=None, late=None):
     """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (rows, 2H); rows = groups * n_clips.
+    late: optional list.  The call's WEIGHT gradients (output projection, GRU, attention query half, embedding rows: everything only the
+    optimizer waits for) are then not computed here: a (closure, event, tensors) entry is appended and Backward.finish runs the closures on the
+    weight-gradient stream beside the encoder's back-propagation -- on the staff's own stream they sit in series with the next segment's decode
+    steps (8-12 ms of GEMMs per call of the bulk clip group, profiles/r05_queue_timeline.txt).  The key / encoder-output gradients stay here.
     deferred: optional HIP stream for everything that does not gate the recurrence (weight gradients, the deferred key / encoder-
     output gradients, embedding scatter): a staff's stream executes in order, so leaving them on it would put ~20 % of MFMA-bound GEMM
     time in series with the HBM-bound attention steps of the next segment; returns (dh0, event after the deferred work or None)."""
@@ -165,25 +169,43 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
             a.persist_ws, a.persist_ws_bytes = persist_ws.data_ptr(), nb_ws
     hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) everything nobody in the recurrence waits for
-    def deferred_work():
+    def deferred_work(part="all"):
+        if part == "attn":          # the key / encoder-output gradients only (the weight gradients follow in Backward.finish)
+            _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, n_clips, T, H, n, sv.get("active"), groups)
+            return
         # Operand ranges of the weight-gradient products (two-term fp16 split): the GRU state lies in (-1, 1), the
         # context is a convex combination of encoder rows, the token half of x an embedding row; the gradients' max magnitudes are measured.
         one = _one(dev)
         xb = torch.maximum(hip.absmax(S[prefix + ".embedding.weight"]), enc_amax) if enc_amax is not None else None
         ob = torch.maximum(one, enc_amax) if enc_amax is not None else None
         am = (lambda t: hip.absmax(t)) if enc_amax is not None else (lambda t: None)
-        _linear_bwd(o2d, Wo, dlog2d, G, prefix + ".out.weight", prefix + ".out.bias", dy_amax=dlog_amax, x_bound=ob)       # dW_out += dlog^T o ; db_out += colsum
         x2d, h2d = sv["x"][:n].view(R, ldx), sv["h"][:n].view(R, H2)
-        _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_all.view(R, 3 * H2), G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0",
-                    dy_amax=am(dgi_all), x_bound=xb)
-        _linear_bwd(h2d, S[prefix + ".gru.weight_hh_l0"], dgh_all.view(R, 3 * H2), G, prefix + ".gru.weight_hh_l0", prefix + ".gru.bias_hh_l0",
-                    dy_amax=am(dgh_all), x_bound=one)
+        # Every product below contracts over the (step, row) pairs of the call.  Rows whose targets had run out were skipped by the forward pass and
+        # carry EXACT zero gradients from then on (dlog, dgi, dgh, dq: zeros): with the bench's lengths that is three quarters of the pairs.  The
+        # pairs that ran (active["live_idx"], planned on the host with everything else) are gathered into dense operands first -- 22 KB per pair,
+        # read once -- and the products, bias sums and operand ranges run over those only.
+        live = sv["active"].get("live_idx") if (sv.get("active") and sv["active"].get("live_steps") == n) else None
+        dlog_w, o_w, dgi_w, dgh_w, dq_w, Rw = dlog2d, o2d, dgi_all.view(R, 3 * H2), dgh_all.view(R, 3 * H2), dq_all.view(R, H), R
+        if live is not None and live.numel() < 0.8 * R:
+            Rw = live.numel()
+            if Rw == 0:
+                return                                    # nothing ran: every gradient of this call is zero
+            sel = lambda t2d: t2d.index_select(0, live)
+            dlog_w, o_w, dgi_w, dgh_w, dq_w, x2d, h2d = sel(dlog_w), sel(o_w), sel(dgi_w), sel(dgh_w), sel(dq_w), sel(x2d), sel(h2d)
+        else:
+            live = None
+        _linear_bwd(o_w, Wo, dlog_w, G, prefix + ".out.weight", prefix + ".out.bias", dy_amax=dlog_amax, x_bound=ob)       # dW_out += dlog^T o ; db_out += colsum
+        _linear_bwd(x2d, S[prefix + ".gru.weight_ih_l0"], dgi_w, G, prefix + ".gru.weight_ih_l0", prefix + ".gru.bias_ih_l0",
+                    dy_amax=am(dgi_w), x_bound=xb)
+        _linear_bwd(h2d, S[prefix + ".gru.weight_hh_l0"], dgh_w, G, prefix + ".gru.weight_hh_l0", prefix + ".gru.bias_hh_l0",
+                    dy_amax=am(dgh_w), x_bound=one)
         # attention query half: dW[:, :2H] += dq^T h ; db += colsum(dq)
         Gw = G[prefix + ".attn.attn.weight"]
-        sk = L.a2s_gemm_pick_splitk(H, H2, R, 1)
-        hip.gemm(dq_all, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, R, beta=1.0, splitk=sk, two_term=(hip.absmax(dq_all), one) if enc_amax is not None else None)
-        _colsum(dq_all, H, G[prefix + ".attn.attn.bias"], R, H)
-        _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, n_clips, T, H, n, sv.get("active"), groups)
+        sk = L.a2s_gemm_pick_splitk(H, H2, Rw, 1)
+        hip.gemm(dq_w, 1, H, h2d, H2, 1, Gw, 4 * H, H, H2, Rw, beta=1.0, splitk=sk, two_term=(hip.absmax(dq_w), one) if enc_amax is not None else None)
+        _colsum(dq_w, H, G[prefix + ".attn.attn.bias"], Rw, H)
+        if part == "all":
+            _attn_deferred(eng, S, G, prefix + ".attn", keys, enc, sv["q"], ds_all, sv["attw"], dctx_all, dK, dEnc, n_clips, T, H, n, sv.get("active"), groups)
         # embedding rows of the tokens consumed at each step: <sos> at step 0, then gt or argmax of the previous step
         tok = torch.full((n, B), SOS, dtype=torch.int32, device=dev)
         if n > 1:
@@ -198,10 +220,22 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
                 prev = torch.where(flags, sv["gt_bar"][:, :n - 1].t().to(torch.int32), prev)
             tok[1:] = prev
         drop = sv["drop"]
-        hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[prefix + ".embedding.weight"]), NULL, hip._p(tok), C.c_long(1), 0, hip._p(dx),
-                                          C.c_long(ldx), 0, R, E, hip._p(drop), hip.f32(1.0 / (1.0 - sv["drop_p"]) if drop is not None else 1.0)),
+        dx_w, ld_w = dx, ldx
+        if live is not None:        # (the token-embedding columns of dx at the pairs that ran; their tokens; their dropout masks)
+            tok = tok.view(-1).index_select(0, live)
+            dx_w, ld_w = dx.view(R, ldx)[:, :E].index_select(0, live), E
+            if drop is not None:
+                drop = drop.reshape(-1, E)[:R].index_select(0, live)
+        hip.check(L.a2s_embed_scatter_add(hip.stream(), hip._p(G[prefix + ".embedding.weight"]), NULL, hip._p(tok), C.c_long(1), 0, hip._p(dx_w),
+                                          C.c_long(ld_w), 0, Rw, E, hip._p(drop), hip.f32(1.0 / (1.0 - sv["drop_p"]) if drop is not None else 1.0)),
                   "a2s_embed_scatter_add")
 
+    if late is not None:
+        deferred_work("attn")
+        ev = torch.cuda.Event()
+        ev.record()
+        late.append((lambda: deferred_work("weights"), ev, (dlog, do_all, dgi_all, dgh_all, dq_all, dx, sv["x"], sv["h"], sv["o"], sv["ids"])))
+        return dh[0], None
     if deferred is None:
         deferred_work()
         return dh[0], None
@@ -256,6 +290,11 @@ class Backward:
         # weight gradients etc. of each staff off its recurrence stream: measured +0.7 % in round 1, but two more streams than the four
         # hardware queues the runtime has (engine.group_stream) -- off by default since the clip groups need a queue (A2S_DEFER_STREAM=1)
         self.use_deferred = self.concurrent and os.environ.get("A2S_DEFER_STREAM", "0") == "1"
+        # round 5: the note decoders' weight gradients run in finish(), on the weight-gradient stream beside the encoder's back-propagation
+        # (A2S_LATE_WGRADS=0 / eng.late_wgrads = False: where they were, behind each call's reverse loop on the staff's stream)
+        lw = getattr(eng, "late_wgrads", None)
+        self.late_wgrads = (os.environ.get("A2S_LATE_WGRADS", "1") != "0") if lw is None else bool(lw)
+        self.late = []                                     # (closure, event on the issuing stream, tensors it reads): appended by any group's host thread
         self.clip_groups = list(clip_groups) if clip_groups else [(0, B)]
         # the deferred products of the decoder backward (weight gradients, key / encoder-output gradients) with measured operand ranges on
         # the two-term fp16 split instead of three bf16 terms (A2S_BWD_TWO_TERM=0: as in round 2)
@@ -315,7 +354,7 @@ class Backward:
                 else:
                     dpr, pr = dout[:, bar0], out_t[:, bar0]
                 calls.append((eng, S, Gg, seg["staff"][name][2], keys_g[prefix], enc_g, dpr, pr, dK_g[prefix], dEnc_staff_g[si], Bg, T,
-                              deferred_streams[si] if use_deferred_g else None, enc_amax_g))
+                              deferred_streams[si] if use_deferred_g else None, enc_amax_g, self.late if self.late_wgrads else None))
             if concurrent_g:    # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
                 res, events = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
                 seg_dh0[si_seg] = ([r[0] for r in res], events)
@@ -421,8 +460,29 @@ class Backward:
         H2 = 2 * H
         enc = sv["enc_out"]
         G["__staff_emb_ptrs__"] = self.group_ptrs[0]
-        for gf in self.group_flat[1:]:
-            flat.add_(gf)
+        late_join = None
+        if self.late:
+            # The note decoders' weight gradients, on the weight-gradient stream: they start now (every closure waits for the event its call
+            # recorded behind its reverse loop) and run beside the key products and the encoder's back-propagation below.  They accumulate
+            # into their clip group's flat buffer; the groups' buffers are folded into `flat` on the same stream afterwards, over the decoder's
+            # parameters only (nothing else is non-zero in them, and the main stream accumulates the encoder's gradients meanwhile), once the
+            # key products below -- which write the other half of the decoders' attention matrices -- are done.
+            dec_lo = next(off for k, off in zip(names, offs) if k.startswith("decoder."))
+            assert all(k.startswith("decoder.") for k, off in zip(names, offs) if off >= dec_lo), "the decoder's parameters must be the tail of the flat layout"
+            wg = _weight_grad_stream(dev)
+            wg.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wg):
+                for fn, ev, tensors in self.late:
+                    wg.wait_event(ev)
+                    for t in tensors:
+                        if t is not None:
+                            t.record_stream(wg)
+                    fn()
+            late_join = dec_lo
+            self.late = []
+        else:
+            for gf in self.group_flat[1:]:
+                flat.add_(gf)
         d_hid_carry = self.d_hidden
         if self.concurrent:
             dEnc.add_(self.dEnc_staff[0]).add_(self.dEnc_staff[1])
@@ -437,6 +497,12 @@ class Backward:
                      two_term=(dk_amax, enc_amax) if self.two_term else None)
             hip.gemm(dKp, H, 1, S[Wn], 4 * H, 1, dEnc, H2, B * T, H2, H, beta=1.0, b_off=H2,
                      two_term=(dk_amax, hip.absmax(S[Wn])) if self.two_term else None)
+        if late_join is not None:
+            wg = _weight_grad_stream(dev)
+            wg.wait_stream(torch.cuda.current_stream())            # (the key products above)
+            with torch.cuda.stream(wg):
+                for gf in self.group_flat[1:]:
+                    flat[late_join:].add_(gf[late_join:])
         # The encoder's last weight gradients (layer 0: ~5 ms of GEMMs on the weight-gradient stream, nothing of the encoder left to run beside
         # them) overlap with the START of the ConvStack backward: the caller's stream does not wait for them here.  The decoder + encoder slice
         # is announced from that stream (a collective issued there is ordered behind its work, which itself waited for everything the main

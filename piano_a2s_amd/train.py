@@ -288,6 +288,8 @@ class TrainStep:
             self.group_plan["step_cost"] = float(_os.environ["A2S_GROUP_STEP_COST"])
         # the ConvStack is enqueued before the host plans the decoder (see _step); A2S_EARLY_CONVSTACK=0: after, as in round 4
         self.early_convstack = _os.environ.get("A2S_EARLY_CONVSTACK", "1") != "0"
+        # the note decoders' weight gradients beside the encoder's back-propagation instead of behind each call's reverse loop (engine_bwd.Backward)
+        self.late_wgrads = _os.environ.get("A2S_LATE_WGRADS", "1") != "0"
         # the long-clip group cut in two by the bar segment of each clip's longest bar (split_long_group); A2S_LONG_SUBGROUPS=0: one long-clip group
         self.long_subgroups = _os.environ.get("A2S_LONG_SUBGROUPS", "1") != "0"
         self.keep_grads = False            # tests: keep the last step's gradient views (name -> tensor) in self.last_grads
@@ -326,6 +328,7 @@ class TrainStep:
         eng = engine.Engine(self.model.cfg, sync_bn=self.sync_bn)
         eng.skip_finished_rows = self.skip_finished_rows
         eng.fuse_bars = self.skip_finished_rows and self.fuse_bars
+        eng.late_wgrads = self.late_wgrads
         gt_host, perm, host_plan = None, None, None
         S = self.state()
         conv_pre = None
