@@ -61,6 +61,8 @@ int a2s_gru_persist_alone(void);
 void a2s_attn_deep_set(int);
 void a2s_attn_defer_combine_set(int);
 void a2s_dec_bwd_fold_set(int);
+void a2s_attn_deep_bwd_set(int);
+int a2s_attn_deep_bwd_enabled(void);
 int a2s_dec_bwd_fold_enabled(void);
 int a2s_attn_defer_combine_enabled(void);
 int a2s_attn_deep_max_clips(void);
@@ -228,6 +230,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_deep")) { a2s_attn_deep_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_defer_combine")) { a2s_attn_defer_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_bwd_fold")) { a2s_dec_bwd_fold_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_deep_bwd")) { a2s_attn_deep_bwd_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_pace_min")) { a2s_attn_pace_min_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
@@ -258,6 +261,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_deep")) return a2s_attn_deep_max_clips();
     if (key && !strcmp(key, "attn_defer_combine")) return a2s_attn_defer_combine_enabled();
     if (key && !strcmp(key, "dec_bwd_fold")) return a2s_dec_bwd_fold_enabled();
+    if (key && !strcmp(key, "attn_deep_bwd")) return a2s_attn_deep_bwd_enabled();
     if (key && !strcmp(key, "attn_pace_min")) return a2s_attn_pace_min();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();

@@ -998,6 +998,173 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     }
 }
 
+// ---- the few-clip form of the fused-rows backward sweep (round 5; forward counterpart: attn_fwd_split256_deep, a2s_seq.hip).  The long-clip
+// group's chain launches this kernel once per backward decode step over 1-8 clips; beside the bulk group's sweeps every DEPENDENT memory round
+// trip costs several microseconds, and attn_bwd_split256_mq has four in series (operands of the prologue, enc blocks of pass A -- two per wave --,
+// the saved weights, the K tiles of pass B): 60-83 us per launch on that chain against 17 alone (profiles/r05_kernel_stats.txt).  Here 512 threads
+// request EVERYTHING the workgroup needs before anything is waited for -- the K chunk (10 float4 per thread), one 16-frame enc block per wave
+// (waves 0-4: 32 float4 per lane), the rows' dctx / ctx (one row per wave), the queries, the saved weights -- and then run the same three phases
+// out of registers.  chunk <= 80 frames, NQ <= 4 rows.  Summation order of pass B differs from the 256-thread kernel (8 frame groups instead of 4):
+// equal to rounding, not to the bit.
+template <int NQ>
+__global__ __launch_bounds__(512) void attn_bwd_split256_deep(const float* __restrict__ Kmat, const float* __restrict__ enc,
+                                                              const float* __restrict__ q, long ldq, const float* __restrict__ v,
+                                                              const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
+                                                              const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
+                                                              float* __restrict__ dctx_out, long lddo, float* __restrict__ dq_partial,
+                                                              float* __restrict__ ds_out, int T, int G, int chunk,
+                                                              const int* __restrict__ clip_order, const int* __restrict__ row_until,
+                                                              int step, int n_clips) {
+    constexpr int H = 256, KF = 10, RG = 8;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dsv = sm;                                         // NQ x chunk
+    f32x4* red4 = reinterpret_cast<f32x4*>(sm + NQ * chunk);    // NQ * (RG - 1) * 64 float4
+    float* dcT = reinterpret_cast<float*>(red4 + NQ * (RG - 1) * 64);     // NQ x ATT_DCS floats
+    float* dots = dcT + NQ * ATT_DCS;                                      // 16
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = clip_order ? clip_order[slot] : slot;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    bool on[NQ];
+    int onmask = 0;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { on[j] = !row_until || step < row_until[j * n_clips + b]; onmask |= on[j] ? (1 << j) : 0; }
+    const float* Kb = Kmat + ((long)b * T + t0) * H;
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    // ---------------------------------------------------------------- every load of the launch
+    const int c4 = tid & 63, rg = tid >> 6;
+    f32x4 kreg[KF];
+#pragma unroll
+    for (int u = 0; u < KF; ++u) {
+        const int fr = rg + RG * u;
+        kreg[u] = fr < n ? *reinterpret_cast<const f32x4*>(Kb + (long)fr * H + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool blk_on = wave * 16 < n;                       // waves 0 .. 4: the enc block of frames 16 wave .. + 15
+    f32x4 e0[16], e1[16];
+    {
+        const int fr = wave * 16 + li;
+        const bool valid = blk_on && fr < n;
+        const float* ep = Eb + (long)min(fr, n - 1) * 2 * H + 8 * lg;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            e0[u] = valid ? *reinterpret_cast<const f32x4*>(ep + 32 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            e1[u] = valid ? *reinterpret_cast<const f32x4*>(ep + 32 * u + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const bool mine = li < NQ && ((onmask >> li) & 1);
+    const long arow = ((long)min(li, NQ - 1) * n_clips + b) * T + t0;
+    float aw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f2 = wave * 16 + 4 * lg + r;
+        aw[r] = (mine && blk_on && f2 < n) ? attw[arow + f2] : 0.f;
+    }
+    f32x4 q4[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) q4[j] = on[j] ? *reinterpret_cast<const f32x4*>(q + ((long)j * n_clips + b) * ldq + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---------------------------------------------------------------- prologue: wave j forms row j's dctx (B operand of pass A) and its dot with the saved context
+    if (wave < NQ) {
+        const int j = wave;
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        float dot = 0.f;
+        if ((onmask >> j) & 1) {
+            const long row = (long)j * n_clips + b;
+            d0 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + lane * 4);
+            d1 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + H + lane * 4);
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+            if (dctx_b) {
+                o0 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + lane * 4);
+                o1 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + H + lane * 4);
+            }
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + lane * 4);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + H + lane * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { d0[c] += o0[c]; d1[c] += o1[c]; }
+            if (dctx_out && g == 0) {
+                *reinterpret_cast<f32x4*>(dctx_out + row * lddo + lane * 4) = d0;
+                *reinterpret_cast<f32x4*>(dctx_out + row * lddo + H + lane * 4) = d1;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot += d0[c] * c0[c] + d1[c] * c1[c];
+            dot = wave_sum(dot);
+        }
+        *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + lane * 4) = d0;
+        *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + H + lane * 4) = d1;
+        if (lane == 0) dots[j] = dot;
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- pass A (waves with a block): da = enc . dctx on the fp32 matrix cores, as attn_bwd_split256_mq
+    if (blk_on) {
+        const float* brow = dcT + min(li, NQ - 1) * ATT_DCS + 8 * lg;
+        const float dotn = dots[min(li, NQ - 1)];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[u][c], b0[c], acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[u][c], b1[c], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f2 = wave * 16 + 4 * lg + r;
+                if (f2 < n) {
+                    const float d_s = aw[r] * (acc[r] - dotn);
+                    dsv[li * chunk + f2] = d_s;
+                    if (ds_out) ds_out[arow + f2] = d_s;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- pass B: dq_j += ds_t (1 - tanh^2(K_tj + q_j)) out of the registers
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);       // E_q; Kmat holds the key image E_K = exp(2K)
+    }
+#pragma unroll
+    for (int u = 0; u < KF; ++u) {
+        const int fr = rg + RG * u;
+        if (fr >= n) break;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            const float w = dsv[j * chunk + fr];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(kreg[u][c], q4[j][c]), acc[j][c]);
+        }
+    }
+    if (rg > 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) red4[(j * (RG - 1) + rg - 1) * 64 + c4] = acc[j];
+    }
+    __syncthreads();
+    if (rg == 0) {
+        const f32x4 v4 = {v[c4 * 4], v[c4 * 4 + 1], v[c4 * 4 + 2], v[c4 * 4 + 3]};            // parameter: 4-byte aligned only
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (!on[j]) continue;
+            f32x4 a = acc[j];
+#pragma unroll
+            for (int u = 0; u < RG - 1; ++u) { const f32x4 o = red4[(j * (RG - 1) + u) * 64 + c4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] += o[c]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] *= v4[c];
+            *reinterpret_cast<f32x4*>(dq_partial + (((long)slot * NQ + j) * G + g) * H + c4 * 4) = a;
+        }
+    }
+}
+
 // one workgroup (256 threads) per row: dq = sum of the G partials; rows the forward pass skipped (upstream gradient exactly zero) get
 // zeros in everything the deferred GEMMs read (dq, ds, dctx)
 __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int G,
@@ -1038,6 +1205,25 @@ static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat
                             dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
 }
 
+// few-clip backward sweep: OFF by default (A2S_ATTN_DEEP_BWD=1 / a2s_debug_set("attn_deep_bwd", 1): on).  Parity-tested (tests/test_gpu_defer_combine.py,
+// tests/test_gpu_ops.py with the switch on) and measured in the training step: 4.2 +- 3.2 ms SLOWER over 10 pairs (profiles/r05_defer_combine_ab.txt) --
+// 512 threads x 208-229 registers + 38 KB of LDS is a whole CU, which beside the bulk group's backward sweeps (5 workgroups per CU, all LDS taken)
+// has to drain first; the forward form (137-172 registers, the bulk group's forward sweeps at 2 per CU) does not pay that.
+static int g_attn_deep_bwd = -1;
+void a2s_attn_deep_bwd_set(int v) { g_attn_deep_bwd = v ? 1 : 0; }
+int a2s_attn_deep_bwd_enabled(void) {
+    if (g_attn_deep_bwd < 0) { const char* e = getenv("A2S_ATTN_DEEP_BWD"); g_attn_deep_bwd = (e && e[0] == '1') ? 1 : 0; }
+    return g_attn_deep_bwd;
+}
+template <int NQ>
+static void launch_bwd_deep(hipStream_t st, int nwg, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
+                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
+                            float* dctx_out, long lddo, float* ws, float* ds_out, int T, int G, int chunk, const a2s_attn_rows& r) {
+    const size_t shm = ((size_t)NQ * chunk + (size_t)NQ * 7 * 64 * 4 + (size_t)NQ * ATT_DCS + 16) * sizeof(float);
+    hipLaunchKernelGGL((attn_bwd_split256_deep<NQ>), dim3(nwg), dim3(512), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                       dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
+}
+
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                                  long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
@@ -1063,7 +1249,16 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     if (r.n_active > 0) {
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         const int nwg = r.n_active * G;
-        if (groups == 1) {
+        if (groups <= 4 && r.n_active <= a2s_attn_deep_max_clips() && chunk <= 80 && a2s_attn_deep_bwd_enabled()) {       // the few-clip form: one round trip
+#define A2S_BWD_DEEP(N) launch_bwd_deep<N>(st, nwg, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r)
+            switch (groups) {
+                case 1: A2S_BWD_DEEP(1); break;
+                case 2: A2S_BWD_DEEP(2); break;
+                case 3: A2S_BWD_DEEP(3); break;
+                default: A2S_BWD_DEEP(4); break;
+            }
+#undef A2S_BWD_DEEP
+        } else if (groups == 1) {
             const size_t shm = a2s_attn_bulk_lds((chunk + 3 * 64 * 4) * sizeof(float), r.n_active, 1);
             if (nt) hipLaunchKernelGGL(attn_bwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
                                        dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);

@@ -1,8 +1,8 @@
 """The attention combine folded into the few-row GRU step (csrc/a2s_step.hip dec_gru_step_cmb, round 5: the few-clip launches of a training step
 leave their softmax combine to the kernel that consumes the contexts -- one launch less per decode step on the long-clip chain) and the
 backward's two folds (dec_bwd_products_g: the GRU-cell backward inside the product kernel; dec_bwd_query_cmb: the sum of the dq partials inside
-the query product -- three launches per backward decode step instead of five) against the stand-alone kernels: the whole fused training step
-both ways.  The two paths use the same expressions in the same order, so the forward
+the query product -- three launches per backward decode step instead of five) and the few-clip backward sweep (attn_bwd_split256_deep: every
+load of a chunk requested before anything is waited for) against the stand-alone / 256-thread kernels: the whole fused training step both ways.  The two paths use the same expressions in the same order, so the forward
 outputs must be IDENTICAL; the backward (which reads the contexts / normalised weights the folded combine left in memory, including the zeros of
 skipped rows) must agree to rounding of its atomics."""
 import random
@@ -30,13 +30,14 @@ def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail):
     dbatch = [t.to(dev) if torch.is_tensor(t) else t for t in batch]
     torch.manual_seed(9)
     init = models.ScoreTranscription(**cfg).state_dict()
-    prev = (L.a2s_debug_get(b"attn_defer_combine"), L.a2s_debug_get(b"dec_persist"), L.a2s_debug_get(b"dec_bwd_fold"))
+    prev = (L.a2s_debug_get(b"attn_defer_combine"), L.a2s_debug_get(b"dec_persist"), L.a2s_debug_get(b"dec_bwd_fold"), L.a2s_debug_get(b"attn_deep_bwd"))
     res = []
     try:
         hip.check(L.a2s_debug_set(b"dec_persist", 0), "debug_set")       # (<= 8 clips would take the persistent decoder: this test is about the launch-per-step kernels)
         for defer in (0, 1):
             hip.check(L.a2s_debug_set(b"attn_defer_combine", defer), "debug_set")
             hip.check(L.a2s_debug_set(b"dec_bwd_fold", defer), "debug_set")       # (the backward's folds: dec_bwd_products_g, dec_bwd_query_cmb)
+            hip.check(L.a2s_debug_set(b"attn_deep_bwd", defer), "debug_set")      # (the few-clip backward sweep: attn_bwd_split256_deep)
             m = models.ScoreTranscription(**cfg)
             m.load_state_dict(init)
             m = m.to(dev).train()
@@ -51,6 +52,7 @@ def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail):
         hip.check(L.a2s_debug_set(b"attn_defer_combine", prev[0]), "debug_set")
         hip.check(L.a2s_debug_set(b"dec_persist", prev[1]), "debug_set")
         hip.check(L.a2s_debug_set(b"dec_bwd_fold", prev[2]), "debug_set")
+        hip.check(L.a2s_debug_set(b"attn_deep_bwd", prev[3]), "debug_set")
     (l0, c0, p0, n_sep, o0), (l1, c1, p1, n_fold, o1) = res
     assert n_fold < 0.93 * n_sep, f"the folded kernels must have been taken: {n_fold} launches against {n_sep}"
     from piano_a2s_amd.spec import PAD
