@@ -335,7 +335,7 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
         }
         int gM = R, gB = 1;                  // rows of the per-step products: see enqueue_note_step (a2s_seq.hip); rows left out carry zero gradients
         long gS = 0;
-        if (a.m_active && a.n_clips > 0 && 2 * a.m_active[s] <= a.n_clips && a.m_active[s] > 0) { gM = a.m_active[s]; gB = R / a.n_clips; gS = a.n_clips; }
+        if (a.m_active && a.n_clips > 0 && a2s_prefix_rows_ok(a.m_active[s], a.n_clips)) { gM = a.m_active[s]; gB = R / a.n_clips; gS = a.n_clips; }
         const float* dos = a.do_all + (long)s * R * 2 * H2;
         float* dgi = a.dgi_all + (long)s * R * 3 * H2;
         float* dgh = a.dgh_all + (long)s * R * 3 * H2;
@@ -865,12 +865,13 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     int onmask = 0;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) onmask |= on[j] ? (1 << j) : 0;
-    if (wave == 0) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
+    // (one row per wave -- rows 0 .. 3 on waves 0 .. 3, a fifth on wave 0 again: the rows' operands are requested side by side instead of one
+    // dependent round trip per row on wave 0 while three waves wait at the barrier)
+    {
+        for (int j = wave; j < NQ; j += 4) {
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
             float dot = 0.f;
-            if (on[j]) {
+            if ((onmask >> j) & 1) {
                 const long row = (long)j * n_clips + b;
                 d0 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + lane * 4);
                 d1 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + H + lane * 4);
@@ -896,6 +897,15 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
         }
     }
     __syncthreads();
+    // the first two K tiles of pass B (frames rg + 4 u + 16 p) are requested HERE: they arrive while pass A multiplies
+    const int c4 = tid & 63, rg = tid >> 6;
+    constexpr int KPRE = 2;
+    f32x4 kpre[KPRE][4];
+#pragma unroll
+    for (int p = 0; p < KPRE; ++p)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            kpre[p][u] = (rg + 16 * p + 12 < n) ? ld_kv<NT>(Kb + (long)(rg + 16 * p + 4 * u) * H + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     // ---- pass A: da[t][j] = enc_t . dctx_j on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation): a wave
     // takes 16 frames, lane (i, g) feeds frame i's columns 32 u + 8 g .. + 7 as the A operand and row min(i, NQ - 1) of dctx at the same
     // columns as the B operand -- 128 MFMAs per 32 KB of enc instead of 8 FMAs + a 6-step cross-lane reduction per lane, frame and row
@@ -911,6 +921,12 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
             const bool valid = fr < n;
             const float* ep = Eb + (long)min(fr, n - 1) * 2 * H + 8 * lg;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};       // two chains: a dependent 16x16x4 waits 40 cycles, an independent one 32
+            float aw[4];                                                          // the saved weights of this lane's outputs: requested with the block, not after it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f2 = blk * 16 + 4 * lg + r;
+                aw[r] = (mine && f2 < n) ? attw[arow + f2] : 0.f;
+            }
 #pragma unroll 4
             for (int u = 0; u < 16; ++u) {
                 f32x4 e0 = ld_kv<NT>(ep + 32 * u);
@@ -931,7 +947,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
                 for (int r = 0; r < 4; ++r) {
                     const int f2 = blk * 16 + 4 * lg + r;
                     if (f2 < n) {
-                        const float d_s = attw[arow + f2] * (acc[r] - dotn);
+                        const float d_s = aw[r] * (acc[r] - dotn);
                         dsv[li * chunk + f2] = d_s;
                         if (ds_out) ds_out[arow + f2] = d_s;
                     }
@@ -941,7 +957,6 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     }
     __syncthreads();
     // ---- pass B: dq_j += ds_t (1 - tanh^2(K_tj + q_j)); thread = (float4 column, row group of 4)
-    const int c4 = tid & 63, rg = tid >> 6;
     f32x4 q4[NQ], acc[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -951,10 +966,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
         for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);       // E_q; Kmat holds the key image E_K = exp(2K)
     }
     int i = rg;
-    for (; i + 12 < n; i += 16) {
-        f32x4 k[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = ld_kv<NT>(Kb + (long)(i + 4 * u) * H + c4 * 4);
+    auto tile = [&](const f32x4 (&k)[4]) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (!on[j]) continue;
@@ -965,6 +977,15 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
                 for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(k[u][c], q4[j][c]), acc[j][c]);
             }
         }
+    };
+#pragma unroll
+    for (int p = 0; p < KPRE; ++p)
+        if (i + 12 < n) { tile(kpre[p]); i += 16; }
+    for (; i + 12 < n; i += 16) {
+        f32x4 k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = ld_kv<NT>(Kb + (long)(i + 4 * u) * H + c4 * 4);
+        tile(k);
     }
     for (; i < n; i += 4) {
         const f32x4 k0 = ld_kv<NT>(Kb + (long)i * H + c4 * 4);

@@ -110,6 +110,13 @@ struct a2s_attn_rows {
     int step;
 };
 #define A2S_ATTN_MAX_GROUPS 5
+// Late steps of a large decoder call run their per-step products on the leading m clips of every fused bar (the clips still running) once
+// m <= percent / 100 of the clips (A2S_PREFIX_PERCENT, default 50: measured, profiles/r05_prefix_percent.txt)
+static inline bool a2s_prefix_rows_ok(int m, int n_clips) {
+    static int pct = -1;
+    if (pct < 0) { const char* e = getenv("A2S_PREFIX_PERCENT"); pct = e ? atoi(e) : 50; if (pct < 1) pct = 1; if (pct > 100) pct = 100; }
+    return m > 0 && 100L * m <= (long)pct * n_clips;
+}
 // A forward attention launch whose combine has been left to its consumer (round 5: the few-row GRU step folds it into its prologue -- one
 // launch and one dependent-launch gap less per decode step on the long-clip chain, where a launch costs ~20 us + ~18 us of gap under the
 // other clip group's traffic: profiles/r05_trace_overlap.txt).  G == 0: nothing deferred, the combine has run.

@@ -556,7 +556,7 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     // finished rows are never read again (models.py:401-419 stops writing them, their targets are <pad>).
     int gM = a.R, gB = 1;
     long gS = 0;
-    if (a.m_active && a.n_clips > 0 && 2 * a.m_active[t] <= a.n_clips && a.m_active[t] > 0) { gM = a.m_active[t]; gB = a.R / a.n_clips; gS = a.n_clips; }
+    if (a.m_active && a.n_clips > 0 && a2s_prefix_rows_ok(a.m_active[t], a.n_clips)) { gM = a.m_active[t]; gB = a.R / a.n_clips; gS = a.n_clips; }
     const float* hp = a.h + (long)si * a.R * H2;
     float* hq = a.h + (long)so * a.R * H2;
     float* xs = a.x + (long)si * a.R * ldx;
