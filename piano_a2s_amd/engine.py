@@ -99,6 +99,25 @@ def _pinned_pool(device):
     return _PINNED_POOLS[key]
 
 
+_BAR_ATTN_SPLIT = _os.environ.get("A2S_BAR_ATTN_SPLIT", "1") != "0"
+_BAR_ATTN_WS = {}
+
+
+def bar_attn_workspace(device, group, n_clips, T, H):
+    """Workspace of the split-T attention kernels for the BAR-level decoder's attention of one clip group (forward and backward; one per (device,
+    group, shape), zero-initialised once as the kernels require, never shared with the note decoders' calls, which may run beside it).  None: the
+    one-workgroup-per-clip kernels (small groups, other widths, A2S_BAR_ATTN_SPLIT=0)."""
+    if not _BAR_ATTN_SPLIT or H != 256 or n_clips < 32:
+        return None
+    key = (_dev_index(device), group, n_clips, T)
+    ws = _BAR_ATTN_WS.get(key)
+    if ws is None:
+        if len(_BAR_ATTN_WS) > 64:
+            _BAR_ATTN_WS.clear()
+        ws = _BAR_ATTN_WS[key] = hip.attn_workspace(n_clips, T, H, device)
+    return ws
+
+
 _HOST_TRACE = None        # tools/phase_times.py --segments: a list that receives (label, host time) at the decoder's host-side milestones
 
 
@@ -818,11 +837,14 @@ class Engine:
                 Wa = S["decoder.attn.attn.weight"]
                 hip.gemm(hidden, 2 * H, 1, Wa, 1, 4 * H, qb, H, Bg, H, 2 * H, bias=S["decoder.attn.attn.bias"])
                 attw = self._empty(Bg, T, dev=dev) if training else None
+                # 5 calls per forward.  Round 5: on the split-T kernels when the group is large (their combine writes the context with 4-byte stores, so
+                # the odd stride of the bar-level GRU input row [token(141) | ctx] does not matter to them): 0.85 -> ~0.2 ms per call at 248 clips, in series
+                # with the group's decode; small groups keep the one-workgroup-per-clip kernel
+                bar_ws = bar_attn_workspace(dev, gidx, Bg, T, H)
                 hip.check(L.a2s_attn_step_fwd(hip.stream(), hip._p(keys_g["decoder"]), hip._p(enc_g), hip._p(qb), C.c_long(H),
                                               hip._p(S["decoder.attn.v.weight"]), C.c_void_p(xbar.data_ptr() + 4 * tokw), C.c_long(ldxb),
                                               C.c_void_p(headin.data_ptr() + 4 * 2 * H), C.c_long(4 * H), hip._p(attw), Bg, T, H,
-                                              C.c_void_p(0), 0, C.c_void_p(0)), "a2s_attn_step_fwd")   # 5 calls per forward: one-WG-per-clip kernel
-                # (the bar-level GRU input row [token(141) | ctx] has an odd stride, which the 16-byte-load split kernels reject)
+                                              C.c_void_p(0), 0, hip._p(bar_ws)), "a2s_attn_step_fwd")
                 gi = hip.linear(xbar, S["decoder.gru.weight_ih_l0"], S["decoder.gru.bias_ih_l0"])
                 gh = hip.linear(hidden, S["decoder.gru.weight_hh_l0"], S["decoder.gru.bias_hh_l0"])
                 hnew = self._empty(Bg, 2 * H, dev=dev)

@@ -419,9 +419,19 @@ class Backward:
             _linear_bwd(b["hprev"], S["decoder.gru.weight_hh_l0"], dgh, Gg, "decoder.gru.weight_hh_l0", "decoder.gru.bias_hh_l0", dx=dhp, dx_beta=1.0)
             dq, ds = torch.empty((Bg, H), device=dev), torch.empty((1, Bg, T), device=dev)
             dctx = torch.empty((1, Bg, H2), device=dev)
-            hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(keys_g["decoder"]), hip._p(enc_g), hip._p(b["qb"]), C.c_long(H), hip._p(S["decoder.attn.v.weight"]),
-                                          hip._p(b["attw"]), _ptr(b["xbar"], tokw), C.c_long(ldxb), _ptr(d_xbar, tokw), C.c_long(ldxb), _ptr(d_headin, H2),
-                                          C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), Bg, T, H, NULL), "attn bwd bar")
+            from .engine import bar_attn_workspace
+            bar_ws = bar_attn_workspace(dev, gidx, Bg, T, H)
+            if bar_ws is not None:
+                # split-T kernels (round 5: 1.3 -> ~0.25 ms per bar at 248 clips): they load the saved context and its gradient 16 bytes at a time, so
+                # the two odd-stride column blocks of the bar-level GRU input row are copied out first (0.5 MB each)
+                ctx_c, dctx_c = b["xbar"][:, tokw:].contiguous(), d_xbar[:, tokw:].contiguous()
+                hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(keys_g["decoder"]), hip._p(enc_g), hip._p(b["qb"]), C.c_long(H), hip._p(S["decoder.attn.v.weight"]),
+                                              hip._p(b["attw"]), hip._p(ctx_c), C.c_long(H2), hip._p(dctx_c), C.c_long(H2), _ptr(d_headin, H2),
+                                              C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), Bg, T, H, hip._p(bar_ws)), "attn bwd bar")
+            else:
+                hip.check(L.a2s_attn_step_bwd(hip.stream(), hip._p(keys_g["decoder"]), hip._p(enc_g), hip._p(b["qb"]), C.c_long(H), hip._p(S["decoder.attn.v.weight"]),
+                                              hip._p(b["attw"]), _ptr(b["xbar"], tokw), C.c_long(ldxb), _ptr(d_xbar, tokw), C.c_long(ldxb), _ptr(d_headin, H2),
+                                              C.c_long(4 * H), hip._p(dctx), C.c_long(H2), hip._p(dq), C.c_long(H), hip._p(ds), Bg, T, H, NULL), "attn bwd bar")
             Wa = S["decoder.attn.attn.weight"]
             hip.gemm(dq, H, 1, Wa, 4 * H, 1, dhp, H2, Bg, H2, H, beta=1.0)                              # d hprev += dq W_h
             hip.gemm(dq, 1, H, b["hprev"], H2, 1, Gg["decoder.attn.attn.weight"], 4 * H, H, H2, Bg, beta=1.0)   # dW_h += dq^T hprev

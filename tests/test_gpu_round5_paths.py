@@ -1,6 +1,6 @@
 """Differential check of everything round 5 put on the training step's default path -- the few-clip forward sweep, the attention combine folded into the
 few-row GRU step, the long-clip sub-groups, the ConvStack enqueued before the decoder is planned, the backward's weight-gradient products over the
-(step, row) pairs that ran only, the late weight gradients -- against the same step with all of them switched off, on odd shapes of the full-width model:
+(step, row) pairs that ran only, the late weight gradients, the bar-level attention on the split-T kernels -- against the same step with all of them switched off, on odd shapes of the full-width model:
 same losses, same clip norm, same parameters after the update (the switches reorder work and drop exact zeros, nothing else)."""
 import random
 
@@ -20,6 +20,7 @@ def dev():
 CASES = [  # B, frames, max_length, bars, tf, full_tail, planner settings
     (12, 151, (40, 24), 5, 0.6, 0.2, {"step_cost": 4.0}),
     (33, 97, (30, 17), 4, 0.8, 0.1, {"step_cost": 8.0}),
+    (70, 1201, (14, 9), 3, 0.7, 0.05, {}),
     (5, 203, (21, 33), 3, 0.5, 0.3, {}),
     (20, 64, (12, 9), 5, 1.0, 0.0, {}),
     (9, 301, (50, 20), 5, 0.0, 0.25, {"step_cost": 4.0}),
@@ -38,13 +39,14 @@ def test_round5_default_path_equals_the_plain_step(dev, B, frames, maxlen, bars,
     init = models.ScoreTranscription(**cfg).state_dict()
     keys = (b"attn_defer_combine", b"attn_deep")
     prev = [L.a2s_debug_get(k) for k in keys]
-    prev_live = engine._LIVE_ROWS
+    prev_live, prev_bar = engine._LIVE_ROWS, engine._BAR_ATTN_SPLIT
     res = []
     try:
         for on in (False, True):
             hip.check(L.a2s_debug_set(b"attn_defer_combine", 1 if on else 0), "debug_set")
             hip.check(L.a2s_debug_set(b"attn_deep", 24 if on else 0), "debug_set")
             engine._LIVE_ROWS = on
+            engine._BAR_ATTN_SPLIT = on               # (the bar-level attention of groups of >= 32 clips on the split-T kernels)
             m = models.ScoreTranscription(**cfg)
             m.load_state_dict(init)
             m = m.to(dev).train()
@@ -58,7 +60,7 @@ def test_round5_default_path_equals_the_plain_step(dev, B, frames, maxlen, bars,
     finally:
         for k, v in zip(keys, prev):
             hip.check(L.a2s_debug_set(k, v), "debug_set")
-        engine._LIVE_ROWS = prev_live
+        engine._LIVE_ROWS, engine._BAR_ATTN_SPLIT = prev_live, prev_bar
     (l0, c0, p0, g0), (l1, c1, p1, g1) = res
     assert torch.isfinite(l1).all() and float(c1[2]) == 1.0, (l1, c1)
     assert torch.allclose(l0, l1, rtol=2e-6, atol=0), (l0, l1, g0, g1)
