@@ -1269,6 +1269,20 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     unsigned* pace_token = r.n_active > 0 ? a2s_attn_pace_gate_impl(st, r.n_active) : nullptr;
     if (r.n_active > 0) {
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
+        // a handful of clips (late in the long-clip group's chain: the one or two clips that hold a full-length bar): a finer split -- the launch
+        // is a chain of dependent passes over the chunk, not bandwidth; the dq partials of 2 G chunks still fit the workspace the forward sized
+        // (2 G x 256 <= G x 516 floats per row).  A2S_ATTN_BWD_FINE=n: clips up to which the finer split applies (default 4, 0: off; measured
+        // 458.1 / 457.8 -> 454.7 / 456.1 ms per step, tools/step_time.py, alternating processes: profiles/r05_prefix_percent.txt)
+        {
+            static int fine = -1;
+            if (fine < 0) { const char* e = getenv("A2S_ATTN_BWD_FINE"); fine = e ? atoi(e) : 4; }
+            if (fine > 0 && r.n_active <= fine && G == a2s_attn_max_split() && 2 * G <= 64) {
+                int c = (T + 2 * G - 1) / (2 * G);
+                c = (c + 3) & ~3;
+                G = (T + c - 1) / c;
+                chunk = c;
+            }
+        }
         const int nwg = r.n_active * G;
         if (groups <= 4 && r.n_active <= a2s_attn_deep_max_clips() && chunk <= 80 && a2s_attn_deep_bwd_enabled()) {       // the few-clip form: one round trip
 #define A2S_BWD_DEEP(N) launch_bwd_deep<N>(st, nwg, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r)
