@@ -37,6 +37,15 @@ int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const fl
                            float* dhprev, long lddp, int R, int H);
 
 #define NW 8                      // waves per workgroup
+// k-steps of operand loads a wave has in flight at a time in the few-row kernels (the CH argument of mfma_rows8): a wave's share of the k-steps is
+// fetched in batches of CH, each batch waited for before its MFMAs.  Round 5 measured ONE batch per operand (-DDEC_CH_GRU=5 -DDEC_CH_OUT=8
+// -DDEC_CH_PROD=12: 124-177 registers, same bits) against batches of 4: the training step 432.5 / 434.6 -> 437.9 / 441.8 ms (tools/lib_ab.sh) --
+// like the GEMM's deeper prefetch (a2s_gemm.hip) it costs more beside the attention sweeps than the round trips it saves.  4 stays.
+#ifndef DEC_CH_GRU
+#define DEC_CH_GRU 4
+#define DEC_CH_OUT 4
+#define DEC_CH_PROD 4
+#endif
 
 // acc[g] += A-row-fragments x B-row-fragments over this wave's share of the k-steps (k-step u covers k in [16u, 16u+16); this lane
 // reads 4 floats at 16u + 4*lk of its A row and of its NT B rows)
@@ -178,9 +187,9 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step(DecGruArgs a) {
     f32x4 t[3], u[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) t[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8<3, 4>(a.x + (long)arow_i * a.ldx, bi, a.kx / 16, wave, lk, t);          // gi: r, z, n
+    mfma_rows8<3, DEC_CH_GRU>(a.x + (long)arow_i * a.ldx, bi, a.kx / 16, wave, lk, t);          // gi: r, z, n
     u[0] = t[0]; u[1] = t[1]; u[2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8<3, 4>(a.h + (long)arow_i * H2, bh, H2 / 16, wave, lk, u);               // + gh on r, z; gh_n apart
+    mfma_rows8<3, DEC_CH_GRU>(a.h + (long)arow_i * H2, bh, H2 / 16, wave, lk, u);               // + gh on r, z; gh_n apart
     f32x4 acc[4] = {u[0], u[1], t[2], u[2]};
     reduce_waves<4>(acc, part, wave, lane);
     if (wave > 0) return;
@@ -350,9 +359,9 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step_cmb(DecGruArgs a, DecCmb
     f32x4 t[3], u[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) t[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8_split<3, 4>(a.x + (long)arow_i * a.ldx, c.E / 16, lrow, bi, a.kx / 16, wave, lk, t);          // gi: r, z, n
+    mfma_rows8_split<3, DEC_CH_GRU>(a.x + (long)arow_i * a.ldx, c.E / 16, lrow, bi, a.kx / 16, wave, lk, t);          // gi: r, z, n
     u[0] = t[0]; u[1] = t[1]; u[2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8<3, 4>(a.h + (long)arow_i * H2, bh, H2 / 16, wave, lk, u);               // + gh on r, z; gh_n apart
+    mfma_rows8<3, DEC_CH_GRU>(a.h + (long)arow_i * H2, bh, H2 / 16, wave, lk, u);               // + gh on r, z; gh_n apart
     f32x4 acc[4] = {u[0], u[1], t[2], u[2]};
     reduce_waves<4>(acc, part, wave, lane);
     if (wave > 0) return;
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const int arow_p = dec_row(a.rowmap, min(row0 + li, R - 1));
     const float* arow = (vocab ? a.o + (long)arow_p * a.ldo : a.hnew + (long)arow_p * a.H2);
-    mfma_rows8<2, 4>(arow, brow, K / 16, wave, lk, acc);
+    mfma_rows8<2, DEC_CH_OUT>(arow, brow, K / 16, wave, lk, acc);
     reduce_waves<2>(acc, part, wave, lane);
     if (wave == 0) {
         const float* bias = vocab ? a.out_b : a.attn_b;
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
             for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
     }
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8<2, 4>(A + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K, brow, K / 16, wave, lk, acc);
+    mfma_rows8<2, DEC_CH_PROD>(A + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K, brow, K / 16, wave, lk, acc);
     reduce_waves<2>(acc, part, wave, lane);
     if (wave > 0) return;
 #pragma unroll
