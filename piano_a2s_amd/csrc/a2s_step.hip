@@ -38,13 +38,21 @@ int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const fl
 
 #define NW 8                      // waves per workgroup
 // k-steps of operand loads a wave has in flight at a time in the few-row kernels (the CH argument of mfma_rows8): a wave's share of the k-steps is
-// fetched in batches of CH, each batch waited for before its MFMAs.  Round 5 measured ONE batch per operand (-DDEC_CH_GRU=5 -DDEC_CH_OUT=8
-// -DDEC_CH_PROD=12: 124-177 registers, same bits) against batches of 4: the training step 432.5 / 434.6 -> 437.9 / 441.8 ms (tools/lib_ab.sh) --
-// like the GEMM's deeper prefetch (a2s_gemm.hip) it costs more beside the attention sweeps than the round trips it saves.  4 stays.
+// fetched in batches of CH, each batch waited for before its MFMAs.  Round 5 measured the whole range in the training step (tools/lib_ab.sh-style
+// alternating processes, 8 pairs each, profiles/r05_step_kernel_batches.txt), same bits everywhere:
+//     one batch per operand (CH = 5 / 8 / 12)   437.9 / 441.8 ms
+//     CH = 4 (rounds 3-5)                        435.4 / 437.0
+//     CH = 2                                     432.1 / 428.5
+//     CH = 1                                     429.2 / 429.0
+// FEWER loads in flight per wave win: these launches run beside the attention sweeps, which keep the memory system's queues full -- a wave that
+// asks for 12-36 float4 at once waits for the last of them, a wave that asks for 3-4 gets them back in the time of one, and the compiler
+// overlaps the next k-step's loads with the MFMAs anyway (the loop is not unrolled across the wait).  The registers (46-70 instead of 119-177 for one batch per operand)
+// also let the dispatcher place the workgroups sooner.
 #ifndef DEC_CH_GRU
-#define DEC_CH_GRU 4
-#define DEC_CH_OUT 4
-#define DEC_CH_PROD 4
+#define DEC_CH_GRU 1
+#define DEC_CH_OUT 1
+#define DEC_CH_PROD 1
+#define DEC_CH_QUERY 1
 #endif
 
 // acc[g] += A-row-fragments x B-row-fragments over this wave's share of the k-steps (k-step u covers k in [16u, 16u+16); this lane
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_query_cmb(float* __restrict__
     }
     __syncthreads();
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8_split<2, 2>(nullptr, 0, dqs + min(li, nb - 1) * DQ_LD, brow, H / 16, wave, lk, acc);
+    mfma_rows8_split<2, DEC_CH_QUERY>(nullptr, 0, dqs + min(li, nb - 1) * DQ_LD, brow, H / 16, wave, lk, acc);
     reduce_waves<2>(acc, part, wave, lane);
     if (wave > 0) return;
 #pragma unroll
@@ -885,7 +893,7 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_query(const float* __restrict
             for (int r = 0; r < 4; ++r) c0[g][r] = dh[(long)dec_row(rowmap, min(row0 + lk * 4 + r, R - 1)) * H2 + min(n0 + g * 16 + li, H2 - 1)];
     }
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8<2, 2>(dq + (long)dec_row(rowmap, min(row0 + li, R - 1)) * H, brow, H / 16, wave, lk, acc);
+    mfma_rows8<2, DEC_CH_QUERY>(dq + (long)dec_row(rowmap, min(row0 + li, R - 1)) * H, brow, H / 16, wave, lk, acc);
     reduce_waves<2>(acc, part, wave, lane);
     if (wave > 0) return;
 #pragma unroll
