@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
 // (waves 0-4: 32 float4 per lane), the rows' dctx / ctx (one row per wave), the queries, the saved weights -- and then run the same three phases
 // out of registers.  chunk <= 80 frames, NQ <= 4 rows.  Summation order of pass B differs from the 256-thread kernel (8 frame groups instead of 4):
 // equal to rounding, not to the bit.
-template <int NQ>
+template <int NQ, bool UPFRONT>
 __global__ __launch_bounds__(512) void attn_bwd_split256_deep(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                               const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                               const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
@@ -1055,22 +1055,25 @@ __global__ __launch_bounds__(512) void attn_bwd_split256_deep(const float* __res
     const float* Eb = enc + ((long)b * T + t0) * 2 * H;
     // ---------------------------------------------------------------- every load of the launch
     const int c4 = tid & 63, rg = tid >> 6;
+    // (UPFRONT = false -- the "wide" form: the same 512-thread decomposition, one enc block per wave and 8 frame groups in pass B, but every operand is
+    // requested where it is used, as in the 256-thread kernel: few loads in flight per wave, few registers)
     f32x4 kreg[KF];
+    if (UPFRONT) {
 #pragma unroll
-    for (int u = 0; u < KF; ++u) {
-        const int fr = rg + RG * u;
-        kreg[u] = fr < n ? *reinterpret_cast<const f32x4*>(Kb + (long)fr * H + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < KF; ++u) {
+            const int fr = rg + RG * u;
+            kreg[u] = fr < n ? *reinterpret_cast<const f32x4*>(Kb + (long)fr * H + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     const bool blk_on = wave * 16 < n;                       // waves 0 .. 4: the enc block of frames 16 wave .. + 15
     f32x4 e0[16], e1[16];
-    {
-        const int fr = wave * 16 + li;
-        const bool valid = blk_on && fr < n;
-        const float* ep = Eb + (long)min(fr, n - 1) * 2 * H + 8 * lg;
+    const bool evalid = blk_on && wave * 16 + li < n;
+    const float* ep = Eb + (long)min(wave * 16 + li, n - 1) * 2 * H + 8 * lg;
+    if (UPFRONT) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            e0[u] = valid ? *reinterpret_cast<const f32x4*>(ep + 32 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            e1[u] = valid ? *reinterpret_cast<const f32x4*>(ep + 32 * u + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            e0[u] = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            e1[u] = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
     const bool mine = li < NQ && ((onmask >> li) & 1);
@@ -1120,14 +1123,28 @@ __global__ __launch_bounds__(512) void attn_bwd_split256_deep(const float* __res
         const float* brow = dcT + min(li, NQ - 1) * ATT_DCS + 8 * lg;
         const float dotn = dots[min(li, NQ - 1)];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        if (UPFRONT) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[u][c], b0[c], acc, 0, 0, 0);
+                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[u][c], b0[c], acc, 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[u][c], b1[c], acc2, 0, 0, 0);
+                for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[u][c], b1[c], acc2, 0, 0, 0);
+            }
+        } else {
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) {
+                const f32x4 x0 = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 x1 = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[c], b0[c], acc, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[c], b1[c], acc2, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
@@ -1156,12 +1173,13 @@ __global__ __launch_bounds__(512) void attn_bwd_split256_deep(const float* __res
     for (int u = 0; u < KF; ++u) {
         const int fr = rg + RG * u;
         if (fr >= n) break;
+        const f32x4 kk = UPFRONT ? kreg[u] : *reinterpret_cast<const f32x4*>(Kb + (long)fr * H + c4 * 4);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (!on[j]) continue;
             const float w = dsv[j * chunk + fr];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(kreg[u][c], q4[j][c]), acc[j][c]);
+            for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(kk[c], q4[j][c]), acc[j][c]);
         }
     }
     if (rg > 0) {
@@ -1230,10 +1248,12 @@ static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat
 // tests/test_gpu_ops.py with the switch on) and measured in the training step: 4.2 +- 3.2 ms SLOWER over 10 pairs (profiles/r05_defer_combine_ab.txt) --
 // 512 threads x 208-229 registers + 38 KB of LDS is a whole CU, which beside the bulk group's backward sweeps (5 workgroups per CU, all LDS taken)
 // has to drain first; the forward form (137-172 registers, the bulk group's forward sweeps at 2 per CU) does not pay that.
+// Mode 2 (A2S_ATTN_DEEP_BWD=2): the same 512-thread decomposition with every operand requested where it is used (52-112 registers): neutral
+// (+1.3 ms over 8 clean pairs).  Both stay switches.
 static int g_attn_deep_bwd = -1;
-void a2s_attn_deep_bwd_set(int v) { g_attn_deep_bwd = v ? 1 : 0; }
+void a2s_attn_deep_bwd_set(int v) { g_attn_deep_bwd = v < 0 ? 0 : (v > 2 ? 2 : v); }      // 0 off, 1 everything up front, 2 wide form (loads at their use)
 int a2s_attn_deep_bwd_enabled(void) {
-    if (g_attn_deep_bwd < 0) { const char* e = getenv("A2S_ATTN_DEEP_BWD"); g_attn_deep_bwd = (e && e[0] == '1') ? 1 : 0; }
+    if (g_attn_deep_bwd < 0) { const char* e = getenv("A2S_ATTN_DEEP_BWD"); g_attn_deep_bwd = e ? (atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e))) : 0; }
     return g_attn_deep_bwd;
 }
 template <int NQ>
@@ -1241,8 +1261,12 @@ static void launch_bwd_deep(hipStream_t st, int nwg, const float* Kmat, const fl
                             const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
                             float* dctx_out, long lddo, float* ws, float* ds_out, int T, int G, int chunk, const a2s_attn_rows& r) {
     const size_t shm = ((size_t)NQ * chunk + (size_t)NQ * 7 * 64 * 4 + (size_t)NQ * ATT_DCS + 16) * sizeof(float);
-    hipLaunchKernelGGL((attn_bwd_split256_deep<NQ>), dim3(nwg), dim3(512), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
-                       dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
+    if (a2s_attn_deep_bwd_enabled() == 2)
+        hipLaunchKernelGGL((attn_bwd_split256_deep<NQ, false>), dim3(nwg), dim3(512), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                           dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
+    else
+        hipLaunchKernelGGL((attn_bwd_split256_deep<NQ, true>), dim3(nwg), dim3(512), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
+                           dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
 }
 
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,

@@ -20,8 +20,8 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("B,tf,full_tail", [(6, 0.6, 0.1), (20, 0.5, 0.0), (3, 0.0, 0.3)])
-def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail):
+@pytest.mark.parametrize("B,tf,full_tail,bwd_sweep", [(6, 0.6, 0.1, 1), (20, 0.5, 0.0, 1), (3, 0.0, 0.3, 1), (6, 0.6, 0.1, 2), (20, 0.5, 0.0, 2)])
+def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail, bwd_sweep):
     import models
     from piano_a2s_amd import hip, spec, synthetic, train
     L = hip.lib()
@@ -37,7 +37,7 @@ def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail):
         for defer in (0, 1):
             hip.check(L.a2s_debug_set(b"attn_defer_combine", defer), "debug_set")
             hip.check(L.a2s_debug_set(b"dec_bwd_fold", defer), "debug_set")       # (the backward's folds: dec_bwd_products_g, dec_bwd_query_cmb)
-            hip.check(L.a2s_debug_set(b"attn_deep_bwd", defer), "debug_set")      # (the few-clip backward sweep: attn_bwd_split256_deep)
+            hip.check(L.a2s_debug_set(b"attn_deep_bwd", bwd_sweep if defer else 0), "debug_set")      # (the few-clip backward sweep: attn_bwd_split256_deep, 1 = loads up front, 2 = wide)
             m = models.ScoreTranscription(**cfg)
             m.load_state_dict(init)
             m = m.to(dev).train()
