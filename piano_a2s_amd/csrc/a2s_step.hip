@@ -425,10 +425,10 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step_rt(DecGruArgs a) {
     f32x4 t[RT * 3], u[RT * 3];
 #pragma unroll
     for (int i = 0; i < RT * 3; ++i) t[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8_rt<3, RT, 2>(ax, bi, a.kx / 16, wave, lk, t);               // gi: r, z, n
+    mfma_rows8_rt<3, RT, DEC_CH_GRU>(ax, bi, a.kx / 16, wave, lk, t);               // gi: r, z, n
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { u[rt * 3 + 0] = t[rt * 3 + 0]; u[rt * 3 + 1] = t[rt * 3 + 1]; u[rt * 3 + 2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    mfma_rows8_rt<3, RT, 2>(ah, bh, H2 / 16, wave, lk, u);                 // + gh on r, z; gh_n apart
+    mfma_rows8_rt<3, RT, DEC_CH_GRU>(ah, bh, H2 / 16, wave, lk, u);                 // + gh on r, z; gh_n apart
     f32x4 acc[4 * RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { acc[rt * 4 + 0] = u[rt * 3 + 0]; acc[rt * 4 + 1] = u[rt * 3 + 1]; acc[rt * 4 + 2] = t[rt * 3 + 2]; acc[rt * 4 + 3] = u[rt * 3 + 2]; }
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_products_rt(DecBwdProdArgs a)
     f32x4 acc[RT * 2];
 #pragma unroll
     for (int i = 0; i < RT * 2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8_rt<2, RT, 2>(arow, brow, K / 16, wave, lk, acc);
+    mfma_rows8_rt<2, RT, DEC_CH_PROD>(arow, brow, K / 16, wave, lk, acc);
     reduce_waves<2 * RT>(acc, part, wave, lane);
     if (wave > 0) return;
 #pragma unroll
