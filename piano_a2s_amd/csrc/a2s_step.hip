@@ -54,17 +54,21 @@ int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const fl
 #define DEC_CH_PROD 1
 #define DEC_CH_QUERY 1
 #endif
+#ifndef DEC_NW_PROD
+#define DEC_NW_PROD 8             // waves of dec_bwd_products / dec_out_step (16 halves a wave's chain of k-steps: measured, no gain -- profiles/r05_step_kernel_batches.txt)
+#define DEC_NW_OUT 8
+#endif
 
 // acc[g] += A-row-fragments x B-row-fragments over this wave's share of the k-steps (k-step u covers k in [16u, 16u+16); this lane
 // reads 4 floats at 16u + 4*lk of its A row and of its NT B rows)
-template <int NT, int CH>
+template <int NT, int CH, int NWV = NW>
 __device__ __forceinline__ void mfma_rows8(const float* __restrict__ arow, const float* const (&brow)[NT], int ksteps, int wave, int lk,
                                            f32x4 (&acc)[NT]) {
-    for (int u0 = wave; u0 < ksteps; u0 += NW * CH) {
+    for (int u0 = wave; u0 < ksteps; u0 += NWV * CH) {
         f32x4 a[CH], b[NT][CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int u = u0 + NW * c;
+            const int u = u0 + NWV * c;
             const bool ok = u < ksteps;
             a[c] = ok ? *reinterpret_cast<const f32x4*>(arow + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -73,7 +77,7 @@ __device__ __forceinline__ void mfma_rows8(const float* __restrict__ arow, const
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            if (u0 + NW * c >= ksteps) break;
+            if (u0 + NWV * c >= ksteps) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -82,11 +86,11 @@ __device__ __forceinline__ void mfma_rows8(const float* __restrict__ arow, const
     }
 }
 
-// Sum of the 8 waves' partial tiles in wave 0, fixed order: (w, w+4) -> (w, w+2) -> (0, 1).  part: 4 * NT * 64 f32x4 of LDS.
-template <int NT>
+// Sum of the waves' partial tiles in wave 0, fixed order: (w, w+4) -> (w, w+2) -> (0, 1) for 8 waves.  part: (NWV / 2) * NT * 64 f32x4 of LDS.
+template <int NT, int NWV = NW>
 __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NT], f32x4* part, int wave, int lane) {
 #pragma unroll
-    for (int half = NW / 2; half >= 1; half >>= 1) {
+    for (int half = NWV / 2; half >= 1; half >>= 1) {
         if (wave >= half && wave < 2 * half) {
 #pragma unroll
             for (int g = 0; g < NT; ++g) part[((wave - half) * NT + g) * 64 + lane] = acc[g];
@@ -527,8 +531,8 @@ __device__ __forceinline__ void dec_row_epilogue(const DecOutArgs& a, int vrow, 
     }
 }
 
-__global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
-    __shared__ f32x4 part[4 * 2 * 64];
+__global__ __launch_bounds__(64 * DEC_NW_OUT) void dec_out_step(DecOutArgs a) {
+    __shared__ f32x4 part[(DEC_NW_OUT / 2) * 2 * 64];
     __shared__ int last_flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.skip && *a.skip) return;
@@ -549,8 +553,8 @@ __global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const int arow_p = dec_row(a.rowmap, min(row0 + li, R - 1));
     const float* arow = (vocab ? a.o + (long)arow_p * a.ldo : a.hnew + (long)arow_p * a.H2);
-    mfma_rows8<2, DEC_CH_OUT>(arow, brow, K / 16, wave, lk, acc);
-    reduce_waves<2>(acc, part, wave, lane);
+    mfma_rows8<2, DEC_CH_OUT, DEC_NW_OUT>(arow, brow, K / 16, wave, lk, acc);
+    reduce_waves<2, DEC_NW_OUT>(acc, part, wave, lane);
     if (wave == 0) {
         const float* bias = vocab ? a.out_b : a.attn_b;
         float* out = vocab ? a.logits : a.q_next;
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(64 * NW) void dec_out_step(DecOutArgs a) {
 #ifndef DEC_X_NOFENCE
     __threadfence();
 #endif
-    for (int rr = wave; rr < 16; rr += NW) {
+    for (int rr = wave; rr < 16; rr += DEC_NW_OUT) {
         const int row = row0 + rr;
         if (row < R) dec_row_epilogue(a, row, t, lane);
     }
@@ -600,8 +604,8 @@ struct DecBwdProdArgs {
     int nxa, kx, R, H2;
 };
 
-__global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
-    __shared__ f32x4 part[4 * 2 * 64];
+__global__ __launch_bounds__(64 * DEC_NW_PROD) void dec_bwd_products(DecBwdProdArgs a) {
+    __shared__ f32x4 part[(DEC_NW_PROD / 2) * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int R = a.R, K = 3 * a.H2, row0 = blockIdx.y * 16;
@@ -621,8 +625,8 @@ __global__ __launch_bounds__(64 * NW) void dec_bwd_products(DecBwdProdArgs a) {
             for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
     }
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8<2, DEC_CH_PROD>(A + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K, brow, K / 16, wave, lk, acc);
-    reduce_waves<2>(acc, part, wave, lane);
+    mfma_rows8<2, DEC_CH_PROD, DEC_NW_PROD>(A + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K, brow, K / 16, wave, lk, acc);
+    reduce_waves<2, DEC_NW_PROD>(acc, part, wave, lane);
     if (wave > 0) return;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -1022,7 +1026,7 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
     f.rowmap = rowmap;
     f.n_clips = a.n_clips > 0 ? a.n_clips : R; f.R = nrows; f.V = a.V; f.E = a.E; f.t = t; f.teacher_force = tf; f.eos_id = a.eos_id;
     f.max_t = a.steps; f.H2 = H2;
-    hipLaunchKernelGGL(dec_out_step, dim3(a2s_cdiv(nrows, 16), NVW + a2s_cdiv(a.H, 32)), dim3(64 * NW), 0, st, f);
+    hipLaunchKernelGGL(dec_out_step, dim3(a2s_cdiv(nrows, 16), NVW + a2s_cdiv(a.H, 32)), dim3(64 * DEC_NW_OUT), 0, st, f);
     A2S_CHECK_LAUNCH("dec_out_step");
     return A2S_OK;
 }
@@ -1079,7 +1083,7 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
         if (rc) return rc;
         if (rt == 4) hipLaunchKernelGGL(dec_bwd_products_rt<4>, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(64 * NW), 0, st, p);
         else if (rt == 2) hipLaunchKernelGGL(dec_bwd_products_rt<2>, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 32)), dim3(64 * NW), 0, st, p);
-        else hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, p);
+        else hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * DEC_NW_PROD), 0, st, p);
     }
     A2S_CHECK_LAUNCH("dec_bwd_products");
     // attention: dctx = dx[:, E:] + do[:, 2H:]
