@@ -1422,7 +1422,10 @@ size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward) {
         const char* m = getenv("A2S_ATTN_BULK_LDS_MQ");
         const char* mb = getenv("A2S_ATTN_BULK_LDS_MQ_BWD");
         cap[0] = e ? atol(e) : 65536;
-        cap[1] = b ? atol(b) : (e ? atol(e) : 32768);
+        // (round 5: 28 KB instead of 32 -- still 5 workgroups per CU, but 17 KB of LDS stay free on every CU: with 5 x 32 KB the long-clip chain's
+        // kernels, which all need 8-16 KB for their cross-wave reduction, could only start where a bulk workgroup had just left; the chain's backward
+        // step period was twice the sum of its kernels' durations (profiles/r05_trace_overlap.txt).  452.3 -> 449.5 ms per step, profiles/r05_prefix_percent.txt)
+        cap[1] = b ? atol(b) : (e ? atol(e) : 28672);
         cap[2] = m ? atol(m) : cap[0];
         cap[3] = mb ? atol(mb) : cap[1];
         for (int i = 0; i < 4; ++i) cap[i] = cap[i] < 0 ? 0 : (cap[i] > 65536 ? 65536 : cap[i]);
