@@ -860,7 +860,9 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     const float* Kb = Kmat + ((long)b * T + t0) * H;
     const float* Eb = enc + ((long)b * T + t0) * 2 * H;
     // dctx of the clip's rows (dctx_a + dctx_b) -> LDS as the B operand of pass A, their dot products with the saved contexts beside them
-    float* dcT = reinterpret_cast<float*>(red4 + NQ * 3 * 64);            // NQ x ATT_DCS floats
+    // (round 5: the dctx image and the cross-group reduction scratch SHARE their LDS -- the image is last read in pass A, the scratch first written after
+    // pass B, a barrier apart: 13.6 KB instead of 22 at four rows, which fits the 17 KB a CU has left beside the bulk group's backward sweeps)
+    float* dcT = reinterpret_cast<float*>(red4);                           // NQ x ATT_DCS floats (8.3 KB at NQ = 4) inside red4's 12.3 KB
     float* dots = dcT + NQ * ATT_DCS;                                      // 16
     int onmask = 0;
 #pragma unroll
@@ -1324,7 +1326,9 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
             else hipLaunchKernelGGL(attn_bwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
                                     dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
         } else {
-            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + (size_t)groups * 3 * 64 * 4 + (size_t)groups * ATT_DCS + 16) * sizeof(float), r.n_active, 3);
+            // [ds rows][max(reduction scratch: groups x 3 x 64 float4, dctx image + dots: groups x ATT_DCS + 16 floats)]
+            const size_t scratch = (size_t)groups * 3 * 64 * 4 > (size_t)groups * ATT_DCS + 16 ? (size_t)groups * 3 * 64 * 4 : (size_t)groups * ATT_DCS + 16;
+            const size_t shm = a2s_attn_bulk_lds(((size_t)groups * chunk + scratch) * sizeof(float), r.n_active, 3);
 #define A2S_BWD_MQ(N) launch_bwd_mq<N>(st, nwg, shm, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r, nt)
             switch (groups) {
                 case 2: A2S_BWD_MQ(2); break;

@@ -109,3 +109,36 @@ if enc:
         n += 1
         if n >= 70:
             break
+
+# ---- (round 5) where the long-clip chain's queue idles: gaps between consecutive kernels of that queue, by the kernel in front of the gap, and what the
+# other queues run during the long ones
+g1s = sorted(g1, key=lambda k: k[1])
+gap_by = {}
+long_gaps = []
+for a, b in zip(g1s[:-1], g1s[1:]):
+    gap = b[1] - a[2]
+    if gap <= 0 or gap > 2000:
+        continue
+    gap_by.setdefault((a[0][:28], b[0][:28]), []).append(gap)
+    if gap > 30:
+        long_gaps.append((a[2], b[1]))
+print("\ngaps on the long-clip group's queue (kernel in front -> kernel behind): n, mean us, p90 us, total ms")
+for (ka, kb), v in sorted(gap_by.items(), key=lambda kv: -sum(kv[1]))[:14]:
+    v = np.array(v)
+    print(f"  {ka:28s} -> {kb:28s} {len(v):6d} {v.mean():8.1f} {np.quantile(v, .9):8.1f} {v.sum() / 1e3:8.1f}")
+tot_long = sum(b - a for a, b in long_gaps)
+print(f"gaps > 30 us: {len(long_gaps)}, {tot_long / 1e3:.1f} ms in all; what the other queues run meanwhile (share of that time, per queue):")
+others = [k for k in K if k[3] != q1]
+starts = np.array([k[1] for k in others])
+ends = np.array([k[2] for k in others])
+cover = {}
+for a, b in long_gaps[:20000]:
+    lo_i = np.searchsorted(starts, a - 3000)
+    hi_i = np.searchsorted(starts, b)
+    for i in range(lo_i, hi_i):
+        o = min(ends[i], b) - max(starts[i], a)
+        if o > 0:
+            key = (others[i][3], others[i][0][:34])
+            cover[key] = cover.get(key, 0.0) + o
+for (q, n), t in sorted(cover.items(), key=lambda kv: -kv[1])[:12]:
+    print(f"  queue {q}  {n:34s} {100 * t / max(tot_long, 1):5.1f} %")
