@@ -13,6 +13,7 @@
 // (global loads for tile t+1 are in flight while tile t is multiplied); LDS images padded so the
 // fragment reads (lane = (m&15, k>>... ) one dword each) are at most 2-way conflicted.
 #include "a2s_common.h"
+int a2s_attn_bulk_cap_enabled(void);
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
@@ -591,10 +592,20 @@ static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
             return;
         }
     }
-    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, g);
+    // Occupancy cap of the bulk clip group's per-step products (M >= 256 rows, small tiles) while another clip group decodes beside it
+    // (a2s_attn_bulk_cap_enabled(): the same condition as the attention sweeps' cap): A2S_GEMM_MID_LDS_PAD bytes of unused dynamic LDS per workgroup.
+    // The long-clip chain's kernels wait for a place beside whole grids of these workgroups (profiles/r05_trace_overlap.txt).  Default 16 KB (3 instead of
+    // 4 workgroups of the 64x32 tile per CU): 447.3 -> 443.5 ms per step, 32 KB 445.2 (profiles/r05_prefix_percent.txt); 0 = off.
+    size_t pad = 0;
+    if (BM * BN <= 64 * 64 && g.M >= 256 && a2s_attn_bulk_cap_enabled()) {
+        static long padv = -1;
+        if (padv < 0) { const char* e = getenv("A2S_GEMM_MID_LDS_PAD"); padv = e ? atol(e) : 16384; if (padv < 0 || padv > 32768) padv = 0; }
+        pad = (size_t)padv;
+    }
+    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), pad, st, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), pad, st, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), pad, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), pad, st, g);
 }
 
 // 256x256 tiles, 8 waves, two-term fp16 split: the big two-term products (19200 -> 256 Linear forward and weight gradient).  The 128x128
