@@ -1410,7 +1410,7 @@ int a2s_attn_nt_enabled(void) {
 // A2S_ATTN_BULK_LDS / A2S_ATTN_BULK_LDS_BWD = bytes (0: no cap).  The cap only pays while ANOTHER clip group decodes beside the bulk one: the host
 // switches it on for exactly those passes (a2s_debug_set("attn_bulk_cap", 1); off by default: greedy decoding of 256 clips 495 -> 468 clips/s with it).
 static int g_attn_bulk_cap = 0;
-void a2s_attn_bulk_cap_set(int on) { g_attn_bulk_cap = on ? 1 : 0; }
+void a2s_attn_bulk_cap_set(int on) { g_attn_bulk_cap = on < 0 ? 0 : (on > 2 ? 2 : on); }      // 0 off, 1 the caps below, 2 forward launches at A2S_ATTN_BULK_LDS_STRONG (one per CU)
 int a2s_attn_bulk_cap_enabled(void) { return g_attn_bulk_cap; }
 size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward) {
     if (!g_attn_bulk_cap) return shm;
@@ -1428,14 +1428,21 @@ size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward) {
         cap[1] = b ? atol(b) : (e ? atol(e) : 28672);
         cap[2] = m ? atol(m) : cap[0];
         cap[3] = mb ? atol(mb) : cap[1];
-        for (int i = 0; i < 4; ++i) cap[i] = cap[i] < 0 ? 0 : (cap[i] > 65536 ? 65536 : cap[i]);
+        // (forward caps may exceed 64 KB -- ONE workgroup per CU above 80 KB: the launchers raise the kernels' dynamic-LDS limit; backward stays <= 64 KB)
+        for (int i = 0; i < 4; ++i) { const long lim = (i == 0 || i == 2) ? 98304 : 65536; cap[i] = cap[i] < 0 ? 0 : (cap[i] > lim ? lim : cap[i]); }
     }
-    const size_t c = (size_t)cap[backward & 3];
+    static long strong = -1;
+    if (strong < 0) { const char* e = getenv("A2S_ATTN_BULK_LDS_STRONG"); strong = e ? atol(e) : 81920; if (strong < 0) strong = 0; if (strong > 98304) strong = 98304; }
+    const size_t c = (g_attn_bulk_cap == 2 && (backward & 1) == 0 && strong > 0) ? (size_t)strong : (size_t)cap[backward & 3];
     return (n_active >= 64 && c > shm) ? c : shm;
 }
 template <int NQ>
 static void launch_fwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                           float* ws, float* attw, int T, int G, int chunk, const a2s_attn_rows& r, const AttnFusedTail& ft, bool nt) {
+    if (nt && shm > 65536) {
+        static bool raised = false;
+        if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split256_mq<NQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304); raised = true; }
+    }
     if (nt) hipLaunchKernelGGL((attn_fwd_split256_mq<NQ, true>), dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk,
                                r.clip_order, r.row_until, r.step, r.n_clips, ft);
     else hipLaunchKernelGGL((attn_fwd_split256_mq<NQ, false>), dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, ws, attw, T, G, chunk,
@@ -1485,6 +1492,10 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
             }
         } else if (groups == 1) {
             const size_t shm = a2s_attn_bulk_lds((chunk + 16 + 128 * 4) * sizeof(float), r.n_active, 0);
+            if (nt && shm > 65536) {
+                static bool raised = false;
+                if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split256<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304); raised = true; }
+            }
             if (nt) hipLaunchKernelGGL(attn_fwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
             else hipLaunchKernelGGL(attn_fwd_split256<false>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, part, attw, T, G, chunk, n_done, n_rows_total, r.clip_order, ft);
         } else {

@@ -688,7 +688,13 @@ class Engine:
             clip_groups = [(0, B)]
         assert clip_groups[0][0] == 0 and clip_groups[-1][1] == B and all(a[1] == b[0] for a, b in zip(clip_groups[:-1], clip_groups[1:]))
         # occupancy cap of the bulk group's attention launches (csrc/a2s_seq.hip a2s_attn_bulk_lds): only while another group decodes beside it
-        hip.check(hip.lib().a2s_debug_set(b"attn_bulk_cap", 1 if (len(clip_groups) > 1 and _os.environ.get("A2S_ATTN_BULK_CAP", "1") != "0") else 0), "debug_set")
+        # (round 5: level 2 -- ONE forward sweep workgroup per CU instead of two -- can be asked for in steps of at least A2S_ATTN_STRONG_CAP_SEGMENTS bar
+        # segments, where the long-clip chain is the step's critical path.  Measured: everywhere, steps of 3 segments 496 -> 488 ms but the others
+        # 440 -> 450; from 3 or 4 segments on, 443.2 / 444.6 -> 446.7 / 443.8 and 445.4 / 444.8 (profiles/r05_prefix_percent.txt): no gain, off by default)
+        cap_level = 0
+        if len(clip_groups) > 1 and _os.environ.get("A2S_ATTN_BULK_CAP", "1") != "0":
+            cap_level = 2 if (len(segments) >= int(_os.environ.get("A2S_ATTN_STRONG_CAP_SEGMENTS", "99")) and training) else 1
+        hip.check(hip.lib().a2s_debug_set(b"attn_bulk_cap", cap_level), "debug_set")
 
         bar_major = fuse
         self.bar_major = bar_major
