@@ -623,7 +623,10 @@ class Engine:
             # ONE host sync per forward, before anything is enqueued
             gt_cpu = tuple(gt_host) if gt_host is not None else (up_gt.cpu(), lo_gt.cpu(), up_len_gt.cpu(), lo_len_gt.cpu())
         # did a persistent launch of the PREVIOUS pass give up a wait?  (its loss was non-finite, the update skipped; from now on launch per step)
-        hip.check_persist_abort(dev)
+        # (train.TrainStep polls the latch itself, without synchronising, and sets abort_check = False: a blocking read here would wait for the ConvStack it has
+        # already enqueued)
+        if getattr(self, "abort_check", True):
+            hip.check_persist_abort(dev)
 
         # ConvStack + encoder are enqueued first: the host-side planning of the decoder below runs while they execute.  Its small
         # host->device uploads go through pinned memory without synchronising (a pageable upload would drain the stream each time).

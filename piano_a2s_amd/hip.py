@@ -84,15 +84,53 @@ def abort_latch(device):
     return t
 
 
+_LATCH_READS = {}         # device index -> [pinned host word, event of the copy in flight or None]
+
+
+def post_persist_abort_read(device):
+    """Enqueue an asynchronous read of the abort latch behind everything the current stream holds (train.TrainStep: at the end of a step).  The
+    NEXT step looks at the host copy with poll_persist_abort -- no synchronisation: a blocking read at the start of Engine.forward made the host
+    wait for the ConvStack the fused step had already enqueued (48 ms) before it planned the decoder and enqueued the encoder (round 5)."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    e = _LATCH_READS.get(idx)
+    if e is None:
+        e = _LATCH_READS[idx] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    e[0].copy_(abort_latch(device), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    e[1] = ev
+
+
+def poll_persist_abort(device, raise_error=False):
+    """Non-blocking form of check_persist_abort: acts on the latch value read by the last post_persist_abort_read once that copy has completed
+    (an abort is then noticed one step later at worst; the step it happened in skipped its update on the device anyway).  Before the first
+    posted read it falls back to the blocking check (the stream is idle then)."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    e = _LATCH_READS.get(idx)
+    if e is None:
+        return check_persist_abort(device, raise_error)
+    if e[1] is None or not e[1].query():
+        return 0
+    e[1] = None
+    bits = int(e[0][0])
+    if not bits:
+        return 0
+    return _persist_abort_seen(bits, abort_latch(device), raise_error)
+
+
 def check_persist_abort(device, raise_error=False):
     """Call where the host has just synchronised with the device anyway (a 4-byte read).  If a persistent launch gave up since the last call:
     its outputs were poisoned (NaN loss -> the update was skipped) -- switch the persistent paths off for the rest of the process (the chip is
     evidently shared or partitioned in a way the residency check cannot see) and warn, or raise (greedy decoding: the ids are unusable)."""
-    global PERSIST_ABORTS
     t = abort_latch(device)
     bits = int(t.item())
     if not bits:
         return 0
+    return _persist_abort_seen(bits, t, raise_error)
+
+
+def _persist_abort_seen(bits, t, raise_error):
+    global PERSIST_ABORTS
     t.zero_()
     PERSIST_ABORTS += 1
     L = lib()

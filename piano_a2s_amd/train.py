@@ -329,6 +329,10 @@ class TrainStep:
         eng.skip_finished_rows = self.skip_finished_rows
         eng.fuse_bars = self.skip_finished_rows and self.fuse_bars
         eng.late_wgrads = self.late_wgrads
+        # the persistent kernels' abort latch: looked at here through the asynchronous read the previous step left behind (hip.post_persist_abort_read)
+        if spectrogram.is_cuda:
+            hip.poll_persist_abort(spectrogram.device)
+            eng.abort_check = False
         gt_host, perm, host_plan = None, None, None
         S = self.state()
         conv_pre = None
@@ -471,6 +475,8 @@ class TrainStep:
         eng.group_hook = None
         self._keep_alive, eng._keep_alive = getattr(eng, "_keep_alive", None), None      # (pinned staging of this step: released by the next one)
         self._last = (outs, eng.bar_major, groups, perm)
+        if spectrogram.is_cuda:
+            hip.post_persist_abort_read(spectrogram.device)
         return losses
 
     @property
