@@ -234,7 +234,10 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
         deferred_work("attn")
         ev = torch.cuda.Event()
         ev.record()
-        late.append((lambda: deferred_work("weights"), ev, (dlog, do_all, dgi_all, dgh_all, dq_all, dx, sv["x"], sv["h"], sv["o"], sv["ids"])))
+        # everything the closure reads that was allocated on this (staff / group) stream: the weight-gradient stream records them all
+        act = sv.get("active") or {}
+        late.append((lambda: deferred_work("weights"), ev, (dlog, do_all, dgi_all, dgh_all, dq_all, dx, sv["x"], sv["h"], sv["o"], sv["ids"], sv["drop"], sv["gt_bar"],
+                                                            sv.get("flags_dev"), act.get("live_idx"), dlog_amax, enc_amax)))
         return dh[0], None
     if deferred is None:
         deferred_work()
@@ -260,6 +263,8 @@ class Backward:
     What the groups write per CLIP (dEnc, dK, d_hidden) they write to disjoint slices; what they ACCUMULATE over clips (every weight
     gradient) goes to a flat gradient buffer of the group's own (16.4 M floats), added to `flat` once after the join -- no two streams
     ever accumulate into the same memory."""
+
+    check_fold = False          # tests set it: finish() then verifies (with a host sync) what the late fold of the group buffers assumes
 
     def __init__(self, eng, S, shape, dev, clip_groups, concurrent, bar_major):
         from .spec import flat_layout, is_buffer
@@ -513,6 +518,9 @@ class Backward:
             with torch.cuda.stream(wg):
                 for gf in self.group_flat[1:]:
                     flat[late_join:].add_(gf[late_join:])
+                if Backward.check_fold:                      # tests: nothing but decoder gradients may sit in the groups' own buffers
+                    for gi, gf in enumerate(self.group_flat[1:], 1):
+                        assert not bool(gf[:late_join].any()), f"clip group {gi}: non-decoder gradients in the group buffer would be lost by the late fold"
         # The encoder's last weight gradients (layer 0: ~5 ms of GEMMs on the weight-gradient stream, nothing of the encoder left to run beside
         # them) overlap with the START of the ConvStack backward: the caller's stream does not wait for them here.  The decoder + encoder slice
         # is announced from that stream (a collective issued there is ordered behind its work, which itself waited for everything the main

@@ -95,6 +95,12 @@ def post_persist_abort_read(device):
     e = _LATCH_READS.get(idx)
     if e is None:
         e = _LATCH_READS[idx] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    if e[1] is not None:
+        # the previous step's read was never consumed (a loop without a host synchronisation per step: the poll at the start of this step came
+        # before that copy had completed).  It is a whole step old -- waiting for it costs nothing -- and must not be overwritten unseen: an
+        # abort would otherwise never be noticed and every following update would be skipped for a NaN loss.
+        e[1].synchronize()
+        _consume_latch_read(e, device, False)
     e[0].copy_(abort_latch(device), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
@@ -110,7 +116,11 @@ def poll_persist_abort(device, raise_error=False):
     if e is None:
         return check_persist_abort(device, raise_error)
     if e[1] is None or not e[1].query():
-        return 0
+        return 0                          # (still in flight: it stays pending -- the next poll or the next post consumes it)
+    return _consume_latch_read(e, device, raise_error)
+
+
+def _consume_latch_read(e, device, raise_error):
     e[1] = None
     bits = int(e[0][0])
     if not bits:

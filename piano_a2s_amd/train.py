@@ -253,6 +253,30 @@ def split_long_group(long_ids, until_up, until_lo, segments, min_gain=0.1):
     return None
 
 
+def plan_step_groups(gt_host, bars, max_length, rng, teacher_forcing_ratio, group_plan=None, long_subgroups=True):
+    """The host's clip-group plan of one step, from the targets alone: gt_host = (upper, lower, ...) host tensors (B, bars, len).  Returns (order,
+    group_cuts, host_plan): the clip permutation, the contiguous clip ranges of the groups in that order -- [ordinary | long] or, when the long
+    clips' longest bars lie in different bar segments of THIS step's coins, [ordinary | long A | long B] (split_long_group) -- and the coins if
+    they had to be drawn for that (engine.draw_plan: the reference's draw order; Engine.forward then takes them as host_plan), else None.
+    TrainStep._step calls it; tests/golden/make_golden.py uses it to choose fixtures that exercise the three-group path."""
+    import numpy as _np
+    up, lo = gt_host[0], gt_host[1]
+    idx_u = torch.arange(1, up.shape[-1] + 1)
+    idx_l = torch.arange(1, lo.shape[-1] + 1)
+    until_u, until_l = ((up != PAD).long() * idx_u).amax(-1).numpy(), ((lo != PAD).long() * idx_l).amax(-1).numpy()
+    order, n_main = plan_clip_groups(until_u, until_l, **(group_plan or {}))
+    B = up.shape[0]
+    group_cuts, host_plan = [(0, n_main), (n_main, B)], None
+    if n_main < B and long_subgroups:
+        # the coins of the step are drawn HERE, in the reference's order: the cut looks at the bar segments
+        host_plan = engine.draw_plan(gt_host, bars, max_length, rng, teacher_forcing_ratio)
+        sub = split_long_group(order[n_main:].tolist(), until_u, until_l, engine.plan_segments(host_plan, bars, True))
+        if sub is not None:
+            order = _np.concatenate([order[:n_main], _np.asarray(sub[0], dtype=order.dtype), _np.asarray(sub[1], dtype=order.dtype)])
+            group_cuts = [(0, n_main), (n_main, n_main + len(sub[0])), (n_main + len(sub[0]), B)]
+    return order, group_cuts, host_plan
+
+
 class TrainStep:
     """model: models.ScoreTranscription on a GPU.  One call = one optimizer step on one minibatch."""
 
@@ -340,24 +364,36 @@ class TrainStep:
         if plan_groups and self.early_convstack and spectrogram.is_cuda:
             # Round 5: the ConvStack does not depend on the decoder's plan (nor on the clip order), so it is ENQUEUED FIRST -- before the host
             # reads the targets and cuts the clip groups (4-5 ms during which the GPU used to idle at the start of every step).  The targets come
-            # over on a side stream, so that the read does not wait for the ConvStack just enqueued on this one.
+            # over on a side stream, so that the read does not wait for the ConvStack just enqueued on this one.  It DOES wait for everything the
+            # caller had enqueued before the step (`uploads`, recorded ahead of the ConvStack): the real trainer uploads the batch with
+            # non_blocking copies from pinned memory on this stream (recipe._to_device), behind the spectrogram's DMA or the online VQT --
+            # without the wait the side stream could read the targets before they land, and the host plan would disagree with the device's.
+            # The same wait bounds the host's run-ahead to one step (the event completes when the previous step's last kernel has): that is
+            # what engine._PinnedPool's two alternating staging areas rely on.
+            uploads = torch.cuda.Event()
+            uploads.record()
             if self.sync_bn and eng.sync_bn:
                 engine.Engine.check_counts(spectrogram.shape[0] * spectrogram.shape[2] * spectrogram.shape[3], spectrogram.device)
             Bc, _, Tc, _ = spectrogram.shape
             mask = (torch.rand((Bc * Tc, self.model.cfg["conv_feature_size"]), device=spectrogram.device) >= 0.2).to(torch.uint8) if self.dropout else None
             conv_out, conv_saved = eng.convstack(S, spectrogram, True, mask)
-            copy_stream = engine.side_streams(spectrogram.device)[0]         # (the targets exist before the step: the copy waits for nothing)
+            # (one of the step's four streams -- a fifth would share a hardware queue with one of them anyway, engine.group_stream; the work the
+            # previous step left on it finished before that step's ConvStack backward, i.e. before `uploads`)
+            copy_stream = engine.side_streams(spectrogram.device)[0]
             srcs = (up_t, lo_t, up_len, lo_len)
             key = tuple((tuple(t.shape), t.dtype) for t in srcs)
             if getattr(self, "_gt_pinned_key", None) != key:              # pinned staging, allocated once per batch shape
                 self._gt_pinned = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in srcs]
                 self._gt_pinned_key = key
+            copy_stream.wait_event(uploads)
             with torch.cuda.stream(copy_stream):
                 for dst, t in zip(self._gt_pinned, srcs):
                     dst.copy_(t, non_blocking=True)
+                    t.record_stream(copy_stream)
                 done = torch.cuda.Event()
                 done.record()
             done.synchronize()
+            hip.poll_persist_abort(spectrogram.device)                    # (the previous step's latch read has landed by now)
             gt_host = [p.clone() for p in self._gt_pinned]
             conv_pre = [conv_out, conv_saved, None]
         if eng.fuse_bars and isinstance(self.clip_groups, (list, tuple)):
@@ -365,21 +401,11 @@ class TrainStep:
         elif eng.fuse_bars and self.clip_groups:
             if gt_host is None:
                 gt_host = [up_t.cpu(), lo_t.cpu(), up_len.cpu(), lo_len.cpu()]       # the one host sync of the step (Engine.forward reuses it)
-            idx_u = torch.arange(1, up_t.shape[-1] + 1)
-            idx_l = torch.arange(1, lo_t.shape[-1] + 1)
-            until_u, until_l = ((gt_host[0] != PAD).long() * idx_u).amax(-1).numpy(), ((gt_host[1] != PAD).long() * idx_l).amax(-1).numpy()
-            order, n_main = plan_clip_groups(until_u, until_l, **self.group_plan)
+            cfg_ = self.model.cfg
+            order, group_cuts, host_plan = plan_step_groups(gt_host, cfg_["max_bars"], cfg_["max_length"], rng, teacher_forcing_ratio, self.group_plan,
+                                                            self.long_subgroups)
             B = up_t.shape[0]
-            group_cuts = [(0, n_main), (n_main, B)]
-            if n_main < B and self.long_subgroups:
-                # the coins of the step are drawn HERE, in the reference's order (Engine.forward takes them as host_plan): the cut looks at the bar segments
-                cfg_ = self.model.cfg
-                host_plan = engine.draw_plan(gt_host, cfg_["max_bars"], cfg_["max_length"], rng, teacher_forcing_ratio)
-                sub = split_long_group(order[n_main:].tolist(), until_u, until_l, engine.plan_segments(host_plan, cfg_["max_bars"], True))
-                if sub is not None:
-                    import numpy as _np
-                    order = _np.concatenate([order[:n_main], _np.asarray(sub[0], dtype=order.dtype), _np.asarray(sub[1], dtype=order.dtype)])
-                    group_cuts = [(0, n_main), (n_main, n_main + len(sub[0])), (n_main + len(sub[0]), B)]
+            n_main = group_cuts[0][1]
             if n_main < B:
                 perm = torch.from_numpy(order)
                 gt_host = [t[perm] for t in gt_host]

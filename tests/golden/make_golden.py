@@ -7,7 +7,7 @@ procedural weights (piano_a2s_amd.spec.procedural_state) and synthetic batches
 (piano_a2s_amd.synthetic.make_batch), and stores inputs' checksums + the reference's outputs.
 Nothing of the reference's text is stored: fixtures are numbers.
 
-Usage:  python tests/golden/make_golden.py [g1] [g2] [g2tf] [g3] [g4] [tok]
+Usage:  python tests/golden/make_golden.py [g1] [g2] [g2tf] [g3] [g4] [g4b] [tok]
 The fixtures are committed; this script documents how they were made and can regenerate them.
 """
 import hashlib
@@ -393,7 +393,22 @@ G4_BATCH = dict(frames=301, upper_range=(10, 60), lower_range=(6, 40), full_tail
 G4 = dict(weights_seed=2041, eos_bias=2.5, batch=12, batch_seed=90, full_rows=((3, 1, "up"), (8, 3, "lo")), tf=0.7, rseeds=(4, 6, 11, 15, 21, 28))
 
 
-def make_g4(ref_models):
+G4B_BATCH = dict(frames=301, upper_range=(10, 60), lower_range=(6, 40), full_tail=0.0, spectrogram="ridges")
+# round 6: TWO clips (2 and 9) with a full-length UPPER bar, in bars 0 and 3 -- with the planner's 12-clip cost setting (step_cost 4) they
+# form the long-clip group, and under a seed whose bar-level coins put bars 0 and 3 into different bar segments the fused step cuts that group in two
+# (train.split_long_group): the three-clip-group path the benchmark runs by default.  Seeds under which the host plan does not split are not candidates.
+G4B = dict(weights_seed=2041, eos_bias=2.5, batch=12, batch_seed=93, full_rows=((2, 0, "up"), (9, 3, "up")), tf=0.7, rseeds=(2, 4, 15, 21, 28, 33),
+           plan_kw={"step_cost": 4.0}, must_split=True)
+
+
+def host_groups(batch, cfg, rseed, tf, plan_kw):
+    """The clip groups train.TrainStep forms on this minibatch under Python-random seed `rseed` (pure host code: piano_a2s_amd.train.plan_step_groups)."""
+    from piano_a2s_amd import train
+    order, cuts, _ = train.plan_step_groups([batch[3], batch[5], batch[4], batch[6]], cfg["max_bars"], cfg["max_length"], random.Random(rseed), tf, plan_kw, True)
+    return order.tolist(), cuts
+
+
+def make_g4(ref_models, G4=None, G4_BATCH=None, name="g4_step"):
     """Round 5: ONE WHOLE OPTIMIZER STEP of the reference on a minibatch that forces the fused step's planner through its
     control flow -- full widths (H = 256, E = 16, 480 bins), T = 301 frames (so that the as-written reference fits in this container's RAM at
     B = 12), two clips (3 and 8, neither at the end: the planner must permute) holding a full-length bar without <eos>, train mode, dropout
@@ -401,10 +416,19 @@ def make_g4(ref_models):
     terms, every gradient norm, the clip norm, and -- from the torch objects the reference recipe instantiates (clip_grad_norm_(5.0),
     Adadelta(lr=1, rho=.95, eps=1e-8); reference pretrain.py:121-129, hparams/pretrain.yaml:44-47) -- per parameter the norm of the update, the norm of
     the updated tensor and 64 sampled values of it.  The Python-random seed is the one of `rseeds` with the largest minimum margin (as g2_tf)."""
+    G4 = G4 or globals()["G4"]
+    G4_BATCH = G4_BATCH or globals()["G4_BATCH"]
     cfg = spec.default_cfg()
     st = spec.procedural_state(cfg, G4["weights_seed"], eos_bias=G4["eos_bias"], lively="token")
     batch = synthetic.make_batch(G4["batch"], cfg, G4["batch_seed"], full_rows=G4["full_rows"], **G4_BATCH)
     no_dropout()
+    rseeds = list(G4["rseeds"])
+    if G4.get("must_split"):
+        plans = {r: host_groups(batch, cfg, r, G4["tf"], G4["plan_kw"]) for r in rseeds}
+        for r, (order, cuts) in plans.items():
+            print(name, ": seed", r, "-> clip groups", cuts, "order", order, flush=True)
+        rseeds = [r for r in rseeds if len(plans[r][1]) == 3]
+        assert rseeds, "no candidate seed cuts the long-clip group in two"
     live = [(batch[3] != 147), (batch[5] != 147)]          # decisions that reach the loss or the next bar's staff token: targets that are not <pad>
 
     def run(rseed, grad):
@@ -428,7 +452,7 @@ def make_g4(ref_models):
         return m, outs, draws, mins
 
     best = None
-    for rseed in G4["rseeds"]:
+    for rseed in rseeds:
         m, outs, draws, mins = run(rseed, False)
         print("g4: python-random seed", rseed, "draws", draws, "min margins at non-pad targets (up, lo)", mins, flush=True)
         if best is None or min(mins) > min(best[1]):
@@ -445,6 +469,10 @@ def make_g4(ref_models):
           "full_rows": [list(r) for r in G4["full_rows"]], "tf": G4["tf"], "random_seed": rseed, "draws": draws, "margins": {}, "min_margin_at_targets": cm_live,
           "batch_kwargs": {k: list(v) if isinstance(v, tuple) else v for k, v in G4_BATCH.items()}, "state_sha256": digest(st.values()),
           "batch_sha256": digest([batch[0], batch[1], batch[2], batch[3], batch[4], batch[5], batch[6]])}
+    if G4.get("must_split"):
+        order, cuts = host_groups(batch, cfg, rseed, G4["tf"], G4["plan_kw"])
+        assert len(cuts) == 3
+        cm["plan_kw"], cm["clip_groups"], cm["clip_order"] = G4["plan_kw"], [list(c) for c in cuts], order
     ts, key, up, lo = [o.detach() for o in outs]
     out["ts"], out["key"] = ts.numpy(), key.numpy()
     for nm, o in (("up", up), ("lo", lo)):
@@ -478,10 +506,10 @@ def make_g4(ref_models):
     for k in sd:
         if spec.is_buffer(k):
             out[f"buf.{k}"] = sd[k].numpy().copy()
-    np.savez_compressed(os.path.join(HERE, "g4_step.npz"), **out)
-    with open(os.path.join(HERE, "g4_step.json"), "w") as f:
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
         json.dump(cm, f, indent=1)
-    print("g4 written: seed", rseed, "rows", out["up_rows"].tolist(), out["lo_rows"].tolist(), "losses", out["losses"].tolist(), "clip norm", float(total))
+    print(name, "written: seed", rseed, "rows", out["up_rows"].tolist(), out["lo_rows"].tolist(), "losses", out["losses"].tolist(), "clip norm", float(total))
 
 
 def make_tok(RefLabels):
@@ -525,3 +553,5 @@ if __name__ == "__main__":
         make_g3(ref_models, only or None)
     if "g4" in what:
         make_g4(ref_models)
+    if "g4b" in what:
+        make_g4(ref_models, G4B, G4B_BATCH, "g4b_step")

@@ -6,6 +6,9 @@ two of which hold a full-length bar without <eos>, train mode, seeded teacher fo
 drives it -- skip_finished_rows, fused bars, plan_clip_groups + the clip permutation, two clip groups decoding concurrently with pipelined
 backward, m_active prefixes and row_list tails, launch-per-step decoder kernels (two groups: the persistent few-clip decoder stays off) -- so
 the kernels the benchmark times meet the reference's numbers directly, not through the repo's own plain step.
+
+Round 6: `g4b_step` is a second such step on a minibatch that the planner cuts into THREE clip groups ([ordinary | long A | long B],
+train.split_long_group) -- the default path of the benchmark; the test asserts the three groups and compares the same quantities.
 """
 import json
 import os
@@ -26,17 +29,28 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(scope="module")
-def g4(golden_dir):
+def _load(golden_dir, name):
     from piano_a2s_amd import spec, synthetic
-    meta = json.load(open(os.path.join(golden_dir, "g4_step.json")))
-    data = np.load(os.path.join(golden_dir, "g4_step.npz"))
+    meta = json.load(open(os.path.join(golden_dir, name + ".json")))
+    data = np.load(os.path.join(golden_dir, name + ".npz"))
     cfg = spec.default_cfg()
     kw = dict(meta["batch_kwargs"])
     kw["upper_range"], kw["lower_range"] = tuple(kw["upper_range"]), tuple(kw["lower_range"])
     batch = synthetic.make_batch(meta["batch"], cfg, meta["batch_seed"], full_rows=[tuple(r) for r in meta["full_rows"]], **kw)
     st = spec.procedural_state(cfg, meta["weights_seed"], eos_bias=meta["eos_bias"], lively=meta["lively"])
     return meta, data, cfg, batch, st
+
+
+@pytest.fixture(scope="module")
+def g4(golden_dir):
+    return _load(golden_dir, "g4_step")
+
+
+@pytest.fixture(scope="module")
+def g4b(golden_dir):
+    """Round 6: a second whole reference step, on a minibatch whose TWO long clips hold their 398-step upper bars in different bar segments under the
+    stored seed -- the fused step cuts them into sub-groups of their own: THREE clip groups (make_golden.py g4b asserts it on the host)."""
+    return _load(golden_dir, "g4b_step")
 
 
 def _report(line):
@@ -46,11 +60,15 @@ def _report(line):
 
 
 # (planner settings, clip groups it must form on this minibatch): the default cost model cuts off the one clip with a 398-step upper bar
-# (the way the benchmark's 256-clip minibatches are cut); a latency floor scaled to 12 clips also sends the 189-step lower bar's clip there
-# ... and (round 5) the two long clips as sub-groups of their own when their longest bars lie in different bar segments of the step (train.split_long_group)
-@pytest.mark.parametrize("plan_kw, expect, subgroups", [({}, [(0, 11), (11, 12)], False), ({"step_cost": 4.0}, [(0, 10), (10, 12)], False),
-                                                        ({"step_cost": 4.0}, None, True)], ids=["default_cost", "step_cost4", "step_cost4_subgroups"])
-def test_reference_step_through_planner(g4, dev, plan_kw, expect, subgroups):
+# (the way the benchmark's 256-clip minibatches are cut); a latency floor scaled to 12 clips also sends the 189-step lower bar's clip there.  On g4's
+# minibatch and seed the long clips' sub-group cut (train.split_long_group) does NOT trigger (the two long clips stay one group: "step_cost4_subgroups_on"
+# is the two-group step with the switch on); g4b is the minibatch on which it does: [ordinary | long A | long B], the benchmark's default path.
+@pytest.mark.parametrize("fixture, plan_kw, expect, subgroups", [
+    ("g4", {}, [(0, 11), (11, 12)], False), ("g4", {"step_cost": 4.0}, [(0, 10), (10, 12)], False), ("g4", {"step_cost": 4.0}, [(0, 10), (10, 12)], True),
+    ("g4b", {"step_cost": 4.0}, [(0, 10), (10, 11), (11, 12)], True), ("g4b", {"step_cost": 4.0}, [(0, 10), (10, 12)], False)],
+    ids=["default_cost", "step_cost4", "step_cost4_subgroups_on", "g4b_three_groups", "g4b_two_groups"])
+def test_reference_step_through_planner(request, dev, fixture, plan_kw, expect, subgroups):
+    g4 = request.getfixturevalue(fixture)
     import models
     from piano_a2s_amd import spec, train
     from piano_a2s_amd.spec import PAD
@@ -72,14 +90,13 @@ def test_reference_step_through_planner(g4, dev, plan_kw, expect, subgroups):
     dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
     losses = step(dbatch, teacher_forcing_ratio=meta["tf"], rng=Counting())
     torch.cuda.synchronize()
-    tag = "g4[" + (",".join(f"{k}={v}" for k, v in plan_kw.items()) or "default") + (",subgroups" if subgroups else "") + "]"
+    tag = fixture + "[" + (",".join(f"{k}={v}" for k, v in plan_kw.items()) or "default") + (",subgroups" if subgroups else "") + "]"
 
     # --- the planner's control flow really ran
     outs_raw, bar_major, groups, perm = step._last
-    if expect is not None:
-        assert [tuple(g) for g in groups] == expect, f"clip groups {groups}"
-    else:       # (whether the two long clips part depends on the bar segments the seeded coins produce: 2 or 3 groups, both are the planner's control flow)
-        assert len(groups) in (2, 3) and groups[0][0] == 0 and groups[-1][1] == meta["batch"], f"clip groups {groups}"
+    assert [tuple(g) for g in groups] == expect, f"clip groups {groups}"
+    if "clip_groups" in meta and subgroups:          # (what the generator saw on the host when it chose the seed)
+        assert [list(g) for g in groups] == meta["clip_groups"] and perm.tolist() == meta["clip_order"]
     assert bar_major and perm is not None and not torch.equal(perm, torch.arange(meta["batch"])), "fused bars + a real clip permutation"
     assert draws["n"] == meta["draws"], f"python-random draws {draws['n']} vs reference {meta['draws']}"
     _report(f"{tag}: clip groups {groups}, permutation {perm.tolist()}, draws {draws['n']}")
