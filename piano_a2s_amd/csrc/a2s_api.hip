@@ -61,6 +61,9 @@ int a2s_gru_persist_alone(void);
 void a2s_attn_deep_set(int);
 void a2s_attn_defer_combine_set(int);
 void a2s_dec_bwd_fold_set(int);
+void a2s_dec_mid_set(int);
+int a2s_dec_mid_enabled(void);
+int a2s_dec_mid_launches(void);
 void a2s_attn_deep_bwd_set(int);
 int a2s_attn_deep_bwd_enabled(void);
 int a2s_dec_bwd_fold_enabled(void);
@@ -230,6 +233,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_deep")) { a2s_attn_deep_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_defer_combine")) { a2s_attn_defer_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_bwd_fold")) { a2s_dec_bwd_fold_set(value); return A2S_OK; }
+    if (!strcmp(key, "dec_mid")) { a2s_dec_mid_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_deep_bwd")) { a2s_attn_deep_bwd_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_pace_min")) { a2s_attn_pace_min_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
@@ -261,6 +265,8 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_deep")) return a2s_attn_deep_max_clips();
     if (key && !strcmp(key, "attn_defer_combine")) return a2s_attn_defer_combine_enabled();
     if (key && !strcmp(key, "dec_bwd_fold")) return a2s_dec_bwd_fold_enabled();
+    if (key && !strcmp(key, "dec_mid")) return a2s_dec_mid_enabled();
+    if (key && !strcmp(key, "dec_mid_launches")) return a2s_dec_mid_launches();
     if (key && !strcmp(key, "attn_deep_bwd")) return a2s_attn_deep_bwd_enabled();
     if (key && !strcmp(key, "attn_pace_min")) return a2s_attn_pace_min();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();

@@ -300,6 +300,8 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
 
 bool a2s_note_decoder_bwd_persist_ok(const a2s_note_dec_bwd_args& a);
 int a2s_note_decoder_bwd_persist(hipStream_t st, const a2s_note_dec_bwd_args& a);
+bool a2s_note_step_mid_bwd_ok(const a2s_note_dec_bwd_args& a);
+int a2s_note_step_mid_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, float* dh_out, int nrows, const int* rowmap);
 
 int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     // few clips: one persistent launch for the whole reverse loop (a2s_dec_persist.hip)
@@ -319,7 +321,12 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     // but it may have none at all -- a row without <eos> whose last targets are <pad> -- while earlier steps still have 1 .. max_rows)
     bool any_fused = false;
     for (int s = a.steps - 1; s >= 0 && !any_fused; --s) any_fused = step_fused(s);
-    if (any_fused) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }
+    // round 6: the dx / dh products of the steps that stay on this loop as ONE launch in front of the attention (dec_bwd_mid, a2s_step.hip), over the
+    // rows still running; it reads the same transposed weight copies
+    const bool mid = a2s_note_step_mid_bwd_ok(a);
+    bool any_mid = false;
+    if (mid) for (int s = a.steps - 1; s >= 0 && !any_mid; --s) any_mid = !step_fused(s);
+    if (any_fused || any_mid) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }
     for (int s = a.steps - 1; s >= 0; --s) {
         const bool fused = step_fused(s);
         a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : R, a.n_active ? a.n_active[s] : 0, s};
@@ -345,8 +352,13 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
         rc = a2s_gru_gates_bwd_impl(st, dh_in, H2, dos, 2 * H2, a.gates + (long)s * R * 4 * H2, a.h + (long)s * R * H2, H2,
                                     dgi, 3 * H2, dgh, 3 * H2, nullptr, 0, dh_out, H2, R, H2);
         if (rc) return rc;
-        // dx = dgi W_ih   (R x ldx): [dtok | dctx_from_gru]
-        rc = a2s_gemm_impl(st, gM, ldx, 3 * H2, 1.f, dgi, 3 * H2, 1, a.w_ih, ldx, 1, 0.f, dxs, ldx, nullptr, 0, gB, gS * 3 * H2, 0, gS * ldx, 0, a.gemm_ws, a.gemm_ws_bytes);
+        if (mid) {
+            const int nrows = step_rows(s);
+            rc = a2s_note_step_mid_bwd(st, a, s, dh_out, nrows, nrows < R ? a.row_list : nullptr);
+        } else {
+            // dx = dgi W_ih   (R x ldx): [dtok | dctx_from_gru]
+            rc = a2s_gemm_impl(st, gM, ldx, 3 * H2, 1.f, dgi, 3 * H2, 1, a.w_ih, ldx, 1, 0.f, dxs, ldx, nullptr, 0, gB, gS * 3 * H2, 0, gS * ldx, 0, a.gemm_ws, a.gemm_ws_bytes);
+        }
         if (rc) return rc;
         // attention: dctx = dx[:, E:] + do[:, 2H:]
         rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
@@ -355,8 +367,10 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
                                     a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
         if (rc) return rc;
         // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
-        rc = a2s_gemm_impl(st, gM, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * 3 * H2, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
+        if (!mid) {
+            rc = a2s_gemm_impl(st, gM, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * 3 * H2, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
+            if (rc) return rc;
+        }
         rc = a2s_gemm_impl(st, gM, H2, a.H, 1.f, a.dq_all + (long)s * R * a.H, a.H, 1, a.attn_w, 2 * H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * a.H, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         cur ^= 1;

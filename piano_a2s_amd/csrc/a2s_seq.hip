@@ -518,6 +518,8 @@ typedef a2s_note_dec_args NoteDecArgs;   // one definition only: the public C st
 bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats, bool greedy = false);
 int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last,
                             int nrows, const int* rowmap, const a2s_attn_deferred* defer = nullptr);
+bool a2s_note_step_mid_ok(int H, int E, const void* const* ptrs, int nptrs);
+int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int nrows, const int* rowmap);
 // rows the fused step of step t would cover: all R, or (training, finished rows skipped) the rows still running, a prefix of row_list
 static int note_step_rows(const NoteDecArgs& a, int t) { return (a.row_list && a.n_rows_active && t >= 0) ? a.n_rows_active[t] : a.R; }
 static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
@@ -565,24 +567,36 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     int rc;
     a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : a.R, a.n_active ? a.n_active[t] : 0, t};
     const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
+    // round 6: the GRU cell of the step -- gh, gi and the gate kernel -- as ONE launch behind the attention (dec_gru_mid, a2s_step.hip), over the
+    // rows still running
+    const void* mid_ptrs[] = {a.x, a.h, a.w_ih, a.w_hh};
+    const bool mid = a2s_note_step_mid_ok(a.H, a.E, mid_ptrs, 4);
     // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
     rc = a2s_gemm_impl(st, gM, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, gB, gS * H2, 0, gS * a.H, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
-    // gh = h W_hh^T + b_hh
-    rc = a2s_gemm_impl(st, gM, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, gB, gS * H2, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
-    if (rc) return rc;
+    if (!mid) {
+        // gh = h W_hh^T + b_hh
+        rc = a2s_gemm_impl(st, gM, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, gB, gS * H2, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
+        if (rc) return rc;
+    }
     // attention -> ctx into x[si][:, E:] and o[sv][:, 2H:]
     rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
                                 a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws,
                                 rows);
     if (rc) return rc;
-    // gi = x W_ih^T + b_ih
-    rc = a2s_gemm_impl(st, gM, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, gB, gS * ldx, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
-    if (rc) return rc;
-    // h' -> h[so] and o[sv][:, :2H]
-    rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
-                                a.gates ? a.gates + (long)sv * a.R * 4 * H2 : nullptr, a.R, H2);
-    if (rc) return rc;
+    if (mid) {
+        const int nrows = note_step_rows(a, t_base ? -1 : t);
+        rc = a2s_note_step_mid_gru(st, a, si, so, sv, nrows, nrows < a.R ? a.row_list : nullptr);
+        if (rc) return rc;
+    } else {
+        // gi = x W_ih^T + b_ih
+        rc = a2s_gemm_impl(st, gM, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, gB, gS * ldx, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
+        if (rc) return rc;
+        // h' -> h[so] and o[sv][:, :2H]
+        rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
+                                    a.gates ? a.gates + (long)sv * a.R * 4 * H2 : nullptr, a.R, H2);
+        if (rc) return rc;
+    }
     // logits = o W_out^T + b_out
     rc = a2s_gemm_impl(st, gM, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, gB, gS * 2 * H2, 0, gS * a.V, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;

@@ -20,6 +20,7 @@
 // Used when the call has at most A2S_DEC_FUSED_MAX_ROWS rows (default 192): with many rows every workgroup re-reads the weights from
 // L2 and the tiled GEMMs win again (they only run under the other staff's attention there anyway).
 #include "a2s_common.h"
+#include <type_traits>
 #include "../../include/a2s.h"
 
 int a2s_gemm_impl(hipStream_t st, int M, int N, int K, float alpha, const float* A, long sAm, long sAk,
@@ -108,39 +109,6 @@ __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NT], f32x4* part, int 
     }
 }
 
-
-// ---- the same products with RT 16-row tiles per workgroup (round 5): the B fragments (weights) a wave fetches serve RT x 16 rows, so a call over
-// hundreds of rows re-reads the weights R / (16 RT) times instead of R / 16 (496 rows, GRU step: 462 MB of L2 reads per launch with RT = 1 --
-// which is why the 16-row kernels lost to the tiled GEMMs above ~192 rows -- 170 MB with RT = 4).  acc[rt * NT + g].
-template <int NT, int RT, int CH>
-__device__ __forceinline__ void mfma_rows8_rt(const float* const (&arow)[RT], const float* const (&brow)[NT], int ksteps, int wave, int lk,
-                                              f32x4 (&acc)[RT * NT]) {
-    for (int u0 = wave; u0 < ksteps; u0 += NW * CH) {
-        f32x4 a[RT][CH], b[NT][CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int u = u0 + NW * c;
-            const bool ok = u < ksteps;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                a[rt][c] = ok ? *reinterpret_cast<const f32x4*>(arow[rt] + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < NT; ++g)
-                b[g][c] = ok ? *reinterpret_cast<const f32x4*>(brow[g] + 16 * u + 4 * lk) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (u0 + NW * c >= ksteps) break;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int g = 0; g < NT; ++g)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        acc[rt * NT + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][c][j], b[g][c][j], acc[rt * NT + g], 0, 0, 0);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------- forward: GRU cell
 // GRU cell of one (row, hidden unit) from the four product sums (reference models.py NoteDecoder's nn.GRU): ONE definition with floating-point
@@ -392,67 +360,119 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step_cmb(DecGruArgs a, DecCmb
     }
 }
 
-// dec_gru_step over RT x 16 rows per workgroup (same arithmetic, same summation order per output: k-steps round robin over the 8 waves, fixed-order tree)
-template <int RT>
-__global__ __launch_bounds__(64 * NW) void dec_gru_step_rt(DecGruArgs a) {
-    __shared__ f32x4 part[4 * 4 * RT * 64];
+// ------------------------------------------------------------------------------------------- forward: GRU cell for HUNDREDS of rows (round 6)
+// The bulk clip group's decode step -- ~500 rows -- ran its two gate products as library-style launches (gh before the attention sweep, gi
+// behind it: 64 x 32 fp32 tiles that walk K as 17 barrier-separated k-tiles fetched through L2, 46-54 us EACH in the step,
+// profiles/r05_step_trace_b256.txt) plus the elementwise gate kernel: ~150 of the ~200 us a step spends outside its sweep, during which the
+// HBM idles.  The 16-row kernels above do not scale to these row counts (every workgroup pulls its weights from L2 again, one k-step of loads
+// in flight per wave: 77 us at 496 rows).  This kernel is the same fused cell -- gi and gh for a tile of hidden units, gate math on the
+// accumulators, no gi / gh round trip through memory -- organised for a few hundred rows:
+//   * a workgroup owns 64 rows x 16 hidden units (their r, z, n gate columns); wave w owns rows 16 w .. 16 w + 15 for ALL of K = kx + H2:
+//     no cross-wave reduction;
+//   * the weights of a 64-wide k-chunk (48 rows x 64 floats) are staged ONCE per workgroup in LDS (double-buffered, 288-byte rows: the
+//     conflict-free stride of the fragment pattern, profiles/r04_lds_patterns.txt) and read as ds_read_b128 fragments by all four waves;
+//   * a wave's own rows never touch LDS: lane (li, lk) fetches 16 bytes at k + 4 lk of row li straight from memory, one chunk ahead; the
+//     weight chunk after the next is in flight in registers meanwhile.  One barrier per chunk.
+// Grid (H2 / 16, rows / 64): 256 workgroups at 496 rows; unit tile x lands on XCD x % 8 in every launch, so an XCD's L2 keeps ITS eighth of
+// the weights (0.8 MB per decoder) across the steps.  The k order inside a 16-wide k-step is the 16-row kernels' (lane group lk supplies
+// k = 4 lk + j for the j-th MFMA); the sum runs over the chunks in order, x part first.
+#define MID_KC 64
+#define MID_LDB 72                // floats per staged weight row: 64 + 8
+__global__ __launch_bounds__(256) void dec_gru_mid(DecGruArgs a) {
+    __shared__ __attribute__((aligned(16))) float bs[2][48 * MID_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.n_done) {
         const bool done = *a.n_done >= a.R;
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.skip = done ? 1 : 0;
         if (done) return;
     }
-    const int H2 = a.H2, R = a.R;
-    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 16 * RT;
+    const int H2 = a.H2, R = a.R, kx = a.kx;
+    const int j0 = blockIdx.x * 16, row0 = blockIdx.y * 64 + wave * 16;
     const int li = lane & 15, lk = lane >> 4;
     const int j = j0 + li;
-    float hp[RT][4], br = 0.f, bz = 0.f, bin = 0.f, bhn = 0.f;
-    if (wave == 0) {
-        br = a.b_ih[j] + a.b_hh[j]; bz = a.b_ih[H2 + j] + a.b_hh[H2 + j]; bin = a.b_ih[2 * H2 + j]; bhn = a.b_hh[2 * H2 + j];
+    const int ncx = (kx + MID_KC - 1) / MID_KC, nc = ncx + (H2 + MID_KC - 1) / MID_KC;
+    // epilogue operands: in flight while the products run
+    const float br = a.b_ih[j] + a.b_hh[j], bz = a.b_ih[H2 + j] + a.b_hh[H2 + j], bin = a.b_ih[2 * H2 + j], bhn = a.b_hh[2 * H2 + j];
+    float hp[4];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+    for (int r = 0; r < 4; ++r) hp[r] = a.h[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * H2 + j];
+    const int arow = dec_row(a.rowmap, min(row0 + li, R - 1));
+    const float* const xa = a.x + (long)arow * a.ldx + 4 * lk;
+    const float* const ha = a.h + (long)arow * H2 + 4 * lk;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // weight chunk c -> registers: item e = tid + 256 i is (staged row e >> 4 = gate * 16 + unit, 16-byte column e & 15)
+    auto bload = [&](int c, f32x4 (&v)[3]) {
+        const bool px = c < ncx;
+        const int k0 = (px ? c : c - ncx) * MID_KC, K = px ? kx : H2;
+        const float* const W = px ? a.w_ih : a.w_hh;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hp[rt][r] = a.h[(long)dec_row(a.rowmap, min(row0 + rt * 16 + lk * 4 + r, R - 1)) * H2 + j];
-    }
-    const float* ax[RT];
-    const float* ah[RT];
+        for (int i = 0; i < 3; ++i) {
+            const int e = tid + 256 * i, r = e >> 4, k = k0 + 4 * (e & 15);
+            v[i] = k < K ? *reinterpret_cast<const f32x4*>(W + ((long)(r >> 4) * H2 + j0 + (r & 15)) * K + k) : zero4;
+        }
+    };
+    auto bstore = [&](int buf, const f32x4 (&v)[3]) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int ar = dec_row(a.rowmap, min(row0 + rt * 16 + li, R - 1));
-        ax[rt] = a.x + (long)ar * a.ldx;
-        ah[rt] = a.h + (long)ar * H2;
-    }
-    const float* bi[3];
-    const float* bh[3];
+        for (int i = 0; i < 3; ++i) {
+            const int e = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(&bs[buf][(e >> 4) * MID_LDB + 4 * (e & 15)]) = v[i];
+        }
+    };
+    auto aload = [&](int c, f32x4 (&v)[4]) {
+        const bool px = c < ncx;
+        const int k0 = (px ? c : c - ncx) * MID_KC, K = px ? kx : H2;
+        const float* const p = px ? xa : ha;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) { bi[g] = a.w_ih + ((long)g * H2 + j0 + li) * a.kx; bh[g] = a.w_hh + ((long)g * H2 + j0 + li) * H2; }
-    f32x4 t[RT * 3], u[RT * 3];
+        for (int u = 0; u < 4; ++u) v[u] = (k0 + 16 * u < K) ? *reinterpret_cast<const f32x4*>(p + k0 + 16 * u) : zero4;     // (K % 16 == 0: a k-step is inside the row or not at all)
+    };
+    f32x4 acc[4] = {zero4, zero4, zero4, zero4};          // r, z, n (input part), n (state part)
+    auto compute = [&](auto PX, int c, int buf, const f32x4 (&av)[4]) {
+        constexpr bool px = decltype(PX)::value;
+        const int k0 = (px ? c : c - ncx) * MID_KC, K = px ? kx : H2;
 #pragma unroll
-    for (int i = 0; i < RT * 3; ++i) t[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8_rt<3, RT, DEC_CH_GRU>(ax, bi, a.kx / 16, wave, lk, t);               // gi: r, z, n
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + 16 * u >= K) break;                   // (uniform)
+            f32x4 b[3];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { u[rt * 3 + 0] = t[rt * 3 + 0]; u[rt * 3 + 1] = t[rt * 3 + 1]; u[rt * 3 + 2] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    mfma_rows8_rt<3, RT, DEC_CH_GRU>(ah, bh, H2 / 16, wave, lk, u);                 // + gh on r, z; gh_n apart
-    f32x4 acc[4 * RT];
+            for (int g = 0; g < 3; ++g) b[g] = *reinterpret_cast<const f32x4*>(&bs[buf][(g * 16 + li) * MID_LDB + 16 * u + 4 * lk]);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { acc[rt * 4 + 0] = u[rt * 3 + 0]; acc[rt * 4 + 1] = u[rt * 3 + 1]; acc[rt * 4 + 2] = t[rt * 3 + 2]; acc[rt * 4 + 3] = u[rt * 3 + 2]; }
-    reduce_waves<4 * RT>(acc, part, wave, lane);
-    if (wave > 0) return;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (row0 + rt * 16 + lk * 4 + r >= R) continue;
-            const int row = dec_row(a.rowmap, row0 + rt * 16 + lk * 4 + r);
-            const GruCellOut cell = gru_cell(acc[rt * 4 + 0][r], acc[rt * 4 + 1][r], acc[rt * 4 + 2][r], acc[rt * 4 + 3][r], br, bz, bin, bhn, hp[rt][r]);
-            const float rg = cell.rg, zg = cell.zg, ng = cell.ng, ghn = cell.ghn, hn = cell.hn;
-            a.hout[(long)row * H2 + j] = hn;
-            a.o[(long)row * a.ldo + j] = hn;
-            if (a.save) {
-                float* sv = a.save + (long)row * 4 * H2;
-                sv[j] = rg; sv[H2 + j] = zg; sv[2 * H2 + j] = ng; sv[3 * H2 + j] = ghn;
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][jj], b[0][jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][jj], b[1][jj], acc[1], 0, 0, 0);
+                acc[px ? 2 : 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][jj], b[2][jj], acc[px ? 2 : 3], 0, 0, 0);
             }
         }
+    };
+    f32x4 bv[3], a_cur[4], a_nxt[4];
+    bload(0, bv);
+    aload(0, a_cur);
+    bstore(0, bv);
+    if (nc > 1) bload(1, bv);
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        if (c + 1 < nc) {
+            aload(c + 1, a_nxt);
+            bstore((c + 1) & 1, bv);                       // (that buffer was last read in iteration c - 1, which ended with a barrier)
+            if (c + 2 < nc) bload(c + 2, bv);
+        }
+        if (c < ncx) compute(std::true_type{}, c, c & 1, a_cur);
+        else compute(std::false_type{}, c, c & 1, a_cur);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a_cur[u] = a_nxt[u];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (row0 + lk * 4 + r >= R) continue;
+        const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
+        const GruCellOut cell = gru_cell(acc[0][r], acc[1][r], acc[2][r], acc[3][r], br, bz, bin, bhn, hp[r]);
+        a.hout[(long)row * H2 + j] = cell.hn;
+        a.o[(long)row * a.ldo + j] = cell.hn;
+        if (a.save) {
+            float* sv = a.save + (long)row * 4 * H2;
+            sv[j] = cell.rg; sv[H2 + j] = cell.zg; sv[2 * H2 + j] = cell.ng; sv[3 * H2 + j] = cell.ghn;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------- forward: output projection + epilogue + next query
@@ -643,54 +663,88 @@ __global__ __launch_bounds__(64 * DEC_NW_PROD) void dec_bwd_products(DecBwdProdA
 }
 
 
-// dec_bwd_products over RT x 16 rows per workgroup
-template <int RT>
-__global__ __launch_bounds__(64 * NW) void dec_bwd_products_rt(DecBwdProdArgs a) {
-    __shared__ f32x4 part[4 * 2 * RT * 64];
+// The same two products for hundreds of rows (round 6; the skeleton of dec_gru_mid): a workgroup owns 64 rows x 32 columns of dx (role A) or dh
+// (role B), wave w rows 16 w .. 16 w + 15 for all of K = 3 H2; the 32 transposed-weight rows of a 64-wide k-chunk are staged once per workgroup
+// in LDS, the gradient rows come straight from memory.  Replaces, in the bulk clip group's backward decode step, the dx product in front of
+// the attention sweep and the dh product behind it (two 64 x 32-tile launches of 30-50 us each in the step) by one launch in front of it.
+__global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
+    __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int R = a.R, K = 3 * a.H2, row0 = blockIdx.y * 16 * RT;
+    const int R = a.R, K = 3 * a.H2, row0 = blockIdx.y * 64 + wave * 16;
     const bool role_a = (int)blockIdx.x < a.nxa;
     const int n0 = (role_a ? blockIdx.x : blockIdx.x - a.nxa) * 32;
     const int ncols = role_a ? a.kx : a.H2;
-    const float* A = role_a ? a.dgi : a.dgh;
-    const float* Bt = role_a ? a.wih_t : a.whh_t;
-    const float* brow[2];
+    const float* const Bt = role_a ? a.wih_t : a.whh_t;
+    const int nc = K / MID_KC;                            // (H2 % 64 == 0 is part of the eligibility test)
+    float c0[2][4];
+    if (!role_a) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) brow[g] = Bt + (long)min(n0 + g * 16 + li, ncols - 1) * K;
-    float c0[RT][2][4];
-    if (wave == 0 && !role_a) {
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    c0[rt][g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + rt * 16 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
+            for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
     }
-    const float* arow[RT];
+    const float* const ar = (role_a ? a.dgi : a.dgh) + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K + 4 * lk;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto bload = [&](int c, f32x4 (&v)[2]) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) arow[rt] = A + (long)dec_row(a.rowmap, min(row0 + rt * 16 + li, R - 1)) * K;
-    f32x4 acc[RT * 2];
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i, n = n0 + (e >> 4);
+            v[i] = n < ncols ? *reinterpret_cast<const f32x4*>(Bt + (long)n * K + c * MID_KC + 4 * (e & 15)) : zero4;
+        }
+    };
+    auto bstore = [&](int buf, const f32x4 (&v)[2]) {
 #pragma unroll
-    for (int i = 0; i < RT * 2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows8_rt<2, RT, DEC_CH_PROD>(arow, brow, K / 16, wave, lk, acc);
-    reduce_waves<2 * RT>(acc, part, wave, lane);
-    if (wave > 0) return;
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(&bs[buf][(e >> 4) * MID_LDB + 4 * (e & 15)]) = v[i];
+        }
+    };
+    auto aload = [&](int c, f32x4 (&v)[4]) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(ar + c * MID_KC + 16 * u);
+    };
+    f32x4 acc[2] = {zero4, zero4};
+    f32x4 bv[2], a_cur[4], a_nxt[4];
+    bload(0, bv);
+    aload(0, a_cur);
+    bstore(0, bv);
+    if (nc > 1) bload(1, bv);
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        if (c + 1 < nc) {
+            aload(c + 1, a_nxt);
+            bstore((c + 1) & 1, bv);
+            if (c + 2 < nc) bload(c + 2, bv);
+        }
+        const float* const bb = bs[c & 1];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int col = n0 + g * 16 + li;
-            if (col >= ncols) continue;
+        for (int u = 0; u < 4; ++u) {
+            f32x4 b[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (row0 + rt * 16 + lk * 4 + r >= R) continue;
-                const int row = dec_row(a.rowmap, row0 + rt * 16 + lk * 4 + r);
-                if (role_a) a.dx[(long)row * a.ldx + col] = acc[rt * 2 + g][r];
-                else a.dh[(long)row * a.H2 + col] = c0[rt][g][r] + acc[rt * 2 + g][r];
+            for (int g = 0; g < 2; ++g) b[g] = *reinterpret_cast<const f32x4*>(&bb[(g * 16 + li) * MID_LDB + 16 * u + 4 * lk]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][jj], b[0][jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][jj], b[1][jj], acc[1], 0, 0, 0);
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a_cur[u] = a_nxt[u];
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int col = n0 + g * 16 + li;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (row0 + lk * 4 + r >= R) continue;
+            const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
+            if (role_a) a.dx[(long)row * a.ldx + col] = acc[g][r];
+            else a.dh[(long)row * a.H2 + col] = c0[g][r] + acc[g][r];
+        }
+    }
 }
 
 // ---- dec_bwd_products with the GRU-cell backward of its rows folded into the prologue (round 5, few-row calls: the long-clip chain).  A backward
@@ -957,14 +1011,15 @@ static int a2s_dec_bwd_fold_max_rows(void) {
     return v;
 }
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-// 16-row tiles per workgroup of the GRU / backward-product kernels: 1 while the launch would otherwise not fill the chip (32-33 column tiles x
-// rows / 16 workgroups), 2 / 4 above (A2S_DEC_ROW_TILES=1|2|4 forces one)
-static int dec_row_tiles(int nrows) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("A2S_DEC_ROW_TILES"); forced = e ? atoi(e) : 0; }
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return nrows > 384 ? 4 : (nrows > 160 ? 2 : 1);
-}
+// The mid-size kernels (dec_gru_mid, dec_bwd_mid: 64-row workgroups, weights staged through LDS) take the launches over more than 160 rows --
+// below that the 16-row kernels fill the chip better (32-33 column tiles x rows / 16 workgroups).  a2s_debug_set("dec_mid", 0): never (A/B
+// measurements, tests: the bulk calls' per-step products then run as library-style launches, the few-row path on the 16-row kernels only).
+static int g_dec_mid = 1;
+void a2s_dec_mid_set(int v) { g_dec_mid = v ? 1 : 0; }
+int a2s_dec_mid_enabled(void) { return g_dec_mid; }
+static int g_dec_mid_launches = 0;          // dec_gru_mid / dec_bwd_mid launches of this process (tests: proof of the path taken)
+int a2s_dec_mid_launches(void) { return g_dec_mid_launches; }
+static bool dec_use_mid(int nrows, int H2) { return g_dec_mid && nrows > 160 && H2 % MID_KC == 0; }
 // greedy: the call is a greedy decode (no ground truth, no backward).  There the 4-launch step wins at every batch size the workspace admits
 // (B = 256: 497 -> 536 clips/s, B = 64: 313 -> 317, profiles/r05_infer_variants.txt) -- one stream decodes a staff, nothing runs beside it that
 // the weight re-reads of the 16-row tiles could disturb -- so the row limit of the training path (A2S_DEC_FUSED_MAX_ROWS) does not apply;
@@ -998,7 +1053,6 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
     g.n_done = greedy ? a.n_done : nullptr; g.skip = flags;
     g.rowmap = rowmap;
     g.R = nrows; g.H2 = H2;
-    const int rt = dec_row_tiles(nrows);
     if (defer && defer->G > 0) {                 // the attention launch in front of this step left its combine to us
         A2S_REQUIRE(H2 == 64 * NW && defer->G <= 16 && a.E % 16 == 0, "note_step_fused_fwd: deferred combine needs 2 * hidden_size == %d and G <= 16", 64 * NW);
         DecCmbArgs c;
@@ -1008,8 +1062,7 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
         c.Rall = R; c.E = a.E;
         hipLaunchKernelGGL(dec_gru_step_cmb, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), dec_cmb_lds_bytes(nrows < 16 ? nrows : 16), st, g, c);
     } else
-    if (rt == 4) hipLaunchKernelGGL(dec_gru_step_rt<4>, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(64 * NW), 0, st, g);
-    else if (rt == 2) hipLaunchKernelGGL(dec_gru_step_rt<2>, dim3(H2 / 16, a2s_cdiv(nrows, 32)), dim3(64 * NW), 0, st, g);
+    if (dec_use_mid(nrows, H2)) hipLaunchKernelGGL(dec_gru_mid, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, g);
     A2S_CHECK_LAUNCH("dec_gru_step");
     DecOutArgs f;
@@ -1059,9 +1112,9 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
     p.dgi = dgi; p.dgh = dgh; p.wih_t = wih_t; p.whh_t = whh_t; p.dx = dxs; p.ldx = ldx; p.dh = dh_out;
     p.rowmap = rowmap;
     p.nxa = a2s_cdiv(ldx, 32); p.kx = ldx; p.R = nrows; p.H2 = H2;
-    const int rt = dec_row_tiles(nrows);
+    const bool mid = dec_use_mid(nrows, H2);
     // few rows (the long-clip chain): the cell backward rides in the product kernel, the partial sums of dq in the query product
-    const bool fold = a2s_dec_bwd_fold_enabled() && rt == 1 && R <= a2s_dec_bwd_fold_max_rows() && H2 == 64 * NW && a.H == 256 && p.nxa >= 16 && rows && (rowmap || nrows == R);
+    const bool fold = a2s_dec_bwd_fold_enabled() && !mid && R <= a2s_dec_bwd_fold_max_rows() && H2 == 64 * NW && a.H == 256 && p.nxa >= 16 && rows && (rowmap || nrows == R);
     int rc;
     if (fold) {
         DecBwdGatesArgs gg;
@@ -1081,8 +1134,7 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
         rc = a2s_gru_gates_bwd_impl(st, dh_in, H2, dos, 2 * H2, a.gates + (long)s * R * 4 * H2, a.h + (long)s * R * H2, H2,
                                     dgi, 3 * H2, dgh, 3 * H2, nullptr, 0, dh_out, H2, R, H2);
         if (rc) return rc;
-        if (rt == 4) hipLaunchKernelGGL(dec_bwd_products_rt<4>, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(64 * NW), 0, st, p);
-        else if (rt == 2) hipLaunchKernelGGL(dec_bwd_products_rt<2>, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 32)), dim3(64 * NW), 0, st, p);
+        if (mid) hipLaunchKernelGGL(dec_bwd_mid, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * DEC_NW_PROD), 0, st, p);
     }
     A2S_CHECK_LAUNCH("dec_bwd_products");
@@ -1106,5 +1158,53 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
     hipLaunchKernelGGL(dec_bwd_query, dim3(a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, nrows, a.H, H2,
                        rowmap);
     A2S_CHECK_LAUNCH("dec_bwd_query");
+    return A2S_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------- the bulk calls' steps on the mid-size kernels (round 6)
+// A decoder call over more rows than the few-row path takes (a2s_dec_fused_max_rows) keeps its launch-per-step loop (a2s_seq.hip / a2s_bwd.hip: query
+// and output products, attention, epilogue as library-style launches), but its GRU cell -- two products + the gate kernel -- is ONE dec_gru_mid
+// launch behind the attention, and the reverse loop's dx / dh products ONE dec_bwd_mid launch in front of it.
+bool a2s_note_step_mid_ok(int H, int E, const void* const* ptrs, int nptrs) {
+    if (!g_dec_mid || (2 * H) % MID_KC || E % 16) return false;
+    for (int i = 0; i < nptrs; ++i) if (!aligned16(ptrs[i])) return false;
+    return true;
+}
+// h' = GRU([token | ctx], h) for rows rowmap[0 .. nrows) (rowmap NULL: rows 0 .. nrows): state slot so, output row o[sv][:, :2H], saved gates
+int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int nrows, const int* rowmap) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    if (nrows <= 0) return A2S_OK;
+    DecGruArgs g;
+    g.x = a.x + (long)si * R * ldx; g.ldx = ldx; g.kx = ldx;
+    g.h = a.h + (long)si * R * H2;
+    g.w_ih = a.w_ih; g.w_hh = a.w_hh; g.b_ih = a.b_ih; g.b_hh = a.b_hh;
+    g.hout = a.h + (long)so * R * H2; g.o = a.o + (long)sv * R * 2 * H2; g.ldo = 2 * H2;
+    g.save = a.gates ? a.gates + (long)sv * R * 4 * H2 : nullptr;
+    g.n_done = nullptr; g.skip = nullptr;
+    g.rowmap = rowmap;
+    g.R = nrows; g.H2 = H2;
+    hipLaunchKernelGGL(dec_gru_mid, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(256), 0, st, g);
+    __atomic_fetch_add(&g_dec_mid_launches, 1, __ATOMIC_RELAXED);
+    A2S_CHECK_LAUNCH("dec_gru_mid");
+    return A2S_OK;
+}
+bool a2s_note_step_mid_bwd_ok(const a2s_note_dec_bwd_args& a) {
+    const void* ptrs[] = {a.dgi_all, a.dgh_all, a.dx, a.dh, a.step_ws};
+    return a.step_ws && a.step_ws_floats >= a2s_note_step_workspace_floats_impl(a.H, a.E) && a2s_note_step_mid_ok(a.H, a.E, ptrs, 5);
+}
+// dx[s] = dgi W_ih and dh_out += dgh W_hh for rows rowmap[0 .. nrows); the transposed weights come from a2s_note_step_fused_bwd_prepare
+int a2s_note_step_mid_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, float* dh_out, int nrows, const int* rowmap) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    if (nrows <= 0) return A2S_OK;
+    DecBwdProdArgs p;
+    p.dgi = a.dgi_all + (long)s * R * 3 * H2; p.dgh = a.dgh_all + (long)s * R * 3 * H2;
+    p.wih_t = a.step_ws + FUSED_HEAD; p.whh_t = p.wih_t + (long)ldx * 3 * H2;
+    p.dx = a.dx + (long)s * R * ldx; p.ldx = ldx; p.dh = dh_out;
+    p.rowmap = rowmap;
+    p.nxa = a2s_cdiv(ldx, 32); p.kx = ldx; p.R = nrows; p.H2 = H2;
+    hipLaunchKernelGGL(dec_bwd_mid, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(256), 0, st, p);
+    __atomic_fetch_add(&g_dec_mid_launches, 1, __ATOMIC_RELAXED);
+    A2S_CHECK_LAUNCH("dec_bwd_mid");
     return A2S_OK;
 }

@@ -41,7 +41,7 @@ def test_targets_uploaded_just_before_the_step_are_the_ones_planned_from(dev):
     from piano_a2s_amd import spec, synthetic, train
     from piano_a2s_amd.spec import PAD
     cfg = spec.default_cfg(max_length=(40, 24))
-    batch = synthetic.make_batch(12, cfg, 77, frames=151, upper_range=(5, 40), lower_range=(3, 24), full_tail=0.2)
+    batch = synthetic.make_batch(12, cfg, 77, frames=151, upper_range=(3, 12), lower_range=(2, 8), full_tail=0.0, full_rows=((3, 1, "up"), (8, 3, "lo")))
     torch.manual_seed(5)
     init = models.ScoreTranscription(**cfg).state_dict()
     busy = _busy(dev)
@@ -113,7 +113,7 @@ def test_group_buffers_hold_decoder_gradients_only(dev):
     import models
     from piano_a2s_amd import engine_bwd, spec, synthetic, train
     cfg = spec.default_cfg(max_length=(40, 24))
-    batch = synthetic.make_batch(12, cfg, 78, frames=151, upper_range=(5, 40), lower_range=(3, 24), full_tail=0.2)
+    batch = synthetic.make_batch(12, cfg, 78, frames=151, upper_range=(3, 12), lower_range=(2, 8), full_tail=0.0, full_rows=((3, 1, "up"), (8, 3, "lo")))
     dbatch = [t.to(dev) if torch.is_tensor(t) else t for t in batch]
     torch.manual_seed(6)
     m = models.ScoreTranscription(**cfg).to(dev).train()
