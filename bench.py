@@ -48,7 +48,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("A2S_BENCH_BATCH", "256")), help="clips per GPU per step")
+    ap.add_argument("--no-reserve", action="store_true", help="do not reserve the caching allocator's per-stream pools before the first step")
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--full-tail", type=float, default=0.01, help="probability of a full-length (no <eos>) row per (clip,bar,staff); SURVEY 8d: 1 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the tail-off secondary measurement and the loss-parity check")
@@ -280,7 +281,7 @@ def linear_roofline(B, T, F, Cf=256, iters=5):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
-    own = bool(L.a2s_linear_dgrad_eligible(rows, K, Cf, F)) and os.environ.get("A2S_LINEAR_DGRAD", "1") != "0"      # what engine_bwd runs
+    own = bool(L.a2s_linear_dgrad_eligible(rows, K, Cf, F)) and hip.LINEAR_KERNELS      # what engine_bwd runs
     if own:
         nb = L.a2s_linear_dgrad_ws_bytes(K, Cf)
         lws = torch.empty(nb // 4, dtype=torch.float32, device=dev)
@@ -297,7 +298,7 @@ def linear_roofline(B, T, F, Cf=256, iters=5):
                                                     C.c_long(K), hip._p(y4), hip._p(mean), hip._p(invstd), hip._p(scale), hip._p(shift), F, hip._p(part), hip._p(dmax),
                                                     hip._p(wmax)), "bnstats")
     bound = hip.act_bound(scale, shift, y4.view(rows, 40, F).abs().amax(dim=(0, 2)).contiguous())
-    own_fwd = bool(L.a2s_linear_fwd_eligible(rows, Cf, K, F)) and os.environ.get("A2S_LINEAR_FWD", "1") != "0"
+    own_fwd = bool(L.a2s_linear_fwd_eligible(rows, Cf, K, F)) and hip.LINEAR_KERNELS
     ms = {"forward": timed(lambda: hip.linear_forward(y4, W, (scale, shift, F), bound, wmax, out=z)),
           "data_gradient": timed(dgrad),
           "weight_gradient": timed(lambda: hip.linear_wgrad(dz, y4, (scale, shift, F), dmax, bound, G)
@@ -305,7 +306,7 @@ def linear_roofline(B, T, F, Cf=256, iters=5):
     flops = 2.0 * rows * K * Cf
     big = 4.0 * rows * K                                   # the (rows, 19200) operand / result: read (written) once
     byts = {"forward": big, "data_gradient": 2 * big, "weight_gradient": big}        # (the data gradient writes da and reads y4 for the statistics)
-    own_wg = bool(L.a2s_linear_wgrad_eligible(rows, Cf, K, F)) and os.environ.get("A2S_LINEAR_WGRAD", "1") != "0"
+    own_wg = bool(L.a2s_linear_wgrad_eligible(rows, Cf, K, F)) and hip.LINEAR_KERNELS
     generic = "gemm_f32_kernel<256, 256, 4, 2, ..., 2> (two-term fp16 tiles)"
     out = {"kernel": "csrc/a2s_linear.hip where the shape qualifies, each incl. its operand-plane pre-pass: forward " + ("lin_fwd" if own_fwd else generic)
                      + "; data gradient " + ("lin_dgrad_bnstats" if own else generic) + "; weight gradient " + ("lin_wgrad (+ lin_wgrad_reduce)" if own_wg else generic),
@@ -641,7 +642,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X: the transcription hot path has no CPU implementation"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.cuda.set_per_process_memory_fraction(float(os.environ.get("A2S_MEM_FRACTION", "0.96")), local)     # an over-sized batch raises in torch instead of taking the box down
+    torch.cuda.set_per_process_memory_fraction(0.96, local)     # an over-sized batch raises in torch instead of taking the box down
     torch.manual_seed(1234)
     random.seed(1234 + (rank if COIN_POLICY == "rank_offset" else 0))      # teacher-forcing coins (COIN_POLICY above)
     from piano_a2s_amd import build as a2s_build
@@ -701,21 +702,16 @@ def main():
 
     batches = make_batches(args.full_tail)
     from piano_a2s_amd import hip as a2s_hip
-    # One segment for the caching allocator's pool, before anything is timed: a step's tensor shapes follow its coins (how many bars fuse), so new
-    # block sizes keep turning up for dozens of steps, and each one the pool cannot serve is a hipMalloc of several GiB -- 50-130 ms during which the
-    # step stands still (round 4: `hipMalloc_segments_per_step`).  A trainer that knows its memory budget reserves it up front; so does the bench
-    # (A2S_POOL_RESERVE_GIB; 0 = off, the default: measured, the segment only serves allocations made on the stream it was allocated on -- the caching
-    # allocator keeps one pool per stream and the step allocates on four -- so the per-step hipMalloc count did not fall (it stays in the JSON) and
-    # 200 GiB pushed the reserved peak to 239 GiB with an allocator retry).
-    pool_gib = float(os.environ.get("A2S_POOL_RESERVE_GIB", "0"))
+    # The caching allocator's pools, reserved before anything is timed (train.reserve_pools: one block per stream the step allocates on): a step's
+    # tensor shapes follow its minibatch and its coins (how many bars fuse), so new block sizes keep turning up for ~10 steps, and each one a pool
+    # cannot serve is a hipMalloc of several GiB -- 50-130 ms during which the step stands still (`hipMalloc_segments_per_step` in the JSON line).
+    # A trainer that knows its memory budget reserves it up front; so does the bench (--no-reserve: off).
+    pool_gib = 0.0
 
     def reserve_pool():
-        if pool_gib > 0:
-            try:
-                pool = torch.empty(int(pool_gib * 2 ** 30), dtype=torch.uint8, device=dev)
-                del pool
-            except RuntimeError:
-                pass
+        nonlocal pool_gib
+        if not args.no_reserve:
+            pool_gib = round(train.reserve_pools(dev, B), 1)
     reserve_pool()
     elapsed, decode_steps = timed(batches, args.warmup, args.steps)
     launches_per_step = round((a2s_hip.lib().a2s_launch_count() - timed.launches0) / args.steps)

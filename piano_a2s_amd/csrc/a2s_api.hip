@@ -60,19 +60,11 @@ void a2s_gru_persist_alone_set(int);
 int a2s_gru_persist_alone(void);
 void a2s_attn_deep_set(int);
 void a2s_attn_defer_combine_set(int);
-void a2s_dec_bwd_fold_set(int);
 void a2s_dec_mid_set(int);
 int a2s_dec_mid_enabled(void);
 int a2s_dec_mid_launches(void);
-void a2s_attn_deep_bwd_set(int);
-int a2s_attn_deep_bwd_enabled(void);
-int a2s_dec_bwd_fold_enabled(void);
 int a2s_attn_defer_combine_enabled(void);
 int a2s_attn_deep_max_clips(void);
-void a2s_attn_pace_set(int);
-int a2s_attn_pace_enabled(void);
-void a2s_attn_pace_min_set(int);
-int a2s_attn_pace_min(void);
 int a2s_dec_persist_launches(void);
 int a2s_dec_persist_enabled(void);
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
@@ -93,8 +85,7 @@ int a2s_log_softmax_bwd_rows_impl(hipStream_t, const float*, const float*, long,
 int a2s_gru_gates_bwd_impl(hipStream_t, const float*, long, const float*, long, const float*, const float*, long, float*, long, float*, long,
                            float*, long, float*, long, int, int);
 int a2s_attn_step_bwd_impl(hipStream_t, const float*, const float*, const float*, long, const float*, const float*, const float*, long,
-                           const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int, float*, const a2s_attn_rows*,
-                           a2s_attn_deferred_bwd* = nullptr);
+                           const float*, long, const float*, long, float*, long, float*, long, float*, int, int, int, float*, const a2s_attn_rows*);
 int a2s_attn_dk_accum_impl(hipStream_t, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, const int*, int);
 int a2s_col_sum_impl(hipStream_t, const float*, long, float*, long, int, float, float, float*, size_t);
 int a2s_embed_scatter_add_impl(hipStream_t, float*, const long long*, const int*, long, int, const float*, long, int, int, int, const uint8_t*, float);
@@ -229,13 +220,9 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_fused_combine")) { a2s_attn_fused_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_nt")) { a2s_attn_nt_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_bulk_cap")) { a2s_attn_bulk_cap_set(value); return A2S_OK; }
-    if (!strcmp(key, "attn_pace")) { a2s_attn_pace_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_deep")) { a2s_attn_deep_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_defer_combine")) { a2s_attn_defer_combine_set(value); return A2S_OK; }
-    if (!strcmp(key, "dec_bwd_fold")) { a2s_dec_bwd_fold_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_mid")) { a2s_dec_mid_set(value); return A2S_OK; }
-    if (!strcmp(key, "attn_deep_bwd")) { a2s_attn_deep_bwd_set(value); return A2S_OK; }
-    if (!strcmp(key, "attn_pace_min")) { a2s_attn_pace_min_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
@@ -261,14 +248,10 @@ int a2s_persist_abort_latch(void* device_word) { a2s_persist_latch_set(device_wo
 
 int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_bulk_cap")) return a2s_attn_bulk_cap_enabled();
-    if (key && !strcmp(key, "attn_pace")) return a2s_attn_pace_enabled();
     if (key && !strcmp(key, "attn_deep")) return a2s_attn_deep_max_clips();
     if (key && !strcmp(key, "attn_defer_combine")) return a2s_attn_defer_combine_enabled();
-    if (key && !strcmp(key, "dec_bwd_fold")) return a2s_dec_bwd_fold_enabled();
     if (key && !strcmp(key, "dec_mid")) return a2s_dec_mid_enabled();
     if (key && !strcmp(key, "dec_mid_launches")) return a2s_dec_mid_launches();
-    if (key && !strcmp(key, "attn_deep_bwd")) return a2s_attn_deep_bwd_enabled();
-    if (key && !strcmp(key, "attn_pace_min")) return a2s_attn_pace_min();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
     if (key && !strcmp(key, "wgrad_rows")) return a2s_wgrad_rows_enabled();

@@ -122,21 +122,18 @@ __global__ __launch_bounds__(256) void attn_step_bwd(const float* __restrict__ K
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                                  long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
-                                 const a2s_attn_rows* rows, a2s_attn_deferred_bwd* defer = nullptr);
-int a2s_attn_deep_max_clips(void);
-int a2s_attn_defer_combine_enabled(void);
+                                 const a2s_attn_rows* rows);
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                            long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws,
-                           const a2s_attn_rows* rows = nullptr, a2s_attn_deferred_bwd* defer = nullptr);
+                           const a2s_attn_rows* rows = nullptr);
 
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                            long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws,
-                           const a2s_attn_rows* rows, a2s_attn_deferred_bwd* defer) {
-    if (defer) defer->G = 0;
+                           const a2s_attn_rows* rows) {
     if (H == 256 && ws)
-        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H, rows, defer);
+        return a2s_attn_step_bwd_split_impl(st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, dq, lddq, ds_out, ws, B, T, H, rows);
     const int n_clips = rows ? rows->n_clips : B;
     const size_t shm = (((T + 3) & ~3) + 2 * H + 16) * sizeof(float);
     A2S_REQUIRE(H >= 1 && H <= 512, "attn_step_bwd: hidden_size must be in 1 .. 512 (got %d)", H);
@@ -302,6 +299,7 @@ bool a2s_note_decoder_bwd_persist_ok(const a2s_note_dec_bwd_args& a);
 int a2s_note_decoder_bwd_persist(hipStream_t st, const a2s_note_dec_bwd_args& a);
 bool a2s_note_step_mid_bwd_ok(const a2s_note_dec_bwd_args& a);
 int a2s_note_step_mid_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, float* dh_out, int nrows, const int* rowmap);
+int a2s_note_step_mid_bwd_query(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, float* dh_out, int nrows, const int* rowmap);
 
 int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
     // few clips: one persistent launch for the whole reverse loop (a2s_dec_persist.hip)
@@ -371,6 +369,10 @@ int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
             rc = a2s_gemm_impl(st, gM, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * 3 * H2, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
             if (rc) return rc;
         }
+        if (mid) {
+            const int nrows = step_rows(s);
+            rc = a2s_note_step_mid_bwd_query(st, a, s, dh_out, nrows, nrows < R ? a.row_list : nullptr);
+        } else
         rc = a2s_gemm_impl(st, gM, H2, a.H, 1.f, a.dq_all + (long)s * R * a.H, a.H, 1, a.attn_w, 2 * H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * a.H, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
         if (rc) return rc;
         cur ^= 1;
@@ -1035,198 +1037,12 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     }
 }
 
-// ---- the few-clip form of the fused-rows backward sweep (round 5; forward counterpart: attn_fwd_split256_deep, a2s_seq.hip).  The long-clip
-// group's chain launches this kernel once per backward decode step over 1-8 clips; beside the bulk group's sweeps every DEPENDENT memory round
-// trip costs several microseconds, and attn_bwd_split256_mq has four in series (operands of the prologue, enc blocks of pass A -- two per wave --,
-// the saved weights, the K tiles of pass B): 60-83 us per launch on that chain against 17 alone (profiles/r05_kernel_stats.txt).  Here 512 threads
-// request EVERYTHING the workgroup needs before anything is waited for -- the K chunk (10 float4 per thread), one 16-frame enc block per wave
-// (waves 0-4: 32 float4 per lane), the rows' dctx / ctx (one row per wave), the queries, the saved weights -- and then run the same three phases
-// out of registers.  chunk <= 80 frames, NQ <= 4 rows.  Summation order of pass B differs from the 256-thread kernel (8 frame groups instead of 4):
-// equal to rounding, not to the bit.
-template <int NQ, bool UPFRONT>
-__global__ __launch_bounds__(512) void attn_bwd_split256_deep(const float* __restrict__ Kmat, const float* __restrict__ enc,
-                                                              const float* __restrict__ q, long ldq, const float* __restrict__ v,
-                                                              const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
-                                                              const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
-                                                              float* __restrict__ dctx_out, long lddo, float* __restrict__ dq_partial,
-                                                              float* __restrict__ ds_out, int T, int G, int chunk,
-                                                              const int* __restrict__ clip_order, const int* __restrict__ row_until,
-                                                              int step, int n_clips) {
-    constexpr int H = 256, KF = 10, RG = 8;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* dsv = sm;                                         // NQ x chunk
-    f32x4* red4 = reinterpret_cast<f32x4*>(sm + NQ * chunk);    // NQ * (RG - 1) * 64 float4
-    float* dcT = reinterpret_cast<float*>(red4 + NQ * (RG - 1) * 64);     // NQ x ATT_DCS floats
-    float* dots = dcT + NQ * ATT_DCS;                                      // 16
-    const int slot = blockIdx.x / G, g = blockIdx.x % G;
-    const int b = clip_order ? clip_order[slot] : slot;
-    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    bool on[NQ];
-    int onmask = 0;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) { on[j] = !row_until || step < row_until[j * n_clips + b]; onmask |= on[j] ? (1 << j) : 0; }
-    const float* Kb = Kmat + ((long)b * T + t0) * H;
-    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
-    // ---------------------------------------------------------------- every load of the launch
-    const int c4 = tid & 63, rg = tid >> 6;
-    // (UPFRONT = false -- the "wide" form: the same 512-thread decomposition, one enc block per wave and 8 frame groups in pass B, but every operand is
-    // requested where it is used, as in the 256-thread kernel: few loads in flight per wave, few registers)
-    f32x4 kreg[KF];
-    if (UPFRONT) {
-#pragma unroll
-        for (int u = 0; u < KF; ++u) {
-            const int fr = rg + RG * u;
-            kreg[u] = fr < n ? *reinterpret_cast<const f32x4*>(Kb + (long)fr * H + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    const bool blk_on = wave * 16 < n;                       // waves 0 .. 4: the enc block of frames 16 wave .. + 15
-    f32x4 e0[16], e1[16];
-    const bool evalid = blk_on && wave * 16 + li < n;
-    const float* ep = Eb + (long)min(wave * 16 + li, n - 1) * 2 * H + 8 * lg;
-    if (UPFRONT) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            e0[u] = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            e1[u] = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    const bool mine = li < NQ && ((onmask >> li) & 1);
-    const long arow = ((long)min(li, NQ - 1) * n_clips + b) * T + t0;
-    float aw[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int f2 = wave * 16 + 4 * lg + r;
-        aw[r] = (mine && blk_on && f2 < n) ? attw[arow + f2] : 0.f;
-    }
-    f32x4 q4[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) q4[j] = on[j] ? *reinterpret_cast<const f32x4*>(q + ((long)j * n_clips + b) * ldq + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    // ---------------------------------------------------------------- prologue: wave j forms row j's dctx (B operand of pass A) and its dot with the saved context
-    if (wave < NQ) {
-        const int j = wave;
-        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-        float dot = 0.f;
-        if ((onmask >> j) & 1) {
-            const long row = (long)j * n_clips + b;
-            d0 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + lane * 4);
-            d1 = *reinterpret_cast<const f32x4*>(dctx_a + row * ldda + H + lane * 4);
-            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-            if (dctx_b) {
-                o0 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + lane * 4);
-                o1 = *reinterpret_cast<const f32x4*>(dctx_b + row * lddb + H + lane * 4);
-            }
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + lane * 4);
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctx + row * ldctx + H + lane * 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { d0[c] += o0[c]; d1[c] += o1[c]; }
-            if (dctx_out && g == 0) {
-                *reinterpret_cast<f32x4*>(dctx_out + row * lddo + lane * 4) = d0;
-                *reinterpret_cast<f32x4*>(dctx_out + row * lddo + H + lane * 4) = d1;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dot += d0[c] * c0[c] + d1[c] * c1[c];
-            dot = wave_sum(dot);
-        }
-        *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + lane * 4) = d0;
-        *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + H + lane * 4) = d1;
-        if (lane == 0) dots[j] = dot;
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- pass A (waves with a block): da = enc . dctx on the fp32 matrix cores, as attn_bwd_split256_mq
-    if (blk_on) {
-        const float* brow = dcT + min(li, NQ - 1) * ATT_DCS + 8 * lg;
-        const float dotn = dots[min(li, NQ - 1)];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        if (UPFRONT) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[u][c], b0[c], acc, 0, 0, 0);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[u][c], b1[c], acc2, 0, 0, 0);
-            }
-        } else {
-#pragma unroll 4
-            for (int u = 0; u < 16; ++u) {
-                const f32x4 x0 = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                const f32x4 x1 = evalid ? *reinterpret_cast<const f32x4*>(ep + 32 * u + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[c], b0[c], acc, 0, 0, 0);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[c], b1[c], acc2, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
-        if (mine) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f2 = wave * 16 + 4 * lg + r;
-                if (f2 < n) {
-                    const float d_s = aw[r] * (acc[r] - dotn);
-                    dsv[li * chunk + f2] = d_s;
-                    if (ds_out) ds_out[arow + f2] = d_s;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- pass B: dq_j += ds_t (1 - tanh^2(K_tj + q_j)) out of the registers
-    f32x4 acc[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);       // E_q; Kmat holds the key image E_K = exp(2K)
-    }
-#pragma unroll
-    for (int u = 0; u < KF; ++u) {
-        const int fr = rg + RG * u;
-        if (fr >= n) break;
-        const f32x4 kk = UPFRONT ? kreg[u] : *reinterpret_cast<const f32x4*>(Kb + (long)fr * H + c4 * 4);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            if (!on[j]) continue;
-            const float w = dsv[j * chunk + fr];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(kk[c], q4[j][c]), acc[j][c]);
-        }
-    }
-    if (rg > 0) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) red4[(j * (RG - 1) + rg - 1) * 64 + c4] = acc[j];
-    }
-    __syncthreads();
-    if (rg == 0) {
-        const f32x4 v4 = {v[c4 * 4], v[c4 * 4 + 1], v[c4 * 4 + 2], v[c4 * 4 + 3]};            // parameter: 4-byte aligned only
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            if (!on[j]) continue;
-            f32x4 a = acc[j];
-#pragma unroll
-            for (int u = 0; u < RG - 1; ++u) { const f32x4 o = red4[(j * (RG - 1) + u) * 64 + c4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) a[c] += o[c]; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) a[c] *= v4[c];
-            *reinterpret_cast<f32x4*>(dq_partial + (((long)slot * NQ + j) * G + g) * H + c4 * 4) = a;
-        }
-    }
-}
-
 // one workgroup (256 threads) per row: dq = sum of the G partials; rows the forward pass skipped (upstream gradient exactly zero) get
 // zeros in everything the deferred GEMMs read (dq, ds, dctx)
 __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int G,
                                                            const int* __restrict__ clip_rank, const int* __restrict__ row_until,
                                                            int n_clips, int groups, int n_active, int step, float* __restrict__ ds_out,
-                                                           int T, float* __restrict__ dctx_out, long lddo, unsigned* __restrict__ pace_token) {
-    if (pace_token && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(pace_token, 0u);       // bandwidth token of the sweep in front (a2s_seq.hip)
+                                                           int T, float* __restrict__ dctx_out, long lddo) {
     const int b = blockIdx.x, j = threadIdx.x;
     const int clip = b % n_clips, grp = b / n_clips;
     const int slot = clip_rank ? clip_rank[clip] : clip;
@@ -1249,7 +1065,6 @@ __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restri
 }
 
 size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward);
-unsigned* a2s_attn_pace_gate_impl(hipStream_t st, int n_active);
 template <int NQ>
 static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                           const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
@@ -1260,35 +1075,10 @@ static void launch_bwd_mq(hipStream_t st, int nwg, size_t shm, const float* Kmat
                             dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
 }
 
-// few-clip backward sweep: OFF by default (A2S_ATTN_DEEP_BWD=1 / a2s_debug_set("attn_deep_bwd", 1): on).  Parity-tested (tests/test_gpu_defer_combine.py,
-// tests/test_gpu_ops.py with the switch on) and measured in the training step: 4.2 +- 3.2 ms SLOWER over 10 pairs (profiles/r05_defer_combine_ab.txt) --
-// 512 threads x 208-229 registers + 38 KB of LDS is a whole CU, which beside the bulk group's backward sweeps (5 workgroups per CU, all LDS taken)
-// has to drain first; the forward form (137-172 registers, the bulk group's forward sweeps at 2 per CU) does not pay that.
-// Mode 2 (A2S_ATTN_DEEP_BWD=2): the same 512-thread decomposition with every operand requested where it is used (52-112 registers): neutral
-// (+1.3 ms over 8 clean pairs).  Both stay switches.
-static int g_attn_deep_bwd = -1;
-void a2s_attn_deep_bwd_set(int v) { g_attn_deep_bwd = v < 0 ? 0 : (v > 2 ? 2 : v); }      // 0 off, 1 everything up front, 2 wide form (loads at their use)
-int a2s_attn_deep_bwd_enabled(void) {
-    if (g_attn_deep_bwd < 0) { const char* e = getenv("A2S_ATTN_DEEP_BWD"); g_attn_deep_bwd = e ? (atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e))) : 0; }
-    return g_attn_deep_bwd;
-}
-template <int NQ>
-static void launch_bwd_deep(hipStream_t st, int nwg, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
-                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
-                            float* dctx_out, long lddo, float* ws, float* ds_out, int T, int G, int chunk, const a2s_attn_rows& r) {
-    const size_t shm = ((size_t)NQ * chunk + (size_t)NQ * 7 * 64 * 4 + (size_t)NQ * ATT_DCS + 16) * sizeof(float);
-    if (a2s_attn_deep_bwd_enabled() == 2)
-        hipLaunchKernelGGL((attn_bwd_split256_deep<NQ, false>), dim3(nwg), dim3(512), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
-                           dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
-    else
-        hipLaunchKernelGGL((attn_bwd_split256_deep<NQ, true>), dim3(nwg), dim3(512), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
-                           dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order, r.row_until, r.step, r.n_clips);
-}
-
 int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                                  const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b,
                                  long lddb, float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, float* ws, int B, int T, int H,
-                                 const a2s_attn_rows* rows, a2s_attn_deferred_bwd* defer) {
+                                 const a2s_attn_rows* rows) {
     A2S_REQUIRE(H == 256 && ws, "attn_step_bwd_split: needs hidden_size 256 and a workspace");
     A2S_REQUIRE(ldq % 4 == 0 && ldctx % 4 == 0 && ldda % 4 == 0 && (!dctx_b || lddb % 4 == 0) && (!dctx_out || lddo % 4 == 0),
                 "attn_step_bwd_split: row strides must be multiples of 4 floats");
@@ -1296,7 +1086,6 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
                 "attn_step_bwd_split: 16-byte alignment");
     a2s_attn_rows r = {nullptr, nullptr, nullptr, B, B, 0};
     if (rows) r = *rows;
-    T = a2s_attn_fake_t(T, r.n_clips);
     A2S_REQUIRE(r.n_clips > 0 && B % r.n_clips == 0, "attn_step_bwd_split: rows (%d) must be a multiple of the clips (%d)", B, r.n_clips);
     const int groups = B / r.n_clips;
     A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_bwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);
@@ -1306,16 +1095,14 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     // streaming loads as in a2s_attn_step_fwd_split_impl -- single-row launches only: measured +12 % on attn_bwd_split256, -0 .. 5 % on the
     // fused-rows kernels, whose enc pass feeds the matrix cores (profiles/r04_attn_mq_bench.txt)
     const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled() && groups == 1;
-    unsigned* pace_token = r.n_active > 0 ? a2s_attn_pace_gate_impl(st, r.n_active) : nullptr;
     if (r.n_active > 0) {
         a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
         // a handful of clips (late in the long-clip group's chain: the one or two clips that hold a full-length bar): a finer split -- the launch
         // is a chain of dependent passes over the chunk, not bandwidth; the dq partials of 2 G chunks still fit the workspace the forward sized
-        // (2 G x 256 <= G x 516 floats per row).  A2S_ATTN_BWD_FINE=n: clips up to which the finer split applies (default 4, 0: off; measured
-        // 458.1 / 457.8 -> 454.7 / 456.1 ms per step, tools/step_time.py, alternating processes: profiles/r05_prefix_percent.txt)
+        // (2 G x 256 <= G x 516 floats per row).  Up to 4 clips (measured 458.1 / 457.8 -> 454.7 / 456.1 ms per step, tools/step_time.py,
+        // alternating processes: profiles/r05_prefix_percent.txt)
         {
-            static int fine = -1;
-            if (fine < 0) { const char* e = getenv("A2S_ATTN_BWD_FINE"); fine = e ? atoi(e) : 4; }
+            const int fine = 4;
             if (fine > 0 && r.n_active <= fine && G == a2s_attn_max_split() && 2 * G <= 64) {
                 int c = (T + 2 * G - 1) / (2 * G);
                 c = (c + 3) & ~3;
@@ -1324,16 +1111,7 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
             }
         }
         const int nwg = r.n_active * G;
-        if (groups <= 4 && r.n_active <= a2s_attn_deep_max_clips() && chunk <= 80 && a2s_attn_deep_bwd_enabled()) {       // the few-clip form: one round trip
-#define A2S_BWD_DEEP(N) launch_bwd_deep<N>(st, nwg, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb, dctx_out, lddo, ws, ds_out, T, G, chunk, r)
-            switch (groups) {
-                case 1: A2S_BWD_DEEP(1); break;
-                case 2: A2S_BWD_DEEP(2); break;
-                case 3: A2S_BWD_DEEP(3); break;
-                default: A2S_BWD_DEEP(4); break;
-            }
-#undef A2S_BWD_DEEP
-        } else if (groups == 1) {
+        if (groups == 1) {
             const size_t shm = a2s_attn_bulk_lds((chunk + 3 * 64 * 4) * sizeof(float), r.n_active, 1);
             if (nt) hipLaunchKernelGGL(attn_bwd_split256<true>, dim3(nwg), dim3(256), shm, st, Kmat, enc, q, ldq, v, attw, ctx, ldctx, dctx_a, ldda, dctx_b, lddb,
                                        dctx_out, lddo, ws, ds_out, T, G, chunk, r.clip_order);
@@ -1354,13 +1132,8 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
         }
         A2S_CHECK_LAUNCH("attn_bwd_split256");
     }
-    // the few-clip launches leave the sum of the partials to the query product that consumes dq (a2s_step.hip: dec_bwd_query_cmb)
-    if (defer && !pace_token && r.n_active > 0 && r.n_active <= a2s_attn_deep_max_clips() && groups <= 4 && G <= 16 && lddq == H && a2s_attn_defer_combine_enabled()) {
-        *defer = a2s_attn_deferred_bwd{ws, ds_out, dctx_out, lddo, r.clip_rank, r.row_until, G, groups, r.n_clips, r.n_active, r.step, T};
-        return A2S_OK;
-    }
     hipLaunchKernelGGL(attn_bwd_combine256, dim3(B), dim3(256), 0, st, ws, dq, lddq, G, r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step,
-                       ds_out, T, dctx_out, lddo, pace_token);
+                       ds_out, T, dctx_out, lddo);
     A2S_CHECK_LAUNCH("attn_bwd_combine256");
     return A2S_OK;
 }

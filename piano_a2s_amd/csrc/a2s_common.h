@@ -58,33 +58,12 @@ int a2s_persist_dbg_get(unsigned bit);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Split of the T frames of a clip over G workgroups for the attention kernels (forward and backward must agree):
-// aim at ~768 workgroups (3 per CU) but never more than A2S_ATTN_MAX_SPLIT chunks (default 16; 64 measured slower overall: with only a handful of clips still
+// aim at ~768 workgroups (3 per CU) but never more than 16 chunks (64 measured slower overall: with only a handful of clips still
 // decoding -- the long-clip group -- a chunk of 76 frames is 5 + 10 dependent load rounds in one workgroup, ~15-35 us per launch; 20
 // frames are 2 + 3); chunk is a multiple of 4 frames.
 #include <stdlib.h>
-static inline int a2s_attn_target_wgs(void) {
-    static int v = 0;
-    if (!v) { const char* e = getenv("A2S_ATTN_WGS"); v = e ? atoi(e) : 768; if (v < 1) v = 768; }
-    return v;
-}
-static inline int a2s_attn_max_split(void) {
-    static int v = 0;
-    if (!v) { const char* e = getenv("A2S_ATTN_MAX_SPLIT"); v = e ? atoi(e) : 16; if (v < 1) v = 16; }
-    return v;
-}
-// measurement only (results are wrong; compiled in only with -DA2S_MEASURE_FAKE_T, piano_a2s_amd.build.build_variant): the split attention
-// kernels of calls with more than 64 clips read A2S_ATTN_FAKE_T percent of the frames -- predicts what a launch that moves fewer bytes would be
-// worth to the training step.  The product library ignores the variable.
-static inline int a2s_attn_fake_t(int T, int n_clips) {
-#ifdef A2S_MEASURE_FAKE_T
-    static int pct = -1;
-    if (pct < 0) { const char* e = getenv("A2S_ATTN_FAKE_T"); pct = e ? atoi(e) : 100; if (pct < 1 || pct > 100) pct = 100; }
-    return (pct == 100 || n_clips <= 64) ? T : ((T * pct / 100) & ~3);
-#else
-    (void)n_clips;
-    return T;
-#endif
-}
+static inline int a2s_attn_target_wgs(void) { return 768; }
+static inline int a2s_attn_max_split(void) { return 16; }
 static inline void a2s_attn_split_geometry(int B, int T, int* G, int* chunk) {
     const int target = a2s_attn_target_wgs();
     int g = (target + B - 1) / B;
@@ -111,12 +90,8 @@ struct a2s_attn_rows {
 };
 #define A2S_ATTN_MAX_GROUPS 5
 // Late steps of a large decoder call run their per-step products on the leading m clips of every fused bar (the clips still running) once
-// m <= percent / 100 of the clips (A2S_PREFIX_PERCENT, default 50: measured, profiles/r05_prefix_percent.txt)
-static inline bool a2s_prefix_rows_ok(int m, int n_clips) {
-    static int pct = -1;
-    if (pct < 0) { const char* e = getenv("A2S_PREFIX_PERCENT"); pct = e ? atoi(e) : 50; if (pct < 1) pct = 1; if (pct > 100) pct = 100; }
-    return m > 0 && 100L * m <= (long)pct * n_clips;
-}
+// m <= half of the clips (measured over 25 ... 100 %: profiles/r05_prefix_percent.txt)
+static inline bool a2s_prefix_rows_ok(int m, int n_clips) { return m > 0 && 2L * m <= (long)n_clips; }
 // A forward attention launch whose combine has been left to its consumer (round 5: the few-row GRU step folds it into its prologue -- one
 // launch and one dependent-launch gap less per decode step on the long-clip chain, where a launch costs ~20 us + ~18 us of gap under the
 // other clip group's traffic: profiles/r05_trace_overlap.txt).  G == 0: nothing deferred, the combine has run.
@@ -126,18 +101,11 @@ struct a2s_attn_deferred {
     const int* clip_rank; const int* row_until;
     int G, groups, n_clips, n_active, step, T;
 };
-// the backward counterpart: the sum of a row's dq partials (and the zeros of skipped rows) left to the query product that consumes dq
-struct a2s_attn_deferred_bwd {
-    const float* part;       // dq partials [H] of (slot, group, g), as attn_bwd_combine256 reads them
-    float* ds_out; float* dctx_out; long lddo;       // zero-filled for skipped rows (or NULL)
-    const int* clip_rank; const int* row_until;
-    int G, groups, n_clips, n_active, step, T;
-};
 // head of the attention workspace: arrival counters of the fused combine (forward: [0, 4096), backward: [4096, 8192)), in floats
 #define A2S_ATTN_TICKETS 8192
 
 // Streaming K / enc loads of the split attention kernels: 0 = off, n > 0 = launches covering at least n clips use non-temporal loads
-// (A2S_ATTN_NT / a2s_debug_set("attn_nt", n)).
+// (a2s_debug_set("attn_nt", n)).
 int a2s_attn_nt_enabled(void);
 void a2s_attn_nt_set(int v);
 

@@ -993,7 +993,7 @@ int a2s_conv_bf16x3_enabled(void) { return g_conv_bf16x3; }
 static int g_conv_f16x2 = -1;
 void a2s_conv_f16x2_set(int on) { g_conv_f16x2 = on; }
 int a2s_conv_f16x2_enabled(void) {
-    if (g_conv_f16x2 < 0) { const char* e = getenv("A2S_CONV_F16X2"); g_conv_f16x2 = e ? atoi(e) : 3; }
+    if (g_conv_f16x2 < 0) g_conv_f16x2 = 3;
     return g_conv_f16x2;
 }
 
@@ -1905,7 +1905,7 @@ int a2s_wgrad_split_enabled(void) { return g_wgrad_split; }
 static int g_wgrad_f16x2 = -1;         // ... with two fp16 terms (needs the max |dy| scalar) instead of three bf16 terms
 void a2s_wgrad_f16x2_set(int on) { g_wgrad_f16x2 = on; }
 int a2s_wgrad_f16x2_enabled(void) {
-    if (g_wgrad_f16x2 < 0) { const char* e = getenv("A2S_WGRAD_F16X2"); g_wgrad_f16x2 = e ? atoi(e) : 1; }
+    if (g_wgrad_f16x2 < 0) g_wgrad_f16x2 = 1;
     return g_wgrad_f16x2;
 }
 

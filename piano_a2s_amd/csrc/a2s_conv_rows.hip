@@ -668,13 +668,21 @@ __device__ __forceinline__ float rw_ror8(float x) {        // lane li of a 16-la
 }
 
 #define R16_SLOTS 4
-template <int CIN, int COUT, bool AFFINE, bool BNRED>
+// PIPE (round 6): the epilogue of output row t - 1 runs UNDER the multiply of row t.  The kernel above spends 3.1 k of its 7.0 k clocks per row
+// outside the multiply (epilogue 1.45 k, barrier, next row's load issue: HISTORY.md Part II 3.1) with the matrix pipes idle, and a second
+// accumulator set did not fit beside both weight terms in registers (214 / 250 of 256).  Here the second weight term lives in LDS (32 KB in
+// fragment order, 3 ds_read_b128 per k-step: it feeds one product in three), which pays for a second accumulator set: the multiply of row t
+// fills set t & 1 while the df-combination, scaling, stores and statistics of row t - 1 -- set (t - 1) & 1, complete since the last barrier --
+// are issued between its k-steps, one m-tile per k-step.  A wave issues one MFMA per ~32 clocks when two waves share a SIMD: the ~350 vector
+// instructions of an epilogue ride in the issue slots in between.  The barrier per row stays (ring slot hand-off, boundary rows).
+template <int CIN, int COUT, bool AFFINE, bool BNRED, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
     static_assert(COUT == 40, "rows16: 40 output channels");
     using G = RwGeom<CIN>;
     constexpr int NTHR = 512, KS = G::KS;
     constexpr int XIT = (G::ITEMS + NTHR - 1) / NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char ring[R16_SLOTS * G::SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char b1img[PIPE ? 8 * G::KS * 1024 : 16];      // second fp16 term of the weights: [tile][k-step][lane x 16 B]
     // accumulator rows that cross the boundary between neighbouring column ranges of a channel group, as TRUE values (sign undone):
     // [iteration parity][boundary: 0 / 1 = halves of group 0 / 1, 2..4 = quarters of group 2][0: left range's last row of D0 | 1: right
     // range's first row of D2][channel]
@@ -709,17 +717,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
 
     // ---- weights: both terms of the wave's tiles (3 or 2), all k-steps
     const unsigned sgn = neg ? 0x80008000u : 0u;
-    s16x8 bw[3][KS][2];
+    constexpr int BWT = PIPE ? 1 : 2;                       // weight terms kept in registers
+    s16x8 bw[3][KS][BWT];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
+            for (int tm = 0; tm < BWT; ++tm) {
                 uint4 v = *reinterpret_cast<const uint4*>(a.wimg + ((size_t)((tile0 + ((wide || d < 2) ? d : 0)) * KS + s) * 2 + tm) * 1024 + lane * 16);
                 v.x ^= sgn; v.y ^= sgn; v.z ^= sgn; v.w ^= sgn;
                 bw[d][s][tm] = __builtin_bit_cast(s16x8, v);
             }
+    if (PIPE) {
+        for (int e = tid; e < 8 * KS * 64; e += NTHR)
+            *reinterpret_cast<uint4*>(b1img + (size_t)e * 16) = *reinterpret_cast<const uint4*>(a.wimg + ((size_t)(e >> 6) * 2 + 1) * 1024 + (e & 63) * 16);
+    }
+    // second weight term of tile d, k-step s (this wave's sign)
+    auto bterm1 = [&](int d, int s) -> s16x8 {
+        if (PIPE) {
+            uint4 v = *reinterpret_cast<const uint4*>(b1img + ((tile0 + ((wide || d < 2) ? d : 0)) * KS + s) * 1024 + lane * 16);
+            v.x ^= sgn; v.y ^= sgn; v.z ^= sgn; v.w ^= sgn;
+            return __builtin_bit_cast(s16x8, v);
+        }
+        return bw[d][s][BWT - 1];
+    };
     const int co = wide ? (wave >> 1) * 16 + q : 32 + (q & 7);      // this lane's output channel
     const bool useful = wide || q < 8;
     const float xscale = a.hdr[120];
@@ -813,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
 #define R16_PRODUCT(TA, TB)                                                                                                  \
     _Pragma("unroll") for (int d = 0; d < NT; ++d)                                                                           \
         _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                     \
-            acc[ig * 2 + ii][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[TA][ii]), __builtin_bit_cast(f16x8, bw[d][s][TB]), acc[ig * 2 + ii][d], 0, 0, 0);
+            acc[ig * 2 + ii][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[TA][ii]), __builtin_bit_cast(f16x8, bw[d][s][TB < BWT ? TB : 0]), acc[ig * 2 + ii][d], 0, 0, 0);
                 R16_PRODUCT(1, 0)
                 R16_PRODUCT(0, 1)
                 R16_PRODUCT(0, 0)
@@ -923,6 +945,150 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
     issue(t_lo + 2, xa);
     __syncthreads();
 
+    if constexpr (PIPE) {
+        // ======================================================================== two accumulator sets: epilogue of row t - 1 under the multiply of row t
+        f32x4 accp[2][4][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) accp[e][i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};      // (the first row's "previous row" is masked out, but must be finite)
+        // one m-tile of the epilogue of row t from accumulator set SET (the arithmetic of `epilogue` above)
+        // (data gradient) yl of one m-tile of row t: requested at the START of the k-step whose end consumes it -- ~36 MFMAs of latency cover,
+        // 4 registers live instead of the 16 of a whole row (the instance has none to spare)
+        auto yl_tile = [&](int i, int t) -> f32x4 {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ylrsrc, yvo + 64 * i, t * COUT * a.F * 4, 0));
+        };
+        auto epi_tile = [&](auto WIDEc, auto SETc, int i, int t, float xl, float xr_, unsigned ob, const f32x4& ylt) {
+            constexpr bool WIDE = decltype(WIDEc)::value;
+            constexpr int SET = decltype(SETc)::value, NM = WIDE ? 4 : 2, D2 = WIDE ? 2 : 1;
+            const int yrow_off = t * COUT * a.F * 4;
+            const float up_src = (g == 3) ? (i > 0 ? accp[SET][i > 0 ? i - 1 : 0][0][3] : xl) : accp[SET][i][0][3];
+            const float dn_src = (g == 0) ? (i < NM - 1 ? accp[SET][i < NM - 1 ? i + 1 : NM - 1][D2][0] : xr_) : accp[SET][i][D2][0];
+            const float X = __int_as_float(__builtin_amdgcn_ds_bpermute(up_addr, __float_as_int(up_src)));
+            const float Y = __int_as_float(__builtin_amdgcn_ds_bpermute(dn_addr, __float_as_int(dn_src)));
+            const bool ok = ob >> i & 1;
+            const float us = ok ? unsc : 0.f;
+            f32x4 d1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d1[r] = WIDE ? accp[SET][i][1][r] : rw_ror8(accp[SET][i][0][r]);
+            f32x4 o;
+            o[0] = ((X + d1[0]) + accp[SET][i][D2][1]) * us;
+            o[1] = ((accp[SET][i][0][0] + d1[1]) + accp[SET][i][D2][2]) * us;
+            o[2] = ((accp[SET][i][0][1] + d1[2]) + accp[SET][i][D2][3]) * us;
+            o[3] = ((accp[SET][i][0][2] + d1[3]) + Y) * us;
+            if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrsrc, yvo + 64 * i, yrow_off, 0);
+            if (BNRED) {
+                const f32x4 xv = ylt;
+                f32x4 gm, xh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gm[k] = (fmaf(xv[k], bsc, bsh) > 0.f) ? o[k] : 0.f;
+                    xh[k] = fmaf(xv[k], bi, -bm * bi);
+                }
+                st_s += (f32x2){gm[0], gm[1]}; st_s += (f32x2){gm[2], gm[3]};
+                st_s2 += (f32x2){gm[0], gm[1]} * (f32x2){xh[0], xh[1]}; st_s2 += (f32x2){gm[2], gm[3]} * (f32x2){xh[2], xh[3]};
+                if (a.out_absmax) st_m = fmaxf(fmaxf(st_m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            } else {
+                st_s += (f32x2){o[0], o[1]}; st_s += (f32x2){o[2], o[3]};
+                st_s2 += (f32x2){o[0], o[1]} * (f32x2){o[0], o[1]}; st_s2 += (f32x2){o[2], o[3]} * (f32x2){o[2], o[3]};
+                st_m = fmaxf(fmaxf(st_m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            }
+        };
+        // boundary rows of row t_e (accumulator set 1 - CUR, exchanged before the last barrier) and the store mask: nothing is stored for a row
+        // in front of the strip (the first iteration has no previous row: its accumulators are the zeros above)
+        auto multiply_p = [&](auto WIDEc, auto CURc, int t_e, int crow, int cslot, const f32x4 (&xr)[XIT]) {
+            constexpr bool WIDE = decltype(WIDEc)::value;
+            constexpr int CUR = decltype(CURc)::value, NM = WIDE ? 4 : 2, NT = WIDE ? 3 : 2;
+            const bool cok = crow >= 0 && crow < a.T && colok;
+            unsigned char* const cbase = ring + cslot * G::SLOT;
+            const bool ev = t_e >= t_lo;
+            const float xl = (ev && bnd_l >= 0) ? xch[1 - CUR][bnd_l >= 0 ? bnd_l : 0][0][q] * sg : 0.f;
+            const float xr_ = (ev && bnd_r >= 0) ? xch[1 - CUR][bnd_r >= 0 ? bnd_r : 0][1][q] * sg : 0.f;
+            unsigned ob = ev ? okbits : 0u;
+            asm volatile("" : "+v"(ob));
+#pragma unroll
+            for (int i = 0; i < NM; ++i)
+#pragma unroll
+                for (int d = 0; d < NT; ++d) accp[CUR][i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                f32x4 ylt[(BNRED && NM > KS) ? NM / KS : 1];          // yl of the m-tiles whose epilogue ends this k-step
+                if (BNRED) {
+#pragma unroll
+                    for (int i = 0; i < NM; ++i)
+                        if (i * KS / NM == s) ylt[(NM > KS) ? i - s * NM / KS : 0] = (ev || true) ? yl_tile(i, t_e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                s16x8 b1[NT];
+#pragma unroll
+                for (int d = 0; d < NT; ++d) b1[d] = bterm1(d, s);
+#pragma unroll
+                for (int ig = 0; ig < NM / 2; ++ig) {
+                    s16x8 av[2][2];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const int off = tm * G::TS + (ig * 2 + ii) * 32;
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(RW_LDS(ring + aaddr[s][0] + off));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(RW_LDS(ring + aaddr[s][1] + off));
+                            av[tm][ii] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+#define R16P_PRODUCT(TA, BV)                                                                                                 \
+    _Pragma("unroll") for (int d = 0; d < NT; ++d)                                                                           \
+        _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                     \
+            accp[CUR][ig * 2 + ii][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[TA][ii]), __builtin_bit_cast(f16x8, BV), accp[CUR][ig * 2 + ii][d], 0, 0, 0);
+                    R16P_PRODUCT(1, bw[d][s][0])
+                    R16P_PRODUCT(0, b1[d])
+                    R16P_PRODUCT(0, bw[d][s][0])
+#undef R16P_PRODUCT
+                }
+#pragma unroll
+                for (int it = 0; it < XIT; ++it)
+                    if (it * KS / XIT == s) commit_item(it, cok, cbase, xr[it]);
+                // the previous row's epilogue, spread over the k-steps
+#pragma unroll
+                for (int i = 0; i < NM; ++i)
+                    if (i * KS / NM == s) epi_tile(WIDEc, std::integral_constant<int, 1 - CUR>{}, i, t_e, xl, xr_, ob, ylt[(BNRED && NM > KS) ? i - s * NM / KS : 0]);
+            }
+        };
+        int slot_w = 3;
+        auto row = [&](auto CURc, int t) {
+            constexpr int CUR = decltype(CURc)::value;
+            if (wide) multiply_p(std::true_type{}, CURc, t - 1, t + 2, slot_w, xa);
+            else multiply_p(std::false_type{}, CURc, t - 1, t + 2, slot_w, xa);
+            if (bnd_r >= 0 && g == 3) xch[CUR][bnd_r >= 0 ? bnd_r : 0][0][q] = (wide ? accp[CUR][3][0][3] : accp[CUR][1][0][3]) * sg;
+            if (bnd_l >= 0 && g == 0) xch[CUR][bnd_l >= 0 ? bnd_l : 0][1][q] = (wide ? accp[CUR][0][2][0] : accp[CUR][0][1][0]) * sg;
+            __syncthreads();
+            issue(t + 3, xa);
+            slot_w = slot_w == R16_SLOTS - 1 ? 0 : slot_w + 1;
+            advance();
+        };
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        int t = t_lo, last = 0;
+        for (;;) {
+            row(C0{}, t);
+            if (++t >= t_hi) { last = 0; break; }
+            row(C1{}, t);
+            if (++t >= t_hi) { last = 1; break; }
+        }
+        // the last row's epilogue
+        {
+            const float xl = bnd_l >= 0 ? xch[last][bnd_l >= 0 ? bnd_l : 0][0][q] * sg : 0.f;
+            const float xr_ = bnd_r >= 0 ? xch[last][bnd_r >= 0 ? bnd_r : 0][1][q] * sg : 0.f;
+            unsigned ob = okbits;
+            asm volatile("" : "+v"(ob));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < nm) {
+                    const f32x4 ylt = BNRED ? yl_tile(i, t_hi - 1) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (wide) { if (last) epi_tile(std::true_type{}, C1{}, i, t_hi - 1, xl, xr_, ob, ylt); else epi_tile(std::true_type{}, C0{}, i, t_hi - 1, xl, xr_, ob, ylt); }
+                    else if (i < 2) { if (last) epi_tile(std::false_type{}, C1{}, i < 2 ? i : 0, t_hi - 1, xl, xr_, ob, ylt); else epi_tile(std::false_type{}, C0{}, i < 2 ? i : 0, t_hi - 1, xl, xr_, ob, ylt); }
+                }
+            }
+        }
+    } else {
     int slot_w = 3, par = 0;
 #ifdef RW_TRACE
     const int rp = wave & 1, ng = wave >> 1;  // (stamp slots: [workgroup][column half][iteration], waves 0 / 1 = channel group 0)
@@ -953,6 +1119,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
         par ^= 1;
         advance();
     }
+    }
 
     // ---- statistics: a column's four 4-row groups, then the column ranges of the group
     {
@@ -982,8 +1149,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows16(RowsArgs a) {
 static int g_conv_rows = -1;
 void a2s_conv_rows_set(int on) { g_conv_rows = on; }
 int a2s_conv_rows_enabled(void) {
-    // bit 0: the row-streaming kernels; bit 1: their second generation (conv3x3_rows16) where it exists (Cout = 40)
-    if (g_conv_rows < 0) { const char* e = getenv("A2S_CONV_ROWS"); g_conv_rows = e ? atoi(e) : 3; }
+    // bit 0: the row-streaming kernels; bit 1: their second generation (conv3x3_rows16) where it exists (Cout = 40); bits 2 / 3: its form with two
+    // accumulator sets (epilogue under the next row's multiply) for the forward / data-gradient launches
+    if (g_conv_rows < 0) { const char* e = getenv("A2S_CONV_ROWS"); g_conv_rows = e ? atoi(e) : 7; }
     return g_conv_rows;
 }
 bool a2s_conv_rows_eligible(int F, int Cin) { return a2s_conv_rows_enabled() && F % 4 == 0 && (Cin == 20 || Cin == 40); }
@@ -1012,7 +1180,11 @@ size_t a2s_conv_rows_workspace_floats(int Cin) {
 template <int CIN, int COUT>
 static int rows16_launch(hipStream_t st, const RowsArgs& a, bool affine, bool bnred, int nwork) {
     constexpr int NT = 512;
-    if (affine) hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, true, false>), dim3(nwork), dim3(NT), 0, st, a);
+    // the two-accumulator-set form (round 6): bit 2 the forward instances, bit 3 the data-gradient instance (24 spilled registers at 40 -> 40)
+    const int en = a2s_conv_rows_enabled();
+    if (affine && (en & 4)) hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, true, false, true>), dim3(nwork), dim3(NT), 0, st, a);
+    else if (affine) hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, true, false>), dim3(nwork), dim3(NT), 0, st, a);
+    else if (bnred && (en & 8)) hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, false, true, true>), dim3(nwork), dim3(NT), 0, st, a);
     else if (bnred) hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, false, true>), dim3(nwork), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_rows16<CIN, COUT, false, false>), dim3(nwork), dim3(NT), 0, st, a);
     A2S_CHECK_LAUNCH("conv3x3_rows16");

@@ -549,7 +549,7 @@ int a2s_gemm_split_enabled(void) { return g_gemm_split; }
 static int g_gemm_f16x2 = -1;
 void a2s_gemm_f16x2_set(int on) { g_gemm_f16x2 = on; }
 int a2s_gemm_f16x2_enabled(void) {
-    if (g_gemm_f16x2 < 0) { const char* e = getenv("A2S_GEMM_F16X2"); g_gemm_f16x2 = e ? atoi(e) : 1; }
+    if (g_gemm_f16x2 < 0) g_gemm_f16x2 = 1;          // (a2s_debug_set("gemm_f16x2", 0) / A2S_ARITH=bf16x3: the three-term bf16 split)
     return g_gemm_f16x2;
 }
 
@@ -593,15 +593,10 @@ static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
         }
     }
     // Occupancy cap of the bulk clip group's per-step products (M >= 256 rows, small tiles) while another clip group decodes beside it
-    // (a2s_attn_bulk_cap_enabled(): the same condition as the attention sweeps' cap): A2S_GEMM_MID_LDS_PAD bytes of unused dynamic LDS per workgroup.
+    // (a2s_attn_bulk_cap_enabled(): the same condition as the attention sweeps' cap): 16 KB of unused dynamic LDS per workgroup.
     // The long-clip chain's kernels wait for a place beside whole grids of these workgroups (profiles/r05_trace_overlap.txt).  Default 16 KB (3 instead of
-    // 4 workgroups of the 64x32 tile per CU): 447.3 -> 443.5 ms per step, 32 KB 445.2 (profiles/r05_prefix_percent.txt); 0 = off.
-    size_t pad = 0;
-    if (BM * BN <= 64 * 64 && g.M >= 256 && a2s_attn_bulk_cap_enabled()) {
-        static long padv = -1;
-        if (padv < 0) { const char* e = getenv("A2S_GEMM_MID_LDS_PAD"); padv = e ? atol(e) : 16384; if (padv < 0 || padv > 32768) padv = 0; }
-        pad = (size_t)padv;
-    }
+    // 4 workgroups of the 64x32 tile per CU): 447.3 -> 443.5 ms per step, 32 KB 445.2 (profiles/r05_prefix_percent.txt).
+    const size_t pad = (BM * BN <= 64 * 64 && g.M >= 256 && a2s_attn_bulk_cap_enabled()) ? 16384 : 0;
     if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), pad, st, g);
     else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), pad, st, g);
     else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), pad, st, g);
@@ -612,12 +607,10 @@ static void launch_cfg(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
 // kernel spends its k-tile period feeding operands into the CU (tools/linear_bench.py trace: 1.3 k clocks issuing the next tile's loads
 // + 2.8 k waiting for them against 1.2 k of multiply): the time goes with the bytes staged per MFMA, and a 256x256 tile stages half.
 static bool big_two_term_ok(const GemmArgs& g, bool akc, bool bkc) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("A2S_GEMM_BIG_TILE"); on = e ? atoi(e) : 1; }
     const bool a_ok = akc || (g.sAm == 1 && g.vecA), b_ok = bkc || (g.sBn == 1 && g.vecB);
     // (the BatchNorm-statistics epilogue keeps its partial layout: a 256-column tile touches at most two channels of period >= 256 and
     // at most as many tiles per channel as the 128-column layout has slots; unused partial rows stay zero)
-    return on && g.two_term && a2s_gemm_f16x2_enabled() && g_gemm_split && (!g.ep_y || g.ep_period >= 256) && g.K >= 128 && a_ok && b_ok && g.M >= 256 && g.N >= 256 &&
+    return g.two_term && a2s_gemm_f16x2_enabled() && g_gemm_split && (!g.ep_y || g.ep_period >= 256) && g.K >= 128 && a_ok && b_ok && g.M >= 256 && g.N >= 256 &&
            (long)a2s_cdiv(g.M, 256) * a2s_cdiv(g.N, 256) * g.batch * g.splitk >= 192;
 }
 static void launch_big_two_term(const GemmArgs& g, bool akc, bool bkc, hipStream_t st) {
@@ -700,13 +693,6 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
         if (mid) {
             const long tiles = (long)a2s_cdiv(M, 64) * a2s_cdiv(N, mid_tile == 2 ? 32 : 64);
             if (ws && tiles < 256 && K >= 512 && a2s_gemm_workspace_bytes_impl(M, N, batch, 4) <= ws_bytes) splitk = 4;
-            else {
-                // measurement switch (A2S_GEMM_MID_SPLITK=n): split K also when the tiles already fill the chip -- a 64x32 tile walks K = 528 as 17
-                // barrier-separated k-tiles of ~3 us each (latency, not work); n shorter walks + one reduce launch
-                static int force = -1;
-                if (force < 0) { const char* e = getenv("A2S_GEMM_MID_SPLITK"); force = e ? atoi(e) : 0; }
-                if (force > 1 && ws && K >= 512 && a2s_gemm_workspace_bytes_impl(M, N, batch, force) <= ws_bytes) splitk = force;
-            }
         } else {
             const long bm = M <= 16 ? 16 : (M <= 32 ? 32 : 64), bn = M <= 64 ? (M <= 16 ? 64 : (M <= 32 ? 64 : 32)) : 64;
             const long tiles = (long)a2s_cdiv(M, bm) * a2s_cdiv(N, bn) * batch;
@@ -754,13 +740,6 @@ int a2s_gemm_affine_impl(hipStream_t st, int M, int N, int K, float alpha, const
     g.vecA = (akc ? (sAk == 1 && aligned(A, sAm, bsA)) : (sAm == 1 && aligned(A, sAk, bsA))) ? 1 : 0;
     g.vecB = (bkc ? (sBk == 1 && aligned(B, sBn, bsB)) : (sBn == 1 && aligned(B, sBk, bsB))) ? 1 : 0;
 
-    {
-        static int log_on = -1;           // A2S_GEMM_LOG=1: one line per large product (which tile path it takes); tools only
-        if (log_on < 0) { const char* e = getenv("A2S_GEMM_LOG"); log_on = e ? atoi(e) : 0; }
-        if (log_on && (long)M * N * K >= (1L << 30))
-            fprintf(stderr, "gemm M=%d N=%d K=%d batch=%d splitk=%d akc=%d bkc=%d two_term=%d big=%d ep=%d\n", M, N, K, batch, splitk, (int)akc, (int)bkc,
-                    two_term, (int)(!g_force_tile && big_two_term_ok(g, akc, bkc)), ep_y != nullptr);
-    }
     if (!g_force_tile && big_two_term_ok(g, akc, bkc)) launch_big_two_term(g, akc, bkc, st);
     else if (ep_y) launch_cfg<128, 128, 2, 2>(g, akc, bkc, st);
     else if (!g_force_tile && mid_tile == 2 && g.splitk >= 1 && M * (long)N < (1L << 22)) launch_cfg<64, 32, 4, 1>(g, akc, bkc, st);

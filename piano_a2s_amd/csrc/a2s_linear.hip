@@ -274,158 +274,8 @@ struct LinFwdArgs {
     int M, K, period;
 };
 
-__global__ __launch_bounds__(LIN_NTH) void lin_fwd(LinFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LF_NS * LF_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-    const int m0 = blockIdx.x * LIN_BM;
-    const int ka = a.a_absmax ? pow2_scale_exp(*a.a_absmax, 12) : 0, kb = pow2_scale_exp(*a.b_absmax, 12);
-    const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kb));
-    const int nks = a.K >> 5, nblk = a.K >> 6, kpc = a.period >> 5;          // k-steps of 32, blocks of 64 (one barrier each), k-steps per channel
-    const bool affine = a.a_scale != nullptr;
-    // staging: item i of a thread = (row, 4 k) of a 64-k block: slot = tid + 512 i -> row = slot >> 4, k = 4 (slot & 15)
-    const int sk = (tid & 15) * 4;
-    const bool second = sk >= 32;                      // which of the block's two k-steps (they may lie in different channels: F % 64 != 0)
-    f32x4 ar[2][4];
-    auto issue_a = [&](int blk, f32x4 (&r)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (tid + LIN_NTH * i) >> 4;
-            r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if defined(LF_X) && (LF_X & 1)        /* timing ablations (-DLF_X= bits: 1 no y4 loads, 2 no conversion / LDS writes, 4 no B loads in the loop, 8 no barrier) */
-            const bool want = m0 + row < a.M && blk < 1;
-#else
-            const bool want = m0 + row < a.M && blk < nblk;
-#endif
-#if defined(LF_X) && (LF_X & 16)       /* 16: the block's 32 KB as ONE contiguous run (same bytes per workgroup, wrong values) */
-            if (want) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)m0 * a.lda + (long)blk * 8192 + (long)(tid + LIN_NTH * i) * 4));
-#else
-            if (want) r[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)(m0 + row) * a.lda + (long)blk * 64 + sk));
-#endif
-        }
-    };
-    // one item (4 k of one row) of block blk: BatchNorm + ReLU + split -> both term images of the block's stage
-    auto commit_item = [&](int blk, int i, const f32x4 (&r)[4]) {
-        if (blk >= nblk) return;
-#if defined(LF_X) && (LF_X & 2)
-        if (blk >= LF_NS) return;
-#endif
-        const int c0 = (2 * blk) / kpc, c1 = (2 * blk + 1) / kpc;
-        const float sc = affine ? (second ? a.a_scale[c1] : a.a_scale[c0]) * psa : psa, sh = affine ? (second ? a.a_shift[c1] : a.a_shift[c0]) * psa : 0.f;
-        const float floor_ = affine ? 0.f : -INFINITY;
-        unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
-        const int row = (tid + LIN_NTH * i) >> 4;
-        float x[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[i][j], sc, sh), floor_), -65000.f, 65000.f);
-        uint2 hi, lo;
-        split2_pair_f16(x[0], x[1], hi.x, lo.x);
-        split2_pair_f16(x[2], x[3], hi.y, lo.y);
-        *reinterpret_cast<uint2*>(st + (0 * LIN_BM + row) * LF_RS + sk * 2) = hi;
-        *reinterpret_cast<uint2*>(st + (1 * LIN_BM + row) * LF_RS + sk * 2) = lo;
-    };
-    auto commit_a = [&](int blk, const f32x4 (&r)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) commit_item(blk, i, r);
-    };
-    // B fragments of block blk: planes + (((nt * nks + ks) * 2 + term) * 64 + lane) * 16, nt = wave * 2 + {0, 1}, ks = 2 blk + {0, 1}
-    lu32x4 bf[2][2][2][2];                             // [ring][k-step of the block][nt][term]
-    auto load_b = [&](int blk, lu32x4 (&dst)[2][2][2]) {
-        if (blk >= nblk) return;
-#if defined(LF_X) && (LF_X & 4)
-        if (blk >= 2) return;
-#endif
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
-                    dst[h][nt][sp] = *reinterpret_cast<const lu32x4*>(a.planes + (((long)(wave * 2 + nt) * nks + 2 * blk + h) * 2 + sp) * 1024 + (unsigned)lane * 16u);
-    };
-    f32x4 acc[8][2];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // block b: activations in ar[b & 1] (issued two iterations before they are committed), B fragments in bf[b & 1]
-    issue_a(0, ar[0]);
-    load_b(0, bf[0]); load_b(1, bf[1]);
-    commit_a(0, ar[0]);
-    issue_a(1, ar[1]); issue_a(2, ar[0]);
-    auto body = [&](int blk, f32x4 (&rnext)[4], lu32x4 (&bcur)[2][2][2]) {
-        if (blk >= nblk) return;
-#if !(defined(LF_X) && (LF_X & 8))
-        __syncthreads();                     // stage blk is complete; stage blk + 1 (= blk - 3) is free
-#endif
-        const unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
-        // four quarters (k-step h, row half): the A fragments of the NEXT quarter are read while this one multiplies -- two waves per SIMD do not
-        // cover the LDS latency of 8 reads in front of every 24 MFMAs (measured: 11.0 -> see the header)
-        auto load_af = [&](int h, int half, lu32x4 (&af)[2][4]) {
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) af[sp][q] = *reinterpret_cast<const lu32x4*>(st + (sp * LIN_BM + (half * 4 + q) * 16 + lr) * LF_RS + h * 64 + lk * 16);
-        };
-        auto multiply = [&](int h, int half, const lu32x4 (&af)[2][4]) {
-#define LF_PRODUCT(SA, SB)                                                                                                       \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                    \
-                    acc[half * 4 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bcur[h][nt][SB]),   \
-                                                                                   __builtin_bit_cast(f16x8, af[SA][q]), acc[half * 4 + q][nt], 0, 0, 0);
-            LF_PRODUCT(1, 0) LF_PRODUCT(0, 1) LF_PRODUCT(0, 0)
-#undef LF_PRODUCT
-        };
-        lu32x4 afa[2][4], afb[2][4];
-        // The two waves of a SIMD run the interval between two barriers in OPPOSITE order: waves 0-3 convert the next block first and multiply
-        // second, waves 4-7 multiply first -- all eight waves leave the barrier together, and with one order for all of them a SIMD's matrix
-        // pipe idles while both of its waves convert (ablation: conversion 2.0 ms + loads 3.5 ms of the 11 ms are such time)
-        auto quarters = [&]() {
-            load_af(0, 0, afa);
-            __builtin_amdgcn_sched_barrier(0);
-            load_af(0, 1, afb); multiply(0, 0, afa);
-            __builtin_amdgcn_sched_barrier(0);
-            load_af(1, 0, afa); multiply(0, 1, afb);
-            __builtin_amdgcn_sched_barrier(0);
-            load_af(1, 1, afb); multiply(1, 0, afa);
-            __builtin_amdgcn_sched_barrier(0);
-            multiply(1, 1, afb);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if (wave < 4) {
-            commit_a(blk + 1, rnext);
-            __builtin_amdgcn_sched_barrier(0);
-            quarters();
-        } else {
-            quarters();
-            commit_a(blk + 1, rnext);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // vector-memory loads complete in order: the B fragments of block blk + 2 (L2 hits) go out BEFORE the y4 loads of block blk + 3 (HBM), and
-        // after those of block blk + 2, which have had two iterations by the time these fragments are waited for
-        load_b(blk + 2, bcur);
-        issue_a(blk + 3, rnext);
-    };
-#pragma unroll 1
-    for (int b0 = 0; b0 < nblk; b0 += 2) {
-        body(b0 + 0, ar[1], bf[0]);
-        body(b0 + 1, ar[0], bf[1]);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int m = m0 + mt * 16 + lr;
-        if (m >= a.M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            f32x4 v = acc[mt][nt];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= unscale;
-            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + wave * 32 + nt * 16 + lk * 4) = v;
-        }
-    }
-}
-
-// ---- the same forward with the two waves of a SIMD in FIXED ROLES (the split of a2s_conv_wrows.hip): waves 0-3 only read fragments and
+// (The symmetric form -- all eight waves stage and multiply, 10.4 ms against 8.2 -- is in the history: round 4, HISTORY.md Part II 3.2.)
+// ---- the forward with the two waves of a SIMD in FIXED ROLES (the split of a2s_conv_wrows.hip): waves 0-3 only read fragments and
 // multiply (128 rows x 64 columns each: 128 accumulators), waves 4-7 only load, convert and write the next stages -- the conversion, the
 // global-load issue and their waits never stand in front of an MFMA.
 __global__ __launch_bounds__(LIN_NTH) void lin_fwd_roles(LinFwdArgs a) {
@@ -572,10 +422,7 @@ int a2s_linear_fwd_impl(hipStream_t st, int M, int N, int K, const float* A, lon
     hipLaunchKernelGGL(lin_pack_planes_k, dim3((unsigned)(((long)N * (K / 8) + 255) / 256)), dim3(256), 0, st, W, (long)K, N, K, w_absmax, planes);
     A2S_CHECK_LAUNCH("lin_pack_planes_k");
     LinFwdArgs a{A, lda, planes, C, ldc, a_scale, a_shift, a_absmax, w_absmax, M, K, a_scale ? period : K};
-    static int roles = -1;                    // A2S_LINEAR_ROLES=0: all eight waves stage and multiply (lin_fwd)
-    if (roles < 0) { const char* e = getenv("A2S_LINEAR_ROLES"); roles = e ? atoi(e) : 1; }
-    if (roles) hipLaunchKernelGGL(lin_fwd_roles, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
-    else hipLaunchKernelGGL(lin_fwd, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
+    hipLaunchKernelGGL(lin_fwd_roles, dim3((M + LIN_BM - 1) / LIN_BM), dim3(LIN_NTH), 0, st, a);
     A2S_CHECK_LAUNCH("lin_fwd");
     return A2S_OK;
 }
@@ -624,143 +471,7 @@ __global__ __launch_bounds__(256) void lin_pack_dz_planes(const float* __restric
     *reinterpret_cast<lu32x4*>(o + 64 * 16) = lo;
 }
 
-__global__ __launch_bounds__(LIN_NTH) void lin_wgrad(LinWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LF_NS * LF_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
-    const int k0 = blockIdx.x * LIN_BM;                       // 128 columns
-    const int b_lo = blockIdx.y * a.blk_per_split, b_hi = min(a.nblk, b_lo + a.blk_per_split);
-    const int ka = a.a_absmax ? pow2_scale_exp(*a.a_absmax, 12) : 0, kd = pow2_scale_exp(*a.d_absmax, 12);
-    const float psa = ldexpf(1.f, ka), unscale = ldexpf(1.f, -(ka + kd));
-    const bool affine = a.a_scale != nullptr;
-    // staging: a thread owns rows 4 rq .. + 3 x columns 4 cq .. + 3 of a 64-row block; its columns lie in one channel (period % 4 == 0).  The 16
-    // lanes rq = 0 .. 15 of a column quad write the 128 bytes of one stage row: 10 LDS clocks per wave-level 8-byte store; with the column quad
-    // in the low lane bits (512-byte runs for the global loads) the stores hit two bank groups: 32 clocks (tools/ubench/b128_read.hip)
-    const int rq = tid & 15, cq = tid >> 4;
-    const int ch = affine ? (k0 + 4 * cq) / a.period : 0;
-    const float sc = affine ? a.a_scale[ch] * psa : psa, sh = affine ? a.a_shift[ch] * psa : 0.f, floor_ = affine ? 0.f : -INFINITY;
-    f32x4 ar[2][4];
-    auto issue_a = [&](int blk, f32x4 (&r)[4]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = blk * 64 + 4 * rq + j;
-            r[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (m < a.M && blk < b_hi) r[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + 4 * cq));
-        }
-    };
-    auto commit_a = [&](int blk, const f32x4 (&r)[4]) {
-        if (blk >= b_hi) return;
-        unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                          // column 4 cq + c: rows 4 rq .. + 3 are 4 consecutive "k" of the stage row
-            float x[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(fmaxf(fmaf(r[j][c], sc, sh), floor_), -65000.f, 65000.f);
-            uint2 hi, lo;
-            split2_pair_f16(x[0], x[1], hi.x, lo.x);
-            split2_pair_f16(x[2], x[3], hi.y, lo.y);
-            *reinterpret_cast<uint2*>(st + (0 * LIN_BM + 4 * cq + c) * LF_RS + rq * 8) = hi;
-            *reinterpret_cast<uint2*>(st + (1 * LIN_BM + 4 * cq + c) * LF_RS + rq * 8) = lo;
-        }
-    };
-    // dz fragments of block blk: steps 2 blk + {0, 1}, n-tiles wave * 2 + {0, 1}
-    lu32x4 df[2][2][2][2];                             // [ring][step of the block][nt][term]
-    auto load_d = [&](int blk, lu32x4 (&dst)[2][2][2]) {
-        if (blk >= b_hi) return;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
-                    dst[h][nt][sp] = *reinterpret_cast<const lu32x4*>(a.planes + ((((long)(2 * blk + h)) * 16 + wave * 2 + nt) * 2 + sp) * 1024 + (unsigned)lane * 16u);
-    };
-    f32x4 acc[8][2];
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bool neg = false;
-    auto flip = [&]() {
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[kt][nt][r] = -acc[kt][nt][r];
-    };
-    if (b_lo < b_hi) {
-        issue_a(b_lo, ar[0]);
-        load_d(b_lo, df[0]); load_d(b_lo + 1, df[1]);
-        commit_a(b_lo, ar[0]);
-        issue_a(b_lo + 1, ar[1]); issue_a(b_lo + 2, ar[0]);
-    }
-    // block b (relative index i = b - b_lo): activations in ar[i & 1], dz fragments in df[i & 1]
-    auto body = [&](int blk, f32x4 (&rnext)[4], lu32x4 (&dcur)[2][2][2]) {
-        if (blk >= b_hi) return;
-        const bool want = ((2 * blk) >> 3) & 1;                // sign of this block's steps in the planes (both steps of a block share it)
-        if (want != neg) { flip(); neg = want; }
-        __syncthreads();
-        const unsigned char* st = lds + (blk % LF_NS) * LF_STAGE;
-        auto load_bf = [&](int h, int half, lu32x4 (&bfr)[2][4]) {
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bfr[sp][q] = *reinterpret_cast<const lu32x4*>(st + (sp * LIN_BM + (half * 4 + q) * 16 + lr) * LF_RS + h * 64 + lk * 16);
-        };
-        auto multiply = [&](int h, int half, const lu32x4 (&bfr)[2][4]) {
-#define LW_PRODUCT(SX, SD)                                                                                                        \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                      \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                     \
-                    acc[half * 4 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bfr[SX][q]),         \
-                                                                                   __builtin_bit_cast(f16x8, dcur[h][nt][SD]), acc[half * 4 + q][nt], 0, 0, 0);
-            LW_PRODUCT(1, 0) LW_PRODUCT(0, 1) LW_PRODUCT(0, 0)
-#undef LW_PRODUCT
-        };
-        lu32x4 fa[2][4], fb[2][4];
-        auto quarters = [&]() {
-            load_bf(0, 0, fa);
-            __builtin_amdgcn_sched_barrier(0);
-            load_bf(0, 1, fb); multiply(0, 0, fa);
-            __builtin_amdgcn_sched_barrier(0);
-            load_bf(1, 0, fa); multiply(0, 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            load_bf(1, 1, fb); multiply(1, 0, fa);
-            __builtin_amdgcn_sched_barrier(0);
-            multiply(1, 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if (wave < 4) {                                        // (opposite phase order of the two waves of a SIMD: see lin_fwd)
-            commit_a(blk + 1, rnext);
-            __builtin_amdgcn_sched_barrier(0);
-            quarters();
-        } else {
-            quarters();
-            commit_a(blk + 1, rnext);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        load_d(blk + 2, dcur);
-        issue_a(blk + 3, rnext);
-    };
-#pragma unroll 1
-    for (int b = b_lo; b < b_hi; b += 2) {
-        body(b + 0, ar[1], df[0]);
-        body(b + 1, ar[0], df[1]);
-    }
-    if (neg) flip();
-    // lane (lr, lk) of tile (kt, nt) owns G[n = 32 wave + 16 nt + lr][k0 + 16 kt + 4 lk .. + 3]
-    float* slab = a.partial + (long)blockIdx.y * 256 * a.K;
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            f32x4 v = acc[kt][nt];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= unscale;
-            *reinterpret_cast<f32x4*>(slab + (long)(wave * 32 + nt * 16 + lr) * a.K + k0 + kt * 16 + lk * 4) = v;
-        }
-}
-
-// ---- the same with fixed wave roles (see lin_fwd_roles): waves 0-3 multiply (128 columns x 64 n each: 128 accumulators), waves 4-7 stage
+// ---- fixed wave roles (see lin_fwd_roles; the symmetric form, 11.05 ms against 10.1, is in the history): waves 0-3 multiply (128 columns x 64 n each: 128 accumulators), waves 4-7 stage
 __global__ __launch_bounds__(LIN_NTH) void lin_wgrad_roles(LinWgradArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LF_NS * LF_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
@@ -950,10 +661,7 @@ int a2s_linear_wgrad_impl(hipStream_t st, int M, int N, int K, const float* dz, 
     hipLaunchKernelGGL(lin_pack_dz_planes, dim3((unsigned)(((long)nsteps * 1024 + 255) / 256)), dim3(256), 0, st, dz, ldz, M, nsteps, dz_absmax, planes);
     A2S_CHECK_LAUNCH("lin_pack_dz_planes");
     LinWgradArgs a{A, lda, planes, partial, a_scale, a_shift, a_absmax, dz_absmax, M, K, a_scale ? period : K, nblk, (nblk + splits - 1) / splits};
-    static int roles = -1;                    // A2S_LINEAR_ROLES=0: all eight waves stage and multiply (lin_wgrad)
-    if (roles < 0) { const char* e = getenv("A2S_LINEAR_ROLES"); roles = e ? atoi(e) : 1; }
-    if (roles) hipLaunchKernelGGL(lin_wgrad_roles, dim3(K / LIN_BM, splits), dim3(LIN_NTH), 0, st, a);
-    else hipLaunchKernelGGL(lin_wgrad, dim3(K / LIN_BM, splits), dim3(LIN_NTH), 0, st, a);
+    hipLaunchKernelGGL(lin_wgrad_roles, dim3(K / LIN_BM, splits), dim3(LIN_NTH), 0, st, a);
     A2S_CHECK_LAUNCH("lin_wgrad");
     const long n = 256L * K;
     hipLaunchKernelGGL(lin_wgrad_reduce, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, partial, splits, n, G, ldg, K);

@@ -247,7 +247,7 @@ int a2s_skinny_gemm_acc_impl(hipStream_t st, const float* A, long lda, const flo
 static int g_gru_fused = -1;                                 // A2S_GRU_FUSED=0 / a2s_debug_set("gru_fused", 0): the three-launch step (A/B measurements)
 void a2s_gru_step_fused_set(int v) { g_gru_fused = v ? 1 : 0; }
 bool a2s_gru_step_fused_enabled(void) {
-    if (g_gru_fused < 0) { const char* e = getenv("A2S_GRU_FUSED"); g_gru_fused = (e && e[0] == '0') ? 0 : 1; }
+    if (g_gru_fused < 0) g_gru_fused = 1;
     return g_gru_fused != 0;
 }
 static bool gru_step_fusable(const float* w_hh, int H) { return a2s_gru_step_fused_enabled() && H % 16 == 0 && ((uintptr_t)w_hh % 16 == 0); }
@@ -519,7 +519,7 @@ bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, i
 int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int t, const int* t_base, int tf, bool last,
                             int nrows, const int* rowmap, const a2s_attn_deferred* defer = nullptr);
 bool a2s_note_step_mid_ok(int H, int E, const void* const* ptrs, int nptrs);
-int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int nrows, const int* rowmap);
+int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int nrows, const int* rowmap);
 // rows the fused step of step t would cover: all R, or (training, finished rows skipped) the rows still running, a prefix of row_list
 static int note_step_rows(const NoteDecArgs& a, int t) { return (a.row_list && a.n_rows_active && t >= 0) ? a.n_rows_active[t] : a.R; }
 static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
@@ -527,7 +527,12 @@ static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
     const int n = note_step_rows(a, t);
     return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, a.V, ptrs, 8, a.step_ws, a.step_ws_floats, a.gt == nullptr && !a.gates);
 }
-// q of slot `sv` from the state in slot `si` (the fused path computes every later query in the previous step's last launch)
+// the launch-per-step loop's steps on the mid-size kernels (round 6)?  Not in graph-replay mode: its captured chunk computes the query at the start of a step
+static bool note_step_mid(const NoteDecArgs& a, const int* t_base) {
+    const void* ptrs[] = {a.x, a.h, a.o, a.q, a.w_ih, a.w_hh, a.out_w, a.attn_w};
+    return !t_base && a2s_note_step_mid_ok(a.H, a.E, ptrs, 8);
+}
+// q of slot `sv` from the state in slot `si` (the fused and the mid-size paths compute every later query in the previous step's last launch)
 static int enqueue_query(hipStream_t st, const NoteDecArgs& a, int si, int sv) {
     const int H2 = 2 * a.H;
     return a2s_gemm_impl(st, a.R, a.H, H2, 1.f, a.h + (long)si * a.R * H2, H2, 1, a.attn_w, 1, 2 * H2, 0.f, a.q + (long)sv * a.R * a.H, a.H, a.attn_b, 0, 1, 0,
@@ -567,39 +572,39 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
     int rc;
     a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : a.R, a.n_active ? a.n_active[t] : 0, t};
     const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
-    // round 6: the GRU cell of the step -- gh, gi and the gate kernel -- as ONE launch behind the attention (dec_gru_mid, a2s_step.hip), over the
-    // rows still running
-    const void* mid_ptrs[] = {a.x, a.h, a.w_ih, a.w_hh};
-    const bool mid = a2s_note_step_mid_ok(a.H, a.E, mid_ptrs, 4);
+    if (note_step_mid(a, t_base)) {
+        // round 6 (a2s_step.hip): the query of slot sv is already there (enqueue_query / the previous step, as on the few-row path); behind the
+        // attention ONE launch for the GRU cell (dec_gru_mid: gh, gi, gates) and ONE for the logits and the next step's query (dec_outq_mid), over
+        // the rows still running
+        rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
+                                    a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws, rows);
+        if (rc) return rc;
+        const int nrows = note_step_rows(a, t);
+        rc = a2s_note_step_mid_gru(st, a, si, so, sv, last ? -1 : sv_next, nrows, nrows < a.R ? a.row_list : nullptr);
+        if (rc) return rc;
+    } else {
     // q = h W_h^T + b   (W = [W_h | W_e], W_h = first 2H columns of the (H, 4H) matrix)
     rc = a2s_gemm_impl(st, gM, a.H, H2, 1.f, hp, H2, 1, a.attn_w, 1, 2 * H2, 0.f, qs, a.H, a.attn_b, 0, gB, gS * H2, 0, gS * a.H, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
-    if (!mid) {
-        // gh = h W_hh^T + b_hh
-        rc = a2s_gemm_impl(st, gM, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, gB, gS * H2, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
-    }
+    // gh = h W_hh^T + b_hh
+    rc = a2s_gemm_impl(st, gM, 3 * H2, H2, 1.f, hp, H2, 1, a.w_hh, 1, H2, 0.f, a.gh, 3 * H2, a.b_hh, 0, gB, gS * H2, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
+    if (rc) return rc;
     // attention -> ctx into x[si][:, E:] and o[sv][:, 2H:]
     rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
                                 a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws,
                                 rows);
     if (rc) return rc;
-    if (mid) {
-        const int nrows = note_step_rows(a, t_base ? -1 : t);
-        rc = a2s_note_step_mid_gru(st, a, si, so, sv, nrows, nrows < a.R ? a.row_list : nullptr);
-        if (rc) return rc;
-    } else {
-        // gi = x W_ih^T + b_ih
-        rc = a2s_gemm_impl(st, gM, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, gB, gS * ldx, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
-        // h' -> h[so] and o[sv][:, :2H]
-        rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
-                                    a.gates ? a.gates + (long)sv * a.R * 4 * H2 : nullptr, a.R, H2);
-        if (rc) return rc;
-    }
+    // gi = x W_ih^T + b_ih
+    rc = a2s_gemm_impl(st, gM, 3 * H2, ldx, 1.f, xs, ldx, 1, a.w_ih, 1, ldx, 0.f, a.gi, 3 * H2, a.b_ih, 0, gB, gS * ldx, 0, gS * 3 * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
+    if (rc) return rc;
+    // h' -> h[so] and o[sv][:, :2H]
+    rc = a2s_gru_gates_fwd_impl(st, a.gi, 3 * H2, a.gh, 3 * H2, hp, H2, hq, H2, os, 2 * H2,
+                                a.gates ? a.gates + (long)sv * a.R * 4 * H2 : nullptr, a.R, H2);
+    if (rc) return rc;
     // logits = o W_out^T + b_out
     rc = a2s_gemm_impl(st, gM, a.V, 2 * H2, 1.f, os, 2 * H2, 1, a.out_w, 1, 2 * H2, 0.f, a.logits, a.V, a.out_b, 0, gB, gS * 2 * H2, 0, gS * a.V, 0, a.gemm_ws, a.gemm_ws_bytes);
     if (rc) return rc;
+    }
     StepFinArgs f;
     f.logits = a.logits; f.ldl = a.V; f.probs = a.probs; f.probs_bstride = a.probs_bstride;
     f.gt = a.gt; f.gt_bstride = a.gt_bstride; f.emb = a.emb;
@@ -678,11 +683,12 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
     // The few-row step kernels take over as soon as the rows still running fit them (the whole call when it is small; the tail of a large
     // training call otherwise: the handful of full-length rows then decode in 4 launches per step instead of 12 over every row).  The
     // first fused step finds no query left behind by a fused predecessor: it is computed for all rows first.
-    bool prev_fused = false;
+    bool prev_q = false;                     // did the previous step leave this step's query behind?
+    const bool mid = note_step_mid(a, nullptr);
     for (; s < a.steps; ++s) {
         const bool fused = note_step_fusable(a, s);
-        if (fused && !prev_fused) { int rc = enqueue_query(st, a, s, s); if (rc) return rc; }
-        prev_fused = fused;
+        if ((fused || mid) && !prev_q) { int rc = enqueue_query(st, a, s, s); if (rc) return rc; }
+        prev_q = fused || mid;
         int rc = enqueue_note_step(st, a, s, s + 1, s, s, nullptr, a.tf_flags ? a.tf_flags[s] : 0, fused, s + 1, s + 1 == a.steps);
         if (rc) return rc;
         if (!a.gt && a.poll > 0 && ((s + 1) % a.poll == 0) && s + 1 < a.steps) {
@@ -701,7 +707,7 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
 static int g_staff_emb_fast = -1;       // the E = 16, S = 32 kernels (A2S_STAFF_EMB_FAST=0 / a2s_debug_set("staff_emb_fast", 0): the generic ones)
 void a2s_staff_emb_fast_set(int v) { g_staff_emb_fast = v ? 1 : 0; }
 int a2s_staff_emb_fast_enabled(void) {
-    if (g_staff_emb_fast < 0) { const char* e = getenv("A2S_STAFF_EMB_FAST"); g_staff_emb_fast = (e && e[0] == '0') ? 0 : 1; }
+    if (g_staff_emb_fast < 0) g_staff_emb_fast = 1;
     return g_staff_emb_fast;
 }
 // reference get_staff_token_* (models.py:164-189): packed bi-GRU (E -> S) final states.  One workgroup per
@@ -1298,14 +1304,14 @@ __global__ __launch_bounds__(512) void attn_fwd_split256_deep(const float* __res
 static int g_attn_deep = -1;
 void a2s_attn_deep_set(int v) { g_attn_deep = v < 0 ? 0 : v; }
 int a2s_attn_deep_max_clips(void) {
-    if (g_attn_deep < 0) { const char* e = getenv("A2S_ATTN_DEEP"); g_attn_deep = e ? atoi(e) : 24; if (g_attn_deep < 0) g_attn_deep = 0; }
+    if (g_attn_deep < 0) g_attn_deep = 24;          // launches over at most this many active clips (a2s_debug_set("attn_deep", n))
     return g_attn_deep;
 }
-// Combine of the few-clip training launches folded into the GRU step (A2S_ATTN_DEFER_COMBINE=0 / a2s_debug_set("attn_defer_combine", 0): off)
+// Combine of the few-clip training launches folded into the GRU step (a2s_debug_set("attn_defer_combine", 0): off)
 static int g_attn_defer = -1;
 void a2s_attn_defer_combine_set(int v) { g_attn_defer = v ? 1 : 0; }
 int a2s_attn_defer_combine_enabled(void) {
-    if (g_attn_defer < 0) { const char* e = getenv("A2S_ATTN_DEFER_COMBINE"); g_attn_defer = (e && e[0] == '0') ? 0 : 1; }
+    if (g_attn_defer < 0) g_attn_defer = 1;
     return g_attn_defer;
 }
 template <int NQ>
@@ -1316,55 +1322,6 @@ static void launch_fwd_deep(hipStream_t st, int nwg, const float* Kmat, const fl
                        r.n_clips);
 }
 
-// ------------------------------------------------------------------------------------------- the bandwidth token of the bulk attention launches
-// Round 5.  The two staves of a clip group run their step loops on two streams.  A decode step is  A  (the attention sweep: HBM-bound, ~150 us
-// over 248 clips) followed by  S  (the step's small dependent kernels: ~130-200 us).  Left alone the two streams fall INTO phase -- two
-// sweeps that overlap share the bandwidth, so they end together, then both streams sit in S with the memory idle: the period is A_up + A_lo + S
-// (profiles/r04_trace_overlap.txt: 280 us of overlapping sweeps + 110-200 us of S on both queues at once).  With the sweeps mutually exclusive
-// the streams fall OUT of phase by themselves -- one sweeps at full bandwidth while the other is in S -- and the period is max(A_up + A_lo, A + S).
-// Exclusion is done on the device, so that it follows the GPU's progress and not the order in which the host threads happen to issue: a
-// one-wave gate kernel in front of a heavy sweep spins (bounded) until it has swapped the token word 0 -> 1; the sweep's combine kernel, which
-// follows it on the stream, puts 0 back before it does anything else.  Light launches (< `min_clips` active clips: the few-row tails, the
-// long-clip group) neither take nor wait for the token.
-// MEASURED (profiles/r05_attn_pace_ab.txt, B = 256, 6 pairs of steps with the same coins): no gain -- 444.2 -> 448.5 ms with the 1 % tail,
-// 444.3 -> 450.9 without.  The small kernels of S run 2-3x slower while a sweep saturates the memory (as the long-clip chain's do: DESIGN.md
-// section 3.4), so S under the other stream's sweep costs what the overlap saves; the in-phase convoy, where both streams' S phases run on an
-// idle memory system, is as good an equilibrium.  OFF by default; A2S_ATTN_PACE=1 / a2s_debug_set("attn_pace", 1) switches it on.
-__device__ unsigned g_pace_token = 0;
-__global__ void attn_pace_gate(unsigned* token, unsigned limit) {
-    if (threadIdx.x == 0) {
-        unsigned n = 0;
-        while (atomicCAS(token, 0u, 1u) != 0u && ++n < limit) __builtin_amdgcn_s_sleep(24);       // ~0.7 us per poll; limit: a few ms, then go anyway
-    }
-}
-__global__ void attn_pace_release(unsigned* token) { if (threadIdx.x == 0) atomicExch(token, 0u); }
-static int g_attn_pace = -1, g_attn_pace_min = -1;
-void a2s_attn_pace_set(int v) { g_attn_pace = v ? 1 : 0; }
-int a2s_attn_pace_enabled(void) {
-    if (g_attn_pace < 0) { const char* e = getenv("A2S_ATTN_PACE"); g_attn_pace = (e && e[0] == '1') ? 1 : 0; }
-    return g_attn_pace;
-}
-void a2s_attn_pace_min_set(int v) { g_attn_pace_min = v > 0 ? v : 1; }
-int a2s_attn_pace_min(void) {
-    if (g_attn_pace_min < 0) { const char* e = getenv("A2S_ATTN_PACE_MIN"); g_attn_pace_min = e ? atoi(e) : 64; if (g_attn_pace_min < 1) g_attn_pace_min = 1; }
-    return g_attn_pace_min;
-}
-// Gate in front of a sweep over n_active clips.  Returns the token's device address when the launch holds the token afterwards (the caller
-// hands it to its combine kernel, or calls a2s_attn_pace_release_impl), else null.
-unsigned* a2s_attn_pace_gate_impl(hipStream_t st, int n_active) {
-    if (!a2s_attn_pace_enabled() || n_active < a2s_attn_pace_min()) return nullptr;
-    static unsigned* token = nullptr;
-    if (!token) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pace_token)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        token = reinterpret_cast<unsigned*>(p);
-    }
-    hipLaunchKernelGGL(attn_pace_gate, dim3(1), dim3(64), 0, st, token, 6000u);
-    return token;
-}
-void a2s_attn_pace_release_impl(hipStream_t st, unsigned* token) {
-    if (token) hipLaunchKernelGGL(attn_pace_release, dim3(1), dim3(64), 0, st, token);
-}
 
 // merge the G partials of a row: ctx = sum_g ctx_g e^{m_g-m} / l ; optional normalisation of the saved weights.  One workgroup per
 // row (= group * n_clips + clip); rows that are skipped this step get zeros.
@@ -1372,8 +1329,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine256(const float* __restri
                                                            float* __restrict__ ctx2, long ldctx2, float* __restrict__ attw, int T, int G,
                                                            const int* __restrict__ n_done, int n_rows_total,
                                                            const int* __restrict__ clip_rank, const int* __restrict__ row_until,
-                                                           int n_clips, int groups, int n_active, int step, unsigned* __restrict__ pace_token) {
-    if (pace_token && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(pace_token, 0u);       // the sweep in front of this launch is over: next sweep, please
+                                                           int n_clips, int groups, int n_active, int step) {
     if (n_done && *n_done >= n_rows_total) return;
     constexpr int H = 256;
     const int b = blockIdx.x;
@@ -1406,13 +1362,13 @@ size_t a2s_attn_workspace_floats_impl(int B, int T, int H, int groups) {
 static int g_attn_fused_combine = -1;
 void a2s_attn_fused_combine_set(int v) { g_attn_fused_combine = v < 0 ? 0 : v; }      // 0 never, 1 always, n >= 2: launches over at most n clips
 int a2s_attn_fused_combine_enabled(void) {
-    if (g_attn_fused_combine < 0) { const char* e = getenv("A2S_ATTN_FUSED_COMBINE"); g_attn_fused_combine = e ? (atoi(e) < 0 ? 0 : atoi(e)) : 0; }
+    if (g_attn_fused_combine < 0) g_attn_fused_combine = 0;
     return g_attn_fused_combine;
 }
 static int g_attn_nt = -1;
 void a2s_attn_nt_set(int v) { g_attn_nt = v < 0 ? 0 : v; }
 int a2s_attn_nt_enabled(void) {
-    if (g_attn_nt < 0) { const char* e = getenv("A2S_ATTN_NT"); g_attn_nt = e ? atoi(e) : 64; if (g_attn_nt < 0) g_attn_nt = 0; }      // default: launches over >= 64 clips
+    if (g_attn_nt < 0) g_attn_nt = 64;      // launches over >= 64 clips
     return g_attn_nt;
 }
 // Occupancy cap of the bulk launches.  A launch over >= 64 clips asks for at least this much LDS -- 64 KB forward (2 workgroups per CU),
@@ -1421,33 +1377,18 @@ int a2s_attn_nt_enabled(void) {
 // memory), and the long-clip group's chain of short dependent kernels -- the step's critical path -- pays that latency several times per
 // decode step.  Measured (profiles/r04_attn_occupancy_cap.txt, B = 256, same box): forward launch alone 155 -> 159 us at 2 per CU, backward
 // 152 -> 203 us (hence 5 there); in the step the long-clip group finishes 11 ms earlier, the bulk group 8 ms later, the step 507 -> 498 ms.
-// A2S_ATTN_BULK_LDS / A2S_ATTN_BULK_LDS_BWD = bytes (0: no cap).  The cap only pays while ANOTHER clip group decodes beside the bulk one: the host
-// switches it on for exactly those passes (a2s_debug_set("attn_bulk_cap", 1); off by default: greedy decoding of 256 clips 495 -> 468 clips/s with it).
+// The cap only pays while ANOTHER clip group decodes beside the bulk one: the host switches it on for exactly those passes
+// (a2s_debug_set("attn_bulk_cap", 1); off by default: greedy decoding of 256 clips 495 -> 468 clips/s with it).  The sizes were swept in rounds 4-6
+// (profiles/r04_attn_occupancy_cap.txt, r05_prefix_percent.txt, r06_cap_sweep.txt: flat within +-2 ms around these values; ONE forward workgroup
+// per CU -- 80 KB and more -- loses 5-10 ms).
 static int g_attn_bulk_cap = 0;
-void a2s_attn_bulk_cap_set(int on) { g_attn_bulk_cap = on < 0 ? 0 : (on > 2 ? 2 : on); }      // 0 off, 1 the caps below, 2 forward launches at A2S_ATTN_BULK_LDS_STRONG (one per CU)
+void a2s_attn_bulk_cap_set(int on) { g_attn_bulk_cap = on > 0 ? 1 : 0; }
 int a2s_attn_bulk_cap_enabled(void) { return g_attn_bulk_cap; }
 size_t a2s_attn_bulk_lds(size_t shm, int n_active, int backward) {
     if (!g_attn_bulk_cap) return shm;
-    // kind: 0 forward single row, 1 backward single row, 2 forward fused bars, 3 backward fused bars (backward & 2: fused bars)
-    static long cap[4] = {-1, -1, -1, -1};
-    if (cap[0] < 0) {
-        const char* e = getenv("A2S_ATTN_BULK_LDS");
-        const char* b = getenv("A2S_ATTN_BULK_LDS_BWD");
-        const char* m = getenv("A2S_ATTN_BULK_LDS_MQ");
-        const char* mb = getenv("A2S_ATTN_BULK_LDS_MQ_BWD");
-        cap[0] = e ? atol(e) : 65536;
-        // (round 5: 28 KB instead of 32 -- still 5 workgroups per CU, but 17 KB of LDS stay free on every CU: with 5 x 32 KB the long-clip chain's
-        // kernels, which all need 8-16 KB for their cross-wave reduction, could only start where a bulk workgroup had just left; the chain's backward
-        // step period was twice the sum of its kernels' durations (profiles/r05_trace_overlap.txt).  452.3 -> 449.5 ms per step, profiles/r05_prefix_percent.txt)
-        cap[1] = b ? atol(b) : (e ? atol(e) : 28672);
-        cap[2] = m ? atol(m) : cap[0];
-        cap[3] = mb ? atol(mb) : cap[1];
-        // (forward caps may exceed 64 KB -- ONE workgroup per CU above 80 KB: the launchers raise the kernels' dynamic-LDS limit; backward stays <= 64 KB)
-        for (int i = 0; i < 4; ++i) { const long lim = (i == 0 || i == 2) ? 98304 : 65536; cap[i] = cap[i] < 0 ? 0 : (cap[i] > lim ? lim : cap[i]); }
-    }
-    static long strong = -1;
-    if (strong < 0) { const char* e = getenv("A2S_ATTN_BULK_LDS_STRONG"); strong = e ? atol(e) : 81920; if (strong < 0) strong = 0; if (strong > 98304) strong = 98304; }
-    const size_t c = (g_attn_bulk_cap == 2 && (backward & 1) == 0 && strong > 0) ? (size_t)strong : (size_t)cap[backward & 3];
+    // forward 64 KB: 2 workgroups per CU.  Backward 28 KB: 5 per CU with 17 KB of LDS left free on every CU -- with 5 x 32 KB the long-clip chain's
+    // kernels, which all need 8-16 KB for their cross-wave reduction, could only start where a bulk workgroup had just left (round 5: 452.3 -> 449.5 ms)
+    const size_t c = (backward & 1) ? 28672 : 65536;
     return (n_active >= 64 && c > shm) ? c : shm;
 }
 template <int NQ>
@@ -1470,7 +1411,6 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     A2S_REQUIRE(ldq % 4 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)Kmat % 16 == 0) && ((uintptr_t)enc % 16 == 0), "attn_step_fwd_split: 16-byte alignment");
     a2s_attn_rows r = {nullptr, nullptr, nullptr, B, B, 0};
     if (rows) r = *rows;
-    T = a2s_attn_fake_t(T, r.n_clips);
     A2S_REQUIRE(r.n_clips > 0 && B % r.n_clips == 0, "attn_step_fwd_split: rows (%d) must be a multiple of the clips (%d)", B, r.n_clips);
     const int groups = B / r.n_clips;
     A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_fwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);
@@ -1491,7 +1431,6 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     // streaming (non-temporal) K / enc loads when many clips are active: the sweep is far larger than any cache, and the lines of a
     // concurrently decoding few-clip group (its K / enc and its weights) then survive in L2 / Infinity Cache (A2S_ATTN_NT)
     const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled();
-    unsigned* pace_token = r.n_active > 0 ? a2s_attn_pace_gate_impl(st, r.n_active) : nullptr;       // (greedy decoding: the combine releases it even when the step is a no-op)
     if (r.n_active > 0 || n_zero > 0) {
         // the grid covers the clips that still have unfinished rows, re-split so that it still fills the chip
         if (r.n_active > 0) a2s_attn_split_geometry(r.n_active, T, &G, &chunk);
@@ -1523,14 +1462,14 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
         }
         A2S_CHECK_LAUNCH("attn_fwd_split256");
     }
-    if (fused) { a2s_attn_pace_release_impl(st, pace_token); return A2S_OK; }
+    if (fused) return A2S_OK;
     // the few-clip launches of a training step leave the combine to the GRU step that consumes the contexts (a2s_step.hip: dec_gru_step_cmb)
-    if (defer && !n_done && !pace_token && r.n_active > 0 && r.n_active <= a2s_attn_deep_max_clips() && groups <= 4 && G <= 16 && a2s_attn_defer_combine_enabled()) {
+    if (defer && !n_done && r.n_active > 0 && r.n_active <= a2s_attn_deep_max_clips() && groups <= 4 && G <= 16 && a2s_attn_defer_combine_enabled()) {
         *defer = a2s_attn_deferred{part, attw, r.clip_rank, r.row_until, G, groups, r.n_clips, r.n_active, r.step, T};
         return A2S_OK;
     }
     hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, part, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total,
-                       r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step, pace_token);
+                       r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step);
     A2S_CHECK_LAUNCH("attn_fwd_combine256");
     return A2S_OK;
 }

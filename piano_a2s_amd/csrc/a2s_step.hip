@@ -31,8 +31,7 @@ int a2s_attn_step_fwd_impl(hipStream_t st, const float* Kmat, const float* enc, 
                            float* ws, const a2s_attn_rows* rows, a2s_attn_deferred* defer = nullptr);
 int a2s_attn_step_bwd_impl(hipStream_t st, const float* Kmat, const float* enc, const float* q, long ldq, const float* v,
                            const float* attw, const float* ctx, long ldctx, const float* dctx_a, long ldda, const float* dctx_b, long lddb,
-                           float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws, const a2s_attn_rows* rows,
-                           a2s_attn_deferred_bwd* defer = nullptr);
+                           float* dctx_out, long lddo, float* dq, long lddq, float* ds_out, int B, int T, int H, float* ws, const a2s_attn_rows* rows);
 int a2s_gru_gates_bwd_impl(hipStream_t st, const float* dh_a, long lda, const float* dh_b, long ldb, const float* save,
                            const float* hprev, long ldhp, float* dgi, long ldgi, float* dgh, long ldgh, float* dgh2, long ldgh2,
                            float* dhprev, long lddp, int R, int H);
@@ -663,34 +662,19 @@ __global__ __launch_bounds__(64 * DEC_NW_PROD) void dec_bwd_products(DecBwdProdA
 }
 
 
-// The same two products for hundreds of rows (round 6; the skeleton of dec_gru_mid): a workgroup owns 64 rows x 32 columns of dx (role A) or dh
-// (role B), wave w rows 16 w .. 16 w + 15 for all of K = 3 H2; the 32 transposed-weight rows of a 64-wide k-chunk are staged once per workgroup
-// in LDS, the gradient rows come straight from memory.  Replaces, in the bulk clip group's backward decode step, the dx product in front of
-// the attention sweep and the dh product behind it (two 64 x 32-tile launches of 30-50 us each in the step) by one launch in front of it.
-__global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
-    __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int R = a.R, K = 3 * a.H2, row0 = blockIdx.y * 64 + wave * 16;
-    const bool role_a = (int)blockIdx.x < a.nxa;
-    const int n0 = (role_a ? blockIdx.x : blockIdx.x - a.nxa) * 32;
-    const int ncols = role_a ? a.kx : a.H2;
-    const float* const Bt = role_a ? a.wih_t : a.whh_t;
-    const int nc = K / MID_KC;                            // (H2 % 64 == 0 is part of the eligibility test)
-    float c0[2][4];
-    if (!role_a) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
-    }
-    const float* const ar = (role_a ? a.dgi : a.dgh) + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K + 4 * lk;
+// ---- 64 rows x 32 columns on the skeleton of dec_gru_mid (round 6): acc[g] (g = 0, 1: the tile's two 16-column n-tiles) += A . B^T over K for the
+// 16 rows of the calling wave.  `ar`: this lane's A row (row li of the wave's m-tile) + 4 lk; B rows n0 .. n0 + 31 of Bt (row stride ldb, rows
+// >= ncols read as zero) are staged per 64-wide k-chunk in LDS, double-buffered; K % 64 == 0.  All four waves of the workgroup must call it.
+__device__ __forceinline__ void mid_product_64x32(const float* __restrict__ ar, const float* __restrict__ Bt, long ldb, int n0, int ncols, int K,
+                                                  float (*bs)[32 * MID_LDB], f32x4 (&acc)[2]) {
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int nc = K / MID_KC;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto bload = [&](int c, f32x4 (&v)[2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + 256 * i, n = n0 + (e >> 4);
-            v[i] = n < ncols ? *reinterpret_cast<const f32x4*>(Bt + (long)n * K + c * MID_KC + 4 * (e & 15)) : zero4;
+            v[i] = n < ncols ? *reinterpret_cast<const f32x4*>(Bt + (long)n * ldb + c * MID_KC + 4 * (e & 15)) : zero4;
         }
     };
     auto bstore = [&](int buf, const f32x4 (&v)[2]) {
@@ -704,7 +688,6 @@ __global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(ar + c * MID_KC + 16 * u);
     };
-    f32x4 acc[2] = {zero4, zero4};
     f32x4 bv[2], a_cur[4], a_nxt[4];
     bload(0, bv);
     aload(0, a_cur);
@@ -714,7 +697,7 @@ __global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
     for (int c = 0; c < nc; ++c) {
         if (c + 1 < nc) {
             aload(c + 1, a_nxt);
-            bstore((c + 1) & 1, bv);
+            bstore((c + 1) & 1, bv);                       // (that buffer was last read in iteration c - 1, which ended with a barrier)
             if (c + 2 < nc) bload(c + 2, bv);
         }
         const float* const bb = bs[c & 1];
@@ -733,6 +716,28 @@ __global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) a_cur[u] = a_nxt[u];
     }
+}
+
+// The two backward products for hundreds of rows: a workgroup owns 64 rows x 32 columns of dx (role A) or dh (role B), wave w rows 16 w .. 16 w + 15
+// for all of K = 3 H2.  Replaces, in the bulk clip group's backward decode step, the dx product in front of the attention sweep and the dh
+// product behind it (two 64 x 32-tile launches of 30-50 us each in the step) by one launch in front of it.
+__global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
+    __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = a.R, K = 3 * a.H2, row0 = blockIdx.y * 64 + wave * 16;
+    const bool role_a = (int)blockIdx.x < a.nxa;
+    const int n0 = (role_a ? blockIdx.x : blockIdx.x - a.nxa) * 32;
+    const int ncols = role_a ? a.kx : a.H2;
+    float c0[2][4];
+    if (!role_a) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c0[g][r] = a.dh[(long)dec_row(a.rowmap, min(row0 + lk * 4 + r, R - 1)) * a.H2 + min(n0 + g * 16 + li, ncols - 1)];
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    mid_product_64x32((role_a ? a.dgi : a.dgh) + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * K + 4 * lk, role_a ? a.wih_t : a.whh_t, K, n0, ncols, K, bs, acc);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int col = n0 + g * 16 + li;
@@ -747,188 +752,67 @@ __global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
     }
 }
 
-// ---- dec_bwd_products with the GRU-cell backward of its rows folded into the prologue (round 5, few-row calls: the long-clip chain).  A backward
-// decode step was  gru_gates_bwd -> dec_bwd_products -> attention sweep -> attn_bwd_combine256 -> dec_bwd_query;  with this kernel and
-// dec_bwd_query_cmb below it is three launches.  Every workgroup (17 column tiles of dx, 16 of dh, x row blocks) forms the dgi (role A) or dgh
-// (role B) rows of ITS <= 16 rows in LDS from the saved gates -- the elementwise kernel's expressions (gru_cell_bwd) -- and multiplies from
-// there; workgroup x of a role also writes row x's dgi / dgh where gru_gates_bwd wrote it (the deferred weight gradients read all of it), a
-// role-B workgroup starts its dh columns from dh z instead of reading them, and the rows of the call that no longer run (row_list[nrows ..])
-// get the plain elementwise pass from whichever workgroup their index falls to.  Requires H2 == 512 (one hidden unit per thread).
-struct DecBwdGatesArgs {
-    const float* dh_in; const float* dos; long lddos;   // dh = dh_in + dos[:, :H2]
-    const float* gates; const float* hprev;             // (Rall, 4 H2) saved [r | z | n | gh_n]; (Rall, H2)
-    float* dgi; float* dgh;                             // (Rall, 3 H2) each, written for every row of the call
-    const int* row_list; int Rall;                      // all Rall rows, the running ones first (NULL: rows 0 .. R are all there is)
-};
-#define DBG_LD (3 * 512 + 4)
-
-__device__ __forceinline__ GruCellGrad dec_cell_bwd_at(const DecBwdGatesArgs& g, int H2, long row, int j) {
-    const float* s = g.gates + row * 4 * H2;
-    const float dh = g.dh_in[row * H2 + j] + g.dos[row * g.lddos + j];
-    return gru_cell_bwd(dh, s[j], s[H2 + j], s[2 * H2 + j], s[3 * H2 + j], g.hprev[row * H2 + j]);
-}
-
-static size_t dec_bwd_g_lds_bytes(int rows_blk) { return 4 * 2 * 64 * sizeof(f32x4) + 16 * 32 * sizeof(float) + (size_t)rows_blk * DBG_LD * sizeof(float); }
-__global__ __launch_bounds__(64 * NW) void dec_bwd_products_g(DecBwdProdArgs a, DecBwdGatesArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float dyn[];
-    f32x4* part = reinterpret_cast<f32x4*>(dyn);          // 4 * 2 * 64
-    float* dhz = dyn + 4 * 2 * 64 * 4;                    // [16][32]: dh z at this workgroup's columns (role B)
-    float* img = dhz + 16 * 32;                           // [rows of a block][DBG_LD]: this role's operand rows
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// dh[:, n] += dq . W_h[:, n] behind the attention sweep, same tiles (B rows = W_h^T rows, (H2, H); K = H)
+__global__ __launch_bounds__(256) void dec_bwd_query_mid(const float* __restrict__ dq, const float* __restrict__ wh_t, float* __restrict__ dh, int R, int H, int H2,
+                                                         const int* __restrict__ rowmap) {
+    __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int R = a.R, H2 = a.H2, K = 3 * H2, row0 = blockIdx.y * 16;
-    const int nb = min(16, R - row0);
-    const bool role_a = (int)blockIdx.x < a.nxa;
-    const int wx = role_a ? blockIdx.x : blockIdx.x - a.nxa;
-    const int n0 = wx * 32;
-    const int ncols = role_a ? a.kx : H2;
-    // ---- rows of the call that no longer run: the elementwise pass only
-    if (g.row_list) {
-        const int nwg = gridDim.x * gridDim.y, w = blockIdx.y * gridDim.x + blockIdx.x;
-        for (int k = R + w; k < g.Rall; k += nwg) {
-            const long row = g.row_list[k];
-            const GruCellGrad c = dec_cell_bwd_at(g, H2, row, tid);
-            float* di = g.dgi + row * K; float* dg = g.dgh + row * K;
-            di[tid] = c.dr; di[H2 + tid] = c.dz; di[2 * H2 + tid] = c.dn;
-            dg[tid] = c.dr; dg[H2 + tid] = c.dz; dg[2 * H2 + tid] = c.dnr;
-            a.dh[row * H2 + tid] = c.dhz;
-        }
-    }
-    // ---- this block's rows: thread = hidden unit; two rows' operands in flight at a time
-    for (int i0 = 0; i0 < nb; i0 += 2) {
-        long rows2[2];
-        GruCellGrad c2[2];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            rows2[rr] = dec_row(a.rowmap, row0 + min(i0 + rr, nb - 1));
-            c2[rr] = dec_cell_bwd_at(g, H2, rows2[rr], tid);
-        }
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int i = i0 + rr;
-            if (i >= nb) break;
-            const GruCellGrad c = c2[rr];
-            float* im = img + i * DBG_LD;
-            im[tid] = c.dr; im[H2 + tid] = c.dz; im[2 * H2 + tid] = role_a ? c.dn : c.dnr;
-            if (!role_a && tid >= n0 && tid < n0 + 32) dhz[i * 32 + tid - n0] = c.dhz;
-            if (wx == i) {                               // the copy in memory (both roles have >= 16 workgroups per row block)
-                float* d = (role_a ? g.dgi : g.dgh) + rows2[rr] * K;
-                d[tid] = c.dr; d[H2 + tid] = c.dz; d[2 * H2 + tid] = role_a ? c.dn : c.dnr;
-            }
-        }
-    }
-    __syncthreads();
-    const float* Bt = role_a ? a.wih_t : a.whh_t;
-    const float* brow[2];
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) brow[gq] = Bt + (long)min(n0 + gq * 16 + li, ncols - 1) * K;
+    const int row0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 32;
     float c0[2][4];
-    if (wave == 0 && !role_a) {
 #pragma unroll
-        for (int gq = 0; gq < 2; ++gq)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c0[gq][r] = dhz[min(lk * 4 + r, nb - 1) * 32 + gq * 16 + li];
-    }
+        for (int r = 0; r < 4; ++r) c0[g][r] = dh[(long)dec_row(rowmap, min(row0 + lk * 4 + r, R - 1)) * H2 + min(n0 + g * 16 + li, H2 - 1)];
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8_split<2, 4>(nullptr, 0, img + min(li, nb - 1) * DBG_LD, brow, K / 16, wave, lk, acc);
-    reduce_waves<2>(acc, part, wave, lane);
-    if (wave > 0) return;
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-        const int col = n0 + gq * 16 + li;
-        if (col >= ncols) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (row0 + lk * 4 + r >= R) continue;
-            const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
-            if (role_a) a.dx[(long)row * a.ldx + col] = acc[gq][r];
-            else a.dh[(long)row * H2 + col] = c0[gq][r] + acc[gq][r];
-        }
-    }
-}
-
-// ---- dec_bwd_query with the sum of the attention sweep's dq partials folded into its prologue (a2s_attn_deferred_bwd; H == 256): every workgroup
-// (16 column tiles x row blocks) adds up the G partials of ITS <= 16 rows into LDS, in attn_bwd_combine256's order; workgroup x writes row x's dq
-// where the combine wrote it (the deferred weight gradients read it); every workgroup zero-fills its share of the skipped rows (dq, ds, dctx).
-struct DecBwdQueryCmb {
-    const float* part; float* ds_out; float* dctx_out; long lddo;
-    const int* clip_rank; const int* row_until;
-    int G, groups, n_clips, n_active, step, T, Rall;
-};
-#define DQ_LD 260
-__global__ __launch_bounds__(64 * NW) void dec_bwd_query_cmb(float* __restrict__ dq, const float* __restrict__ wh_t, float* __restrict__ dh,
-                                                             int R, int H, int H2, const int* __restrict__ rowmap, DecBwdQueryCmb c) {
-    extern __shared__ __attribute__((aligned(16))) float dyn_q[];
-    f32x4* part = reinterpret_cast<f32x4*>(dyn_q);        // 4 * 2 * 64
-    float* dqs = dyn_q + 4 * 2 * 64 * 4;                  // [rows of a block][DQ_LD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int row0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
-    const int nb = min(16, R - row0);
-    {
-        const int nwg = gridDim.x * gridDim.y, w = blockIdx.y * gridDim.x + blockIdx.x;
-        for (int b = w; b < c.Rall; b += nwg) {
-            const int clip = b % c.n_clips;
-            const int slot = c.clip_rank ? c.clip_rank[clip] : clip;
-            if (slot >= c.n_active || (c.row_until && c.step >= c.row_until[b])) {
-                if (tid < 256) dq[(long)b * H + tid] = 0.f;
-                if (c.ds_out) for (int t = tid; t < c.T; t += 64 * NW) c.ds_out[(long)b * c.T + t] = 0.f;
-                if (c.dctx_out) c.dctx_out[(long)b * c.lddo + tid] = 0.f;
-            }
-        }
-    }
-    const float* brow[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) brow[g] = wh_t + (long)min(n0 + g * 16 + li, H2 - 1) * H;
-    float c0[2][4];
-    if (wave == 0) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c0[g][r] = dh[(long)dec_row(rowmap, min(row0 + lk * 4 + r, R - 1)) * H2 + min(n0 + g * 16 + li, H2 - 1)];
-    }
-    // ---- dq of the block's rows: thread = (row parity, column); four rows' partials in flight (two per thread)
-    {
-        const int j = tid & 255;
-        for (int i0 = tid >> 8; i0 < nb; i0 += 4) {
-            float p[2][16];
-            int brow_[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int i = min(i0 + 2 * rr, nb - 1);
-                const int b = dec_row(rowmap, row0 + i);
-                const int clip = b % c.n_clips, grp = b / c.n_clips;
-                const int slot = c.clip_rank ? c.clip_rank[clip] : clip;
-                const bool on = slot < c.n_active && !(c.row_until && c.step >= c.row_until[b]);
-                const float* pb = c.part + ((long)slot * c.groups + grp) * c.G * 256;
-                brow_[rr] = b;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) p[rr][u] = (on && u < c.G) ? pb[(long)u * 256 + j] : 0.f;
-            }
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int i = i0 + 2 * rr;
-                if (i >= nb) break;
-                float s = 0.f;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s += p[rr][u];          // (attn_bwd_combine256's order: partials 0, 1, 2, ...; G <= 16)
-                dqs[i * DQ_LD + j] = s;
-                if ((int)blockIdx.x == i) dq[(long)brow_[rr] * H + j] = s;
-            }
-        }
-    }
-    __syncthreads();
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    mfma_rows8_split<2, DEC_CH_QUERY>(nullptr, 0, dqs + min(li, nb - 1) * DQ_LD, brow, H / 16, wave, lk, acc);
-    reduce_waves<2>(acc, part, wave, lane);
-    if (wave > 0) return;
+    mid_product_64x32(dq + (long)dec_row(rowmap, min(row0 + li, R - 1)) * H + 4 * lk, wh_t, H, n0, H2, H, bs, acc);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int col = n0 + g * 16 + li;
         if (col >= H2) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (row0 + lk * 4 + r < R) dh[(long)dec_row(rowmap, row0 + lk * 4 + r) * H2 + col] = c0[g][r] + acc[g][r];
+            if (row0 + lk * 4 + r >= R) continue;
+            const int row = dec_row(rowmap, row0 + lk * 4 + r);
+            dh[(long)row * H2 + col] = c0[g][r] + acc[g][r];
+        }
+    }
+}
+
+// Forward: logits = [h' | ctx] W_out^T + b (role A: 32-column tiles of the vocabulary, K = 2 H2) and the NEXT step's attention query
+// q = h' W_h^T + b (role B: 32-column tiles of H, K = H2; absent in the last step) in one launch -- in the bulk loop two split-K products and
+// their two reduce launches (~85 us in the step).  The epilogue (log-softmax, token choice, embedding) stays note_step_finalize.
+struct DecOutqMidArgs {
+    const float* o; long ldo;                           // (R, ldo) rows [h' | ctx]
+    const float* out_w; const float* out_b; float* logits; long ldl; int V;
+    const float* attn_w; long ld_aw; const float* attn_b; float* q_next; int H;      // q_next NULL: no query role
+    const int* rowmap;
+    int nva, R, H2;                                     // nva: vocabulary tiles
+};
+__global__ __launch_bounds__(256) void dec_outq_mid(DecOutqMidArgs a) {
+    __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = a.R, row0 = blockIdx.y * 64 + wave * 16;
+    const bool role_a = (int)blockIdx.x < a.nva;
+    const int n0 = (role_a ? blockIdx.x : blockIdx.x - a.nva) * 32;
+    const int ncols = role_a ? a.V : a.H;
+    float bias[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) bias[g] = (role_a ? a.out_b : a.attn_b)[min(n0 + g * 16 + li, ncols - 1)];
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    mid_product_64x32(a.o + (long)dec_row(a.rowmap, min(row0 + li, R - 1)) * a.ldo + 4 * lk, role_a ? a.out_w : a.attn_w, role_a ? 2L * a.H2 : a.ld_aw, n0, ncols,
+                      role_a ? 2 * a.H2 : a.H2, bs, acc);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int col = n0 + g * 16 + li;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (row0 + lk * 4 + r >= R) continue;
+            const int row = dec_row(a.rowmap, row0 + lk * 4 + r);
+            if (role_a) a.logits[(long)row * a.ldl + col] = acc[g][r] + bias[g];
+            else a.q_next[(long)row * a.H + col] = acc[g][r] + bias[g];
         }
     }
 }
@@ -978,11 +862,11 @@ static int g_dec_fused = -1, g_dec_fused_max_rows = -1;
 void a2s_dec_fused_set(int v) { g_dec_fused = v ? 1 : 0; }
 void a2s_dec_fused_max_rows_set(int v) { g_dec_fused_max_rows = v; }
 int a2s_dec_fused_enabled(void) {
-    if (g_dec_fused < 0) { const char* e = getenv("A2S_DEC_FUSED"); g_dec_fused = (e && e[0] == '0') ? 0 : 1; }
+    if (g_dec_fused < 0) { const char* e = getenv("A2S_DEC_FUSED"); g_dec_fused = (e && e[0] == '0') ? 0 : 1; }      // (documented fallback: INTEGRATION.md)
     return g_dec_fused;
 }
 int a2s_dec_fused_max_rows(void) {
-    if (g_dec_fused_max_rows < 0) { const char* e = getenv("A2S_DEC_FUSED_MAX_ROWS"); g_dec_fused_max_rows = e ? atoi(e) : 192; }
+    if (g_dec_fused_max_rows < 0) g_dec_fused_max_rows = 192;
     return g_dec_fused_max_rows;
 }
 // scratch layout (floats): [16: flags | FUSED_MAX_RB: tickets | max_rows x 176: logits] then [W_ih^T | W_hh^T | W_h^T] for the backward
@@ -992,23 +876,6 @@ size_t a2s_note_step_fused_head_floats(void) { return (size_t)FUSED_HEAD; }
 size_t a2s_note_step_workspace_floats_impl(int H, int E) {
     const long H2 = 2L * H, kx = E + H2;
     return (size_t)(FUSED_HEAD + kx * 3 * H2 + H2 * 3 * H2 + H2 * H);
-}
-// the backward folds of the few-row chain: OFF by default (A2S_DEC_BWD_FOLD=1 / a2s_debug_set("dec_bwd_fold", 1): on).  Parity-tested
-// (tests/test_gpu_defer_combine.py) and measured in the training step (profiles/r05_defer_combine_ab.txt): 0 to +2.5 ms SLOWER per step -- under
-// the backward's conditions a launch on the long-clip chain costs ~5 us including its gap (profiles/r05_trace_overlap.txt), which is what the serial
-// prologues of the folded kernels cost as well.
-static int g_dec_bwd_fold = -1;
-void a2s_dec_bwd_fold_set(int v) { g_dec_bwd_fold = v ? 1 : 0; }
-int a2s_dec_bwd_fold_enabled(void) {
-    if (g_dec_bwd_fold < 0) { const char* e = getenv("A2S_DEC_BWD_FOLD"); g_dec_bwd_fold = (e && e[0] == '1') ? 1 : 0; }
-    return g_dec_bwd_fold;
-}
-// (calls of at most this many rows: the few-clip groups.  The tail steps of a LARGE call also run on the few-row kernels, but there the rows that
-// no longer run -- hundreds -- would get their elementwise pass from a few dozen workgroups: measured 5 ms per step slower)
-static int a2s_dec_bwd_fold_max_rows(void) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("A2S_DEC_BWD_FOLD_ROWS"); v = e ? atoi(e) : 96; }
-    return v;
 }
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // The mid-size kernels (dec_gru_mid, dec_bwd_mid: 64-row workgroups, weights staged through LDS) take the launches over more than 160 rows --
@@ -1022,15 +889,9 @@ int a2s_dec_mid_launches(void) { return g_dec_mid_launches; }
 static bool dec_use_mid(int nrows, int H2) { return g_dec_mid && nrows > 160 && H2 % MID_KC == 0; }
 // greedy: the call is a greedy decode (no ground truth, no backward).  There the 4-launch step wins at every batch size the workspace admits
 // (B = 256: 497 -> 536 clips/s, B = 64: 313 -> 317, profiles/r05_infer_variants.txt) -- one stream decodes a staff, nothing runs beside it that
-// the weight re-reads of the 16-row tiles could disturb -- so the row limit of the training path (A2S_DEC_FUSED_MAX_ROWS) does not apply;
-// A2S_DEC_FUSED_GREEDY_ALL=0 restores it.
-static int dec_fused_greedy_all(void) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("A2S_DEC_FUSED_GREEDY_ALL"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v;
-}
+// the weight re-reads of the 16-row tiles could disturb -- so the row limit of the training path (a2s_dec_fused_max_rows) does not apply.
 bool a2s_dec_step_fusable(int R, int H, int E, int V, const void* const* ptrs, int nptrs, const float* ws, size_t ws_floats, bool greedy) {
-    const int max_rows = (greedy && dec_fused_greedy_all()) ? FUSED_MAX_ROWS_CAP : a2s_dec_fused_max_rows();
+    const int max_rows = greedy ? FUSED_MAX_ROWS_CAP : a2s_dec_fused_max_rows();
     if (!a2s_dec_fused_enabled() || R > max_rows || R > FUSED_MAX_ROWS_CAP || !ws || ws_floats < a2s_note_step_workspace_floats_impl(H, E)) return false;
     if (H % 16 || E % 16 || (V + 15) / 16 != NTV || !aligned16(ws)) return false;
     for (int i = 0; i < nptrs; ++i) if (!aligned16(ptrs[i])) return false;
@@ -1062,7 +923,7 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
         c.Rall = R; c.E = a.E;
         hipLaunchKernelGGL(dec_gru_step_cmb, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), dec_cmb_lds_bytes(nrows < 16 ? nrows : 16), st, g, c);
     } else
-    if (dec_use_mid(nrows, H2)) hipLaunchKernelGGL(dec_gru_mid, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(256), 0, st, g);
+    if (dec_use_mid(nrows, H2)) { hipLaunchKernelGGL(dec_gru_mid, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(256), 0, st, g); __atomic_fetch_add(&g_dec_mid_launches, 1, __ATOMIC_RELAXED); }
     else hipLaunchKernelGGL(dec_gru_step, dim3(H2 / 16, a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, g);
     A2S_CHECK_LAUNCH("dec_gru_step");
     DecOutArgs f;
@@ -1113,50 +974,21 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
     p.rowmap = rowmap;
     p.nxa = a2s_cdiv(ldx, 32); p.kx = ldx; p.R = nrows; p.H2 = H2;
     const bool mid = dec_use_mid(nrows, H2);
-    // few rows (the long-clip chain): the cell backward rides in the product kernel, the partial sums of dq in the query product
-    const bool fold = a2s_dec_bwd_fold_enabled() && !mid && R <= a2s_dec_bwd_fold_max_rows() && H2 == 64 * NW && a.H == 256 && p.nxa >= 16 && rows && (rowmap || nrows == R);
-    int rc;
-    if (fold) {
-        DecBwdGatesArgs gg;
-        gg.dh_in = dh_in; gg.dos = dos; gg.lddos = 2 * H2; gg.gates = a.gates + (long)s * R * 4 * H2; gg.hprev = a.h + (long)s * R * H2;
-        gg.dgi = dgi; gg.dgh = dgh; gg.row_list = rowmap; gg.Rall = R;
-        static int attr_set = 0;                                  // 1: ok, -1: the runtime refused the LDS size
-        const size_t shm = dec_bwd_g_lds_bytes(nrows < 16 ? nrows : 16);
-        if (!attr_set) {
-            const size_t shm_max = dec_bwd_g_lds_bytes(16);
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_products_g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max);
-            if (e != hipSuccess) (void)hipGetLastError();
-            attr_set = e == hipSuccess ? 1 : -1;
-        }
-        A2S_REQUIRE(attr_set == 1, "note_step_fused_bwd: %zu bytes of LDS refused (A2S_DEC_BWD_FOLD=0 avoids the kernel)", shm);
-        hipLaunchKernelGGL(dec_bwd_products_g, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), shm, st, p, gg);
-    } else {
-        rc = a2s_gru_gates_bwd_impl(st, dh_in, H2, dos, 2 * H2, a.gates + (long)s * R * 4 * H2, a.h + (long)s * R * H2, H2,
+    int rc = a2s_gru_gates_bwd_impl(st, dh_in, H2, dos, 2 * H2, a.gates + (long)s * R * 4 * H2, a.h + (long)s * R * H2, H2,
                                     dgi, 3 * H2, dgh, 3 * H2, nullptr, 0, dh_out, H2, R, H2);
-        if (rc) return rc;
-        if (mid) hipLaunchKernelGGL(dec_bwd_mid, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * DEC_NW_PROD), 0, st, p);
-    }
+    if (rc) return rc;
+    if (mid) { hipLaunchKernelGGL(dec_bwd_mid, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(256), 0, st, p); __atomic_fetch_add(&g_dec_mid_launches, 1, __ATOMIC_RELAXED); }
+    else hipLaunchKernelGGL(dec_bwd_products, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * DEC_NW_PROD), 0, st, p);
     A2S_CHECK_LAUNCH("dec_bwd_products");
     // attention: dctx = dx[:, E:] + do[:, 2H:]
-    a2s_attn_deferred_bwd defer;
-    defer.G = 0;
     rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
                                 a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
                                 a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
-                                a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows, fold ? &defer : nullptr);
+                                a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
     if (rc) return rc;
-    if (defer.G > 0) {
-        DecBwdQueryCmb c;
-        c.part = defer.part; c.ds_out = defer.ds_out; c.dctx_out = defer.dctx_out; c.lddo = defer.lddo; c.clip_rank = defer.clip_rank; c.row_until = defer.row_until;
-        c.G = defer.G; c.groups = defer.groups; c.n_clips = defer.n_clips; c.n_active = defer.n_active; c.step = defer.step; c.T = defer.T; c.Rall = R;
-        A2S_REQUIRE(defer.lddo == H2, "note_step_fused_bwd: deferred combine needs a dense dctx row (%ld)", defer.lddo);
-        hipLaunchKernelGGL(dec_bwd_query_cmb, dim3(a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW),
-                           4 * 2 * 64 * sizeof(f32x4) + (size_t)(nrows < 16 ? nrows : 16) * DQ_LD * sizeof(float), st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, nrows, a.H, H2,
-                           rowmap, c);
-    } else
-    hipLaunchKernelGGL(dec_bwd_query, dim3(a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, nrows, a.H, H2,
-                       rowmap);
+    if (mid) hipLaunchKernelGGL(dec_bwd_query_mid, dim3(a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(256), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, nrows, a.H, H2, rowmap);
+    else hipLaunchKernelGGL(dec_bwd_query, dim3(a2s_cdiv(H2, 32), a2s_cdiv(nrows, 16)), dim3(64 * NW), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, nrows, a.H, H2,
+                            rowmap);
     A2S_CHECK_LAUNCH("dec_bwd_query");
     return A2S_OK;
 }
@@ -1167,12 +999,13 @@ int a2s_note_step_fused_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int 
 // and output products, attention, epilogue as library-style launches), but its GRU cell -- two products + the gate kernel -- is ONE dec_gru_mid
 // launch behind the attention, and the reverse loop's dx / dh products ONE dec_bwd_mid launch in front of it.
 bool a2s_note_step_mid_ok(int H, int E, const void* const* ptrs, int nptrs) {
-    if (!g_dec_mid || (2 * H) % MID_KC || E % 16) return false;
+    if (!g_dec_mid || H % MID_KC || E % 16) return false;          // (K = 2H, 4H, 6H and H are walked in 64-wide chunks)
     for (int i = 0; i < nptrs; ++i) if (!aligned16(ptrs[i])) return false;
     return true;
 }
-// h' = GRU([token | ctx], h) for rows rowmap[0 .. nrows) (rowmap NULL: rows 0 .. nrows): state slot so, output row o[sv][:, :2H], saved gates
-int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int nrows, const int* rowmap) {
+// h' = GRU([token | ctx], h) for rows rowmap[0 .. nrows) (rowmap NULL: rows 0 .. nrows): state slot so, output row o[sv][:, :2H], saved gates;
+// then logits of the rows and (sv_next >= 0) the next step's query into slot sv_next
+int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int nrows, const int* rowmap) {
     const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
     if (nrows <= 0) return A2S_OK;
     DecGruArgs g;
@@ -1187,6 +1020,13 @@ int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, in
     hipLaunchKernelGGL(dec_gru_mid, dim3(H2 / 16, a2s_cdiv(nrows, 64)), dim3(256), 0, st, g);
     __atomic_fetch_add(&g_dec_mid_launches, 1, __ATOMIC_RELAXED);
     A2S_CHECK_LAUNCH("dec_gru_mid");
+    DecOutqMidArgs f;
+    f.o = g.o; f.ldo = 2 * H2; f.out_w = a.out_w; f.out_b = a.out_b; f.logits = a.logits; f.ldl = a.V; f.V = a.V;
+    f.attn_w = a.attn_w; f.ld_aw = 2 * H2; f.attn_b = a.attn_b; f.q_next = sv_next >= 0 ? a.q + (long)sv_next * R * a.H : nullptr; f.H = a.H;
+    f.rowmap = rowmap;
+    f.nva = a2s_cdiv(a.V, 32); f.R = nrows; f.H2 = H2;
+    hipLaunchKernelGGL(dec_outq_mid, dim3(f.nva + (f.q_next ? a2s_cdiv(a.H, 32) : 0), a2s_cdiv(nrows, 64)), dim3(256), 0, st, f);
+    A2S_CHECK_LAUNCH("dec_outq_mid");
     return A2S_OK;
 }
 bool a2s_note_step_mid_bwd_ok(const a2s_note_dec_bwd_args& a) {
@@ -1206,5 +1046,14 @@ int a2s_note_step_mid_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s,
     hipLaunchKernelGGL(dec_bwd_mid, dim3(p.nxa + a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(256), 0, st, p);
     __atomic_fetch_add(&g_dec_mid_launches, 1, __ATOMIC_RELAXED);
     A2S_CHECK_LAUNCH("dec_bwd_mid");
+    return A2S_OK;
+}
+// dh_out += dq[s] W_h for rows rowmap[0 .. nrows), behind the attention sweep of the step
+int a2s_note_step_mid_bwd_query(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, float* dh_out, int nrows, const int* rowmap) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    if (nrows <= 0) return A2S_OK;
+    const float* wh_t = a.step_ws + FUSED_HEAD + (long)ldx * 3 * H2 + (long)H2 * 3 * H2;
+    hipLaunchKernelGGL(dec_bwd_query_mid, dim3(a2s_cdiv(H2, 32), a2s_cdiv(nrows, 64)), dim3(256), 0, st, a.dq_all + (long)s * R * a.H, wh_t, dh_out, nrows, a.H, H2, rowmap);
+    A2S_CHECK_LAUNCH("dec_bwd_query_mid");
     return A2S_OK;
 }

@@ -41,15 +41,15 @@ import os as _os
 # kernels, not by host launch cost -- so it is opt-in.
 _GREEDY_GRAPH = _os.environ.get("A2S_GREEDY_GRAPH") == "1"
 # the encoder's input projections and the attention key images on the two-term fp16 split (operand ranges known: DESIGN.md section 5)
-# instead of three bf16 terms; A2S_ENC_TWO_TERM=0: as in round 2
-_ENC_TWO_TERM = _os.environ.get("A2S_ENC_TWO_TERM", "1") != "0"
-# late steps of a large decoder call: the per-step products only on the leading clips that still have an unfinished row (A2S_TAIL_PREFIX=0: all rows)
-_TAIL_PREFIX = _os.environ.get("A2S_TAIL_PREFIX", "1") != "0"
-# ... and the few-row step kernels on the rows still running once those fit them (A2S_TAIL_ROWS=0: only calls that are small as a whole)
-_TAIL_ROWS = _os.environ.get("A2S_TAIL_ROWS", "1") != "0"
+# instead of three bf16 terms (round 2's)
+_ENC_TWO_TERM = True
+# late steps of a large decoder call: the per-step products only on the leading clips that still have an unfinished row (False: all rows)
+_TAIL_PREFIX = True
+# ... and the few-row step kernels on the rows still running once those fit them (False: only calls that are small as a whole)
+_TAIL_ROWS = True
 # the (step, row) pairs of a decoder call that still ran, as a flat index list: the backward's weight-gradient products contract over those only
-# (A2S_LIVE_ROWS=0: over every row of every step, three quarters of which are the exact zeros of finished rows at the bench's lengths)
-_LIVE_ROWS = _os.environ.get("A2S_LIVE_ROWS", "1") != "0"
+# (False: over every row of every step, three quarters of which are the exact zeros of finished rows at the bench's lengths)
+_LIVE_ROWS = True
 _SIDE_STREAMS = {}
 
 
@@ -99,8 +99,11 @@ def _pinned_pool(device):
     return _PINNED_POOLS[key]
 
 
-_BAR_ATTN_SPLIT = _os.environ.get("A2S_BAR_ATTN_SPLIT", "1") != "0"
+_BAR_ATTN_SPLIT = True          # the bar-level decoder's attention of groups of >= 32 clips on the split-T kernels (tests switch it)
 _BAR_ATTN_WS = {}
+# the round-4 persistent note decoder for the last clip group also while another group decodes beside it (tests only: it owns every CU it runs on
+# and stops the bulk group there -- 540 against 514 ms per step, profiles/r04_dec_persist_beside_bulk.txt)
+_PERSIST_BESIDE = False
 
 
 def bar_attn_workspace(device, group, n_clips, T, H):
@@ -129,6 +132,8 @@ def _trace(label):
 
 _GROUP_STREAMS = {}
 _GROUP_POOL = None
+_LONG_LOWER_STREAMS = {}
+_LONG_STAVES_EXTRA = _os.environ.get("A2S_X_LONG_STAVES") == "1"      # EXPERIMENT (round 6): the long sub-groups' lower staves on streams of their own
 
 
 def staff_streams(device, group):
@@ -139,8 +144,11 @@ def staff_streams(device, group):
     of its own and the long-clip group's two staves run side by side instead of one after the other (1292 -> 876 dependent steps)."""
     cur = torch.cuda.current_stream()
     side = side_streams(device, 0)
-    if _os.environ.get("A2S_STAFF_ON_OWN_STREAM", "1") == "0":          # A/B: round-2's first layout (group 0 on the two side streams,
-        return side if group == 0 else (cur, cur)                       # the long-clip group's staves one after the other on its stream)
+    if group >= 1 and _LONG_STAVES_EXTRA:
+        key = (_dev_index(device), group)
+        if key not in _LONG_LOWER_STREAMS:
+            _LONG_LOWER_STREAMS[key] = torch.cuda.Stream(device=key[0])
+        return (cur, _LONG_LOWER_STREAMS[key])
     return (cur, side[1]) if group == 0 else (cur, side[0])
 
 
@@ -167,7 +175,7 @@ def group_stream(device, group):
 def staves_concurrent(gidx, n_groups):
     """Do the two note decoders of clip group gidx run side by side on two streams?  Group 0 always; the long-clip group when it is the only one beside
     it; with two long-clip sub-groups each of them runs upper then lower on its one stream (four streams in all, see group_stream)."""
-    return gidx == 0 or (gidx == 1 and n_groups == 2)
+    return gidx == 0 or (gidx == 1 and n_groups == 2) or _LONG_STAVES_EXTRA
 
 
 def draw_plan(gt_cpu, bars, maxlen, rng, teacher_forcing_ratio):
@@ -233,27 +241,23 @@ def run_clip_groups(device, fns):
             done.record()
         return r, done
 
-    if _os.environ.get("A2S_ISSUE_THREADS", "1") == "0":
-        rest = [task(g, fn) for g, fn in enumerate(fns[1:], start=1)]
-        first = fns[0]()
-    else:
-        if _GROUP_POOL is None:
-            from concurrent.futures import ThreadPoolExecutor
-            _GROUP_POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="a2s-group")
-        futures = [_GROUP_POOL.submit(task, g, fn) for g, fn in enumerate(fns[1:], start=1)]
-        first = fns[0]()
-        rest = [f.result() for f in futures]
+    if _GROUP_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _GROUP_POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="a2s-group")
+    futures = [_GROUP_POOL.submit(task, g, fn) for g, fn in enumerate(fns[1:], start=1)]
+    first = fns[0]()
+    rest = [f.result() for f in futures]
     for _, done in rest:
         torch.cuda.current_stream().wait_event(done)
     return [first] + [r for r, _ in rest]
 
 
 def encoder_streams(device, batch=0):
-    """Streams for the two directions of an encoder GRU layer (A2S_ENC_SERIAL=1: both on the current stream, for A/B measurements).
+    """Streams for the two directions of an encoder GRU layer.
     batch: clips of the call.  The persistent recurrences (csrc/a2s_persist.hip) need every workgroup of a launch resident: 16 per 16 clips, two per
     CU.  Up to 256 clips both directions fit side by side (2 x 256 workgroups on 256 CUs); above that (up to 512 clips) ONE direction fits, so the two run
     one after the other on the current stream and the library is told that nothing persistent runs beside a launch ("gru_persist_alone")."""
-    serial = _os.environ.get("A2S_ENC_SERIAL") == "1" or batch > 256
+    serial = batch > 256
     hip.check(hip.lib().a2s_debug_set(b"gru_persist_alone", 1 if batch > 256 else 0), "a2s_debug_set")
     if serial:
         cur = torch.cuda.current_stream()
@@ -269,7 +273,7 @@ def fork_on_streams(device, streams, fns):
     these functions enqueue (encoder directions, the two staves) are bound by the HOST's launch rate (~6 us per kernel, measured:
     two loops issued from one thread take exactly twice one loop), and ctypes drops the GIL inside liba2s_hip.so, so two threads
     issue two streams at the same time.  Returns a join() callable: it returns [fns[i]() results] and makes the caller's current
-    stream wait for both.  A2S_ISSUE_THREADS=0: issue inline from the calling thread."""
+    stream wait for both."""
     global _ISSUE_POOL
     fork = torch.cuda.Event()
     fork.record()
@@ -288,18 +292,14 @@ def fork_on_streams(device, streams, fns):
         done.record(st)
         return r, done
 
-    if _os.environ.get("A2S_ISSUE_THREADS", "1") == "0":
-        results = [task(st, fn) for st, fn in zip(streams, fns)]
-        futures = None
-    else:
-        if _ISSUE_POOL is None:
-            from concurrent.futures import ThreadPoolExecutor
-            _ISSUE_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="a2s-issue")      # 2 staves x up to 2 clip groups
-        futures = [_ISSUE_POOL.submit(task, st, fn) for st, fn in zip(streams, fns)]
+    if _ISSUE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _ISSUE_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="a2s-issue")      # 2 staves x up to 3 clip groups
+    futures = [_ISSUE_POOL.submit(task, st, fn) for st, fn in zip(streams, fns)]
 
     def join(wait=True):
         """wait=False: the caller's stream is NOT made to wait; returns (results, [events to wait for later])."""
-        res = results if futures is None else [f.result() for f in futures]
+        res = [f.result() for f in futures]
         events = [done for _, done in res if done is not None]
         if not wait:
             return [r for r, _ in res], events
@@ -397,19 +397,13 @@ class Engine:
             saved.setdefault("abound", []).append(hip.act_bound(scale, shift, yabs_out))
             x, yabs = y, yabs_out
         # the (B*T, 40*F) operand of the 19200->256 Linear is relu(bn4(y4)): formed while the GEMM stages its A tiles (column k belongs
-        # to channel k // F), never written to memory (A2S_MATERIALIZE_A4=1: the separate bn_relu_apply pass, for A/B measurements)
+        # to channel k // F), never written to memory
         y4 = x.view(B * T, 40 * F)
         Cf = self.cfg["conv_feature_size"]
-        if _os.environ.get("A2S_MATERIALIZE_A4") == "1":
-            a4 = self._empty(B * T, 40 * F, dev=dev)
-            hip.check(L.a2s_bn_relu_apply(hip.stream(), hip._p(x), hip._p(a4), hip._p(scale), hip._p(shift), C.c_long(a4.numel()), 40, F),
-                      "a2s_bn_relu_apply")
-            z = hip.linear(a4, S["convstack.out.weight"])
-        else:
-            a4 = None
-            # two-term fp16 split: activations scaled by the power of two of their bound, the weights by that of max|W|
-            saved["w_out_amax"] = hip.absmax(S["convstack.out.weight"])
-            z = hip.linear_forward(y4, S["convstack.out.weight"], (scale, shift, F), saved["abound"][3], saved["w_out_amax"])
+        a4 = None
+        # two-term fp16 split: activations scaled by the power of two of their bound, the weights by that of max|W|
+        saved["w_out_amax"] = hip.absmax(S["convstack.out.weight"])
+        z = hip.linear_forward(y4, S["convstack.out.weight"], (scale, shift, F), saved["abound"][3], saved["w_out_amax"])
         rows = B * T
         rpb = 64
         nblk = (rows + rpb - 1) // rpb
@@ -691,12 +685,9 @@ class Engine:
             clip_groups = [(0, B)]
         assert clip_groups[0][0] == 0 and clip_groups[-1][1] == B and all(a[1] == b[0] for a, b in zip(clip_groups[:-1], clip_groups[1:]))
         # occupancy cap of the bulk group's attention launches (csrc/a2s_seq.hip a2s_attn_bulk_lds): only while another group decodes beside it
-        # (round 5: level 2 -- ONE forward sweep workgroup per CU instead of two -- can be asked for in steps of at least A2S_ATTN_STRONG_CAP_SEGMENTS bar
-        # segments, where the long-clip chain is the step's critical path.  Measured: everywhere, steps of 3 segments 496 -> 488 ms but the others
-        # 440 -> 450; from 3 or 4 segments on, 443.2 / 444.6 -> 446.7 / 443.8 and 445.4 / 444.8 (profiles/r05_prefix_percent.txt): no gain, off by default)
         cap_level = 0
-        if len(clip_groups) > 1 and _os.environ.get("A2S_ATTN_BULK_CAP", "1") != "0":
-            cap_level = 2 if (len(segments) >= int(_os.environ.get("A2S_ATTN_STRONG_CAP_SEGMENTS", "99")) and training) else 1
+        if len(clip_groups) > 1:
+            cap_level = 1
         hip.check(hip.lib().a2s_debug_set(b"attn_bulk_cap", cap_level), "debug_set")
 
         bar_major = fuse
@@ -744,11 +735,11 @@ class Engine:
             # hold a clip's keys / encoder outputs in LDS and wait for each other: two such launches in flight at once would share the CUs and
             # starve each other.  So only the LAST group may take that path (the long clips; or the whole minibatch when it is that small), and
             # its two staves then run one after the other on the group's stream.
-            # ... and only when no other clip group decodes beside it (A2S_DEC_PERSIST_BESIDE=1 lifts that): a persistent launch occupies the
+            # ... and only when no other clip group decodes beside it (engine._PERSIST_BESIDE lifts that, tests): a persistent launch occupies the
             # registers and LDS of every CU, so a bulk group that runs concurrently is stopped for as long as it is resident -- measured at
             # B = 256 with 8 long clips: the long-clip chain went from ~230 to ~85 ms per step, the bulk group's first segment from 280 to 825 us
             # per step, and the step from 514 to 540 ms (profiles/r04_dec_persist_beside_bulk.txt).
-            alone = len(clip_groups) == 1 or _os.environ.get("A2S_DEC_PERSIST_BESIDE") == "1"
+            alone = len(clip_groups) == 1 or _PERSIST_BESIDE
             persist_g = (Bg <= 8 and gidx == len(clip_groups) - 1 and alone and H == 256 and E == 16 and (plan is not None or (inference and not greedy_graph))
                          and _os.environ.get("A2S_DEC_PERSIST", "1") != "0")
             concurrent_g = concurrent and staves_concurrent(gidx, len(clip_groups)) and not persist_g

@@ -293,17 +293,17 @@ class Backward:
         self.dEnc_staff = [torch.zeros_like(self.dEnc), torch.zeros_like(self.dEnc)] if self.concurrent else [self.dEnc, self.dEnc]
         self.bar_major = bool(bar_major)
         # weight gradients etc. of each staff off its recurrence stream: measured +0.7 % in round 1, but two more streams than the four
-        # hardware queues the runtime has (engine.group_stream) -- off by default since the clip groups need a queue (A2S_DEFER_STREAM=1)
-        self.use_deferred = self.concurrent and os.environ.get("A2S_DEFER_STREAM", "0") == "1"
+        # hardware queues the runtime has (engine.group_stream) -- off since the clip groups need a queue
+        self.use_deferred = False
         # round 5: the note decoders' weight gradients run in finish(), on the weight-gradient stream beside the encoder's back-propagation
-        # (A2S_LATE_WGRADS=0 / eng.late_wgrads = False: where they were, behind each call's reverse loop on the staff's stream)
+        # (eng.late_wgrads = False: where they were, behind each call's reverse loop on the staff's stream)
         lw = getattr(eng, "late_wgrads", None)
-        self.late_wgrads = (os.environ.get("A2S_LATE_WGRADS", "1") != "0") if lw is None else bool(lw)
+        self.late_wgrads = True if lw is None else bool(lw)
         self.late = []                                     # (closure, event on the issuing stream, tensors it reads): appended by any group's host thread
         self.clip_groups = list(clip_groups) if clip_groups else [(0, B)]
         # the deferred products of the decoder backward (weight gradients, key / encoder-output gradients) with measured operand ranges on
-        # the two-term fp16 split instead of three bf16 terms (A2S_BWD_TWO_TERM=0: as in round 2)
-        self.two_term = os.environ.get("A2S_BWD_TWO_TERM", "1") != "0"
+        # the two-term fp16 split instead of three bf16 terms (round 2's)
+        self.two_term = True
         self.d_hidden = torch.empty((B, H2), dtype=torch.float32, device=dev)       # gradient wrt the encoder's bridge output (initial bar-level hidden)
         self.group_flat = [self.flat] + [torch.zeros_like(self.flat) for _ in self.clip_groups[1:]]
         self.group_ptrs = [self.G["__staff_emb_ptrs__"]]
@@ -525,7 +525,7 @@ class Backward:
         # them) overlap with the START of the ConvStack backward: the caller's stream does not wait for them here.  The decoder + encoder slice
         # is announced from that stream (a collective issued there is ordered behind its work, which itself waited for everything the main
         # stream had enqueued when those GEMMs were launched), and the main stream joins it after the ConvStack backward.
-        defer = _os_env("A2S_DEFER_ENC_WGRAD", "1") != "0"
+        defer = True
         d_conv = _encoder_bwd(eng, S, G, sv["enc"], dEnc, d_hid_carry, B, T, wait_weight_grads=not defer)
         n_conv = next(off for k, off in zip(names, offs) if not k.startswith("convstack."))      # state_dict order: convstack first
         if grad_ready is not None:
@@ -615,7 +615,7 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T, wait_weight_grads=True):
             dhn.append(d)
         _colsum(dpre, 2 * H, G["encoder.fc.bias"], B, H, x_off=l * H)
     gws = [hip.gemm_workspace(B, dev), hip.gemm_workspace(B, dev)]
-    two_term = os.environ.get("A2S_BWD_TWO_TERM", "1") != "0"
+    two_term = True
     in_amax = hip.absmax(es["layers"][0]["in"]) if two_term else None        # max of the ConvStack features (layer 0's input)
     dout = dEnc                                              # gradient wrt layer-1 outputs (B,T,2H)
     for layer in (1, 0):
@@ -676,24 +676,26 @@ def _encoder_bwd(eng, S, G, es, dEnc, d_hidden, B, T, wait_weight_grads=True):
     return dout                                              # (B, T, conv_feature_size)
 
 
-# A2S_FUSE_BN_APPLY=1: form the BatchNorm input gradient inside the weight-gradient kernel (a2s_conv3x3_wgrad_bn) instead of a separate
-# bn_bwd_apply pass.  Built and parity-tested, but OFF: the extra operand pushes conv3x3_wgrad<40> from 202 to 281 registers
-# (occupancy 2 -> 1) and the ConvStack backward got 19 % slower (409 -> 487 ms at B=256) instead of 14 % faster.
-_FUSE_BN_APPLY = os.environ.get("A2S_FUSE_BN_APPLY", "0") == "1"
-_FUSE_BN_APPLY_L1 = os.environ.get("A2S_FUSE_BN_APPLY_L1", "1") != "0"
-_DGRAD_BNSTATS = os.environ.get("A2S_DGRAD_BNSTATS", "1") != "0"      # BatchNorm-backward statistics in the data-gradient conv's epilogue
+# How the ConvStack's backward is laid out.  Module constants (tests set them directly); the one environment switch is the documented fallback
+# A2S_FUSE_BN_ROWS=0: the BatchNorm-backward apply as a tensor pass of its own instead of inside the row-streaming weight gradient.
+# _FUSE_BN_APPLY: the round-2 form of that fusion (inside the tiled weight gradient a2s_conv3x3_wgrad_bn) -- parity-tested, slower (the extra operand
+# pushes conv3x3_wgrad<40> from 202 to 281 registers); kept for conv1 only (_FUSE_BN_APPLY_L1), whose weight gradient is its own kernel.
+_FUSE_BN_APPLY = False
+_FUSE_BN_APPLY_L1 = True
+_DGRAD_BNSTATS = True           # BatchNorm-backward statistics in the data-gradient conv's epilogue
 # synchronised BatchNorm keeps the fused backward paths (statistics from the producers' partials, ONE small all-reduce per layer, the input gradient
-# formed inside the weight-gradient kernel): round 5; A2S_SYNC_BN_FUSED=0 = round 4's separate statistics + apply passes
-_SYNC_FUSED = os.environ.get("A2S_SYNC_BN_FUSED", "1") != "0"
-def _lin_wgrad_overlap():       # the 19200 -> 256 Linear's weight gradient beside its data gradient (round 5); read per step (tools/ab_step.py env:)
-    return os.environ.get("A2S_LINEAR_WGRAD_OVERLAP", "1") != "0"
+# formed inside the weight-gradient kernel): round 5; False = round 4's separate statistics + apply passes
+_SYNC_FUSED = True
+# The 19200 -> 256 Linear's weight gradient beside its data gradient on the weight-gradient stream (round 5) or behind it on the main stream.  Round 6
+# A/B (tools/step_time.py, 12 steps, alternating processes, profiles/r06_ab_switches.txt): beside 446.9 / 445.9 ms, behind 443.6 / 444.5 -- the data
+# gradient is on the backward's critical chain and runs 15.1 ms alone against 20.4 beside the weight gradient: behind.
+_LIN_WGRAD_OVERLAP = False
 _FUSE_BN_ROWS = os.environ.get("A2S_FUSE_BN_ROWS", "1") != "0"        # BatchNorm-backward apply inside the row-streaming weight gradient's staging
-_LINEAR_DGRAD = os.environ.get("A2S_LINEAR_DGRAD", "1") != "0"        # the Linear's data gradient on its own kernel (csrc/a2s_linear.hip)
 
 
 def _linear_dgrad_generic(L, dev, rows, F, Cf, dz, Wout, da, y4, bn4, dz_amax, w_amax):
     """Data gradient of the 19200 -> Cf Linear + layer-4 BatchNorm-backward statistics on the generic two-term GEMM tiles (shapes the kernel of
-    csrc/a2s_linear.hip does not take, or A2S_LINEAR_DGRAD=0).  Returns (partials, blocks)."""
+    csrc/a2s_linear.hip does not take, or hip.LINEAR_KERNELS off).  Returns (partials, blocks)."""
     nblk = L.a2s_gemm_bnstats_blocks(rows, F)
     part = torch.empty((nblk, 40, 2), dtype=torch.float32, device=dev)
     if L.a2s_debug_get(b"gemm_bf16x3") > 0:
@@ -775,7 +777,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         def lin_wgrad():
             if not hip.linear_wgrad(dz, y4, (bn4[2], bn4[3], F), dz_amax, cs["abound"][3], G["convstack.out.weight"]):       # round 4: csrc/a2s_linear.hip
                 _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
-        lin_overlap = _lin_wgrad_overlap()
+        lin_overlap = _LIN_WGRAD_OVERLAP
         if lin_overlap:
             # round 5: the Linear's weight gradient (reads y4 once, 10-13 ms) and its data gradient (writes da, re-reads y4, 15 ms) only share dz: the
             # weight gradient goes to the weight-gradient stream (idle by now: the decoder is over) and runs BESIDE the data gradient; the main stream
@@ -792,7 +794,7 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
             if w_amax is None:
                 w_amax = hip.absmax(Wout)
-            if _LINEAR_DGRAD and L.a2s_linear_dgrad_eligible(rows, 40 * F, Cf, F):
+            if hip.LINEAR_KERNELS and L.a2s_linear_dgrad_eligible(rows, 40 * F, Cf, F):
                 # round 4: the kernel of its own (csrc/a2s_linear.hip): the weight pre-split once per launch, a workgroup's rows of dz resident in LDS
                 # for all column tiles, no barrier in the sweep
                 nblk = L.a2s_linear_dgrad_blocks(rows)

@@ -59,12 +59,27 @@ def lib():
         for fn in ("a2s_note_step_workspace_floats", "a2s_note_decoder_persist_ws_bytes", "a2s_note_decoder_bwd_persist_ws_bytes", "a2s_linear_dgrad_ws_bytes", "a2s_linear_wgrad_ws_bytes", "a2s_gemm_workspace_bytes", "a2s_bn_bwd_partial_floats", "a2s_conv3x3_wgrad_workspace_bytes", "a2s_attn_workspace_floats", "a2s_attn_workspace_floats_fused",
                    "a2s_conv3x3_workspace_floats"):
             getattr(_lib, fn).restype = C.c_size_t
-        for env, key in (("A2S_CONV_BF16X3", b"conv_bf16x3"), ("A2S_CONV_ROWS", b"conv_rows"), ("A2S_GEMM_BF16X3", b"gemm_bf16x3"), ("A2S_WGRAD_BF16X3", b"wgrad_bf16x3"), ("A2S_CONV_F16X2", b"conv_f16x2"), ("A2S_WGRAD_F16X2", b"wgrad_f16x2"),
-                         ("A2S_DEC_FUSED", b"dec_fused"), ("A2S_DEC_FUSED_MAX_ROWS", b"dec_fused_max_rows"), ("A2S_DEC_PERSIST", b"dec_persist")):
+        # A2S_ARITH: the arithmetic of the dense contractions -- "f16x2" (default: two exact fp16 terms per fp32 operand, three
+        # products), "bf16x3" (rounds 1-2: three bf16 terms, six products) or "f32" (fp32-input matrix instructions / vector FMAs); per-kernel keys:
+        # a2s_debug_set("conv_f16x2" | "wgrad_f16x2" | "gemm_f16x2" | "conv_bf16x3" | "gemm_bf16x3" | "wgrad_bf16x3", n)
+        arith = os.environ.get("A2S_ARITH", "f16x2")
+        if arith not in ("f16x2", "bf16x3", "f32"):
+            raise A2SError(f"A2S_ARITH={arith!r}: expected f16x2, bf16x3 or f32")
+        if arith != "f16x2":
+            for key in (b"conv_f16x2", b"wgrad_f16x2", b"gemm_f16x2"):
+                _lib.a2s_debug_set(key, 0)
+        if arith == "f32":
+            for key in (b"conv_bf16x3", b"gemm_bf16x3", b"wgrad_bf16x3"):
+                _lib.a2s_debug_set(key, 0)
+        # documented fallbacks: the row-streaming convolutions, the few-row decoder path, the persistent note decoder
+        for env, key in (("A2S_CONV_ROWS", b"conv_rows"), ("A2S_DEC_FUSED", b"dec_fused"), ("A2S_DEC_PERSIST", b"dec_persist")):
             if os.environ.get(env):
                 _lib.a2s_debug_set(key, int(os.environ[env]))
     return _lib
 
+
+# the 19200 -> 256 Linear on the kernels of csrc/a2s_linear.hip (A2S_LINEAR_KERNELS=0: the generic two-term GEMM tiles; bench.py times both)
+LINEAR_KERNELS = os.environ.get("A2S_LINEAR_KERNELS", "1") != "0"
 
 _ABORT_LATCH = {}
 PERSIST_ABORTS = 0          # persistent launches of this process that gave up a bounded wait (observed through the latch)
@@ -328,12 +343,12 @@ def conv3x3_wgrad_for_test(dy, x, scale, shift):
 
 def linear_forward(x2d, weight, x_affine, x_bound, w_absmax, out=None):
     """The ConvStack's 19200 -> 256 Linear forward as the engine issues it: the kernel of its own (csrc/a2s_linear.hip: weight pre-split once,
-    activations through a four-stage LDS ring) where the shape qualifies (A2S_LINEAR_FWD=0: never), the generic two-term GEMM tile otherwise."""
+    activations through a four-stage LDS ring) where the shape qualifies (hip.LINEAR_KERNELS / A2S_LINEAR_KERNELS=0: never), the generic two-term GEMM tile otherwise."""
     M, K = x2d.shape
     N = weight.shape[0]
     L = lib()
     period = x_affine[2]
-    if (os.environ.get("A2S_LINEAR_FWD", "1") != "0" and x2d.is_contiguous() and weight.is_contiguous() and x_bound is not None
+    if (LINEAR_KERNELS and x2d.is_contiguous() and weight.is_contiguous() and x_bound is not None
             and L.a2s_linear_fwd_eligible(M, N, K, period)):
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
@@ -347,11 +362,11 @@ def linear_forward(x2d, weight, x_affine, x_bound, w_absmax, out=None):
 
 def linear_wgrad(dz, x2d, x_affine, dz_absmax, x_bound, G):
     """G (N, K) += dz^T relu(bn(x)) for the ConvStack's 19200 -> 256 Linear on the kernel of csrc/a2s_linear.hip; returns False when the shape
-    does not qualify (A2S_LINEAR_WGRAD=0: never) -- the caller then runs the generic split-K GEMM."""
+    does not qualify (hip.LINEAR_KERNELS off: never) -- the caller then runs the generic split-K GEMM."""
     M, K = x2d.shape
     N = dz.shape[1]
     L = lib()
-    if (os.environ.get("A2S_LINEAR_WGRAD", "1") == "0" or not (x2d.is_contiguous() and dz.is_contiguous() and G.is_contiguous()) or dz_absmax is None
+    if (not LINEAR_KERNELS or not (x2d.is_contiguous() and dz.is_contiguous() and G.is_contiguous()) or dz_absmax is None
             or x_bound is None or not L.a2s_linear_wgrad_eligible(M, N, K, x_affine[2])):
         return False
     nb = L.a2s_linear_wgrad_ws_bytes(M, K)

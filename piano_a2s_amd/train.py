@@ -42,7 +42,7 @@ class GradientExchange:
         self.world = world
         # active whenever a process group exists -- also with a single rank (torchrun --nproc-per-node 1): the collectives then run
         # through RCCL exactly as with N ranks, which is what lets a 1-GPU box exercise the data-parallel path end to end
-        self.active = dist.is_available() and dist.is_initialized() and _os.environ.get("A2S_NO_EXCHANGE") != "1"      # (debug: A/B without the collectives)
+        self.active = dist.is_available() and dist.is_initialized()
         self.pending = []
         self.issued = 0
 
@@ -160,6 +160,38 @@ class FusedAdadelta:
             self.lr = sd.get("lr", self.lr)
 
 
+def reserve_pools(device, batch, frames=1201, scale=1.0):
+    """Reserve the caching allocator's pools for the working set of the fused step BEFORE the first step: one block per stream the step allocates on,
+    allocated and handed straight back -- the allocator keeps the segment and carves every later request of that stream out of it (it keeps one
+    pool per stream, and the step allocates on four).  Without it the pools grow by hipMalloc for as long as new (minibatch, coin) shapes keep turning
+    up -- ~10 steps at 256 clips (tools/alloc_by_stream.py: 224, 28, 0, 0, 1, 9, 0, 3, 4, 0 ... segments per step), each a driver call of 50-130 ms
+    under load.  Sizes: what those pools hold after 24 steps at 256 clips x 1201 frames (default 155 GiB, lower-staff stream 27, long-clip groups 6-7),
+    plus 3 %, scaled by the clips x frames of the caller.  Returns the GiB reserved."""
+    per = {"default": 160.0, "side0": 1.0, "side1": 28.0, "group1": 6.5, "group2": 8.0}
+    f = scale * (batch / 256.0) * (frames / 1201.0)
+    streams = {"default": torch.cuda.current_stream(device), "side0": engine.side_streams(device)[0], "side1": engine.side_streams(device)[1],
+               "group1": engine.group_stream(device, 1), "group2": engine.group_stream(device, 2)}
+    total = 0.0
+    torch.cuda.synchronize(device)
+    torch.cuda.empty_cache()                     # (what earlier work left cached belongs to other shapes: the reservation replaces it)
+    for name, gib in sorted(per.items(), key=lambda kv: kv[1]):          # small pools first: the big one takes what is left
+        for shrink in (1.0, 0.85, 0.7, 0.5):
+            n = int(gib * f * shrink * 2 ** 30)
+            free, _ = torch.cuda.mem_get_info(device)
+            if n > free - (8 << 30):
+                continue
+            with torch.cuda.stream(streams[name]):
+                try:
+                    block = torch.empty(n, dtype=torch.uint8, device=device)
+                    del block
+                    total += n / 2 ** 30
+                    break
+                except RuntimeError:
+                    pass
+    torch.cuda.synchronize(device)
+    return total
+
+
 def plan_clip_groups(until_up, until_lo, max_tail_frac=0.5, min_gain=0.08, step_cost=150.0, jump=1.3, max_candidates=8):
     """Cut a minibatch into [ordinary clips | long clips] for Engine.forward's clip groups.
 
@@ -206,9 +238,6 @@ def plan_clip_groups(until_up, until_lo, max_tail_frac=0.5, min_gain=0.08, step_
         c = max(ct, cm, wt + wm)
         if c < best:
             best_k, best = k, c
-    extra = int(_os.environ.get("A2S_GROUP_EXTRA", "0"))          # measurement switch: that many more of the longest clips join the long group
-    if best_k is not None and extra > 0:
-        best_k = min(best_k + extra, B - 1)
     if best_k is None:
         return ident, B
     # inside the ordinary group the clips with the longest rows come first (by_len is a stable descending sort): late in a decoder call
@@ -290,7 +319,7 @@ class TrainStep:
         clips holding exceptionally long bars decode as a group of their own, concurrently with the ordinary ones (plan_clip_groups;
         Engine.forward) -- the minibatch is permuted for that, which no loss term, gradient or statistic depends on.  group_plan: keyword
         overrides of plan_clip_groups' cost model (e.g. dict(step_cost=4.0) makes a 12-clip minibatch split the way a 256-clip one does with
-        the default 150: tests/test_gpu_g4.py); A2S_GROUP_STEP_COST sets step_cost from the environment."""
+        the default 150: tests/test_gpu_g4.py)."""
         self.model = model
         # The host side of a step is a few hundred small CPU tensor operations (the decode plan).  Above ~32 k elements torch runs each of them
         # as an OpenMP region over every core of the box (256 here): one descheduled worker stalls the region, and the thread waiting for it
@@ -304,18 +333,16 @@ class TrainStep:
         self.fuse_bars = (_os.environ.get("A2S_FUSE_BARS", "1") != "0") if fuse_bars is None else bool(fuse_bars)
         # True / False, or an explicit list of contiguous clip ranges [(0, n), (n, B)] (tests: no planner, no permutation)
         self.clip_groups = (_os.environ.get("A2S_CLIP_GROUPS", "1") != "0") if clip_groups is None else clip_groups
-        # each clip group's decoder backward follows its forward at once (see __call__); A2S_PIPELINE_GROUPS=0: forward of every group,
-        # then the objective, then backward of every group
-        self.pipeline_groups = _os.environ.get("A2S_PIPELINE_GROUPS", "1") != "0"
+        # each clip group's decoder backward follows its forward at once (see __call__); False: forward of every group, then the objective,
+        # then backward of every group
+        self.pipeline_groups = True
         self.group_plan = dict(group_plan or {})
-        if "step_cost" not in self.group_plan and _os.environ.get("A2S_GROUP_STEP_COST"):
-            self.group_plan["step_cost"] = float(_os.environ["A2S_GROUP_STEP_COST"])
-        # the ConvStack is enqueued before the host plans the decoder (see _step); A2S_EARLY_CONVSTACK=0: after, as in round 4
-        self.early_convstack = _os.environ.get("A2S_EARLY_CONVSTACK", "1") != "0"
+        # the ConvStack is enqueued before the host plans the decoder (see _step); False: after, as in round 4
+        self.early_convstack = True
         # the note decoders' weight gradients beside the encoder's back-propagation instead of behind each call's reverse loop (engine_bwd.Backward)
-        self.late_wgrads = _os.environ.get("A2S_LATE_WGRADS", "1") != "0"
-        # the long-clip group cut in two by the bar segment of each clip's longest bar (split_long_group); A2S_LONG_SUBGROUPS=0: one long-clip group
-        self.long_subgroups = _os.environ.get("A2S_LONG_SUBGROUPS", "1") != "0"
+        self.late_wgrads = True
+        # the long-clip group cut in two by the bar segment of each clip's longest bar (split_long_group); False: one long-clip group
+        self.long_subgroups = True
         self.keep_grads = False            # tests: keep the last step's gradient views (name -> tensor) in self.last_grads
         self.last_grads = None
         self._last = None

@@ -74,7 +74,7 @@ def test_fused_training_step_with_the_persistent_long_clip_group(dev):
     at most 8: loss terms, gradient norm and updated parameters with the persistent path equal those with the launch-per-step path."""
     import os
     import models
-    from piano_a2s_amd import hip, synthetic, train
+    from piano_a2s_amd import engine, hip, synthetic, train
     cfg = _cfg()
     B = 24
     # clips 20..23 hold full-length bars -> the planner's long group
@@ -84,7 +84,7 @@ def test_fused_training_step_with_the_persistent_long_clip_group(dev):
     torch.manual_seed(5)
     init = models.ScoreTranscription(**cfg).state_dict()
     res = []
-    os.environ["A2S_DEC_PERSIST_BESIDE"] = "1"          # (off by default: it stops the other group while resident; correctness is what is tested here)
+    engine._PERSIST_BESIDE = True          # (off by default: it stops the other group while resident; correctness is what is tested here)
     for persist in (False, True):
         os.environ["A2S_DEC_PERSIST"] = "1" if persist else "0"
         hip.check(hip.lib().a2s_debug_set(b"dec_persist", 1 if persist else 0), "debug_set")
@@ -97,7 +97,7 @@ def test_fused_training_step_with_the_persistent_long_clip_group(dev):
         res.append((losses[:, 0].double().cpu(), step.opt.ctl.double().cpu(), step.flat.double().cpu(), step._last[2]))
         del step, m
     os.environ["A2S_DEC_PERSIST"] = "1"
-    os.environ.pop("A2S_DEC_PERSIST_BESIDE", None)
+    engine._PERSIST_BESIDE = False
     hip.check(hip.lib().a2s_debug_set(b"dec_persist", 1), "debug_set")
     (l0, c0, p0, g0), (l1, c1, p1, g1) = res
     assert g1 is not None and len(g1) == 2 and g1[1][1] - g1[1][0] <= 8, f"expected a long-clip group of at most 8 clips, got {g1}"

@@ -1,10 +1,9 @@
 """The attention combine folded into the few-row GRU step (csrc/a2s_step.hip dec_gru_step_cmb, round 5: the few-clip launches of a training step
-leave their softmax combine to the kernel that consumes the contexts -- one launch less per decode step on the long-clip chain) and the
-backward's two folds (dec_bwd_products_g: the GRU-cell backward inside the product kernel; dec_bwd_query_cmb: the sum of the dq partials inside
-the query product -- three launches per backward decode step instead of five) and the few-clip backward sweep (attn_bwd_split256_deep: every
-load of a chunk requested before anything is waited for) against the stand-alone / 256-thread kernels: the whole fused training step both ways.  The two paths use the same expressions in the same order, so the forward
+leave their softmax combine to the kernel that consumes the contexts -- one launch less per decode step on the long-clip chain) against the
+stand-alone combine kernel: the whole fused training step both ways.  The two paths use the same expressions in the same order, so the forward
 outputs must be IDENTICAL; the backward (which reads the contexts / normalised weights the folded combine left in memory, including the zeros of
-skipped rows) must agree to rounding of its atomics."""
+skipped rows) must agree to rounding of its atomics.  (Round 5 also folded the backward's gate kernel and dq sum into its products and had a
+512-thread backward sweep: measured slower, removed in round 6 -- HISTORY.md.)"""
 import random
 
 import pytest
@@ -20,8 +19,8 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("B,tf,full_tail,bwd_sweep", [(6, 0.6, 0.1, 1), (20, 0.5, 0.0, 1), (3, 0.0, 0.3, 1), (6, 0.6, 0.1, 2), (20, 0.5, 0.0, 2)])
-def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail, bwd_sweep):
+@pytest.mark.parametrize("B,tf,full_tail", [(6, 0.6, 0.1), (20, 0.5, 0.0), (3, 0.0, 0.3)])
+def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail):
     import models
     from piano_a2s_amd import hip, spec, synthetic, train
     L = hip.lib()
@@ -30,14 +29,12 @@ def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail, bwd_sweep):
     dbatch = [t.to(dev) if torch.is_tensor(t) else t for t in batch]
     torch.manual_seed(9)
     init = models.ScoreTranscription(**cfg).state_dict()
-    prev = (L.a2s_debug_get(b"attn_defer_combine"), L.a2s_debug_get(b"dec_persist"), L.a2s_debug_get(b"dec_bwd_fold"), L.a2s_debug_get(b"attn_deep_bwd"))
+    prev = (L.a2s_debug_get(b"attn_defer_combine"), L.a2s_debug_get(b"dec_persist"))
     res = []
     try:
         hip.check(L.a2s_debug_set(b"dec_persist", 0), "debug_set")       # (<= 8 clips would take the persistent decoder: this test is about the launch-per-step kernels)
         for defer in (0, 1):
             hip.check(L.a2s_debug_set(b"attn_defer_combine", defer), "debug_set")
-            hip.check(L.a2s_debug_set(b"dec_bwd_fold", defer), "debug_set")       # (the backward's folds: dec_bwd_products_g, dec_bwd_query_cmb)
-            hip.check(L.a2s_debug_set(b"attn_deep_bwd", bwd_sweep if defer else 0), "debug_set")      # (the few-clip backward sweep: attn_bwd_split256_deep, 1 = loads up front, 2 = wide)
             m = models.ScoreTranscription(**cfg)
             m.load_state_dict(init)
             m = m.to(dev).train()
@@ -51,10 +48,8 @@ def test_folded_combine_equals_combine_kernel(dev, B, tf, full_tail, bwd_sweep):
     finally:
         hip.check(L.a2s_debug_set(b"attn_defer_combine", prev[0]), "debug_set")
         hip.check(L.a2s_debug_set(b"dec_persist", prev[1]), "debug_set")
-        hip.check(L.a2s_debug_set(b"dec_bwd_fold", prev[2]), "debug_set")
-        hip.check(L.a2s_debug_set(b"attn_deep_bwd", prev[3]), "debug_set")
     (l0, c0, p0, n_sep, o0), (l1, c1, p1, n_fold, o1) = res
-    assert n_fold < 0.93 * n_sep, f"the folded kernels must have been taken: {n_fold} launches against {n_sep}"
+    assert n_fold < 0.97 * n_sep, f"the folded kernel must have been taken: {n_fold} launches against {n_sep}"
     from piano_a2s_amd.spec import PAD
     live = {"up": (batch[3] != PAD).to(dev), "lo": (batch[5] != PAD).to(dev)}       # (the fused step leaves positions with <pad> targets unwritten)
     for a, b, name in zip(o0, o1, ("ts", "key", "up", "lo")):

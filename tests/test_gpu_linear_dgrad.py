@@ -100,11 +100,11 @@ def test_linear_forward_kernel(dev, M, channels, period):
     ymax = y.view(M, channels, period).abs().amax(dim=(0, 2)).contiguous()
     bound, wmax = hip.act_bound(scale, shift, ymax), hip.absmax(W)
     z_new = hip.linear_forward(y, W, (scale, shift, period), bound, wmax)
-    os.environ["A2S_LINEAR_FWD"] = "0"
+    hip.LINEAR_KERNELS = False                    # (the generic two-term GEMM tiles)
     try:
         z_old = hip.linear_forward(y, W, (scale, shift, period), bound, wmax)
     finally:
-        os.environ.pop("A2S_LINEAR_FWD", None)
+        hip.LINEAR_KERNELS = True
     torch.cuda.synchronize()
     ch = torch.arange(K, device=dev) // period
     a = torch.relu(y.double() * scale.double()[ch] + shift.double()[ch])

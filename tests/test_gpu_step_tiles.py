@@ -51,7 +51,8 @@ def test_mid_size_step_kernels_equal_tiled_gemm_step(dev, B):
     assert mid0 == 0, "the baseline must not have used the mid-size kernels"
     for name, (l1, c1, p1, n1, mid1, _) in zip(("bulk loop", "few-row path"), rest):
         assert n1 < 0.9 * n_tiled, f"{name}: {n1} launches against {n_tiled}"
-        assert mid1 >= steps, f"{name}: {mid1} mid-size launches for {steps} decode steps (forward alone would be one per step)"
+        # (the bulk loop: one dec_gru_mid per forward step and one dec_bwd_mid per backward step; the few-row path: only its launches over > 160 rows)
+        assert mid1 >= (steps if name == "bulk loop" else 1), f"{name}: {mid1} mid-size launches for {steps} decode steps"
         assert torch.isfinite(l1).all() and float(c1[2]) == 1.0
         assert torch.allclose(l0, l1, rtol=2e-5, atol=0), (name, l0, l1)
         assert abs(float(c0[0]) - float(c1[0])) <= 1e-4 * float(c0[0]), (name, c0, c1)

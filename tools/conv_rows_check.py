@@ -11,7 +11,7 @@ from piano_a2s_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 L = hip.lib()
-ROWS = int(os.environ.get("ROWS", "3"))          # conv_rows switch: 1 = first generation everywhere, 3 = rows16 where it exists (default)
+ROWS = int(os.environ.get("ROWS", "7"))          # conv_rows switch: 1 = first generation everywhere, 3 = rows16 where it exists, 7 / 15 = + its two-accumulator-set form
 
 
 def fwd(x, w, scale, shift, rows):
@@ -122,7 +122,7 @@ def bench(B):
         yl = torch.randn(B, T, co, F, device=dev) if flip else None
         bn = [torch.randn(co, device=dev) * 0.1, torch.rand(co, device=dev) + 0.5, torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev) * 0.1]
         res = {}
-        for rows in (0, 1, 3):
+        for rows in (0, 1, 3, 7, 15):         # 7 / 15: rows16 with two accumulator sets for the forward / forward + data-gradient launches (round 6)
             hip.check(L.a2s_debug_set(b"conv_rows", rows), "set")
             nblk = L.a2s_conv3x3_stat_blocks(B, T, F, ci)
             partial = torch.empty(nblk, co, 2, device=dev)
@@ -135,10 +135,12 @@ def bench(B):
                 fn = lambda: hip.check(L.a2s_conv3x3(hip.stream(), hip._p(x), hip._p(w), hip._p(y), hip._p(scale), hip._p(shift), hip._p(partial), B, T, F, ci, co, 0,
                                                      hip._p(cws)), "conv")
             res[rows] = timed(fn)
-        hip.check(L.a2s_debug_set(b"conv_rows", 3), "set")
+        hip.check(L.a2s_debug_set(b"conv_rows", ROWS), "set")
         fl = 2.0 * 9 * ci * co * B * T * F
         gb = 4.0 * B * T * F * (ci + co + (co if flip else 0))
-        print(f"{what:12s} {ci:2d}->{co:2d} B={B}: tiled {res[0]:7.2f} ms   rows {res[1]:7.2f} ms   rows16 {res[3]:7.2f} ms = {fl / res[3] / 1e9:6.1f} TFLOP/s, {gb / res[3] / 1e6:5.0f} GB/s algorithmic", flush=True)
+        best = min(res[3], res[7], res[15])
+        print(f"{what:12s} {ci:2d}->{co:2d} B={B}: tiled {res[0]:7.2f} ms   rows {res[1]:7.2f} ms   rows16 {res[3]:7.2f} ms   two sets fwd {res[7]:7.2f} / fwd+dgrad {res[15]:7.2f} ms"
+              f" = {fl / best / 1e9:6.1f} TFLOP/s, {gb / best / 1e6:5.0f} GB/s algorithmic", flush=True)
         del x, y, yl
 
 
