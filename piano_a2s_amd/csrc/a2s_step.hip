@@ -442,15 +442,18 @@ __global__ __launch_bounds__(256) void dec_gru_mid(DecGruArgs a) {
             }
         }
     };
-    f32x4 bv[3], a_cur[4], a_nxt[4];
+    // the wave's own rows are TWO chunks ahead (they were written by the previous launch, on any XCD: the longest round trip of the kernel -- in the
+    // step, beside the other staff's sweep, 3-5 us against 0.7 us of multiply per chunk), the weight chunk two ahead in registers, one in LDS
+    f32x4 bv[3], a_cur[4], a_n1[4], a_n2[4];
     bload(0, bv);
     aload(0, a_cur);
+    if (nc > 1) aload(1, a_n1);
     bstore(0, bv);
     if (nc > 1) bload(1, bv);
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
+        if (c + 2 < nc) aload(c + 2, a_n2);
         if (c + 1 < nc) {
-            aload(c + 1, a_nxt);
             bstore((c + 1) & 1, bv);                       // (that buffer was last read in iteration c - 1, which ended with a barrier)
             if (c + 2 < nc) bload(c + 2, bv);
         }
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void dec_gru_mid(DecGruArgs a) {
         else compute(std::false_type{}, c, c & 1, a_cur);
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a_cur[u] = a_nxt[u];
+        for (int u = 0; u < 4; ++u) { a_cur[u] = a_n1[u]; a_n1[u] = a_n2[u]; }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -688,15 +691,16 @@ __device__ __forceinline__ void mid_product_64x32(const float* __restrict__ ar, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(ar + c * MID_KC + 16 * u);
     };
-    f32x4 bv[2], a_cur[4], a_nxt[4];
+    f32x4 bv[2], a_cur[4], a_n1[4], a_n2[4];             // (the wave's rows two chunks ahead, as in dec_gru_mid)
     bload(0, bv);
     aload(0, a_cur);
+    if (nc > 1) aload(1, a_n1);
     bstore(0, bv);
     if (nc > 1) bload(1, bv);
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
+        if (c + 2 < nc) aload(c + 2, a_n2);
         if (c + 1 < nc) {
-            aload(c + 1, a_nxt);
             bstore((c + 1) & 1, bv);                       // (that buffer was last read in iteration c - 1, which ended with a barrier)
             if (c + 2 < nc) bload(c + 2, bv);
         }
@@ -714,7 +718,7 @@ __device__ __forceinline__ void mid_product_64x32(const float* __restrict__ ar, 
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a_cur[u] = a_nxt[u];
+        for (int u = 0; u < 4; ++u) { a_cur[u] = a_n1[u]; a_n1[u] = a_n2[u]; }
     }
 }
 

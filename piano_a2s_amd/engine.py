@@ -132,8 +132,6 @@ def _trace(label):
 
 _GROUP_STREAMS = {}
 _GROUP_POOL = None
-_LONG_LOWER_STREAMS = {}
-_LONG_STAVES_EXTRA = _os.environ.get("A2S_X_LONG_STAVES") == "1"      # EXPERIMENT (round 6): the long sub-groups' lower staves on streams of their own
 
 
 def staff_streams(device, group):
@@ -144,11 +142,6 @@ def staff_streams(device, group):
     of its own and the long-clip group's two staves run side by side instead of one after the other (1292 -> 876 dependent steps)."""
     cur = torch.cuda.current_stream()
     side = side_streams(device, 0)
-    if group >= 1 and _LONG_STAVES_EXTRA:
-        key = (_dev_index(device), group)
-        if key not in _LONG_LOWER_STREAMS:
-            _LONG_LOWER_STREAMS[key] = torch.cuda.Stream(device=key[0])
-        return (cur, _LONG_LOWER_STREAMS[key])
     return (cur, side[1]) if group == 0 else (cur, side[0])
 
 
@@ -174,8 +167,10 @@ def group_stream(device, group):
 
 def staves_concurrent(gidx, n_groups):
     """Do the two note decoders of clip group gidx run side by side on two streams?  Group 0 always; the long-clip group when it is the only one beside
-    it; with two long-clip sub-groups each of them runs upper then lower on its one stream (four streams in all, see group_stream)."""
-    return gidx == 0 or (gidx == 1 and n_groups == 2) or _LONG_STAVES_EXTRA
+    it; with two long-clip sub-groups each of them runs upper then lower on its one stream (four streams in all, see group_stream).  Round 6
+    re-measured the alternative -- the sub-groups' lower staves on two more streams: 442 -> 456 ms per step on the four hardware queues (the
+    extra streams share queues with the others and wait in line), 493 with GPU_MAX_HW_QUEUES=6 or 8 (profiles/r06_long_staves_streams.txt)."""
+    return gidx == 0 or (gidx == 1 and n_groups == 2)
 
 
 def draw_plan(gt_cpu, bars, maxlen, rng, teacher_forcing_ratio):

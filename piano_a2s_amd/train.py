@@ -166,7 +166,7 @@ def reserve_pools(device, batch, frames=1201, scale=1.0):
     pool per stream, and the step allocates on four).  Without it the pools grow by hipMalloc for as long as new (minibatch, coin) shapes keep turning
     up -- ~10 steps at 256 clips (tools/alloc_by_stream.py: 224, 28, 0, 0, 1, 9, 0, 3, 4, 0 ... segments per step), each a driver call of 50-130 ms
     under load.  Sizes: what those pools hold after 24 steps at 256 clips x 1201 frames (default 155 GiB, lower-staff stream 27, long-clip groups 6-7),
-    plus 3 %, scaled by the clips x frames of the caller.  Returns the GiB reserved."""
+    plus 3 %, scaled by the clips x frames of the caller, in blocks of 24 GiB.  Returns the GiB reserved."""
     per = {"default": 160.0, "side0": 1.0, "side1": 28.0, "group1": 6.5, "group2": 8.0}
     f = scale * (batch / 256.0) * (frames / 1201.0)
     streams = {"default": torch.cuda.current_stream(device), "side0": engine.side_streams(device)[0], "side1": engine.side_streams(device)[1],
@@ -174,20 +174,23 @@ def reserve_pools(device, batch, frames=1201, scale=1.0):
     total = 0.0
     torch.cuda.synchronize(device)
     torch.cuda.empty_cache()                     # (what earlier work left cached belongs to other shapes: the reservation replaces it)
+    chunk = 24.0 * max(f, 0.25)          # GiB per block: the step's largest tensors (the 40-channel activations, 22 GiB at 256 clips) fit in one; a single
+    held = []                              # allocation of the whole default pool (160 GiB) is refused by the runtime
     for name, gib in sorted(per.items(), key=lambda kv: kv[1]):          # small pools first: the big one takes what is left
-        for shrink in (1.0, 0.85, 0.7, 0.5):
-            n = int(gib * f * shrink * 2 ** 30)
-            free, _ = torch.cuda.mem_get_info(device)
-            if n > free - (8 << 30):
-                continue
-            with torch.cuda.stream(streams[name]):
-                try:
-                    block = torch.empty(n, dtype=torch.uint8, device=device)
-                    del block
-                    total += n / 2 ** 30
+        want = gib * f
+        with torch.cuda.stream(streams[name]):
+            while want > 0.25:
+                n = int(min(want, chunk) * 2 ** 30)
+                free, _ = torch.cuda.mem_get_info(device)
+                if n > free - (12 << 30):
                     break
+                try:
+                    held.append(torch.empty(n, dtype=torch.uint8, device=device))
                 except RuntimeError:
-                    pass
+                    break
+                total += n / 2 ** 30
+                want -= n / 2 ** 30
+    del held                               # back to the allocator: the segments stay cached, one pool per stream
     torch.cuda.synchronize(device)
     return total
 
