@@ -689,7 +689,7 @@ _SYNC_FUSED = True
 # The 19200 -> 256 Linear's weight gradient beside its data gradient on the weight-gradient stream (round 5) or behind it on the main stream.  Round 6
 # A/B (tools/step_time.py, 12 steps, alternating processes, profiles/r06_ab_switches.txt): beside 446.9 / 445.9 ms, behind 443.6 / 444.5 -- the data
 # gradient is on the backward's critical chain and runs 15.1 ms alone against 20.4 beside the weight gradient: behind.
-_LIN_WGRAD_OVERLAP = False
+_LIN_WGRAD_AT = "before"
 _FUSE_BN_ROWS = os.environ.get("A2S_FUSE_BN_ROWS", "1") != "0"        # BatchNorm-backward apply inside the row-streaming weight gradient's staging
 
 
@@ -777,18 +777,24 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         def lin_wgrad():
             if not hip.linear_wgrad(dz, y4, (bn4[2], bn4[3], F), dz_amax, cs["abound"][3], G["convstack.out.weight"]):       # round 4: csrc/a2s_linear.hip
                 _linear_bwd(y4, Wout, dz, G, "convstack.out.weight", None, x_affine=(bn4[2], bn4[3], F), dy_amax=dz_amax, x_bound=cs["abound"][3])
-        lin_overlap = _LIN_WGRAD_OVERLAP
-        if lin_overlap:
-            # round 5: the Linear's weight gradient (reads y4 once, 10-13 ms) and its data gradient (writes da, re-reads y4, 15 ms) only share dz: the
-            # weight gradient goes to the weight-gradient stream (idle by now: the decoder is over) and runs BESIDE the data gradient; the main stream
-            # joins it at the end of the ConvStack backward
+        # Where the Linear's weight gradient (reads y4 once, 10-11 ms alone; nothing but the optimizer waits for it) runs -- _LIN_WGRAD_AT:
+        #   "before"  on the main stream in front of the data gradient (on the backward's critical chain);
+        #   "beside"  round 5: on the weight-gradient stream beside the data gradient;
+        #   4 / 3 / 2 on the weight-gradient stream from the moment layer i's weight gradient is enqueued on the main stream (beside the later, smaller
+        #             launches of the chain); the main stream joins that stream at the end of the ConvStack backward.
+        lin_at = _LIN_WGRAD_AT
+        lin_overlap = lin_at != "before"
+
+        def lin_wgrad_side():
             wg_stream = _weight_grad_stream(dev)
             ev = torch.cuda.Event()
             ev.record()
             wg_stream.wait_event(ev)
             with torch.cuda.stream(wg_stream):
                 lin_wgrad()
-        else:
+        if lin_at == "beside":
+            lin_wgrad_side()
+        elif lin_at == "before":
             lin_wgrad()
         if _DGRAD_BNSTATS and (not eng.sync_bn or _SYNC_FUSED) and F >= 128 and F % 4 == 0 and rows > 64:      # (the epilogue lives in the 128-row GEMM tile)
             # data gradient of the Linear with the layer-4 BatchNorm-backward statistics accumulated in the GEMM's epilogue
@@ -831,6 +837,8 @@ def _convstack_bwd(eng, S, G, cs, d_out, B, T, F):
         dy_amax = torch.zeros(1, dtype=torch.float32, device=dev) if (i > 1 and (not eng.sync_bn or _SYNC_FUSED)) else None
         fuse_rows = (_FUSE_BN_ROWS and (not eng.sync_bn or _SYNC_FUSED) and i > 1 and g_amax is not None and g_partial is not None and in_bn is not None
                      and L.a2s_conv3x3_wgrad_bn_ranged_eligible(F, ci, co))
+        if a4 is None and lin_at == i:
+            lin_wgrad_side()
         if fuse_rows:
             # round 4: BatchNorm backward as statistics only; dy is formed by the STAGING waves of the row-streaming weight-gradient kernel (they
             # wait 40-57 % of their time for the multiply waves), written once for the data-gradient convolution: one pass over (g, y) less
