@@ -768,8 +768,8 @@ def main():
                                         "fp32 operand carried as TWO exact fp16 terms under power-of-two scales derived from operand ranges the producing "
                                         "kernels write (three term products per fp32 product), the other 128x128 GEMM tiles on the bf16 pipes with three "
                                         "bf16 terms (six products); element error vs float64 equal to the fp32-input MFMA kernels' (DESIGN.md section 5); "
-                                        "A2S_CONV_ROWS=0 selects round 2's tiled convolutions, A2S_CONV_F16X2=0 A2S_WGRAD_F16X2=0 the three-term "
-                                        "kernels, A2S_CONV_BF16X3=0 A2S_GEMM_BF16X3=0 A2S_WGRAD_BF16X3=0 the fp32-input ones",
+                                        "A2S_CONV_ROWS=0 selects round 2's tiled convolutions, A2S_ARITH=bf16x3 the three-term "
+                                        "kernels, A2S_ARITH=f32 the fp32-input ones",
                           "final_loss": round(loss, 4), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}}
         if secondary is not None:
             out["tail_off"] = secondary

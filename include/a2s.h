@@ -57,7 +57,7 @@ int a2s_gemm_f32_bnstats(void* stream, int M, int N, int K, const float* A, long
  * fp32-level accuracy; 128x128 tiles with k- or row-contiguous operands, otherwise the call runs as the unscaled entry): a_absmax /
  * b_absmax are device scalars holding max |A| / max |B| (a2s_absmax, or the BatchNorm backward's a2s_bn_bwd_amax), from which the kernel
  * derives exact power-of-two operand scales; NULL = that operand is O(1) (post-BatchNorm activations) and is used as is.  Switch:
- * a2s_debug_set("gemm_f16x2", 0/1), environment A2S_GEMM_F16X2 (default 1). */
+ * a2s_debug_set("gemm_f16x2", 0/1) (default 1; environment: A2S_ARITH). */
 int a2s_gemm_f32_affine_scaled(void* stream, int M, int N, int K, float alpha, const float* A, long sAm, long sAk, const float* B, long sBk,
                                long sBn, float beta, float* C, long ldc, const float* bias, int act, int batch, long bsA, long bsB, long bsC,
                                int splitk, float* workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_period,
@@ -104,10 +104,11 @@ void a2s_gemm_debug_tile(int cfg);
  * (default 3; 0 = the fp32-input MFMA kernel everywhere); "gemm_bf16x3" 0/1 -- the same split for 128x128 GEMM tiles whose two
  * operands are k- or row-contiguous (default 1); "wgrad_bf16x3" 0/1/2 -- the split-operand weight-gradient convolution: 1 (default) where it is
  * faster than conv3x3_wgrad (40 -> 40 channels), 2 every eligible launch;
- * "attn_defer_combine" 0/1 (default 1, A2S_ATTN_DEFER_COMBINE): inside a2s_note_decoder_fwd, the few-clip attention launches of a training call
+ * "attn_defer_combine" 0/1 (default 1): inside a2s_note_decoder_fwd, the few-clip attention launches of a training call
  * leave their softmax combine to the GRU-step kernel that consumes the contexts (csrc/a2s_step.hip dec_gru_step_cmb; same bits as the combine
- * kernel); "dec_bwd_fold" 0/1 (default 0, A2S_DEC_BWD_FOLD): the corresponding folds of a2s_note_decoder_bwd (measured slower, parity-tested);
- * "attn_deep" n (A2S_ATTN_DEEP, default 24): training launches over at most n clips use the one-round-trip forward sweep */
+ * kernel); "dec_mid" 0/1 (default 1, round 6): the launch-per-step loop's GRU cell, output + next query and backward products on the mid-size
+ * fused kernels (0: library-style products; read-only "dec_mid_launches" counts them);
+ * "attn_deep" n (default 24): training launches over at most n clips use the one-round-trip forward sweep */
 int a2s_debug_set(const char* key, int value);
 int a2s_debug_get(const char* key);   /* current value of "conv_bf16x3" / "gemm_bf16x3" / "wgrad_bf16x3" / "gru_fused"; -1 for an unknown key;
                                         * also "device_cus" / "device_xccs": compute units and XCDs the runtime reports for the current device */
@@ -247,7 +248,7 @@ typedef struct a2s_note_dec_args {
     int R, T, H, E, V, steps, poll, eos_id;
     int use_graph;                    /* greedy decode (gt NULL, nothing saved for backward): capture `poll` steps into a hipGraph and replay */
     float* step_ws; size_t step_ws_floats;   /* a2s_note_step_workspace_floats(H, E) floats or NULL: scratch of the fused few-row step kernels
-                                                (csrc/a2s_step.hip: 4 launches per step instead of 9-13; used when R <= A2S_DEC_FUSED_MAX_ROWS) */
+                                                (csrc/a2s_step.hip: 4 launches per step instead of 9-13; used when R <= "dec_fused_max_rows", default 192; above that the launch-per-step loop with the mid-size kernels dec_gru_mid / dec_outq_mid / dec_bwd_mid) */
     /* round 4: ONE persistent launch for every step of the call when it covers at most 8 clips (csrc/a2s_dec_persist.hip: one clip per XCD,
        keys / encoder outputs resident in LDS, weights in registers).  Needs the teacher-forcing flags on the device too and a scratch area: */
     const int* tf_flags_dev;          /* device, `steps` ints: the same bits as tf_flags (NULL with tf_flags NULL) */

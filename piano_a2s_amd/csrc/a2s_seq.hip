@@ -244,7 +244,7 @@ int a2s_skinny_gemm_acc_impl(hipStream_t st, const float* A, long lda, const flo
     return A2S_OK;
 }
 
-static int g_gru_fused = -1;                                 // A2S_GRU_FUSED=0 / a2s_debug_set("gru_fused", 0): the three-launch step (A/B measurements)
+static int g_gru_fused = -1;                                 // a2s_debug_set("gru_fused", 0): the three-launch step (A/B measurements)
 void a2s_gru_step_fused_set(int v) { g_gru_fused = v ? 1 : 0; }
 bool a2s_gru_step_fused_enabled(void) {
     if (g_gru_fused < 0) g_gru_fused = 1;
@@ -704,7 +704,7 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
 }
 
 // ------------------------------------------------------------------------------------------- staff embedding
-static int g_staff_emb_fast = -1;       // the E = 16, S = 32 kernels (A2S_STAFF_EMB_FAST=0 / a2s_debug_set("staff_emb_fast", 0): the generic ones)
+static int g_staff_emb_fast = -1;       // the E = 16, S = 32 kernels (a2s_debug_set("staff_emb_fast", 0): the generic ones)
 void a2s_staff_emb_fast_set(int v) { g_staff_emb_fast = v ? 1 : 0; }
 int a2s_staff_emb_fast_enabled(void) {
     if (g_staff_emb_fast < 0) g_staff_emb_fast = 1;
@@ -891,7 +891,7 @@ __device__ __forceinline__ void attn_combine_row(const volatile float* pb, int G
     float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) { acc0 = fmaf(p0[u], wgt[u], acc0); acc1 = fmaf(p1[u], wgt[u], acc1); }
-    for (int g0 = 16; g0 < G; g0 += 16) {             // (only with A2S_ATTN_MAX_SPLIT > 16)
+    for (int g0 = 16; g0 < G; g0 += 16) {             // (only if a2s_attn_max_split() > 16)
         float q0[16], q1[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
 // covers a handful of clips, every workgroup has a CU to itself and the kernel's time IS its dependent round trips (each 2-3x longer while the bulk group's
 // sweeps saturate the memory: DESIGN.md section 3.4).  Here every load of the chunk is issued before anything is waited for: 8 waves, a wave holds the
 // key rows of its <= 10 frames, a thread its float4 column of <= 20 encoder rows (116 registers), ONE round trip.  Same partial layout and raw scores
-// as attn_fwd_split256[_mq]: the combine kernel does not change.  Launches over at most A2S_ATTN_DEEP (default 24) clips, chunks of <= 80 frames.
+// as attn_fwd_split256[_mq]: the combine kernel does not change.  Launches over at most a2s_debug_set("attn_deep") (default 24) clips, chunks of <= 80 frames.
 template <int NQ>
 __global__ __launch_bounds__(512) void attn_fwd_split256_deep(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                               const float* __restrict__ q, long ldq, const float* __restrict__ v,
@@ -1355,7 +1355,7 @@ size_t a2s_attn_workspace_floats_impl(int B, int T, int H, int groups) {
     return A2S_ATTN_TICKETS + rows * (groups > 0 ? groups : 1) * (2 * H + 4);
 }
 
-// Fused combine (OFF by default; a2s_debug_set("attn_fused_combine", 1) / A2S_ATTN_FUSED_COMBINE=1): the split kernels' last-arriving
+// Fused combine (OFF by default; a2s_debug_set("attn_fused_combine", 1)): the split kernels' last-arriving
 // workgroup per clip merges the partials, no separate combine launch.  Parity-tested, and measured SLOWER in the training step (632 ->
 // 692 ms): every one of the ~770 workgroups of a launch pays a device-scope release (L2 write-back) before its ticket and the last one
 // an acquire (L2 invalidate) -- on an 8-XCD part that costs more than the 7 us launch it saves and evicts the other streams' lines.
@@ -1416,7 +1416,7 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     A2S_REQUIRE(groups <= A2S_ATTN_MAX_GROUPS, "attn_step_fwd_split: at most %d fused bars (got %d)", A2S_ATTN_MAX_GROUPS, groups);
     A2S_REQUIRE(r.n_active >= 0 && r.n_active <= r.n_clips && (!r.clip_order || r.clip_rank), "attn_step_fwd_split: bad row compaction");
     A2S_REQUIRE(groups == 1 || !n_done, "attn_step_fwd_split: fused bars are a training-only path");
-    A2S_REQUIRE(a2s_attn_max_split() <= 64, "attn_step_fwd_split: A2S_ATTN_MAX_SPLIT must be <= 64");
+    A2S_REQUIRE(a2s_attn_max_split() <= 64, "attn_step_fwd_split: the split must be <= 64");
     int G = 1, chunk = T;
     // workspace: [A2S_ATTN_TICKETS ints: arrival counters, zero between launches (the allocation must be zero-initialised once)] [partials]
     int* tickets = reinterpret_cast<int*>(ws);
@@ -1429,7 +1429,7 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     const int n_zero = fused ? r.n_clips - r.n_active : 0;
     const AttnFusedTail ft = {fused ? tickets : nullptr, ctx, ldctx, ctx2, ldctx2, r.n_active, B};
     // streaming (non-temporal) K / enc loads when many clips are active: the sweep is far larger than any cache, and the lines of a
-    // concurrently decoding few-clip group (its K / enc and its weights) then survive in L2 / Infinity Cache (A2S_ATTN_NT)
+    // concurrently decoding few-clip group (its K / enc and its weights) then survive in L2 / Infinity Cache ("attn_nt")
     const bool nt = a2s_attn_nt_enabled() > 0 && r.n_active >= a2s_attn_nt_enabled();
     if (r.n_active > 0 || n_zero > 0) {
         // the grid covers the clips that still have unfinished rows, re-split so that it still fills the chip

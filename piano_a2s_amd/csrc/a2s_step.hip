@@ -17,7 +17,7 @@
 //
 // All operands are K-contiguous rows fetched straight from L2 with 16-byte loads (no LDS staging, as gru_step_fwd_fused); the 8 waves
 // of a workgroup take the 16-wide k-steps round robin and their partial tiles meet in a fixed-order tree through LDS (deterministic).
-// Used when the call has at most A2S_DEC_FUSED_MAX_ROWS rows (default 192): with many rows every workgroup re-reads the weights from
+// Used when the call has at most a2s_debug_set("dec_fused_max_rows") rows (default 192): with many rows every workgroup re-reads the weights from
 // L2 and the tiled GEMMs win again (they only run under the other staff's attention there anyway).
 #include "a2s_common.h"
 #include <type_traits>

@@ -109,7 +109,7 @@ _PERSIST_BESIDE = False
 def bar_attn_workspace(device, group, n_clips, T, H):
     """Workspace of the split-T attention kernels for the BAR-level decoder's attention of one clip group (forward and backward; one per (device,
     group, shape), zero-initialised once as the kernels require, never shared with the note decoders' calls, which may run beside it).  None: the
-    one-workgroup-per-clip kernels (small groups, other widths, A2S_BAR_ATTN_SPLIT=0)."""
+    one-workgroup-per-clip kernels (small groups, other widths, engine._BAR_ATTN_SPLIT = False)."""
     if not _BAR_ATTN_SPLIT or H != 256 or n_clips < 32:
         return None
     key = (_dev_index(device), group, n_clips, T)

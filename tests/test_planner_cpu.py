@@ -88,3 +88,31 @@ def test_plan_clip_groups_small_batches_stay_whole():
     up, lo = _untils(B=3)
     order, n_main = train.plan_clip_groups(up, lo)
     assert n_main == 3 and order.tolist() == [0, 1, 2]
+
+
+def test_plan_step_groups_matches_the_g4b_fixture():
+    """train.plan_step_groups is the product's whole clip-group decision as a pure function of the targets and the coins: on the g4b minibatch and seed it
+    forms the THREE groups the fixture's generator stored (tests/golden/make_golden.py g4b ran the same function next to the reference), draws the coins
+    in the reference's order (1170 draws, the reference's count), and without sub-groups the same minibatch is two groups."""
+    import json
+    import os
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4b_step.json")))
+    cfg = spec.default_cfg()
+    kw = dict(meta["batch_kwargs"])
+    kw["upper_range"], kw["lower_range"] = tuple(kw["upper_range"]), tuple(kw["lower_range"])
+    batch = synthetic.make_batch(meta["batch"], cfg, meta["batch_seed"], full_rows=[tuple(r) for r in meta["full_rows"]], **kw)
+    gt = [batch[3], batch[5], batch[4], batch[6]]
+
+    class Counting(random.Random):
+        n = 0
+
+        def random(self):
+            Counting.n += 1
+            return super().random()
+    order, cuts, plan = train.plan_step_groups(gt, cfg["max_bars"], cfg["max_length"], Counting(meta["random_seed"]), meta["tf"], meta["plan_kw"], True)
+    assert [list(c) for c in cuts] == meta["clip_groups"] and len(cuts) == 3
+    assert order.tolist() == meta["clip_order"]
+    assert plan is not None and Counting.n == meta["draws"]
+    order2, cuts2, plan2 = train.plan_step_groups(gt, cfg["max_bars"], cfg["max_length"], random.Random(meta["random_seed"]), meta["tf"], meta["plan_kw"], False)
+    assert cuts2 == [(0, 10), (10, 12)] and plan2 is None
+    assert sorted(order2.tolist()) == list(range(meta["batch"]))
