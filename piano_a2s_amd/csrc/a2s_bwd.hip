@@ -853,8 +853,12 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
 
 // Fused bars (see attn_fwd_split256_mq): NQ rows of one clip per workgroup, the clip's enc and K chunk streamed once for all of them.
 #define ATT_DCS 516             // floats per row of the dctx image in LDS (2H + 4: the rows of a clip land 4 banks apart)
+#ifndef ATT_BWD_MQ_WAVES
+#define ATT_BWD_MQ_WAVES 4        // waves per SIMD the register budget is sized for (launch bounds); ATT_BWD_MQ_KPRE: K tiles of pass B requested ahead of pass A
+#define ATT_BWD_MQ_KPRE 2
+#endif
 template <int NQ, bool NT>
-__global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
+__global__ __launch_bounds__(256, ATT_BWD_MQ_WAVES) void attn_bwd_split256_mq(const float* __restrict__ Kmat, const float* __restrict__ enc,
                                                             const float* __restrict__ q, long ldq, const float* __restrict__ v,
                                                             const float* __restrict__ attw, const float* __restrict__ ctx, long ldctx,
                                                             const float* __restrict__ dctx_a, long ldda, const float* __restrict__ dctx_b, long lddb,
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_split256_mq(const float* __re
     __syncthreads();
     // the first two K tiles of pass B (frames rg + 4 u + 16 p) are requested HERE: they arrive while pass A multiplies
     const int c4 = tid & 63, rg = tid >> 6;
-    constexpr int KPRE = 2;
+    constexpr int KPRE = ATT_BWD_MQ_KPRE;
     f32x4 kpre[KPRE][4];
 #pragma unroll
     for (int p = 0; p < KPRE; ++p)

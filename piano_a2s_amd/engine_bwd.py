@@ -686,9 +686,9 @@ _DGRAD_BNSTATS = True           # BatchNorm-backward statistics in the data-grad
 # synchronised BatchNorm keeps the fused backward paths (statistics from the producers' partials, ONE small all-reduce per layer, the input gradient
 # formed inside the weight-gradient kernel): round 5; False = round 4's separate statistics + apply passes
 _SYNC_FUSED = True
-# The 19200 -> 256 Linear's weight gradient beside its data gradient on the weight-gradient stream (round 5) or behind it on the main stream.  Round 6
-# A/B (tools/step_time.py, 12 steps, alternating processes, profiles/r06_ab_switches.txt): beside 446.9 / 445.9 ms, behind 443.6 / 444.5 -- the data
-# gradient is on the backward's critical chain and runs 15.1 ms alone against 20.4 beside the weight gradient: behind.
+# Where the 19200 -> 256 Linear's weight gradient runs (see _convstack_bwd).  Round 6 A/Bs (profiles/r06_ab_switches.txt, r06_ab_lin_wgrad_placement.txt): in
+# front of the data gradient on the main stream 454.6 ms per step, beside it on the weight-gradient stream (round 5) 454.5, beside conv4's / conv3's /
+# conv2's weight gradient 456.9 / 456.3 / 463.3 -- no placement of this 11 ms launch moves the step; the simplest is the default.
 _LIN_WGRAD_AT = "before"
 _FUSE_BN_ROWS = os.environ.get("A2S_FUSE_BN_ROWS", "1") != "0"        # BatchNorm-backward apply inside the row-streaming weight gradient's staging
 

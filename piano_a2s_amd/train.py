@@ -167,7 +167,9 @@ def reserve_pools(device, batch, frames=1201, scale=1.0):
     up -- ~10 steps at 256 clips (tools/alloc_by_stream.py: 224, 28, 0, 0, 1, 9, 0, 3, 4, 0 ... segments per step), each a driver call of 50-130 ms
     under load.  Sizes: what those pools hold after 24 steps at 256 clips x 1201 frames (default 155 GiB, lower-staff stream 27, long-clip groups 6-7),
     plus 3 %, scaled by the clips x frames of the caller, in blocks of 24 GiB.  Returns the GiB reserved."""
-    per = {"default": 160.0, "side0": 1.0, "side1": 28.0, "group1": 6.5, "group2": 8.0}
+    # (about three quarters of what the pools end up holding: the warm-up steps grow them to their final size -- reserving all of it up front left the
+    # allocator at 266 of the MI355X's 268 GiB once the shapes of 20 steps had been seen)
+    per = {"default": 115.0, "side0": 1.0, "side1": 22.0, "group1": 5.0, "group2": 6.0}
     f = scale * (batch / 256.0) * (frames / 1201.0)
     streams = {"default": torch.cuda.current_stream(device), "side0": engine.side_streams(device)[0], "side1": engine.side_streams(device)[1],
                "group1": engine.group_stream(device, 1), "group2": engine.group_stream(device, 2)}
