@@ -854,7 +854,10 @@ __global__ __launch_bounds__(256) void attn_bwd_split256(const float* __restrict
 // Fused bars (see attn_fwd_split256_mq): NQ rows of one clip per workgroup, the clip's enc and K chunk streamed once for all of them.
 #define ATT_DCS 516             // floats per row of the dctx image in LDS (2H + 4: the rows of a clip land 4 banks apart)
 #ifndef ATT_BWD_MQ_WAVES
-#define ATT_BWD_MQ_WAVES 4        // waves per SIMD the register budget is sized for (launch bounds); ATT_BWD_MQ_KPRE: K tiles of pass B requested ahead of pass A
+// waves per SIMD the register budget is sized for (launch bounds); ATT_BWD_MQ_KPRE: K tiles of pass B requested ahead of pass A.  Round 6 measured
+// (6, 1) -- 74-80 registers instead of 92, so that five bulk workgroups per CU leave a SIMD 112 registers for the long-clip chain's waves instead
+// of 32 -- against (4, 2): 443.7 against 443.7 ms per step over three rounds (profiles/r06_lib_ab_variants.txt): the chain does not wait for registers.
+#define ATT_BWD_MQ_WAVES 4
 #define ATT_BWD_MQ_KPRE 2
 #endif
 template <int NQ, bool NT>

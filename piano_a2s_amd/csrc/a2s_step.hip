@@ -377,7 +377,14 @@ __global__ __launch_bounds__(64 * NW) void dec_gru_step_cmb(DecGruArgs a, DecCmb
 // k = 4 lk + j for the j-th MFMA); the sum runs over the chunks in order, x part first.
 #define MID_KC 64
 #define MID_LDB 72                // floats per staged weight row: 64 + 8
-__global__ __launch_bounds__(256) void dec_gru_mid(DecGruArgs a) {
+#ifndef MID_WAVES
+// waves per SIMD the mid-size kernels' register budget is sized for (launch bounds) and chunks the wave's own rows are requested ahead (1 or 2).
+// Measured in the step (tools/lib_ab2.sh, three rounds of 12 steps, profiles/r06_lib_ab_variants.txt): (1 wave, 2 ahead: 156 / 108 / 112 / 104
+// registers) 441.7 ms, (4 waves, 1 ahead: 122 / 88 / 90 / 84) 442.1 -- equal; the smaller footprint is the default.
+#define MID_WAVES 4
+#define MID_AHEAD 1
+#endif
+__global__ __launch_bounds__(256, MID_WAVES) void dec_gru_mid(DecGruArgs a) {
     __shared__ __attribute__((aligned(16))) float bs[2][48 * MID_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.n_done) {
@@ -442,17 +449,21 @@ __global__ __launch_bounds__(256) void dec_gru_mid(DecGruArgs a) {
             }
         }
     };
-    // the wave's own rows are TWO chunks ahead (they were written by the previous launch, on any XCD: the longest round trip of the kernel -- in the
+    // the wave's own rows are MID_AHEAD chunks ahead (they were written by the previous launch, on any XCD: the longest round trip of the kernel -- in the
     // step, beside the other staff's sweep, 3-5 us against 0.7 us of multiply per chunk), the weight chunk two ahead in registers, one in LDS
     f32x4 bv[3], a_cur[4], a_n1[4], a_n2[4];
     bload(0, bv);
     aload(0, a_cur);
-    if (nc > 1) aload(1, a_n1);
+    if (MID_AHEAD > 1 && nc > 1) aload(1, a_n1);
     bstore(0, bv);
     if (nc > 1) bload(1, bv);
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
+#if MID_AHEAD > 1
         if (c + 2 < nc) aload(c + 2, a_n2);
+#else
+        if (c + 1 < nc) aload(c + 1, a_n1);
+#endif
         if (c + 1 < nc) {
             bstore((c + 1) & 1, bv);                       // (that buffer was last read in iteration c - 1, which ended with a barrier)
             if (c + 2 < nc) bload(c + 2, bv);
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(256) void dec_gru_mid(DecGruArgs a) {
         else compute(std::false_type{}, c, c & 1, a_cur);
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a_cur[u] = a_n1[u]; a_n1[u] = a_n2[u]; }
+        for (int u = 0; u < 4; ++u) { a_cur[u] = a_n1[u]; if (MID_AHEAD > 1) a_n1[u] = a_n2[u]; }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -691,15 +702,19 @@ __device__ __forceinline__ void mid_product_64x32(const float* __restrict__ ar, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(ar + c * MID_KC + 16 * u);
     };
-    f32x4 bv[2], a_cur[4], a_n1[4], a_n2[4];             // (the wave's rows two chunks ahead, as in dec_gru_mid)
+    f32x4 bv[2], a_cur[4], a_n1[4], a_n2[4];             // (the wave's rows MID_AHEAD chunks ahead, as in dec_gru_mid)
     bload(0, bv);
     aload(0, a_cur);
-    if (nc > 1) aload(1, a_n1);
+    if (MID_AHEAD > 1 && nc > 1) aload(1, a_n1);
     bstore(0, bv);
     if (nc > 1) bload(1, bv);
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
+#if MID_AHEAD > 1
         if (c + 2 < nc) aload(c + 2, a_n2);
+#else
+        if (c + 1 < nc) aload(c + 1, a_n1);
+#endif
         if (c + 1 < nc) {
             bstore((c + 1) & 1, bv);                       // (that buffer was last read in iteration c - 1, which ended with a barrier)
             if (c + 2 < nc) bload(c + 2, bv);
@@ -718,14 +733,14 @@ __device__ __forceinline__ void mid_product_64x32(const float* __restrict__ ar, 
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a_cur[u] = a_n1[u]; a_n1[u] = a_n2[u]; }
+        for (int u = 0; u < 4; ++u) { a_cur[u] = a_n1[u]; if (MID_AHEAD > 1) a_n1[u] = a_n2[u]; }
     }
 }
 
 // The two backward products for hundreds of rows: a workgroup owns 64 rows x 32 columns of dx (role A) or dh (role B), wave w rows 16 w .. 16 w + 15
 // for all of K = 3 H2.  Replaces, in the bulk clip group's backward decode step, the dx product in front of the attention sweep and the dh
 // product behind it (two 64 x 32-tile launches of 30-50 us each in the step) by one launch in front of it.
-__global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
+__global__ __launch_bounds__(256, MID_WAVES) void dec_bwd_mid(DecBwdProdArgs a) {
     __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -757,7 +772,7 @@ __global__ __launch_bounds__(256) void dec_bwd_mid(DecBwdProdArgs a) {
 }
 
 // dh[:, n] += dq . W_h[:, n] behind the attention sweep, same tiles (B rows = W_h^T rows, (H2, H); K = H)
-__global__ __launch_bounds__(256) void dec_bwd_query_mid(const float* __restrict__ dq, const float* __restrict__ wh_t, float* __restrict__ dh, int R, int H, int H2,
+__global__ __launch_bounds__(256, MID_WAVES) void dec_bwd_query_mid(const float* __restrict__ dq, const float* __restrict__ wh_t, float* __restrict__ dh, int R, int H, int H2,
                                                          const int* __restrict__ rowmap) {
     __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -793,7 +808,7 @@ struct DecOutqMidArgs {
     const int* rowmap;
     int nva, R, H2;                                     // nva: vocabulary tiles
 };
-__global__ __launch_bounds__(256) void dec_outq_mid(DecOutqMidArgs a) {
+__global__ __launch_bounds__(256, MID_WAVES) void dec_outq_mid(DecOutqMidArgs a) {
     __shared__ __attribute__((aligned(16))) float bs[2][32 * MID_LDB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
