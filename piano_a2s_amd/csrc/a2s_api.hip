@@ -20,6 +20,8 @@ int a2s_gemm_bnstats_slots(int);
 int a2s_conv3x3_impl(hipStream_t, const float*, const float*, float*, const float*, const float*, float*, int, int, int, int, int, int, float*,
                      const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*);
 void a2s_conv_rows_set(int);
+void a2s_conv_c1_fast_set(int);
+int a2s_conv_c1_fast_enabled(void);
 int a2s_conv_rows_enabled(void);
 void a2s_wgrad_rows_set(int);
 int a2s_wgrad_rows_enabled(void);
@@ -233,6 +235,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "gemm_tile")) { a2s_gemm_debug_tile_impl(value); return A2S_OK; }
     if (!strcmp(key, "conv_bf16x3")) { a2s_conv_bf16x3_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_rows")) { a2s_conv_rows_set(value); return A2S_OK; }
+    if (!strcmp(key, "conv_c1_fast")) { a2s_conv_c1_fast_set(value); return A2S_OK; }
     if (!strcmp(key, "wgrad_rows")) { a2s_wgrad_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "staff_emb_fast")) { a2s_staff_emb_fast_set(value); return A2S_OK; }
     if (!strcmp(key, "conv_f16x2")) { a2s_conv_f16x2_set(value); return A2S_OK; }
@@ -254,6 +257,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "dec_mid_launches")) return a2s_dec_mid_launches();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
+    if (key && !strcmp(key, "conv_c1_fast")) return a2s_conv_c1_fast_enabled();
     if (key && !strcmp(key, "wgrad_rows")) return a2s_wgrad_rows_enabled();
     if (key && !strcmp(key, "staff_emb_fast")) return a2s_staff_emb_fast_enabled();
     if (key && !strcmp(key, "conv_f16x2")) return a2s_conv_f16x2_enabled();

@@ -882,6 +882,88 @@ __global__ __launch_bounds__(256) void conv3x3_c1(ConvArgs a) {
     }
 }
 
+// The same kernel with the channel count fixed at compile time and F a multiple of 4 (the model's 20 x 480): with a run-time Cout the
+// per-channel accumulators above are indexed dynamically (s_set_gpr_idx and ~50 register moves per channel: 3070 VALU instructions per
+// quad, the kernel ran at the VALU's pace, 4.4 ms at B = 256 against 2.1 ms of HBM time).  Here everything unrolls: one aligned 16-byte
+// load and two edge scalars per window row, packed fp32 FMAs, the same order of operations per output -- results are bit-identical.
+template <int COUT>
+__global__ __launch_bounds__(256, 4) void conv3x3_c1_fixed(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lw[COUT * 12];             // 9 taps per channel, padded to 12 for 16-byte reads
+    __shared__ float red[4][COUT][2];
+    for (int e = threadIdx.x; e < COUT * 12; e += 256) lw[e] = (e % 12 < 9) ? a.w[(e / 12) * 9 + e % 12] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qpr = a.F / 4;
+    const long nquads = (long)a.B * a.T * qpr;
+    float s1[COUT], s2[COUT], m1[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) { s1[co] = 0.f; s2[co] = 0.f; m1[co] = 0.f; }
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
+        const int f0 = (int)(q % qpr) * 4;
+        const long row = q / qpr;
+        const int t = (int)(row % a.T);
+        float v[3][6];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int tt = t + dt - 1;
+            const bool in = tt >= 0 && tt < a.T;
+            const float* xr = a.x + (row + dt - 1) * a.F + f0;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            float l = 0.f, r = 0.f;
+            if (in) {
+                c = *reinterpret_cast<const f32x4*>(xr);
+                if (f0 > 0) l = xr[-1];
+                if (f0 + 4 < a.F) r = xr[4];
+            }
+            v[dt][0] = l; v[dt][1] = c[0]; v[dt][2] = c[1]; v[dt][3] = c[2]; v[dt][4] = c[3]; v[dt][5] = r;
+        }
+        float* dst = a.y + row * COUT * a.F + f0;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            asm volatile("" ::: "memory");            // the taps are re-read from LDS per channel: hoisted out of the loop they cost 180 registers
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&lw[co * 12]), w1 = *reinterpret_cast<const f32x4*>(&lw[co * 12 + 4]);
+            const float w8 = lw[co * 12 + 8];
+            const float w[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w8};
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int df = 0; df < 3; ++df)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) o[p] = fmaf(v[dt][p + df], w[dt * 3 + df], o[p]);
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst + (long)co * a.F));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { s1[co] += o[p]; s2[co] = fmaf(o[p], o[p], s2[co]); }
+            m1[co] = fmaxf(fmaxf(m1[co], fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        }
+    }
+    if (a.out_absmax) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float m = wave_max(m1[co]);
+            if (lane == 0) {
+                const unsigned bits = __float_as_uint(m);
+                if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(a.out_absmax + co), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    atomicMax(reinterpret_cast<unsigned*>(a.out_absmax + co), bits);
+            }
+        }
+    }
+    if (a.stat_partial) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float w1 = wave_sum(s1[co]), w2 = wave_sum(s2[co]);
+            if (lane == 0) { red[wave][co][0] = w1; red[wave][co][1] = w2; }
+        }
+        __syncthreads();
+        if (threadIdx.x < COUT) {
+            float s = 0.f, q2 = 0.f;
+            for (int w = 0; w < 4; ++w) { s += red[w][threadIdx.x][0]; q2 += red[w][threadIdx.x][1]; }
+            a.stat_partial[((long)blockIdx.x * COUT + threadIdx.x) * 2 + 0] = s;
+            a.stat_partial[((long)blockIdx.x * COUT + threadIdx.x) * 2 + 1] = q2;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- BatchNorm
 // Fixed-order reduction of the per-workgroup partials in double (the reference's CPU kernel accumulates
 // batch statistics in double: at::acc_type<float> on CPU), then the affine the consumer applies on load.
@@ -985,6 +1067,9 @@ int a2s_act_bound_impl(hipStream_t st, const float* scale, const float* shift, c
 }
 
 // ------------------------------------------------------------------------------------------- launchers
+static int g_conv_c1_fast = 1;        // the first layer's compile-time-shaped kernels (conv3x3_c1_fixed, conv3x3_wgrad_c1_stream); 0 = the generic ones (tests: bit-equal)
+void a2s_conv_c1_fast_set(int on) { g_conv_c1_fast = on; }
+int a2s_conv_c1_fast_enabled(void) { return g_conv_c1_fast; }
 static int g_conv_bf16x3 = 3;         // convolutions on the bf16 matrix pipes with 3-term split operands (conv3x3_split<.., 3>): bit 0 forward, bit 1 data-gradient launches
 void a2s_conv_bf16x3_set(int on) { g_conv_bf16x3 = on; }
 int a2s_conv_bf16x3_enabled(void) { return g_conv_bf16x3; }
@@ -1039,7 +1124,9 @@ int a2s_conv3x3_impl(hipStream_t st, const float* x, const float* w, float* y, c
     }
     if (Cin == 1) {
         A2S_REQUIRE(Cout <= 20 && !flip && !in_scale, "conv3x3: Cin=1 path supports Cout<=20, no flip, no input affine");
-        hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_conv3x3_stat_blocks_impl(B, T, F, 1)), dim3(256), 0, st, a);
+        const bool fixed = g_conv_c1_fast && Cout == 20 && F % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+        if (fixed) hipLaunchKernelGGL(conv3x3_c1_fixed<20>, dim3(a2s_conv3x3_stat_blocks_impl(B, T, F, 1)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(conv3x3_c1, dim3(a2s_conv3x3_stat_blocks_impl(B, T, F, 1)), dim3(256), 0, st, a);
     } else {
         A2S_REQUIRE(Cin % 4 == 0 && Cin % CV_CK == 0, "conv3x3: Cin must be a multiple of %d", CV_CK);
         A2S_REQUIRE(ws, "conv3x3: needs a workspace of a2s_conv3x3_workspace_floats(Cin) floats for the packed weights");
@@ -1609,6 +1696,112 @@ __global__ void wgrad_reduce_c1(const float* __restrict__ partial, float* __rest
     dW[idx] += s;
 }
 
+// The model's case of conv3x3_wgrad_c1 (fused BatchNorm backward, F a multiple of 4 * C1W_PARTS) restructured for the memory system -- same
+// rows per workgroup, same order of additions per tap sum, so the slabs are bit-identical:
+//   * the NEXT row's dy / y / input loads are issued before the current row's tap sums are computed (the old kernel alternated a load phase
+//     and a compute phase per workgroup, 4.1 TB/s);
+//   * the tap sums read LDS 16 bytes at a time: one quad of dy and one quad per window row for 4 positions (the old loop: 4 scalar reads
+//     per position, 2-4-way bank conflicts -- SQ_LDS_BANK_CONFLICT / SQ_LDS_ACTIVE = 0.67).  The window rows are stored at a stride of
+//     F + 8 with x[f] at column 4 + f, so the quads are aligned and the zero borders sit at columns 3 and F + 4.
+#define C1W_XN 2                            // input-window quads per thread and row: 3 * F / 4 <= 2 * 256
+template <int COUT, int F>
+__global__ __launch_bounds__(256, 3) void conv3x3_wgrad_c1_stream(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ partial,
+                                                                  int B, int T, BnBwdFuse bn) {
+    static_assert(F % (4 * C1W_PARTS) == 0 && 3 * F / 4 <= 256 * C1W_XN && COUT * F <= 4 * 256 * C1W_XIT && COUT * C1W_PARTS <= 256, "shape");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int LXS = F + 8;
+    float* ldy = sm;                            // COUT * F
+    float* lx = sm + COUT * F;                  // 3 * LXS
+    __shared__ float lconst[COUT * 6];
+    const int tid = threadIdx.x;
+    if (tid < COUT) {
+        float* k = lconst + tid * 6;
+        k[0] = bn.mean[tid]; k[1] = bn.invstd[tid]; k[2] = bn.scale[tid]; k[3] = bn.shift[tid]; k[4] = bn.c12[2 * tid]; k[5] = bn.c12[2 * tid + 1];
+    }
+    const int co = tid / C1W_PARTS, part = tid % C1W_PARTS;
+    constexpr int fper = F / C1W_PARTS, nq = COUT * F / 4, nx = 3 * F / 4;      // quads of a dy row, of the 3-row input window
+    const int fa = part * fper;
+    const bool worker = co < COUT;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    const long rows = (long)B * T;
+    f32x4 g4[C1W_XIT], y4[C1W_XIT];
+    f32x4 xv[C1W_XN];
+    auto issue = [&](long row) {
+        const f32x4* drow = reinterpret_cast<const f32x4*>(dy + row * (long)COUT * F);
+        const f32x4* yrow = reinterpret_cast<const f32x4*>(bn.y + row * (long)COUT * F);
+#pragma unroll
+        for (int it = 0; it < C1W_XIT; ++it) {
+            const int e = tid + 256 * it;
+            if (e < nq) { g4[it] = drow[e]; y4[it] = yrow[e]; }
+        }
+        const int t = (int)(row % T);
+#pragma unroll
+        for (int it = 0; it < C1W_XN; ++it) {
+            const int e = tid + 256 * it, r = e / (F / 4), tt = t + r - 1;
+            xv[it] = (e < nx && tt >= 0 && tt < T) ? reinterpret_cast<const f32x4*>(x + (row + r - 1) * F)[e % (F / 4)] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (tid < 6) lx[(tid >> 1) * LXS + ((tid & 1) ? F + 4 : 3)] = 0.f;        // the zero borders left and right of the window rows
+    if ((long)blockIdx.x < rows) issue(blockIdx.x);
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        __syncthreads();                        // the previous row's tap sums are done with LDS (and lconst is written)
+#pragma unroll
+        for (int it = 0; it < C1W_XIT; ++it) {
+            const int e = tid + 256 * it;
+            if (e < nq) {
+                const float* k = lconst + ((e * 4) / F) * 6;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = bn_bwd_value(g4[it][q], y4[it][q], k[0], k[1], k[2], k[3], k[4], k[5]);
+                reinterpret_cast<f32x4*>(ldy)[e] = v;
+                if (bn.dy_out) reinterpret_cast<f32x4*>(bn.dy_out + row * (long)COUT * F)[e] = v;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < C1W_XN; ++it) {
+            const int e = tid + 256 * it;
+            if (e < nx) *reinterpret_cast<f32x4*>(lx + (e / (F / 4)) * LXS + 4 + 4 * (e % (F / 4))) = xv[it];
+        }
+        if (row + gridDim.x < rows) issue(row + gridDim.x);      // in flight while this row's tap sums are computed
+        __syncthreads();
+        if (worker) {
+            const float* d = ldy + co * F + fa;
+            const float* xr = lx + 4 + fa;
+            float left[3];
+            f32x4 cur[3];
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) { left[dt] = xr[dt * LXS - 1]; cur[dt] = *reinterpret_cast<const f32x4*>(xr + dt * LXS); }
+#pragma unroll 2
+            for (int j = 0; j < fper; j += 4) {                 // (fully unrolled, the 40 quad reads are all issued first: 100 spilled registers)
+                const f32x4 g = *reinterpret_cast<const f32x4*>(d + j);
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    const f32x4 nxt = *reinterpret_cast<const f32x4*>(xr + dt * LXS + j + 4);      // only [0] is used past the row's end: the border
+                    const float w[6] = {left[dt], cur[dt][0], cur[dt][1], cur[dt][2], cur[dt][3], nxt[0]};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int df = 0; df < 3; ++df) acc[dt * 3 + df] = fmaf(g[p], w[p + df], acc[dt * 3 + df]);
+                    left[dt] = cur[dt][3]; cur[dt] = nxt;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* red = sm;                            // 256 * 9 floats
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[tid * 9 + k] = worker ? acc[k] : 0.f;
+    __syncthreads();
+    if (tid < COUT * 9) {
+        const int c = tid / 9, k = tid % 9;
+        float s = 0.f;
+        for (int p = 0; p < C1W_PARTS; ++p) s += red[(c * C1W_PARTS + p) * 9 + k];
+        partial[(long)blockIdx.x * COUT * 9 + tid] = s;
+    }
+}
+
 // ---- weight gradient on the bf16 matrix pipes with 3-term split operands (see conv3x3_bf16x3).  K = positions: a fragment is 8
 // consecutive f positions of ONE channel row, so dy (M = co) and the input (N = ci) both stay position-contiguous in LDS; an N-tile is
 // 16 input channels at ONE tap, which makes the +-1 column shift of the tap uniform per MFMA: the lane reads the aligned 8 positions plus
@@ -1928,9 +2121,11 @@ int a2s_conv3x3_wgrad_impl(hipStream_t st, const float* dy, const float* x, cons
     const BnBwdFuse bn{bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_c12, dy_out};
     A2S_REQUIRE(ws_bytes >= a2s_conv3x3_wgrad_workspace_bytes_impl(Cin, Cout), "conv3x3_wgrad: workspace too small");
     if (Cin == 1 && !in_scale && Cout * C1W_PARTS <= 256 && (size_t)Cout * F >= 256 * 9) {
-        const size_t shm = ((size_t)Cout * F + 3 * (F + 2)) * sizeof(float);
+        const size_t shm = ((size_t)Cout * F + 3 * (F + 8)) * sizeof(float);
         if (shm <= 64 * 1024) {
-            hipLaunchKernelGGL(conv3x3_wgrad_c1, dim3(WGRAD_SLABS), dim3(256), shm, st, dy, x, ws, B, T, F, Cout, bn);
+            const bool stream = g_conv_c1_fast && bn_y && Cout == 20 && F == 480 && (((uintptr_t)dy | (uintptr_t)bn_y | (uintptr_t)dy_out | (uintptr_t)x) & 15) == 0;
+            if (stream) hipLaunchKernelGGL((conv3x3_wgrad_c1_stream<20, 480>), dim3(WGRAD_SLABS), dim3(256), shm, st, dy, x, ws, B, T, bn);
+            else hipLaunchKernelGGL(conv3x3_wgrad_c1, dim3(WGRAD_SLABS), dim3(256), shm, st, dy, x, ws, B, T, F, Cout, bn);
             A2S_CHECK_LAUNCH("conv3x3_wgrad_c1");
             hipLaunchKernelGGL(wgrad_reduce_c1, dim3(a2s_cdiv(Cout * 9, 256)), dim3(256), 0, st, ws, dW, WGRAD_SLABS, Cout * 9);
             A2S_CHECK_LAUNCH("wgrad_reduce_c1");
