@@ -156,23 +156,24 @@ def conv_roofline(B, T, F, iters=6):
     return out
 
 
-def step_roofline(B, T, F, H, clip_steps, ms_per_step):
+def step_roofline(B, T, F, H, clip_steps, ms_per_step, shared_steps=0.0):
     """Whole-step HBM roofline: ALGORITHMIC bytes of one optimizer step (derivation: DESIGN.md section 6) / measured step time / 8 TB/s.
       ConvStack, per clip, in units u = T x F x 4 bytes (one channel plane): forward = input (1) + every activation tensor written once and
         read once by its consumer (2 x 120 channels); backward = every activation read once more (120) + every activation gradient written
         once and read once (2 x 120) + the layer input of each weight gradient (80)  ->  681 u;
       encoder: features, the four input projections and the two layers' outputs, forward + backward  ~ 60 MB per clip;
       decoder: every (clip, decode step) pair that is still running streams the clip's key image and encoder outputs once in the forward
-        and once in the backward pass: 2 x T x 3H x 4 bytes per pair (pairs counted by the step's own plan)."""
+        and once in the backward pass: 2 x T x 3H x 4 bytes per pair (pairs counted by the step's own plan) -- minus the encoder outputs (2H of the 3H)
+        of the pairs of the lower staff that one pass serves together with the upper staff's (round 6: `shared_steps`, also from the plan)."""
     u = T * F * 4.0
     conv = B * 681.0 * u
     enc = B * 60e6
-    attn = 2.0 * clip_steps * T * 3 * H * 4.0
+    attn = 2.0 * (clip_steps * 3 - shared_steps * 2) * T * H * 4.0
     total = conv + enc + attn
     gbs = total / (ms_per_step * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
             "algorithmic_bytes_per_step": int(total), "parts_GB": {"convstack": round(conv / 1e9, 1), "encoder": round(enc / 1e9, 1), "decoder_attention": round(attn / 1e9, 1)},
-            "attention_clip_steps_per_step": int(clip_steps), "ms_per_step": ms_per_step,
+            "attention_clip_steps_per_step": int(clip_steps), "attention_shared_enc_clip_steps_per_step": int(shared_steps), "ms_per_step": ms_per_step,
             "what": "algorithmic HBM bytes of one optimizer step / the timed step / HBM peak (the profile is flat: no single kernel is more than 5 % of the step)"}
 
 
@@ -209,7 +210,7 @@ def phase_roofline(step, batches, B, T, F, H, n_steps=6):
     wrap(engine.Engine, "encoder", "encoder_fwd")
     wrap(engine_bwd, "_encoder_bwd", "encoder_bwd")
     wrap(engine_bwd, "_convstack_bwd", "convstack_bwd")
-    tot, clip_steps, walls = {}, [], []
+    tot, clip_steps, shared_steps, walls = {}, [], [], []
     try:
         for k in range(n_steps + 1):
             marks.clear()
@@ -220,6 +221,7 @@ def phase_roofline(step, batches, B, T, F, H, n_steps=6):
             if k == 0:
                 continue
             clip_steps.append(getattr(step, "attn_clip_steps", 0))
+            shared_steps.append(getattr(step, "attn_shared_clip_steps", 0))
             walls.append(marks[0][1].elapsed_time(marks[-1][1]))
             for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
                 name = {"before encoder_bwd": "decoder", "end": "clip_adadelta", "before convstack_fwd": "host_plan_gap"}.get(n1, n1)
@@ -232,9 +234,10 @@ def phase_roofline(step, batches, B, T, F, H, n_steps=6):
     ms = {k: v / n_steps for k, v in tot.items()}
     u = T * F * 4.0
     cs = sum(clip_steps) / max(len(clip_steps), 1)
+    sh = sum(shared_steps) / max(len(shared_steps), 1)
     flop_fwd = B * 41.07e9
     work = {"convstack_fwd": (B * 241.0 * u, flop_fwd), "convstack_bwd": (B * 440.0 * u, 2 * flop_fwd),
-            "encoder_fwd": (B * 30e6, B * 5.66e9), "encoder_bwd": (B * 30e6, B * 2 * 5.66e9), "decoder": (2.0 * cs * T * 3 * H * 4.0, None)}
+            "encoder_fwd": (B * 30e6, B * 5.66e9), "encoder_bwd": (B * 30e6, B * 2 * 5.66e9), "decoder": (2.0 * (cs * 3 - sh * 2) * T * H * 4.0, None)}
     peak_tf = MFMA_BF16_PEAK_TFS / 3
     out = {"steps": n_steps, "ms_per_step": round(sum(walls) / len(walls), 2), "attention_clip_steps_per_step": int(cs),
            "peak_GBs": HBM_PEAK_GBS, "peak_TFLOPs_two_term": round(peak_tf, 1),
@@ -671,6 +674,7 @@ def main():
         """W untimed + K timed steps, bracketed by barrier + synchronize on both sides; max over ranks; decode steps executed per step."""
         decode_steps = []
         timed.clip_steps = []
+        timed.shared_steps = []
         for i in range(warmup):
             step(batches[i % len(batches)], TF_RATIO)
         torch.cuda.synchronize()
@@ -686,6 +690,7 @@ def main():
             step(batches[i % len(batches)], TF_RATIO)
             decode_steps.append(step.decode_steps)
             timed.clip_steps.append(getattr(step, "attn_clip_steps", 0))
+            timed.shared_steps.append(getattr(step, "attn_shared_clip_steps", 0))
             marks[i + 1].record()
             segs.append(torch.cuda.memory_stats().get("segment.all.allocated", 0))
         timed.new_segments = [b - a for a, b in zip(segs[:-1], segs[1:])]
@@ -779,7 +784,8 @@ def main():
         batches = None
         torch.cuda.empty_cache()
         out["roofline"] = conv_roofline(B, 1201, cfg["freq_bins"])
-        out["roofline_step"] = step_roofline(B, 1201, cfg["freq_bins"], cfg["hidden_size"], clip_steps_per_step, out["ms_per_step"])
+        out["roofline_step"] = step_roofline(B, 1201, cfg["freq_bins"], cfg["hidden_size"], clip_steps_per_step, out["ms_per_step"],
+                                             sum(timed.shared_steps) / max(len(timed.shared_steps), 1))
         if phases is not None:
             out["roofline_phases"] = phases
         out["roofline_linear"] = linear_roofline(B, 1201, cfg["freq_bins"])

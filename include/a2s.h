@@ -255,6 +255,13 @@ typedef struct a2s_note_dec_args {
     float* persist_ws; size_t persist_ws_bytes;   /* a2s_note_decoder_persist_ws_bytes(n_clips, R, steps) bytes, 256-byte aligned, or NULL */
 } a2s_note_dec_args;
 int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps_done);
+/* Round 6: the two NoteDecoders of a segment (/root/reference/models.py:261-275: decode_notes of the upper and of the lower staff over the same
+ * encoder_outputs) issued by ONE host loop on their two streams; while both staves run a step, the step's attention sweep is one launch that reads
+ * the encoder outputs once for both (csrc/a2s_seq.hip: attn_fwd_split256_pair).  pair_order / pair_rank: device, n_clips ints -- the clips sorted by
+ * the step the last row of EITHER staff finishes at (latest first) and the inverse permutation; pair_n_active: HOST, max(steps) ints.  Training calls
+ * with the finished-row bookkeeping only; anything else runs the two calls one after the other (a2s_note_decoder_fwd twice). */
+int a2s_note_decoder_fwd_pair(void* stream_upper, void* stream_lower, const a2s_note_dec_args* upper, const a2s_note_dec_args* lower,
+                              const int* pair_order, const int* pair_rank, const int* pair_n_active, int* steps_done_upper, int* steps_done_lower);
 size_t a2s_note_step_workspace_floats(int H, int E);
 /* scratch of the persistent path (0: that many clips are not supported) */
 size_t a2s_note_decoder_persist_ws_bytes(int n_clips, int R, int steps);
@@ -322,6 +329,10 @@ typedef struct a2s_note_dec_bwd_args {
     const float* w_ih_full;                  /* unused (reserved) */
 } a2s_note_dec_bwd_args;
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args);
+/* Round 6: the reverse loops of a segment's two NoteDecoders from one host loop on their two streams, the attention sweep of a step as ONE launch
+ * for both staves while both step (see a2s_note_decoder_fwd_pair; autograd of /root/reference/models.py:261-275). */
+int a2s_note_decoder_bwd_pair(void* stream_upper, void* stream_lower, const a2s_note_dec_bwd_args* upper, const a2s_note_dec_bwd_args* lower,
+                              const int* pair_order, const int* pair_rank, const int* pair_n_active);
 
 /* BPTT of one encoder GRU direction (reverse of a2s_gru_seq_fwd) */
 int a2s_gru_seq_bwd(void* stream, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride,

@@ -82,6 +82,14 @@ size_t a2s_note_step_workspace_floats_impl(int H, int E);
 
 bool a2s_gru_step_fused_enabled(void);
 int a2s_note_decoder_fwd_impl(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
+int a2s_note_decoder_fwd_pair_impl(hipStream_t su, hipStream_t sl, const a2s_note_dec_args& au, const a2s_note_dec_args& al, const int* pair_order,
+                                   const int* pair_rank, const int* pair_n_active, int* done_u, int* done_l);
+void a2s_attn_pair_set(int);
+int a2s_attn_pair_enabled(void);
+long a2s_attn_pair_launches(void);
+long a2s_attn_pair_bwd_launches(void);
+int a2s_note_decoder_bwd_pair_impl(hipStream_t su, hipStream_t sl, const a2s_note_dec_bwd_args& au, const a2s_note_dec_bwd_args& al, const int* pair_order,
+                                   const int* pair_rank, const int* pair_n_active);
 
 int a2s_log_softmax_bwd_rows_impl(hipStream_t, const float*, const float*, long, int, float*, int, int, int, int);
 int a2s_gru_gates_bwd_impl(hipStream_t, const float*, long, const float*, long, const float*, const float*, long, float*, long, float*, long,
@@ -225,6 +233,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_deep")) { a2s_attn_deep_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_defer_combine")) { a2s_attn_defer_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_mid")) { a2s_dec_mid_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_pair")) { a2s_attn_pair_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
@@ -254,6 +263,9 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_deep")) return a2s_attn_deep_max_clips();
     if (key && !strcmp(key, "attn_defer_combine")) return a2s_attn_defer_combine_enabled();
     if (key && !strcmp(key, "dec_mid")) return a2s_dec_mid_enabled();
+    if (key && !strcmp(key, "attn_pair")) return a2s_attn_pair_enabled();
+    if (key && !strcmp(key, "attn_pair_launches")) return (int)a2s_attn_pair_launches();
+    if (key && !strcmp(key, "attn_pair_bwd_launches")) return (int)a2s_attn_pair_bwd_launches();
     if (key && !strcmp(key, "dec_mid_launches")) return a2s_dec_mid_launches();
     if (key && !strcmp(key, "conv_bf16x3")) return a2s_conv_bf16x3_enabled();
     if (key && !strcmp(key, "conv_rows")) return a2s_conv_rows_enabled();
@@ -369,6 +381,12 @@ int a2s_note_decoder_fwd(void* stream, const a2s_note_dec_args* args, int* steps
     if (!args) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "note_decoder_fwd: null args"); return A2S_ERR_ARG; }
     return a2s_note_decoder_fwd_impl(ST, *args, steps_done);
 }
+int a2s_note_decoder_fwd_pair(void* stream_upper, void* stream_lower, const a2s_note_dec_args* upper, const a2s_note_dec_args* lower,
+                              const int* pair_order, const int* pair_rank, const int* pair_n_active, int* steps_done_upper, int* steps_done_lower) {
+    if (!upper || !lower) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "note_decoder_fwd_pair: null args"); return A2S_ERR_ARG; }
+    return a2s_note_decoder_fwd_pair_impl((hipStream_t)stream_upper, (hipStream_t)stream_lower, *upper, *lower, pair_order, pair_rank, pair_n_active,
+                                          steps_done_upper, steps_done_lower);
+}
 int a2s_staff_emb_fwd(void* stream, const float* note_emb, const float* const* gru_w, const long long* ids64, const int* ids32,
                       long id_bstride, const long long* lengths, long len_stride, float* out, long ldo, int col0, float* hsave,
                       int R, int maxlen, int E, int S) {
@@ -413,6 +431,11 @@ int a2s_ew_act_bwd(void* stream, const float* g, const float* y, float* dx, long
 int a2s_note_decoder_bwd(void* stream, const a2s_note_dec_bwd_args* args) {
     if (!args) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "note_decoder_bwd: null args"); return A2S_ERR_ARG; }
     return a2s_note_decoder_bwd_impl(ST, *args);
+}
+int a2s_note_decoder_bwd_pair(void* stream_upper, void* stream_lower, const a2s_note_dec_bwd_args* upper, const a2s_note_dec_bwd_args* lower,
+                              const int* pair_order, const int* pair_rank, const int* pair_n_active) {
+    if (!upper || !lower) { snprintf(a2s_err_msg, sizeof(a2s_err_msg), "note_decoder_bwd_pair: null args"); return A2S_ERR_ARG; }
+    return a2s_note_decoder_bwd_pair_impl((hipStream_t)stream_upper, (hipStream_t)stream_lower, *upper, *lower, pair_order, pair_rank, pair_n_active);
 }
 int a2s_gru_seq_bwd(void* stream, const float* dout, long do_bstride, long do_tstride, const float* out, long out_bstride, long out_tstride,
                     const float* gates, const float* w_hh, const float* dhn, float* dgi_all, float* dgh_shift, float* dgh_first,

@@ -301,86 +301,167 @@ bool a2s_note_step_mid_bwd_ok(const a2s_note_dec_bwd_args& a);
 int a2s_note_step_mid_bwd(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, float* dh_out, int nrows, const int* rowmap);
 int a2s_note_step_mid_bwd_query(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, float* dh_out, int nrows, const int* rowmap);
 
-int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
-    // few clips: one persistent launch for the whole reverse loop (a2s_dec_persist.hip)
-    if (a2s_note_decoder_bwd_persist_ok(a)) return a2s_note_decoder_bwd_persist(st, a);
-    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
-    hipError_t e = hipMemsetAsync(a.dh, 0, sizeof(float) * 2 * R * H2, st);
-    // (steps that skip finished rows leave their dx rows unwritten: they must read as zero gradients)
-    if (e == hipSuccess && (a.m_active || a.row_list)) e = hipMemsetAsync(a.dx, 0, sizeof(float) * (size_t)a.steps * R * ldx, st);
-    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd memset: %s", hipGetErrorString(e));
-    int cur = 0;
+// the pair's clip bookkeeping at one step and the geometry its dq partials use (both staves' sweeps of the step in one launch: attn_bwd_split256_pair)
+struct AttnPairBwdStep { const int* clip_order; const int* clip_rank; int n_clips; int n_active; int step; int G; int chunk; };
+static int attn_pair_bwd_sweep(hipStream_t st, const a2s_note_dec_bwd_args& au, const a2s_note_dec_bwd_args& al, int s, AttnPairBwdStep& p);
+static int attn_pair_bwd_combine(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const AttnPairBwdStep& p);
+int a2s_attn_pair_enabled(void);
+
+static int note_bwd_step_rows(const a2s_note_dec_bwd_args& a, int s) { return (a.row_list && a.n_rows_active) ? a.n_rows_active[s] : a.R; }
+static bool note_bwd_step_fused(const a2s_note_dec_bwd_args& a, int s) {
     const void* ptrs[] = {a.dgi_all, a.dgh_all, a.dq_all, a.dx, a.dh, a.w_ih, a.w_hh, a.attn_w};
-    // rows step s covers on the few-row kernels: all R, or the rows still running (a prefix of row_list); the kernels take over for the steps
-    // whose rows fit them (see a2s_note_decoder_fwd_impl)
-    auto step_rows = [&](int s) { return (a.row_list && a.n_rows_active) ? a.n_rows_active[s] : R; };
-    auto step_fused = [&](int s) { const int n = step_rows(s); return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, 173, ptrs, 8, a.step_ws, a.step_ws_floats); };      // (the vocabulary size plays no role here)
-    // transposed weight copies for the few-row kernels: needed as soon as ANY step of the call runs on them (the last step has the fewest rows,
-    // but it may have none at all -- a row without <eos> whose last targets are <pad> -- while earlier steps still have 1 .. max_rows)
-    bool any_fused = false;
-    for (int s = a.steps - 1; s >= 0 && !any_fused; --s) any_fused = step_fused(s);
-    // round 6: the dx / dh products of the steps that stay on this loop as ONE launch in front of the attention (dec_bwd_mid, a2s_step.hip), over the
-    // rows still running; it reads the same transposed weight copies
-    const bool mid = a2s_note_step_mid_bwd_ok(a);
-    bool any_mid = false;
-    if (mid) for (int s = a.steps - 1; s >= 0 && !any_mid; --s) any_mid = !step_fused(s);
-    if (any_fused || any_mid) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }
-    for (int s = a.steps - 1; s >= 0; --s) {
-        const bool fused = step_fused(s);
-        a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : R, a.n_active ? a.n_active[s] : 0, s};
-        const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
-        float* dh_in = a.dh + (long)cur * R * H2;
-        float* dh_out = a.dh + (long)(cur ^ 1) * R * H2;
-        if (fused) {
-            const int nrows = step_rows(s);
-            int rc = a2s_note_step_fused_bwd(st, a, s, dh_in, dh_out, rows, nrows, nrows < R ? a.row_list : nullptr);
-            if (rc) return rc;
-            cur ^= 1;
-            continue;
-        }
-        int gM = R, gB = 1;                  // rows of the per-step products: see enqueue_note_step (a2s_seq.hip); rows left out carry zero gradients
-        long gS = 0;
-        if (a.m_active && a.n_clips > 0 && a2s_prefix_rows_ok(a.m_active[s], a.n_clips)) { gM = a.m_active[s]; gB = R / a.n_clips; gS = a.n_clips; }
-        const float* dos = a.do_all + (long)s * R * 2 * H2;
-        float* dgi = a.dgi_all + (long)s * R * 3 * H2;
-        float* dgh = a.dgh_all + (long)s * R * 3 * H2;
-        float* dxs = a.dx + (long)s * R * ldx;
-        int rc;
+    const int n = note_bwd_step_rows(a, s);
+    return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, 173, ptrs, 8, a.step_ws, a.step_ws_floats);      // (the vocabulary size plays no role here)
+}
+
+// One reverse step of a note decoder; `cur` = which half of a.dh holds the incoming carry (flipped on return).  part: 0 = the whole step; 1 = what
+// comes before the attention sweep of a launch-per-step step (GRU cell, dx products), 2 = what comes behind it (dq reduction, dh products) -- the
+// pair loop runs 1, the two staves' sweep as one launch, then 2 with `pair` set.
+static int note_bwd_step(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, int& cur, bool mid, int part, const AttnPairBwdStep* pair) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    const bool fused = note_bwd_step_fused(a, s);
+    a2s_attn_rows rows_v = {a.clip_order, a.clip_rank, a.row_until, a.n_clips > 0 ? a.n_clips : R, a.n_active ? a.n_active[s] : 0, s};
+    const a2s_attn_rows* rows = a.n_active ? &rows_v : nullptr;
+    float* dh_in = a.dh + (long)cur * R * H2;
+    float* dh_out = a.dh + (long)(cur ^ 1) * R * H2;
+    if (fused) {
+        const int nrows = note_bwd_step_rows(a, s);
+        int rc = a2s_note_step_fused_bwd(st, a, s, dh_in, dh_out, rows, nrows, nrows < R ? a.row_list : nullptr);
+        if (rc) return rc;
+        cur ^= 1;
+        return A2S_OK;
+    }
+    int gM = R, gB = 1;                  // rows of the per-step products: see enqueue_note_step (a2s_seq.hip); rows left out carry zero gradients
+    long gS = 0;
+    if (a.m_active && a.n_clips > 0 && a2s_prefix_rows_ok(a.m_active[s], a.n_clips)) { gM = a.m_active[s]; gB = R / a.n_clips; gS = a.n_clips; }
+    const float* dos = a.do_all + (long)s * R * 2 * H2;
+    float* dgi = a.dgi_all + (long)s * R * 3 * H2;
+    float* dgh = a.dgh_all + (long)s * R * 3 * H2;
+    float* dxs = a.dx + (long)s * R * ldx;
+    int rc = A2S_OK;
+    if (part != 2) {
         // GRU cell: dh = carry + dh_from_out;  hprev = h[s]
         rc = a2s_gru_gates_bwd_impl(st, dh_in, H2, dos, 2 * H2, a.gates + (long)s * R * 4 * H2, a.h + (long)s * R * H2, H2,
                                     dgi, 3 * H2, dgh, 3 * H2, nullptr, 0, dh_out, H2, R, H2);
         if (rc) return rc;
         if (mid) {
-            const int nrows = step_rows(s);
+            const int nrows = note_bwd_step_rows(a, s);
             rc = a2s_note_step_mid_bwd(st, a, s, dh_out, nrows, nrows < R ? a.row_list : nullptr);
         } else {
             // dx = dgi W_ih   (R x ldx): [dtok | dctx_from_gru]
             rc = a2s_gemm_impl(st, gM, ldx, 3 * H2, 1.f, dgi, 3 * H2, 1, a.w_ih, ldx, 1, 0.f, dxs, ldx, nullptr, 0, gB, gS * 3 * H2, 0, gS * ldx, 0, a.gemm_ws, a.gemm_ws_bytes);
         }
         if (rc) return rc;
-        // attention: dctx = dx[:, E:] + do[:, 2H:]
-        rc = a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
-                                    a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
-                                    a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
-                                    a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
-        if (rc) return rc;
-        // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
-        if (!mid) {
-            rc = a2s_gemm_impl(st, gM, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * 3 * H2, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
-            if (rc) return rc;
-        }
-        if (mid) {
-            const int nrows = step_rows(s);
-            rc = a2s_note_step_mid_bwd_query(st, a, s, dh_out, nrows, nrows < R ? a.row_list : nullptr);
-        } else
-        rc = a2s_gemm_impl(st, gM, H2, a.H, 1.f, a.dq_all + (long)s * R * a.H, a.H, 1, a.attn_w, 2 * H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * a.H, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
-        if (rc) return rc;
-        cur ^= 1;
+        if (part == 1) return A2S_OK;
     }
+    // attention: dctx = dx[:, E:] + do[:, 2H:]
+    rc = pair ? attn_pair_bwd_combine(st, a, s, *pair)
+              : a2s_attn_step_bwd_impl(st, a.keys, a.enc, a.q + (long)s * R * a.H, a.H, a.attn_v, a.attw + (long)s * R * a.T,
+                                       a.x + (long)s * R * ldx + a.E, ldx, dxs + a.E, ldx, dos + H2, 2 * H2,
+                                       a.dctx_all + (long)s * R * H2, H2, a.dq_all + (long)s * R * a.H, a.H,
+                                       a.ds_all + (long)s * R * a.T, R, a.T, a.H, a.attn_ws, rows);
+    if (rc) return rc;
+    // dh_prev += dgh W_hh + dq W_h   (W_h = first 2H columns of attn_w (H, 4H))
+    if (!mid) {
+        rc = a2s_gemm_impl(st, gM, H2, 3 * H2, 1.f, dgh, 3 * H2, 1, a.w_hh, H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * 3 * H2, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
+        if (rc) return rc;
+    }
+    if (mid) {
+        const int nrows = note_bwd_step_rows(a, s);
+        rc = a2s_note_step_mid_bwd_query(st, a, s, dh_out, nrows, nrows < R ? a.row_list : nullptr);
+    } else
+    rc = a2s_gemm_impl(st, gM, H2, a.H, 1.f, a.dq_all + (long)s * R * a.H, a.H, 1, a.attn_w, 2 * H2, 1, 1.f, dh_out, H2, nullptr, 0, gB, gS * a.H, 0, gS * H2, 0, a.gemm_ws, a.gemm_ws_bytes);
+    if (rc) return rc;
+    cur ^= 1;
+    return A2S_OK;
+}
+
+// what a reverse loop needs before its first step: zeroed carries / dx, the transposed weight copies of the few-row and mid-size kernels
+static int note_bwd_prepare(hipStream_t st, const a2s_note_dec_bwd_args& a, bool* mid_out) {
+    const int H2 = 2 * a.H, ldx = a.E + H2, R = a.R;
+    hipError_t e = hipMemsetAsync(a.dh, 0, sizeof(float) * 2 * R * H2, st);
+    // (steps that skip finished rows leave their dx rows unwritten: they must read as zero gradients)
+    if (e == hipSuccess && (a.m_active || a.row_list)) e = hipMemsetAsync(a.dx, 0, sizeof(float) * (size_t)a.steps * R * ldx, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd memset: %s", hipGetErrorString(e));
+    // transposed weight copies for the few-row kernels: needed as soon as ANY step of the call runs on them (the last step has the fewest rows,
+    // but it may have none at all -- a row without <eos> whose last targets are <pad> -- while earlier steps still have 1 .. max_rows)
+    bool any_fused = false;
+    for (int s = a.steps - 1; s >= 0 && !any_fused; --s) any_fused = note_bwd_step_fused(a, s);
+    // round 6: the dx / dh products of the steps that stay on this loop as ONE launch in front of the attention (dec_bwd_mid, a2s_step.hip), over the
+    // rows still running; it reads the same transposed weight copies
+    const bool mid = a2s_note_step_mid_bwd_ok(a);
+    bool any_mid = false;
+    if (mid) for (int s = a.steps - 1; s >= 0 && !any_mid; --s) any_mid = !note_bwd_step_fused(a, s);
+    if (any_fused || any_mid) { int rc = a2s_note_step_fused_bwd_prepare(st, a); if (rc) return rc; }
+    *mid_out = mid;
+    return A2S_OK;
+}
+static int note_bwd_finish(hipStream_t st, const a2s_note_dec_bwd_args& a, int cur) {
     if (cur != 0) {   // leave the final carry in dh[0]
-        e = hipMemcpyAsync(a.dh, a.dh + (long)R * H2, sizeof(float) * R * H2, hipMemcpyDeviceToDevice, st);
+        const hipError_t e = hipMemcpyAsync(a.dh, a.dh + (long)a.R * 2 * a.H, sizeof(float) * a.R * 2 * a.H, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd copy: %s", hipGetErrorString(e));
     }
+    return A2S_OK;
+}
+
+int a2s_note_decoder_bwd_impl(hipStream_t st, const a2s_note_dec_bwd_args& a) {
+    // few clips: one persistent launch for the whole reverse loop (a2s_dec_persist.hip)
+    if (a2s_note_decoder_bwd_persist_ok(a)) return a2s_note_decoder_bwd_persist(st, a);
+    bool mid = false;
+    int rc = note_bwd_prepare(st, a, &mid);
+    if (rc) return rc;
+    int cur = 0;
+    // rows step s covers on the few-row kernels: all R, or the rows still running (a prefix of row_list); the kernels take over for the steps
+    // whose rows fit them (see a2s_note_decoder_fwd_impl)
+    for (int s = a.steps - 1; s >= 0; --s) {
+        rc = note_bwd_step(st, a, s, cur, mid, 0, nullptr);
+        if (rc) return rc;
+    }
+    return note_bwd_finish(st, a, cur);
+}
+
+// The reverse loops of a segment's two NoteDecoders issued by ONE host loop on their two streams (forward: a2s_note_decoder_fwd_pair_impl,
+// a2s_seq.hip): the longer staff runs its last steps alone, then both staves step together and the attention sweep of a step is one launch for both.
+int a2s_note_decoder_bwd_pair_impl(hipStream_t su, hipStream_t sl, const a2s_note_dec_bwd_args& au, const a2s_note_dec_bwd_args& al, const int* pair_order,
+                                   const int* pair_rank, const int* pair_n_active) {
+    const a2s_note_dec_bwd_args* as[2] = {&au, &al};
+    hipStream_t sts[2] = {su, sl};
+    const bool can_pair = a2s_attn_pair_enabled() && su != sl && pair_order && pair_rank && pair_n_active && au.n_active && al.n_active && au.n_clips > 0 &&
+                          au.n_clips == al.n_clips && au.R == al.R && au.T == al.T && au.H == 256 && al.H == 256 && au.enc == al.enc && au.attn_ws && al.attn_ws &&
+                          !a2s_note_decoder_bwd_persist_ok(au) && !a2s_note_decoder_bwd_persist_ok(al) && a2s_note_step_mid_bwd_ok(au) && a2s_note_step_mid_bwd_ok(al);
+    if (!can_pair) {
+        const int rc = a2s_note_decoder_bwd_impl(su, au);
+        return rc ? rc : a2s_note_decoder_bwd_impl(sl, al);
+    }
+    static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k)
+        if (!ev[k]) { const hipError_t e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming); if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd_pair: hipEventCreate: %s", hipGetErrorString(e)); }
+    bool mid[2] = {false, false};
+    int cur[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) { const int rc = note_bwd_prepare(sts[k], *as[k], &mid[k]); if (rc) return rc; }
+    const int nmax = au.steps > al.steps ? au.steps : al.steps;
+    for (int s = nmax - 1; s >= 0; --s) {
+        bool in[2], fused[2] = {false, false};
+        for (int k = 0; k < 2; ++k) { in[k] = s < as[k]->steps; if (in[k]) fused[k] = note_bwd_step_fused(*as[k], s); }
+        AttnPairBwdStep p = {pair_order, pair_rank, au.n_clips, pair_n_active[s], s, 1, au.T};
+        const bool joint = in[0] && in[1] && mid[0] && mid[1] && !fused[0] && !fused[1] && p.n_active > 0 && au.n_active[s] > 0 && al.n_active[s] > 0;
+        if (!joint) {
+            for (int k = 0; k < 2; ++k)
+                if (in[k]) { const int rc = note_bwd_step(sts[k], *as[k], s, cur[k], mid[k], 0, nullptr); if (rc) return rc; }
+            continue;
+        }
+        for (int k = 0; k < 2; ++k) { const int rc = note_bwd_step(sts[k], *as[k], s, cur[k], mid[k], 1, nullptr); if (rc) return rc; }
+        hipError_t e = hipEventRecord(ev[1], sl);                           // the lower staff's dx of this step
+        if (e == hipSuccess) e = hipStreamWaitEvent(su, ev[1], 0);
+        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd_pair: event: %s", hipGetErrorString(e));
+        const int rc = attn_pair_bwd_sweep(su, au, al, s, p);
+        if (rc) return rc;
+        e = hipEventRecord(ev[0], su);
+        if (e == hipSuccess) e = hipStreamWaitEvent(sl, ev[0], 0);
+        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd_pair: event: %s", hipGetErrorString(e));
+        for (int k = 0; k < 2; ++k) { const int rc2 = note_bwd_step(sts[k], *as[k], s, cur[k], mid[k], 2, &p); if (rc2) return rc2; }
+    }
+    for (int k = 0; k < 2; ++k) { const int rc = note_bwd_finish(sts[k], *as[k], cur[k]); if (rc) return rc; }
     return A2S_OK;
 }
 
@@ -1044,6 +1125,200 @@ __global__ __launch_bounds__(256, ATT_BWD_MQ_WAVES) void attn_bwd_split256_mq(co
     }
 }
 
+// Both staves on one pass over the encoder outputs (round 6; forward: attn_fwd_split256_pair in a2s_seq.hip).  Pass A's matrix products have 16
+// output columns and a clip has at most 5 fused bars: the lower staff's dctx rows ride in columns NQ .. 2 NQ - 1 of the SAME MFMAs, so the chunk's
+// encoder rows are read once and multiplied once for both staves; pass B runs per staff over that staff's key image.  Per-staff outputs (ds, dq
+// partials, summed dctx) exactly as attn_bwd_split256_mq writes them; the staves' own attn_bwd_combine256 launches follow.
+struct AttnPairBwdSide { const float* Kmat; const float* q; const float* v; const float* attw; const float* ctx; const float* dctx_a; const float* dctx_b;
+                         float* dctx_out; float* dq_partial; float* ds_out; const int* row_until; };
+template <int NQ, bool NT>
+__global__ __launch_bounds__(256, ATT_BWD_MQ_WAVES) void attn_bwd_split256_pair(AttnPairBwdSide s0, AttnPairBwdSide s1, const float* __restrict__ enc, long ldq,
+                                                                                 long ldctx, long ldda, long lddb, long lddo, int T, int G, int chunk,
+                                                                                 const int* __restrict__ clip_order, int step, int n_clips) {
+    constexpr int H = 256, NJ = 2 * NQ;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dsv = sm;                                            // NJ x chunk
+    f32x4* red4 = reinterpret_cast<f32x4*>(sm + NJ * chunk);    // NQ * 3 * 64 float4 (one staff at a time) | the dctx image
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = clip_order ? clip_order[slot] : slot;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int onmask = 0;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        onmask |= (!s0.row_until || step < s0.row_until[j * n_clips + b]) ? (1 << j) : 0;
+        onmask |= (!s1.row_until || step < s1.row_until[j * n_clips + b]) ? (1 << (NQ + j)) : 0;
+    }
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    float* dcT = reinterpret_cast<float*>(red4);                // NJ x ATT_DCS floats
+    float* dots = dcT + NJ * ATT_DCS;                           // 16
+    for (int j = wave; j < NJ; j += 4) {
+        const AttnPairBwdSide& sd = j < NQ ? s0 : s1;
+        const int jr = j < NQ ? j : j - NQ;
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        float dot = 0.f;
+        if ((onmask >> j) & 1) {
+            const long row = (long)jr * n_clips + b;
+            d0 = *reinterpret_cast<const f32x4*>(sd.dctx_a + row * ldda + lane * 4);
+            d1 = *reinterpret_cast<const f32x4*>(sd.dctx_a + row * ldda + H + lane * 4);
+            if (sd.dctx_b) {
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(sd.dctx_b + row * lddb + lane * 4);
+                const f32x4 o1 = *reinterpret_cast<const f32x4*>(sd.dctx_b + row * lddb + H + lane * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { d0[c] += o0[c]; d1[c] += o1[c]; }
+            }
+            if (sd.dctx_out && g == 0) {
+                *reinterpret_cast<f32x4*>(sd.dctx_out + row * lddo + lane * 4) = d0;
+                *reinterpret_cast<f32x4*>(sd.dctx_out + row * lddo + H + lane * 4) = d1;
+            }
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(sd.ctx + row * ldctx + lane * 4);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(sd.ctx + row * ldctx + H + lane * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot += d0[c] * c0[c] + d1[c] * c1[c];
+            dot = wave_sum(dot);
+        }
+        *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + lane * 4) = d0;
+        *reinterpret_cast<f32x4*>(dcT + j * ATT_DCS + H + lane * 4) = d1;
+        if (lane == 0) dots[j] = dot;
+    }
+    __syncthreads();
+    const int c4 = tid & 63, rg = tid >> 6;
+    constexpr int KPRE = ATT_BWD_MQ_KPRE;
+    const int pre_side = (onmask & ((1 << NQ) - 1)) ? 0 : 1;          // the staff pass B starts with: its first K tiles are requested before pass A
+    f32x4 kpre[KPRE][4];
+    {
+        const float* Kp = (pre_side ? s1.Kmat : s0.Kmat) + ((long)b * T + t0) * H;
+#pragma unroll
+        for (int p = 0; p < KPRE; ++p)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                kpre[p][u] = (rg + 16 * p + 12 < n) ? ld_kv<NT>(Kp + (long)(rg + 16 * p + 4 * u) * H + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- pass A (see attn_bwd_split256_mq): da[t][j] = enc_t . dctx_j for the rows of BOTH staves in one set of matrix products
+    {
+        const int li = lane & 15, lg = lane >> 4;
+        const int lr = min(li, NJ - 1);
+        const float* brow = dcT + lr * ATT_DCS + 8 * lg;
+        const float dotn = dots[lr];
+        const bool mine = li < NJ && ((onmask >> li) & 1);
+        const AttnPairBwdSide& sd = lr < NQ ? s0 : s1;
+        const long arow = ((long)(lr < NQ ? lr : lr - NQ) * n_clips + b) * T + t0;
+        const float* attw = sd.attw;
+        float* ds_out = sd.ds_out;
+        for (int blk = wave; blk * 16 < n; blk += 4) {
+            const int fr = blk * 16 + li;
+            const bool valid = fr < n;
+            const float* ep = Eb + (long)min(fr, n - 1) * 2 * H + 8 * lg;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+            float aw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f2 = blk * 16 + 4 * lg + r;
+                aw[r] = (mine && f2 < n) ? attw[arow + f2] : 0.f;
+            }
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) {
+                f32x4 e0 = ld_kv<NT>(ep + 32 * u);
+                f32x4 e1 = ld_kv<NT>(ep + 32 * u + 4);
+                if (!valid) e0 = e1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * u);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 32 * u + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[c], b0[c], acc, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[c], b1[c], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+            if (mine) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f2 = blk * 16 + 4 * lg + r;
+                    if (f2 < n) {
+                        const float d_s = aw[r] * (acc[r] - dotn);
+                        dsv[li * chunk + f2] = d_s;
+                        if (ds_out) ds_out[arow + f2] = d_s;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass B, per staff: dq_j += ds_t (1 - tanh^2(K_tj + q_j)) over that staff's key image
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int side = pass == 0 ? pre_side : 1 - pre_side;
+        const int smask = (onmask >> (side * NQ)) & ((1 << NQ) - 1);
+        if (!smask) continue;                                      // uniform over the workgroup
+        const AttnPairBwdSide& sd = side ? s1 : s0;
+        const float* Kb = sd.Kmat + ((long)b * T + t0) * H;
+        const float* dsj = dsv + side * NQ * chunk;
+        f32x4 q4[NQ], acc[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            q4[j] = ((smask >> j) & 1) ? *reinterpret_cast<const f32x4*>(sd.q + ((long)j * n_clips + b) * ldq + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);
+        }
+        int i = rg;
+        auto tile = [&](const f32x4 (&k)[4]) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (!((smask >> j) & 1)) continue;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float w = dsj[j * chunk + i + 4 * u];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(k[u][c], q4[j][c]), acc[j][c]);
+                }
+            }
+        };
+        if (pass == 0) {
+#pragma unroll
+            for (int p = 0; p < KPRE; ++p)
+                if (i + 12 < n) { tile(kpre[p]); i += 16; }
+        }
+        for (; i + 12 < n; i += 16) {
+            f32x4 k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = ld_kv<NT>(Kb + (long)(i + 4 * u) * H + c4 * 4);
+            tile(k);
+        }
+        for (; i < n; i += 4) {
+            const f32x4 k0 = ld_kv<NT>(Kb + (long)i * H + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (!((smask >> j) & 1)) continue;
+                const float w = dsj[j * chunk + i];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[j][c] = fmaf(w, sech2_ek(k0[c], q4[j][c]), acc[j][c]);
+            }
+        }
+        if (pass == 1) __syncthreads();                            // the first staff's reduction is done with the scratch
+        if (rg > 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) red4[(j * 3 + rg - 1) * 64 + c4] = acc[j];
+        }
+        __syncthreads();
+        if (rg == 0) {
+            const f32x4 v4 = {sd.v[c4 * 4], sd.v[c4 * 4 + 1], sd.v[c4 * 4 + 2], sd.v[c4 * 4 + 3]};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (!((smask >> j) & 1)) continue;
+                f32x4 a = acc[j];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { const f32x4 o = red4[(j * 3 + u) * 64 + c4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] += o[c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] *= v4[c];
+                *reinterpret_cast<f32x4*>(sd.dq_partial + (((long)slot * NQ + j) * G + g) * H + c4 * 4) = a;
+            }
+        }
+    }
+}
+
 // one workgroup (256 threads) per row: dq = sum of the G partials; rows the forward pass skipped (upstream gradient exactly zero) get
 // zeros in everything the deferred GEMMs read (dq, ds, dctx)
 __global__ __launch_bounds__(256) void attn_bwd_combine256(const float* __restrict__ dq_partial, float* __restrict__ dq, long lddq, int G,
@@ -1141,6 +1416,55 @@ int a2s_attn_step_bwd_split_impl(hipStream_t st, const float* Kmat, const float*
     }
     hipLaunchKernelGGL(attn_bwd_combine256, dim3(B), dim3(256), 0, st, ws, dq, lddq, G, r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step,
                        ds_out, T, dctx_out, lddo);
+    A2S_CHECK_LAUNCH("attn_bwd_combine256");
+    return A2S_OK;
+}
+
+template <int NQ>
+static void launch_bwd_pair(hipStream_t st, int nwg, size_t shm, const AttnPairBwdSide& s0, const AttnPairBwdSide& s1, const float* enc, long ldq, long ldctx,
+                            long ldda, long lddb, long lddo, int T, const AttnPairBwdStep& p) {
+    hipLaunchKernelGGL((attn_bwd_split256_pair<NQ, false>), dim3(nwg), dim3(256), shm, st, s0, s1, enc, ldq, ldctx, ldda, lddb, lddo, T, p.G, p.chunk,
+                       p.clip_order, p.step, p.n_clips);
+}
+static long g_attn_pair_bwd_launches = 0;
+long a2s_attn_pair_bwd_launches(void) { return g_attn_pair_bwd_launches; }
+
+static AttnPairBwdSide attn_pair_bwd_side(const a2s_note_dec_bwd_args& a, int s) {
+    const int H2 = 2 * a.H, ldx = a.E + H2;
+    const long R = a.R;
+    return AttnPairBwdSide{a.keys, a.q + (long)s * R * a.H, a.attn_v, a.attw + (long)s * R * a.T, a.x + (long)s * R * ldx + a.E, a.dx + (long)s * R * ldx + a.E,
+                           a.do_all + (long)s * R * 2 * H2 + H2, a.dctx_all + (long)s * R * H2, a.attn_ws + A2S_ATTN_TICKETS, a.ds_all + (long)s * R * a.T, a.row_until};
+}
+
+static int attn_pair_bwd_sweep(hipStream_t st, const a2s_note_dec_bwd_args& au, const a2s_note_dec_bwd_args& al, int s, AttnPairBwdStep& p) {
+    const int T = au.T, H2 = 2 * au.H, ldx = au.E + H2, groups = au.R / p.n_clips;
+    A2S_REQUIRE(au.H == 256 && au.E == al.E && au.enc == al.enc && au.R == al.R && groups >= 1 && groups <= A2S_ATTN_MAX_GROUPS && ldx % 4 == 0,
+                "attn_pair_bwd_sweep: the staves must decode the same rows over the same encoder outputs");
+    a2s_attn_split_geometry(p.n_active, T, &p.G, &p.chunk);
+    const AttnPairBwdSide s0 = attn_pair_bwd_side(au, s), s1 = attn_pair_bwd_side(al, s);
+    const size_t red = (size_t)groups * 3 * 64 * 4, img = (size_t)2 * groups * ATT_DCS + 16;
+    const size_t shm = a2s_attn_bulk_lds(((size_t)2 * groups * p.chunk + (red > img ? red : img)) * sizeof(float), p.n_active, 3);
+    const int nwg = p.n_active * p.G;
+#define A2S_BWD_PAIR(N) launch_bwd_pair<N>(st, nwg, shm, s0, s1, au.enc, au.H, ldx, ldx, 2 * H2, H2, T, p)
+    switch (groups) {
+        case 1: A2S_BWD_PAIR(1); break;
+        case 2: A2S_BWD_PAIR(2); break;
+        case 3: A2S_BWD_PAIR(3); break;
+        case 4: A2S_BWD_PAIR(4); break;
+        default: A2S_BWD_PAIR(5); break;
+    }
+#undef A2S_BWD_PAIR
+    A2S_CHECK_LAUNCH("attn_bwd_split256_pair");
+    __atomic_fetch_add(&g_attn_pair_bwd_launches, 1, __ATOMIC_RELAXED);
+    return A2S_OK;
+}
+
+// one staff's dq reduction behind a pair sweep (rows the forward skipped: zeros in dq, ds, dctx)
+static int attn_pair_bwd_combine(hipStream_t st, const a2s_note_dec_bwd_args& a, int s, const AttnPairBwdStep& p) {
+    const int H2 = 2 * a.H;
+    const long R = a.R;
+    hipLaunchKernelGGL(attn_bwd_combine256, dim3(a.R), dim3(256), 0, st, a.attn_ws + A2S_ATTN_TICKETS, a.dq_all + (long)s * R * a.H, (long)a.H, p.G, p.clip_rank,
+                       a.row_until, p.n_clips, a.R / p.n_clips, p.n_active, p.step, a.ds_all + (long)s * R * a.T, a.T, a.dctx_all + (long)s * R * H2, (long)H2);
     A2S_CHECK_LAUNCH("attn_bwd_combine256");
     return A2S_OK;
 }

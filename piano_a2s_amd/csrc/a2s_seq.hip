@@ -521,6 +521,11 @@ int a2s_note_step_fused_fwd(hipStream_t st, const a2s_note_dec_args& a, int si, 
 bool a2s_note_step_mid_ok(int H, int E, const void* const* ptrs, int nptrs);
 int a2s_note_step_mid_gru(hipStream_t st, const a2s_note_dec_args& a, int si, int so, int sv, int sv_next, int nrows, const int* rowmap);
 // rows the fused step of step t would cover: all R, or (training, finished rows skipped) the rows still running, a prefix of row_list
+// both staves' sweeps of a step in one launch (round 6, further down): the pair's clip bookkeeping at this step and the geometry its partials use
+struct AttnPairStep { const int* clip_order; const int* clip_rank; int n_clips; int n_active; int step; int G; int chunk; };
+static int attn_pair_sweep(hipStream_t st, const NoteDecArgs& au, const NoteDecArgs& al, int sv, AttnPairStep& p);
+static int attn_pair_combine(hipStream_t st, const NoteDecArgs& a, int si, int sv, const AttnPairStep& p);
+int a2s_attn_pair_enabled(void);
 static int note_step_rows(const NoteDecArgs& a, int t) { return (a.row_list && a.n_rows_active && t >= 0) ? a.n_rows_active[t] : a.R; }
 static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
     const void* ptrs[] = {a.x, a.h, a.o, a.q, a.w_ih, a.w_hh, a.out_w, a.attn_w};
@@ -543,7 +548,7 @@ static int enqueue_query(hipStream_t st, const NoteDecArgs& a, int si, int sv) {
 // per-step saved tensors (q, o, gates, attention weights) go to index `sv`.  fused: the few-row path of a2s_step.hip -- the query
 // of slot sv must already be there (enqueue_query / the previous step), this step leaves the next one's in slot sv_next (!last).
 static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int so, int sv, int t, const int* t_base, int tf,
-                             bool fused = false, int sv_next = 0, bool last = false) {
+                             bool fused = false, int sv_next = 0, bool last = false, const AttnPairStep* pair = nullptr) {
     const int H2 = 2 * a.H, ldx = a.E + H2;
     if (fused) {
         float* xs = a.x + (long)si * a.R * ldx;
@@ -576,8 +581,10 @@ static int enqueue_note_step(hipStream_t st, const NoteDecArgs& a, int si, int s
         // round 6 (a2s_step.hip): the query of slot sv is already there (enqueue_query / the previous step, as on the few-row path); behind the
         // attention ONE launch for the GRU cell (dec_gru_mid: gh, gi, gates) and ONE for the logits and the next step's query (dec_outq_mid), over
         // the rows still running
-        rc = a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
-                                    a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws, rows);
+        // (pair: the sweep of this step has been launched for both staves at once -- only this staff's combine is left)
+        rc = pair ? attn_pair_combine(st, a, si, sv, *pair)
+                  : a2s_attn_step_fwd_impl(st, a.keys, a.enc, qs, a.H, a.attn_v, xs + a.E, ldx, os + H2, 2 * H2,
+                                           a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.R, a.T, a.H, a.gt ? nullptr : a.n_done, a.R, a.attn_ws, rows);
         if (rc) return rc;
         const int nrows = note_step_rows(a, t);
         rc = a2s_note_step_mid_gru(st, a, si, so, sv, last ? -1 : sv_next, nrows, nrows < a.R ? a.row_list : nullptr);
@@ -662,23 +669,27 @@ static int note_decoder_greedy_graph(hipStream_t st, const NoteDecArgs& a, int* 
 bool a2s_note_decoder_fwd_persist_ok(const a2s_note_dec_args& a);
 int a2s_note_decoder_fwd_persist(hipStream_t st, const a2s_note_dec_args& a, int* steps_done);
 
+// Tail steps on the few-row kernels write only the rows still running.  What the backward pass reads of the others (operands of its
+// weight-gradient products over all rows and steps, the saved gates) must be finite: everything behind slot 0 starts as zeros
+// (~6 GB per training step at B = 256, ~1.3 ms; issued here and not by the Python host: see engine.Engine._decode_staff).
+static int note_decoder_zero_fill(hipStream_t st, const NoteDecArgs& a) {
+    if (!(a.row_list && a.n_rows_active && a.steps > 0)) return A2S_OK;
+    const long H2 = 2L * a.H, ldx = a.E + H2, n = a.steps, R = a.R;
+    hipError_t e = hipMemsetAsync(a.h + R * H2, 0, sizeof(float) * n * R * H2, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.x + R * ldx, 0, sizeof(float) * n * R * ldx, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.q, 0, sizeof(float) * n * R * a.H, st);
+    if (e == hipSuccess) e = hipMemsetAsync(a.o, 0, sizeof(float) * n * R * 2 * H2, st);
+    if (e == hipSuccess && a.gates) e = hipMemsetAsync(a.gates, 0, sizeof(float) * n * R * 4 * H2, st);
+    if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder memset: %s", hipGetErrorString(e));
+    return A2S_OK;
+}
+
 int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_done) {
     // few clips: one persistent launch for the whole call (a2s_dec_persist.hip)
     if (a2s_note_decoder_fwd_persist_ok(a)) return a2s_note_decoder_fwd_persist(st, a, steps_done);
     // stream capture is not allowed on the legacy default stream: callers that want the graph path run on a created stream
     if (!a.gt && a.use_graph && a.t_base && !a.gates && !a.attw && !a.drop && st != nullptr) return note_decoder_greedy_graph(st, a, steps_done);
-    if (a.row_list && a.n_rows_active && a.steps > 0) {
-        // Tail steps on the few-row kernels write only the rows still running.  What the backward pass reads of the others (operands of its
-        // weight-gradient products over all rows and steps, the saved gates) must be finite: everything behind slot 0 starts as zeros
-        // (~6 GB per training step at B = 256, ~1.3 ms; issued here and not by the Python host: see engine.Engine._decode_staff).
-        const long H2 = 2L * a.H, ldx = a.E + H2, n = a.steps, R = a.R;
-        hipError_t e = hipMemsetAsync(a.h + R * H2, 0, sizeof(float) * n * R * H2, st);
-        if (e == hipSuccess) e = hipMemsetAsync(a.x + R * ldx, 0, sizeof(float) * n * R * ldx, st);
-        if (e == hipSuccess) e = hipMemsetAsync(a.q, 0, sizeof(float) * n * R * a.H, st);
-        if (e == hipSuccess) e = hipMemsetAsync(a.o, 0, sizeof(float) * n * R * 2 * H2, st);
-        if (e == hipSuccess && a.gates) e = hipMemsetAsync(a.gates, 0, sizeof(float) * n * R * 4 * H2, st);
-        if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder memset: %s", hipGetErrorString(e));
-    }
+    { const int rc0 = note_decoder_zero_fill(st, a); if (rc0) return rc0; }
     int s = 0;
     // The few-row step kernels take over as soon as the rows still running fit them (the whole call when it is small; the tail of a large
     // training call otherwise: the handful of full-length rows then decode in 4 launches per step instead of 12 over every row).  The
@@ -700,6 +711,62 @@ int a2s_note_decoder_fwd_impl(hipStream_t st, const NoteDecArgs& a, int* steps_d
         }
     }
     if (steps_done) *steps_done = s;
+    return A2S_OK;
+}
+
+// The two NoteDecoders of a segment (models.py:261-275) decoded by ONE host loop on their two streams: while both staves run a step on the
+// mid-size kernels, the step's attention sweep is one launch for both (attn_fwd_split256_pair on the upper staff's stream: it waits for the lower
+// staff's query, the lower staff's stream waits for it); everything else of a step stays per staff on the staff's own stream, and every step that
+// does not qualify (one staff has ended, or runs its tail on the few-row kernels) is the single-staff step unchanged.  pair_n_active: HOST array,
+// max(steps) ints -- clips with an unfinished row of either staff at step t, a prefix of pair_order.
+int a2s_note_decoder_fwd_pair_impl(hipStream_t su, hipStream_t sl, const NoteDecArgs& au, const NoteDecArgs& al, const int* pair_order,
+                                   const int* pair_rank, const int* pair_n_active, int* done_u, int* done_l) {
+    const NoteDecArgs* as[2] = {&au, &al};
+    hipStream_t sts[2] = {su, sl};
+    const bool can_pair = a2s_attn_pair_enabled() && su != sl && pair_order && pair_rank && pair_n_active && au.gt && al.gt && au.n_active && al.n_active &&
+                          au.n_clips > 0 && au.n_clips == al.n_clips && au.R == al.R && au.T == al.T && au.H == 256 && al.H == 256 && au.enc == al.enc &&
+                          au.attn_ws && al.attn_ws && !a2s_note_decoder_fwd_persist_ok(au) && !a2s_note_decoder_fwd_persist_ok(al) &&
+                          note_step_mid(au, nullptr) && note_step_mid(al, nullptr);
+    if (!can_pair) {
+        int rc = a2s_note_decoder_fwd_impl(su, au, done_u);
+        return rc ? rc : a2s_note_decoder_fwd_impl(sl, al, done_l);
+    }
+    static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k)
+        if (!ev[k]) { const hipError_t e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming); if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_fwd_pair: hipEventCreate: %s", hipGetErrorString(e)); }
+    for (int k = 0; k < 2; ++k) { const int rc = note_decoder_zero_fill(sts[k], *as[k]); if (rc) return rc; }
+    bool prev_q[2] = {false, false};
+    const int nmax = au.steps > al.steps ? au.steps : al.steps;
+    for (int s = 0; s < nmax; ++s) {
+        bool fused[2] = {false, false}, in[2];
+        for (int k = 0; k < 2; ++k) {
+            in[k] = s < as[k]->steps;
+            if (!in[k]) continue;
+            fused[k] = note_step_fusable(*as[k], s);
+            if (!prev_q[k]) { const int rc = enqueue_query(sts[k], *as[k], s, s); if (rc) return rc; }       // (every step here is a fused or a mid-size one)
+            prev_q[k] = true;
+        }
+        AttnPairStep p = {pair_order, pair_rank, au.n_clips, pair_n_active[s < nmax ? s : 0], s, 1, au.T};
+        const bool joint = in[0] && in[1] && !fused[0] && !fused[1] && p.n_active > 0 && au.n_active[s] > 0 && al.n_active[s] > 0;
+        if (joint) {
+            hipError_t e = hipEventRecord(ev[1], sl);                       // the lower staff's query of this step
+            if (e == hipSuccess) e = hipStreamWaitEvent(su, ev[1], 0);
+            if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_fwd_pair: event: %s", hipGetErrorString(e));
+            const int rc = attn_pair_sweep(su, au, al, s, p);
+            if (rc) return rc;
+            e = hipEventRecord(ev[0], su);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sl, ev[0], 0);
+            if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_fwd_pair: event: %s", hipGetErrorString(e));
+        }
+        for (int k = 0; k < 2; ++k) {
+            if (!in[k]) continue;
+            const NoteDecArgs& a = *as[k];
+            const int rc = enqueue_note_step(sts[k], a, s, s + 1, s, s, nullptr, a.tf_flags ? a.tf_flags[s] : 0, fused[k], s + 1, s + 1 == a.steps, joint ? &p : nullptr);
+            if (rc) return rc;
+        }
+    }
+    if (done_u) *done_u = au.steps;
+    if (done_l) *done_l = al.steps;
     return A2S_OK;
 }
 
@@ -1184,6 +1251,146 @@ __global__ __launch_bounds__(256) void attn_fwd_split256_mq(const float* __restr
 
 
 
+// ---- both staves on one pass over the encoder outputs (round 6).  The upper and the lower NoteDecoder of a segment attend over the SAME encoder
+// outputs with key images of their own (models.py:261-275: both decode_notes calls get `encoder_outputs`); per decode step a clip's sweep is
+// 1.23 MB of keys + 2.46 MB of encoder outputs per staff.  While both staves of a clip still decode, this kernel scores the chunk against the
+// upper staff's key image and queries, then against the lower staff's, and forms all 2 * NQ partial contexts from ONE pass over the chunk's
+// encoder rows: 4.92 MB per clip and step instead of 7.38.  Same passes, partial layout and raw scores as attn_fwd_split256_mq, per staff into
+// that staff's workspace -- the staves' own combine launches follow unchanged.  Clips in the order of the PAIR (the step the clip's last row of
+// either staff finishes at); a staff without an unfinished row in a clip is skipped there (its key image is not read).
+struct AttnPairSide { const float* Kmat; const float* q; const float* v; float* partial; float* scores; const int* row_until; };
+template <int NQ, bool NT>
+__global__ __launch_bounds__(256) void attn_fwd_split256_pair(AttnPairSide s0, AttnPairSide s1, const float* __restrict__ enc, long ldq, int T, int G, int chunk,
+                                                              const int* __restrict__ clip_order, int step, int n_clips) {
+    constexpr int H = 256, NJ = 2 * NQ;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pw = sm;                                   // NJ x chunk weights
+    float* red = sm + NJ * chunk;                     // 16 + NJ * 128 * 4 floats
+    const int slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int b = clip_order ? clip_order[slot] : slot;
+    const int t0 = g * chunk, t1 = min(T, t0 + chunk), n = t1 - t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool on[NJ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        on[j] = !s0.row_until || step < s0.row_until[j * n_clips + b];
+        on[NQ + j] = !s1.row_until || step < s1.row_until[j * n_clips + b];
+    }
+    // ---- pass 1, once per staff: scores of the chunk against that staff's key image
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const AttnPairSide& sd = side ? s1 : s0;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) any = any || on[side * NQ + j];
+        if (!any) continue;                            // uniform over the workgroup
+        const float* Kb = sd.Kmat + ((long)b * T + t0) * H;
+        f32x4 q4[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            q4[j] = on[side * NQ + j] ? *reinterpret_cast<const f32x4*>(sd.q + ((long)j * n_clips + b) * ldq + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q4[j][c] = exp2x_clamped(q4[j][c]);
+        const f32x4 v4 = {sd.v[lane * 4], sd.v[lane * 4 + 1], sd.v[lane * 4 + 2], sd.v[lane * 4 + 3]};
+        for (int r = wave * 4; r < n; r += 16) {
+            f32x4 k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                k[u] = (r + u < n) ? ld_kv<NT>(Kb + (long)(r + u) * H + lane * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (!on[side * NQ + j]) continue;
+                float sj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    sj[u] = v4[0] * tanh_ek(k[u][0], q4[j][0]) + v4[1] * tanh_ek(k[u][1], q4[j][1])
+                          + v4[2] * tanh_ek(k[u][2], q4[j][2]) + v4[3] * tanh_ek(k[u][3], q4[j][3]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sj[u] = wave_sum_lane63(sj[u]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (r + u < n) pw[(side * NQ + j) * chunk + r + u] = sj[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float mj[NJ], lj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        mj[j] = 0.f; lj[j] = 0.f;
+        if (!on[j]) continue;
+        float* scores = j < NQ ? s0.scores : s1.scores;
+        const int jr = j < NQ ? j : j - NQ;
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += 256) m = fmaxf(m, pw[j * chunk + i]);
+        m = block_max(m, red);
+        float l = 0.f;
+        for (int i = tid; i < n; i += 256) {
+            const float sc = pw[j * chunk + i];
+            if (scores) scores[((long)jr * n_clips + b) * T + t0 + i] = sc;
+            const float p = __expf(sc - m);
+            pw[j * chunk + i] = p; l += p;
+        }
+        l = block_sum(l, red);
+        mj[j] = m; lj[j] = l;
+    }
+    __syncthreads();
+    // ---- pass 2, once: every partial context from one pass over the chunk's encoder rows
+    const float* Eb = enc + ((long)b * T + t0) * 2 * H;
+    const int c4 = tid & 127, rp = tid >> 7;
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int i = rp;
+    for (; i + 6 < n; i += 8) {
+        const f32x4 e0 = ld_kv<NT>(Eb + (long)(i + 0) * 2 * H + c4 * 4);
+        const f32x4 e1 = ld_kv<NT>(Eb + (long)(i + 2) * 2 * H + c4 * 4);
+        const f32x4 e2 = ld_kv<NT>(Eb + (long)(i + 4) * 2 * H + c4 * 4);
+        const f32x4 e3 = ld_kv<NT>(Eb + (long)(i + 6) * 2 * H + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (!on[j]) continue;
+            const float* pj = pw + j * chunk;
+            const float w0 = pj[i], w1 = pj[i + 2], w2 = pj[i + 4], w3 = pj[i + 6];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] += w0 * e0[c] + w1 * e1[c] + w2 * e2[c] + w3 * e3[c];
+        }
+    }
+    for (; i < n; i += 2) {
+        const f32x4 e0 = ld_kv<NT>(Eb + (long)i * 2 * H + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (!on[j]) continue;
+            const float w0 = pw[j * chunk + i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[j][c] += w0 * e0[c];
+        }
+    }
+    f32x4* red4 = reinterpret_cast<f32x4*>(red + 16);
+    if (rp == 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) red4[j * 128 + c4] = acc[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (!on[j]) continue;
+        const int jr = j < NQ ? j : j - NQ;
+        float* pout = (j < NQ ? s0.partial : s1.partial) + (((long)slot * NQ + jr) * G + g) * (2 * H + 4);
+        if (rp == 0) {
+            const f32x4 o = red4[j * 128 + c4];
+            f32x4 a = acc[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] += o[c];
+            *reinterpret_cast<f32x4*>(pout + 4 + c4 * 4) = a;
+        }
+        if (tid == 0) { pout[0] = mj[j]; pout[1] = lj[j]; }
+    }
+}
+
 // ---- few-clip form of the sweep (round 5).  The kernels above stream a chunk in rounds of 4 frames per wave / 4 rows per thread -- 5 + 10 dependent
 // load rounds for a 76-frame chunk -- which is right for a launch that fills the chip many times over and wrong for the long-clip chain, where a launch
 // covers a handful of clips, every workgroup has a CU to itself and the kernel's time IS its dependent round trips (each 2-3x longer while the bulk group's
@@ -1470,6 +1677,60 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     }
     hipLaunchKernelGGL(attn_fwd_combine256, dim3(B), dim3(256), 0, st, part, ctx, ldctx, ctx2, ldctx2, attw, T, G, n_done, n_rows_total,
                        r.clip_rank, r.row_until, r.n_clips, groups, r.n_active, r.step);
+    A2S_CHECK_LAUNCH("attn_fwd_combine256");
+    return A2S_OK;
+}
+
+// ---- the two staves' sweeps of one decode step as ONE launch (attn_fwd_split256_pair), then each staff's own combine (a2s_attn_pair_combine, on
+// that staff's stream).  rows_u / rows_l: the staves' row bookkeeping (row_until of their own); pair: clip order / rank / active count of the
+// PAIR at this step.  Both staves' partials use the pair's geometry.
+static int g_attn_pair = 1;                  // a2s_debug_set("attn_pair", 0): every staff sweeps on its own (the A/B and the parity tests)
+static long g_attn_pair_launches = 0;
+void a2s_attn_pair_set(int on) { g_attn_pair = on ? 1 : 0; }
+int a2s_attn_pair_enabled(void) { return g_attn_pair; }
+long a2s_attn_pair_launches(void) { return g_attn_pair_launches; }
+
+template <int NQ>
+static void launch_fwd_pair(hipStream_t st, int nwg, size_t shm, const AttnPairSide& s0, const AttnPairSide& s1, const float* enc, long ldq, int T,
+                            const AttnPairStep& p, bool nt) {
+    if (nt && shm > 65536) {
+        static bool raised = false;
+        if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_split256_pair<NQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304); raised = true; }
+    }
+    if (nt) hipLaunchKernelGGL((attn_fwd_split256_pair<NQ, true>), dim3(nwg), dim3(256), shm, st, s0, s1, enc, ldq, T, p.G, p.chunk, p.clip_order, p.step, p.n_clips);
+    else hipLaunchKernelGGL((attn_fwd_split256_pair<NQ, false>), dim3(nwg), dim3(256), shm, st, s0, s1, enc, ldq, T, p.G, p.chunk, p.clip_order, p.step, p.n_clips);
+}
+
+static int attn_pair_sweep(hipStream_t st, const NoteDecArgs& au, const NoteDecArgs& al, int sv, AttnPairStep& p) {
+    const int T = au.T, H = au.H, groups = au.R / p.n_clips;
+    A2S_REQUIRE(H == 256 && au.attn_ws && al.attn_ws && au.enc == al.enc && au.R == al.R && au.T == al.T && groups >= 1 && groups <= A2S_ATTN_MAX_GROUPS,
+                "attn_pair_sweep: the staves must decode the same rows over the same encoder outputs");
+    a2s_attn_split_geometry(p.n_active, T, &p.G, &p.chunk);
+    const AttnPairSide s0 = {au.keys, au.q + (long)sv * au.R * H, au.attn_v, au.attn_ws + A2S_ATTN_TICKETS, au.attw ? au.attw + (long)sv * au.R * T : nullptr, au.row_until};
+    const AttnPairSide s1 = {al.keys, al.q + (long)sv * al.R * H, al.attn_v, al.attn_ws + A2S_ATTN_TICKETS, al.attw ? al.attw + (long)sv * al.R * T : nullptr, al.row_until};
+    const bool nt = a2s_attn_nt_enabled() > 0 && p.n_active >= a2s_attn_nt_enabled();
+    const size_t shm = a2s_attn_bulk_lds(((size_t)2 * groups * p.chunk + 16 + (size_t)2 * groups * 128 * 4) * sizeof(float), p.n_active, 2);
+    const int nwg = p.n_active * p.G;
+    switch (groups) {
+        case 1: launch_fwd_pair<1>(st, nwg, shm, s0, s1, au.enc, H, T, p, nt); break;
+        case 2: launch_fwd_pair<2>(st, nwg, shm, s0, s1, au.enc, H, T, p, nt); break;
+        case 3: launch_fwd_pair<3>(st, nwg, shm, s0, s1, au.enc, H, T, p, nt); break;
+        case 4: launch_fwd_pair<4>(st, nwg, shm, s0, s1, au.enc, H, T, p, nt); break;
+        default: launch_fwd_pair<5>(st, nwg, shm, s0, s1, au.enc, H, T, p, nt); break;
+    }
+    A2S_CHECK_LAUNCH("attn_fwd_split256_pair");
+    __atomic_fetch_add(&g_attn_pair_launches, 1, __ATOMIC_RELAXED);
+    return A2S_OK;
+}
+
+// one staff's combine behind a pair sweep: contexts into x[si][:, E:] and o[sv][:, 2H:], weights normalised in place
+static int attn_pair_combine(hipStream_t st, const NoteDecArgs& a, int si, int sv, const AttnPairStep& p) {
+    const int H2 = 2 * a.H, ldx = a.E + H2;
+    float* xs = a.x + (long)si * a.R * ldx;
+    float* os = a.o + (long)sv * a.R * 2 * H2;
+    hipLaunchKernelGGL(attn_fwd_combine256, dim3(a.R), dim3(256), 0, st, a.attn_ws + A2S_ATTN_TICKETS, xs + a.E, (long)ldx, os + H2, (long)(2 * H2),
+                       a.attw ? a.attw + (long)sv * a.R * a.T : nullptr, a.T, p.G, (const int*)nullptr, a.R, p.clip_rank, a.row_until, p.n_clips,
+                       a.R / p.n_clips, p.n_active, p.step);
     A2S_CHECK_LAUNCH("attn_fwd_combine256");
     return A2S_OK;
 }

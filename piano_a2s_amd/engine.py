@@ -104,6 +104,7 @@ _BAR_ATTN_WS = {}
 # the round-4 persistent note decoder for the last clip group also while another group decodes beside it (tests only: it owns every CU it runs on
 # and stops the bulk group there -- 540 against 514 ms per step, profiles/r04_dec_persist_beside_bulk.txt)
 _PERSIST_BESIDE = False
+_PAIR_STAVES = True             # group 0's two staves issued by one host loop, their sweeps sharing the encoder-output reads (Engine._decode_pair)
 
 
 def bar_attn_workspace(device, group, n_clips, T, H):
@@ -313,6 +314,7 @@ class Engine:
     def __init__(self, cfg, sync_bn=False):
         self.cfg = cfg
         self.attn_clip_steps = []
+        self.attn_shared_clip_steps = []       # ... of which: pairs served by a pass shared between the two staves (Engine._decode_pair)
         self.poll = 16            # greedy decode: host looks at the device-side done counter every `poll` steps
         # Synchronised BatchNorm (what SpeechBrain's DDP wrapping gives the reference): batch statistics over the
         # GLOBAL minibatch -- per-channel (sum, sum of squares, count) are all-reduced between the ranks.  Off by default:
@@ -492,7 +494,7 @@ class Engine:
                                i64=ids_are_i64, hsave=hsave))
 
     def _decode_staff(self, S, prefix, keys, enc, h0, max_steps, probs_bar, gt_bar, steps, tf_flags, training, drop_p, B, T, attn_ws=None, gemm_ws=None,
-                      active=None, drop=None, flags_dev=None, persist=False):
+                      active=None, drop=None, flags_dev=None, persist=False, defer_launch=False):
         """One NoteDecoder.decode_notes call over B rows.  probs_bar: view (B, max_steps, V) of the output tensor (strided).
         tf_flags: per step, bit g = teacher-force the rows of group g.
         active: optional dict(until: (B,) int32, order / rank: (n_clips,) int32 device tensors; n_active: host int array per step;
@@ -569,17 +571,37 @@ class Engine:
                 persist_ws = torch.empty(nb_ws, dtype=torch.uint8, device=dev)
                 a.persist_ws, a.persist_ws_bytes = persist_ws.data_ptr(), nb_ws
                 a.tf_flags_dev = flags_dev.data_ptr() if flags_dev is not None else None
+        def finish(launched):
+            # steps the reference would have executed: known from the plan with ground truth; read back from the device
+            # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
+            executed = n if gt_bar is not None else int(steps_exec.item())
+            if gt_bar is None and a.persist_ws:
+                hip.check_persist_abort(dev, raise_error=True)       # (the host has just synchronised: a persistent launch that gave up returns unusable ids)
+            saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=launched, ids=ids, flags=list(flags),
+                         gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active, flags_dev=flags_dev,
+                         step_ws=step_ws, persist_ws=persist_ws, logits=logits, gh=gh, gi=gi, eos_seen=eos_seen, n_done=n_done)
+            return ids, lengths, saved
+        if defer_launch:                      # _decode_pair: the arguments are ready, the caller launches both staves with one call
+            return a, finish
         done = C.c_int(0)
         hip.check(L.a2s_note_decoder_fwd(hip.stream(), C.byref(a), C.byref(done)), "a2s_note_decoder_fwd")
-        # steps the reference would have executed: known from the plan with ground truth; read back from the device
-        # in greedy mode (launched steps can overshoot the early break by < poll; those were no-ops)
-        executed = n if gt_bar is not None else int(steps_exec.item())
-        if gt_bar is None and a.persist_ws:
-            hip.check_persist_abort(dev, raise_error=True)       # (the host has just synchronised: a persistent launch that gave up returns unusable ids)
-        saved = dict(h=h, x=x, q=q, o=o, gates=gates, attw=attw, drop=drop, steps=executed, launched=done.value, ids=ids, flags=list(flags),
-                     gt_bar=gt_bar, prefix=prefix, max_steps=max_steps, drop_p=drop_p, attn_ws=attn_ws, gemm_ws=gemm_ws, active=active, flags_dev=flags_dev,
-                     step_ws=step_ws, persist_ws=persist_ws)
-        return ids, lengths, saved
+        return finish(done.value)
+
+    def _decode_pair(self, calls, streams, pair):
+        """The two NoteDecoder calls of a segment (models.py:261-275) issued by ONE host loop: calls = the argument tuples of _decode_staff for the
+        upper and the lower staff, streams = their streams, pair = dict(order, rank: device int32 (n_clips,), n_active: host int array) -- the
+        clip bookkeeping of both staves together.  While both staves run, a decode step's attention sweep is one launch that reads the encoder
+        outputs once (a2s_note_decoder_fwd_pair)."""
+        prepared = []
+        for st, args in zip(streams, calls):
+            with torch.cuda.stream(st):
+                prepared.append(self._decode_staff(*args, defer_launch=True))
+        (au, fin_u), (al, fin_l) = prepared
+        du, dl = C.c_int(0), C.c_int(0)
+        hip.check(hip.lib().a2s_note_decoder_fwd_pair(C.c_void_p(streams[0].cuda_stream), C.c_void_p(streams[1].cuda_stream), C.byref(au), C.byref(al),
+                                                      hip._p(pair["order"]), hip._p(pair["rank"]), pair["n_active"], C.byref(du), C.byref(dl)),
+                  "a2s_note_decoder_fwd_pair")
+        return [fin_u(du.value), fin_l(dl.value)]
 
     # ------------------------------------------------------------------ full forward
     def forward(self, S, spectrogram, inference=True, ground_truth=None, teacher_forcing_ratio=0.0, training=False,
@@ -786,6 +808,24 @@ class Engine:
             # Every host-side decision of the decoder and every small upload happens HERE, while the GPU is busy with the ConvStack and
             # the encoder enqueued above -- not once per (segment, staff) in the middle of the decoder.
             _trace(f"g{gidx} planning starts")
+            def pair_rows(seg, n):
+                """Clip bookkeeping of BOTH staves of a segment together (a2s_note_decoder_fwd_pair): the clips sorted by the step their last row of
+                either staff finishes at."""
+                until = torch.stack([until_all[gi_idx][bar][b0:b1].clamp(max=gsteps[bar][gi_idx]) for gi_idx in (0, 1) for bar in seg])
+                clip_until = until.amax(dim=0)
+                order = torch.argsort(clip_until, descending=True, stable=True).to(torch.int32)
+                rank = torch.empty_like(order)
+                rank[order.long()] = torch.arange(Bg, dtype=torch.int32)
+                n_act = Bg - torch.cumsum(torch.bincount(clip_until.long(), minlength=n + 1), 0)[:n]
+                # (clip, step) pairs whose encoder outputs ONE pass serves for both staves: steps both staves run on the launch-per-step loop (more rows
+                # still running than the few-row kernels take), clips with an unfinished row of each staff -- bench.py's step roofline
+                nb_, fmax, t_ = len(seg), L.a2s_debug_get(b"dec_fused_max_rows"), torch.arange(n).unsqueeze(1)
+                rows_live = [(until[k * nb_:(k + 1) * nb_].reshape(1, -1) > t_).sum(1) for k in (0, 1)]
+                clip_live = [until[k * nb_:(k + 1) * nb_].amax(dim=0).unsqueeze(0) > t_ for k in (0, 1)]
+                joint = (rows_live[0] > fmax) & (rows_live[1] > fmax)
+                self.attn_shared_clip_steps.append(int(((clip_live[0] & clip_live[1]).sum(1) * joint).sum()))
+                return dict(order=upload(order), rank=upload(rank), n_active=(C.c_int * max(n, 1))(*n_act.tolist()))
+
             seg_plan = []
             for seg in segments:
                 sp = {}
@@ -798,6 +838,11 @@ class Engine:
                     # the backward pass needs the flags on the device (which token each step consumed)
                     flags_dev = upload(torch.tensor(flags[:steps], dtype=torch.int32)) if training and steps > 0 else None
                     sp[gi_idx] = (steps, flags, active_rows(gi_idx, seg, steps) if skip else None, flags_dev)
+                # both staves' step loops issued as one (the sweeps of a step share the pass over the encoder outputs): training, two streams
+                # (the bulk group only, and only calls over more rows than the few-row step kernels take: those loops are bound by the host's launch rate)
+                if (plan is not None and skip and training and concurrent_g and gidx == 0 and _PAIR_STAVES and sp[0][0] > 0 and sp[1][0] > 0 and H == 256
+                        and len(seg) * Bg > L.a2s_debug_get(b"dec_fused_max_rows") and L.a2s_debug_get(b"attn_pair")):
+                    sp["pair"] = pair_rows(seg, max(sp[0][0], sp[1][0]))
                 seg_plan.append(sp)
 
             sos_ids = torch.full((Bg, 2), SOS, dtype=torch.long, device=dev)
@@ -914,7 +959,11 @@ class Engine:
                     drop = (rand((steps + 1, R, E)) >= 0.1).to(torch.uint8) if drop_on else None
                     calls.append((name, (S, prefix, keys_g[prefix], enc_g, h0, maxs, probs, gt_bar, steps, flags, training, 0.1 if drop_on else 0.0, R, T,
                                          attn_ws[gi_idx], gemm_ws[gi_idx], active, drop, flags_dev, persist_g)))
-                if concurrent_g:
+                if concurrent_g and seg_plan[seg_i].get("pair") is not None:
+                    _trace(f"g{gidx} seg {seg_i} staves forked (one loop)")
+                    pair_join = fork_on_streams(dev, [streams[1]], [lambda cs=[args for _, args in calls], pr=seg_plan[seg_i]["pair"]: self._decode_pair(cs, streams, pr)])
+                    join = lambda pj=pair_join: pj()[0]
+                elif concurrent_g:
                     _trace(f"g{gidx} seg {seg_i} staves forked")
                     join = fork_on_streams(dev, streams, [lambda args=args: self._decode_staff(*args) for _, args in calls])
                 elif greedy_graph:
@@ -947,7 +996,7 @@ class Engine:
                     if concurrent_g and gt_cpu is None:
                         for _ in range(sv["steps"]):          # the reference draws once per executed step, also in inference (upper, then lower)
                             rng.random()
-                seg_saved.append(dict(bars=seg, staff=staff))
+                seg_saved.append(dict(bars=seg, staff=staff, pair=seg_plan[seg_i].get("pair")))
                 for bar in seg:
                     bar_saved[bar]["staff"] = staff            # (shared by the bars of a fused segment)
                 # (4) token for the bar after the segment: one draw per bar, after both staves (drawn in the plan with ground truth)

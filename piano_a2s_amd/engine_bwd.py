@@ -102,7 +102,7 @@ def _attn_deferred(eng, S, G, prefix, keys, enc, q_all, ds_all, attw_all, dctx_a
     _colsum(dvp, H, G[prefix + ".v.weight"], nblk, H)
 
 
-def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T, deferred=None, enc_amax=None, late=None):
+def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc, n_clips, T, deferred=None, enc_amax=None, late=None, defer_launch=False):
     """Reverse of Engine._decode_staff.  Returns the gradient wrt the initial hidden (rows, 2H); rows = groups * n_clips.
     late: optional list.  The call's WEIGHT gradients (output projection, GRU, attention query half, embedding rows: everything only the
     optimizer waits for) are then not computed here: a (closure, event, tensors) entry is appended and Backward.finish runs the closures on the
@@ -167,7 +167,8 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
         if nb_ws:
             persist_ws = torch.empty(nb_ws, dtype=torch.uint8, device=dev)
             a.persist_ws, a.persist_ws_bytes = persist_ws.data_ptr(), nb_ws
-    hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
+    if not defer_launch:
+        hip.check(L.a2s_note_decoder_bwd(hip.stream(), C.byref(a)), "a2s_note_decoder_bwd")
     # (d) everything nobody in the recurrence waits for
     def deferred_work(part="all"):
         if part == "attn":          # the key / encoder-output gradients only (the weight gradients follow in Backward.finish)
@@ -230,29 +231,50 @@ def _note_decoder_bwd(eng, S, G, sv, keys, enc, dprobs_bar, probs_bar, dK, dEnc,
                                           C.c_long(ld_w), 0, Rw, E, hip._p(drop), hip.f32(1.0 / (1.0 - sv["drop_p"]) if drop is not None else 1.0)),
                   "a2s_embed_scatter_add")
 
-    if late is not None:
-        deferred_work("attn")
+    def after_launch():
+        if late is not None:
+            deferred_work("attn")
+            ev = torch.cuda.Event()
+            ev.record()
+            # everything the closure reads that was allocated on this (staff / group) stream: the weight-gradient stream records them all
+            act = sv.get("active") or {}
+            late.append((lambda: deferred_work("weights"), ev, (dlog, do_all, dgi_all, dgh_all, dq_all, dx, sv["x"], sv["h"], sv["o"], sv["ids"], sv["drop"], sv["gt_bar"],
+                                                                sv.get("flags_dev"), act.get("live_idx"), dlog_amax, enc_amax)))
+            return dh[0], None
+        if deferred is None:
+            deferred_work()
+            return dh[0], None
         ev = torch.cuda.Event()
         ev.record()
-        # everything the closure reads that was allocated on this (staff / group) stream: the weight-gradient stream records them all
-        act = sv.get("active") or {}
-        late.append((lambda: deferred_work("weights"), ev, (dlog, do_all, dgi_all, dgh_all, dq_all, dx, sv["x"], sv["h"], sv["o"], sv["ids"], sv["drop"], sv["gt_bar"],
-                                                            sv.get("flags_dev"), act.get("live_idx"), dlog_amax, enc_amax)))
-        return dh[0], None
-    if deferred is None:
-        deferred_work()
-        return dh[0], None
-    ev = torch.cuda.Event()
-    ev.record()
-    deferred.wait_event(ev)
-    for t in (dlog, do_all, dgi_all, dgh_all, dq_all, ds_all, dctx_all, dx):
-        t.record_stream(deferred)                       # keep the allocator from handing them back to the staff stream too early
-    with torch.cuda.stream(deferred):
-        deferred_work()
-        done = torch.cuda.Event()
-        done.record()
-    return dh[0], done
+        deferred.wait_event(ev)
+        for t in (dlog, do_all, dgi_all, dgh_all, dq_all, ds_all, dctx_all, dx):
+            t.record_stream(deferred)                       # keep the allocator from handing them back to the staff stream too early
+        with torch.cuda.stream(deferred):
+            deferred_work()
+            done = torch.cuda.Event()
+            done.record()
+        return dh[0], done
 
+    if defer_launch:                  # _note_decoder_bwd_pair: the arguments are ready (kept alive by the closure), the caller launches both staves with one call
+        return a, after_launch, (persist_ws,)
+    return after_launch()
+
+
+def _note_decoder_bwd_pair(calls, streams, pair):
+    """The reverse loops of a segment's two note decoders issued by ONE host loop on their two streams (Engine._decode_pair in reverse): while both staves
+    step, the attention sweep of a step is one launch that reads the encoder outputs once for both (a2s_note_decoder_bwd_pair).  calls: the argument
+    tuples of _note_decoder_bwd (upper, lower); returns their results."""
+    prepared = []
+    for st, args in zip(streams, calls):
+        with torch.cuda.stream(st):
+            prepared.append(_note_decoder_bwd(*args, defer_launch=True))
+    hip.check(hip.lib().a2s_note_decoder_bwd_pair(C.c_void_p(streams[0].cuda_stream), C.c_void_p(streams[1].cuda_stream), C.byref(prepared[0][0]),
+                                                  C.byref(prepared[1][0]), hip._p(pair["order"]), hip._p(pair["rank"]), pair["n_active"]), "a2s_note_decoder_bwd_pair")
+    res = []
+    for st, (_, after, _keep) in zip(streams, prepared):
+        with torch.cuda.stream(st):
+            res.append(after())
+    return res
 
 class Backward:
     """The backward pass in three phases, so that the decoder part of each clip group can be started by whoever has that group's loss
@@ -360,7 +382,12 @@ class Backward:
                     dpr, pr = dout[:, bar0], out_t[:, bar0]
                 calls.append((eng, S, Gg, seg["staff"][name][2], keys_g[prefix], enc_g, dpr, pr, dK_g[prefix], dEnc_staff_g[si], Bg, T,
                               deferred_streams[si] if use_deferred_g else None, enc_amax_g, self.late if self.late_wgrads else None))
-            if concurrent_g:    # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
+            if concurrent_g and seg.get("pair") is not None and L.a2s_debug_get(b"attn_pair"):
+                # both staves' reverse loops from one host thread, their sweeps as one launch per step (as the forward ran them)
+                (res,), events = fork_on_streams(dev, [streams[1]], [lambda: _note_decoder_bwd_pair(calls, streams, seg["pair"])])(wait=False)
+                seg_dh0[si_seg] = ([r[0] for r in res], events)
+                deferred_done.extend(r[1] for r in res if r[1] is not None)
+            elif concurrent_g:    # one host thread per staff (engine.fork_on_streams); the current stream waits when the result is consumed
                 res, events = fork_on_streams(dev, streams, [lambda args=args: _note_decoder_bwd(*args) for args in calls])(wait=False)
                 seg_dh0[si_seg] = ([r[0] for r in res], events)
                 deferred_done.extend(r[1] for r in res if r[1] is not None)

@@ -508,6 +508,7 @@ class TrainStep:
             G = engine_bwd.backward(eng, S, gouts, grad_ready=exchange.slice_ready, loss_total=losses[:, 0].sum())
         self.decode_steps = sum(seg["staff"][k][2]["steps"] for g in eng.saved["groups"] for seg in g["segments"] for k in ("up", "lo"))
         self.attn_clip_steps = sum(eng.attn_clip_steps)        # forward; the backward streams the same pairs once more
+        self.attn_shared_clip_steps = sum(eng.attn_shared_clip_steps)      # ... of which: encoder outputs read by a pass shared between the staves
         if self.time_exchange and exchange.active:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -105,7 +105,9 @@ def main():
         lock = threading.Lock()
         orig_ds = engine.Engine._decode_staff
 
-        def ds(self, S, prefix, keys, enc, h0, maxs, probs, gt_bar, steps, *rest):
+        def ds(self, S, prefix, keys, enc, h0, maxs, probs, gt_bar, steps, *rest, **kw):
+            if kw.get("defer_launch"):          # Engine._decode_pair: timed there
+                return orig_ds(self, S, prefix, keys, enc, h0, maxs, probs, gt_bar, steps, *rest, **kw)
             host_marks.append((f"host reaches fwd {prefix.split('.')[-1][:5]} rows {h0.shape[0]}", time.time()))
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -116,9 +118,45 @@ def main():
                 seg_marks.append((f"fwd {prefix.split('.')[-1][:5]} rows {h0.shape[0]:4d} steps {steps:3d}", e0, e1, steps))
             return r
         engine.Engine._decode_staff = ds
+        orig_dp = engine.Engine._decode_pair
+
+        def dp(self, calls, streams, pair):
+            host_marks.append((f"host reaches fwd pair rows {calls[0][4].shape[0]}", time.time()))
+            ev = []
+            for st in streams:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                ev.append(e0)
+            r = orig_dp(self, calls, streams, pair)
+            for st, e0, args in zip(streams, ev, calls):
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(st)
+                with lock:
+                    seg_marks.append((f"fwd {args[1].split('.')[-1][:5]} rows {args[4].shape[0]:4d} steps {args[8]:3d} (one loop for both staves)", e0, e1, args[8]))
+            return r
+        engine.Engine._decode_pair = dp
+        orig_nbp = engine_bwd._note_decoder_bwd_pair
+
+        def nbp(calls, streams, pair):
+            ev = []
+            for st in streams:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                ev.append(e0)
+            r = orig_nbp(calls, streams, pair)
+            for st, e0, args in zip(streams, ev, calls):
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(st)
+                sv = args[3]
+                with lock:
+                    seg_marks.append((f"bwd {sv['prefix'].split('.')[-1][:5]} rows {sv['groups'] * args[5].shape[0]:4d} steps {sv['steps']:3d} (one loop for both staves; incl. deferred products)", e0, e1, sv["steps"]))
+            return r
+        engine_bwd._note_decoder_bwd_pair = nbp
         orig_nb = engine_bwd._note_decoder_bwd
 
         def nb(eng, S, G, sv, keys, enc, *rest, **kw):
+            if kw.get("defer_launch"):
+                return orig_nb(eng, S, G, sv, keys, enc, *rest, **kw)
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig_nb(eng, S, G, sv, keys, enc, *rest, **kw)
