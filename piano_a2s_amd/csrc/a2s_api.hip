@@ -88,6 +88,8 @@ void a2s_attn_pair_set(int);
 int a2s_attn_pair_enabled(void);
 long a2s_attn_pair_launches(void);
 long a2s_attn_pair_bwd_launches(void);
+void a2s_attn_pair_fused_rows_set(int);
+int a2s_attn_pair_fused_rows(void);
 int a2s_note_decoder_bwd_pair_impl(hipStream_t su, hipStream_t sl, const a2s_note_dec_bwd_args& au, const a2s_note_dec_bwd_args& al, const int* pair_order,
                                    const int* pair_rank, const int* pair_n_active);
 
@@ -234,6 +236,7 @@ int a2s_debug_set(const char* key, int value) {
     if (!strcmp(key, "attn_defer_combine")) { a2s_attn_defer_combine_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_mid")) { a2s_dec_mid_set(value); return A2S_OK; }
     if (!strcmp(key, "attn_pair")) { a2s_attn_pair_set(value); return A2S_OK; }
+    if (!strcmp(key, "attn_pair_fused_rows")) { a2s_attn_pair_fused_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "dec_fused_max_rows")) { a2s_dec_fused_max_rows_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_fused")) { a2s_gru_step_fused_set(value); return A2S_OK; }
     if (!strcmp(key, "gru_persist")) { a2s_gru_persist_set(value); return A2S_OK; }
@@ -264,6 +267,7 @@ int a2s_debug_get(const char* key) {
     if (key && !strcmp(key, "attn_defer_combine")) return a2s_attn_defer_combine_enabled();
     if (key && !strcmp(key, "dec_mid")) return a2s_dec_mid_enabled();
     if (key && !strcmp(key, "attn_pair")) return a2s_attn_pair_enabled();
+    if (key && !strcmp(key, "attn_pair_fused_rows")) return a2s_attn_pair_fused_rows();
     if (key && !strcmp(key, "attn_pair_launches")) return (int)a2s_attn_pair_launches();
     if (key && !strcmp(key, "attn_pair_bwd_launches")) return (int)a2s_attn_pair_bwd_launches();
     if (key && !strcmp(key, "dec_mid_launches")) return a2s_dec_mid_launches();

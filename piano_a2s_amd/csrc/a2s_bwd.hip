@@ -308,9 +308,13 @@ static int attn_pair_bwd_combine(hipStream_t st, const a2s_note_dec_bwd_args& a,
 int a2s_attn_pair_enabled(void);
 
 static int note_bwd_step_rows(const a2s_note_dec_bwd_args& a, int s) { return (a.row_list && a.n_rows_active) ? a.n_rows_active[s] : a.R; }
+int a2s_attn_pair_fused_rows(void);             // (a2s_seq.hip: the pair loops hand over to the few-row kernels at fewer rows)
+static thread_local int t_pair_rows_limit = -1;
+struct PairRowsLimit { PairRowsLimit(int v) { t_pair_rows_limit = v; } ~PairRowsLimit() { t_pair_rows_limit = -1; } };
 static bool note_bwd_step_fused(const a2s_note_dec_bwd_args& a, int s) {
     const void* ptrs[] = {a.dgi_all, a.dgh_all, a.dq_all, a.dx, a.dh, a.w_ih, a.w_hh, a.attn_w};
     const int n = note_bwd_step_rows(a, s);
+    if (t_pair_rows_limit >= 0 && n > t_pair_rows_limit) return false;
     return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, 173, ptrs, 8, a.step_ws, a.step_ws_floats);      // (the vocabulary size plays no role here)
 }
 
@@ -438,6 +442,7 @@ int a2s_note_decoder_bwd_pair_impl(hipStream_t su, hipStream_t sl, const a2s_not
         if (!ev[k]) { const hipError_t e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming); if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_bwd_pair: hipEventCreate: %s", hipGetErrorString(e)); }
     bool mid[2] = {false, false};
     int cur[2] = {0, 0};
+    const PairRowsLimit limit(a2s_attn_pair_fused_rows());
     for (int k = 0; k < 2; ++k) { const int rc = note_bwd_prepare(sts[k], *as[k], &mid[k]); if (rc) return rc; }
     const int nmax = au.steps > al.steps ? au.steps : al.steps;
     for (int s = nmax - 1; s >= 0; --s) {

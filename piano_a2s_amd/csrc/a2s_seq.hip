@@ -527,9 +527,16 @@ static int attn_pair_sweep(hipStream_t st, const NoteDecArgs& au, const NoteDecA
 static int attn_pair_combine(hipStream_t st, const NoteDecArgs& a, int si, int sv, const AttnPairStep& p);
 int a2s_attn_pair_enabled(void);
 static int note_step_rows(const NoteDecArgs& a, int t) { return (a.row_list && a.n_rows_active && t >= 0) ? a.n_rows_active[t] : a.R; }
+// inside the pair loop (a2s_note_decoder_fwd_pair_impl) the few-row kernels take over later: at a2s_debug_set("attn_pair_fused_rows") rows (32) instead of
+// "dec_fused_max_rows" (192) -- above that, a lockstep step with its shared sweep beats two few-row steps (192 -> 64: +1.2 ms per step, 64 -> 32: +2.2, 32 -> 16: +0.1,
+// never: -16.8; profiles/r06_pair_fused_rows_ab.txt)
+int a2s_attn_pair_fused_rows(void);
+static thread_local int t_pair_rows_limit = -1;
+struct PairRowsLimit { PairRowsLimit(int v) { t_pair_rows_limit = v; } ~PairRowsLimit() { t_pair_rows_limit = -1; } };
 static bool note_step_fusable(const NoteDecArgs& a, int t = -1) {
     const void* ptrs[] = {a.x, a.h, a.o, a.q, a.w_ih, a.w_hh, a.out_w, a.attn_w};
     const int n = note_step_rows(a, t);
+    if (t_pair_rows_limit >= 0 && n > t_pair_rows_limit) return false;
     return n > 0 && a2s_dec_step_fusable(n, a.H, a.E, a.V, ptrs, 8, a.step_ws, a.step_ws_floats, a.gt == nullptr && !a.gates);
 }
 // the launch-per-step loop's steps on the mid-size kernels (round 6)?  Not in graph-replay mode: its captured chunk computes the query at the start of a step
@@ -734,6 +741,7 @@ int a2s_note_decoder_fwd_pair_impl(hipStream_t su, hipStream_t sl, const NoteDec
     static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
     for (int k = 0; k < 2; ++k)
         if (!ev[k]) { const hipError_t e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming); if (e != hipSuccess) A2S_FAIL(A2S_ERR_HIP, "note_decoder_fwd_pair: hipEventCreate: %s", hipGetErrorString(e)); }
+    const PairRowsLimit limit(a2s_attn_pair_fused_rows());
     for (int k = 0; k < 2; ++k) { const int rc = note_decoder_zero_fill(sts[k], *as[k]); if (rc) return rc; }
     bool prev_q[2] = {false, false};
     const int nmax = au.steps > al.steps ? au.steps : al.steps;
@@ -1689,6 +1697,10 @@ static long g_attn_pair_launches = 0;
 void a2s_attn_pair_set(int on) { g_attn_pair = on ? 1 : 0; }
 int a2s_attn_pair_enabled(void) { return g_attn_pair; }
 long a2s_attn_pair_launches(void) { return g_attn_pair_launches; }
+int a2s_dec_fused_max_rows(void);
+static int g_attn_pair_fused_rows = 32;
+void a2s_attn_pair_fused_rows_set(int v) { g_attn_pair_fused_rows = v; }
+int a2s_attn_pair_fused_rows(void) { const int cap = a2s_dec_fused_max_rows(); return g_attn_pair_fused_rows < cap ? g_attn_pair_fused_rows : cap; }
 
 template <int NQ>
 static void launch_fwd_pair(hipStream_t st, int nwg, size_t shm, const AttnPairSide& s0, const AttnPairSide& s1, const float* enc, long ldq, int T,

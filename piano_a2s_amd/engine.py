@@ -819,7 +819,7 @@ class Engine:
                 n_act = Bg - torch.cumsum(torch.bincount(clip_until.long(), minlength=n + 1), 0)[:n]
                 # (clip, step) pairs whose encoder outputs ONE pass serves for both staves: steps both staves run on the launch-per-step loop (more rows
                 # still running than the few-row kernels take), clips with an unfinished row of each staff -- bench.py's step roofline
-                nb_, fmax, t_ = len(seg), L.a2s_debug_get(b"dec_fused_max_rows"), torch.arange(n).unsqueeze(1)
+                nb_, fmax, t_ = len(seg), L.a2s_debug_get(b"attn_pair_fused_rows"), torch.arange(n).unsqueeze(1)
                 rows_live = [(until[k * nb_:(k + 1) * nb_].reshape(1, -1) > t_).sum(1) for k in (0, 1)]
                 clip_live = [until[k * nb_:(k + 1) * nb_].amax(dim=0).unsqueeze(0) > t_ for k in (0, 1)]
                 joint = (rows_live[0] > fmax) & (rows_live[1] > fmax)
@@ -841,7 +841,7 @@ class Engine:
                 # both staves' step loops issued as one (the sweeps of a step share the pass over the encoder outputs): training, two streams
                 # (the bulk group only, and only calls over more rows than the few-row step kernels take: those loops are bound by the host's launch rate)
                 if (plan is not None and skip and training and concurrent_g and gidx == 0 and _PAIR_STAVES and sp[0][0] > 0 and sp[1][0] > 0 and H == 256
-                        and len(seg) * Bg > L.a2s_debug_get(b"dec_fused_max_rows") and L.a2s_debug_get(b"attn_pair")):
+                        and len(seg) * Bg > L.a2s_debug_get(b"attn_pair_fused_rows") and L.a2s_debug_get(b"attn_pair")):
                     sp["pair"] = pair_rows(seg, max(sp[0][0], sp[1][0]))
                 seg_plan.append(sp)
 
