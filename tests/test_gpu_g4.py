@@ -63,15 +63,25 @@ def _report(line):
 # (the way the benchmark's 256-clip minibatches are cut); a latency floor scaled to 12 clips also sends the 189-step lower bar's clip there.  On g4's
 # minibatch and seed the long clips' sub-group cut (train.split_long_group) does NOT trigger (the two long clips stay one group: "step_cost4_subgroups_on"
 # is the two-group step with the switch on); g4b is the minibatch on which it does: [ordinary | long A | long B], the benchmark's default path.
-@pytest.mark.parametrize("fixture, plan_kw, expect, subgroups", [
-    ("g4", {}, [(0, 11), (11, 12)], False), ("g4", {"step_cost": 4.0}, [(0, 10), (10, 12)], False), ("g4", {"step_cost": 4.0}, [(0, 10), (10, 12)], True),
-    ("g4b", {"step_cost": 4.0}, [(0, 10), (10, 11), (11, 12)], True), ("g4b", {"step_cost": 4.0}, [(0, 10), (10, 12)], False)],
-    ids=["default_cost", "step_cost4", "step_cost4_subgroups_on", "g4b_three_groups", "g4b_two_groups"])
-def test_reference_step_through_planner(request, dev, fixture, plan_kw, expect, subgroups):
+# pair_rows: a2s_debug_set("attn_pair_fused_rows") for the test -- None: the default (the pair loop of the ordinary group hands its last <= 32 rows to the
+# few-row kernels); 1: every step of the ordinary group's calls over more than one row runs in lockstep with ONE attention sweep for both staves
+# (round 6: attn_fwd_split256_pair / attn_bwd_split256_pair), so the reference's numbers are met THROUGH those kernels, not beside them.
+@pytest.mark.parametrize("fixture, plan_kw, expect, subgroups, pair_rows", [
+    ("g4", {}, [(0, 11), (11, 12)], False, None), ("g4", {"step_cost": 4.0}, [(0, 10), (10, 12)], False, None), ("g4", {"step_cost": 4.0}, [(0, 10), (10, 12)], True, None),
+    ("g4b", {"step_cost": 4.0}, [(0, 10), (10, 11), (11, 12)], True, None), ("g4b", {"step_cost": 4.0}, [(0, 10), (10, 12)], False, None),
+    ("g4", {"step_cost": 4.0}, [(0, 10), (10, 12)], False, 1), ("g4b", {"step_cost": 4.0}, [(0, 10), (10, 11), (11, 12)], True, 1)],
+    ids=["default_cost", "step_cost4", "step_cost4_subgroups_on", "g4b_three_groups", "g4b_two_groups", "g4_pair_sweeps", "g4b_pair_sweeps"])
+def test_reference_step_through_planner(request, dev, fixture, plan_kw, expect, subgroups, pair_rows):
     g4 = request.getfixturevalue(fixture)
     import models
-    from piano_a2s_amd import spec, train
+    from piano_a2s_amd import hip, spec, train
     from piano_a2s_amd.spec import PAD
+    L = hip.lib()
+    prev_rows = L.a2s_debug_get(b"attn_pair_fused_rows")
+    if pair_rows is not None:
+        hip.check(L.a2s_debug_set(b"attn_pair_fused_rows", pair_rows), "debug_set")
+        request.addfinalizer(lambda: hip.check(L.a2s_debug_set(b"attn_pair_fused_rows", prev_rows), "debug_set"))
+    pair0 = (L.a2s_debug_get(b"attn_pair_launches"), L.a2s_debug_get(b"attn_pair_bwd_launches"))
     meta, data, cfg, batch, st = g4
     m = models.ScoreTranscription(**cfg)
     m.load_state_dict(st)
@@ -90,7 +100,7 @@ def test_reference_step_through_planner(request, dev, fixture, plan_kw, expect, 
     dbatch = [b.to(dev) if torch.is_tensor(b) else b for b in batch]
     losses = step(dbatch, teacher_forcing_ratio=meta["tf"], rng=Counting())
     torch.cuda.synchronize()
-    tag = fixture + "[" + (",".join(f"{k}={v}" for k, v in plan_kw.items()) or "default") + (",subgroups" if subgroups else "") + "]"
+    tag = fixture + "[" + (",".join(f"{k}={v}" for k, v in plan_kw.items()) or "default") + (",subgroups" if subgroups else "") + (f",pair_rows={pair_rows}" if pair_rows is not None else "") + "]"
 
     # --- the planner's control flow really ran
     outs_raw, bar_major, groups, perm = step._last
@@ -100,6 +110,10 @@ def test_reference_step_through_planner(request, dev, fixture, plan_kw, expect, 
     assert bar_major and perm is not None and not torch.equal(perm, torch.arange(meta["batch"])), "fused bars + a real clip permutation"
     assert draws["n"] == meta["draws"], f"python-random draws {draws['n']} vs reference {meta['draws']}"
     _report(f"{tag}: clip groups {groups}, permutation {perm.tolist()}, draws {draws['n']}")
+    pair_n = (L.a2s_debug_get(b"attn_pair_launches") - pair0[0], L.a2s_debug_get(b"attn_pair_bwd_launches") - pair0[1])
+    _report(f"{tag}: attention sweeps shared by the two staves (forward, backward): {pair_n}, of {step.decode_steps} decode steps; few-row hand-over at {L.a2s_debug_get(b'attn_pair_fused_rows')} rows")
+    if pair_rows is not None:
+        assert pair_n[0] > 50 and pair_n[1] == pair_n[0], f"the pair sweeps did not run: {pair_n}"
 
     # --- loss terms (reference pretrain.py:72-88)
     got = losses[:, 0].cpu().numpy()
