@@ -754,7 +754,7 @@ int a2s_note_decoder_fwd_pair_impl(hipStream_t su, hipStream_t sl, const NoteDec
             if (!prev_q[k]) { const int rc = enqueue_query(sts[k], *as[k], s, s); if (rc) return rc; }       // (every step here is a fused or a mid-size one)
             prev_q[k] = true;
         }
-        AttnPairStep p = {pair_order, pair_rank, au.n_clips, pair_n_active[s < nmax ? s : 0], s, 1, au.T};
+        AttnPairStep p = {pair_order, pair_rank, au.n_clips, pair_n_active[s], s, 1, au.T};
         const bool joint = in[0] && in[1] && !fused[0] && !fused[1] && p.n_active > 0 && au.n_active[s] > 0 && al.n_active[s] > 0;
         if (joint) {
             hipError_t e = hipEventRecord(ev[1], sl);                       // the lower staff's query of this step
@@ -1689,7 +1689,7 @@ int a2s_attn_step_fwd_split_impl(hipStream_t st, const float* Kmat, const float*
     return A2S_OK;
 }
 
-// ---- the two staves' sweeps of one decode step as ONE launch (attn_fwd_split256_pair), then each staff's own combine (a2s_attn_pair_combine, on
+// ---- the two staves' sweeps of one decode step as ONE launch (attn_fwd_split256_pair), then each staff's own combine (attn_pair_combine, on
 // that staff's stream).  rows_u / rows_l: the staves' row bookkeeping (row_until of their own); pair: clip order / rank / active count of the
 // PAIR at this step.  Both staves' partials use the pair's geometry.
 static int g_attn_pair = 1;                  // a2s_debug_set("attn_pair", 0): every staff sweeps on its own (the A/B and the parity tests)
