@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r6f; mkdir -p $O
 rm -f gpurun_out/g4_parity_report.txt
-(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v Warn | tail -4) > $O/gpu_tests.txt 2>&1
+(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -4) > $O/gpu_tests.txt 2>&1
 cp gpurun_out/g4_parity_report.txt $O/g4_parity_report.txt 2>/dev/null
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err | grep '^{"metric' | tail -1 > $O/bench_driver_flags_b256.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-inference --no-straggler-sim > $O/bench_kt.log 2>&1
